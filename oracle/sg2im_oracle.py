@@ -1,0 +1,613 @@
+"""CPU oracle for the sg2im training hot path -- TEST INFRASTRUCTURE ONLY.
+
+A functional restatement (plain torch CPU ops over a ``{state_dict name: tensor}``
+mapping, no nn.Module) of the algorithm in the reference tree.  Every function
+cites the reference file:line it follows (paths relative to /root/reference).
+
+Pinning: the reference ships no tests / golden vectors, so the
+oracle is pinned by (a) ``tests/golden/*.pt`` -- outputs of the *imported
+reference modules* produced by ``tests/golden/make_golden.py`` in the build
+container, and (b) ``tests/test_oracle_vs_reference.py`` which compares against
+the live reference whenever /root/reference exists.
+
+This file must never be imported from ``sg2im_amd/`` (the product path).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5        # torch.nn.BatchNorm2d default (sg2im/layers.py:26)
+BN_MOMENTUM = 0.1
+
+
+# ----------------------------------------------------------------------------
+# small helpers
+# ----------------------------------------------------------------------------
+
+def make_vocab(num_objs, num_preds):
+  """Synthetic vocab with the conventions of scripts/preprocess_vg.py:231,335 and
+  sg2im/data/coco.py:181-205: object 0 is ``__image__``, predicate 0 is
+  ``__in_image__``."""
+  objs = ['__image__'] + ['obj%d' % i for i in range(1, num_objs)]
+  preds = ['__in_image__'] + ['pred%d' % i for i in range(1, num_preds)]
+  return {
+    'object_idx_to_name': objs,
+    'object_name_to_idx': {n: i for i, n in enumerate(objs)},
+    'pred_idx_to_name': preds,
+    'pred_name_to_idx': {n: i for i, n in enumerate(preds)},
+  }
+
+
+def activation_slope(name):
+  """sg2im/layers.py:33-46.  The reference overwrites ``name = 'leakyrelu'``
+  unconditionally (line 39), so every activation string yields a LeakyReLU; only a
+  ``leakyrelu-<slope>`` string changes the slope from torch's default 0.01."""
+  slope = 0.01
+  if name.lower().startswith('leakyrelu') and '-' in name:
+    slope = float(name.split('-')[1])
+  return slope
+
+
+def mlp(P, prefix, x, n_linear=2):
+  """sg2im/layers.py:216-232 with the defaults the model uses (activation='relu',
+  batch_norm='none', final_nonlinearity=True): Linear-ReLU-...-Linear-ReLU.  With
+  no BatchNorm1d the Sequential indices of the Linear layers are 0, 2, 4, ..."""
+  for i in range(n_linear):
+    k = 2 * i
+    x = F.relu(F.linear(x, P['%s.%d.weight' % (prefix, k)], P['%s.%d.bias' % (prefix, k)]))
+  return x
+
+
+def batch_norm(P, prefix, x, training):
+  """nn.BatchNorm2d forward (sg2im/layers.py:26).  In training mode the running
+  statistics in ``P`` are updated in place, like the module does."""
+  rm, rv = P.get(prefix + '.running_mean'), P.get(prefix + '.running_var')
+  y = F.batch_norm(x, rm, rv, P[prefix + '.weight'], P[prefix + '.bias'],
+                   training=training, momentum=BN_MOMENTUM, eps=BN_EPS)
+  nbt = P.get(prefix + '.num_batches_tracked')
+  if training and nbt is not None:
+    nbt += 1
+  return y
+
+
+# ----------------------------------------------------------------------------
+# graph convolution (sg2im/graph.py)
+# ----------------------------------------------------------------------------
+
+def gconv_pool(new_t, s_idx, o_idx, O, H, Dout, pooling='avg'):
+  """sg2im/graph.py:87-114.  Column split of the net1 output into (s, p, o) parts,
+  then two scatter_add calls (all subject edges, then all object edges) and the
+  'avg' division by clamp(count, min=1).  Returns (pooled (O,H), new_p (T,Dout))."""
+  T = new_t.size(0)
+  new_s = new_t[:, :H]
+  new_p = new_t[:, H:H + Dout]
+  new_o = new_t[:, H + Dout:2 * H + Dout]
+  pooled = torch.zeros(O, H, dtype=new_t.dtype)
+  pooled = pooled.scatter_add(0, s_idx.view(-1, 1).expand_as(new_s), new_s)
+  pooled = pooled.scatter_add(0, o_idx.view(-1, 1).expand_as(new_o), new_o)
+  if pooling == 'avg':
+    counts = torch.zeros(O, dtype=new_t.dtype)
+    ones = torch.ones(T, dtype=new_t.dtype)
+    counts = counts.scatter_add(0, s_idx, ones)
+    counts = counts.scatter_add(0, o_idx, ones)
+    pooled = pooled / counts.clamp(min=1).view(-1, 1)
+  elif pooling != 'sum':
+    raise AssertionError('Invalid pooling "%s"' % pooling)   # graph.py:45
+  return pooled, new_p
+
+
+def gconv_pool_sequential(new_t, s_idx, o_idx, O, H, Dout, pooling='avg'):
+  """Order rule of the reference's CPU scatter_add, spelled out (SURVEY.md section 7,
+  probe-verified): per object, starting from +0.0, add every subject-role row in
+  increasing t, then every object-role row in increasing t, in fp32; then divide by
+  max(1, count).  Pure-Python loops: small cases only.  The HIP pool kernel must be
+  *bit-identical* to this."""
+  T = new_t.size(0)
+  pooled = torch.zeros(O, H, dtype=torch.float32)
+  counts = [0] * O
+  for t in range(T):
+    j = int(s_idx[t])
+    pooled[j] = pooled[j] + new_t[t, :H]
+    counts[j] += 1
+  for t in range(T):
+    j = int(o_idx[t])
+    pooled[j] = pooled[j] + new_t[t, H + Dout:2 * H + Dout]
+    counts[j] += 1
+  if pooling == 'avg':
+    div = torch.tensor([max(1, c) for c in counts], dtype=torch.float32)
+    pooled = pooled / div.view(-1, 1)
+  return pooled
+
+
+def graph_triple_conv(P, prefix, obj_vecs, pred_vecs, edges, hidden_dim, out_dim,
+                      pooling='avg'):
+  """sg2im/graph.py:56-120 (one GraphTripleConv layer)."""
+  O = obj_vecs.size(0)
+  s_idx = edges[:, 0].contiguous()
+  o_idx = edges[:, 1].contiguous()
+  triple_in = torch.cat([obj_vecs[s_idx], pred_vecs, obj_vecs[o_idx]], dim=1)
+  new_t = mlp(P, prefix + '.net1', triple_in)
+  pooled, new_p = gconv_pool(new_t, s_idx, o_idx, O, hidden_dim, out_dim, pooling)
+  new_obj = mlp(P, prefix + '.net2', pooled)
+  return new_obj, new_p
+
+
+# ----------------------------------------------------------------------------
+# layout (sg2im/layout.py) and crops (sg2im/bilinear.py)
+# ----------------------------------------------------------------------------
+
+def boxes_to_grid(boxes, H, W):
+  """sg2im/layout.py:94-128."""
+  O = boxes.size(0)
+  b = boxes.view(O, 4, 1, 1)
+  x0, y0, x1, y1 = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+  X = torch.linspace(0, 1, steps=W).view(1, 1, W).to(boxes)
+  Y = torch.linspace(0, 1, steps=H).view(1, H, 1).to(boxes)
+  X = ((X - x0) / (x1 - x0)).expand(O, H, W)
+  Y = ((Y - y0) / (y1 - y0)).expand(O, H, W)
+  return torch.stack([X, Y], dim=3).mul(2).sub(1)
+
+
+def pool_samples(samples, obj_to_img, n_images=None):
+  """sg2im/layout.py:131-162 ('sum' pooling, the only mode model.py uses).  The
+  reference derives N from obj_to_img.max()+1 (line 143); ``n_images`` lets a caller
+  pin it explicitly."""
+  O, D, H, W = samples.size()
+  N = int(obj_to_img.max().item()) + 1 if n_images is None else n_images
+  out = torch.zeros(N, D, H, W, dtype=samples.dtype)
+  idx = obj_to_img.view(O, 1, 1, 1).expand(O, D, H, W)
+  return out.scatter_add(0, idx, samples)
+
+
+def masks_to_layout(vecs, boxes, masks, obj_to_img, H, W=None, align_corners=False,
+                    n_images=None):
+  """sg2im/layout.py:66-91.  ``align_corners=False`` is what F.grid_sample does when
+  the reference is imported under torch >= 1.3 (SURVEY.md section 8c caveat i)."""
+  O, D = vecs.size()
+  M = masks.size(1)
+  assert masks.size() == (O, M, M)
+  W = H if W is None else W
+  grid = boxes_to_grid(boxes, H, W)
+  img_in = vecs.view(O, D, 1, 1) * masks.float().view(O, 1, M, M)
+  sampled = F.grid_sample(img_in, grid, mode='bilinear', padding_mode='zeros',
+                          align_corners=align_corners)
+  return pool_samples(sampled, obj_to_img, n_images)
+
+
+def boxes_to_layout(vecs, boxes, obj_to_img, H, W=None, align_corners=False,
+                    n_images=None):
+  """sg2im/layout.py:30-63 (constant 8x8 input per object)."""
+  O, D = vecs.size()
+  W = H if W is None else W
+  grid = boxes_to_grid(boxes, H, W)
+  img_in = vecs.view(O, D, 1, 1).expand(O, D, 8, 8)
+  sampled = F.grid_sample(img_in, grid, mode='bilinear', padding_mode='zeros',
+                          align_corners=align_corners)
+  return pool_samples(sampled, obj_to_img, n_images)
+
+
+def tensor_linspace(start, end, steps):
+  """sg2im/bilinear.py:249-278: start*linspace(1,0) + end*linspace(0,1)."""
+  w0 = torch.linspace(1, 0, steps=steps).to(start)
+  w1 = torch.linspace(0, 1, steps=steps).to(start)
+  return start.unsqueeze(-1) * w0 + end.unsqueeze(-1) * w1
+
+
+def crop_bbox_batch(feats, bbox, bbox_to_feats, HH, WW=None, align_corners=False):
+  """sg2im/bilinear.py:28-132, 'cudnn' backend.  The reference loops over images and
+  copies each image once per box (bilinear.py:76-87); gathering ``feats[bbox_to_feats]``
+  is the same computation for every box ordering because the final inverse
+  permutation (bilinear.py:96-100) restores box order."""
+  WW = HH if WW is None else WW
+  B = bbox.size(0)
+  per_box = feats[bbox_to_feats]
+  bb = 2 * bbox - 1
+  X = tensor_linspace(bb[:, 0], bb[:, 2], WW).view(B, 1, WW).expand(B, HH, WW)
+  Y = tensor_linspace(bb[:, 1], bb[:, 3], HH).view(B, HH, 1).expand(B, HH, WW)
+  grid = torch.stack([X, Y], dim=3)
+  return F.grid_sample(per_box, grid, mode='bilinear', padding_mode='zeros',
+                       align_corners=align_corners)
+
+
+# ----------------------------------------------------------------------------
+# generator (sg2im/model.py, sg2im/crn.py)
+# ----------------------------------------------------------------------------
+
+def refinement_network(P, prefix, layout, n_modules, slope, training):
+  """sg2im/crn.py:88-111 (+ RefinementModule.forward crn.py:53-65), 'batch' norm."""
+  N, _, H, W = layout.size()
+  h, w = H, W
+  for _ in range(n_modules):
+    h //= 2
+    w //= 2
+  assert h != 0 and w != 0
+  feats = torch.zeros(N, 1, h, w).to(layout)
+  for i in range(n_modules):
+    feats = F.interpolate(feats, scale_factor=2, mode='nearest')
+    hh = feats.size(2)
+    lay = layout
+    if H > hh:
+      factor = H // hh
+      lay = F.avg_pool2d(layout, kernel_size=factor, stride=factor)
+    x = torch.cat([lay, feats], dim=1)
+    p = '%s.refinement_modules.%d.net' % (prefix, i)
+    x = F.conv2d(x, P[p + '.0.weight'], P[p + '.0.bias'], padding=1)
+    x = F.leaky_relu(batch_norm(P, p + '.1', x, training), slope)
+    x = F.conv2d(x, P[p + '.3.weight'], P[p + '.3.bias'], padding=1)
+    feats = F.leaky_relu(batch_norm(P, p + '.4', x, training), slope)
+  o = prefix + '.output_conv'
+  x = F.leaky_relu(F.conv2d(feats, P[o + '.0.weight'], P[o + '.0.bias'], padding=1), slope)
+  return F.conv2d(x, P[o + '.2.weight'], P[o + '.2.bias'])
+
+
+def mask_net(P, prefix, obj_vecs, mask_size, training):
+  """sg2im/model.py:94-106,146-147: [up2, BN, conv3x3, ReLU] x log2(mask_size), then
+  conv1x1 -> sigmoid.  Sequential indices: block b has BN at 4b+1, conv at 4b+2."""
+  O = obj_vecs.size(0)
+  x = obj_vecs.view(O, -1, 1, 1)
+  size, b = 1, 0
+  while size < mask_size:
+    x = F.interpolate(x, scale_factor=2, mode='nearest')
+    x = batch_norm(P, '%s.%d' % (prefix, 4 * b + 1), x, training)
+    x = F.relu(F.conv2d(x, P['%s.%d.weight' % (prefix, 4 * b + 2)],
+                        P['%s.%d.bias' % (prefix, 4 * b + 2)], padding=1))
+    size *= 2
+    b += 1
+  if size != mask_size:
+    raise ValueError('Mask size must be a power of 2')   # model.py:104
+  k = 4 * b
+  scores = F.conv2d(x, P['%s.%d.weight' % (prefix, k)], P['%s.%d.bias' % (prefix, k)])
+  return scores.squeeze(1).sigmoid()
+
+
+def generator_forward(P, cfg, objs, triples, obj_to_img=None, boxes_gt=None,
+                      masks_gt=None, noise=None, training=True, align_corners=False):
+  """sg2im/model.py:108-171.  ``cfg`` holds the Sg2ImModel constructor kwargs.
+  ``noise`` (N, layout_noise_dim, H, W) replaces the torch.randn draw of
+  model.py:164-168 so both sides of a parity test see the same noise."""
+  O = objs.size(0)
+  s, p, o = triples[:, 0], triples[:, 1], triples[:, 2]
+  edges = torch.stack([s, o], dim=1)
+  if obj_to_img is None:
+    obj_to_img = torch.zeros(O, dtype=objs.dtype)
+  obj_vecs = P['obj_embeddings.weight'][objs]
+  obj_vecs_orig = obj_vecs
+  pred_vecs = P['pred_embeddings.weight'][p]
+  L = cfg.get('gconv_num_layers', 5)
+  Hd, Dg = cfg.get('gconv_hidden_dim', 512), cfg.get('gconv_dim', 128)
+  pooling = cfg.get('gconv_pooling', 'avg')
+  if L == 0:
+    obj_vecs = F.linear(obj_vecs, P['gconv.weight'], P['gconv.bias'])   # model.py:53-54
+  else:
+    obj_vecs, pred_vecs = graph_triple_conv(P, 'gconv', obj_vecs, pred_vecs, edges, Hd, Dg, pooling)
+  for i in range(L - 1):
+    obj_vecs, pred_vecs = graph_triple_conv(P, 'gconv_net.gconvs.%d' % i, obj_vecs,
+                                            pred_vecs, edges, Hd, Dg, pooling)
+  boxes_pred = mlp(P, 'box_net', obj_vecs)
+
+  masks_pred = None
+  mask_size = cfg.get('mask_size', None)
+  if mask_size is not None and mask_size > 0:
+    masks_pred = mask_net(P, 'mask_net', obj_vecs, mask_size, training)
+
+  rel_in = torch.cat([boxes_pred[s], boxes_pred[o], obj_vecs_orig[s], obj_vecs_orig[o]], dim=1)
+  rel_scores = mlp(P, 'rel_aux_net', rel_in)
+
+  H, W = cfg.get('image_size', (64, 64))
+  layout_boxes = boxes_pred if boxes_gt is None else boxes_gt
+  if masks_pred is None:
+    layout = boxes_to_layout(obj_vecs, layout_boxes, obj_to_img, H, W, align_corners)
+  else:
+    layout_masks = masks_pred if masks_gt is None else masks_gt
+    layout = masks_to_layout(obj_vecs, layout_boxes, layout_masks, obj_to_img, H, W, align_corners)
+
+  nd = cfg.get('layout_noise_dim', 0)
+  if nd > 0:
+    if noise is None:
+      noise = torch.randn(layout.size(0), nd, H, W, dtype=layout.dtype)
+    layout = torch.cat([layout, noise], dim=1)
+  n_modules = len(cfg.get('refinement_dims', (1024, 512, 256, 128, 64)))
+  slope = activation_slope(cfg.get('activation', 'leakyrelu-0.2'))
+  if cfg.get('normalization', 'batch') != 'batch':
+    raise NotImplementedError('oracle restates the default normalization only')
+  img = refinement_network(P, 'refinement_net', layout, n_modules, slope, training)
+  return img, boxes_pred, masks_pred, rel_scores
+
+
+# ----------------------------------------------------------------------------
+# discriminators (sg2im/discriminators.py, sg2im/layers.py:129-213)
+# ----------------------------------------------------------------------------
+
+def parse_conv_arch(arch):
+  """The 'CK-X-S' tokens of build_cnn (layers.py:160-182).  Other tokens (R, U, P,
+  FC) are outside the default flag surface and not restated."""
+  out = []
+  for tok in arch.split(','):
+    if tok[0] == 'I':
+      continue
+    if tok[0] != 'C':
+      raise NotImplementedError('arch token "%s" not restated' % tok)
+    vals = [int(v) for v in tok[1:].split('-')]
+    k, c = vals[0], vals[1]
+    out.append((k, c, vals[2] if len(vals) == 3 else 1))
+  return out
+
+
+def disc_cnn(P, prefix, x, arch, slope, padding, training):
+  """build_cnn with C-tokens only, normalization='batch': every conv except the first
+  is preceded by BN + activation, nothing follows the last (layers.py:166-169).
+  Sequential indices: conv i sits at 3i, its preceding BN at 3i-2."""
+  for i, (k, c, stride) in enumerate(parse_conv_arch(arch)):
+    if i > 0:
+      x = F.leaky_relu(batch_norm(P, '%s.%d' % (prefix, 3 * i - 2), x, training), slope)
+    pad = 0 if padding == 'valid' else (k - 1) // 2
+    x = F.conv2d(x, P['%s.%d.weight' % (prefix, 3 * i)], P['%s.%d.bias' % (prefix, 3 * i)],
+                 stride=stride, padding=pad)
+  return x
+
+
+def patch_discriminator(P, dcfg, x, training=True):
+  """sg2im/discriminators.py:42-45: returns the raw CNN features; ``classifier``
+  (line 40) is never applied."""
+  slope = activation_slope(dcfg.get('activation', 'leakyrelu-0.2'))
+  return disc_cnn(P, 'cnn', x, dcfg['arch'], slope, dcfg.get('padding', 'same'), training)
+
+
+def ac_crop_discriminator(P, dcfg, imgs, objs, boxes, obj_to_img, training=True,
+                          align_corners=False):
+  """sg2im/discriminators.py:87-90 + AcDiscriminator.forward :68-75."""
+  crops = crop_bbox_batch(imgs, boxes, obj_to_img, dcfg.get('object_size', 64),
+                          align_corners=align_corners)
+  slope = activation_slope(dcfg.get('activation', 'relu'))
+  feats = disc_cnn(P, 'discriminator.cnn.0', crops, dcfg['arch'], slope,
+                   dcfg.get('padding', 'same'), training)
+  vecs = feats.view(feats.size(0), feats.size(1), -1).mean(dim=2)     # GlobalAvgPool layers.py:83-86
+  vecs = F.linear(vecs, P['discriminator.cnn.2.weight'], P['discriminator.cnn.2.bias'])
+  real = F.linear(vecs, P['discriminator.real_classifier.weight'], P['discriminator.real_classifier.bias'])
+  cls = F.linear(vecs, P['discriminator.obj_classifier.weight'], P['discriminator.obj_classifier.bias'])
+  return real, F.cross_entropy(cls, objs)
+
+
+# ----------------------------------------------------------------------------
+# losses (sg2im/losses.py, scripts/train.py:387-412)
+# ----------------------------------------------------------------------------
+
+def bce_loss(x, target):
+  """sg2im/losses.py:39-57."""
+  return (x.clamp(min=0) - x * target + (1 + (-x.abs()).exp()).log()).mean()
+
+
+def gan_g_loss(scores_fake):
+  """sg2im/losses.py:72-84."""
+  s = scores_fake.reshape(-1)
+  return bce_loss(s, torch.ones_like(s))
+
+
+def gan_d_loss(scores_real, scores_fake):
+  """sg2im/losses.py:87-103."""
+  assert scores_real.size() == scores_fake.size()
+  r, f = scores_real.reshape(-1), scores_fake.reshape(-1)
+  return bce_loss(r, torch.ones_like(r)) + bce_loss(f, torch.zeros_like(f))
+
+
+DEFAULT_LOSS_WEIGHTS = dict(            # scripts/train.py:108-131
+  l1_pixel_loss_weight=1.0, bbox_pred_loss_weight=10.0, predicate_pred_loss_weight=0.0,
+  mask_loss_weight=0.0, discriminator_loss_weight=0.01, d_obj_weight=1.0,
+  d_img_weight=1.0, ac_loss_weight=0.1)
+
+
+def generator_losses(w, imgs, imgs_pred, boxes, boxes_pred, masks, masks_pred,
+                     predicates, rel_scores):
+  """scripts/train.py:387-412 (calculate_model_losses)."""
+  losses = {}
+  total = torch.zeros(1).to(imgs)
+  losses['L1_pixel_loss'] = F.l1_loss(imgs_pred, imgs) * w['l1_pixel_loss_weight']
+  total = total + losses['L1_pixel_loss']
+  losses['bbox_pred'] = F.mse_loss(boxes_pred, boxes) * w['bbox_pred_loss_weight']
+  total = total + losses['bbox_pred']
+  if w['predicate_pred_loss_weight'] > 0:
+    losses['predicate_pred'] = F.cross_entropy(rel_scores, predicates) * w['predicate_pred_loss_weight']
+    total = total + losses['predicate_pred']
+  if w['mask_loss_weight'] > 0 and masks is not None and masks_pred is not None:
+    losses['mask_loss'] = F.binary_cross_entropy(masks_pred, masks.float()) * w['mask_loss_weight']
+    total = total + losses['mask_loss']
+  return total, losses
+
+
+# ----------------------------------------------------------------------------
+# one training iteration (scripts/train.py:524-592)
+# ----------------------------------------------------------------------------
+
+class OracleTrainer(object):
+  """The loop body of scripts/train.py:524-592 on CPU: generator forward + losses +
+  Adam, then the object and image discriminator updates.  Parameters are leaf tensors
+  in three dicts (generator / D_obj / D_img) keyed by state_dict names; buffers (BN
+  running stats) live in the same dicts without grad."""
+
+  def __init__(self, PG, PDo, PDi, gcfg, docfg, dicfg, weights=None, lr=1e-4,
+               align_corners=False):
+    self.PG, self.PDo, self.PDi = PG, PDo, PDi
+    self.gcfg, self.docfg, self.dicfg = gcfg, docfg, dicfg
+    self.w = dict(DEFAULT_LOSS_WEIGHTS)
+    if weights:
+      self.w.update(weights)
+    self.align_corners = align_corners
+    self.training = True
+    for P in (PG, PDo, PDi):
+      for k, v in P.items():
+        if v.is_floating_point() and not ('running_' in k):
+          v.requires_grad_(True)
+    # torch.optim.Adam(model.parameters(), lr) -- train.py:426,436,443
+    self.opt_g = torch.optim.Adam([v for v in PG.values() if v.requires_grad], lr=lr)
+    self.opt_do = torch.optim.Adam([v for v in PDo.values() if v.requires_grad], lr=lr)
+    self.opt_di = torch.optim.Adam([v for v in PDi.values() if v.requires_grad], lr=lr)
+
+  def g_forward_loss(self, batch, noise=None):
+    imgs, objs, boxes, masks, triples, obj_to_img = batch
+    w = self.w
+    out = generator_forward(self.PG, self.gcfg, objs, triples, obj_to_img, boxes_gt=boxes,
+                            masks_gt=masks, noise=noise, training=self.training,
+                            align_corners=self.align_corners)
+    imgs_pred, boxes_pred, masks_pred, rel_scores = out
+    total, losses = generator_losses(w, imgs, imgs_pred, boxes, boxes_pred, masks, masks_pred,
+                                     triples[:, 1], rel_scores)
+    # train.py:538-550
+    scores_fake, ac_loss = ac_crop_discriminator(self.PDo, self.docfg, imgs_pred, objs, boxes,
+                                                 obj_to_img, True, self.align_corners)
+    losses['ac_loss'] = ac_loss * w['ac_loss_weight']
+    total = total + losses['ac_loss']
+    losses['g_gan_obj_loss'] = gan_g_loss(scores_fake) * (w['discriminator_loss_weight'] * w['d_obj_weight'])
+    total = total + losses['g_gan_obj_loss']
+    scores_fake = patch_discriminator(self.PDi, self.dicfg, imgs_pred, True)
+    losses['g_gan_img_loss'] = gan_g_loss(scores_fake) * (w['discriminator_loss_weight'] * w['d_img_weight'])
+    total = total + losses['g_gan_img_loss']
+    losses['total_loss'] = total
+    return total, losses, out
+
+  def d_obj_loss(self, batch, imgs_fake):
+    imgs, objs, boxes, masks, triples, obj_to_img = batch
+    # train.py:566-575
+    sf, ac_f = ac_crop_discriminator(self.PDo, self.docfg, imgs_fake, objs, boxes, obj_to_img,
+                                     True, self.align_corners)
+    sr, ac_r = ac_crop_discriminator(self.PDo, self.docfg, imgs, objs, boxes, obj_to_img,
+                                     True, self.align_corners)
+    parts = {'d_obj_gan_loss': gan_d_loss(sr, sf), 'd_ac_loss_real': ac_r, 'd_ac_loss_fake': ac_f}
+    return parts['d_obj_gan_loss'] + ac_r + ac_f, parts
+
+  def d_img_loss(self, batch, imgs_fake):
+    imgs = batch[0]
+    # train.py:581-588
+    sf = patch_discriminator(self.PDi, self.dicfg, imgs_fake, True)
+    sr = patch_discriminator(self.PDi, self.dicfg, imgs, True)
+    loss = gan_d_loss(sr, sf)
+    return loss, {'d_img_gan_loss': loss}
+
+  def step(self, batch, noise=None):
+    total, losses, out = self.g_forward_loss(batch, noise)
+    if not math.isfinite(float(total)):          # train.py:553-555
+      return None
+    self.opt_g.zero_grad()
+    # the reference also deposits (discarded) grads in the D params here (train.py:559)
+    total.backward()
+    self.opt_g.step()
+    imgs_fake = out[0].detach()
+    ld, parts_o = self.d_obj_loss(batch, imgs_fake)
+    self.opt_do.zero_grad()
+    ld.backward()
+    self.opt_do.step()
+    li, parts_i = self.d_img_loss(batch, imgs_fake)
+    self.opt_di.zero_grad()
+    li.backward()
+    self.opt_di.step()
+    res = {k: float(v) for k, v in losses.items()}
+    res.update({k: float(v) for k, v in parts_o.items()})
+    res.update({k: float(v) for k, v in parts_i.items()})
+    return res
+
+
+# ----------------------------------------------------------------------------
+# parameter initialisation with the reference's shapes / state_dict names
+# ----------------------------------------------------------------------------
+
+def _lin(P, name, dout, din, gen, kaiming=False):
+  if kaiming:      # graph.py:26-29 -> kaiming_normal_ on Linear weights
+    P[name + '.weight'] = torch.randn(dout, din, generator=gen) * math.sqrt(2.0 / din)
+  else:            # nn.Linear default init: U(-1/sqrt(din), 1/sqrt(din)) for W and b
+    P[name + '.weight'] = (torch.rand(dout, din, generator=gen) * 2 - 1) / math.sqrt(din)
+  P[name + '.bias'] = (torch.rand(dout, generator=gen) * 2 - 1) / math.sqrt(din)
+
+
+def _conv(P, name, cout, cin, k, gen, kaiming=False):
+  fan_in = cin * k * k
+  if kaiming:      # crn.py:49-51,84-85
+    P[name + '.weight'] = torch.randn(cout, cin, k, k, generator=gen) * math.sqrt(2.0 / fan_in)
+  else:
+    P[name + '.weight'] = (torch.rand(cout, cin, k, k, generator=gen) * 2 - 1) / math.sqrt(fan_in)
+  P[name + '.bias'] = (torch.rand(cout, generator=gen) * 2 - 1) / math.sqrt(fan_in)
+
+
+def _bn(P, name, c, gen, randomize):
+  P[name + '.weight'] = torch.ones(c) if not randomize else 0.5 + torch.rand(c, generator=gen)
+  P[name + '.bias'] = torch.zeros(c) if not randomize else 0.2 * torch.randn(c, generator=gen)
+  P[name + '.running_mean'] = torch.zeros(c)
+  P[name + '.running_var'] = torch.ones(c)
+  P[name + '.num_batches_tracked'] = torch.tensor(0, dtype=torch.long)
+
+
+def init_generator_params(cfg, seed=0, randomize_bn=False):
+  """Random parameters with exactly the names/shapes of Sg2ImModel.state_dict()
+  (SURVEY.md section 8b).  The distributions follow the reference's initialisers but the
+  draws are this function's own (seeded) -- fixtures carry explicit weights when the
+  reference's own draws matter."""
+  g = torch.Generator().manual_seed(seed)
+  vocab = cfg['vocab']
+  C, Pn = len(vocab['object_idx_to_name']), len(vocab['pred_idx_to_name'])
+  E, Dg, Hd = cfg.get('embedding_dim', 64), cfg.get('gconv_dim', 128), cfg.get('gconv_hidden_dim', 512)
+  L = cfg.get('gconv_num_layers', 5)
+  P = {}
+  P['obj_embeddings.weight'] = torch.randn(C + 1, E, generator=g)      # model.py:50
+  P['pred_embeddings.weight'] = torch.randn(Pn, E, generator=g)
+  def gconv(prefix, din, dout):
+    _lin(P, prefix + '.net1.0', Hd, 3 * din, g, True)
+    _lin(P, prefix + '.net1.2', 2 * Hd + dout, Hd, g, True)
+    _lin(P, prefix + '.net2.0', Hd, Hd, g, True)
+    _lin(P, prefix + '.net2.2', dout, Hd, g, True)
+  if L == 0:
+    _lin(P, 'gconv', Dg, E, g)
+  else:
+    gconv('gconv', E, Dg)
+  for i in range(L - 1):
+    gconv('gconv_net.gconvs.%d' % i, Dg, Dg)
+  _lin(P, 'box_net.0', Hd, Dg, g)
+  _lin(P, 'box_net.2', 4, Hd, g)
+  ms = cfg.get('mask_size', None)
+  if ms is not None and ms > 0:
+    size, b = 1, 0
+    while size < ms:
+      _bn(P, 'mask_net.%d' % (4 * b + 1), Dg, g, randomize_bn)
+      _conv(P, 'mask_net.%d' % (4 * b + 2), Dg, Dg, 3, g)
+      size *= 2
+      b += 1
+    _conv(P, 'mask_net.%d' % (4 * b), 1, Dg, 1, g)
+  _lin(P, 'rel_aux_net.0', Hd, 2 * E + 8, g)
+  _lin(P, 'rel_aux_net.2', Pn, Hd, g)
+  dims = (Dg + cfg.get('layout_noise_dim', 0),) + tuple(cfg.get('refinement_dims', (1024, 512, 256, 128, 64)))
+  for i in range(1, len(dims)):
+    cin = 1 if i == 1 else dims[i - 1]
+    p = 'refinement_net.refinement_modules.%d.net' % (i - 1)
+    _conv(P, p + '.0', dims[i], dims[0] + cin, 3, g, True)
+    _bn(P, p + '.1', dims[i], g, randomize_bn)
+    _conv(P, p + '.3', dims[i], dims[i], 3, g, True)
+    _bn(P, p + '.4', dims[i], g, randomize_bn)
+  _conv(P, 'refinement_net.output_conv.0', dims[-1], dims[-1], 3, g, True)
+  _conv(P, 'refinement_net.output_conv.2', 3, dims[-1], 1, g, True)
+  return P
+
+
+def _init_disc_cnn(P, prefix, arch, cin, gen, randomize_bn):
+  c = cin
+  for i, (k, cout, _s) in enumerate(parse_conv_arch(arch)):
+    if i > 0:
+      _bn(P, '%s.%d' % (prefix, 3 * i - 2), c, gen, randomize_bn)
+    _conv(P, '%s.%d' % (prefix, 3 * i), cout, c, k, gen)
+    c = cout
+  return c
+
+
+def init_patch_discriminator_params(dcfg, seed=1, randomize_bn=False):
+  g = torch.Generator().manual_seed(seed)
+  P = {}
+  c = _init_disc_cnn(P, 'cnn', dcfg['arch'], 3, g, randomize_bn)
+  _conv(P, 'classifier', 1, c, 1, g)         # discriminators.py:40 (present, unused)
+  return P
+
+
+def init_ac_discriminator_params(dcfg, seed=2, randomize_bn=False):
+  g = torch.Generator().manual_seed(seed)
+  P = {}
+  c = _init_disc_cnn(P, 'discriminator.cnn.0', dcfg['arch'], 3, g, randomize_bn)
+  _lin(P, 'discriminator.cnn.2', 1024, c, g)
+  _lin(P, 'discriminator.real_classifier', 1, 1024, g)
+  _lin(P, 'discriminator.obj_classifier', len(dcfg['vocab']['object_idx_to_name']), 1024, g)
+  return P

@@ -1,0 +1,124 @@
+"""CPU: the oracle restatement reproduces the golden vectors that
+tests/golden/make_golden.py produced by running the imported reference."""
+import pytest
+import torch
+
+from oracle import sg2im_oracle as orc
+from tests.util import GOLDEN_NAMES, load_golden, clone_params, assert_close
+
+# fp32 CPU vs fp32 CPU, same library: differences come only from op ordering
+RTOL, ATOL = 1e-5, 1e-6
+
+
+def _trainer(fix):
+  cfg = fix['config']
+  gcfg = dict(cfg['g'], vocab=fix['vocab'])
+  docfg = dict(cfg['d_obj'], vocab=fix['vocab'])
+  dicfg = dict(cfg['d_img'])
+  sd = fix['state_before']
+  tr = orc.OracleTrainer(clone_params(sd['G']), clone_params(sd['Do']), clone_params(sd['Di']),
+                         gcfg, docfg, dicfg)
+  return tr
+
+
+@pytest.mark.parametrize('name', GOLDEN_NAMES)
+def test_generator_step_matches_reference(name):
+  fix = load_golden(name)
+  tr = _trainer(fix)
+  batch = fix['batch'][:6]
+  total, losses, out = tr.g_forward_loss(batch, fix['noise'])
+  want = fix['outputs']
+  assert_close(out[0], want['imgs_pred'], RTOL, ATOL, 'imgs_pred')
+  assert_close(out[1], want['boxes_pred'], RTOL, ATOL, 'boxes_pred')
+  assert_close(out[2], want['masks_pred'], RTOL, ATOL, 'masks_pred')
+  assert_close(out[3], want['rel_scores'], RTOL, ATOL, 'rel_scores')
+  L = fix['losses']
+  for mine, theirs in (('L1_pixel_loss', 'l1'), ('bbox_pred', 'bbox'), ('ac_loss', 'ac'),
+                       ('g_gan_obj_loss', 'g_gan_obj'), ('g_gan_img_loss', 'g_gan_img'),
+                       ('total_loss', 'total')):
+    assert abs(float(losses[mine]) - L[theirs]) <= 1e-5 * max(1.0, abs(L[theirs])), mine
+  total.backward()
+  for k, g in fix['grads']['G'].items():
+    got = tr.PG[k].grad
+    if g is None:
+      assert got is None or float(got.abs().max()) == 0.0, k
+    else:
+      assert_close(got, g, 1e-4, 1e-6, 'grad G.' + k)
+  # BN running statistics after one training-mode forward
+  for k, v in fix['state_after_g_forward']['G'].items():
+    assert_close(tr.PG[k].float(), v.float(), RTOL, ATOL, 'buffer G.' + k)
+
+
+@pytest.mark.parametrize('name', GOLDEN_NAMES)
+def test_discriminator_steps_match_reference(name):
+  fix = load_golden(name)
+  tr = _trainer(fix)
+  batch = fix['batch'][:6]
+  fake = fix['outputs']['imgs_pred']
+  # replay the G-step's D forwards so the BN running stats advance like the reference's
+  with torch.no_grad():
+    tr.g_forward_loss(batch, fix['noise'])
+  ld, parts = tr.d_obj_loss(batch, fake)
+  assert abs(float(ld) - fix['losses']['d_obj']) <= 1e-5 * max(1.0, abs(fix['losses']['d_obj']))
+  ld.backward()
+  for k, g in fix['grads']['Do'].items():
+    assert_close(tr.PDo[k].grad, g, 1e-4, 1e-6, 'grad Do.' + k)
+  li, _ = tr.d_img_loss(batch, fake)
+  assert abs(float(li) - fix['losses']['d_img']) <= 1e-5 * max(1.0, abs(fix['losses']['d_img']))
+  li.backward()
+  for k, g in fix['grads']['Di'].items():
+    if g is None:      # PatchDiscriminator.classifier is never applied (discriminators.py:40-45)
+      assert tr.PDi[k].grad is None
+    else:
+      assert_close(tr.PDi[k].grad, g, 1e-4, 1e-6, 'grad Di.' + k)
+
+
+@pytest.mark.parametrize('name', GOLDEN_NAMES)
+def test_standalone_ops_match_reference(name):
+  fix = load_golden(name)
+  imgs, objs, boxes, masks, triples, obj_to_img = fix['batch'][:6]
+  ops = fix['ops']
+  H, W = fix['config']['g']['image_size']
+  assert_close(orc.boxes_to_layout(ops['vecs'], boxes, obj_to_img, H, W), ops['boxes_to_layout'],
+               RTOL, ATOL, 'boxes_to_layout')
+  assert_close(orc.masks_to_layout(ops['vecs'], boxes, ops['soft_masks'], obj_to_img, H, W),
+               ops['masks_to_layout_soft'], RTOL, ATOL, 'masks_to_layout soft')
+  if masks is not None:
+    assert_close(orc.masks_to_layout(ops['vecs'], boxes, masks, obj_to_img, H, W),
+                 ops['masks_to_layout_gt'], RTOL, ATOL, 'masks_to_layout gt')
+  assert_close(orc.crop_bbox_batch(imgs, boxes, obj_to_img, fix['config']['d_obj']['object_size']),
+               ops['crops'], RTOL, ATOL, 'crops')
+  D = ops['vecs'].size(1)
+  edges = torch.stack([triples[:, 0], triples[:, 2]], dim=1)
+  P = {'g.' + k: v for k, v in ops['gconv_sum_sd'].items()}
+  no, npred = orc.graph_triple_conv(P, 'g', ops['vecs'], ops['gconv_sum_pred_in'], edges, 2 * D, D, 'sum')
+  assert torch.equal(no, ops['gconv_sum_obj_out'])        # same ops, same order -> bit-equal
+  assert torch.equal(npred, ops['gconv_sum_pred_out'])
+
+
+def test_pool_order_rule_is_bit_exact():
+  """gconv_pool (torch scatter_add, what the reference runs) == the sequential order
+  rule the HIP kernel implements, bit for bit."""
+  g = torch.Generator().manual_seed(3)
+  T, O, H, D = 700, 9, 24, 8
+  new_t = torch.randn(T, 2 * H + D, generator=g) * 100
+  s = torch.randint(0, O, (T,), generator=g)
+  o = torch.randint(0, O - 1, (T,), generator=g)      # object O-1 appears only as subject or never
+  for pooling in ('sum', 'avg'):
+    a, _ = orc.gconv_pool(new_t, s, o, O, H, D, pooling)
+    b = orc.gconv_pool_sequential(new_t, s, o, O, H, D, pooling)
+    assert torch.equal(a, b), pooling
+
+
+def test_known_answers():
+  """Known-answer facts about the reference recorded in SURVEY.md section 8c."""
+  # (a) unit box layout: a 4x4 block of exactly 1.0 centred in an 8x8 zero map
+  L = orc.boxes_to_layout(torch.ones(1, 1), torch.tensor([[.25, .25, .75, .75]]), torch.tensor([0]), 8)
+  want = torch.zeros(8, 8)
+  want[2:6, 2:6] = 1.0
+  assert torch.equal(L[0, 0], want)
+  # (b) 'relu' still means LeakyReLU(0.01); 'leakyrelu-0.2' -> 0.2
+  assert orc.activation_slope('relu') == 0.01 and orc.activation_slope('leakyrelu-0.2') == 0.2
+  # (i) boxes_pred >= 0 (final ReLU of build_mlp)
+  fix = load_golden('tiny_coco')
+  assert float(fix['outputs']['boxes_pred'].min()) >= 0.0
