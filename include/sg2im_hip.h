@@ -1,0 +1,224 @@
+/* sg2im_hip.h - C ABI of libsg2im_hip.so, the MI355X (gfx950) kernels behind the
+ * sg2im training hot path.
+ *
+ * The reference (google/sg2im) has no FFI/plugin boundary: its hot path bottoms out in
+ * ATen operator calls.  Each entry point below therefore cites the reference call site
+ * (file:line under /root/reference) whose ATen operator sequence it replaces.  All
+ * pointers are device pointers (HBM) unless stated; tensors are fp32, indices int64,
+ * image-like activations are NHWC; every function is asynchronous on `stream`, keeps no
+ * state and returns SG2IM_OK (0) or an error code.  No torch types appear here; the
+ * Python host (sg2im_amd/) binds this with ctypes.
+ */
+#ifndef SG2IM_HIP_H
+#define SG2IM_HIP_H
+
+#include <stddef.h>
+#include <hip/hip_runtime_api.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SG2IM_OK 0
+#define SG2IM_ERR_ARG 1   /* invalid argument (the reference would raise / assert) */
+#define SG2IM_ERR_HIP 2   /* a HIP runtime call failed; see hipGetLastError() */
+
+int sg2im_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Convolution / linear layers (implicit GEMM on the fp32 matrix cores).
+ * Replaces nn.Conv2d / nn.Linear forward+backward as used by sg2im/crn.py:41-47,79-86,
+ * sg2im/layers.py:178,221, sg2im/model.py:100,105, together with the torch.cat
+ * (crn.py:63, graph.py:82, model.py:151), F.upsample (crn.py:107, model.py:98), row
+ * gathers (graph.py:77-78, model.py:149-150) and the BatchNorm-apply + LeakyReLU of the
+ * *previous* layer (layers.py:26,46), which are folded into the operand loader.
+ *
+ * A conv input is a virtual tensor: the channel concatenation of `nsrc` sources.
+ * Weights are [cout][kh][kw][sum(channels)] (= a channels_last torch parameter).
+ * A linear layer is kh=kw=1, in_h=in_w=out_h=out_w=1, batch=rows.
+ * ---------------------------------------------------------------------------------- */
+typedef struct sg2im_src {
+  const float* data;        /* NHWC tensor [batch][in_h>>up][in_w>>up][ld] or rows [rows][ld] */
+  const long long* gather;  /* optional: row r reads data[gather[r]] (linear geometry only) */
+  const float* scale;       /* optional per-channel affine applied on load: v*scale+shift ... */
+  const float* shift;
+  float slope;              /* ... followed by leaky-relu with this slope (1 = identity) */
+  int channels;
+  int ld;                   /* floats between consecutive pixels / rows (>= channels) */
+  int upsample_log2;        /* 0, or 1 = source is nearest-upsampled x2 on the fly */
+} sg2im_src;
+
+typedef struct sg2im_conv_desc {
+  sg2im_src src[4];
+  int nsrc;
+  int batch, in_h, in_w;    /* logical input size (after upsampling) */
+  int out_h, out_w;
+  int kh, kw, stride, pad;
+} sg2im_conv_desc;
+
+/* out[pix][co] = leaky_{out_slope}( conv(X, W)[pix][co] + bias[co] ) (+ out if accumulate) */
+int sg2im_conv2d_forward(const sg2im_conv_desc* desc, const float* weight, int cout,
+                         const float* bias, float out_slope, float* out, long long ld_out,
+                         int accumulate, float* workspace, size_t workspace_bytes,
+                         hipStream_t stream);
+/* dX[inpix][c - c_begin] for concat channels c in [c_begin, c_begin + c_count), written with
+ * row stride ld_dx.  `desc` is the forward descriptor (sources are not dereferenced). */
+int sg2im_conv2d_backward_data(const sg2im_conv_desc* desc, const float* weight, int cout,
+                               const float* dy, int ld_dy, int c_begin, int c_count, float* dx,
+                               long long ld_dx, int accumulate, float* workspace,
+                               size_t workspace_bytes, hipStream_t stream);
+/* dW[co][kh][kw][c] = sum_pix dY[pix][co] * X[pix (+) tap][c]  (+ dW if accumulate) */
+int sg2im_conv2d_backward_weight(const sg2im_conv_desc* desc, const float* dy, int ld_dy, int cout,
+                                 float* dweight, int accumulate, float* workspace,
+                                 size_t workspace_bytes, hipStream_t stream);
+/* out[n] = sum_m x[m][n] (+ out): bias gradients (autograd of Conv2d/Linear bias) */
+/* partial: scratch float[2 * cols * 256] */
+int sg2im_column_sum(const float* x, long long rows, int cols, long long ld, float* out,
+                     int accumulate, float* partial, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Triple-indexed gather / scatter of GraphTripleConv (sg2im/graph.py:73-114) and the
+ * embedding lookups (sg2im/model.py:131,133).
+ * ---------------------------------------------------------------------------------- */
+/* Stable CSR over destination rows.  Entries e in [0, n_a) come from keys_a (entry id e),
+ * entries in [n_a, n_a+n_b) from keys_b (entry id n_a + index).  Row j lists its entry ids
+ * in increasing order, i.e. all keys_a hits in index order, then all keys_b hits - the
+ * accumulation order of the reference's two scatter_add calls (graph.py:98-99).
+ * row_ptr: int[n_rows+1]; entries: int[n_a+n_b]; scratch: int[n_rows + n_a + n_b]. */
+int sg2im_csr_build(const long long* keys_a, int n_a, const long long* keys_b, int n_b, int n_rows,
+                    int* row_ptr, int* entries, int* scratch, hipStream_t stream);
+/* out[j][0:width] = sum over row j's entries, in CSR order, starting from +0.0f, of
+ *   src_a[e*ld_a + 0:width]            (e <  n_a)
+ *   src_b[(e-n_a)*ld_b + 0:width]      (e >= n_a)
+ * then, if average != 0, divided by max(1, #entries)  (graph.py:92-114: pooling sum/avg).
+ * Bit-exact w.r.t. the sequential fp32 order rule (oracle.gconv_pool_sequential). */
+int sg2im_segment_sum(const float* src_a, long long ld_a, int n_a, const float* src_b, long long ld_b,
+                      const int* row_ptr, const int* entries, int n_rows, int width, int average,
+                      float* out, long long ld_out, hipStream_t stream);
+/* dst[i][0:width] = src[idx[i]][0:width] (bit-exact copy) ; if row_ptr != NULL the row is
+ * divided by max(1, row_ptr[idx[i]+1]-row_ptr[idx[i]])  (backward of the 'avg' pooling). */
+int sg2im_gather_rows(const float* src, long long ld_src, const long long* idx, int n, int width,
+                      const int* row_ptr, float* dst, long long ld_dst, hipStream_t stream);
+/* dst[r][0:width] = src[r][0:width] for strided row matrices (the new_p column slice of the
+ * net1 output, graph.py:88, travelling through backward) */
+int sg2im_copy_2d(const float* src, long long ld_src, float* dst, long long ld_dst, long long rows,
+                  int width, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Scene layout (sg2im/layout.py:30-162) - boxes_to_layout / masks_to_layout fused:
+ * grid construction, bilinear sampling (zeros padding) and the per-image scatter_add.
+ *   layout[n][y][x][d] = sum_{o : obj_to_img[o]=n} vecs[o][d] * S_o(y,x)
+ * S_o = bilinear sample of masks[o] (or of an all-ones 8x8 map when masks == NULL) at the
+ * grid of layout.py:94-128.  Objects are visited in index order per image (img CSR).
+ * masks: float [O][M][M] or, when masks_i64 != NULL, int64 (the GT masks, layout.py:87).
+ * ---------------------------------------------------------------------------------- */
+int sg2im_layout_forward(const float* vecs, long long ld_vecs, const float* boxes,
+                         const float* masks, const long long* masks_i64, int mask_size,
+                         const int* img_row_ptr, const int* img_entries, int n_images, int n_objs,
+                         int dim, int height, int width, int align_corners, float* layout,
+                         long long ld_layout, hipStream_t stream);
+/* d_vecs[o][d] = sum_{y,x} dlayout[n_o][y][x][d] * S_o(y,x)  (deterministic two-stage sum;
+ * workspace: sg2im_layout_backward_workspace() bytes);  optional d_masks [O][M][M] for float
+ * (predicted) masks: d_masks[o][i][j] = sum_{y,x} <dlayout[n_o][y][x], vecs[o]> * dS_o/dm_ij. */
+size_t sg2im_layout_backward_workspace(int n_objs, int dim, int height, int width);
+int sg2im_layout_backward(const float* dlayout, long long ld_dlayout, const float* vecs,
+                          long long ld_vecs, const float* boxes, const float* masks,
+                          const long long* masks_i64, int mask_size, const long long* obj_to_img,
+                          const int* img_row_ptr, const int* img_entries, int n_images,
+                          int n_objs, int dim, int height, int width, int align_corners,
+                          float* d_vecs, long long ld_dvecs, float* d_masks, float* workspace,
+                          hipStream_t stream);
+
+/* Object crops for the object discriminator (sg2im/bilinear.py:28-132, 'cudnn' path):
+ * crops[o] = bilinear sample of image obj_to_img[o] on linspace(2*x0-1, 2*x1-1, size).
+ * imgs are NHWC [N][H][W][C] (row stride ld_img); crops NHWC [O][size][size][C]. */
+int sg2im_crop_forward(const float* imgs, long long ld_img, int n_images, int height, int width,
+                       int channels, const float* boxes, const long long* obj_to_img, int n_objs,
+                       int size, int align_corners, float* crops, hipStream_t stream);
+/* d_imgs must be zero-initialised by the caller; contributions are added atomically. */
+int sg2im_crop_backward(const float* d_crops, int n_images, int height, int width, int channels,
+                        const float* boxes, const long long* obj_to_img, int n_objs, int size,
+                        int align_corners, float* d_imgs, long long ld_dimg, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * BatchNorm2d (training statistics), pooling, layout-pyramid helpers
+ * (sg2im/layers.py:22-31, sg2im/crn.py:53-64, sg2im/model.py:94-106).
+ * ---------------------------------------------------------------------------------- */
+/* Per-channel batch statistics of x [rows][C] (row stride ld) -> mean, invstd, and the folded
+ * affine scale = gamma*invstd, shift = beta - mean*scale that the conv loader applies.
+ * training != 0: batch stats; running_mean/var/num_batches_tracked (may be NULL) are updated
+ * with `momentum` like nn.BatchNorm2d.  training == 0: running stats are used instead.
+ * unbiased_rows (0 = rows): sample count used for the unbiased running_var factor - mask_net
+ * normalises a x2-upsampled tensor (model.py:98-99) whose statistics equal the source's.
+ * partial: scratch float[2 * C * 256]. */
+int sg2im_bn_stats(const float* x, long long rows, int channels, long long ld, const float* gamma,
+                   const float* beta, float eps, float momentum, int training, float* running_mean,
+                   float* running_var, long long* num_batches_tracked, long long unbiased_rows,
+                   float* mean, float* invstd, float* scale, float* shift, float* partial,
+                   hipStream_t stream);
+/* Backward through z = leaky_slope(scale*y+shift) and the batch statistics:
+ *   dz is read from `g` [rows][ld_g] (channel offset already applied by the caller), or, when
+ *   pool2 != 0, as the 2x2 sum of g laid out [batch][2h][2w][ld_g] (nearest-upsample backward).
+ *   outputs: dy [rows][C] dense, dgamma[C], dbeta[C] (+= if accumulate).
+ *   training == 0 -> statistics are constants (eval-mode BN).
+ *   partial: scratch float[2 * C * 256 + 3 * C]. */
+int sg2im_bn_act_backward(const float* g, long long ld_g, int pool2, int batch, int h, int w,
+                          const float* y, long long ld_y, int channels, const float* gamma,
+                          const float* mean, const float* invstd, const float* scale,
+                          const float* shift, float slope, int training, float* dy,
+                          float* dgamma, float* dbeta, int accumulate, float* partial,
+                          hipStream_t stream);
+/* dx = g * leaky'(y): backward of a fused output activation (y is the activated output for
+ * slope >= 0: sign(y) == sign(pre-activation)); pool2 as above. */
+int sg2im_act_backward(const float* g, long long ld_g, int pool2, int batch, int h, int w,
+                       const float* y, long long ld_y, int channels, float slope, float* dx,
+                       hipStream_t stream);
+/* NHWC average pooling by `factor` (crn.py:62) and its backward summed over the pyramid:
+ * dlayout[n][y][x][c] (+)= sum_l dlevel_l[n][y/f_l][x/f_l][c] / f_l^2 for c < channels. */
+int sg2im_avgpool_forward(const float* x, int batch, int h, int w, int channels, int factor,
+                          float* out, hipStream_t stream);
+int sg2im_pyramid_backward(const float* const* dlevels, const int* factors, const long long* lds,
+                           int n_levels, int batch, int h, int w, int channels, float* dlayout,
+                           long long ld_out, hipStream_t stream);
+/* layout conversions at the API boundary (the reference is NCHW throughout) */
+int sg2im_nchw_to_nhwc(const float* src, int batch, int channels, int h, int w, float* dst,
+                       long long ld_dst, int c_offset, hipStream_t stream);
+int sg2im_nhwc_to_nchw(const float* src, long long ld_src, int c_offset, int batch, int channels,
+                       int h, int w, float* dst, hipStream_t stream);
+/* GlobalAvgPool (sg2im/layers.py:83-86) over NHWC [batch][hw][C] and its backward */
+int sg2im_gap_forward(const float* x, int batch, int hw, int channels, float* out, hipStream_t stream);
+int sg2im_gap_backward(const float* dout, int batch, int hw, int channels, float* dx, hipStream_t stream);
+/* sigmoid of mask scores (model.py:147) and its backward */
+int sg2im_sigmoid_forward(const float* x, long long n, float* y, hipStream_t stream);
+int sg2im_sigmoid_backward(const float* y, const float* dy, long long n, float* dx, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Losses (sg2im/losses.py:39-103, scripts/train.py:387-412) - each writes the scalar loss
+ * (already multiplied by `weight`) to loss[0] and d(loss)/d(input) to grad (may be NULL).
+ * ---------------------------------------------------------------------------------- */
+int sg2im_l1_loss(const float* pred, const float* target, long long n, float weight, float* loss,
+                  float* grad, float* partial, hipStream_t stream);
+int sg2im_mse_loss(const float* pred, const float* target, long long n, float weight, float* loss,
+                   float* grad, float* partial, hipStream_t stream);
+/* mean( max(x,0) - x*t + log(1+exp(-|x|)) ) with a constant target t (losses.py:39-57) */
+int sg2im_bce_logits_loss(const float* x, long long n, float target, float weight, float* loss,
+                          float* grad, float* partial, hipStream_t stream);
+/* mean_i( logsumexp(scores[i]) - scores[i][labels[i]] )  (F.cross_entropy, discriminators.py:74);
+ * partial: scratch float[max(256, rows)] (256 floats for the element-wise losses above) */
+int sg2im_cross_entropy_loss(const float* scores, int rows, int classes, const long long* labels,
+                             float weight, float* loss, float* grad, float* partial,
+                             hipStream_t stream);
+/* y = a * x[0..n) with a read from device memory (chains an upstream scalar gradient) */
+int sg2im_scale_by_scalar(const float* x, const float* a_dev, long long n, float* y, hipStream_t stream);
+
+/* Fused Adam over a flat parameter arena (torch.optim.Adam defaults, scripts/train.py:426-443):
+ * m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps);
+ * grad_scale multiplies g first (1/world_size after a sum all-reduce). */
+int sg2im_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
+                    float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                    hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SG2IM_HIP_H */

@@ -1,0 +1,102 @@
+"""ctypes binding of libsg2im_hip.so (C ABI declared in include/sg2im_hip.h).
+
+The product path has no CPU fallback: if the library is missing or a call fails the
+error is raised here, loudly.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_longlong, c_size_t, c_void_p, POINTER, Structure
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libsg2im_hip.so')
+
+SG2IM_OK, SG2IM_ERR_ARG, SG2IM_ERR_HIP = 0, 1, 2
+
+
+class Sg2imHipError(RuntimeError):
+  pass
+
+
+class Src(Structure):
+  _fields_ = [('data', c_void_p), ('gather', c_void_p), ('scale', c_void_p), ('shift', c_void_p),
+              ('slope', c_float), ('channels', c_int), ('ld', c_int), ('upsample_log2', c_int)]
+
+
+class ConvDesc(Structure):
+  _fields_ = [('src', Src * 4), ('nsrc', c_int), ('batch', c_int), ('in_h', c_int), ('in_w', c_int),
+              ('out_h', c_int), ('out_w', c_int), ('kh', c_int), ('kw', c_int), ('stride', c_int),
+              ('pad', c_int)]
+
+
+_P, _I, _L, _F, _Z = c_void_p, c_int, c_longlong, c_float, c_size_t
+_D = POINTER(ConvDesc)
+
+# name -> argtypes (return type is int for all but the two noted)
+_SIGNATURES = {
+  'sg2im_abi_version': [],
+  'sg2im_conv2d_forward': [_D, _P, _I, _P, _F, _P, _L, _I, _P, _Z, _P],
+  'sg2im_conv2d_backward_data': [_D, _P, _I, _P, _I, _I, _I, _P, _L, _I, _P, _Z, _P],
+  'sg2im_conv2d_backward_weight': [_D, _P, _I, _I, _P, _I, _P, _Z, _P],
+  'sg2im_column_sum': [_P, _L, _I, _L, _P, _I, _P, _P],
+  'sg2im_csr_build': [_P, _I, _P, _I, _I, _P, _P, _P, _P],
+  'sg2im_segment_sum': [_P, _L, _I, _P, _L, _P, _P, _I, _I, _I, _P, _L, _P],
+  'sg2im_gather_rows': [_P, _L, _P, _I, _I, _P, _P, _L, _P],
+  'sg2im_copy_2d': [_P, _L, _P, _L, _L, _I, _P],
+  'sg2im_layout_forward': [_P, _L, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P],
+  'sg2im_layout_backward_workspace': [_I, _I, _I, _I],
+  'sg2im_layout_backward': [_P, _L, _P, _L, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P,
+                            _P, _P],
+  'sg2im_crop_forward': [_P, _L, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _P],
+  'sg2im_crop_backward': [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _L, _P],
+  'sg2im_bn_stats': [_P, _L, _I, _L, _P, _P, _F, _F, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P],
+  'sg2im_bn_act_backward': [_P, _L, _I, _I, _I, _I, _P, _L, _I, _P, _P, _P, _P, _P, _F, _I, _P, _P, _P, _I,
+                            _P, _P],
+  'sg2im_act_backward': [_P, _L, _I, _I, _I, _I, _P, _L, _I, _F, _P, _P],
+  'sg2im_avgpool_forward': [_P, _I, _I, _I, _I, _I, _P, _P],
+  'sg2im_pyramid_backward': [POINTER(c_void_p), POINTER(c_int), POINTER(c_longlong), _I, _I, _I, _I, _I, _P,
+                             _L, _P],
+  'sg2im_nchw_to_nhwc': [_P, _I, _I, _I, _I, _P, _L, _I, _P],
+  'sg2im_nhwc_to_nchw': [_P, _L, _I, _I, _I, _I, _I, _P, _P],
+  'sg2im_gap_forward': [_P, _I, _I, _I, _P, _P],
+  'sg2im_gap_backward': [_P, _I, _I, _I, _P, _P],
+  'sg2im_sigmoid_forward': [_P, _L, _P, _P],
+  'sg2im_sigmoid_backward': [_P, _P, _L, _P, _P],
+  'sg2im_l1_loss': [_P, _P, _L, _F, _P, _P, _P, _P],
+  'sg2im_mse_loss': [_P, _P, _L, _F, _P, _P, _P, _P],
+  'sg2im_bce_logits_loss': [_P, _L, _F, _F, _P, _P, _P, _P],
+  'sg2im_cross_entropy_loss': [_P, _I, _I, _P, _F, _P, _P, _P, _P],
+  'sg2im_scale_by_scalar': [_P, _P, _L, _P, _P],
+  'sg2im_adam_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
+}
+_RESTYPE = {'sg2im_layout_backward_workspace': c_size_t}
+EXPORTS = tuple(sorted(_SIGNATURES))
+
+_lib = None
+
+
+def load():
+  """Load the shared library (once).  Raises Sg2imHipError when it is missing - there is
+  deliberately no fallback implementation."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise Sg2imHipError(
+      'libsg2im_hip.so not found at %s - build it with `python -m sg2im_amd.build` '
+      '(or __graft_entry__.build()); the HIP path has no fallback' % LIB_PATH)
+  lib = ctypes.CDLL(LIB_PATH)
+  for name, argtypes in _SIGNATURES.items():
+    fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+    fn.argtypes = argtypes
+    fn.restype = _RESTYPE.get(name, c_int)
+  _lib = lib
+  return lib
+
+
+def call(name, *args):
+  """Invoke an int-returning entry point and raise on a non-zero status."""
+  rc = getattr(load(), name)(*args)
+  if rc != SG2IM_OK:
+    kind = {SG2IM_ERR_ARG: 'invalid argument', SG2IM_ERR_HIP: 'HIP runtime error'}.get(rc, 'error %d' % rc)
+    raise Sg2imHipError('%s failed: %s' % (name, kind))
+  return rc

@@ -1,0 +1,732 @@
+// Convolution / linear layers as implicit GEMM on the fp32 matrix cores.
+//
+//   conv_fwd    out[pix][co]        = sum_{tap,c} X[pix (+) tap][c] * W[co][tap][c]     (NT)
+//   conv_dgrad  dX[inpix][c]        = sum_{tap,co} dY[inpix (-) tap][co] * W[co][tap][c] (NN)
+//   conv_wgrad  dW[co][tap][c]      = sum_{pix} dY[pix][co] * X[pix (+) tap][c]          (TN)
+//
+// Activations are NHWC, weights are [Cout][KH][KW][Ctot] (the physical layout of a
+// torch channels_last (Cout,Cin,KH,KW) parameter).  A linear layer is the 1x1 case on
+// a [rows,1,1,K] tensor.  The X operand is a *virtual* tensor: the channel concat of
+// up to four sources, each optionally nearest-upsampled x2, row-gathered, and with a
+// pending per-channel affine + LeakyReLU (the previous layer's BatchNorm + activation)
+// applied on the fly - so torch.cat / F.upsample / obj_vecs[idx] / BN-apply of the
+// reference (sg2im/crn.py:58-64,107; sg2im/graph.py:77-82; sg2im/layers.py:166-169)
+// are never materialised.
+#include <algorithm>
+#include "igemm.h"
+#include "sg2im_hip.h"
+
+namespace sg2im {
+
+struct FwdParams {
+  ConvGeom g;
+  const float* Wt;
+  int Cout;
+  int M;            // NB*Ho*Wo
+  int iters;        // total K iterations
+  int nch;          // K chunks per tap (VEC=4)
+  Epi e;
+};
+
+struct DgradParams {
+  ConvGeom g;       // geometry of the *forward* conv; g.src[0] describes dY: p, C=Cout, ld
+  const float* Wt;
+  int c_begin, Nc;  // input-channel range [c_begin, c_begin+Nc) produced by this launch
+  int M;            // NB*H*W
+  int iters, nch;
+  Epi e;
+};
+
+struct WgradParams {
+  ConvGeom g;
+  const float* dY;  // [NB*Ho*Wo][ldy]
+  int ldy;
+  int Cout;
+  int P;            // NB*Ho*Wo (reduction length)
+  int iters;        // ceil(P / BK)
+  int ntile_c;      // column tiles per tap (VEC=4)
+  Epi e;
+};
+
+// ---------------------------------------------------------------------------
+// virtual-tensor element access
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ long long pixel_row(const ConvGeom& g, const Src& S, int n, int hi, int wi) {
+  if (S.gidx) return S.gidx[n];
+  return ((long long)n * (g.H >> S.up) + (hi >> S.up)) * (g.W >> S.up) + (wi >> S.up);
+}
+
+__device__ __forceinline__ float4 load4(const ConvGeom& g, const Src& S, int n, int hi, int wi, int c) {
+  float4 v = *reinterpret_cast<const float4*>(S.p + pixel_row(g, S, n, hi, wi) * S.ld + c);
+  if (S.scale) {
+    const float4 sc = *reinterpret_cast<const float4*>(S.scale + c);
+    const float4 sh = *reinterpret_cast<const float4*>(S.shift + c);
+    v.x = leaky(fmaf(v.x, sc.x, sh.x), S.slope);
+    v.y = leaky(fmaf(v.y, sc.y, sh.y), S.slope);
+    v.z = leaky(fmaf(v.z, sc.z, sh.z), S.slope);
+    v.w = leaky(fmaf(v.w, sc.w, sh.w), S.slope);
+  }
+  return v;
+}
+
+__device__ __forceinline__ float load1(const ConvGeom& g, const Src& S, int n, int hi, int wi, int c) {
+  float v = S.p[pixel_row(g, S, n, hi, wi) * S.ld + c];
+  if (S.scale) v = leaky(fmaf(v, S.scale[c], S.shift[c]), S.slope);
+  return v;
+}
+
+__device__ __forceinline__ void zero_acc(f32x16& a) {
+  #pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+
+// K-chunk `ch` (within one tap) -> source, its first concat channel, chunk base
+__device__ __forceinline__ void locate_chunk(const ConvGeom& g, int ch, int& s, int& cstart, int& cb) {
+  const int n0 = (g.s0.C + BK - 1) / BK, n1 = (g.s1.C + BK - 1) / BK, n2 = (g.s2.C + BK - 1) / BK;
+  if (ch < n0) { s = 0; cstart = 0; }
+  else if (ch < n0 + n1) { s = 1; cstart = g.s0.C; ch -= n0; }
+  else if (ch < n0 + n1 + n2) { s = 2; cstart = g.s0.C + g.s1.C; ch -= n0 + n1; }
+  else { s = 3; cstart = g.s0.C + g.s1.C + g.s2.C; ch -= n0 + n1 + n2; }
+  cb = ch * BK;
+}
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int VEC>
+__global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NVA = BM / 32, NVB = BN / 32;
+  constexpr int AF = LdsTile<BM, false>::FLOATS, BF = LdsTile<BN, false>::FLOATS;
+  constexpr int STAGE = AF + BF;            // stage s: A at smem + s*STAGE, B right behind it
+  const ConvGeom& g = p.g;
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, split = blockIdx.z;
+  const int per = (p.iters + p.e.nsplit - 1) / p.e.nsplit;
+  const int it_begin = split * per;
+  const int it_end = min(p.iters, it_begin + per);
+  const int col4 = tid & 7, r0 = tid >> 3;
+  const int ldw = g.KH * g.KW * g.Ctot;
+  const int Ktot = ldw;
+
+  int rn[NVA], rhb[NVA], rwb[NVA];
+  {
+    const int HoWo = g.Ho * g.Wo;
+    #pragma unroll
+    for (int i = 0; i < NVA; ++i) {
+      const int m = m0 + r0 + 32 * i;
+      if (m < p.M) {
+        const int n = m / HoWo, rem = m - n * HoWo;
+        const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+        rn[i] = n; rhb[i] = ho * g.stride - g.pad; rwb[i] = wo * g.stride - g.pad;
+      } else { rn[i] = -1; rhb[i] = 0; rwb[i] = 0; }
+    }
+  }
+
+  float4 ra[NVA], rb[NVB];
+  auto load = [&](int it) {
+    if (VEC == 4) {
+      const int tap = it / p.nch;
+      int s, cstart, cb;
+      locate_chunk(g, it - tap * p.nch, s, cstart, cb);
+      const Src S = pick_src(g, s);
+      const int kh = tap / g.KW, kw = tap - kh * g.KW;
+      const int c = cb + 4 * col4;
+      const bool cok = c < S.C;
+      #pragma unroll
+      for (int i = 0; i < NVA; ++i) {
+        const int hi = rhb[i] + kh, wi = rwb[i] + kw;
+        const bool ok = cok && rn[i] >= 0 && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+        ra[i] = ok ? load4(g, S, rn[i], hi, wi, c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      const long long wcol = (long long)tap * g.Ctot + cstart + c;
+      #pragma unroll
+      for (int i = 0; i < NVB; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        rb[i] = (cok && n < p.Cout) ? *reinterpret_cast<const float4*>(p.Wt + (long long)n * ldw + wcol)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+      float av[NVA][4], bv[NVB][4];
+      #pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = it * BK + 4 * col4 + j;
+        const bool kok = k < Ktot;
+        const int kk = kok ? k : 0;
+        const int tap = kk / g.Ctot, c = kk - tap * g.Ctot;
+        int s, cs;
+        locate_channel(g, c, s, cs);
+        const Src S = pick_src(g, s);
+        const int kh = tap / g.KW, kw = tap - kh * g.KW;
+        #pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+          const int hi = rhb[i] + kh, wi = rwb[i] + kw;
+          const bool ok = kok && rn[i] >= 0 && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+          av[i][j] = ok ? load1(g, S, rn[i], hi, wi, cs) : 0.f;
+        }
+        #pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+          const int n = n0 + r0 + 32 * i;
+          bv[i][j] = (kok && n < p.Cout) ? p.Wt[(long long)n * ldw + k] : 0.f;
+        }
+      }
+      #pragma unroll
+      for (int i = 0; i < NVA; ++i) ra[i] = make_float4(av[i][0], av[i][1], av[i][2], av[i][3]);
+      #pragma unroll
+      for (int i = 0; i < NVB; ++i) rb[i] = make_float4(bv[i][0], bv[i][1], bv[i][2], bv[i][3]);
+    }
+  };
+
+  f32x16 acc[BM / 64][BN / 64];
+  #pragma unroll
+  for (int a = 0; a < BM / 64; ++a)
+    #pragma unroll
+    for (int b = 0; b < BN / 64; ++b) zero_acc(acc[a][b]);
+
+  int wm0, wn0, lane;
+  wave_origin<BM, BN>(tid, wm0, wn0, lane);
+
+  if (it_begin < it_end) {
+    load(it_begin);
+    store_tile<BM, false>(smem, ra, tid);
+    store_tile<BN, false>(smem + AF, rb, tid);
+    __syncthreads();
+    int cur = 0;
+    for (int it = it_begin; it < it_end; ++it) {
+      const bool more = it + 1 < it_end;
+      if (more) load(it + 1);
+      mma_chunk<BM, BN, false, false>(smem + cur * STAGE, smem + cur * STAGE + AF, wm0, wn0, lane, acc);
+      if (more) {
+        store_tile<BM, false>(smem + (cur ^ 1) * STAGE, ra, tid);
+        store_tile<BN, false>(smem + (cur ^ 1) * STAGE + AF, rb, tid);
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  epilogue<BM, BN>(p.e, p.M, p.Cout, p.Cout, m0, n0, wm0, wn0, lane, split, acc);
+}
+
+// ---------------------------------------------------------------------------
+// data gradient (transposed convolution of dY with the same weights)
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int VEC>
+__global__ __launch_bounds__(NTHREADS) void conv_dgrad_kernel(const DgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NVA = BM / 32, NVB = BN / 32;
+  constexpr int AF = LdsTile<BM, false>::FLOATS, BF = LdsTile<BN, true>::FLOATS;
+  constexpr int STAGE = AF + BF;            // stage s: A at smem + s*STAGE, B right behind it
+  const ConvGeom& g = p.g;
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, split = blockIdx.z;
+  const int per = (p.iters + p.e.nsplit - 1) / p.e.nsplit;
+  const int it_begin = split * per;
+  const int it_end = min(p.iters, it_begin + per);
+  const int col4 = tid & 7, r0 = tid >> 3;
+  const int taps = g.KH * g.KW;
+  const int ldw = taps * g.Ctot;
+  const int Cout = g.s0.C, ldy = g.s0.ld;
+  const float* dY = g.s0.p;
+  const int Ktot = taps * Cout;
+
+  // A rows are *input* pixels (n, h, w)
+  int rn[NVA], rh[NVA], rw[NVA];
+  {
+    const int HW = g.H * g.W;
+    #pragma unroll
+    for (int i = 0; i < NVA; ++i) {
+      const int m = m0 + r0 + 32 * i;
+      if (m < p.M) {
+        const int n = m / HW, rem = m - n * HW;
+        rn[i] = n; rh[i] = rem / g.W; rw[i] = rem - rh[i] * g.W;
+        rh[i] += g.pad; rw[i] += g.pad;
+      } else { rn[i] = -1; rh[i] = 0; rw[i] = 0; }
+    }
+  }
+  // B thread mapping (k-major tile [BK][BN])
+  constexpr int Q = BN / 4;
+  const int bcol4 = tid % Q, bk0 = tid / Q;
+
+  auto out_pixel = [&](int i, int kh, int kw, long long& row) -> bool {
+    const int nh = rh[i] - kh, nw = rw[i] - kw;      // = ho*stride, wo*stride
+    if (rn[i] < 0 || nh < 0 || nw < 0) return false;
+    int ho = nh, wo = nw;
+    if (g.stride != 1) {
+      ho = nh / g.stride; wo = nw / g.stride;
+      if (ho * g.stride != nh || wo * g.stride != nw) return false;
+    }
+    if (ho >= g.Ho || wo >= g.Wo) return false;
+    row = ((long long)rn[i] * g.Ho + ho) * g.Wo + wo;
+    return true;
+  };
+
+  float4 ra[NVA], rb[NVB];
+  auto load = [&](int it) {
+    if (VEC == 4) {
+      const int tap = it / p.nch, cb = (it - tap * p.nch) * BK;
+      const int kh = tap / g.KW, kw = tap - kh * g.KW;
+      const int co = cb + 4 * col4;
+      const bool cok = co < Cout;
+      #pragma unroll
+      for (int i = 0; i < NVA; ++i) {
+        long long row;
+        const bool ok = cok && out_pixel(i, kh, kw, row);
+        ra[i] = ok ? *reinterpret_cast<const float4*>(dY + row * ldy + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      const int nn = n0 + 4 * bcol4;
+      #pragma unroll
+      for (int i = 0; i < NVB; ++i) {
+        const int cok2 = cb + bk0 + (1024 / BN) * i;
+        rb[i] = (cok2 < Cout && nn < p.Nc)
+                  ? *reinterpret_cast<const float4*>(p.Wt + (long long)cok2 * ldw + (long long)tap * g.Ctot + p.c_begin + nn)
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+      float av[NVA][4];
+      #pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = it * BK + 4 * col4 + j;
+        const bool kok = k < Ktot;
+        const int tap = kok ? k / Cout : 0, co = kok ? k - tap * Cout : 0;
+        const int kh = tap / g.KW, kw = tap - kh * g.KW;
+        #pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+          long long row;
+          const bool ok = kok && out_pixel(i, kh, kw, row);
+          av[i][j] = ok ? dY[row * ldy + co] : 0.f;
+        }
+      }
+      #pragma unroll
+      for (int i = 0; i < NVA; ++i) ra[i] = make_float4(av[i][0], av[i][1], av[i][2], av[i][3]);
+      #pragma unroll
+      for (int i = 0; i < NVB; ++i) {
+        const int k = it * BK + bk0 + (1024 / BN) * i;
+        const bool kok = k < Ktot;
+        const int tap = kok ? k / Cout : 0, co = kok ? k - tap * Cout : 0;
+        const float* wrow = p.Wt + (long long)co * ldw + (long long)tap * g.Ctot + p.c_begin;
+        float bv[4];
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int nn = n0 + 4 * bcol4 + j;
+          bv[j] = (kok && nn < p.Nc) ? wrow[nn] : 0.f;
+        }
+        rb[i] = make_float4(bv[0], bv[1], bv[2], bv[3]);
+      }
+    }
+  };
+
+  f32x16 acc[BM / 64][BN / 64];
+  #pragma unroll
+  for (int a = 0; a < BM / 64; ++a)
+    #pragma unroll
+    for (int b = 0; b < BN / 64; ++b) zero_acc(acc[a][b]);
+
+  int wm0, wn0, lane;
+  wave_origin<BM, BN>(tid, wm0, wn0, lane);
+
+  if (it_begin < it_end) {
+    load(it_begin);
+    store_tile<BM, false>(smem, ra, tid);
+    store_tile<BN, true>(smem + AF, rb, tid);
+    __syncthreads();
+    int cur = 0;
+    for (int it = it_begin; it < it_end; ++it) {
+      const bool more = it + 1 < it_end;
+      if (more) load(it + 1);
+      mma_chunk<BM, BN, false, true>(smem + cur * STAGE, smem + cur * STAGE + AF, wm0, wn0, lane, acc);
+      if (more) {
+        store_tile<BM, false>(smem + (cur ^ 1) * STAGE, ra, tid);
+        store_tile<BN, true>(smem + (cur ^ 1) * STAGE + AF, rb, tid);
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  epilogue<BM, BN>(p.e, p.M, p.Nc, p.Nc, m0, n0, wm0, wn0, lane, split, acc);
+}
+
+// ---------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int VEC>
+__global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NVA = BM / 32, NVB = BN / 32;
+  constexpr int AF = LdsTile<BM, true>::FLOATS, BF = LdsTile<BN, true>::FLOATS;
+  constexpr int STAGE = AF + BF;            // stage s: A at smem + s*STAGE, B right behind it
+  const ConvGeom& g = p.g;
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.y * BM, split = blockIdx.z;
+  const int per = (p.iters + p.e.nsplit - 1) / p.e.nsplit;
+  const int it_begin = split * per;
+  const int it_end = min(p.iters, it_begin + per);
+  const int taps = g.KH * g.KW;
+  const int Ntot = taps * g.Ctot;
+  const int HoWo = g.Ho * g.Wo;
+
+  // column tile -> (tap, first concat channel) for VEC=4, flat column for VEC=1
+  int n0, tap0 = 0, c0 = 0;
+  if (VEC == 4) {
+    tap0 = blockIdx.x / p.ntile_c;
+    c0 = (blockIdx.x - tap0 * p.ntile_c) * BN;
+    n0 = tap0 * g.Ctot + c0;
+  } else {
+    n0 = blockIdx.x * BN;
+  }
+  constexpr int QA = BM / 4, QB = BN / 4;
+  const int acol4 = tid % QA, ak0 = tid / QA;
+  const int bcol4 = tid % QB, bk0 = tid / QB;
+
+  // per-thread B column(s): fixed for the whole reduction
+  int bs = 0, bcs = 0;
+  const int bc = c0 + 4 * bcol4;
+  const bool bok = (VEC == 4) && bc < g.Ctot;
+  locate_channel(g, bok ? bc : 0, bs, bcs);
+  const Src BS = pick_src(g, bs);
+  const int bkh = tap0 / g.KW, bkw = tap0 - bkh * g.KW;
+  int js[4], jcs[4], jkh[4], jkw[4];
+  bool jok[4];
+  if (VEC != 4) {
+    #pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + 4 * bcol4 + j;
+      jok[j] = n < Ntot;
+      const int tap = jok[j] ? n / g.Ctot : 0, c = jok[j] ? n - tap * g.Ctot : 0;
+      locate_channel(g, c, js[j], jcs[j]);
+      jkh[j] = tap / g.KW; jkw[j] = tap - jkh[j] * g.KW;
+    }
+  }
+
+  float4 ra[NVA], rb[NVB];
+  auto load = [&](int it) {
+    #pragma unroll
+    for (int i = 0; i < NVA; ++i) {
+      const int pix = it * BK + ak0 + (1024 / BM) * i;
+      const int co = m0 + 4 * acol4;
+      if (VEC == 4) {
+        ra[i] = (pix < p.P && co < p.Cout) ? *reinterpret_cast<const float4*>(p.dY + (long long)pix * p.ldy + co)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        float v[4];
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (pix < p.P && co + j < p.Cout) ? p.dY[(long long)pix * p.ldy + co + j] : 0.f;
+        ra[i] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    #pragma unroll
+    for (int i = 0; i < NVB; ++i) {
+      const int pix = it * BK + bk0 + (1024 / BN) * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pix < p.P) {
+        const int n = pix / HoWo, rem = pix - n * HoWo;
+        const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+        const int hb = ho * g.stride - g.pad, wb = wo * g.stride - g.pad;
+        if (VEC == 4) {
+          const int hi = hb + bkh, wi = wb + bkw;
+          if (bok && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W) v = load4(g, BS, n, hi, wi, bcs);
+        } else {
+          float e[4];
+          #pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int hi = hb + jkh[j], wi = wb + jkw[j];
+            e[j] = (jok[j] && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W)
+                     ? load1(g, pick_src(g, js[j]), n, hi, wi, jcs[j]) : 0.f;
+          }
+          v = make_float4(e[0], e[1], e[2], e[3]);
+        }
+      }
+      rb[i] = v;
+    }
+  };
+
+  f32x16 acc[BM / 64][BN / 64];
+  #pragma unroll
+  for (int a = 0; a < BM / 64; ++a)
+    #pragma unroll
+    for (int b = 0; b < BN / 64; ++b) zero_acc(acc[a][b]);
+
+  int wm0, wn0, lane;
+  wave_origin<BM, BN>(tid, wm0, wn0, lane);
+
+  if (it_begin < it_end) {
+    load(it_begin);
+    store_tile<BM, true>(smem, ra, tid);
+    store_tile<BN, true>(smem + AF, rb, tid);
+    __syncthreads();
+    int cur = 0;
+    for (int it = it_begin; it < it_end; ++it) {
+      const bool more = it + 1 < it_end;
+      if (more) load(it + 1);
+      mma_chunk<BM, BN, true, true>(smem + cur * STAGE, smem + cur * STAGE + AF, wm0, wn0, lane, acc);
+      if (more) {
+        store_tile<BM, true>(smem + (cur ^ 1) * STAGE, ra, tid);
+        store_tile<BN, true>(smem + (cur ^ 1) * STAGE + AF, rb, tid);
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  // columns of this tile are [n0, n0 + ncols): in VEC=4 mode clip to the tap's channels
+  const int ncols_end = (VEC == 4) ? tap0 * g.Ctot + g.Ctot : Ntot;
+  epilogue<BM, BN>(p.e, p.Cout, Ntot, ncols_end, m0, n0, wm0, wn0, lane, split, acc);
+}
+
+// ---------------------------------------------------------------------------
+// split-K finish: C = act(sum_s ws[s] + bias) (+ C)
+// ---------------------------------------------------------------------------
+__global__ void splitk_finish_kernel(const float* __restrict__ ws, int nsplit, long long MN, int N,
+                                     float* __restrict__ C, long long ldc, const float* __restrict__ bias,
+                                     float slope, int accumulate) {
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < MN;
+       idx += (long long)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    for (int s = 0; s < nsplit; ++s) v += ws[(long long)s * MN + idx];
+    const long long m = idx / N;
+    const int n = (int)(idx - m * N);
+    if (bias) v += bias[n];
+    v = leaky(v, slope);
+    float* dst = C + m * ldc + n;
+    if (accumulate) v += *dst;
+    *dst = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static int g_num_cu = 256;
+
+template <typename K>
+static hipError_t ensure_lds(K kernel, size_t bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+static Src* src_at(ConvGeom& g, int i) { return i == 0 ? &g.s0 : i == 1 ? &g.s1 : i == 2 ? &g.s2 : &g.s3; }
+
+static bool geom_vec4(ConvGeom& g) {
+  for (int i = 0; i < g.nsrc; ++i) {
+    const Src& s = *src_at(g, i);
+    if (s.C % 4 || s.ld % 4 || ((uintptr_t)s.p & 15)) return false;
+    if (s.scale && (((uintptr_t)s.scale & 15) || ((uintptr_t)s.shift & 15))) return false;
+  }
+  return g.Ctot % 4 == 0;
+}
+
+static void fill_geom(ConvGeom& g, const sg2im_conv_desc* d) {
+  g.nsrc = d->nsrc;
+  g.Ctot = 0;
+  for (int i = 0; i < 4; ++i) {
+    Src& s = *src_at(g, i);
+    if (i < d->nsrc) {
+      const sg2im_src& q = d->src[i];
+      s.p = q.data; s.gidx = q.gather; s.scale = q.scale; s.shift = q.shift; s.slope = q.slope;
+      s.C = q.channels; s.ld = q.ld; s.up = q.upsample_log2;
+      g.Ctot += q.channels;
+    } else {
+      s = Src{nullptr, nullptr, nullptr, nullptr, 1.f, 0, 0, 0};
+    }
+  }
+  g.NB = d->batch; g.H = d->in_h; g.W = d->in_w; g.Ho = d->out_h; g.Wo = d->out_w;
+  g.KH = d->kh; g.KW = d->kw; g.stride = d->stride; g.pad = d->pad;
+}
+
+static int check_desc(const sg2im_conv_desc* d) {
+  if (!d || d->nsrc < 1 || d->nsrc > 4) return 1;
+  if (d->stride < 1 || d->kh < 1 || d->kw < 1) return 1;
+  const int eh = (d->in_h + 2 * d->pad - d->kh) / d->stride + 1;
+  const int ew = (d->in_w + 2 * d->pad - d->kw) / d->stride + 1;
+  if (eh != d->out_h || ew != d->out_w) return 1;
+  for (int i = 0; i < d->nsrc; ++i) {
+    if (!d->src[i].data || d->src[i].channels < 1 || d->src[i].ld < d->src[i].channels) return 1;
+    if (d->src[i].upsample_log2 < 0 || d->src[i].upsample_log2 > 1) return 1;
+    if (d->src[i].gather && (d->in_h != 1 || d->in_w != 1)) return 1;
+    if (d->src[i].upsample_log2 && ((d->in_h & 1) || (d->in_w & 1))) return 1;
+  }
+  return 0;
+}
+
+// choose split-K so that tiles * nsplit fills the chip, bounded by work and workspace
+static int choose_split(long long tiles, int iters, long long MN, size_t ws_bytes, int min_iters) {
+  const long long target = 2LL * g_num_cu;
+  int ns = 1;
+  if (tiles < target) ns = (int)((target + tiles - 1) / tiles);
+  ns = std::min(ns, std::max(1, iters / min_iters));
+  const long long cap = MN > 0 ? (long long)(ws_bytes / sizeof(float)) / MN : 1;
+  ns = (int)std::min<long long>(ns, std::max<long long>(1, cap));
+  ns = std::min(ns, 64);
+  if (ns > 1) {                       // make every split non-empty
+    const int per = (iters + ns - 1) / ns;
+    ns = (iters + per - 1) / per;
+  }
+  return ns;
+}
+
+static hipError_t finish_split(const Epi& e, long long M, int N, hipStream_t st) {
+  if (e.nsplit <= 1) return hipSuccess;
+  const long long MN = M * N;
+  const int blocks = (int)std::min<long long>((MN + 255) / 256, 4096);
+  hipLaunchKernelGGL(splitk_finish_kernel, dim3(blocks), dim3(256), 0, st, e.ws, e.nsplit, MN, N, e.C, e.ldc,
+                     e.bias, e.slope, e.accumulate);
+  return hipGetLastError();
+}
+
+template <int BM, int BN, int VEC>
+static hipError_t launch_fwd(FwdParams& p, hipStream_t st) {
+  constexpr size_t lds = 2 * (LdsTile<BM, false>::FLOATS + LdsTile<BN, false>::FLOATS) * sizeof(float);
+  static bool once = false;
+  if (!once) { hipError_t e = ensure_lds(conv_fwd_kernel<BM, BN, VEC>, lds); if (e != hipSuccess) return e; once = true; }
+  dim3 grid((p.Cout + BN - 1) / BN, (p.M + BM - 1) / BM, p.e.nsplit);
+  hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, VEC>), grid, dim3(NTHREADS), lds, st, p);
+  return hipGetLastError();
+}
+
+template <int BM, int BN, int VEC>
+static hipError_t launch_dgrad(DgradParams& p, hipStream_t st) {
+  constexpr size_t lds = 2 * (LdsTile<BM, false>::FLOATS + LdsTile<BN, true>::FLOATS) * sizeof(float);
+  static bool once = false;
+  if (!once) { hipError_t e = ensure_lds(conv_dgrad_kernel<BM, BN, VEC>, lds); if (e != hipSuccess) return e; once = true; }
+  dim3 grid((p.Nc + BN - 1) / BN, (p.M + BM - 1) / BM, p.e.nsplit);
+  hipLaunchKernelGGL((conv_dgrad_kernel<BM, BN, VEC>), grid, dim3(NTHREADS), lds, st, p);
+  return hipGetLastError();
+}
+
+template <int BM, int BN, int VEC>
+static hipError_t launch_wgrad(WgradParams& p, int ntiles_n, hipStream_t st) {
+  constexpr size_t lds = 2 * (LdsTile<BM, true>::FLOATS + LdsTile<BN, true>::FLOATS) * sizeof(float);
+  static bool once = false;
+  if (!once) { hipError_t e = ensure_lds(conv_wgrad_kernel<BM, BN, VEC>, lds); if (e != hipSuccess) return e; once = true; }
+  dim3 grid(ntiles_n, (p.Cout + BM - 1) / BM, p.e.nsplit);
+  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, VEC>), grid, dim3(NTHREADS), lds, st, p);
+  return hipGetLastError();
+}
+
+// tile choice: 0 -> 128x128, 1 -> 128x64, 2 -> 64x64
+static int choose_tile(long long M, int N) {
+  if (N <= 64) return (M >= 128 * 64) ? 1 : 2;
+  const long long t128 = ((M + 127) / 128) * ((N + 127) / 128);
+  if (t128 >= g_num_cu / 2) return 0;
+  return 2;
+}
+
+}  // namespace sg2im
+
+using namespace sg2im;
+
+extern "C" {
+
+int sg2im_conv2d_forward(const sg2im_conv_desc* d, const float* weight, int cout, const float* bias,
+                         float out_slope, float* out, long long ld_out, int accumulate,
+                         float* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (check_desc(d) || !weight || !out || cout < 1) return SG2IM_ERR_ARG;
+  FwdParams p;
+  fill_geom(p.g, d);
+  p.Wt = weight; p.Cout = cout;
+  p.M = d->batch * d->out_h * d->out_w;
+  if (p.M == 0) return SG2IM_OK;
+  const bool v4 = geom_vec4(p.g) && !((uintptr_t)weight & 15);
+  const int taps = d->kh * d->kw;
+  if (v4) {
+    p.nch = 0;
+    for (int i = 0; i < p.g.nsrc; ++i) p.nch += (src_at(p.g, i)->C + BK - 1) / BK;
+    p.iters = taps * p.nch;
+  } else {
+    p.nch = 0;
+    p.iters = (taps * p.g.Ctot + BK - 1) / BK;
+  }
+  const int tile = choose_tile(p.M, cout);
+  const int bm = tile == 2 ? 64 : 128, bn = tile == 0 ? 128 : 64;
+  const long long tiles = ((long long)(p.M + bm - 1) / bm) * ((cout + bn - 1) / bn);
+  p.e = Epi{out, ld_out, bias, out_slope, accumulate, workspace, 1};
+  p.e.nsplit = workspace ? choose_split(tiles, p.iters, (long long)p.M * cout, workspace_bytes, 4) : 1;
+  hipError_t err;
+  if (v4) {
+    err = tile == 0 ? launch_fwd<128, 128, 4>(p, stream) : tile == 1 ? launch_fwd<128, 64, 4>(p, stream)
+                                                                      : launch_fwd<64, 64, 4>(p, stream);
+  } else {
+    err = launch_fwd<64, 64, 1>(p, stream);
+  }
+  if (err != hipSuccess) return SG2IM_ERR_HIP;
+  return finish_split(p.e, p.M, cout, stream) == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+}
+
+int sg2im_conv2d_backward_data(const sg2im_conv_desc* d, const float* weight, int cout, const float* dy,
+                               int ld_dy, int c_begin, int c_count, float* dx, long long ld_dx,
+                               int accumulate, float* workspace, size_t workspace_bytes,
+                               hipStream_t stream) {
+  if (!d || !weight || !dy || !dx || cout < 1 || c_count < 1 || ld_dy < cout) return SG2IM_ERR_ARG;
+  if (check_desc(d)) return SG2IM_ERR_ARG;
+  DgradParams p;
+  // geometry (and Ctot) of the forward conv; src[0] is then re-purposed to carry dY
+  ConvGeom& g = p.g;
+  fill_geom(g, d);
+  g.nsrc = 1;
+  for (int i = 0; i < 4; ++i) *src_at(g, i) = Src{nullptr, nullptr, nullptr, nullptr, 1.f, 0, 0, 0};
+  g.s0.p = dy; g.s0.C = cout; g.s0.ld = ld_dy;
+  if (c_begin < 0 || c_begin + c_count > g.Ctot) return SG2IM_ERR_ARG;
+  p.Wt = weight; p.c_begin = c_begin; p.Nc = c_count;
+  p.M = d->batch * d->in_h * d->in_w;
+  if (p.M == 0) return SG2IM_OK;
+  const int taps = d->kh * d->kw;
+  const bool v4 = (cout % 4 == 0) && (ld_dy % 4 == 0) && !((uintptr_t)dy & 15) && (g.Ctot % 4 == 0) &&
+                  (c_begin % 4 == 0) && (c_count % 4 == 0) && !((uintptr_t)weight & 15);
+  if (v4) { p.nch = (cout + BK - 1) / BK; p.iters = taps * p.nch; }
+  else { p.nch = 0; p.iters = (taps * cout + BK - 1) / BK; }
+  const int tile = choose_tile(p.M, c_count);
+  const int bm = tile == 2 ? 64 : 128, bn = tile == 0 ? 128 : 64;
+  const long long tiles = ((long long)(p.M + bm - 1) / bm) * ((c_count + bn - 1) / bn);
+  p.e = Epi{dx, ld_dx, nullptr, 1.f, accumulate, workspace, 1};
+  p.e.nsplit = workspace ? choose_split(tiles, p.iters, (long long)p.M * c_count, workspace_bytes, 4) : 1;
+  hipError_t err;
+  if (v4) {
+    err = tile == 0 ? launch_dgrad<128, 128, 4>(p, stream) : tile == 1 ? launch_dgrad<128, 64, 4>(p, stream)
+                                                                        : launch_dgrad<64, 64, 4>(p, stream);
+  } else {
+    err = launch_dgrad<64, 64, 1>(p, stream);
+  }
+  if (err != hipSuccess) return SG2IM_ERR_HIP;
+  return finish_split(p.e, p.M, c_count, stream) == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+}
+
+int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int ld_dy, int cout,
+                                 float* dweight, int accumulate, float* workspace,
+                                 size_t workspace_bytes, hipStream_t stream) {
+  if (check_desc(d) || !dy || !dweight || cout < 1 || ld_dy < cout) return SG2IM_ERR_ARG;
+  WgradParams p;
+  fill_geom(p.g, d);
+  p.dY = dy; p.ldy = ld_dy; p.Cout = cout;
+  p.P = d->batch * d->out_h * d->out_w;
+  const int taps = d->kh * d->kw;
+  const int Ntot = taps * p.g.Ctot;
+  if (p.P == 0) {
+    if (!accumulate && hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)cout * Ntot, stream) != hipSuccess) return SG2IM_ERR_HIP;
+    return SG2IM_OK;
+  }
+  p.iters = (p.P + BK - 1) / BK;
+  const bool v4 = geom_vec4(p.g) && (cout % 4 == 0) && (ld_dy % 4 == 0) && !((uintptr_t)dy & 15);
+  // tile: M = cout, N = Ntot
+  int tile;
+  if (cout <= 64) tile = 2;
+  else if (p.g.Ctot <= 64) tile = 1;
+  else tile = 0;
+  if (!v4) tile = 2;
+  const int bm = tile == 2 ? 64 : 128, bn = tile == 0 ? 128 : 64;
+  int ntiles_n;
+  if (v4) { p.ntile_c = (p.g.Ctot + bn - 1) / bn; ntiles_n = taps * p.ntile_c; }
+  else { p.ntile_c = 0; ntiles_n = (Ntot + bn - 1) / bn; }
+  const long long tiles = (long long)ntiles_n * ((cout + bm - 1) / bm);
+  p.e = Epi{dweight, (long long)Ntot, nullptr, 1.f, accumulate, workspace, 1};
+  p.e.nsplit = workspace ? choose_split(tiles, p.iters, (long long)cout * Ntot, workspace_bytes, 8) : 1;
+  hipError_t err;
+  if (v4) {
+    err = tile == 0 ? launch_wgrad<128, 128, 4>(p, ntiles_n, stream)
+        : tile == 1 ? launch_wgrad<128, 64, 4>(p, ntiles_n, stream)
+                    : launch_wgrad<64, 64, 4>(p, ntiles_n, stream);
+  } else {
+    err = launch_wgrad<64, 64, 1>(p, ntiles_n, stream);
+  }
+  if (err != hipSuccess) return SG2IM_ERR_HIP;
+  return finish_split(p.e, cout, Ntot, stream) == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+}
+
+}  // extern "C"

@@ -1,0 +1,206 @@
+// Triple-indexed gather / scatter of GraphTripleConv and the embedding lookups.
+//
+// The reference pools with two torch scatter_add calls (sg2im/graph.py:98-99,106-107).
+// On the CPU that is "for each destination row: add all subject-role rows in increasing
+// triple index, then all object-role rows in increasing triple index, starting from +0"
+// (probe-verified; restated in oracle.gconv_pool_sequential).  The
+// kernels here reproduce exactly that order through a *stable* CSR over destination
+// rows instead of atomics, so the pooled vectors are bit-identical and run-to-run
+// deterministic.  These kernels are HBM/latency bound: rows are read with 16-byte
+// coalesced loads, one workgroup per destination row.
+#include <algorithm>
+#include <hip/hip_runtime.h>
+#include "sg2im_hip.h"
+
+namespace sg2im {
+
+__global__ void csr_count_kernel(const long long* __restrict__ ka, int na, const long long* __restrict__ kb,
+                                 int nb, int* __restrict__ counts) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < na) atomicAdd(&counts[(int)ka[e]], 1);
+  else if (e < na + nb) atomicAdd(&counts[(int)kb[e - na]], 1);
+}
+
+// exclusive scan of counts[0..n) -> row_ptr[0..n], single workgroup, then reset counts to 0
+// so they can serve as fill cursors
+__global__ void csr_scan_kernel(int* __restrict__ counts, int n, int* __restrict__ row_ptr) {
+  __shared__ int warp_sums[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += blockDim.x) {
+    const int i = base + tid;
+    const int v = i < n ? counts[i] : 0;
+    int x = v;
+    #pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int y = __shfl_up(x, off);
+      if (lane >= off) x += y;
+    }
+    if (lane == 63) warp_sums[wave] = x;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += warp_sums[w];
+    const int c = carry;
+    if (i < n) { row_ptr[i] = c + woff + x - v; counts[i] = 0; }
+    __syncthreads();
+    if (tid == blockDim.x - 1) carry = c + woff + x;
+    __syncthreads();
+  }
+  if (tid == 0) row_ptr[n] = carry;
+}
+
+__global__ void csr_fill_kernel(const long long* __restrict__ ka, int na, const long long* __restrict__ kb,
+                                int nb, const int* __restrict__ row_ptr, int* __restrict__ cursor,
+                                int* __restrict__ tmp) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= na + nb) return;
+  const int key = (int)(e < na ? ka[e] : kb[e - na]);
+  const int pos = atomicAdd(&cursor[key], 1);
+  tmp[row_ptr[key] + pos] = e;
+}
+
+// rank sort of every row segment (entry ids are unique): one wavefront per row
+__global__ void csr_ranksort_kernel(const int* __restrict__ row_ptr, const int* __restrict__ tmp,
+                                    int n_rows, int* __restrict__ entries) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n_rows) return;
+  const int b = row_ptr[row], e = row_ptr[row + 1];
+  for (int i = b + lane; i < e; i += 64) {
+    const int v = tmp[i];
+    int rank = 0;
+    for (int j = b; j < e; ++j) rank += tmp[j] < v;
+    entries[b + rank] = v;
+  }
+}
+
+// one workgroup per destination row; threads stride over the row in float4
+__global__ void segment_sum_kernel(const float* __restrict__ src_a, long long ld_a, int n_a,
+                                   const float* __restrict__ src_b, long long ld_b,
+                                   const int* __restrict__ row_ptr, const int* __restrict__ entries,
+                                   int width, int average, float* __restrict__ out, long long ld_out) {
+  const int row = blockIdx.x;
+  const int b = row_ptr[row], e = row_ptr[row + 1];
+  const float cnt = (float)max(1, e - b);
+  const bool v4 = (width % 4 == 0) && (ld_a % 4 == 0) && (ld_b % 4 == 0) && (ld_out % 4 == 0) &&
+                  !(((uintptr_t)src_a | (uintptr_t)src_b | (uintptr_t)out) & 15);
+  if (v4) {
+    for (int c = threadIdx.x * 4; c < width; c += blockDim.x * 4) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = b; i < e; ++i) {
+        const int id = entries[i];
+        const float* p = id < n_a ? src_a + (long long)id * ld_a : src_b + (long long)(id - n_a) * ld_b;
+        const float4 v = *reinterpret_cast<const float4*>(p + c);
+        acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w;
+      }
+      if (average) { acc.x = acc.x / cnt; acc.y = acc.y / cnt; acc.z = acc.z / cnt; acc.w = acc.w / cnt; }
+      *reinterpret_cast<float4*>(out + (long long)row * ld_out + c) = acc;
+    }
+  } else {
+    for (int c = threadIdx.x; c < width; c += blockDim.x) {
+      float acc = 0.f;
+      for (int i = b; i < e; ++i) {
+        const int id = entries[i];
+        acc = acc + (id < n_a ? src_a[(long long)id * ld_a + c] : src_b[(long long)(id - n_a) * ld_b + c]);
+      }
+      if (average) acc = acc / cnt;
+      out[(long long)row * ld_out + c] = acc;
+    }
+  }
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, long long ld_src,
+                                   const long long* __restrict__ idx, int width,
+                                   const int* __restrict__ row_ptr, float* __restrict__ dst,
+                                   long long ld_dst) {
+  const int i = blockIdx.x;
+  const long long r = idx[i];
+  float div = 1.f;
+  if (row_ptr) div = (float)max(1, row_ptr[r + 1] - row_ptr[r]);
+  const float* s = src + r * ld_src;
+  float* d = dst + (long long)i * ld_dst;
+  const bool v4 = (width % 4 == 0) && (ld_src % 4 == 0) && (ld_dst % 4 == 0) &&
+                  !(((uintptr_t)src | (uintptr_t)dst) & 15);
+  if (v4) {
+    for (int c = threadIdx.x * 4; c < width; c += blockDim.x * 4) {
+      float4 v = *reinterpret_cast<const float4*>(s + c);
+      if (row_ptr) { v.x = v.x / div; v.y = v.y / div; v.z = v.z / div; v.w = v.w / div; }
+      *reinterpret_cast<float4*>(d + c) = v;
+    }
+  } else {
+    for (int c = threadIdx.x; c < width; c += blockDim.x) d[c] = row_ptr ? s[c] / div : s[c];
+  }
+}
+
+__global__ void copy_2d_kernel(const float* __restrict__ src, long long ld_src, float* __restrict__ dst,
+                               long long ld_dst, long long rows, int width) {
+  const long long total = rows * width;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / width; const int c = (int)(i - r * width);
+    dst[r * ld_dst + c] = src[r * ld_src + c];
+  }
+}
+
+}  // namespace sg2im
+
+using namespace sg2im;
+
+extern "C" {
+
+int sg2im_abi_version(void) { return 1; }
+
+int sg2im_csr_build(const long long* keys_a, int n_a, const long long* keys_b, int n_b, int n_rows,
+                    int* row_ptr, int* entries, int* scratch, hipStream_t stream) {
+  if (n_a < 0 || n_b < 0 || n_rows < 1 || !row_ptr || !scratch || (n_a && !keys_a) || (n_b && !keys_b))
+    return SG2IM_ERR_ARG;
+  const int n = n_a + n_b;
+  int* counts = scratch;            // [n_rows]
+  int* tmp = scratch + n_rows;      // [n]
+  if (hipMemsetAsync(counts, 0, sizeof(int) * n_rows, stream) != hipSuccess) return SG2IM_ERR_HIP;
+  if (n > 0) {
+    if (!entries) return SG2IM_ERR_ARG;
+    hipLaunchKernelGGL(csr_count_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, keys_a, n_a, keys_b, n_b, counts);
+  }
+  hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, n_rows, row_ptr);
+  if (n > 0) {
+    hipLaunchKernelGGL(csr_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, keys_a, n_a, keys_b, n_b,
+                       row_ptr, counts, tmp);
+    hipLaunchKernelGGL(csr_ranksort_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream, row_ptr, tmp, n_rows, entries);
+  }
+  return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+}
+
+int sg2im_segment_sum(const float* src_a, long long ld_a, int n_a, const float* src_b, long long ld_b,
+                      const int* row_ptr, const int* entries, int n_rows, int width, int average,
+                      float* out, long long ld_out, hipStream_t stream) {
+  if (n_rows < 0 || width < 1 || !row_ptr || !out || !src_a) return SG2IM_ERR_ARG;
+  if (n_rows == 0) return SG2IM_OK;
+  if (!src_b) { src_b = src_a; ld_b = ld_a; }
+  const int threads = std::min(256, std::max(64, ((width + 3) / 4 + 63) / 64 * 64));
+  hipLaunchKernelGGL(segment_sum_kernel, dim3(n_rows), dim3(threads), 0, stream, src_a, ld_a, n_a, src_b, ld_b,
+                     row_ptr, entries, width, average, out, ld_out);
+  return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+}
+
+int sg2im_copy_2d(const float* src, long long ld_src, float* dst, long long ld_dst, long long rows,
+                  int width, hipStream_t stream) {
+  if (!src || !dst || width < 1 || rows < 0) return SG2IM_ERR_ARG;
+  if (rows == 0) return SG2IM_OK;
+  const int blocks = (int)std::min<long long>((rows * width + 255) / 256, 4096);
+  hipLaunchKernelGGL(copy_2d_kernel, dim3(blocks), dim3(256), 0, stream, src, ld_src, dst, ld_dst, rows, width);
+  return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+}
+
+int sg2im_gather_rows(const float* src, long long ld_src, const long long* idx, int n, int width,
+                      const int* row_ptr, float* dst, long long ld_dst, hipStream_t stream) {
+  if (n < 0 || width < 1 || !src || !idx || !dst) return SG2IM_ERR_ARG;
+  if (n == 0) return SG2IM_OK;
+  const int threads = std::min(256, std::max(64, ((width + 3) / 4 + 63) / 64 * 64));
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(n), dim3(threads), 0, stream, src, ld_src, idx, width, row_ptr, dst, ld_dst);
+  return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+}
+
+}  // extern "C"

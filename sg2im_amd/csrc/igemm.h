@@ -1,0 +1,211 @@
+// Implicit-GEMM engine on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// One 256-thread workgroup (4 wavefronts of 64, arranged 2x2) owns a BM x BN output
+// tile.  The reduction runs in chunks of BK = 32; operand tiles are staged through
+// LDS (double buffered, register prefetch of the next chunk while the current one is
+// on the matrix pipe).  Two LDS images exist per operand:
+//   * "m-major"  [rows][BK+4]  - the reduction index is contiguous in global memory
+//                                (activations NHWC along channels, weight rows);
+//                                fragments are fetched with ds_read_b128.
+//   * "k-major"  [BK][rows+4]  - the reduction index is the global row (weight-gradient
+//                                and data-gradient operands); fragments via ds_read_b32.
+// The fp32 MFMA consumes one A and one B scalar per lane per K=2 step:
+//   lane l: A[i = l&31][k = l>>5],  B[k = l>>5][j = l&31]   (cdna_hip_programming.md section 3)
+// Inside a BK chunk the k order is permuted (kperm) so an m-major lane reads four
+// consecutive k with one 16-byte LDS read; both operands use the same permutation,
+// which only reorders the (commutative up to rounding) fp32 accumulation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sg2im {
+
+constexpr int BK = 32;
+constexpr int MLD = BK + 4;          // m-major LDS row stride (floats); 144 B keeps 16-B alignment
+constexpr int KPAD = 4;              // k-major LDS row pad (floats)
+constexpr int NTHREADS = 256;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// One input "source": a dense NHWC tensor (or a row matrix when H=W=1) that supplies
+// C consecutive channels of a virtual channel-concatenated operand.
+struct Src {
+  const float* p;          // base pointer
+  const long long* gidx;   // optional row gather (row-matrix geometry only)
+  const float* scale;      // optional fused per-channel affine + leaky (pending BN/act)
+  const float* shift;
+  float slope;             // leaky slope applied after the affine (1.0f = identity)
+  int C;                   // channels supplied by this source
+  int ld;                  // floats between consecutive pixels / rows
+  int up;                  // log2 of nearest-neighbour upsampling (0 or 1)
+};
+
+struct ConvGeom {
+  Src s0, s1, s2, s3;      // unused sources have C == 0 (named members: a dynamically indexed
+                           // array inside a by-value kernel argument is demoted to scratch)
+  int nsrc;
+  int Ctot;                // sum of src[i].C  (inner size of a weight row per tap)
+  int NB, H, W;            // batch and *logical* input size (after upsampling)
+  int Ho, Wo;              // output size
+  int KH, KW, stride, pad;
+};
+
+struct Epi {
+  float* C;                // destination
+  long long ldc;           // floats between destination rows
+  const float* bias;       // per-column bias or nullptr
+  float slope;             // leaky slope of the fused output activation (1 = none, 0 = ReLU)
+  int accumulate;          // 1: C += result
+  float* ws;               // split-K partials [nsplit][M][N]; used when nsplit > 1
+  int nsplit;
+};
+
+__device__ __forceinline__ int kperm(int s, int h) { return 8 * (s >> 2) + 4 * h + (s & 3); }
+
+// field-by-field select: a whole-struct conditional copy out of the kernarg segment is
+// lowered to memcpy into scratch
+// (by-value sel4: a ternary over lvalues selects the *address* and again indexes scratch)
+template <typename T> __device__ __forceinline__ T sel4(int s, T a, T b, T c, T d) {
+  return s == 0 ? a : s == 1 ? b : s == 2 ? c : d;
+}
+#define SG2IM_PICK(f) sel4(s, g.s0.f, g.s1.f, g.s2.f, g.s3.f)
+__device__ __forceinline__ Src pick_src(const ConvGeom& g, int s) {
+  Src S;
+  S.p = SG2IM_PICK(p); S.gidx = SG2IM_PICK(gidx); S.scale = SG2IM_PICK(scale); S.shift = SG2IM_PICK(shift);
+  S.slope = SG2IM_PICK(slope); S.C = SG2IM_PICK(C); S.ld = SG2IM_PICK(ld); S.up = SG2IM_PICK(up);
+  return S;
+}
+#undef SG2IM_PICK
+
+__device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// channel c of the virtual concat -> (source index, channel within the source)
+__device__ __forceinline__ void locate_channel(const ConvGeom& g, int c, int& s, int& cs) {
+  const int e0 = g.s0.C, e1 = e0 + g.s1.C, e2 = e1 + g.s2.C;
+  if (c < e0) { s = 0; cs = c; }
+  else if (c < e1) { s = 1; cs = c - e0; }
+  else if (c < e2) { s = 2; cs = c - e1; }
+  else { s = 3; cs = c - e2; }
+}
+
+// ---------------------------------------------------------------------------
+// LDS image sizes
+// ---------------------------------------------------------------------------
+template <int ROWS, bool KMAJOR> struct LdsTile {
+  static constexpr int FLOATS = KMAJOR ? BK * (ROWS + KPAD) : ROWS * MLD;
+};
+
+// registers -> LDS.  Thread mapping (both images): NV = ROWS/32 float4 per thread.
+//   m-major: col4 = tid & 7,            row = (tid >> 3) + 32 * i
+//   k-major: col4 = tid % (ROWS/4),     krow = tid / (ROWS/4) + (1024/ROWS) * i
+template <int ROWS, bool KMAJOR>
+__device__ __forceinline__ void store_tile(float* lds, const float4 (&r)[ROWS / 32], int tid) {
+  constexpr int NV = ROWS / 32;
+  if (!KMAJOR) {
+    const int col4 = tid & 7, r0 = tid >> 3;
+    #pragma unroll
+    for (int i = 0; i < NV; ++i)
+      *reinterpret_cast<float4*>(lds + (r0 + 32 * i) * MLD + 4 * col4) = r[i];
+  } else {
+    constexpr int Q = ROWS / 4;
+    const int col4 = tid % Q, k0 = tid / Q;
+    #pragma unroll
+    for (int i = 0; i < NV; ++i)
+      *reinterpret_cast<float4*>(lds + (k0 + (1024 / ROWS) * i) * (ROWS + KPAD) + 4 * col4) = r[i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// one BK chunk of MFMAs for a wave owning TM x TN 32x32 tiles
+// ---------------------------------------------------------------------------
+template <int BM, int BN, bool AK, bool BKM>
+__device__ __forceinline__ void mma_chunk(const float* __restrict__ As, const float* __restrict__ Bs,
+                                          int wm0, int wn0, int lane,
+                                          f32x16 (&acc)[BM / 64][BN / 64]) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  const int i = lane & 31, h = lane >> 5;
+  float a[TM][16], b[TN][16];
+  #pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    if (!AK) {
+      const float* row = As + (wm0 + tm * 32 + i) * MLD + 4 * h;
+      #pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(row + 8 * g);
+        a[tm][4 * g + 0] = v.x; a[tm][4 * g + 1] = v.y; a[tm][4 * g + 2] = v.z; a[tm][4 * g + 3] = v.w;
+      }
+    } else {
+      #pragma unroll
+      for (int s = 0; s < 16; ++s) a[tm][s] = As[kperm(s, h) * (BM + KPAD) + wm0 + tm * 32 + i];
+    }
+  }
+  #pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    if (!BKM) {
+      const float* row = Bs + (wn0 + tn * 32 + i) * MLD + 4 * h;
+      #pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(row + 8 * g);
+        b[tn][4 * g + 0] = v.x; b[tn][4 * g + 1] = v.y; b[tn][4 * g + 2] = v.z; b[tn][4 * g + 3] = v.w;
+      }
+    } else {
+      #pragma unroll
+      for (int s = 0; s < 16; ++s) b[tn][s] = Bs[kperm(s, h) * (BN + KPAD) + wn0 + tn * 32 + i];
+    }
+  }
+  #pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    #pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      #pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// epilogue: C/D layout of the 32x32 MFMA: col = lane & 31,
+// row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+// ---------------------------------------------------------------------------
+template <int BM, int BN>
+__device__ __forceinline__ void epilogue(const Epi& e, int M, int N, int nlimit, int m0, int n0, int wm0,
+                                         int wn0, int lane, int split,
+                                         const f32x16 (&acc)[BM / 64][BN / 64]) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  const int j = lane & 31, h = lane >> 5;
+  #pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n0 + wn0 + tn * 32 + j;
+    if (n >= nlimit) continue;
+    const float bv = (e.nsplit == 1 && e.bias) ? e.bias[n] : 0.f;
+    #pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      #pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= M) continue;
+        float v = acc[tm][tn][r];
+        if (e.nsplit > 1) {
+          e.ws[((long long)split * M + m) * N + n] = v;
+        } else {
+          v = leaky(v + bv, e.slope);
+          float* dst = e.C + (long long)m * e.ldc + n;
+          if (e.accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
+// wave placement inside the block tile: 2 x 2 wavefronts
+template <int BM, int BN>
+__device__ __forceinline__ void wave_origin(int tid, int& wm0, int& wn0, int& lane) {
+  const int wave = tid >> 6;
+  lane = tid & 63;
+  wm0 = (wave >> 1) * (BM / 2);
+  wn0 = (wave & 1) * (BN / 2);
+}
+
+}  // namespace sg2im

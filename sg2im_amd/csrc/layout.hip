@@ -1,0 +1,423 @@
+// Scene layout (reference sg2im/layout.py) and object crops (reference sg2im/bilinear.py).
+//
+// The reference materialises, per object, img_in (O,D,M,M), a sampling grid (O,H,W,2) and
+// the sampled tensor (O,D,H,W) - 426 MB at the COCO-64 batch - before a scatter_add into
+// the 67 MB layout (layout.py:87-88,146-148).  Because the sampled value factorises,
+//   sampled[o,d,y,x] = vecs[o,d] * S_o(y,x),   S_o = bilinear_zero_pad(mask_o)(grid_o(y,x)),
+// the kernels below compute S_o on the fly in LDS and write the layout exactly once
+// (HBM-bound: algorithmic bytes = N*H*W*D*4 written + O*(D+4+M*M)*4 read).  The
+// factorised form differs from the reference's (v*m)*w rounding by ~1 ulp (SURVEY.md
+// section 8a row 6: 4.8e-7 abs), so the layout is checked with a tolerance; the
+// per-image accumulation order (objects in index order) is the reference's.
+#include <algorithm>
+#include <hip/hip_runtime.h>
+#include "sg2im_hip.h"
+
+namespace sg2im {
+
+// torch.linspace(0, 1, steps)[i] as computed by ATen on the CPU (symmetric halves)
+__device__ __forceinline__ float lin01(int i, int steps) {
+  if (steps == 1) return 0.f;
+  const float step = 1.f / (float)(steps - 1);
+  return i < steps / 2 ? (float)i * step : 1.f - (float)(steps - 1 - i) * step;
+}
+
+__device__ __forceinline__ float unnormalize(float g, int size, int align_corners) {
+  // ATen grid_sampler_unnormalize
+  return align_corners ? (g + 1.f) * 0.5f * (float)(size - 1) : ((g + 1.f) * (float)size - 1.f) * 0.5f;
+}
+
+struct MaskRef { const float* f; const long long* i64; int M; };   // M == 0: all-ones 8x8 map
+
+__device__ __forceinline__ float mask_at(const MaskRef& m, int o, int y, int x) {
+  if (m.M == 0) return 1.f;
+  const long long idx = ((long long)o * m.M + y) * m.M + x;
+  return m.i64 ? (float)m.i64[idx] : m.f[idx];
+}
+
+// bilinear footprint of one output pixel in the object's M x M map
+struct Foot { int x0, y0; float wx0, wx1, wy0, wy1; };   // weights already zeroed when out of bounds
+
+__device__ __forceinline__ Foot footprint(const float* box, int y, int x, int H, int W, int Min,
+                                          int align_corners) {
+  // layout.py:94-128: X = (linspace(0,1,W) - x0) / (x1 - x0); grid = 2*X - 1
+  const float bx0 = box[0], by0 = box[1], bx1 = box[2], by1 = box[3];
+  const float gx = ((lin01(x, W) - bx0) / (bx1 - bx0)) * 2.f - 1.f;
+  const float gy = ((lin01(y, H) - by0) / (by1 - by0)) * 2.f - 1.f;
+  const float ix = unnormalize(gx, Min, align_corners), iy = unnormalize(gy, Min, align_corners);
+  const float fx = floorf(ix), fy = floorf(iy);
+  Foot f;
+  // clamp the float before the int conversion: degenerate boxes give inf/NaN grids in the
+  // reference; here such pixels simply fall outside the map
+  f.x0 = (int)fminf(fmaxf(fx, -2.f), (float)Min + 1.f);
+  f.y0 = (int)fminf(fmaxf(fy, -2.f), (float)Min + 1.f);
+  const float tx = ix - fx, ty = iy - fy;
+  f.wx0 = (f.x0 >= 0 && f.x0 < Min) ? 1.f - tx : 0.f;
+  f.wx1 = (f.x0 + 1 >= 0 && f.x0 + 1 < Min) ? tx : 0.f;
+  f.wy0 = (f.y0 >= 0 && f.y0 < Min) ? 1.f - ty : 0.f;
+  f.wy1 = (f.y0 + 1 >= 0 && f.y0 + 1 < Min) ? ty : 0.f;
+  if (!(ix == ix) || !(iy == iy) || fabsf(ix) > 1e8f || fabsf(iy) > 1e8f) { f.wx0 = f.wx1 = f.wy0 = f.wy1 = 0.f; f.x0 = f.y0 = -2; }
+  return f;
+}
+
+__device__ __forceinline__ float sample_map(const MaskRef& m, int o, const Foot& f) {
+  float s = 0.f;
+  if (f.wy0 != 0.f) {
+    if (f.wx0 != 0.f) s += mask_at(m, o, f.y0, f.x0) * (f.wx0 * f.wy0);
+    if (f.wx1 != 0.f) s += mask_at(m, o, f.y0, f.x0 + 1) * (f.wx1 * f.wy0);
+  }
+  if (f.wy1 != 0.f) {
+    if (f.wx0 != 0.f) s += mask_at(m, o, f.y0 + 1, f.x0) * (f.wx0 * f.wy1);
+    if (f.wx1 != 0.f) s += mask_at(m, o, f.y0 + 1, f.x0 + 1) * (f.wx1 * f.wy1);
+  }
+  return s;
+}
+
+constexpr int LP = 32;       // pixels per workgroup
+constexpr int LO = 32;       // objects per LDS pass
+
+// grid: (ceil(H*W / LP), n_images); 256 threads = 32 pixels x 8 channel lanes
+__global__ __launch_bounds__(256) void layout_fwd_kernel(const float* __restrict__ vecs, long long ld_vecs,
+                                                         const float* __restrict__ boxes, MaskRef mk,
+                                                         const int* __restrict__ img_row_ptr,
+                                                         const int* __restrict__ img_entries, int D, int H,
+                                                         int W, int align_corners, float* __restrict__ out,
+                                                         long long ld_out) {
+  __shared__ float S[LO][LP + 1];
+  __shared__ int objs[LO];
+  const int n = blockIdx.y, p0 = blockIdx.x * LP, HW = H * W;
+  const int tid = threadIdx.x;
+  const int p = tid >> 3, cl = tid & 7;
+  const int ob = img_row_ptr[n], oe = img_row_ptr[n + 1];
+  const int Min = mk.M == 0 ? 8 : mk.M;
+  const bool v4 = (D % 4 == 0) && (ld_vecs % 4 == 0) && (ld_out % 4 == 0) && !(((uintptr_t)vecs | (uintptr_t)out) & 15);
+  const int pix = p0 + p;
+  float* orow = out + ((long long)n * HW + pix) * ld_out;
+  const int nq = v4 ? D / 4 : D;              // work items per pixel (quads or scalars)
+  for (int q0 = 0; q0 < nq; q0 += 8 * 4) {    // 4 register accumulators per thread per pass
+    float4 acc[4];
+    #pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int cb = ob; cb < oe; cb += LO) {
+      const int nobj = min(LO, oe - cb);
+      __syncthreads();
+      if (tid < nobj) objs[tid] = img_entries[cb + tid];
+      __syncthreads();
+      for (int e = tid; e < nobj * LP; e += 256) {
+        const int oi = e / LP, pp = e - oi * LP;
+        const int px = p0 + pp;
+        float s = 0.f;
+        if (px < HW) {
+          const int o = objs[oi];
+          const Foot f = footprint(boxes + 4LL * o, px / W, px % W, H, W, Min, align_corners);
+          s = sample_map(mk, o, f);
+        }
+        S[oi][pp] = s;
+      }
+      __syncthreads();
+      if (pix < HW) {
+        for (int oi = 0; oi < nobj; ++oi) {
+          const float s = S[oi][p];
+          const float* vrow = vecs + (long long)objs[oi] * ld_vecs;
+          #pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int q = q0 + cl + 8 * k;
+            if (q < nq) {
+              if (v4) {
+                const float4 v = *reinterpret_cast<const float4*>(vrow + 4 * q);
+                acc[k].x += v.x * s; acc[k].y += v.y * s; acc[k].z += v.z * s; acc[k].w += v.w * s;
+              } else {
+                acc[k].x += vrow[q] * s;
+              }
+            }
+          }
+        }
+      }
+    }
+    if (pix < HW) {
+      #pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int q = q0 + cl + 8 * k;
+        if (q < nq) {
+          if (v4) *reinterpret_cast<float4*>(orow + 4 * q) = acc[k];
+          else orow[q] = acc[k].x;
+        }
+      }
+    }
+  }
+}
+
+// ---- backward w.r.t. vecs: partial[tile][o_local][d] then reduce --------------------
+constexpr int BP = 64;      // pixels per workgroup
+constexpr int BO = 8;       // objects per register pass
+
+// grid: (ceil(HW/BP), n_images).  part: [n_tiles][O][D]
+__global__ __launch_bounds__(256) void layout_bwd_vecs_kernel(const float* __restrict__ dl, long long ld_dl,
+                                                              const float* __restrict__ boxes, MaskRef mk,
+                                                              const int* __restrict__ img_row_ptr,
+                                                              const int* __restrict__ img_entries, int O, int D,
+                                                              int H, int W, int align_corners,
+                                                              float* __restrict__ part) {
+  __shared__ float S[BO][BP + 1];
+  __shared__ int objs[BO];
+  extern __shared__ float red[];          // [BO][TR][D] reduction scratch
+  const int n = blockIdx.y, p0 = blockIdx.x * BP, HW = H * W;
+  const int tid = threadIdx.x;
+  const int ob = img_row_ptr[n], oe = img_row_ptr[n + 1];
+  const int Min = mk.M == 0 ? 8 : mk.M;
+  // thread -> (channel c, pixel group pg): TC channel lanes
+  const int TC = D < 256 ? D : 256, TR = 256 / TC;
+  const int tx = tid % TC, pg = tid / TC;
+  for (int cb = ob; cb < oe; cb += BO) {
+    const int nobj = min(BO, oe - cb);
+    __syncthreads();
+    if (tid < nobj) objs[tid] = img_entries[cb + tid];
+    __syncthreads();
+    for (int e = tid; e < nobj * BP; e += 256) {
+      const int oi = e / BP, pp = e - oi * BP;
+      const int px = p0 + pp;
+      float s = 0.f;
+      if (px < HW) {
+        const int o = objs[oi];
+        const Foot f = footprint(boxes + 4LL * o, px / W, px % W, H, W, Min, align_corners);
+        s = sample_map(mk, o, f);
+      }
+      S[oi][pp] = s;
+    }
+    __syncthreads();
+    for (int c = tx; c < D; c += TC) {
+      float acc[BO];
+      #pragma unroll
+      for (int k = 0; k < BO; ++k) acc[k] = 0.f;
+      if (pg < TR) {
+        for (int pp = pg; pp < BP; pp += TR) {
+          const int px = p0 + pp;
+          if (px >= HW) break;
+          const float g = dl[((long long)n * HW + px) * ld_dl + c];
+          #pragma unroll
+          for (int k = 0; k < BO; ++k) acc[k] = fmaf(g, S[k][pp], acc[k]);
+        }
+      }
+      if (TR > 1) {
+        #pragma unroll
+        for (int k = 0; k < BO; ++k) red[(k * TR + pg) * TC + tx] = acc[k];
+        __syncthreads();
+        if (pg == 0) {
+          #pragma unroll
+          for (int k = 0; k < BO; ++k) {
+            float s = acc[k];
+            for (int t = 1; t < TR; ++t) s += red[(k * TR + t) * TC + tx];
+            acc[k] = s;
+          }
+        }
+        __syncthreads();
+      }
+      if (pg == 0) {
+        #pragma unroll
+        for (int k = 0; k < BO; ++k)
+          if (k < nobj) part[((long long)blockIdx.x * O + objs[k]) * D + c] = acc[k];
+      }
+    }
+  }
+}
+
+__global__ void layout_bwd_reduce_kernel(const float* __restrict__ part, int n_tiles, int O, int D,
+                                         float* __restrict__ dvecs, long long ld_dvecs) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)O * D) return;
+  float s = 0.f;
+  for (int t = 0; t < n_tiles; ++t) s += part[(long long)t * O * D + i];
+  dvecs[(i / D) * ld_dvecs + (i % D)] = s;
+}
+
+// ---- backward w.r.t. (soft) masks: one workgroup per object ---------------------------
+__global__ __launch_bounds__(256) void layout_bwd_masks_kernel(const float* __restrict__ dl, long long ld_dl,
+                                                               const float* __restrict__ vecs, long long ld_vecs,
+                                                               const float* __restrict__ boxes, int M,
+                                                               const long long* __restrict__ obj_to_img, int D,
+                                                               int H, int W, int align_corners,
+                                                               float* __restrict__ dmasks) {
+  extern __shared__ float sm[];            // [D] vec + [M*M] grad
+  float* v = sm;
+  float* gm = sm + D;
+  const int o = blockIdx.x, tid = threadIdx.x, HW = H * W;
+  const long long n = obj_to_img[o];
+  for (int i = tid; i < D; i += 256) v[i] = vecs[(long long)o * ld_vecs + i];
+  for (int i = tid; i < M * M; i += 256) gm[i] = 0.f;
+  __syncthreads();
+  for (int px = tid; px < HW; px += 256) {
+    const Foot f = footprint(boxes + 4LL * o, px / W, px % W, H, W, M, align_corners);
+    if ((f.wx0 == 0.f && f.wx1 == 0.f) || (f.wy0 == 0.f && f.wy1 == 0.f)) continue;
+    const float* g = dl + (n * HW + px) * ld_dl;
+    float ds = 0.f;
+    for (int d = 0; d < D; ++d) ds = fmaf(g[d], v[d], ds);
+    if (f.wy0 != 0.f) {
+      if (f.wx0 != 0.f) atomicAdd(&gm[f.y0 * M + f.x0], ds * (f.wx0 * f.wy0));
+      if (f.wx1 != 0.f) atomicAdd(&gm[f.y0 * M + f.x0 + 1], ds * (f.wx1 * f.wy0));
+    }
+    if (f.wy1 != 0.f) {
+      if (f.wx0 != 0.f) atomicAdd(&gm[(f.y0 + 1) * M + f.x0], ds * (f.wx0 * f.wy1));
+      if (f.wx1 != 0.f) atomicAdd(&gm[(f.y0 + 1) * M + f.x0 + 1], ds * (f.wx1 * f.wy1));
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < M * M; i += 256) dmasks[(long long)o * M * M + i] = gm[i];
+}
+
+// ---- crops ---------------------------------------------------------------------------
+struct CropFoot { int x0, y0; float w00, w01, w10, w11; };
+
+__device__ __forceinline__ CropFoot crop_foot(const float* box, int i, int j, int size, int H, int W,
+                                              int align_corners) {
+  // bilinear.py:123-130: bbox = 2*bbox-1; X = tensor_linspace(x0, x1, WW)
+  const float x0 = 2.f * box[0] - 1.f, y0 = 2.f * box[1] - 1.f;
+  const float x1 = 2.f * box[2] - 1.f, y1 = 2.f * box[3] - 1.f;
+  const float wj = lin01(j, size), wi = lin01(i, size);
+  // tensor_linspace: start * linspace(1,0) + end * linspace(0,1)  (bilinear.py:265-277)
+  const float gx = (1.f - wj) * x0 + wj * x1;
+  const float gy = (1.f - wi) * y0 + wi * y1;
+  const float ix = unnormalize(gx, W, align_corners), iy = unnormalize(gy, H, align_corners);
+  const float fx = floorf(ix), fy = floorf(iy);
+  CropFoot f;
+  f.x0 = (int)fminf(fmaxf(fx, -2.f), (float)W + 1.f);
+  f.y0 = (int)fminf(fmaxf(fy, -2.f), (float)H + 1.f);
+  const float tx = ix - fx, ty = iy - fy;
+  const bool xa = f.x0 >= 0 && f.x0 < W, xb = f.x0 + 1 >= 0 && f.x0 + 1 < W;
+  const bool ya = f.y0 >= 0 && f.y0 < H, yb = f.y0 + 1 >= 0 && f.y0 + 1 < H;
+  f.w00 = (xa && ya) ? (1.f - tx) * (1.f - ty) : 0.f;
+  f.w01 = (xb && ya) ? tx * (1.f - ty) : 0.f;
+  f.w10 = (xa && yb) ? (1.f - tx) * ty : 0.f;
+  f.w11 = (xb && yb) ? tx * ty : 0.f;
+  if (!(ix == ix) || !(iy == iy)) { f.w00 = f.w01 = f.w10 = f.w11 = 0.f; f.x0 = f.y0 = -2; }
+  return f;
+}
+
+__global__ void crop_fwd_kernel(const float* __restrict__ imgs, long long ld_img, int H, int W, int C,
+                                const float* __restrict__ boxes, const long long* __restrict__ obj_to_img,
+                                int O, int size, int align_corners, float* __restrict__ crops) {
+  const long long total = (long long)O * size * size;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(t % size); const int i = (int)((t / size) % size); const int o = (int)(t / ((long long)size * size));
+    const CropFoot f = crop_foot(boxes + 4LL * o, i, j, size, H, W, align_corners);
+    const float* img = imgs + obj_to_img[o] * H * W * ld_img;
+    for (int c = 0; c < C; ++c) {
+      float s = 0.f;
+      if (f.w00 != 0.f) s += img[((long long)f.y0 * W + f.x0) * ld_img + c] * f.w00;
+      if (f.w01 != 0.f) s += img[((long long)f.y0 * W + f.x0 + 1) * ld_img + c] * f.w01;
+      if (f.w10 != 0.f) s += img[((long long)(f.y0 + 1) * W + f.x0) * ld_img + c] * f.w10;
+      if (f.w11 != 0.f) s += img[((long long)(f.y0 + 1) * W + f.x0 + 1) * ld_img + c] * f.w11;
+      crops[t * C + c] = s;
+    }
+  }
+}
+
+__global__ void crop_bwd_kernel(const float* __restrict__ dcrops, int H, int W, int C,
+                                const float* __restrict__ boxes, const long long* __restrict__ obj_to_img,
+                                int O, int size, int align_corners, float* __restrict__ dimgs, long long ld) {
+  const long long total = (long long)O * size * size;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(t % size); const int i = (int)((t / size) % size); const int o = (int)(t / ((long long)size * size));
+    const CropFoot f = crop_foot(boxes + 4LL * o, i, j, size, H, W, align_corners);
+    float* img = dimgs + obj_to_img[o] * H * W * ld;
+    for (int c = 0; c < C; ++c) {
+      const float g = dcrops[t * C + c];
+      if (f.w00 != 0.f) atomicAdd(&img[((long long)f.y0 * W + f.x0) * ld + c], g * f.w00);
+      if (f.w01 != 0.f) atomicAdd(&img[((long long)f.y0 * W + f.x0 + 1) * ld + c], g * f.w01);
+      if (f.w10 != 0.f) atomicAdd(&img[((long long)(f.y0 + 1) * W + f.x0) * ld + c], g * f.w10);
+      if (f.w11 != 0.f) atomicAdd(&img[((long long)(f.y0 + 1) * W + f.x0 + 1) * ld + c], g * f.w11);
+    }
+  }
+}
+
+static inline int ok_or(hipError_t e) { return e == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP; }
+
+}  // namespace sg2im
+
+using namespace sg2im;
+
+extern "C" {
+
+int sg2im_layout_forward(const float* vecs, long long ld_vecs, const float* boxes,
+                         const float* masks, const long long* masks_i64, int mask_size,
+                         const int* img_row_ptr, const int* img_entries, int n_images, int n_objs,
+                         int dim, int height, int width, int align_corners, float* layout,
+                         long long ld_layout, hipStream_t stream) {
+  if (!vecs || !boxes || !img_row_ptr || !layout || dim < 1 || height < 1 || width < 1 || n_images < 0)
+    return SG2IM_ERR_ARG;
+  if ((masks || masks_i64) && mask_size < 1) return SG2IM_ERR_ARG;
+  if (n_images == 0) return SG2IM_OK;
+  (void)n_objs;
+  const MaskRef mk{masks, masks_i64, (masks || masks_i64) ? mask_size : 0};
+  dim3 grid((height * width + LP - 1) / LP, n_images);
+  hipLaunchKernelGGL(layout_fwd_kernel, grid, dim3(256), 0, stream, vecs, ld_vecs, boxes, mk, img_row_ptr, img_entries,
+                     dim, height, width, align_corners, layout, ld_layout);
+  return ok_or(hipGetLastError());
+}
+
+size_t sg2im_layout_backward_workspace(int n_objs, int dim, int height, int width) {
+  return sizeof(float) * (size_t)((height * width + BP - 1) / BP) * (size_t)n_objs * (size_t)dim;
+}
+
+int sg2im_layout_backward(const float* dlayout, long long ld_dlayout, const float* vecs,
+                          long long ld_vecs, const float* boxes, const float* masks,
+                          const long long* masks_i64, int mask_size, const long long* obj_to_img,
+                          const int* img_row_ptr, const int* img_entries, int n_images,
+                          int n_objs, int dim, int height, int width, int align_corners,
+                          float* d_vecs, long long ld_dvecs, float* d_masks, float* workspace,
+                          hipStream_t stream) {
+  if (!dlayout || !boxes || !img_row_ptr || dim < 1 || height < 1 || width < 1) return SG2IM_ERR_ARG;
+  if (n_objs == 0) return SG2IM_OK;
+  const MaskRef mk{masks, masks_i64, (masks || masks_i64) ? mask_size : 0};
+  if (d_vecs) {
+    if (!workspace) return SG2IM_ERR_ARG;
+    const int n_tiles = (height * width + BP - 1) / BP;
+    // objects that belong to no image (cannot happen with a valid obj_to_img) keep zero grads
+    if (hipMemsetAsync(workspace, 0, sg2im_layout_backward_workspace(n_objs, dim, height, width), stream) != hipSuccess)
+      return SG2IM_ERR_HIP;
+    const int TC = dim < 256 ? dim : 256, TR = 256 / TC;
+    const size_t lds = sizeof(float) * (size_t)BO * TR * TC;
+    dim3 grid(n_tiles, n_images);
+    hipLaunchKernelGGL(layout_bwd_vecs_kernel, grid, dim3(256), lds, stream, dlayout, ld_dlayout, boxes, mk,
+                       img_row_ptr, img_entries, n_objs, dim, height, width, align_corners, workspace);
+    const long long tot = (long long)n_objs * dim;
+    hipLaunchKernelGGL(layout_bwd_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, workspace,
+                       n_tiles, n_objs, dim, d_vecs, ld_dvecs);
+  }
+  if (d_masks) {
+    if (!masks || !vecs || !obj_to_img || mask_size < 1) return SG2IM_ERR_ARG;
+    const size_t lds = sizeof(float) * (size_t)(dim + mask_size * mask_size);
+    hipLaunchKernelGGL(layout_bwd_masks_kernel, dim3(n_objs), dim3(256), lds, stream, dlayout, ld_dlayout, vecs,
+                       ld_vecs, boxes, mask_size, obj_to_img, dim, height, width, align_corners, d_masks);
+  }
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_crop_forward(const float* imgs, long long ld_img, int n_images, int height, int width,
+                       int channels, const float* boxes, const long long* obj_to_img, int n_objs,
+                       int size, int align_corners, float* crops, hipStream_t stream) {
+  if (!imgs || !boxes || !obj_to_img || !crops || size < 1 || channels < 1) return SG2IM_ERR_ARG;
+  (void)n_images;
+  const long long total = (long long)n_objs * size * size;
+  if (total == 0) return SG2IM_OK;
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(crop_fwd_kernel, dim3(blocks), dim3(256), 0, stream, imgs, ld_img, height, width, channels, boxes,
+                     obj_to_img, n_objs, size, align_corners, crops);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_crop_backward(const float* d_crops, int n_images, int height, int width, int channels,
+                        const float* boxes, const long long* obj_to_img, int n_objs, int size,
+                        int align_corners, float* d_imgs, long long ld_dimg, hipStream_t stream) {
+  if (!d_crops || !boxes || !obj_to_img || !d_imgs || size < 1 || channels < 1) return SG2IM_ERR_ARG;
+  (void)n_images;
+  const long long total = (long long)n_objs * size * size;
+  if (total == 0) return SG2IM_OK;
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(crop_bwd_kernel, dim3(blocks), dim3(256), 0, stream, d_crops, height, width, channels, boxes,
+                     obj_to_img, n_objs, size, align_corners, d_imgs, ld_dimg);
+  return ok_or(hipGetLastError());
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+// Loss kernels (reference sg2im/losses.py, scripts/train.py:387-412) and the fused Adam
+// update (torch.optim.Adam defaults, scripts/train.py:426-443).  Every loss kernel
+// produces the scalar loss AND d(loss)/d(input) in one pass over the input (HBM-bound,
+// one read + one write); the scalar is reduced deterministically: per-workgroup partials
+// in a fixed slot, summed in double by a single-thread epilogue kernel.
+#include <algorithm>
+#include <cmath>
+#include <hip/hip_runtime.h>
+#include "sg2im_hip.h"
+
+namespace sg2im {
+
+constexpr int LOSS_BLOCKS = 256;
+
+__device__ __forceinline__ float block_sum(float v) {
+  __shared__ float ws[4];
+  #pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) ws[wave] = v;
+  __syncthreads();
+  float s = 0.f;
+  if (threadIdx.x == 0) for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += ws[w];
+  return s;    // valid on thread 0
+}
+
+enum { L_L1 = 0, L_MSE = 1, L_BCE = 2 };
+
+template <int KIND>
+__global__ void elementwise_loss_kernel(const float* __restrict__ x, const float* __restrict__ t, long long n,
+                                        float target, float gscale, float* __restrict__ grad,
+                                        float* __restrict__ partial) {
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    float l, g;
+    if (KIND == L_L1) {
+      const float d = v - t[i];
+      l = fabsf(d); g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    } else if (KIND == L_MSE) {
+      const float d = v - t[i];
+      l = d * d; g = 2.f * d;
+    } else {
+      // losses.py:55-56: max(x,0) - x*t + log(1 + exp(-|x|))
+      const float e = expf(-fabsf(v));
+      l = fmaxf(v, 0.f) - v * target + logf(1.f + e);
+      const float sig = v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+      g = sig - target;
+    }
+    s += l;
+    if (grad) grad[i] = g * gscale;
+  }
+  s = block_sum(s);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ void loss_final_kernel(const float* __restrict__ partial, int n, double scale, float* __restrict__ loss) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += partial[i];
+    loss[0] = (float)(s * scale);
+  }
+}
+
+// one wavefront per row
+__global__ void cross_entropy_kernel(const float* __restrict__ scores, int rows, int C,
+                                     const long long* __restrict__ labels, float gscale,
+                                     float* __restrict__ grad, float* __restrict__ partial) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const float* s = scores + (long long)r * C;
+  float mx = -INFINITY;
+  for (int c = lane; c < C; c += 64) mx = fmaxf(mx, s[c]);
+  #pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  float sum = 0.f;
+  for (int c = lane; c < C; c += 64) sum += expf(s[c] - mx);
+  #pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+  const int y = (int)labels[r];
+  const float lse = mx + logf(sum);
+  if (lane == 0) partial[r] = lse - s[y];
+  if (grad) {
+    for (int c = lane; c < C; c += 64) {
+      const float p = expf(s[c] - mx) / sum;
+      grad[(long long)r * C + c] = (p - (c == y ? 1.f : 0.f)) * gscale;
+    }
+  }
+}
+
+__global__ void scale_by_scalar_kernel(const float* __restrict__ x, const float* __restrict__ a, long long n,
+                                       float* __restrict__ y) {
+  const float s = a[0];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = x[i] * s;
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n, float one_minus_b1, float b2, float one_minus_b2,
+                            float step_size, float inv_bc2_sqrt, float eps, float gscale) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    const float mi = m[i] + (gi - m[i]) * one_minus_b1;          // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = v[i] * b2 + gi * gi * one_minus_b2;         // mul_(beta2).addcmul_(g, g, 1-beta2)
+    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+    m[i] = mi; v[i] = vi;
+  }
+}
+
+static inline int ok_or(hipError_t e) { return e == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP; }
+
+template <int KIND>
+static int run_elementwise(const float* x, const float* t, long long n, float target, float weight,
+                           float* loss, float* grad, float* partial, hipStream_t stream) {
+  if (!x || !loss || !partial || n < 1 || (KIND != L_BCE && !t)) return SG2IM_ERR_ARG;
+  const int blocks = (int)std::min<long long>(LOSS_BLOCKS, (n + 255) / 256);
+  hipLaunchKernelGGL((elementwise_loss_kernel<KIND>), dim3(blocks), dim3(256), 0, stream, x, t, n, target,
+                     (float)((double)weight / (double)n), grad, partial);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, stream, partial, blocks, (double)weight / (double)n, loss);
+  return ok_or(hipGetLastError());
+}
+
+}  // namespace sg2im
+
+using namespace sg2im;
+
+extern "C" {
+
+int sg2im_l1_loss(const float* pred, const float* target, long long n, float weight, float* loss,
+                  float* grad, float* partial, hipStream_t stream) {
+  return run_elementwise<L_L1>(pred, target, n, 0.f, weight, loss, grad, partial, stream);
+}
+
+int sg2im_mse_loss(const float* pred, const float* target, long long n, float weight, float* loss,
+                   float* grad, float* partial, hipStream_t stream) {
+  return run_elementwise<L_MSE>(pred, target, n, 0.f, weight, loss, grad, partial, stream);
+}
+
+int sg2im_bce_logits_loss(const float* x, long long n, float target, float weight, float* loss,
+                          float* grad, float* partial, hipStream_t stream) {
+  return run_elementwise<L_BCE>(x, nullptr, n, target, weight, loss, grad, partial, stream);
+}
+
+int sg2im_cross_entropy_loss(const float* scores, int rows, int classes, const long long* labels,
+                             float weight, float* loss, float* grad, float* partial,
+                             hipStream_t stream) {
+  if (!scores || !labels || !loss || !partial || rows < 1 || classes < 1) return SG2IM_ERR_ARG;
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3(rows), dim3(64), 0, stream, scores, rows, classes, labels,
+                     (float)((double)weight / (double)rows), grad, partial);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, stream, partial, rows, (double)weight / (double)rows, loss);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_scale_by_scalar(const float* x, const float* a_dev, long long n, float* y, hipStream_t stream) {
+  if (!x || !a_dev || !y) return SG2IM_ERR_ARG;
+  if (n == 0) return SG2IM_OK;
+  const int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(scale_by_scalar_kernel, dim3(blocks), dim3(256), 0, stream, x, a_dev, n, y);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
+                    float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                    hipStream_t stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) return SG2IM_ERR_ARG;
+  if (n == 0) return SG2IM_OK;
+  const double bc1 = 1.0 - std::pow((double)beta1, step);
+  const double bc2 = 1.0 - std::pow((double)beta2, step);
+  const int blocks = (int)std::min<long long>((n + 255) / 256, 16384);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, n,
+                     1.f - beta1, beta2, 1.f - beta2, (float)((double)lr / bc1), (float)(1.0 / std::sqrt(bc2)), eps,
+                     grad_scale);
+  return ok_or(hipGetLastError());
+}
+
+}  // extern "C"

@@ -1,0 +1,436 @@
+// BatchNorm2d statistics / backward, pooling, layout conversions and other HBM-bound
+// NHWC helpers of the hot path.  All tensors are [rows][C] with the channel index
+// contiguous, so a workgroup maps threadIdx -> (channel, row group): global accesses
+// are coalesced along channels and per-channel reductions run down the rows, finishing
+// through LDS and a per-workgroup partial that a tiny second kernel reduces in double.
+#include <algorithm>
+#include <hip/hip_runtime.h>
+#include "sg2im_hip.h"
+
+namespace sg2im {
+
+constexpr int RED_BLOCKS = 256;   // row blocks of the two-stage per-channel reductions
+
+__device__ __forceinline__ float leakyf(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// thread -> (channel lane tx, row group ty); channels covered: tx, tx + TC, ...
+struct ChanMap { int TC, TR, tx, ty; };
+__device__ __forceinline__ ChanMap chan_map(int C) {
+  ChanMap m;
+  m.TC = C < (int)blockDim.x ? C : (int)blockDim.x;
+  m.TR = blockDim.x / m.TC;
+  m.tx = threadIdx.x % m.TC;
+  m.ty = threadIdx.x / m.TC;      // ty >= TR -> idle thread
+  return m;
+}
+
+// ---------------------------------------------------------------------------
+// generic per-channel sums of up to two row-wise quantities
+// ---------------------------------------------------------------------------
+template <typename F>
+__device__ __forceinline__ void channel_reduce2(int C, long long rows, float* partial, F f) {
+  // f(row, c, s0, s1) accumulates into s0/s1.  partial: [gridDim.x][2][C]
+  extern __shared__ float red[];
+  const ChanMap m = chan_map(C);
+  const long long per = (rows + gridDim.x - 1) / gridDim.x;
+  const long long r0 = (long long)blockIdx.x * per;
+  const long long r1 = r0 + per < rows ? r0 + per : rows;
+  for (int c = m.tx; c < C; c += m.TC) {
+    float s0 = 0.f, s1 = 0.f;
+    if (m.ty < m.TR)
+      for (long long r = r0 + m.ty; r < r1; r += m.TR) f(r, c, s0, s1);
+    // reduce over ty through LDS (only needed when TR > 1; c loop runs once then)
+    if (m.TR > 1) {
+      red[threadIdx.x] = s0; red[blockDim.x + threadIdx.x] = s1;
+      __syncthreads();
+      if (m.ty == 0) {
+        for (int t = 1; t < m.TR; ++t) { s0 += red[t * m.TC + m.tx]; s1 += red[blockDim.x + t * m.TC + m.tx]; }
+      }
+      __syncthreads();
+    }
+    if (m.ty == 0) {
+      partial[((long long)blockIdx.x * 2 + 0) * C + c] = s0;
+      partial[((long long)blockIdx.x * 2 + 1) * C + c] = s1;
+    }
+  }
+}
+
+__global__ void bn_stats_partial_kernel(const float* __restrict__ x, long long rows, int C, long long ld,
+                                        float* __restrict__ partial) {
+  channel_reduce2(C, rows, partial, [&](long long r, int c, float& s0, float& s1) {
+    const float v = x[r * ld + c];
+    s0 += v; s1 = fmaf(v, v, s1);
+  });
+}
+
+__global__ void bn_stats_final_kernel(const float* __restrict__ partial, int nblk, long long rows,
+                                      long long unbiased_rows, int C,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      float eps, float momentum, int training,
+                                      float* __restrict__ running_mean, float* __restrict__ running_var,
+                                      long long* __restrict__ nbt, float* __restrict__ mean,
+                                      float* __restrict__ invstd, float* __restrict__ scale,
+                                      float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && training && nbt) *nbt += 1;
+  if (c >= C) return;
+  double mu, var;
+  if (training) {
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += partial[((long long)b * 2) * C + c]; ss += partial[((long long)b * 2 + 1) * C + c]; }
+    mu = s / (double)rows;
+    var = ss / (double)rows - mu * mu;
+    if (var < 0.0) var = 0.0;
+    if (running_mean) {
+      const double nu = (double)(unbiased_rows > 0 ? unbiased_rows : rows);
+      const double unbiased = nu > 1.0 ? var * nu / (nu - 1.0) : var;
+      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+  } else {
+    mu = running_mean[c]; var = running_var[c];
+  }
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  mean[c] = (float)mu; invstd[c] = is;
+  const float sc = g * is;
+  scale[c] = sc; shift[c] = b - (float)mu * sc;
+}
+
+// dz source: plain [rows][ld_g] or 2x2 sum of an upsampled-resolution tensor
+struct GradSrc { const float* g; long long ld; int pool2, h, w; };
+__device__ __forceinline__ float read_dz(const GradSrc& s, long long r, int c) {
+  if (!s.pool2) return s.g[r * s.ld + c];
+  const long long hw = (long long)s.h * s.w;
+  const long long n = r / hw; const int rem = (int)(r - n * hw);
+  const int y = rem / s.w, x = rem - y * s.w;
+  const long long W2 = 2LL * s.w;
+  const float* p = s.g + ((n * 2 * s.h + 2 * y) * W2 + 2 * x) * s.ld + c;
+  return (p[0] + p[s.ld]) + (p[W2 * s.ld] + p[(W2 + 1) * s.ld]);
+}
+
+__global__ void bn_bwd_partial_kernel(GradSrc gs, const float* __restrict__ y, long long ld_y, long long rows,
+                                      int C, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                      float slope, float* __restrict__ partial) {
+  channel_reduce2(C, rows, partial, [&](long long r, int c, float& s0, float& s1) {
+    const float yv = y[r * ld_y + c];
+    const float u = fmaf(yv, scale[c], shift[c]);
+    const float du = read_dz(gs, r, c) * (u > 0.f ? 1.f : slope);
+    s0 += du; s1 = fmaf(du, (yv - mean[c]) * invstd[c], s1);
+  });
+}
+
+// coef[0][c] = a, coef[1][c] = k1, coef[2][c] = k0 with dy = a*du + k1*y + k0
+__global__ void bn_bwd_final_kernel(const float* __restrict__ partial, int nblk, long long rows, int C,
+                                    const float* __restrict__ gamma, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, int training, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta, int accumulate, float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, sx = 0.0;
+  for (int b = 0; b < nblk; ++b) { s += partial[((long long)b * 2) * C + c]; sx += partial[((long long)b * 2 + 1) * C + c]; }
+  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sx;
+  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
+  const double g = gamma ? gamma[c] : 1.0, is = invstd[c], mu = mean[c];
+  const double a = g * is;
+  double k1 = 0.0, k0 = 0.0;
+  if (training) {
+    const double M = (double)rows;
+    k1 = -a * sx * is / M;
+    k0 = -a * s / M - k1 * mu;
+  }
+  coef[c] = (float)a; coef[C + c] = (float)k1; coef[2 * C + c] = (float)k0;
+}
+
+__global__ void bn_bwd_apply_kernel(GradSrc gs, const float* __restrict__ y, long long ld_y, long long rows,
+                                    int C, const float* __restrict__ scale, const float* __restrict__ shift,
+                                    float slope, const float* __restrict__ coef, float* __restrict__ dy) {
+  const long long total = rows * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / C; const int c = (int)(i - r * C);
+    const float yv = y[r * ld_y + c];
+    const float u = fmaf(yv, scale[c], shift[c]);
+    const float du = read_dz(gs, r, c) * (u > 0.f ? 1.f : slope);
+    dy[i] = fmaf(coef[c], du, fmaf(coef[C + c], yv, coef[2 * C + c]));
+  }
+}
+
+__global__ void act_bwd_kernel(GradSrc gs, const float* __restrict__ y, long long ld_y, long long rows, int C,
+                               float slope, float* __restrict__ dx) {
+  const long long total = rows * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / C; const int c = (int)(i - r * C);
+    dx[i] = read_dz(gs, r, c) * (y[r * ld_y + c] > 0.f ? 1.f : slope);
+  }
+}
+
+__global__ void avgpool_kernel(const float* __restrict__ x, int B, int H, int W, int C, int f,
+                               float* __restrict__ out) {
+  const int Ho = H / f, Wo = W / f;
+  const long long total = (long long)B * Ho * Wo * C;
+  const float inv = 1.f / (float)(f * f);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); long long t = i / C;
+    const int xo = (int)(t % Wo); t /= Wo;
+    const int yo = (int)(t % Ho); const long long n = t / Ho;
+    float s = 0.f;
+    for (int dy = 0; dy < f; ++dy)
+      for (int dx = 0; dx < f; ++dx)
+        s += x[((n * H + yo * f + dy) * W + xo * f + dx) * C + c];
+    out[i] = s * inv;
+  }
+}
+
+struct PyramidArgs { const float* lvl[8]; long long ld[8]; int f[8]; int n; };
+__global__ void pyramid_bwd_kernel(PyramidArgs a, int B, int H, int W, int C, float* __restrict__ out,
+                                   long long ld_out) {
+  const long long total = (long long)B * H * W * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); long long t = i / C;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H); const long long n = t / H;
+    float s = 0.f;
+    #pragma unroll
+    for (int l = 0; l < 8; ++l) {
+      if (l < a.n) {
+        const int f = a.f[l];
+        const int h = H / f, w = W / f;
+        s += a.lvl[l][((n * h + y / f) * w + x / f) * a.ld[l] + c] * (1.f / (float)(f * f));
+      }
+    }
+    out[((n * H + y) * W + x) * ld_out + c] = s;
+  }
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, int B, int C, int H, int W,
+                                    float* __restrict__ dst, long long ld, int coff) {
+  const long long total = (long long)B * C * H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); long long t = i / C;     // enumerate in NHWC order (coalesced writes)
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H); const long long n = t / H;
+    dst[((n * H + y) * W + x) * ld + coff + c] = src[((n * C + c) * H + y) * W + x];
+  }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, long long ld, int coff, int B, int C,
+                                    int H, int W, float* __restrict__ dst) {
+  const long long total = (long long)B * C * H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W); long long t = i / W;     // enumerate in NCHW order (coalesced writes)
+    const int y = (int)(t % H); t /= H;
+    const int c = (int)(t % C); const long long n = t / C;
+    dst[i] = src[((n * H + y) * W + x) * ld + coff + c];
+  }
+}
+
+__global__ void gap_fwd_kernel(const float* __restrict__ x, int B, int HW, int C, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int n = i / C, c = i - n * C;
+  float s = 0.f;
+  for (int p = 0; p < HW; ++p) s += x[((long long)n * HW + p) * C + c];
+  out[i] = s / (float)HW;
+}
+
+__global__ void gap_bwd_kernel(const float* __restrict__ dout, int B, int HW, int C, float* __restrict__ dx) {
+  const long long total = (long long)B * HW * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); const long long n = i / ((long long)HW * C);
+    dx[i] = dout[n * C + c] / (float)HW;
+  }
+}
+
+__global__ void sigmoid_fwd_kernel(const float* __restrict__ x, long long n, float* __restrict__ y) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = 1.f / (1.f + expf(-x[i]));
+}
+
+__global__ void sigmoid_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, long long n,
+                                   float* __restrict__ dx) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float s = y[i];
+    dx[i] = dy[i] * s * (1.f - s);
+  }
+}
+
+__global__ void colsum_partial_kernel(const float* __restrict__ x, long long rows, int C, long long ld,
+                                      float* __restrict__ partial) {
+  channel_reduce2(C, rows, partial, [&](long long r, int c, float& s0, float& s1) { s0 += x[r * ld + c]; });
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out,
+                                    int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += partial[((long long)b * 2) * C + c];
+  out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+}
+
+static inline int red_blocks(long long rows) {
+  return (int)std::max<long long>(1, std::min<long long>(RED_BLOCKS, (rows + 31) / 32));
+}
+static inline int ew_blocks(long long total) {
+  return (int)std::max<long long>(1, std::min<long long>((total + 255) / 256, 8192));
+}
+static inline int ok_or(hipError_t e) { return e == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP; }
+
+}  // namespace sg2im
+
+using namespace sg2im;
+
+extern "C" {
+
+int sg2im_bn_stats(const float* x, long long rows, int channels, long long ld, const float* gamma,
+                   const float* beta, float eps, float momentum, int training, float* running_mean,
+                   float* running_var, long long* num_batches_tracked, long long unbiased_rows,
+                   float* mean, float* invstd, float* scale, float* shift, float* partial,
+                   hipStream_t stream) {
+  if (channels < 1 || rows < 1 || !mean || !invstd || !scale || !shift) return SG2IM_ERR_ARG;
+  if (training && (!x || !partial)) return SG2IM_ERR_ARG;
+  if (!training && (!running_mean || !running_var)) return SG2IM_ERR_ARG;
+  int nblk = 0;
+  if (training) {
+    nblk = red_blocks(rows);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nblk), dim3(256), 2 * 256 * sizeof(float), stream, x, rows,
+                       channels, ld, partial);
+  }
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((channels + 255) / 256), dim3(256), 0, stream, partial, nblk, rows,
+                     unbiased_rows, channels, gamma, beta, eps, momentum, training, running_mean, running_var,
+                     num_batches_tracked, mean, invstd, scale, shift);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_bn_act_backward(const float* g, long long ld_g, int pool2, int batch, int h, int w,
+                          const float* y, long long ld_y, int channels, const float* gamma,
+                          const float* mean, const float* invstd, const float* scale,
+                          const float* shift, float slope, int training, float* dy,
+                          float* dgamma, float* dbeta, int accumulate, float* partial,
+                          hipStream_t stream) {
+  if (!g || !y || !dy || !partial || channels < 1 || !mean || !invstd || !scale || !shift) return SG2IM_ERR_ARG;
+  const long long rows = (long long)batch * h * w;
+  if (rows < 1) return SG2IM_ERR_ARG;
+  const GradSrc gs{g, ld_g, pool2, h, w};
+  const int nblk = red_blocks(rows);
+  float* coef = partial + (size_t)2 * channels * RED_BLOCKS;     // 3*C floats behind the partials
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk), dim3(256), 2 * 256 * sizeof(float), stream, gs, y, ld_y, rows,
+                     channels, mean, invstd, scale, shift, slope, partial);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((channels + 255) / 256), dim3(256), 0, stream, partial, nblk, rows,
+                     channels, gamma, mean, invstd, training, dgamma, dbeta, accumulate, coef);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(rows * channels)), dim3(256), 0, stream, gs, y, ld_y, rows,
+                     channels, scale, shift, slope, coef, dy);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_act_backward(const float* g, long long ld_g, int pool2, int batch, int h, int w,
+                       const float* y, long long ld_y, int channels, float slope, float* dx,
+                       hipStream_t stream) {
+  if (!g || !y || !dx || channels < 1) return SG2IM_ERR_ARG;
+  const long long rows = (long long)batch * h * w;
+  if (rows == 0) return SG2IM_OK;
+  const GradSrc gs{g, ld_g, pool2, h, w};
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(rows * channels)), dim3(256), 0, stream, gs, y, ld_y, rows,
+                     channels, slope, dx);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_avgpool_forward(const float* x, int batch, int h, int w, int channels, int factor,
+                          float* out, hipStream_t stream) {
+  if (!x || !out || factor < 1 || h % factor || w % factor) return SG2IM_ERR_ARG;
+  const long long total = (long long)batch * (h / factor) * (w / factor) * channels;
+  if (total == 0) return SG2IM_OK;
+  hipLaunchKernelGGL(avgpool_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, x, batch, h, w, channels, factor, out);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_pyramid_backward(const float* const* dlevels, const int* factors, const long long* lds,
+                           int n_levels, int batch, int h, int w, int channels, float* dlayout,
+                           long long ld_out, hipStream_t stream) {
+  if (!dlevels || !factors || !lds || n_levels < 1 || n_levels > 8 || !dlayout) return SG2IM_ERR_ARG;
+  PyramidArgs a;
+  a.n = n_levels;
+  for (int l = 0; l < 8; ++l) {
+    a.lvl[l] = l < n_levels ? dlevels[l] : nullptr;
+    a.ld[l] = l < n_levels ? lds[l] : 0;
+    a.f[l] = l < n_levels ? factors[l] : 1;
+    if (l < n_levels && (factors[l] < 1 || h % factors[l] || w % factors[l])) return SG2IM_ERR_ARG;
+  }
+  const long long total = (long long)batch * h * w * channels;
+  if (total == 0) return SG2IM_OK;
+  hipLaunchKernelGGL(pyramid_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, a, batch, h, w, channels,
+                     dlayout, ld_out);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_nchw_to_nhwc(const float* src, int batch, int channels, int h, int w, float* dst,
+                       long long ld_dst, int c_offset, hipStream_t stream) {
+  if (!src || !dst) return SG2IM_ERR_ARG;
+  const long long total = (long long)batch * channels * h * w;
+  if (total == 0) return SG2IM_OK;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, src, batch, channels, h, w,
+                     dst, ld_dst, c_offset);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_nhwc_to_nchw(const float* src, long long ld_src, int c_offset, int batch, int channels,
+                       int h, int w, float* dst, hipStream_t stream) {
+  if (!src || !dst) return SG2IM_ERR_ARG;
+  const long long total = (long long)batch * channels * h * w;
+  if (total == 0) return SG2IM_OK;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, src, ld_src, c_offset, batch,
+                     channels, h, w, dst);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_gap_forward(const float* x, int batch, int hw, int channels, float* out, hipStream_t stream) {
+  if (!x || !out || hw < 1) return SG2IM_ERR_ARG;
+  if (batch * channels == 0) return SG2IM_OK;
+  hipLaunchKernelGGL(gap_fwd_kernel, dim3((batch * channels + 255) / 256), dim3(256), 0, stream, x, batch, hw, channels, out);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_gap_backward(const float* dout, int batch, int hw, int channels, float* dx, hipStream_t stream) {
+  if (!dout || !dx || hw < 1) return SG2IM_ERR_ARG;
+  const long long total = (long long)batch * hw * channels;
+  if (total == 0) return SG2IM_OK;
+  hipLaunchKernelGGL(gap_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, dout, batch, hw, channels, dx);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_sigmoid_forward(const float* x, long long n, float* y, hipStream_t stream) {
+  if (!x || !y) return SG2IM_ERR_ARG;
+  if (n == 0) return SG2IM_OK;
+  hipLaunchKernelGGL(sigmoid_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, x, n, y);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_sigmoid_backward(const float* y, const float* dy, long long n, float* dx, hipStream_t stream) {
+  if (!y || !dy || !dx) return SG2IM_ERR_ARG;
+  if (n == 0) return SG2IM_OK;
+  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, y, dy, n, dx);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_column_sum(const float* x, long long rows, int cols, long long ld, float* out, int accumulate,
+                     float* partial, hipStream_t stream) {
+  if (!x || !out || !partial || cols < 1) return SG2IM_ERR_ARG;
+  if (rows == 0) {
+    if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * cols, stream) != hipSuccess) return SG2IM_ERR_HIP;
+    return SG2IM_OK;
+  }
+  const int nblk = red_blocks(rows);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 2 * 256 * sizeof(float), stream, x, rows, cols, ld, partial);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, stream, partial, nblk, cols, out, accumulate);
+  return ok_or(hipGetLastError());
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+"""Image / object PatchGAN discriminators (reference sg2im/discriminators.py) on HIP."""
+import torch
+import torch.nn as nn
+
+from . import functional as HF
+from .bilinear import crop_bbox_batch_nhwc
+from .layers import GlobalAvgPool, build_cnn
+from .layout import ALIGN_CORNERS
+
+
+class PatchDiscriminator(nn.Module):
+  def __init__(self, arch, normalization='batch', activation='leakyrelu-0.2', padding='same', pooling='avg',
+               input_size=(128, 128), layout_dim=0):
+    super(PatchDiscriminator, self).__init__()
+    input_dim = 3 + layout_dim
+    self.cnn, output_dim = build_cnn(arch='I%d,%s' % (input_dim, arch), normalization=normalization,
+                                     activation=activation, pooling=pooling, padding=padding)
+    # present in the state_dict but never applied (reference sg2im/discriminators.py:40-45)
+    self.classifier = nn.Conv2d(output_dim, 1, kernel_size=1, stride=1)
+
+  def forward_nhwc(self, x_nhwc):
+    return self.cnn(x_nhwc)
+
+  def forward(self, x, layout=None):
+    if layout is not None:
+      x = torch.cat([x, layout], dim=1)
+    return HF.NhwcToNchw.apply(self.cnn(HF.NchwToNhwc.apply(x)))
+
+
+class AcDiscriminator(nn.Module):
+  def __init__(self, vocab, arch, normalization='none', activation='relu', padding='same', pooling='avg'):
+    super(AcDiscriminator, self).__init__()
+    self.vocab = vocab
+    cnn, D = build_cnn(arch=arch, normalization=normalization, activation=activation, pooling=pooling,
+                       padding=padding)
+    self.cnn = nn.Sequential(cnn, GlobalAvgPool(), nn.Linear(D, 1024))
+    num_objects = len(vocab['object_idx_to_name'])
+    self.real_classifier = nn.Linear(1024, 1)
+    self.obj_classifier = nn.Linear(1024, num_objects)
+
+  def scores_nhwc(self, x_nhwc):
+    feats = self.cnn[0](x_nhwc)
+    vecs = self.cnn[1](feats)
+    fc = self.cnn[2]
+    vecs = HF.LinearAct.apply(vecs, fc.weight, fc.bias, 1.0)
+    real = HF.LinearAct.apply(vecs, self.real_classifier.weight, self.real_classifier.bias, 1.0)
+    cls = HF.LinearAct.apply(vecs, self.obj_classifier.weight, self.obj_classifier.bias, 1.0)
+    return real, cls
+
+  def forward_nhwc(self, x_nhwc, y):
+    real, cls = self.scores_nhwc(x_nhwc)
+    return real, HF.CrossEntropyLoss.apply(cls, y, 1.0)      # reference sg2im/discriminators.py:74
+
+  def forward(self, x, y):
+    if x.dim() == 3:
+      x = x[:, None]
+    return self.forward_nhwc(HF.NchwToNhwc.apply(x), y)
+
+
+class AcCropDiscriminator(nn.Module):
+  def __init__(self, vocab, arch, normalization='none', activation='relu', object_size=64, padding='same',
+               pooling='avg'):
+    super(AcCropDiscriminator, self).__init__()
+    self.vocab = vocab
+    self.discriminator = AcDiscriminator(vocab, arch, normalization, activation, padding, pooling)
+    self.object_size = object_size
+    self.align_corners = ALIGN_CORNERS
+
+  def forward_nhwc(self, imgs_nhwc, objs, boxes, obj_to_img):
+    crops = crop_bbox_batch_nhwc(imgs_nhwc, boxes, obj_to_img, self.object_size,
+                                 align_corners=self.align_corners)
+    return self.discriminator.forward_nhwc(crops, objs)
+
+  def forward(self, imgs, objs, boxes, obj_to_img):
+    """imgs (N,3,H,W) -> (real_scores (O,1), ac_loss scalar)  (reference :87-90)"""
+    return self.forward_nhwc(HF.NchwToNhwc.apply(imgs), objs, boxes, obj_to_img)

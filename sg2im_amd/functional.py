@@ -1,0 +1,663 @@
+"""autograd.Function wrappers: each one is a whole block of the reference model whose
+forward AND backward are explicit sequences of HIP kernels (sg2im_amd.ops).  Internally
+image-like tensors are NHWC and BatchNorm+LeakyReLU stay *pending* (folded into the next
+convolution's operand loader), so no torch compute kernel runs on the hot path.
+"""
+from ctypes import c_void_p
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+from .ops import conv_desc, nhwc_src, rows_src, SrcSpec
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+def _fptr(t, offset_floats=0):
+  return c_void_p(t.data_ptr() + 4 * offset_floats)
+
+
+def _new(like, *shape):
+  return torch.empty(*shape, dtype=torch.float32, device=like.device)
+
+
+def _cl_weight(w):
+  """physical [Cout][KH][KW][Cin] view of a conv weight parameter (channels_last storage)"""
+  p = w.permute(0, 2, 3, 1)
+  if not p.is_contiguous():
+    raise RuntimeError('conv weights must be stored channels_last; call sg2im_amd.layers.to_channels_last(module)')
+  return p
+
+
+def _cl_grad(dw_phys):
+  """[Cout][KH][KW][Cin] gradient -> (Cout,Cin,KH,KW)-shaped channels_last tensor"""
+  return dw_phys.permute(0, 3, 1, 2)
+
+
+# ----------------------------------------------------------------------------
+# layout conversions at the API boundary
+# ----------------------------------------------------------------------------
+
+class NchwToNhwc(Function):
+  @staticmethod
+  def forward(ctx, x):
+    N, C, H, W = x.shape
+    return ops.nchw_to_nhwc(x.contiguous(), _new(x, N, H, W, C))
+
+  @staticmethod
+  def backward(ctx, g):
+    N, H, W, C = g.shape
+    return ops.nhwc_to_nchw(g.contiguous(), _new(g, N, C, H, W))
+
+
+class NhwcToNchw(Function):
+  @staticmethod
+  def forward(ctx, x):
+    N, H, W, C = x.shape
+    return ops.nhwc_to_nchw(x.contiguous(), _new(x, N, C, H, W))
+
+  @staticmethod
+  def backward(ctx, g):
+    N, C, H, W = g.shape
+    return ops.nchw_to_nhwc(g.contiguous(), _new(g, N, H, W, C))
+
+
+# ----------------------------------------------------------------------------
+# linear layers
+# ----------------------------------------------------------------------------
+
+def _linear_bwd(desc, W, dpre, need_dx, need_dw, need_db, K):
+  """dpre: dense (M,N) gradient of the pre-activation.  Returns (dx (M,K), dW, db)."""
+  M, N = dpre.shape
+  dx = dw = db = None
+  if need_dx:
+    dx = _new(dpre, M, K)
+    ops.conv2d_backward_data(desc, W, N, dpre, N, 0, K, dx, K)
+  if need_dw:
+    dw = _new(dpre, N, K)
+    ops.conv2d_backward_weight(desc, dpre, N, N, dw)
+  if need_db:
+    db = _new(dpre, N)
+    ops.column_sum(_fptr(dpre), M, N, N, db)
+  return dx, dw, db
+
+
+def _act_bwd_rows(g, y, slope):
+  """dpre = g * leaky'(y) for dense row matrices (y is the activated output)"""
+  M, N = y.shape
+  g = g.contiguous()
+  if slope == 1.0:
+    return g
+  return ops.act_backward(_fptr(g), N, 0, M, 1, 1, y, N, N, slope, _new(y, M, N))
+
+
+class LinearAct(Function):
+  """y = leaky_slope(x W^T + b)   (nn.Linear [+ ReLU], reference sg2im/layers.py:216-232)"""
+
+  @staticmethod
+  def forward(ctx, x, W, b, slope):
+    M, K = x.shape
+    N = W.size(0)
+    desc = conv_desc([rows_src(x)], M, 1, 1)
+    y = ops.conv2d_forward(desc, W, N, b, _new(x, M, N), N, slope)
+    ctx.save_for_backward(x, W, y)
+    ctx.slope = slope
+    return y
+
+  @staticmethod
+  def backward(ctx, g):
+    x, W, y = ctx.saved_tensors
+    dpre = _act_bwd_rows(g, y, ctx.slope)
+    desc = conv_desc([rows_src(x)], x.size(0), 1, 1)
+    dx, dw, db = _linear_bwd(desc, W, dpre, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                             ctx.needs_input_grad[2], x.size(1))
+    return dx, dw, db, None
+
+
+class Mlp2(Function):
+  """ReLU(W2 ReLU(W1 x + b1) + b2): build_mlp([D, H, out]) (reference sg2im/model.py:76-78)"""
+
+  @staticmethod
+  def forward(ctx, x, W1, b1, W2, b2):
+    M = x.size(0)
+    d1 = conv_desc([rows_src(x)], M, 1, 1)
+    h = ops.conv2d_forward(d1, W1, W1.size(0), b1, _new(x, M, W1.size(0)), W1.size(0), 0.0)
+    d2 = conv_desc([rows_src(h)], M, 1, 1)
+    y = ops.conv2d_forward(d2, W2, W2.size(0), b2, _new(x, M, W2.size(0)), W2.size(0), 0.0)
+    ctx.save_for_backward(x, W1, W2, h, y)
+    return y
+
+  @staticmethod
+  def backward(ctx, g):
+    x, W1, W2, h, y = ctx.saved_tensors
+    M = x.size(0)
+    ni = ctx.needs_input_grad
+    dp2 = _act_bwd_rows(g, y, 0.0)
+    d2 = conv_desc([rows_src(h)], M, 1, 1)
+    dh, dW2, db2 = _linear_bwd(d2, W2, dp2, True, ni[3], ni[4], h.size(1))
+    dp1 = _act_bwd_rows(dh, h, 0.0)
+    d1 = conv_desc([rows_src(x)], M, 1, 1)
+    dx, dW1, db1 = _linear_bwd(d1, W1, dp1, ni[0], ni[1], ni[2], x.size(1))
+    return dx, dW1, db1, dW2, db2
+
+
+class Embedding(Function):
+  """weight[idx]  (nn.Embedding, reference sg2im/model.py:131,133); bit-exact row copy.
+  Backward is a deterministic CSR segment-sum instead of atomics."""
+
+  @staticmethod
+  def forward(ctx, weight, idx):
+    out = ops.gather_rows(weight, idx, _new(weight, idx.numel(), weight.size(1)))
+    ctx.save_for_backward(idx)
+    ctx.rows = weight.size(0)
+    return out
+
+  @staticmethod
+  def backward(ctx, g):
+    idx, = ctx.saved_tensors
+    g = g.contiguous()
+    csr = ops.Csr(idx, None, ctx.rows)
+    dw = ops.segment_sum(g, None, csr, g.size(1), False, _new(g, ctx.rows, g.size(1)))
+    return dw, None
+
+
+# ----------------------------------------------------------------------------
+# graph convolution
+# ----------------------------------------------------------------------------
+
+class GraphTripleConvFn(Function):
+  """One GraphTripleConv layer (reference sg2im/graph.py:56-120): gather+concat folded into
+  the net1 GEMM, deterministic CSR pooling, net2."""
+
+  @staticmethod
+  def forward(ctx, obj_vecs, pred_vecs, s_idx, o_idx, csr, avg, W1a, b1a, W1b, b1b, W2a, b2a, W2b, b2b):
+    T, O = pred_vecs.size(0), obj_vecs.size(0)
+    H, Dout = W2a.size(0), W2b.size(0)
+    NT = W1b.size(0)                                  # 2H + Dout
+    if obj_vecs.stride(1) != 1:
+      obj_vecs = obj_vecs.contiguous()
+    if pred_vecs.size(0) > 0 and pred_vecs.stride(1) != 1:
+      pred_vecs = pred_vecs.contiguous()
+    d1 = conv_desc([rows_src(obj_vecs, s_idx), rows_src(pred_vecs), rows_src(obj_vecs, o_idx)], T, 1, 1)
+    h1 = ops.conv2d_forward(d1, W1a, H, b1a, _new(obj_vecs, T, H), H, 0.0)
+    new_t = ops.conv2d_forward(conv_desc([rows_src(h1)], T, 1, 1), W1b, NT, b1b, _new(obj_vecs, T, NT), NT, 0.0)
+    pooled = _new(obj_vecs, O, H)
+    ops.segment_sum(new_t[:, :H], new_t[:, H + Dout:], csr, H, avg, pooled)
+    h2 = ops.conv2d_forward(conv_desc([rows_src(pooled)], O, 1, 1), W2a, H, b2a, _new(obj_vecs, O, H), H, 0.0)
+    new_obj = ops.conv2d_forward(conv_desc([rows_src(h2)], O, 1, 1), W2b, Dout, b2b, _new(obj_vecs, O, Dout),
+                                 Dout, 0.0)
+    ctx.save_for_backward(obj_vecs, pred_vecs, s_idx, o_idx, W1a, W1b, W2a, W2b, h1, new_t, pooled, h2, new_obj)
+    ctx.csr, ctx.avg = csr, avg
+    return new_obj, new_t[:, H:H + Dout]
+
+  @staticmethod
+  def backward(ctx, g_obj, g_pred):
+    (obj_vecs, pred_vecs, s_idx, o_idx, W1a, W1b, W2a, W2b, h1, new_t, pooled, h2, new_obj) = ctx.saved_tensors
+    csr, avg = ctx.csr, ctx.avg
+    T, O = pred_vecs.size(0), obj_vecs.size(0)
+    Din, H, Dout = obj_vecs.size(1), W2a.size(0), W2b.size(0)
+    NT = W1b.size(0)
+    ni = ctx.needs_input_grad
+    z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=obj_vecs.device)
+    # net2
+    if g_obj is None:
+      g_obj = z(O, Dout)
+    dp4 = _act_bwd_rows(g_obj, new_obj, 0.0)
+    dh2, dW2b, db2b = _linear_bwd(conv_desc([rows_src(h2)], O, 1, 1), W2b, dp4, True, ni[12], ni[13], H)
+    dp3 = _act_bwd_rows(dh2, h2, 0.0)
+    dpooled, dW2a, db2a = _linear_bwd(conv_desc([rows_src(pooled)], O, 1, 1), W2a, dp3, True, ni[10], ni[11], H)
+    # pooling backward: rows of dpooled go back to the s / o column blocks (divided by the count)
+    d_new_t = _new(obj_vecs, T, NT)
+    cavg = csr if avg else None
+    ops.gather_rows(dpooled, s_idx, d_new_t[:, :H], cavg)
+    ops.gather_rows(dpooled, o_idx, d_new_t[:, H + Dout:], cavg)
+    if g_pred is None:
+      d_new_t[:, H:H + Dout].zero_()
+    else:
+      ops.copy_2d(g_pred, d_new_t[:, H:H + Dout])
+    # net1
+    dp2 = ops.act_backward(_fptr(d_new_t), NT, 0, T, 1, 1, new_t, NT, NT, 0.0, d_new_t) if T > 0 else d_new_t
+    dh1, dW1b, db1b = _linear_bwd(conv_desc([rows_src(h1)], T, 1, 1), W1b, dp2, True, ni[8], ni[9], H)
+    dp1 = _act_bwd_rows(dh1, h1, 0.0)
+    d1 = conv_desc([rows_src(obj_vecs, s_idx), rows_src(pred_vecs), rows_src(obj_vecs, o_idx)], T, 1, 1)
+    need_dx = ni[0] or ni[1]
+    dX, dW1a, db1a = _linear_bwd(d1, W1a, dp1, need_dx, ni[6], ni[7], 3 * Din)
+    d_obj = d_pred = None
+    if ni[0]:
+      d_obj = ops.segment_sum(dX[:, :Din], dX[:, 2 * Din:], csr, Din, False, _new(obj_vecs, O, Din))
+    if ni[1]:
+      d_pred = dX[:, Din:2 * Din]
+    return (d_obj, d_pred, None, None, None, None, dW1a, db1a, dW1b, db1b, dW2a, db2a, dW2b, db2b)
+
+
+class RelAux(Function):
+  """rel_aux_net on cat[boxes[s], boxes[o], vecs[s], vecs[o]] (reference sg2im/model.py:149-152)"""
+
+  @staticmethod
+  def forward(ctx, boxes, vecs, s_idx, o_idx, csr, W1, b1, W2, b2):
+    T = s_idx.numel()
+    boxes, vecs = boxes.contiguous(), vecs.contiguous()
+    d1 = conv_desc([rows_src(boxes, s_idx), rows_src(boxes, o_idx), rows_src(vecs, s_idx), rows_src(vecs, o_idx)],
+                   T, 1, 1)
+    h = ops.conv2d_forward(d1, W1, W1.size(0), b1, _new(vecs, T, W1.size(0)), W1.size(0), 0.0)
+    y = ops.conv2d_forward(conv_desc([rows_src(h)], T, 1, 1), W2, W2.size(0), b2, _new(vecs, T, W2.size(0)),
+                           W2.size(0), 0.0)
+    ctx.save_for_backward(boxes, vecs, s_idx, o_idx, W1, W2, h, y)
+    ctx.csr = csr
+    return y
+
+  @staticmethod
+  def backward(ctx, g):
+    boxes, vecs, s_idx, o_idx, W1, W2, h, y = ctx.saved_tensors
+    T, E = s_idx.numel(), vecs.size(1)
+    ni = ctx.needs_input_grad
+    dp2 = _act_bwd_rows(g, y, 0.0)
+    dh, dW2, db2 = _linear_bwd(conv_desc([rows_src(h)], T, 1, 1), W2, dp2, True, ni[7], ni[8], h.size(1))
+    dp1 = _act_bwd_rows(dh, h, 0.0)
+    d1 = conv_desc([rows_src(boxes, s_idx), rows_src(boxes, o_idx), rows_src(vecs, s_idx), rows_src(vecs, o_idx)],
+                   T, 1, 1)
+    dX, dW1, db1 = _linear_bwd(d1, W1, dp1, ni[0] or ni[1], ni[5], ni[6], 8 + 2 * E)
+    d_boxes = d_vecs = None
+    if ni[0]:
+      d_boxes = ops.segment_sum(dX[:, 0:4], dX[:, 4:8], ctx.csr, 4, False, _new(vecs, boxes.size(0), 4))
+    if ni[1]:
+      d_vecs = ops.segment_sum(dX[:, 8:8 + E], dX[:, 8 + E:], ctx.csr, E, False, _new(vecs, vecs.size(0), E))
+    return d_boxes, d_vecs, None, None, None, dW1, db1, dW2, db2
+
+
+# ----------------------------------------------------------------------------
+# layout
+# ----------------------------------------------------------------------------
+
+class LayoutFn(Function):
+  """masks_to_layout / boxes_to_layout (+ the layout-noise concat of model.py:164-169):
+  returns the NHWC tensor (N, H, W, D + noise_dim) the refinement network consumes."""
+
+  @staticmethod
+  def forward(ctx, vecs, boxes, masks, obj_to_img, noise, n_images, H, W, align_corners):
+    D = vecs.size(1)
+    nd = noise.size(1) if noise is not None else 0
+    if vecs.stride(1) != 1:
+      vecs = vecs.contiguous()
+    boxes = boxes.contiguous()
+    img_csr = ops.Csr(obj_to_img, None, n_images)
+    out = _new(vecs, n_images, H, W, D + nd)
+    ops.layout_forward(vecs, boxes, masks, img_csr, n_images, H, W, align_corners, out)
+    if nd > 0:
+      ops.nchw_to_nhwc(noise.contiguous(), out, D)
+    ctx.save_for_backward(vecs, boxes, masks, obj_to_img)
+    ctx.img_csr, ctx.geom = img_csr, (n_images, H, W, align_corners)
+    return out
+
+  @staticmethod
+  def backward(ctx, g):
+    vecs, boxes, masks, obj_to_img = ctx.saved_tensors
+    n_images, H, W, ac = ctx.geom
+    ni = ctx.needs_input_grad
+    if ni[1]:
+      raise NotImplementedError('gradient of the layout w.r.t. the boxes is not implemented yet '
+                                '(the training loop always passes boxes_gt, reference scripts/train.py:526)')
+    g = g.contiguous()
+    d_vecs = _new(vecs, vecs.size(0), vecs.size(1)) if ni[0] else None
+    d_masks = None
+    if ni[2] and masks is not None and masks.is_floating_point():
+      d_masks = _new(vecs, *masks.shape)
+    if d_vecs is not None or d_masks is not None:
+      ops.layout_backward(g, vecs, boxes, masks, obj_to_img, ctx.img_csr, n_images, H, W, ac, d_vecs, d_masks)
+    return d_vecs, None, d_masks, None, None, None, None, None, None
+
+
+class CropFn(Function):
+  """crop_bbox_batch (reference sg2im/bilinear.py:28-132) on NHWC images -> NHWC crops"""
+
+  @staticmethod
+  def forward(ctx, imgs, boxes, obj_to_img, size, align_corners):
+    imgs, boxes = imgs.contiguous(), boxes.contiguous()
+    out = ops.crop_forward(imgs, boxes, obj_to_img, size, align_corners,
+                           _new(imgs, boxes.size(0), size, size, imgs.size(3)))
+    ctx.save_for_backward(boxes, obj_to_img)
+    ctx.geom = (tuple(imgs.shape), size, align_corners)
+    return out
+
+  @staticmethod
+  def backward(ctx, g):
+    boxes, obj_to_img = ctx.saved_tensors
+    shape, size, ac = ctx.geom
+    d = torch.zeros(shape, dtype=torch.float32, device=g.device)
+    ops.crop_backward(g.contiguous(), boxes, obj_to_img, size, ac, d)
+    return d, None, None, None, None
+
+
+# ----------------------------------------------------------------------------
+# conv blocks
+# ----------------------------------------------------------------------------
+
+def _conv_param_grads(desc, dy, cout, w_phys_shape, need_w, need_b):
+  """dy: dense NHWC gradient of the conv output"""
+  dw = db = None
+  rows = dy.numel() // cout
+  if need_w:
+    dw = _new(dy, *w_phys_shape)
+    ops.conv2d_backward_weight(desc, dy, cout, cout, dw)
+    dw = _cl_grad(dw)
+  if need_b:
+    db = _new(dy, cout)
+    ops.column_sum(_fptr(dy), rows, cout, cout, db)
+  return dw, db
+
+
+class RefinementFn(Function):
+  """RefinementNetwork.forward (reference sg2im/crn.py:88-111) on an NHWC layout.
+
+  params (flat): per module [W0, b0, W1, b1] ..., then [Wo0, bo0, Wo2, bo2];
+  bns: list of (bn0, bn1) module pairs (parameter containers);  BN gamma/beta are passed
+  as tensors as well so autograd sees them: per module [g0, be0, g1, be1] after the conv
+  params of ALL modules and the output convs.
+  """
+
+  @staticmethod
+  def forward(ctx, layout, bns, slope, training, *params):
+    L = len(bns)
+    N, H, W, Cl = layout.shape
+    convp = params[:4 * L]
+    Wo0, bo0, Wo2, bo2 = params[4 * L:4 * L + 4]
+    bnp = params[4 * L + 4:]
+    h0, w0 = H >> L, W >> L
+    if h0 == 0 or w0 == 0:
+      raise AssertionError('too many refinement modules for this image size')     # crn.py:103-104
+    layout = layout.contiguous()
+    feats = torch.zeros(N, h0, w0, 1, dtype=torch.float32, device=layout.device)   # crn.py:105
+    feat_src = nhwc_src(feats, up=1)
+    saved = []
+    pyr = []
+    for i in range(L):
+      h, w = H >> (L - 1 - i), W >> (L - 1 - i)
+      f = H // h
+      lay = layout if f == 1 else ops.avgpool_forward(layout, f, _new(layout, N, h, w, Cl))
+      pyr.append(lay)
+      W0p, b0, W1p, b1 = convp[4 * i:4 * i + 4]
+      C = W0p.size(0)
+      bn0, bn1 = bns[i]
+      d0 = conv_desc([nhwc_src(lay), feat_src], N, h, w, 3, 3, 1, 1)
+      y0 = ops.conv2d_forward(d0, _cl_weight(W0p), C, b0, _new(layout, N, h, w, C), C)
+      st0 = ops.bn_stats(y0, N * h * w, C, C, bn0, training, BN_EPS, BN_MOMENTUM)
+      d1 = conv_desc([nhwc_src(y0, 0, st0.scale, st0.shift, slope)], N, h, w, 3, 3, 1, 1)
+      y1 = ops.conv2d_forward(d1, _cl_weight(W1p), C, b1, _new(layout, N, h, w, C), C)
+      st1 = ops.bn_stats(y1, N * h * w, C, C, bn1, training, BN_EPS, BN_MOMENTUM)
+      saved.append((lay, feat_src, y0, st0, y1, st1, h, w, C))
+      feat_src = nhwc_src(y1, 1, st1.scale, st1.shift, slope)
+    last = saved[-1]
+    Cf = last[8]
+    do0 = conv_desc([nhwc_src(last[4], 0, last[5].scale, last[5].shift, slope)], N, H, W, 3, 3, 1, 1)
+    z = ops.conv2d_forward(do0, _cl_weight(Wo0), Wo0.size(0), bo0, _new(layout, N, H, W, Wo0.size(0)),
+                           Wo0.size(0), slope)
+    do2 = conv_desc([nhwc_src(z)], N, H, W, 1, 1, 1, 0)
+    img = ops.conv2d_forward(do2, _cl_weight(Wo2), Wo2.size(0), bo2, _new(layout, N, H, W, Wo2.size(0)),
+                             Wo2.size(0))
+    ctx.saved = saved
+    ctx.misc = (L, slope, training, z, do0, do2, Cl, Cf)
+    ctx.save_for_backward(*params)
+    ctx.shape = (N, H, W, Cl)
+    return img
+
+  @staticmethod
+  def backward(ctx, g):
+    params = ctx.saved_tensors
+    L, slope, training, z, do0, do2, Cl, Cf = ctx.misc
+    N, H, W, _ = ctx.shape
+    saved = ctx.saved
+    convp = params[:4 * L]
+    Wo0, bo0, Wo2, bo2 = params[4 * L:4 * L + 4]
+    bnp = params[4 * L + 4:]
+    ni = ctx.needs_input_grad[4:]
+    grads = [None] * len(params)
+    g = g.contiguous()
+    Co = Wo0.size(0)
+    # output 1x1 conv
+    grads[4 * L + 2], grads[4 * L + 3] = _conv_param_grads(do2, g, Wo2.size(0), (Wo2.size(0), 1, 1, Co),
+                                                           ni[4 * L + 2], ni[4 * L + 3])
+    dz = _new(g, N, H, W, Co)
+    ops.conv2d_backward_data(do2, _cl_weight(Wo2), Wo2.size(0), g, Wo2.size(0), 0, Co, dz, Co)
+    ops.act_backward(_fptr(dz), Co, 0, N, H, W, z, Co, Co, slope, dz)
+    grads[4 * L], grads[4 * L + 1] = _conv_param_grads(do0, dz, Co, (Co, 3, 3, Cf), ni[4 * L], ni[4 * L + 1])
+    gz = _new(g, N, H, W, Cf)                      # grad w.r.t. activated feats of the last module
+    ops.conv2d_backward_data(do0, _cl_weight(Wo0), Co, dz, Co, 0, Cf, gz, Cf)
+    pool2 = 0
+    need_layout = ctx.needs_input_grad[0]
+    Cg = Cl                                         # layout channels that need gradients
+    dlevels = []
+    for i in range(L - 1, -1, -1):
+      lay, feat_src, y0, st0, y1, st1, h, w, C = saved[i]
+      W0p, b0, W1p, b1 = convp[4 * i:4 * i + 4]
+      g0, be0, g1, be1 = bnp[4 * i:4 * i + 4]
+      k = 4 * L + 4 + 4 * i
+      dg1 = _new(g, C) if ni[k + 2] else None
+      db1n = _new(g, C) if ni[k + 3] else None
+      dy1 = ops.bn_act_backward(_fptr(gz), gz.size(3), pool2, N, h, w, y1, C, C, g1, st1, slope, training,
+                                _new(g, N, h, w, C), dg1, db1n)
+      grads[k + 2], grads[k + 3] = dg1, db1n
+      d1 = conv_desc([nhwc_src(y0, 0, st0.scale, st0.shift, slope)], N, h, w, 3, 3, 1, 1)
+      grads[4 * i + 2], grads[4 * i + 3] = _conv_param_grads(d1, dy1, C, (C, 3, 3, C), ni[4 * i + 2], ni[4 * i + 3])
+      gz0 = _new(g, N, h, w, C)
+      ops.conv2d_backward_data(d1, _cl_weight(W1p), C, dy1, C, 0, C, gz0, C)
+      dg0 = _new(g, C) if ni[k] else None
+      db0n = _new(g, C) if ni[k + 1] else None
+      dy0 = ops.bn_act_backward(_fptr(gz0), C, 0, N, h, w, y0, C, C, g0, st0, slope, training, dy1, dg0, db0n)
+      grads[k], grads[k + 1] = dg0, db0n
+      Cprev = feat_src.channels
+      d0 = conv_desc([nhwc_src(lay), feat_src], N, h, w, 3, 3, 1, 1)
+      grads[4 * i], grads[4 * i + 1] = _conv_param_grads(d0, dy0, C, (C, 3, 3, Cl + Cprev), ni[4 * i], ni[4 * i + 1])
+      if need_layout:
+        dl = _new(g, N, h, w, Cg)
+        ops.conv2d_backward_data(d0, _cl_weight(W0p), C, dy0, C, 0, Cg, dl, Cg)
+        dlevels.append((dl, H // h))
+      if i > 0:
+        gz = _new(g, N, h, w, Cprev)               # at this (upsampled) resolution; summed 2x2 next
+        ops.conv2d_backward_data(d0, _cl_weight(W0p), C, dy0, C, Cl, Cprev, gz, Cprev)
+        pool2 = 1
+    dlayout = None
+    if need_layout:
+      dlayout = _new(g, N, H, W, Cl)
+      ops.pyramid_backward([t for t, _ in dlevels], [f for _, f in dlevels], [Cg] * len(dlevels), N, H, W, Cg,
+                           dlayout)
+    ctx.saved = None
+    return (dlayout, None, None, None) + tuple(grads)
+
+
+class MaskNetFn(Function):
+  """mask_net (reference sg2im/model.py:94-106,146-147): [up2, BN, conv3x3, ReLU] x k, conv1x1,
+  sigmoid.  params: per block [gamma, beta, W, b] ..., then [Wf, bf]."""
+
+  @staticmethod
+  def forward(ctx, obj_vecs, bns, training, *params):
+    nb = len(bns)
+    O, D = obj_vecs.shape
+    x = obj_vecs.contiguous().view(O, 1, 1, D)
+    saved = []
+    s = 1
+    for b in range(nb):
+      gam, bet, Wp, bias = params[4 * b:4 * b + 4]
+      # statistics of the upsampled tensor == statistics of x (each value repeated 4x);
+      # only the unbiased running_var factor sees the repeated count
+      st = ops.bn_stats(x, O * s * s, D, D, bns[b], training, BN_EPS, BN_MOMENTUM, unbiased_rows=4 * O * s * s)
+      d = conv_desc([nhwc_src(x, 1, st.scale, st.shift, 1.0)], O, 2 * s, 2 * s, 3, 3, 1, 1)
+      y = ops.conv2d_forward(d, _cl_weight(Wp), D, bias, _new(x, O, 2 * s, 2 * s, D), D, 0.0)
+      saved.append((x, st, y, s))
+      x = y
+      s *= 2
+    Wf, bf = params[4 * nb:4 * nb + 2]
+    df = conv_desc([nhwc_src(x)], O, s, s, 1, 1, 1, 0)
+    scores = ops.conv2d_forward(df, _cl_weight(Wf), 1, bf, _new(x, O, s, s, 1), 1)
+    masks = ops.sigmoid_forward(scores, _new(x, O, s, s))
+    ctx.saved, ctx.misc = saved, (nb, training, x, df, s)
+    ctx.save_for_backward(masks, *params)
+    return masks
+
+  @staticmethod
+  def backward(ctx, g):
+    masks = ctx.saved_tensors[0]
+    params = ctx.saved_tensors[1:]
+    nb, training, xl, df, s = ctx.misc
+    saved = ctx.saved
+    O, D = masks.size(0), xl.size(3)
+    ni = ctx.needs_input_grad[3:]
+    grads = [None] * len(params)
+    Wf, bf = params[4 * nb:4 * nb + 2]
+    ds = ops.sigmoid_backward(masks, g.contiguous(), _new(g, O, s, s, 1))
+    grads[4 * nb], grads[4 * nb + 1] = _conv_param_grads(df, ds, 1, (1, 1, 1, D), ni[4 * nb], ni[4 * nb + 1])
+    gz = _new(g, O, s, s, D)
+    ops.conv2d_backward_data(df, _cl_weight(Wf), 1, ds, 1, 0, D, gz, D)
+    for b in range(nb - 1, -1, -1):
+      x, st, y, sb = saved[b]
+      gam, bet, Wp, bias = params[4 * b:4 * b + 4]
+      s2 = 2 * sb
+      dpre = ops.act_backward(_fptr(gz), D, 0, O, s2, s2, y, D, D, 0.0, gz)
+      d = conv_desc([nhwc_src(x, 1, st.scale, st.shift, 1.0)], O, s2, s2, 3, 3, 1, 1)
+      grads[4 * b + 2], grads[4 * b + 3] = _conv_param_grads(d, dpre, D, (D, 3, 3, D), ni[4 * b + 2], ni[4 * b + 3])
+      gup = _new(g, O, s2, s2, D)
+      ops.conv2d_backward_data(d, _cl_weight(Wp), D, dpre, D, 0, D, gup, D)
+      dgam = _new(g, D) if ni[4 * b] else None
+      dbet = _new(g, D) if ni[4 * b + 1] else None
+      gz = ops.bn_act_backward(_fptr(gup), D, 1, O, sb, sb, x, D, D, gam, st, 1.0, training, _new(g, O, sb, sb, D),
+                               dgam, dbet)
+      grads[4 * b], grads[4 * b + 1] = dgam, dbet
+    ctx.saved = None
+    d_obj = gz.view(O, D) if ctx.needs_input_grad[0] else None
+    return (d_obj, None, None) + tuple(grads)
+
+
+class DiscCnnFn(Function):
+  """build_cnn with 'CK-X-S' tokens, batch norm, valid/same padding (reference
+  sg2im/layers.py:129-213): conv, then [BN, LeakyReLU, conv] ... on an NHWC input.
+  specs: list of (k, cout, stride, pad); params: [W0, b0], then per later conv
+  [gamma, beta, W, b]."""
+
+  @staticmethod
+  def forward(ctx, x, bns, specs, slope, training, *params):
+    x = x.contiguous()
+    N, H, W, Cin = x.shape
+    saved = []
+    src = nhwc_src(x)
+    h, w = H, W
+    for i, (k, cout, stride, pad) in enumerate(specs):
+      if i == 0:
+        Wp, bias = params[0:2]
+      else:
+        Wp, bias = params[2 + 4 * (i - 1) + 2:2 + 4 * (i - 1) + 4]
+      d = conv_desc([src], N, h, w, k, k, stride, pad)
+      y = ops.conv2d_forward(d, _cl_weight(Wp), cout, bias, _new(x, N, d.out_h, d.out_w, cout), cout)
+      st = None
+      if i + 1 < len(specs):
+        st = ops.bn_stats(y, N * d.out_h * d.out_w, cout, cout, bns[i], training, BN_EPS, BN_MOMENTUM)
+      saved.append((src, d, y, st, h, w))
+      h, w = d.out_h, d.out_w
+      if st is not None:
+        src = nhwc_src(y, 0, st.scale, st.shift, slope)
+    ctx.saved, ctx.misc = saved, (specs, slope, training, tuple(x.shape))
+    ctx.save_for_backward(*params)
+    return saved[-1][2]
+
+  @staticmethod
+  def backward(ctx, g):
+    params = ctx.saved_tensors
+    specs, slope, training, xshape = ctx.misc
+    saved = ctx.saved
+    N = xshape[0]
+    ni = ctx.needs_input_grad[5:]
+    grads = [None] * len(params)
+    dy = g.contiguous()
+    for i in range(len(specs) - 1, -1, -1):
+      k, cout, stride, pad = specs[i]
+      src, d, y, st, h, w = saved[i]
+      cin = src.channels
+      if i == 0:
+        Wp, wi = params[0], 0
+      else:
+        wi = 2 + 4 * (i - 1) + 2
+        Wp = params[wi]
+      grads[wi], grads[wi + 1] = _conv_param_grads(d, dy, cout, (cout, k, k, cin), ni[wi], ni[wi + 1])
+      if i == 0:
+        dx = None
+        if ctx.needs_input_grad[0]:
+          dx = _new(g, *xshape)
+          ops.conv2d_backward_data(d, _cl_weight(Wp), cout, dy, cout, 0, cin, dx, cin)
+        ctx.saved = None
+        return (dx, None, None, None, None) + tuple(grads)
+      gz = _new(g, N, h, w, cin)
+      ops.conv2d_backward_data(d, _cl_weight(Wp), cout, dy, cout, 0, cin, gz, cin)
+      yp, stp = saved[i - 1][2], saved[i - 1][3]
+      gi = 2 + 4 * (i - 1)
+      dgam = _new(g, cin) if ni[gi] else None
+      dbet = _new(g, cin) if ni[gi + 1] else None
+      dy = ops.bn_act_backward(_fptr(gz), cin, 0, N, h, w, yp, cin, cin, params[gi], stp, slope, training, gz, dgam,
+                               dbet)
+      grads[gi], grads[gi + 1] = dgam, dbet
+
+
+class GapFn(Function):
+  """GlobalAvgPool over NHWC (reference sg2im/layers.py:83-86)"""
+
+  @staticmethod
+  def forward(ctx, x):
+    N, H, W, C = x.shape
+    ctx.hw = H * W
+    ctx.shape = tuple(x.shape)
+    return ops.gap_forward(x.contiguous(), _new(x, N, C))
+
+  @staticmethod
+  def backward(ctx, g):
+    return ops.gap_backward(g.contiguous(), ctx.hw, _new(g, *ctx.shape))
+
+
+# ----------------------------------------------------------------------------
+# losses
+# ----------------------------------------------------------------------------
+
+class _LossFn(Function):
+  @staticmethod
+  def _finish(ctx, loss, grad):
+    ctx.save_for_backward(grad)
+    return loss.view(())
+
+  @staticmethod
+  def backward(ctx, g):
+    grad, = ctx.saved_tensors
+    out = ops.scale_by_scalar(grad, g.contiguous().view(1), torch.empty_like(grad))
+    return (out,) + (None,) * 3
+
+
+class L1Loss(_LossFn):
+  @staticmethod
+  def forward(ctx, pred, target, weight, _unused=None):
+    pred, target = pred.contiguous(), target.contiguous()
+    grad = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
+    loss = ops.l1_loss(pred, target, weight, grad)
+    return _LossFn._finish(ctx, loss, grad)
+
+
+class MseLoss(_LossFn):
+  @staticmethod
+  def forward(ctx, pred, target, weight, _unused=None):
+    pred, target = pred.contiguous(), target.contiguous()
+    grad = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
+    loss = ops.mse_loss(pred, target, weight, grad)
+    return _LossFn._finish(ctx, loss, grad)
+
+
+class BceLogitsLoss(_LossFn):
+  @staticmethod
+  def forward(ctx, x, target, weight, _unused=None):
+    x = x.contiguous()
+    grad = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+    loss = ops.bce_logits_loss(x, target, weight, grad)
+    return _LossFn._finish(ctx, loss, grad)
+
+
+class CrossEntropyLoss(_LossFn):
+  @staticmethod
+  def forward(ctx, scores, labels, weight, _unused=None):
+    scores = scores.contiguous()
+    grad = torch.empty_like(scores) if ctx.needs_input_grad[0] else None
+    loss = ops.cross_entropy_loss(scores, labels, weight, grad)
+    return _LossFn._finish(ctx, loss, grad)

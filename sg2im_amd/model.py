@@ -1,0 +1,160 @@
+"""Sg2ImModel with the reference's constructor / forward / state_dict surface
+(reference sg2im/model.py) running on hand-written HIP kernels for gfx950."""
+import torch
+import torch.nn as nn
+
+from . import functional as HF
+from . import ops
+from .crn import RefinementNetwork
+from .graph import GraphTripleConv, GraphTripleConvNet
+from .layers import build_mlp, to_channels_last
+from .layout import ALIGN_CORNERS, layout_nhwc
+
+
+class Sg2ImModel(nn.Module):
+  def __init__(self, vocab, image_size=(64, 64), embedding_dim=64, gconv_dim=128, gconv_hidden_dim=512,
+               gconv_pooling='avg', gconv_num_layers=5, refinement_dims=(1024, 512, 256, 128, 64),
+               normalization='batch', activation='leakyrelu-0.2', mask_size=None,
+               mlp_normalization='none', layout_noise_dim=0, **kwargs):
+    super(Sg2ImModel, self).__init__()
+    if len(kwargs) > 0:      # reference sg2im/model.py:41-42
+      print('WARNING: Model got unexpected kwargs ', kwargs)
+    self.vocab = vocab
+    self.image_size = image_size
+    self.layout_noise_dim = layout_noise_dim
+    self.align_corners = ALIGN_CORNERS
+
+    num_objs = len(vocab['object_idx_to_name'])
+    num_preds = len(vocab['pred_idx_to_name'])
+    self.obj_embeddings = nn.Embedding(num_objs + 1, embedding_dim)
+    self.pred_embeddings = nn.Embedding(num_preds, embedding_dim)
+
+    if gconv_num_layers == 0:
+      self.gconv = nn.Linear(embedding_dim, gconv_dim)
+    elif gconv_num_layers > 0:
+      self.gconv = GraphTripleConv(input_dim=embedding_dim, output_dim=gconv_dim, hidden_dim=gconv_hidden_dim,
+                                   pooling=gconv_pooling, mlp_normalization=mlp_normalization)
+    self.gconv_net = None
+    if gconv_num_layers > 1:
+      self.gconv_net = GraphTripleConvNet(input_dim=gconv_dim, hidden_dim=gconv_hidden_dim,
+                                          pooling=gconv_pooling, num_layers=gconv_num_layers - 1,
+                                          mlp_normalization=mlp_normalization)
+
+    self.box_net = build_mlp([gconv_dim, gconv_hidden_dim, 4], batch_norm=mlp_normalization)
+    self.mask_net = None
+    if mask_size is not None and mask_size > 0:
+      self.mask_net = self._build_mask_net(num_objs, gconv_dim, mask_size)
+    self.rel_aux_net = build_mlp([2 * embedding_dim + 8, gconv_hidden_dim, num_preds],
+                                 batch_norm=mlp_normalization)
+    self.refinement_net = RefinementNetwork(dims=(gconv_dim + layout_noise_dim,) + tuple(refinement_dims),
+                                            normalization=normalization, activation=activation)
+
+  def _build_mask_net(self, num_objs, dim, mask_size):
+    """Container with the Sequential indices of reference sg2im/model.py:94-106."""
+    layers, cur = [], 1
+    while cur < mask_size:
+      layers += [nn.Upsample(scale_factor=2, mode='nearest'), nn.BatchNorm2d(dim),
+                 nn.Conv2d(dim, dim, kernel_size=3, padding=1), nn.ReLU()]
+      cur *= 2
+    if cur != mask_size:
+      raise ValueError('Mask size must be a power of 2')
+    layers.append(nn.Conv2d(dim, 1, kernel_size=1))
+    return to_channels_last(nn.Sequential(*layers))
+
+  def _run_mask_net(self, obj_vecs):
+    bns = [m for m in self.mask_net if isinstance(m, nn.BatchNorm2d)]
+    convs = [m for m in self.mask_net if isinstance(m, nn.Conv2d)]
+    params = []
+    for bn, cv in zip(bns, convs[:-1]):
+      params += [bn.weight, bn.bias, cv.weight, cv.bias]
+    params += [convs[-1].weight, convs[-1].bias]
+    return HF.MaskNetFn.apply(obj_vecs, bns, self.training, *params)
+
+  def forward_nhwc(self, objs, triples, obj_to_img=None, boxes_gt=None, masks_gt=None, num_images=None):
+    """Same computation as ``forward`` (reference sg2im/model.py:108-171) but the image
+    is returned NHWC, the internal layout of the kernels.  ``num_images`` avoids the host
+    sync of reference sg2im/layout.py:143 (N = obj_to_img.max()+1)."""
+    O = objs.size(0)
+    s = triples[:, 0].contiguous()
+    p = triples[:, 1].contiguous()
+    o = triples[:, 2].contiguous()
+    if obj_to_img is None:
+      obj_to_img = torch.zeros(O, dtype=objs.dtype, device=objs.device)
+      num_images = 1
+    edges = (s, o, ops.Csr(s, o, O))
+
+    obj_vecs = HF.Embedding.apply(self.obj_embeddings.weight, objs)
+    obj_vecs_orig = obj_vecs
+    pred_vecs = HF.Embedding.apply(self.pred_embeddings.weight, p)
+    if isinstance(self.gconv, nn.Linear):
+      obj_vecs = HF.LinearAct.apply(obj_vecs, self.gconv.weight, self.gconv.bias, 1.0)
+    else:
+      obj_vecs, pred_vecs = self.gconv(obj_vecs, pred_vecs, edges)
+    if self.gconv_net is not None:
+      obj_vecs, pred_vecs = self.gconv_net(obj_vecs, pred_vecs, edges)
+
+    boxes_pred = self.box_net(obj_vecs)
+    masks_pred = None
+    if self.mask_net is not None:
+      masks_pred = self._run_mask_net(obj_vecs)
+
+    r1, r2 = self.rel_aux_net.linears()
+    rel_scores = HF.RelAux.apply(boxes_pred, obj_vecs_orig, s, o, edges[2], r1.weight, r1.bias, r2.weight, r2.bias)
+
+    H, W = self.image_size
+    layout_boxes = boxes_pred if boxes_gt is None else boxes_gt
+    layout_masks = None
+    if masks_pred is not None:
+      layout_masks = masks_pred if masks_gt is None else masks_gt
+    if num_images is None:
+      num_images = int(obj_to_img.max().item()) + 1          # reference sg2im/layout.py:143
+    noise = None
+    if self.layout_noise_dim > 0:                             # reference sg2im/model.py:164-168
+      noise = torch.randn((num_images, self.layout_noise_dim, H, W), dtype=obj_vecs.dtype,
+                          device=obj_vecs.device)
+    layout = layout_nhwc(obj_vecs, layout_boxes, layout_masks, obj_to_img, H, W, noise=noise,
+                         n_images=num_images, align_corners=self.align_corners)
+    img = self.refinement_net.forward_nhwc(layout)
+    return img, boxes_pred, masks_pred, rel_scores
+
+  def forward(self, objs, triples, obj_to_img=None, boxes_gt=None, masks_gt=None, num_images=None):
+    """Required: objs (O,) int64 categories, triples (T,3) int64 [s,p,o].  Optional:
+    obj_to_img (O,), boxes_gt (O,4), masks_gt (O,M,M).  Returns (img (N,3,H,W),
+    boxes_pred (O,4), masks_pred (O,M,M) | None, rel_scores (T,P))."""
+    img, boxes_pred, masks_pred, rel_scores = self.forward_nhwc(objs, triples, obj_to_img, boxes_gt,
+                                                                masks_gt, num_images)
+    return HF.NhwcToNchw.apply(img), boxes_pred, masks_pred, rel_scores
+
+  def encode_scene_graphs(self, scene_graphs):
+    """Scene-graph dict(s) {'objects': [...], 'relationships': [[s, pred, o], ...]} ->
+    (objs, triples, obj_to_img) LongTensors on the model's device.  Like the reference
+    (sg2im/model.py:173-227) this appends '__image__' / '__in_image__' to the *caller's*
+    dicts and raises ValueError on out-of-vocabulary names."""
+    if isinstance(scene_graphs, dict):
+      scene_graphs = [scene_graphs]
+    name_to_obj = self.vocab['object_name_to_idx']
+    name_to_pred = self.vocab['pred_name_to_idx']
+    objs, triples, obj_to_img = [], [], []
+    offset = 0
+    for img_idx, sg in enumerate(scene_graphs):
+      sg['objects'].append('__image__')
+      image_node = len(sg['objects']) - 1
+      sg['relationships'].extend([j, '__in_image__', image_node] for j in range(image_node))
+      for name in sg['objects']:
+        if name not in name_to_obj:
+          raise ValueError('Object "%s" not in vocab' % name)
+        objs.append(name_to_obj[name])
+        obj_to_img.append(img_idx)
+      for s, pred, o in sg['relationships']:
+        if pred not in name_to_pred:
+          raise ValueError('Relationship "%s" not in vocab' % pred)
+        triples.append([s + offset, name_to_pred[pred], o + offset])
+      offset += len(sg['objects'])
+    device = next(self.parameters()).device
+    as_long = lambda v: torch.tensor(v, dtype=torch.int64, device=device)
+    return as_long(objs), as_long(triples), as_long(obj_to_img)
+
+  def forward_json(self, scene_graphs):
+    """encode_scene_graphs + forward (reference sg2im/model.py:229-232)."""
+    objs, triples, obj_to_img = self.encode_scene_graphs(scene_graphs)
+    return self.forward(objs, triples, obj_to_img)

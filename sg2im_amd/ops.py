@@ -1,0 +1,377 @@
+"""Thin tensor-level wrappers over the C ABI (include/sg2im_hip.h).
+
+PyTorch is used here only as plumbing: device memory (torch tensors), the current HIP
+stream and shapes.  Every function enqueues HIP kernels from libsg2im_hip.so on
+``torch.cuda.current_stream()`` and returns immediately.  Inputs must live on the GPU;
+anything else raises - there is no CPU path.
+"""
+import ctypes
+from ctypes import byref, c_int, c_longlong, c_void_p
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, call
+
+WORKSPACE_BYTES = 256 << 20      # split-K partials / layout-backward partials
+_ws = {}
+_scratch = {}
+
+
+def _stream():
+  return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f(t):
+  """device pointer of an fp32 CUDA tensor (None -> NULL)"""
+  if t is None:
+    return None
+  if not (t.is_cuda and t.dtype == torch.float32):
+    raise TypeError('expected a float32 tensor on the GPU, got %s on %s' % (t.dtype, t.device))
+  return c_void_p(t.data_ptr())
+
+
+def _i64(t):
+  if t is None:
+    return None
+  if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
+    raise TypeError('expected a contiguous int64 tensor on the GPU')
+  return c_void_p(t.data_ptr())
+
+
+def _i32(t):
+  if t is None:
+    return None
+  if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+    raise TypeError('expected a contiguous int32 tensor on the GPU')
+  return c_void_p(t.data_ptr())
+
+
+def workspace(device):
+  key = (device.index, torch.cuda.current_stream().cuda_stream)
+  w = _ws.get(key)
+  if w is None:
+    w = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
+    _ws[key] = w
+  return w
+
+
+def scratch(device, nfloats):
+  """Reduction scratch (per device+stream), grown on demand."""
+  key = (device.index, torch.cuda.current_stream().cuda_stream)
+  s = _scratch.get(key)
+  if s is None or s.numel() < nfloats:
+    s = torch.empty(max(int(nfloats), 1 << 20), dtype=torch.float32, device=device)
+    _scratch[key] = s
+  return s
+
+
+def rows_ld(t):
+  """(pointer, ld) of a 2-D row matrix whose rows are contiguous (column slices allowed)."""
+  if t.dim() != 2 or (t.size(1) > 1 and t.stride(1) != 1):
+    raise ValueError('expected a row matrix with unit column stride')
+  return _f(t), t.stride(0) if t.size(0) > 1 else max(t.stride(0), t.size(1))
+
+
+# ----------------------------------------------------------------------------
+# conv / linear
+# ----------------------------------------------------------------------------
+
+class SrcSpec(object):
+  __slots__ = ('t', 'channels', 'ld', 'up', 'gather', 'scale', 'shift', 'slope')
+
+  def __init__(self, t, channels, ld, up=0, gather=None, scale=None, shift=None, slope=1.0):
+    self.t, self.channels, self.ld, self.up = t, int(channels), int(ld), int(up)
+    self.gather, self.scale, self.shift, self.slope = gather, scale, shift, float(slope)
+
+
+def nhwc_src(t, up=0, scale=None, shift=None, slope=1.0):
+  """source from a contiguous NHWC tensor"""
+  assert t.dim() == 4 and t.is_contiguous()
+  return SrcSpec(t, t.size(3), t.size(3), up, None, scale, shift, slope)
+
+
+def rows_src(t, gather=None):
+  """source from a row matrix (optionally row-gathered)"""
+  _, ld = rows_ld(t)
+  return SrcSpec(t, t.size(1), ld, 0, gather)
+
+
+def conv_desc(srcs, batch, in_h, in_w, kh=1, kw=1, stride=1, pad=0):
+  d = ConvDesc()
+  d.nsrc = len(srcs)
+  for i, s in enumerate(srcs):
+    q = d.src[i]
+    q.data = s.t.data_ptr()
+    q.gather = s.gather.data_ptr() if s.gather is not None else None
+    q.scale = s.scale.data_ptr() if s.scale is not None else None
+    q.shift = s.shift.data_ptr() if s.shift is not None else None
+    q.slope, q.channels, q.ld, q.upsample_log2 = s.slope, s.channels, s.ld, s.up
+    if not (s.t.is_cuda and s.t.dtype == torch.float32):
+      raise TypeError('conv source must be a float32 GPU tensor')
+  d.batch, d.in_h, d.in_w = int(batch), int(in_h), int(in_w)
+  d.kh, d.kw, d.stride, d.pad = int(kh), int(kw), int(stride), int(pad)
+  d.out_h = (in_h + 2 * pad - kh) // stride + 1
+  d.out_w = (in_w + 2 * pad - kw) // stride + 1
+  d._keep = srcs            # keep the tensors alive as long as the descriptor
+  return d
+
+
+def conv2d_forward(desc, weight, cout, bias, out, ld_out, out_slope=1.0, accumulate=False):
+  ws = workspace(out.device)
+  call('sg2im_conv2d_forward', byref(desc), _f(weight), int(cout), _f(bias), float(out_slope), _f(out),
+       int(ld_out), int(accumulate), _f(ws), ws.numel() * 4, _stream())
+  return out
+
+
+def conv2d_backward_data(desc, weight, cout, dy, ld_dy, c_begin, c_count, dx, ld_dx, accumulate=False):
+  ws = workspace(dx.device)
+  call('sg2im_conv2d_backward_data', byref(desc), _f(weight), int(cout), _f(dy), int(ld_dy), int(c_begin),
+       int(c_count), _f(dx), int(ld_dx), int(accumulate), _f(ws), ws.numel() * 4, _stream())
+  return dx
+
+
+def conv2d_backward_weight(desc, dy, ld_dy, cout, dweight, accumulate=False):
+  ws = workspace(dweight.device)
+  call('sg2im_conv2d_backward_weight', byref(desc), _f(dy), int(ld_dy), int(cout), _f(dweight),
+       int(accumulate), _f(ws), ws.numel() * 4, _stream())
+  return dweight
+
+
+def column_sum(x_ptr, rows, cols, ld, out, accumulate=False):
+  part = scratch(out.device, 2 * cols * 256)
+  call('sg2im_column_sum', x_ptr, int(rows), int(cols), int(ld), _f(out), int(accumulate), _f(part), _stream())
+  return out
+
+
+# ----------------------------------------------------------------------------
+# graph
+# ----------------------------------------------------------------------------
+
+class Csr(object):
+  """Stable CSR over destination rows (see sg2im_csr_build)."""
+  __slots__ = ('row_ptr', 'entries', 'n_a', 'n_b', 'n_rows')
+
+  def __init__(self, keys_a, keys_b, n_rows):
+    dev = keys_a.device
+    self.n_a = keys_a.numel()
+    self.n_b = keys_b.numel() if keys_b is not None else 0
+    self.n_rows = int(n_rows)
+    n = self.n_a + self.n_b
+    self.row_ptr = torch.empty(self.n_rows + 1, dtype=torch.int32, device=dev)
+    self.entries = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    tmp = torch.empty(self.n_rows + max(n, 1), dtype=torch.int32, device=dev)
+    call('sg2im_csr_build', _i64(keys_a), self.n_a, _i64(keys_b), self.n_b, self.n_rows, _i32(self.row_ptr),
+         _i32(self.entries), _i32(tmp), _stream())
+
+
+def segment_sum(src_a, src_b, csr, width, average, out):
+  pa, lda = rows_ld(src_a)
+  pb, ldb = rows_ld(src_b) if src_b is not None else (None, 0)
+  po, ldo = rows_ld(out)
+  call('sg2im_segment_sum', pa, lda, csr.n_a, pb, ldb, _i32(csr.row_ptr), _i32(csr.entries), csr.n_rows,
+       int(width), int(average), po, ldo, _stream())
+  return out
+
+
+def gather_rows(src, idx, out, csr_for_average=None):
+  ps, lds = rows_ld(src)
+  po, ldo = rows_ld(out)
+  rp = _i32(csr_for_average.row_ptr) if csr_for_average is not None else None
+  call('sg2im_gather_rows', ps, lds, _i64(idx), idx.numel(), out.size(1), rp, po, ldo, _stream())
+  return out
+
+
+def copy_2d(src, out):
+  ps, lds = rows_ld(src)
+  po, ldo = rows_ld(out)
+  call('sg2im_copy_2d', ps, lds, po, ldo, src.size(0), src.size(1), _stream())
+  return out
+
+
+# ----------------------------------------------------------------------------
+# layout / crops
+# ----------------------------------------------------------------------------
+
+def _mask_args(masks):
+  if masks is None:
+    return None, None, 0
+  if masks.dtype == torch.int64:
+    return None, _i64(masks.contiguous()), masks.size(1)
+  return _f(masks.contiguous()), None, masks.size(1)
+
+
+def layout_forward(vecs, boxes, masks, img_csr, n_images, H, W, align_corners, out):
+  """out: NHWC (N,H,W,ld) tensor; channels [0, D) are written."""
+  pv, ldv = rows_ld(vecs)
+  mf, mi, M = _mask_args(masks)
+  call('sg2im_layout_forward', pv, ldv, _f(boxes), mf, mi, M, _i32(img_csr.row_ptr), _i32(img_csr.entries),
+       int(n_images), vecs.size(0), vecs.size(1), int(H), int(W), int(align_corners), _f(out), out.size(3),
+       _stream())
+  return out
+
+
+def layout_backward(dlayout, vecs, boxes, masks, obj_to_img, img_csr, n_images, H, W, align_corners,
+                    d_vecs, d_masks):
+  pv, ldv = rows_ld(vecs)
+  mf, mi, M = _mask_args(masks)
+  O, D = vecs.size(0), vecs.size(1)
+  need = _lib.load().sg2im_layout_backward_workspace(O, D, int(H), int(W))
+  ws = workspace(vecs.device)
+  if need > ws.numel() * 4:
+    raise _lib.Sg2imHipError('layout backward needs %d workspace bytes' % need)
+  pd, ldd = rows_ld(d_vecs) if d_vecs is not None else (None, 0)
+  call('sg2im_layout_backward', _f(dlayout), dlayout.size(3), pv, ldv, _f(boxes), mf, mi, M, _i64(obj_to_img),
+       _i32(img_csr.row_ptr), _i32(img_csr.entries), int(n_images), O, D, int(H), int(W), int(align_corners),
+       pd, ldd, _f(d_masks), _f(ws), _stream())
+
+
+def crop_forward(imgs_nhwc, boxes, obj_to_img, size, align_corners, out):
+  N, H, W, C = imgs_nhwc.shape
+  call('sg2im_crop_forward', _f(imgs_nhwc), C, N, H, W, C, _f(boxes), _i64(obj_to_img), boxes.size(0), int(size),
+       int(align_corners), _f(out), _stream())
+  return out
+
+
+def crop_backward(d_crops, boxes, obj_to_img, size, align_corners, d_imgs_nhwc):
+  N, H, W, C = d_imgs_nhwc.shape
+  call('sg2im_crop_backward', _f(d_crops), N, H, W, C, _f(boxes), _i64(obj_to_img), boxes.size(0), int(size),
+       int(align_corners), _f(d_imgs_nhwc), C, _stream())
+  return d_imgs_nhwc
+
+
+# ----------------------------------------------------------------------------
+# batch norm / pooling / conversions
+# ----------------------------------------------------------------------------
+
+class BnState(object):
+  """Per-call BatchNorm statistics + the folded affine the next conv loader applies."""
+  __slots__ = ('mean', 'invstd', 'scale', 'shift')
+
+  def __init__(self, C, device):
+    buf = torch.empty(4, C, dtype=torch.float32, device=device)
+    self.mean, self.invstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
+
+
+def bn_stats(x, rows, C, ld, bn, training, eps=1e-5, momentum=0.1, unbiased_rows=0):
+  """x: any float tensor viewed as [rows][ld]; bn: a module holding weight/bias/running_*."""
+  st = BnState(C, x.device)
+  part = scratch(x.device, 2 * C * 256)
+  nbt = bn.num_batches_tracked
+  call('sg2im_bn_stats', _f(x), int(rows), int(C), int(ld), _f(bn.weight), _f(bn.bias), float(eps),
+       float(momentum), int(training), _f(bn.running_mean), _f(bn.running_var),
+       c_void_p(nbt.data_ptr()) if nbt is not None else None, int(unbiased_rows), _f(st.mean), _f(st.invstd), _f(st.scale),
+       _f(st.shift), _f(part), _stream())
+  return st
+
+
+def bn_act_backward(g, ld_g, pool2, batch, h, w, y, ld_y, C, gamma, st, slope, training, dy, dgamma, dbeta,
+                    accumulate=False):
+  part = scratch(y.device, 2 * C * 256 + 3 * C)
+  call('sg2im_bn_act_backward', g, int(ld_g), int(pool2), int(batch), int(h), int(w), _f(y), int(ld_y), int(C),
+       _f(gamma), _f(st.mean), _f(st.invstd), _f(st.scale), _f(st.shift), float(slope), int(training), _f(dy),
+       _f(dgamma), _f(dbeta), int(accumulate), _f(part), _stream())
+  return dy
+
+
+def act_backward(g, ld_g, pool2, batch, h, w, y, ld_y, C, slope, dx):
+  call('sg2im_act_backward', g, int(ld_g), int(pool2), int(batch), int(h), int(w), _f(y), int(ld_y), int(C),
+       float(slope), _f(dx), _stream())
+  return dx
+
+
+def avgpool_forward(x, factor, out):
+  N, H, W, C = x.shape
+  call('sg2im_avgpool_forward', _f(x), N, H, W, C, int(factor), _f(out), _stream())
+  return out
+
+
+def pyramid_backward(levels, factors, lds, batch, H, W, C, out):
+  n = len(levels)
+  ptrs = (c_void_p * n)(*[t.data_ptr() for t in levels])
+  fs = (c_int * n)(*factors)
+  ls = (c_longlong * n)(*lds)
+  call('sg2im_pyramid_backward', ptrs, fs, ls, n, int(batch), int(H), int(W), int(C), _f(out), out.size(3),
+       _stream())
+  return out
+
+
+def nchw_to_nhwc(src, out, c_offset=0):
+  N, C, H, W = src.shape
+  call('sg2im_nchw_to_nhwc', _f(src), N, C, H, W, _f(out), out.size(3), int(c_offset), _stream())
+  return out
+
+
+def nhwc_to_nchw(src, out, c_offset=0):
+  N, C, H, W = out.shape
+  call('sg2im_nhwc_to_nchw', _f(src), src.size(3), int(c_offset), N, C, H, W, _f(out), _stream())
+  return out
+
+
+def gap_forward(x, out):
+  N, H, W, C = x.shape
+  call('sg2im_gap_forward', _f(x), N, H * W, C, _f(out), _stream())
+  return out
+
+
+def gap_backward(dout, hw, dx):
+  N, C = dout.shape
+  call('sg2im_gap_backward', _f(dout), N, int(hw), C, _f(dx), _stream())
+  return dx
+
+
+def sigmoid_forward(x, out):
+  call('sg2im_sigmoid_forward', _f(x), x.numel(), _f(out), _stream())
+  return out
+
+
+def sigmoid_backward(y, dy, dx):
+  call('sg2im_sigmoid_backward', _f(y), _f(dy), y.numel(), _f(dx), _stream())
+  return dx
+
+
+# ----------------------------------------------------------------------------
+# losses / optimiser
+# ----------------------------------------------------------------------------
+
+def _loss_out(device):
+  return torch.empty(1, dtype=torch.float32, device=device)
+
+
+def l1_loss(pred, target, weight, grad):
+  loss = _loss_out(pred.device)
+  call('sg2im_l1_loss', _f(pred), _f(target), pred.numel(), float(weight), _f(loss), _f(grad),
+       _f(scratch(pred.device, 256)), _stream())
+  return loss
+
+
+def mse_loss(pred, target, weight, grad):
+  loss = _loss_out(pred.device)
+  call('sg2im_mse_loss', _f(pred), _f(target), pred.numel(), float(weight), _f(loss), _f(grad),
+       _f(scratch(pred.device, 256)), _stream())
+  return loss
+
+
+def bce_logits_loss(x, target, weight, grad):
+  loss = _loss_out(x.device)
+  call('sg2im_bce_logits_loss', _f(x), x.numel(), float(target), float(weight), _f(loss), _f(grad),
+       _f(scratch(x.device, 256)), _stream())
+  return loss
+
+
+def cross_entropy_loss(scores, labels, weight, grad):
+  loss = _loss_out(scores.device)
+  R, C = scores.shape
+  call('sg2im_cross_entropy_loss', _f(scores), R, C, _i64(labels), float(weight), _f(loss), _f(grad),
+       _f(scratch(scores.device, max(256, R))), _stream())
+  return loss
+
+
+def scale_by_scalar(x, a_dev, out):
+  call('sg2im_scale_by_scalar', _f(x), _f(a_dev), x.numel(), _f(out), _stream())
+  return out
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale=1.0):
+  call('sg2im_adam_step', _f(param), _f(grad), _f(exp_avg), _f(exp_avg_sq), param.numel(), float(lr),
+       float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _stream())

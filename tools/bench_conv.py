@@ -1,0 +1,65 @@
+"""Per-layer timing of the implicit-GEMM kernels at the COCO-64 / batch-32 shapes
+(SURVEY.md section 8a table T1).  Prints ms and achieved TFLOP/s per layer and pass."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+from sg2im_amd import ops
+
+D = torch.device('cuda', 0)
+N = 32
+LAYERS = [  # name, H, C0, C1(up), Cout, k, stride, pad
+  ('m0.conv0', 4, 160, 1, 1024, 3, 1, 1), ('m0.conv1', 4, 1024, 0, 1024, 3, 1, 1),
+  ('m1.conv0', 8, 160, 1024, 512, 3, 1, 1), ('m1.conv1', 8, 512, 0, 512, 3, 1, 1),
+  ('m2.conv0', 16, 160, 512, 256, 3, 1, 1), ('m2.conv1', 16, 256, 0, 256, 3, 1, 1),
+  ('m3.conv0', 32, 160, 256, 128, 3, 1, 1), ('m3.conv1', 32, 128, 0, 128, 3, 1, 1),
+  ('m4.conv0', 64, 160, 128, 64, 3, 1, 1), ('m4.conv1', 64, 64, 0, 64, 3, 1, 1),
+  ('out.conv0', 64, 64, 0, 64, 3, 1, 1), ('out.conv1', 64, 64, 0, 3, 1, 1, 0),
+  ('d_img.c0', 64, 3, 0, 64, 4, 2, 0), ('d_img.c1', 31, 64, 0, 128, 4, 2, 0), ('d_img.c2', 14, 128, 0, 256, 4, 2, 0),
+]
+
+
+def timeit(fn, iters=10):
+  fn(); fn()
+  torch.cuda.synchronize()
+  a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  a.record()
+  for _ in range(iters):
+    fn()
+  b.record()
+  torch.cuda.synchronize()
+  return a.elapsed_time(b) / iters
+
+
+def main():
+  tot = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
+  totf = 0.0
+  print('%-10s %9s | %8s %7s | %8s %7s | %8s %7s' % ('layer', 'GFLOP', 'fwd ms', 'TF/s', 'dgrad ms', 'TF/s', 'wgrad ms', 'TF/s'))
+  for name, H, C0, C1, Cout, k, s, p in LAYERS:
+    x0 = torch.randn(N, H, H, C0, device=D)
+    srcs = [ops.nhwc_src(x0)]
+    if C1:
+      srcs.append(ops.nhwc_src(torch.randn(N, H // 2, H // 2, C1, device=D), 1))
+    d = ops.conv_desc(srcs, N, H, H, k, k, s, p)
+    Ct = C0 + C1
+    W = torch.randn(Cout, k, k, Ct, device=D) * 0.01
+    b = torch.randn(Cout, device=D)
+    y = torch.empty(N, d.out_h, d.out_w, Cout, device=D)
+    gy = torch.randn_like(y)
+    dx = torch.empty(N, H, H, Ct, device=D)
+    dw = torch.empty_like(W)
+    gf = 2.0 * N * d.out_h * d.out_w * Cout * Ct * k * k / 1e9
+    t1 = timeit(lambda: ops.conv2d_forward(d, W, Cout, b, y, Cout))
+    t2 = timeit(lambda: ops.conv2d_backward_data(d, W, Cout, gy, Cout, 0, Ct, dx, Ct))
+    t3 = timeit(lambda: ops.conv2d_backward_weight(d, gy, Cout, Cout, dw))
+    print('%-10s %9.2f | %8.3f %7.1f | %8.3f %7.1f | %8.3f %7.1f' % (name, gf, t1, gf / t1, t2, gf / t2, t3, gf / t3), flush=True)
+    tot['fwd'] += t1; tot['dgrad'] += t2; tot['wgrad'] += t3; totf += gf
+  print('TOTAL %.1f GFLOP/pass: fwd %.2f ms (%.1f TF/s)  dgrad %.2f ms (%.1f)  wgrad %.2f ms (%.1f)' %
+        (totf, tot['fwd'], totf / tot['fwd'], tot['dgrad'], totf / tot['dgrad'], tot['wgrad'], totf / tot['wgrad']))
+
+
+if __name__ == '__main__':
+  main()

@@ -1,0 +1,344 @@
+"""Diagnostic sweep: run every HIP op against the CPU oracle / torch CPU reference and
+print an error table (never raises).  Usage on the GPU box:
+   python tools/gpu_check.py > gpurun_out/check.log 2>&1
+"""
+import os
+import sys
+import time
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torch.nn.functional as F
+
+from oracle import sg2im_oracle as orc
+from sg2im_amd import ops
+from sg2im_amd import functional as HF
+from sg2im_amd.synthetic import make_vocab, synthetic_batch
+from tests import hip_harness as hh
+from tests.util import load_golden, clone_params
+
+D = torch.device('cuda', 0)
+RESULTS = []
+
+
+def err(a, b):
+  a, b = a.detach().double().cpu(), b.detach().double().cpu()
+  if a.shape != b.shape:
+    return float('nan'), 'shape %s vs %s' % (tuple(a.shape), tuple(b.shape))
+  d = (a - b).abs().max().item() if a.numel() else 0.0
+  s = b.abs().max().item() if b.numel() else 0.0
+  return d / max(s, 1e-30), 'abs %.3e scale %.3e' % (d, s)
+
+
+def report(name, a, b, exact=False):
+  if exact:
+    ok = torch.equal(a.detach().cpu(), b.detach().cpu())
+    RESULTS.append((name, 0.0 if ok else 1.0, 'bit-exact' if ok else 'NOT bit-exact'))
+  else:
+    e, info = err(a, b)
+    RESULTS.append((name, e, info))
+  print('%-58s rel %.3e  %s' % (RESULTS[-1][0], RESULTS[-1][1], RESULTS[-1][2]), flush=True)
+
+
+def section(fn):
+  t0 = time.time()
+  try:
+    fn()
+  except Exception:
+    print('!!! %s raised' % fn.__name__)
+    traceback.print_exc()
+    RESULTS.append((fn.__name__, float('inf'), 'EXCEPTION'))
+  torch.cuda.synchronize()
+  print('--- %s done in %.1fs' % (fn.__name__, time.time() - t0), flush=True)
+
+
+def conv_case(name, N, H, W, C0, C1, up1, Cout, k, stride, pad, bnact=False, seed=0):
+  g = torch.Generator().manual_seed(seed)
+  x0 = torch.randn(N, C0, H, W, generator=g)
+  xs = [x0]
+  if C1:
+    h1, w1 = (H // 2, W // 2) if up1 else (H, W)
+    x1 = torch.randn(N, C1, h1, w1, generator=g)
+    xs.append(x1)
+  Ct = C0 + C1
+  Wt = torch.randn(Cout, Ct, k, k, generator=g) / (Ct * k * k) ** 0.5
+  b = torch.randn(Cout, generator=g)
+  sc = sh = None
+  # CPU reference
+  xr = [t.clone().requires_grad_(True) for t in xs]
+  parts = [xr[0]]
+  if bnact:
+    sc = torch.rand(C0, generator=g) + 0.5
+    sh = torch.randn(C0, generator=g) * 0.3
+    parts[0] = F.leaky_relu(xr[0] * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), 0.2)
+  if C1:
+    parts.append(F.interpolate(xr[1], scale_factor=2, mode='nearest') if up1 else xr[1])
+  Wr, br = Wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+  y = F.conv2d(torch.cat(parts, 1), Wr, br, stride=stride, padding=pad)
+  gy = torch.randn(y.shape, generator=g)
+  y.backward(gy)
+  # HIP
+  nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(D)
+  srcs = [ops.nhwc_src(nhwc(xs[0]), 0, sc.to(D) if bnact else None, sh.to(D) if bnact else None, 0.2 if bnact else 1.0)]
+  if C1:
+    srcs.append(ops.nhwc_src(nhwc(xs[1]), 1 if up1 else 0))
+  d = ops.conv_desc(srcs, N, H, W, k, k, stride, pad)
+  Wp = Wt.permute(0, 2, 3, 1).contiguous().to(D)
+  out = torch.empty(N, d.out_h, d.out_w, Cout, device=D)
+  ops.conv2d_forward(d, Wp, Cout, b.to(D), out, Cout)
+  report(name + ' fwd', out.permute(0, 3, 1, 2), y)
+  gyd = nhwc(gy)
+  dw = torch.empty(Cout, k, k, Ct, device=D)
+  ops.conv2d_backward_weight(d, gyd, Cout, Cout, dw)
+  report(name + ' wgrad', dw.permute(0, 3, 1, 2), Wr.grad)
+  if not bnact:
+    dx0 = torch.empty(N, H, W, C0, device=D)
+    ops.conv2d_backward_data(d, Wp, Cout, gyd, Cout, 0, C0, dx0, C0)
+    report(name + ' dgrad0', dx0.permute(0, 3, 1, 2), xr[0].grad)
+  if C1:
+    dx1 = torch.empty(N, H, W, C1, device=D)
+    ops.conv2d_backward_data(d, Wp, Cout, gyd, Cout, C0, C1, dx1, C1)
+    ref = xr[1].grad
+    got = dx1.permute(0, 3, 1, 2)
+    if up1:
+      got = F.avg_pool2d(got.cpu(), 2) * 4
+    report(name + ' dgrad1', got, ref)
+
+
+def sec_conv():
+  conv_case('conv3x3 64->64 16x16 (tile64)', 2, 16, 16, 64, 0, 0, 64, 3, 1, 1)
+  conv_case('conv3x3 160+128up->128 16x16', 4, 16, 16, 160, 128, 1, 128, 3, 1, 1)
+  conv_case('conv3x3 bnact 128->256 8x8 splitK', 4, 8, 8, 128, 0, 0, 256, 3, 1, 1, bnact=True)
+  conv_case('conv3x3 32->64 64x64 (128x64 tile)', 4, 64, 64, 32, 0, 0, 64, 3, 1, 1)
+  conv_case('conv3x3 96->192 32x32 (128x128 tile)', 8, 32, 32, 96, 0, 0, 192, 3, 1, 1)
+  conv_case('conv4x4s2 3->64 valid 64x64 (VEC1)', 4, 64, 64, 3, 0, 0, 64, 4, 2, 0)
+  conv_case('conv4x4s2 64->128 valid 31x31', 4, 31, 31, 64, 0, 0, 128, 4, 2, 0)
+  conv_case('conv4x4s2 128->256 valid 14x14', 4, 14, 14, 128, 0, 0, 256, 4, 2, 0)
+  conv_case('conv3x3 160+1up->96 4x4 (VEC1 concat)', 4, 4, 4, 160, 1, 1, 96, 3, 1, 1)
+  conv_case('conv1x1 64->3 32x32', 2, 32, 32, 64, 0, 0, 3, 1, 1, 0)
+  conv_case('conv1x1 128->1 16x16', 8, 16, 16, 128, 0, 0, 1, 1, 1, 0)
+  conv_case('conv3x3 1184->512 8x8 (m1.conv0 shape)', 4, 8, 8, 160, 1024, 1, 512, 3, 1, 1)
+
+
+def sec_linear():
+  g = torch.Generator().manual_seed(1)
+  for (M, K, N) in ((203, 128, 512), (342, 512, 1152), (7, 20, 12), (300, 264, 512)):
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    xr, Wr, br = [t.clone().requires_grad_(True) for t in (x, W, b)]
+    y = F.relu(F.linear(xr, Wr, br))
+    gy = torch.randn(M, N, generator=g)
+    y.backward(gy)
+    xd, Wd, bd = [t.clone().to(D).requires_grad_(True) for t in (x, W, b)]
+    yd = HF.LinearAct.apply(xd, Wd, bd, 0.0)
+    yd.backward(gy.to(D))
+    tag = 'linear %dx%d->%d' % (M, K, N)
+    report(tag + ' fwd', yd, y)
+    report(tag + ' dx', xd.grad, xr.grad)
+    report(tag + ' dW', Wd.grad, Wr.grad)
+    report(tag + ' db', bd.grad, br.grad)
+
+
+def sec_pool():
+  g = torch.Generator().manual_seed(3)
+  for (T, O, H, Dd) in ((700, 9, 24, 8), (342, 203, 512, 128), (5, 4, 6, 3)):
+    new_t = torch.randn(T, 2 * H + Dd, generator=g) * 100
+    s = torch.randint(0, O, (T,), generator=g)
+    o = torch.randint(0, max(O - 1, 1), (T,), generator=g)
+    csr = ops.Csr(s.to(D), o.to(D), O)
+    nt = new_t.to(D)
+    for pooling in ('sum', 'avg'):
+      want, _ = orc.gconv_pool(new_t, s, o, O, H, Dd, pooling)
+      out = torch.empty(O, H, device=D)
+      ops.segment_sum(nt[:, :H], nt[:, H + Dd:], csr, H, pooling == 'avg', out)
+      report('pool %s T=%d O=%d H=%d' % (pooling, T, O, H), out, want, exact=True)
+    rp = csr.row_ptr.cpu()
+    cnt = torch.bincount(torch.cat([s, o]), minlength=O)
+    report('csr counts T=%d' % T, (rp[1:] - rp[:-1]).long(), cnt, exact=True)
+  tab = torch.randn(50, 16, generator=g)
+  idx = torch.randint(0, 50, (77,), generator=g)
+  report('gather rows', ops.gather_rows(tab.to(D), idx.to(D), torch.empty(77, 16, device=D)), tab[idx], exact=True)
+
+
+def sec_gconv():
+  g = torch.Generator().manual_seed(5)
+  batch = synthetic_batch(8, seed=2)
+  objs, triples = batch[1], batch[4]
+  O, T = objs.numel(), triples.size(0)
+  Din, H, Dout = 128, 512, 128
+  P = {}
+  orc._lin(P, 'g.net1.0', H, 3 * Din, g, True); orc._lin(P, 'g.net1.2', 2 * H + Dout, H, g, True)
+  orc._lin(P, 'g.net2.0', H, H, g, True); orc._lin(P, 'g.net2.2', Dout, H, g, True)
+  ov, pv = torch.randn(O, Din, generator=g), torch.randn(T, Din, generator=g)
+  edges = torch.stack([triples[:, 0], triples[:, 2]], 1)
+  Pl = hh.oracle_leafs(P)
+  ovr, pvr = ov.clone().requires_grad_(True), pv.clone().requires_grad_(True)
+  no, npd = orc.graph_triple_conv(Pl, 'g', ovr, pvr, edges, H, Dout, 'avg')
+  go, gp = torch.randn(O, Dout, generator=g), torch.randn(T, Dout, generator=g)
+  (no * go).sum().add((npd * gp).sum()).backward()
+  from sg2im_amd.graph import GraphTripleConv
+  m = GraphTripleConv(Din, Dout, H, 'avg')
+  hh.load_params(m, {k[2:]: v for k, v in P.items()})
+  m = m.to(D)
+  ovd, pvd = ov.to(D).requires_grad_(True), pv.to(D).requires_grad_(True)
+  nod, npdd = m(ovd, pvd, edges.to(D))
+  (nod * go.to(D)).sum().add((npdd * gp.to(D)).sum()).backward()
+  report('gconv obj out', nod, no); report('gconv pred out', npdd, npd)
+  report('gconv d obj', ovd.grad, ovr.grad); report('gconv d pred', pvd.grad, pvr.grad)
+  for k, p in m.named_parameters():
+    report('gconv d ' + k, p.grad, Pl['g.' + k].grad)
+
+
+def sec_layout():
+  g = torch.Generator().manual_seed(7)
+  for (N, S, Dd, M, tag) in ((4, 64, 128, 16, 'coco64'), (2, 32, 20, 8, 'odd')):
+    batch = synthetic_batch(N, image_size=(S, S), mask_size=M, seed=9)
+    imgs, objs, boxes, masks, triples, o2i, _ = batch
+    O = objs.numel()
+    vecs = torch.randn(O, Dd, generator=g)
+    soft = torch.rand(O, M, M, generator=g)
+    from sg2im_amd.layout import layout_nhwc
+    for name, mk in (('gtmask', masks), ('softmask', soft), ('boxes', None)):
+      vr = vecs.clone().requires_grad_(True)
+      mr = mk.clone().requires_grad_(True) if (mk is not None and mk.is_floating_point()) else mk
+      want = orc.masks_to_layout(vr, boxes, mr, o2i, S) if mk is not None else orc.boxes_to_layout(vr, boxes, o2i, S)
+      gl = torch.randn(want.shape, generator=g)
+      want.backward(gl)
+      vd = vecs.to(D).requires_grad_(True)
+      md = mk.to(D) if mk is not None else None
+      if md is not None and md.is_floating_point():
+        md.requires_grad_(True)
+      got = layout_nhwc(vd, boxes.to(D), md, o2i.to(D), S, n_images=N)
+      got.backward(gl.permute(0, 2, 3, 1).contiguous().to(D))
+      report('layout %s %s fwd' % (tag, name), got.permute(0, 3, 1, 2), want)
+      report('layout %s %s dvecs' % (tag, name), vd.grad, vr.grad)
+      if md is not None and md.is_floating_point():
+        report('layout %s %s dmasks' % (tag, name), md.grad, mr.grad)
+    # crops
+    ir = imgs.clone().requires_grad_(True)
+    want = orc.crop_bbox_batch(ir, boxes, o2i, 32)
+    gc = torch.randn(want.shape, generator=g)
+    want.backward(gc)
+    from sg2im_amd.bilinear import crop_bbox_batch
+    idv = imgs.to(D).requires_grad_(True)
+    got = crop_bbox_batch(idv, boxes.to(D), o2i.to(D), 32)
+    got.backward(gc.to(D))
+    report('crop %s fwd' % tag, got, want)
+    report('crop %s dimg' % tag, idv.grad, ir.grad)
+
+
+def sec_losses():
+  g = torch.Generator().manual_seed(11)
+  from sg2im_amd import losses as L
+  a, b = torch.randn(3, 5, 7, generator=g), torch.randn(3, 5, 7, generator=g)
+  for name, fn, ref in (('l1', L.l1_loss, F.l1_loss), ('mse', L.mse_loss, F.mse_loss)):
+    ar = a.clone().requires_grad_(True)
+    want = ref(ar, b) * 2.5
+    want.backward()
+    ad = a.to(D).requires_grad_(True)
+    got = fn(ad, b.to(D), 2.5)
+    got.backward()
+    report('loss %s' % name, got, want); report('loss %s grad' % name, ad.grad, ar.grad)
+  for t in (0.0, 1.0):
+    ar = a.clone().requires_grad_(True)
+    want = orc.bce_loss(ar.view(-1), torch.full((a.numel(),), t)) * 3
+    want.backward()
+    ad = a.to(D).requires_grad_(True)
+    got = L.bce_loss(ad, t) * 3
+    got.backward()
+    report('loss bce t=%g' % t, got, want); report('loss bce grad t=%g' % t, ad.grad, ar.grad)
+  s = torch.randn(203, 184, generator=g) * 3
+  y = torch.randint(0, 184, (203,), generator=g)
+  sr = s.clone().requires_grad_(True)
+  want = F.cross_entropy(sr, y)
+  want.backward()
+  sd = s.to(D).requires_grad_(True)
+  got = L.cross_entropy(sd, y.to(D))
+  got.backward()
+  report('loss ce', got, want); report('loss ce grad', sd.grad, sr.grad)
+  # adam
+  p, gr = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
+  pr = p.clone().requires_grad_(True)
+  opt = torch.optim.Adam([pr], lr=1e-2)
+  pd, m, v = p.to(D), torch.zeros(1000, device=D), torch.zeros(1000, device=D)
+  for step in (1, 2, 3):
+    pr.grad = gr * step
+    opt.step()
+    ops.adam_step(pd, (gr * step).to(D), m, v, 1e-2, 0.9, 0.999, 1e-8, step)
+  report('adam 3 steps', pd, pr)
+
+
+def golden_case(name):
+  fix = load_golden(name)
+  cfg = fix['config']
+  gcfg = dict(cfg['g'], vocab=fix['vocab'])
+  docfg = dict(cfg['d_obj'], vocab=fix['vocab'])
+  dicfg = dict(cfg['d_img'])
+  sd = fix['state_before']
+  G = hh.build_generator(gcfg, sd['G']); Do = hh.build_d_obj(docfg, sd['Do']); Di = hh.build_d_img(dicfg, sd['Di'])
+  for m in (G, Do, Di):
+    m.train()
+  imgs, objs, boxes, masks, triples, o2i = [hh.to_dev(t) for t in fix['batch'][:6]]
+  from sg2im_amd import losses as L
+  w = fix['weights']
+  with hh.fixed_noise(fix['noise']):
+    out = G(objs, triples, o2i, boxes_gt=boxes, masks_gt=masks, num_images=imgs.size(0))
+  ip, bp, mp, rs = out
+  W = fix['outputs']
+  report(name + ' imgs_pred', ip, W['imgs_pred']); report(name + ' boxes_pred', bp, W['boxes_pred'])
+  report(name + ' masks_pred', mp, W['masks_pred']); report(name + ' rel_scores', rs, W['rel_scores'])
+  l1 = L.l1_loss(ip, imgs, w['l1']); lb = L.mse_loss(bp, boxes, w['bbox'])
+  sf, ac = Do(ip, objs, boxes, o2i)
+  report(name + ' d_obj scores', sf, W['d_obj_scores_fake'])
+  sfi = Di(ip)
+  report(name + ' d_img scores', sfi, W['d_img_scores_fake'])
+  total = l1 + lb + ac * w['ac'] + L.gan_g_loss(sf) * (w['d'] * w['d_obj']) + L.gan_g_loss(sfi) * (w['d'] * w['d_img'])
+  report(name + ' total loss', total, torch.tensor(fix['losses']['total']))
+  total.backward()
+  for k, gref in fix['grads']['G'].items():
+    got = dict(G.named_parameters())[k].grad
+    if gref is None:
+      RESULTS.append((name + ' G.grad ' + k, 0.0 if got is None else float(got.abs().max()), 'expect None'))
+      continue
+    if got is None:
+      RESULTS.append((name + ' G.grad ' + k, float('inf'), 'MISSING')); print('MISSING grad', k); continue
+    report(name + ' G.grad ' + k, got, gref)
+  for k, v in fix['state_after_g_forward']['G'].items():
+    report(name + ' G.buf ' + k, G.state_dict()[k].float(), v.float())
+  fake = ip.detach()
+  Do.zero_grad(); Di.zero_grad()
+  sf, acf = Do(fake, objs, boxes, o2i); sr, acr = Do(imgs, objs, boxes, o2i)
+  ld = L.gan_d_loss(sr, sf) + acr + acf
+  report(name + ' d_obj loss', ld, torch.tensor(fix['losses']['d_obj']))
+  ld.backward()
+  for k, gref in fix['grads']['Do'].items():
+    report(name + ' Do.grad ' + k, dict(Do.named_parameters())[k].grad, gref)
+  li = L.gan_d_loss(Di(imgs), Di(fake))
+  report(name + ' d_img loss', li, torch.tensor(fix['losses']['d_img']))
+  li.backward()
+  for k, gref in fix['grads']['Di'].items():
+    if gref is not None:
+      report(name + ' Di.grad ' + k, dict(Di.named_parameters())[k].grad, gref)
+
+
+def sec_golden_coco():
+  golden_case('tiny_coco')
+
+
+def sec_golden_vg():
+  golden_case('tiny_vg')
+
+
+if __name__ == '__main__':
+  print(torch.cuda.get_device_name(0))
+  only = sys.argv[1:]
+  for fn in (sec_pool, sec_linear, sec_conv, sec_gconv, sec_layout, sec_losses, sec_golden_coco, sec_golden_vg):
+    if not only or fn.__name__ in only:
+      section(fn)
+  bad = [r for r in RESULTS if not (r[1] <= 1e-4)]
+  print('\n==== %d checks, %d above 1e-4 ====' % (len(RESULTS), len(bad)))
+  for r in bad:
+    print('BAD %-58s %.3e %s' % r)
