@@ -1,0 +1,166 @@
+"""bench.py - training images/sec of one full G+D step (reference scripts/train.py:524-592)
+on MI355X.
+
+  python bench.py --gpus 1 --steps 30 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8d "C1"): 64x64 COCO-shape synthetic
+scene graphs (3..8 objects + __image__ per image, <= 16 triples), batch 32 PER GPU (weak
+scaling), fp32, generator kwargs = the reference's train.py defaults, both discriminators,
+three Adam optimisers.  Inputs are resident in HBM before the timed region starts.
+
+Prints ONE JSON line on rank 0: the driver's contract fields plus
+  roofline     - the implicit-GEMM (conv + linear) kernel family against the fp32 MFMA peak,
+                 measured live with HIP events on the launch stream in a separate
+                 instrumented pass of the same step (events would otherwise serialise the
+                 timed region);
+  cpu_baseline - the CPU oracle (oracle/sg2im_oracle.py, a torch-CPU restatement of the
+                 reference loop body) timed on this host's cores on the same batch.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=30)
+  ap.add_argument('--warmup', type=int, default=5)
+  ap.add_argument('--batch_size', type=int, default=32, help='images per GPU (reference default, train.py:51)')
+  ap.add_argument('--image_size', type=int, default=64)
+  ap.add_argument('--cpu_baseline_steps', type=int, default=3, help='0 disables the CPU-oracle leg')
+  ap.add_argument('--no_roofline', action='store_true')
+  ap.add_argument('--seed', type=int, default=0)
+  return ap.parse_args()
+
+
+def cpu_baseline(vocab, batch, steps):
+  """Oracle ('port' of the reference loop body) on the host cores, same batch."""
+  from oracle import sg2im_oracle as orc
+  from sg2im_amd.trainer import GENERATOR_DEFAULTS, D_OBJ_DEFAULTS, D_IMG_DEFAULTS
+  gcfg = dict(GENERATOR_DEFAULTS, vocab=vocab)
+  docfg = dict(D_OBJ_DEFAULTS, vocab=vocab)
+  dicfg = dict(D_IMG_DEFAULTS)
+  tr = orc.OracleTrainer(orc.init_generator_params(gcfg, 0), orc.init_ac_discriminator_params(docfg, 2),
+                         orc.init_patch_discriminator_params(dicfg, 1), gcfg, docfg, dicfg)
+  cpu_batch = tuple(batch[:6])
+  tr.step(cpu_batch)                    # warm-up (MKL-DNN primitive caches)
+  t0 = time.time()
+  for _ in range(steps):
+    tr.step(cpu_batch)
+  dt = (time.time() - t0) / steps
+  return {'value': round(cpu_batch[0].size(0) / dt, 2), 'unit': 'images/sec', 'cores': torch.get_num_threads(),
+          'kind': 'port',
+          'sample': '%d warm G+D steps of the same batch-%d COCO-64 workload (%.2f s/step)' % (
+            steps, cpu_batch[0].size(0), dt)}
+
+
+def main():
+  args = parse()
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world != args.gpus:
+    if world == 1 and args.gpus > 1:
+      raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+  if not torch.cuda.is_available():
+    raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
+  torch.cuda.set_device(local_rank)
+  device = torch.device('cuda', local_rank)
+  if world > 1:
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+
+  from sg2im_amd import ops
+  from sg2im_amd.synthetic import make_vocab, synthetic_batch
+  from sg2im_amd.trainer import Trainer
+
+  S = args.image_size
+  vocab = make_vocab(184, 7)            # COCO-Stuff: 184 object ids incl. __image__, 7 predicates
+  cpu_batch = synthetic_batch(args.batch_size, image_size=(S, S), num_objs=184, num_preds=7, min_objs=3,
+                              max_objs=8, mask_size=16, style='coco', seed=args.seed + rank)
+  batch = tuple(t.to(device) if torch.is_tensor(t) else t for t in cpu_batch)
+  trainer = Trainer(vocab, device, generator_kwargs={'image_size': (S, S)}, world_size=world, seed=1234)
+
+  def sync():
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+      torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    trainer.step(batch)
+  sync()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    losses = trainer.step(batch)
+  sync()
+  elapsed = time.perf_counter() - t0
+  if world > 1:
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+  host_losses = Trainer.losses_to_host(losses)
+
+  roofline = None
+  if rank == 0 and not args.no_roofline:
+    # instrumented pass: HIP events around every implicit-GEMM launch of 3 more steps
+    ops.TIMER = ops.KernelTimer()
+    n_prof = 3
+    for _ in range(n_prof):
+      trainer.step(batch)
+    summ = ops.TIMER.summary()
+    ops.TIMER = None
+    flops = sum(v['flops'] for v in summ.values())
+    ms = sum(v['ms'] for v in summ.values())
+    launches = sum(v['launches'] for v in summ.values())
+    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    roofline = {
+      'bound': 'mfma', 'kernel': 'implicit-GEMM family conv_fwd/dgrad/wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32)',
+      'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+      'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+      'launches_per_step': launches // n_prof, 'gflop_per_step': round(flops / n_prof / 1e9, 1),
+      'ms_per_step_in_kernel': round(ms / n_prof, 3),
+      'by_kind': {k: {'launches_per_step': v['launches'] // n_prof, 'gflop_per_step': round(v['flops'] / n_prof / 1e9, 1),
+                      'ms_per_step': round(v['ms'] / n_prof, 3),
+                      'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else 0.0}
+                  for k, v in summ.items()},
+    }
+  if world > 1:
+    dist.barrier()
+
+  if rank == 0:
+    cpu = None
+    if world == 1 and args.cpu_baseline_steps > 0:
+      cpu = cpu_baseline(vocab, cpu_batch, args.cpu_baseline_steps)
+    imgs = args.batch_size * world * args.steps
+    out = {
+      'metric': 'training images/sec (G+D step)', 'value': round(imgs / elapsed, 2), 'unit': 'images/sec',
+      'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+      'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+      'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+      'config': {'workload': 'COCO-%d synthetic scene graphs (3-8 objects + __image__, <=16 triples per image), '
+                             'batch %d per GPU, full G + D_obj + D_img step with 3x Adam' % (S, args.batch_size),
+                 'global_batch': args.batch_size * world, 'image_size': S,
+                 'objects': int(batch[1].numel()), 'triples': int(batch[4].size(0)),
+                 'parallelism': 'dp%d' % world, 'total_loss': round(host_losses['total_loss'], 5)},
+      'roofline': roofline, 'cpu_baseline': cpu,
+    }
+    print(json.dumps(out), flush=True)
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -218,6 +218,14 @@ int sg2im_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
                     float lr, float beta1, float beta2, float eps, int step, float grad_scale,
                     hipStream_t stream);
 
+/* Same update with the step counter on the device: state = float[4] {step, step_size,
+ * 1/sqrt(bias_correction2), applied}, zero-initialised by the caller.  If guard != NULL and
+ * guard[0] is not finite the whole update (and the step counter) is skipped - the
+ * device-side form of "if not math.isfinite(total_loss): continue" (scripts/train.py:553-555). */
+int sg2im_adam_step_guarded(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                            long long n, float lr, float beta1, float beta2, float eps,
+                            float grad_scale, float* state, const float* guard, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

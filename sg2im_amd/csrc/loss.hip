@@ -110,6 +110,43 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+// Guarded variant: the step counter lives on the device and only advances when the
+// guard scalar (the generator's total loss) is finite - the device-side form of the
+// reference's "if not math.isfinite(total_loss): continue" (scripts/train.py:553-555),
+// which needs a host sync there.  state[0] = step count (as float), state[1] = step_size,
+// state[2] = 1/sqrt(bias_correction2), state[3] = 1.0 if this step is applied else 0.0.
+__global__ void adam_prepare_kernel(float* __restrict__ state, const float* __restrict__ guard, float lr,
+                                    float b1, float b2) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const bool ok = guard ? isfinite(guard[0]) : true;
+    if (ok) {
+      const float t = state[0] + 1.f;
+      state[0] = t;
+      const double bc1 = 1.0 - pow((double)b1, (double)t);
+      const double bc2 = 1.0 - pow((double)b2, (double)t);
+      state[1] = (float)((double)lr / bc1);
+      state[2] = (float)(1.0 / sqrt(bc2));
+    }
+    state[3] = ok ? 1.f : 0.f;
+  }
+}
+
+__global__ void adam_guarded_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                    float* __restrict__ v, long long n, float one_minus_b1, float b2,
+                                    float one_minus_b2, const float* __restrict__ state, float eps, float gscale) {
+  if (state[3] == 0.f) return;
+  const float step_size = state[1], inv_bc2_sqrt = state[2];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    const float mi = m[i] + (gi - m[i]) * one_minus_b1;
+    const float vi = v[i] * b2 + gi * gi * one_minus_b2;
+    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+    m[i] = mi; v[i] = vi;
+  }
+}
+
 static inline int ok_or(hipError_t e) { return e == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP; }
 
 template <int KIND>
@@ -177,3 +214,17 @@ int sg2im_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
 }
 
 }  // extern "C"
+
+extern "C" int sg2im_adam_step_guarded(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                       long long n, float lr, float beta1, float beta2, float eps,
+                                       float grad_scale, float* state, const float* guard,
+                                       hipStream_t stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !state) return SG2IM_ERR_ARG;
+  hipLaunchKernelGGL(sg2im::adam_prepare_kernel, dim3(1), dim3(64), 0, stream, state, guard, lr, beta1, beta2);
+  if (n > 0) {
+    const int blocks = (int)std::min<long long>((n + 255) / 256, 16384);
+    hipLaunchKernelGGL(sg2im::adam_guarded_kernel, dim3(blocks), dim3(256), 0, stream, param, grad, exp_avg,
+                       exp_avg_sq, n, 1.f - beta1, beta2, 1.f - beta2, state, eps, grad_scale);
+  }
+  return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+}

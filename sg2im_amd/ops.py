@@ -117,24 +117,66 @@ def conv_desc(srcs, batch, in_h, in_w, kh=1, kw=1, stride=1, pad=0):
   return d
 
 
+class KernelTimer(object):
+  """Optional HIP-event timing of the implicit-GEMM launches (bench.py's roofline leg).
+  Events are recorded on the stream the kernels are launched on (torch's current stream),
+  so ``elapsed_time`` is the device-side duration of the launch (incl. its split-K finish)."""
+
+  def __init__(self):
+    self.records = []        # (kind, flops, start_event, end_event)
+
+  def summary(self):
+    torch.cuda.synchronize()
+    out = {}
+    for kind, flops, e0, e1 in self.records:
+      d = out.setdefault(kind, {'launches': 0, 'flops': 0.0, 'ms': 0.0})
+      d['launches'] += 1
+      d['flops'] += flops
+      d['ms'] += e0.elapsed_time(e1)
+    return out
+
+
+TIMER = None     # set to a KernelTimer to time every conv / linear launch
+
+
+def _timed(kind, flops, fn):
+  if TIMER is None:
+    return fn()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  fn()
+  e1.record()
+  TIMER.records.append((kind, flops, e0, e1))
+
+
+def _desc_k(desc):
+  return desc.kh * desc.kw * sum(desc.src[i].channels for i in range(desc.nsrc))
+
+
 def conv2d_forward(desc, weight, cout, bias, out, ld_out, out_slope=1.0, accumulate=False):
   ws = workspace(out.device)
-  call('sg2im_conv2d_forward', byref(desc), _f(weight), int(cout), _f(bias), float(out_slope), _f(out),
-       int(ld_out), int(accumulate), _f(ws), ws.numel() * 4, _stream())
+  flops = 2.0 * desc.batch * desc.out_h * desc.out_w * cout * _desc_k(desc)
+  _timed('igemm_fwd', flops, lambda: call(
+    'sg2im_conv2d_forward', byref(desc), _f(weight), int(cout), _f(bias), float(out_slope), _f(out),
+    int(ld_out), int(accumulate), _f(ws), ws.numel() * 4, _stream()))
   return out
 
 
 def conv2d_backward_data(desc, weight, cout, dy, ld_dy, c_begin, c_count, dx, ld_dx, accumulate=False):
   ws = workspace(dx.device)
-  call('sg2im_conv2d_backward_data', byref(desc), _f(weight), int(cout), _f(dy), int(ld_dy), int(c_begin),
-       int(c_count), _f(dx), int(ld_dx), int(accumulate), _f(ws), ws.numel() * 4, _stream())
+  flops = 2.0 * desc.batch * desc.out_h * desc.out_w * cout * desc.kh * desc.kw * c_count
+  _timed('igemm_dgrad', flops, lambda: call(
+    'sg2im_conv2d_backward_data', byref(desc), _f(weight), int(cout), _f(dy), int(ld_dy), int(c_begin),
+    int(c_count), _f(dx), int(ld_dx), int(accumulate), _f(ws), ws.numel() * 4, _stream()))
   return dx
 
 
 def conv2d_backward_weight(desc, dy, ld_dy, cout, dweight, accumulate=False):
   ws = workspace(dweight.device)
-  call('sg2im_conv2d_backward_weight', byref(desc), _f(dy), int(ld_dy), int(cout), _f(dweight),
-       int(accumulate), _f(ws), ws.numel() * 4, _stream())
+  flops = 2.0 * desc.batch * desc.out_h * desc.out_w * cout * _desc_k(desc)
+  _timed('igemm_wgrad', flops, lambda: call(
+    'sg2im_conv2d_backward_weight', byref(desc), _f(dy), int(ld_dy), int(cout), _f(dweight),
+    int(accumulate), _f(ws), ws.numel() * 4, _stream()))
   return dweight
 
 
@@ -375,3 +417,10 @@ def scale_by_scalar(x, a_dev, out):
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale=1.0):
   call('sg2im_adam_step', _f(param), _f(grad), _f(exp_avg), _f(exp_avg_sq), param.numel(), float(lr),
        float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _stream())
+
+
+def adam_step_guarded(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, state, guard, grad_scale=1.0):
+  """Adam with the step counter in ``state`` (float[4] on the device); skipped entirely
+  when ``guard`` (a device scalar, e.g. the generator loss) is not finite."""
+  call('sg2im_adam_step_guarded', _f(param), _f(grad), _f(exp_avg), _f(exp_avg_sq), param.numel(), float(lr),
+       float(beta1), float(beta2), float(eps), float(grad_scale), _f(state), _f(guard), _stream())

@@ -1,0 +1,90 @@
+"""Flat parameter arenas + fused Adam.
+
+All parameters of a network live in ONE contiguous fp32 HBM buffer (and their gradients
+in a second one), so the optimiser is a single HIP kernel launch over the arena
+(sg2im_adam_step) and a data-parallel gradient exchange is one RCCL all-reduce over one
+buffer - instead of the reference's per-tensor torch.optim.Adam loop
+(scripts/train.py:426-443, ~150 tensors for the generator).
+"""
+import torch
+
+from . import ops
+
+
+class FlatParams(object):
+  """Re-homes every parameter of ``module`` into one flat buffer (values preserved, conv
+  weights keep their channels_last strides) and gives every parameter a ``.grad`` view
+  into a flat gradient buffer, which autograd then accumulates into in place."""
+
+  def __init__(self, module):
+    params = [p for p in module.parameters()]
+    if not params:
+      raise ValueError('module has no parameters')
+    dev = params[0].device
+    offs, total = [], 0
+    for p in params:
+      offs.append(total)
+      total += (p.numel() + 3) // 4 * 4            # keep every tensor 16-byte aligned
+    self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+    self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+    self.params, self.offsets = params, offs
+    with torch.no_grad():
+      for p, off in zip(params, offs):
+        view = self._view(self.flat, p, off)
+        view.copy_(p.data)
+        p.data = view
+        p.grad = self._view(self.grad, p, off)
+    self.numel = total
+
+  @staticmethod
+  def _view(buf, p, off):
+    # same sizes/strides as the parameter (dense, possibly permuted) on top of the arena
+    return torch.as_strided(buf, p.size(), p.stride(), off)
+
+  def zero_grad(self):
+    self.grad.zero_()
+    for p, off in zip(self.params, self.offsets):
+      if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
+        p.grad = self._view(self.grad, p, off)
+
+
+class FlatAdam(object):
+  """torch.optim.Adam(lr, betas=(0.9, 0.999), eps=1e-8) over a FlatParams arena.  A
+  parameter that never receives a gradient keeps g = m = v = 0 and is left untouched,
+  like a ``grad is None`` parameter that torch.optim.Adam skips."""
+
+  def __init__(self, flat, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+    self.flat, self.lr, self.betas, self.eps = flat, lr, betas, eps
+    self.exp_avg = torch.zeros_like(flat.flat)
+    self.exp_avg_sq = torch.zeros_like(flat.flat)
+    self.t = 0
+    self.state = torch.zeros(4, dtype=torch.float32, device=flat.flat.device)   # device-side step counter
+
+  def zero_grad(self):
+    self.flat.zero_grad()
+
+  def reset_state(self):
+    """a fresh optimiser (the reference re-creates Adam when the generator switches to
+    eval mode, scripts/train.py:509-512)"""
+    self.exp_avg.zero_()
+    self.exp_avg_sq.zero_()
+    self.state.zero_()
+    self.t = 0
+
+  def step(self, grad_scale=1.0):
+    self.t += 1
+    ops.adam_step(self.flat.flat, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0],
+                  self.betas[1], self.eps, self.t, grad_scale)
+
+  def step_guarded(self, guard, grad_scale=1.0):
+    """Apply the update unless the device scalar ``guard`` is non-finite (no host sync)."""
+    ops.adam_step_guarded(self.flat.flat, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0],
+                          self.betas[1], self.eps, self.state, guard, grad_scale)
+
+  def state_dict(self):
+    return {'t': self.t, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq, 'lr': self.lr}
+
+  def load_state_dict(self, sd):
+    self.t = sd['t']
+    self.exp_avg.copy_(sd['exp_avg'])
+    self.exp_avg_sq.copy_(sd['exp_avg_sq'])

@@ -1,0 +1,152 @@
+"""One G + D training iteration of the reference loop body (scripts/train.py:524-592) on
+MI355X, data parallel over whole images with RCCL.
+
+Differences from the reference that do not change the mathematics:
+  * images are converted to NHWC once per step; every kernel works in NHWC;
+  * the discriminators are frozen while the generator's loss is back-propagated - the
+    reference deposits gradients in the D parameters there (train.py:559) and throws them
+    away with the next zero_grad (train.py:577,590);
+  * losses stay on the device: no ``.item()`` per loss (train.py:145,552; utils.py:88);
+  * ``num_images`` is passed down, removing the host sync of layout.py:143;
+  * under data parallelism the gradient of every network is summed with one all-reduce
+    over its flat gradient arena and scaled by 1/world_size inside the Adam kernel.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import functional as HF
+from . import losses as L
+from .discriminators import AcCropDiscriminator, PatchDiscriminator
+from .model import Sg2ImModel
+from .optim import FlatAdam, FlatParams
+
+GENERATOR_DEFAULTS = dict(         # reference scripts/train.py:94-104
+  image_size=(64, 64), embedding_dim=128, gconv_dim=128, gconv_hidden_dim=512, gconv_num_layers=5,
+  mlp_normalization='none', refinement_dims=(1024, 512, 256, 128, 64), normalization='batch',
+  activation='leakyrelu-0.2', mask_size=16, layout_noise_dim=32)
+D_OBJ_DEFAULTS = dict(arch='C4-64-2,C4-128-2,C4-256-2', normalization='batch', activation='leakyrelu-0.2',
+                      padding='valid', object_size=32)           # train.py:117-125
+D_IMG_DEFAULTS = dict(arch='C4-64-2,C4-128-2,C4-256-2', normalization='batch', activation='leakyrelu-0.2',
+                      padding='valid')                           # train.py:117-130
+LOSS_WEIGHTS = dict(l1_pixel_loss_weight=1.0, bbox_pred_loss_weight=10.0, predicate_pred_loss_weight=0.0,
+                    mask_loss_weight=0.0, discriminator_loss_weight=0.01, d_obj_weight=1.0, d_img_weight=1.0,
+                    ac_loss_weight=0.1)                          # train.py:108-131
+
+
+def _set_requires_grad(module, flag):
+  for p in module.parameters():
+    p.requires_grad_(flag)
+
+
+class Trainer(object):
+  def __init__(self, vocab, device, generator_kwargs=None, d_obj_kwargs=None, d_img_kwargs=None,
+               loss_weights=None, learning_rate=1e-4, world_size=1, seed=None):
+    self.device = device
+    self.world_size = world_size
+    if seed is not None:
+      torch.manual_seed(seed)            # identical initial weights on every rank
+    gk = dict(GENERATOR_DEFAULTS)
+    gk.update(generator_kwargs or {})
+    dok = dict(D_OBJ_DEFAULTS)
+    dok.update(d_obj_kwargs or {})
+    dik = dict(D_IMG_DEFAULTS)
+    dik.update(d_img_kwargs or {})
+    self.model_kwargs = dict(gk, vocab=vocab)
+    self.d_obj_kwargs = dict(dok, vocab=vocab)
+    self.d_img_kwargs = dik
+    self.w = dict(LOSS_WEIGHTS)
+    self.w.update(loss_weights or {})
+    if self.w['predicate_pred_loss_weight'] > 0 or self.w['mask_loss_weight'] > 0:
+      raise NotImplementedError('predicate / mask auxiliary losses (default weight 0) are not wired yet')
+    self.model = Sg2ImModel(vocab, **gk).to(device)
+    self.d_obj = AcCropDiscriminator(vocab, **dok).to(device)
+    self.d_img = PatchDiscriminator(**dik).to(device)
+    for m in (self.model, self.d_obj, self.d_img):
+      m.train()
+    self.flat_g, self.flat_do, self.flat_di = FlatParams(self.model), FlatParams(self.d_obj), FlatParams(self.d_img)
+    self.opt_g = FlatAdam(self.flat_g, lr=learning_rate)
+    self.opt_do = FlatAdam(self.flat_do, lr=learning_rate)
+    self.opt_di = FlatAdam(self.flat_di, lr=learning_rate)
+    self.t = 0
+
+  # -- data-parallel helpers --------------------------------------------------
+  def _allreduce(self, flat):
+    if self.world_size > 1:
+      dist.all_reduce(flat.grad)
+
+  def set_generator_eval(self):
+    """reference scripts/train.py:509-512: eval-mode BN for G and a fresh Adam"""
+    self.model.eval()
+    self.opt_g.reset_state()
+
+  # -- one iteration ----------------------------------------------------------
+  def step(self, batch):
+    """batch: (imgs (N,3,H,W), objs, boxes, masks | None, triples, obj_to_img) on the device.
+    Returns a dict of 0-dim device tensors (no host sync)."""
+    imgs, objs, boxes, masks, triples, obj_to_img = batch[:6]
+    w = self.w
+    N = imgs.size(0)
+    gs = 1.0 / self.world_size
+    self.t += 1
+    imgs_nhwc = HF.NchwToNhwc.apply(imgs)
+
+    # ---- generator (train.py:524-560)
+    _set_requires_grad(self.d_obj, False)
+    _set_requires_grad(self.d_img, False)
+    imgs_pred, boxes_pred, masks_pred, rel_scores = self.model.forward_nhwc(
+      objs, triples, obj_to_img, boxes_gt=boxes, masks_gt=masks, num_images=N)
+    losses = {}
+    losses['L1_pixel_loss'] = L.l1_loss(imgs_pred, imgs_nhwc, w['l1_pixel_loss_weight'])
+    losses['bbox_pred'] = L.mse_loss(boxes_pred, boxes, w['bbox_pred_loss_weight'])
+    scores_fake, ac_loss = self.d_obj.forward_nhwc(imgs_pred, objs, boxes, obj_to_img)
+    losses['ac_loss'] = ac_loss * w['ac_loss_weight']
+    losses['g_gan_obj_loss'] = L.gan_g_loss(scores_fake) * (w['discriminator_loss_weight'] * w['d_obj_weight'])
+    scores_fake = self.d_img.forward_nhwc(imgs_pred)
+    losses['g_gan_img_loss'] = L.gan_g_loss(scores_fake) * (w['discriminator_loss_weight'] * w['d_img_weight'])
+    total = None
+    for v in losses.values():
+      total = v if total is None else total + v
+    losses['total_loss'] = total
+    self.opt_g.zero_grad()
+    total.backward()
+    self._allreduce(self.flat_g)
+    # NaN guard of train.py:553-555 without a host sync: every optimiser of this iteration
+    # skips its update when the generator loss is not finite (on any rank)
+    guard = total.detach().reshape(1).clone()
+    if self.world_size > 1:
+      dist.all_reduce(guard)
+    self.opt_g.step_guarded(guard, gs)
+
+    # ---- object discriminator (train.py:566-579)
+    _set_requires_grad(self.d_obj, True)
+    imgs_fake = imgs_pred.detach()
+    sf, ac_fake = self.d_obj.forward_nhwc(imgs_fake, objs, boxes, obj_to_img)
+    sr, ac_real = self.d_obj.forward_nhwc(imgs_nhwc, objs, boxes, obj_to_img)
+    losses['d_obj_gan_loss'] = L.gan_d_loss(sr, sf)
+    losses['d_ac_loss_real'], losses['d_ac_loss_fake'] = ac_real, ac_fake
+    d_obj_total = losses['d_obj_gan_loss'] + ac_real + ac_fake
+    self.opt_do.zero_grad()
+    d_obj_total.backward()
+    self._allreduce(self.flat_do)
+    self.opt_do.step_guarded(guard, gs)
+
+    # ---- image discriminator (train.py:581-592)
+    _set_requires_grad(self.d_img, True)
+    sf = self.d_img.forward_nhwc(imgs_fake)
+    sr = self.d_img.forward_nhwc(imgs_nhwc)
+    losses['d_img_gan_loss'] = L.gan_d_loss(sr, sf)
+    self.opt_di.zero_grad()
+    losses['d_img_gan_loss'].backward()
+    self._allreduce(self.flat_di)
+    self.opt_di.step_guarded(guard, gs)
+    return {k: v.detach() for k, v in losses.items()}
+
+  @staticmethod
+  def losses_to_host(losses):
+    """one host sync for a whole dict (call at print_every, train.py:594-609)"""
+    out = {k: float(v) for k, v in losses.items()}
+    if not math.isfinite(out.get('total_loss', 0.0)):
+      print('WARNING: Got loss = NaN')       # the reference skips the update (train.py:553-555)
+    return out
