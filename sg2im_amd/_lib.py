@@ -85,6 +85,11 @@ def load():
     raise Sg2imHipError(
       'libsg2im_hip.so not found at %s - build it with `python -m sg2im_amd.build` '
       '(or __graft_entry__.build()); the HIP path has no fallback' % LIB_PATH)
+  # torch must own the process' HIP runtime: it bundles its own libamdhip64 and the device
+  # pointers / streams we are handed come from that instance.  Importing torch first makes
+  # our library's libamdhip64 dependency resolve to the already-loaded copy.
+  import torch  # noqa: F401
+  torch.cuda.is_available()
   lib = ctypes.CDLL(LIB_PATH)
   for name, argtypes in _SIGNATURES.items():
     fn = getattr(lib, name)          # AttributeError if the symbol is not exported

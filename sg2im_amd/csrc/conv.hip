@@ -29,11 +29,12 @@ struct FwdParams {
 };
 
 struct DgradParams {
-  ConvGeom g;       // geometry of the *forward* conv; g.src[0] describes dY: p, C=Cout, ld
+  ConvGeom g;       // geometry of the *forward* conv; g.s0 describes dY: p, C=Cout, ld
   const float* Wt;
   int c_begin, Nc;  // input-channel range [c_begin, c_begin+Nc) produced by this launch
-  int M;            // NB*H*W
-  int iters, nch;
+  int M;            // NB*H*W (rows of the largest parity class when parity != 0)
+  int iters, nch;   // (parity == 0) total K iterations / chunks per tap
+  int parity;       // 1: stride-2 parity decomposition, blockIdx.z = class (no split-K)
   Epi e;
 };
 
@@ -80,6 +81,8 @@ __device__ __forceinline__ void zero_acc(f32x16& a) {
   for (int r = 0; r < 16; ++r) a[r] = 0.f;
 }
 
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
 // K-chunk `ch` (within one tap) -> source, its first concat channel, chunk base
 __device__ __forceinline__ void locate_chunk(const ConvGeom& g, int ch, int& s, int& cstart, int& cb) {
   const int n0 = (g.s0.C + BK - 1) / BK, n1 = (g.s1.C + BK - 1) / BK, n2 = (g.s2.C + BK - 1) / BK;
@@ -90,6 +93,11 @@ __device__ __forceinline__ void locate_chunk(const ConvGeom& g, int ch, int& s, 
   cb = ch * BK;
 }
 
+#define SG2IM_ZERO_ACC()                                   \
+  f32x16 acc[BM / 64][BN / 64];                            \
+  _Pragma("unroll") for (int a_ = 0; a_ < BM / 64; ++a_)   \
+    _Pragma("unroll") for (int b_ = 0; b_ < BN / 64; ++b_) zero_acc(acc[a_][b_]);
+
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NVA = BM / 32, NVB = BN / 32;
   constexpr int AF = LdsTile<BM, false>::FLOATS, BF = LdsTile<BN, false>::FLOATS;
-  constexpr int STAGE = AF + BF;            // stage s: A at smem + s*STAGE, B right behind it
+  constexpr int STAGE = AF + BF;
   const ConvGeom& g = p.g;
   const int tid = threadIdx.x;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, split = blockIdx.z;
@@ -123,8 +131,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
     }
   }
 
-  float4 ra[NVA], rb[NVB];
-  auto load = [&](int it) {
+  float4 ra0[NVA], rb0[NVB], ra1[NVA], rb1[NVB];
+  auto load_into = [&](int it, float4 (&ra)[NVA], float4 (&rb)[NVB]) {
     if (VEC == 4) {
       const int tap = it / p.nch;
       int s, cstart, cb;
@@ -137,14 +145,13 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
       for (int i = 0; i < NVA; ++i) {
         const int hi = rhb[i] + kh, wi = rwb[i] + kw;
         const bool ok = cok && rn[i] >= 0 && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-        ra[i] = ok ? load4(g, S, rn[i], hi, wi, c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ra[i] = ok ? load4(g, S, rn[i], hi, wi, c) : zero4();
       }
       const long long wcol = (long long)tap * g.Ctot + cstart + c;
       #pragma unroll
       for (int i = 0; i < NVB; ++i) {
         const int n = n0 + r0 + 32 * i;
-        rb[i] = (cok && n < p.Cout) ? *reinterpret_cast<const float4*>(p.Wt + (long long)n * ldw + wcol)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[i] = (cok && n < p.Cout) ? *reinterpret_cast<const float4*>(p.Wt + (long long)n * ldw + wcol) : zero4();
       }
     } else {
       float av[NVA][4], bv[NVB][4];
@@ -177,73 +184,101 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
     }
   };
 
-  f32x16 acc[BM / 64][BN / 64];
-  #pragma unroll
-  for (int a = 0; a < BM / 64; ++a)
-    #pragma unroll
-    for (int b = 0; b < BN / 64; ++b) zero_acc(acc[a][b]);
-
+  SG2IM_ZERO_ACC()
   int wm0, wn0, lane;
   wave_origin<BM, BN>(tid, wm0, wn0, lane);
 
-  if (it_begin < it_end) {
-    load(it_begin);
-    store_tile<BM, false>(smem, ra, tid);
-    store_tile<BN, false>(smem + AF, rb, tid);
-    __syncthreads();
-    int cur = 0;
-    for (int it = it_begin; it < it_end; ++it) {
-      const bool more = it + 1 < it_end;
-      if (more) load(it + 1);
-      mma_chunk<BM, BN, false, false>(smem + cur * STAGE, smem + cur * STAGE + AF, wm0, wn0, lane, acc);
-      if (more) {
-        store_tile<BM, false>(smem + (cur ^ 1) * STAGE, ra, tid);
-        store_tile<BN, false>(smem + (cur ^ 1) * STAGE + AF, rb, tid);
+  k_pipeline(it_begin, it_end,
+    [&](int it, auto set) {
+      if constexpr (decltype(set)::value == 0) load_into(it, ra0, rb0); else load_into(it, ra1, rb1);
+    },
+    [&](auto set, int B_) {
+      if constexpr (decltype(set)::value == 0) {
+        store_tile<BM, false>(smem + B_ * STAGE, ra0, tid);
+        store_tile<BN, false>(smem + B_ * STAGE + AF, rb0, tid);
+      } else {
+        store_tile<BM, false>(smem + B_ * STAGE, ra1, tid);
+        store_tile<BN, false>(smem + B_ * STAGE + AF, rb1, tid);
       }
-      __syncthreads();
-      cur ^= 1;
-    }
-  }
+    },
+    [&](int B_) {
+      mma_chunk<BM, BN, false, false>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, acc);
+    });
   epilogue<BM, BN>(p.e, p.M, p.Cout, p.Cout, m0, n0, wm0, wn0, lane, split, acc);
 }
 
 // ---------------------------------------------------------------------------
 // data gradient (transposed convolution of dY with the same weights)
+// VA: vector width of the dY loads (4 needs Cout % 4 == 0), VB: of the weight loads
+// (4 needs Ctot, c_begin, c_count % 4 == 0).  VA == 1 implies the flat-K enumeration.
+//
+// parity mode (stride 2): an input pixel (h, w) only sees the taps with
+// kh = (h + pad) mod 2 (mod 2) - the other taps hit no output pixel.  The rows are
+// therefore split into the 4 classes (h mod 2, w mod 2), blockIdx.z = class, and each
+// class runs a dense stride-1 problem over its KH/2 x KW/2 live taps: 4x fewer MFMAs
+// than sweeping all taps with zero operands.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int VEC>
+struct ParityRow {
+  int H, W, Hc, Wc, ph, pw;
+  __device__ __forceinline__ long long operator()(int m) const {
+    const int hw = Hc * Wc;
+    const int n = m / hw, rem = m - n * hw;
+    const int hp = rem / Wc, wp = rem - hp * Wc;
+    return ((long long)n * H + 2 * hp + ph) * W + 2 * wp + pw;
+  }
+};
+
+template <int BM, int BN, int VA, int VB>
 __global__ __launch_bounds__(NTHREADS) void conv_dgrad_kernel(const DgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NVA = BM / 32, NVB = BN / 32;
   constexpr int AF = LdsTile<BM, false>::FLOATS, BF = LdsTile<BN, true>::FLOATS;
-  constexpr int STAGE = AF + BF;            // stage s: A at smem + s*STAGE, B right behind it
+  constexpr int STAGE = AF + BF;
   const ConvGeom& g = p.g;
   const int tid = threadIdx.x;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, split = blockIdx.z;
-  const int per = (p.iters + p.e.nsplit - 1) / p.e.nsplit;
-  const int it_begin = split * per;
-  const int it_end = min(p.iters, it_begin + per);
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int col4 = tid & 7, r0 = tid >> 3;
   const int taps = g.KH * g.KW;
   const int ldw = taps * g.Ctot;
   const int Cout = g.s0.C, ldy = g.s0.ld;
   const float* dY = g.s0.p;
+
+  // row space, live taps and K range of this workgroup
+  int split = 0, ph = 0, pw = 0, Hc = g.H, Wc = g.W, kh0 = 0, kw0 = 0, nkw = g.KW, kstep = 1;
+  int M = p.M, iters = p.iters, nch = p.nch;
+  if (p.parity) {
+    const int cls = blockIdx.z;
+    ph = cls >> 1; pw = cls & 1;
+    Hc = (g.H - ph + 1) >> 1; Wc = (g.W - pw + 1) >> 1;
+    M = g.NB * Hc * Wc;
+    kh0 = (ph + g.pad) & 1; kw0 = (pw + g.pad) & 1; kstep = 2;
+    const int nkh = (g.KH - kh0 + 1) >> 1;
+    nkw = (g.KW - kw0 + 1) >> 1;
+    nch = (Cout + BK - 1) / BK;
+    iters = nkh * nkw * nch;
+    if (m0 >= M) return;
+  } else {
+    split = blockIdx.z;
+  }
+  const int per = (iters + p.e.nsplit - 1) / p.e.nsplit;
+  const int it_begin = split * per;
+  const int it_end = min(iters, it_begin + per);
   const int Ktot = taps * Cout;
 
-  // A rows are *input* pixels (n, h, w)
+  // A rows are *input* pixels (n, h, w); stored pre-shifted by the padding
   int rn[NVA], rh[NVA], rw[NVA];
   {
-    const int HW = g.H * g.W;
+    const int HW = Hc * Wc;
     #pragma unroll
     for (int i = 0; i < NVA; ++i) {
       const int m = m0 + r0 + 32 * i;
-      if (m < p.M) {
+      if (m < M) {
         const int n = m / HW, rem = m - n * HW;
-        rn[i] = n; rh[i] = rem / g.W; rw[i] = rem - rh[i] * g.W;
-        rh[i] += g.pad; rw[i] += g.pad;
+        const int hp = rem / Wc, wp = rem - hp * Wc;
+        rn[i] = n; rh[i] = hp * kstep + ph + g.pad; rw[i] = wp * kstep + pw + g.pad;
       } else { rn[i] = -1; rh[i] = 0; rw[i] = 0; }
     }
   }
-  // B thread mapping (k-major tile [BK][BN])
   constexpr int Q = BN / 4;
   const int bcol4 = tid % Q, bk0 = tid / Q;
 
@@ -260,26 +295,34 @@ __global__ __launch_bounds__(NTHREADS) void conv_dgrad_kernel(const DgradParams 
     return true;
   };
 
-  float4 ra[NVA], rb[NVB];
-  auto load = [&](int it) {
-    if (VEC == 4) {
-      const int tap = it / p.nch, cb = (it - tap * p.nch) * BK;
-      const int kh = tap / g.KW, kw = tap - kh * g.KW;
+  float4 ra0[NVA], rb0[NVB], ra1[NVA], rb1[NVB];
+  auto load_into = [&](int it, float4 (&ra)[NVA], float4 (&rb)[NVB]) {
+    if (VA == 4) {
+      const int t = it / nch, cb = (it - t * nch) * BK;
+      const int th = t / nkw;
+      const int kh = kh0 + kstep * th, kw = kw0 + kstep * (t - th * nkw);
+      const int tap = kh * g.KW + kw;
       const int co = cb + 4 * col4;
       const bool cok = co < Cout;
       #pragma unroll
       for (int i = 0; i < NVA; ++i) {
         long long row;
         const bool ok = cok && out_pixel(i, kh, kw, row);
-        ra[i] = ok ? *reinterpret_cast<const float4*>(dY + row * ldy + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ra[i] = ok ? *reinterpret_cast<const float4*>(dY + row * ldy + co) : zero4();
       }
       const int nn = n0 + 4 * bcol4;
       #pragma unroll
       for (int i = 0; i < NVB; ++i) {
         const int cok2 = cb + bk0 + (1024 / BN) * i;
-        rb[i] = (cok2 < Cout && nn < p.Nc)
-                  ? *reinterpret_cast<const float4*>(p.Wt + (long long)cok2 * ldw + (long long)tap * g.Ctot + p.c_begin + nn)
-                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* wrow = p.Wt + (long long)cok2 * ldw + (long long)tap * g.Ctot + p.c_begin;
+        if (VB == 4) {
+          rb[i] = (cok2 < Cout && nn < p.Nc) ? *reinterpret_cast<const float4*>(wrow + nn) : zero4();
+        } else {
+          float bv[4];
+          #pragma unroll
+          for (int j = 0; j < 4; ++j) bv[j] = (cok2 < Cout && nn + j < p.Nc) ? wrow[nn + j] : 0.f;
+          rb[i] = make_float4(bv[0], bv[1], bv[2], bv[3]);
+        }
       }
     } else {
       float av[NVA][4];
@@ -315,34 +358,31 @@ __global__ __launch_bounds__(NTHREADS) void conv_dgrad_kernel(const DgradParams 
     }
   };
 
-  f32x16 acc[BM / 64][BN / 64];
-  #pragma unroll
-  for (int a = 0; a < BM / 64; ++a)
-    #pragma unroll
-    for (int b = 0; b < BN / 64; ++b) zero_acc(acc[a][b]);
-
+  SG2IM_ZERO_ACC()
   int wm0, wn0, lane;
   wave_origin<BM, BN>(tid, wm0, wn0, lane);
 
-  if (it_begin < it_end) {
-    load(it_begin);
-    store_tile<BM, false>(smem, ra, tid);
-    store_tile<BN, true>(smem + AF, rb, tid);
-    __syncthreads();
-    int cur = 0;
-    for (int it = it_begin; it < it_end; ++it) {
-      const bool more = it + 1 < it_end;
-      if (more) load(it + 1);
-      mma_chunk<BM, BN, false, true>(smem + cur * STAGE, smem + cur * STAGE + AF, wm0, wn0, lane, acc);
-      if (more) {
-        store_tile<BM, false>(smem + (cur ^ 1) * STAGE, ra, tid);
-        store_tile<BN, true>(smem + (cur ^ 1) * STAGE + AF, rb, tid);
+  k_pipeline(it_begin, it_end,
+    [&](int it, auto set) {
+      if constexpr (decltype(set)::value == 0) load_into(it, ra0, rb0); else load_into(it, ra1, rb1);
+    },
+    [&](auto set, int B_) {
+      if constexpr (decltype(set)::value == 0) {
+        store_tile<BM, false>(smem + B_ * STAGE, ra0, tid);
+        store_tile<BN, true>(smem + B_ * STAGE + AF, rb0, tid);
+      } else {
+        store_tile<BM, false>(smem + B_ * STAGE, ra1, tid);
+        store_tile<BN, true>(smem + B_ * STAGE + AF, rb1, tid);
       }
-      __syncthreads();
-      cur ^= 1;
-    }
+    },
+    [&](int B_) {
+      mma_chunk<BM, BN, false, true>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, acc);
+    });
+  if (p.parity) {
+    epilogue<BM, BN>(p.e, M, p.Nc, p.Nc, m0, n0, wm0, wn0, lane, 0, acc, ParityRow{g.H, g.W, Hc, Wc, ph, pw});
+  } else {
+    epilogue<BM, BN>(p.e, M, p.Nc, p.Nc, m0, n0, wm0, wn0, lane, split, acc);
   }
-  epilogue<BM, BN>(p.e, p.M, p.Nc, p.Nc, m0, n0, wm0, wn0, lane, split, acc);
 }
 
 // ---------------------------------------------------------------------------
@@ -353,7 +393,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NVA = BM / 32, NVB = BN / 32;
   constexpr int AF = LdsTile<BM, true>::FLOATS, BF = LdsTile<BN, true>::FLOATS;
-  constexpr int STAGE = AF + BF;            // stage s: A at smem + s*STAGE, B right behind it
+  constexpr int STAGE = AF + BF;
   const ConvGeom& g = p.g;
   const int tid = threadIdx.x;
   const int m0 = blockIdx.y * BM, split = blockIdx.z;
@@ -397,15 +437,15 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams 
     }
   }
 
-  float4 ra[NVA], rb[NVB];
-  auto load = [&](int it) {
+  float4 ra0[NVA], rb0[NVB], ra1[NVA], rb1[NVB];
+  auto load_into = [&](int it, float4 (&ra)[NVA], float4 (&rb)[NVB]) {
     #pragma unroll
     for (int i = 0; i < NVA; ++i) {
       const int pix = it * BK + ak0 + (1024 / BM) * i;
       const int co = m0 + 4 * acol4;
       if (VEC == 4) {
         ra[i] = (pix < p.P && co < p.Cout) ? *reinterpret_cast<const float4*>(p.dY + (long long)pix * p.ldy + co)
-                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                                               : zero4();
       } else {
         float v[4];
         #pragma unroll
@@ -416,7 +456,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams 
     #pragma unroll
     for (int i = 0; i < NVB; ++i) {
       const int pix = it * BK + bk0 + (1024 / BN) * i;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 v = zero4();
       if (pix < p.P) {
         const int n = pix / HoWo, rem = pix - n * HoWo;
         const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
@@ -439,33 +479,26 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams 
     }
   };
 
-  f32x16 acc[BM / 64][BN / 64];
-  #pragma unroll
-  for (int a = 0; a < BM / 64; ++a)
-    #pragma unroll
-    for (int b = 0; b < BN / 64; ++b) zero_acc(acc[a][b]);
-
+  SG2IM_ZERO_ACC()
   int wm0, wn0, lane;
   wave_origin<BM, BN>(tid, wm0, wn0, lane);
 
-  if (it_begin < it_end) {
-    load(it_begin);
-    store_tile<BM, true>(smem, ra, tid);
-    store_tile<BN, true>(smem + AF, rb, tid);
-    __syncthreads();
-    int cur = 0;
-    for (int it = it_begin; it < it_end; ++it) {
-      const bool more = it + 1 < it_end;
-      if (more) load(it + 1);
-      mma_chunk<BM, BN, true, true>(smem + cur * STAGE, smem + cur * STAGE + AF, wm0, wn0, lane, acc);
-      if (more) {
-        store_tile<BM, true>(smem + (cur ^ 1) * STAGE, ra, tid);
-        store_tile<BN, true>(smem + (cur ^ 1) * STAGE + AF, rb, tid);
+  k_pipeline(it_begin, it_end,
+    [&](int it, auto set) {
+      if constexpr (decltype(set)::value == 0) load_into(it, ra0, rb0); else load_into(it, ra1, rb1);
+    },
+    [&](auto set, int B_) {
+      if constexpr (decltype(set)::value == 0) {
+        store_tile<BM, true>(smem + B_ * STAGE, ra0, tid);
+        store_tile<BN, true>(smem + B_ * STAGE + AF, rb0, tid);
+      } else {
+        store_tile<BM, true>(smem + B_ * STAGE, ra1, tid);
+        store_tile<BN, true>(smem + B_ * STAGE + AF, rb1, tid);
       }
-      __syncthreads();
-      cur ^= 1;
-    }
-  }
+    },
+    [&](int B_) {
+      mma_chunk<BM, BN, true, true>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, acc);
+    });
   // columns of this tile are [n0, n0 + ncols): in VEC=4 mode clip to the tap's channels
   const int ncols_end = (VEC == 4) ? tap0 * g.Ctot + g.Ctot : Ntot;
   epilogue<BM, BN>(p.e, p.Cout, Ntot, ncols_end, m0, n0, wm0, wn0, lane, split, acc);
@@ -546,8 +579,16 @@ static int check_desc(const sg2im_conv_desc* d) {
   return 0;
 }
 
-// choose split-K so that tiles * nsplit fills the chip, bounded by work and workspace
-static int choose_split(long long tiles, int iters, long long MN, size_t ws_bytes, int min_iters) {
+// ---- tile / split-K choice ------------------------------------------------------------
+// Candidates: 0 -> 128x128, 1 -> 128x64, 2 -> 64x64, 3 -> 64x128.  A launch should put >= 2 workgroups
+// on each of the 256 CUs; small problems get there through smaller tiles and split-K
+// (partials in the workspace, combined by splitk_finish_kernel).
+struct Plan { int tile, bm, bn, nsplit; long long tiles; };
+
+static const int kBM[4] = {128, 128, 64, 64}, kBN[4] = {128, 64, 64, 128};
+static const double kEff[4] = {1.0, 0.92, 0.80, 0.90};   // relative MFMA efficiency of the tile shapes
+
+static int split_for(long long tiles, int iters, long long MN, size_t ws_bytes, int min_iters) {
   const long long target = 2LL * g_num_cu;
   int ns = 1;
   if (tiles < target) ns = (int)((target + tiles - 1) / tiles);
@@ -560,6 +601,27 @@ static int choose_split(long long tiles, int iters, long long MN, size_t ws_byte
     ns = (iters + per - 1) / per;
   }
   return ns;
+}
+
+// ntn(bn): number of N tiles for tile width bn (wgrad tiles N per tap)
+template <typename NT>
+static Plan make_plan(long long M, long long N, int iters, long long MN, size_t ws_bytes, bool can_split,
+                      int min_iters, bool only64, NT ntn) {
+  Plan best{2, 64, 64, 1, 0};
+  double best_score = -1.0;
+  for (int t = 0; t < 4; ++t) {
+    if (only64 && t != 2) continue;
+    const long long tm = (M + kBM[t] - 1) / kBM[t], tn = ntn(kBN[t]);
+    const long long tiles = tm * tn;
+    const int ns = can_split ? split_for(tiles, iters, MN, ws_bytes, min_iters) : 1;
+    const double useful = (double)(M * N) / (double)(tiles * kBM[t] * kBN[t]);
+    const double blocks = (double)tiles * ns;
+    const double fill = blocks >= 2.0 * g_num_cu ? 1.0 : blocks / (2.0 * g_num_cu);
+    const double split_cost = ns > 1 ? 0.93 : 1.0;
+    const double score = kEff[t] * useful * fill * split_cost;
+    if (score > best_score) { best_score = score; best = Plan{t, kBM[t], kBN[t], ns, tiles}; }
+  }
+  return best;
 }
 
 static hipError_t finish_split(const Epi& e, long long M, int N, hipStream_t st) {
@@ -581,13 +643,13 @@ static hipError_t launch_fwd(FwdParams& p, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <int BM, int BN, int VEC>
+template <int BM, int BN, int VA, int VB>
 static hipError_t launch_dgrad(DgradParams& p, hipStream_t st) {
   constexpr size_t lds = 2 * (LdsTile<BM, false>::FLOATS + LdsTile<BN, true>::FLOATS) * sizeof(float);
   static bool once = false;
-  if (!once) { hipError_t e = ensure_lds(conv_dgrad_kernel<BM, BN, VEC>, lds); if (e != hipSuccess) return e; once = true; }
-  dim3 grid((p.Nc + BN - 1) / BN, (p.M + BM - 1) / BM, p.e.nsplit);
-  hipLaunchKernelGGL((conv_dgrad_kernel<BM, BN, VEC>), grid, dim3(NTHREADS), lds, st, p);
+  if (!once) { hipError_t e = ensure_lds(conv_dgrad_kernel<BM, BN, VA, VB>, lds); if (e != hipSuccess) return e; once = true; }
+  dim3 grid((p.Nc + BN - 1) / BN, (p.M + BM - 1) / BM, p.parity ? 4 : p.e.nsplit);
+  hipLaunchKernelGGL((conv_dgrad_kernel<BM, BN, VA, VB>), grid, dim3(NTHREADS), lds, st, p);
   return hipGetLastError();
 }
 
@@ -599,14 +661,6 @@ static hipError_t launch_wgrad(WgradParams& p, int ntiles_n, hipStream_t st) {
   dim3 grid(ntiles_n, (p.Cout + BM - 1) / BM, p.e.nsplit);
   hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, VEC>), grid, dim3(NTHREADS), lds, st, p);
   return hipGetLastError();
-}
-
-// tile choice: 0 -> 128x128, 1 -> 128x64, 2 -> 64x64
-static int choose_tile(long long M, int N) {
-  if (N <= 64) return (M >= 128 * 64) ? 1 : 2;
-  const long long t128 = ((M + 127) / 128) * ((N + 127) / 128);
-  if (t128 >= g_num_cu / 2) return 0;
-  return 2;
 }
 
 }  // namespace sg2im
@@ -634,15 +688,13 @@ int sg2im_conv2d_forward(const sg2im_conv_desc* d, const float* weight, int cout
     p.nch = 0;
     p.iters = (taps * p.g.Ctot + BK - 1) / BK;
   }
-  const int tile = choose_tile(p.M, cout);
-  const int bm = tile == 2 ? 64 : 128, bn = tile == 0 ? 128 : 64;
-  const long long tiles = ((long long)(p.M + bm - 1) / bm) * ((cout + bn - 1) / bn);
-  p.e = Epi{out, ld_out, bias, out_slope, accumulate, workspace, 1};
-  p.e.nsplit = workspace ? choose_split(tiles, p.iters, (long long)p.M * cout, workspace_bytes, 4) : 1;
+  const Plan pl = make_plan(p.M, cout, p.iters, (long long)p.M * cout, workspace_bytes, workspace != nullptr, 4, !v4,
+                            [&](int bn) { return (long long)(cout + bn - 1) / bn; });
+  p.e = Epi{out, ld_out, bias, out_slope, accumulate, workspace, pl.nsplit};
   hipError_t err;
   if (v4) {
-    err = tile == 0 ? launch_fwd<128, 128, 4>(p, stream) : tile == 1 ? launch_fwd<128, 64, 4>(p, stream)
-                                                                      : launch_fwd<64, 64, 4>(p, stream);
+    err = pl.tile == 0 ? launch_fwd<128, 128, 4>(p, stream) : pl.tile == 1 ? launch_fwd<128, 64, 4>(p, stream)
+        : pl.tile == 2 ? launch_fwd<64, 64, 4>(p, stream) : launch_fwd<64, 128, 4>(p, stream);
   } else {
     err = launch_fwd<64, 64, 1>(p, stream);
   }
@@ -657,7 +709,7 @@ int sg2im_conv2d_backward_data(const sg2im_conv_desc* d, const float* weight, in
   if (!d || !weight || !dy || !dx || cout < 1 || c_count < 1 || ld_dy < cout) return SG2IM_ERR_ARG;
   if (check_desc(d)) return SG2IM_ERR_ARG;
   DgradParams p;
-  // geometry (and Ctot) of the forward conv; src[0] is then re-purposed to carry dY
+  // geometry (and Ctot) of the forward conv; s0 is then re-purposed to carry dY
   ConvGeom& g = p.g;
   fill_geom(g, d);
   g.nsrc = 1;
@@ -665,27 +717,45 @@ int sg2im_conv2d_backward_data(const sg2im_conv_desc* d, const float* weight, in
   g.s0.p = dy; g.s0.C = cout; g.s0.ld = ld_dy;
   if (c_begin < 0 || c_begin + c_count > g.Ctot) return SG2IM_ERR_ARG;
   p.Wt = weight; p.c_begin = c_begin; p.Nc = c_count;
-  p.M = d->batch * d->in_h * d->in_w;
-  if (p.M == 0) return SG2IM_OK;
+  const long long Mfull = (long long)d->batch * d->in_h * d->in_w;
+  if (Mfull == 0) return SG2IM_OK;
   const int taps = d->kh * d->kw;
-  const bool v4 = (cout % 4 == 0) && (ld_dy % 4 == 0) && !((uintptr_t)dy & 15) && (g.Ctot % 4 == 0) &&
-                  (c_begin % 4 == 0) && (c_count % 4 == 0) && !((uintptr_t)weight & 15);
-  if (v4) { p.nch = (cout + BK - 1) / BK; p.iters = taps * p.nch; }
+  const bool va4 = (cout % 4 == 0) && (ld_dy % 4 == 0) && !((uintptr_t)dy & 15);
+  const bool vb4 = (g.Ctot % 4 == 0) && (c_begin % 4 == 0) && (c_count % 4 == 0) && !((uintptr_t)weight & 15);
+  // stride-2 parity decomposition: needs the chunked (VA=4) K enumeration and writes every
+  // destination row exactly once, so it is not combined with split-K
+  p.parity = (d->stride == 2 && va4 && d->kh >= 2 && d->kw >= 2) ? 1 : 0;
+  if (va4) { p.nch = (cout + BK - 1) / BK; p.iters = taps * p.nch; }
   else { p.nch = 0; p.iters = (taps * cout + BK - 1) / BK; }
-  const int tile = choose_tile(p.M, c_count);
-  const int bm = tile == 2 ? 64 : 128, bn = tile == 0 ? 128 : 64;
-  const long long tiles = ((long long)(p.M + bm - 1) / bm) * ((c_count + bn - 1) / bn);
-  p.e = Epi{dx, ld_dx, nullptr, 1.f, accumulate, workspace, 1};
-  p.e.nsplit = workspace ? choose_split(tiles, p.iters, (long long)p.M * c_count, workspace_bytes, 4) : 1;
+  long long Mrows = Mfull;
+  int iters_eff = p.iters;
+  if (p.parity) {
+    Mrows = (long long)d->batch * ((d->in_h + 1) / 2) * ((d->in_w + 1) / 2);     // largest class
+    iters_eff = ((d->kh + 1) / 2) * ((d->kw + 1) / 2) * p.nch;
+  }
+  p.M = (int)Mrows;
+  Plan pl = make_plan(Mrows, c_count, iters_eff, Mfull * c_count, workspace_bytes,
+                      workspace != nullptr && !p.parity, 4, !va4,
+                      [&](int bn) { return (long long)(c_count + bn - 1) / bn; });
+  if (va4 && !vb4 && (pl.tile == 0 || pl.tile == 3)) {      // narrow scalar-B outputs: 64-wide tiles only
+    const int t = pl.tile == 0 ? 1 : 2;
+    pl = Plan{t, kBM[t], kBN[t], 1, 0};
+    if (!p.parity && workspace)
+      pl.nsplit = split_for(((Mrows + pl.bm - 1) / pl.bm) * ((c_count + 63) / 64), iters_eff, Mfull * c_count,
+                            workspace_bytes, 4);
+  }
+  p.e = Epi{dx, ld_dx, nullptr, 1.f, accumulate, workspace, pl.nsplit};
   hipError_t err;
-  if (v4) {
-    err = tile == 0 ? launch_dgrad<128, 128, 4>(p, stream) : tile == 1 ? launch_dgrad<128, 64, 4>(p, stream)
-                                                                        : launch_dgrad<64, 64, 4>(p, stream);
+  if (va4 && vb4) {
+    err = pl.tile == 0 ? launch_dgrad<128, 128, 4, 4>(p, stream) : pl.tile == 1 ? launch_dgrad<128, 64, 4, 4>(p, stream)
+        : pl.tile == 2 ? launch_dgrad<64, 64, 4, 4>(p, stream) : launch_dgrad<64, 128, 4, 4>(p, stream);
+  } else if (va4) {
+    err = pl.tile == 2 ? launch_dgrad<64, 64, 4, 1>(p, stream) : launch_dgrad<128, 64, 4, 1>(p, stream);
   } else {
-    err = launch_dgrad<64, 64, 1>(p, stream);
+    err = launch_dgrad<64, 64, 1, 1>(p, stream);
   }
   if (err != hipSuccess) return SG2IM_ERR_HIP;
-  return finish_split(p.e, p.M, c_count, stream) == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+  return finish_split(p.e, Mfull, c_count, stream) == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
 }
 
 int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int ld_dy, int cout,
@@ -699,29 +769,27 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
   const int taps = d->kh * d->kw;
   const int Ntot = taps * p.g.Ctot;
   if (p.P == 0) {
-    if (!accumulate && hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)cout * Ntot, stream) != hipSuccess) return SG2IM_ERR_HIP;
+    if (!accumulate && hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)cout * Ntot, stream) != hipSuccess)
+      return SG2IM_ERR_HIP;
     return SG2IM_OK;
   }
   p.iters = (p.P + BK - 1) / BK;
   const bool v4 = geom_vec4(p.g) && (cout % 4 == 0) && (ld_dy % 4 == 0) && !((uintptr_t)dy & 15);
-  // tile: M = cout, N = Ntot
-  int tile;
-  if (cout <= 64) tile = 2;
-  else if (p.g.Ctot <= 64) tile = 1;
-  else tile = 0;
-  if (!v4) tile = 2;
-  const int bm = tile == 2 ? 64 : 128, bn = tile == 0 ? 128 : 64;
+  const int Ctot = p.g.Ctot;
+  const Plan pl = make_plan(cout, Ntot, p.iters, (long long)cout * Ntot, workspace_bytes, workspace != nullptr, 2,
+                            !v4, [&](int bn) {
+                              return v4 ? (long long)taps * ((Ctot + bn - 1) / bn) : (long long)(Ntot + bn - 1) / bn;
+                            });
   int ntiles_n;
-  if (v4) { p.ntile_c = (p.g.Ctot + bn - 1) / bn; ntiles_n = taps * p.ntile_c; }
-  else { p.ntile_c = 0; ntiles_n = (Ntot + bn - 1) / bn; }
-  const long long tiles = (long long)ntiles_n * ((cout + bm - 1) / bm);
-  p.e = Epi{dweight, (long long)Ntot, nullptr, 1.f, accumulate, workspace, 1};
-  p.e.nsplit = workspace ? choose_split(tiles, p.iters, (long long)cout * Ntot, workspace_bytes, 8) : 1;
+  if (v4) { p.ntile_c = (Ctot + pl.bn - 1) / pl.bn; ntiles_n = taps * p.ntile_c; }
+  else { p.ntile_c = 0; ntiles_n = (Ntot + pl.bn - 1) / pl.bn; }
+  p.e = Epi{dweight, (long long)Ntot, nullptr, 1.f, accumulate, workspace, pl.nsplit};
   hipError_t err;
   if (v4) {
-    err = tile == 0 ? launch_wgrad<128, 128, 4>(p, ntiles_n, stream)
-        : tile == 1 ? launch_wgrad<128, 64, 4>(p, ntiles_n, stream)
-                    : launch_wgrad<64, 64, 4>(p, ntiles_n, stream);
+    err = pl.tile == 0 ? launch_wgrad<128, 128, 4>(p, ntiles_n, stream)
+        : pl.tile == 1 ? launch_wgrad<128, 64, 4>(p, ntiles_n, stream)
+        : pl.tile == 2 ? launch_wgrad<64, 64, 4>(p, ntiles_n, stream)
+                       : launch_wgrad<64, 128, 4>(p, ntiles_n, stream);
   } else {
     err = launch_wgrad<64, 64, 1>(p, ntiles_n, stream);
   }

@@ -168,10 +168,14 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ As, const fl
 // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31,
 // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 // ---------------------------------------------------------------------------
-template <int BM, int BN>
+struct IdentityRow { __device__ __forceinline__ long long operator()(int m) const { return m; } };
+
+// `rowmap` turns a tile-local GEMM row into the destination row (identity except for the
+// stride-2 parity classes of the data gradient); split-K partials are not remapped.
+template <int BM, int BN, typename RowMap = IdentityRow>
 __device__ __forceinline__ void epilogue(const Epi& e, int M, int N, int nlimit, int m0, int n0, int wm0,
                                          int wn0, int lane, int split,
-                                         const f32x16 (&acc)[BM / 64][BN / 64]) {
+                                         const f32x16 (&acc)[BM / 64][BN / 64], RowMap rowmap = RowMap()) {
   constexpr int TM = BM / 64, TN = BN / 64;
   const int j = lane & 31, h = lane >> 5;
   #pragma unroll
@@ -190,12 +194,65 @@ __device__ __forceinline__ void epilogue(const Epi& e, int M, int N, int nlimit,
           e.ws[((long long)split * M + m) * N + n] = v;
         } else {
           v = leaky(v + bv, e.slope);
-          float* dst = e.C + (long long)m * e.ldc + n;
+          float* dst = e.C + rowmap(m) * e.ldc + n;
           if (e.accumulate) v += *dst;
           *dst = v;
         }
       }
     }
+  }
+}
+
+// Software pipeline shared by the three kernels: two K-chunks of global loads are kept in
+// flight in registers (sets 0/1) while the matrix cores work on the chunk staged in LDS,
+// so a load has two chunk-times (~4-8k cycles) to land instead of one.
+//   load(it, set)   : global -> register set        stage(set, buf) : registers -> LDS buffer
+//   mma(buf)        : one BK chunk of MFMAs out of LDS buffer `buf`
+// (register sets / LDS buffers are selected by compile-time tags so the register arrays are
+// never dynamically indexed, which would demote them to scratch)
+template <int I> struct IC { static constexpr int value = I; };
+
+template <typename Load, typename Stage, typename Mma>
+__device__ __forceinline__ void k_pipeline(int it_begin, int it_end, Load load, Stage stage, Mma mma) {
+  const int n = it_end - it_begin;
+  if (n <= 0) return;
+  load(it_begin, IC<0>());
+  if (n > 1) load(it_begin + 1, IC<1>());
+  stage(IC<0>(), 0);
+  __syncthreads();
+  // ONE mma call site (runtime LDS buffer index): with the MFMA block instantiated twice
+  // hipcc gives each copy its own accumulator registers and doubles the AGPR budget.
+  // The loads / stages exist twice (wave-uniform branch on the chunk parity) so that each
+  // copy addresses its register set statically.
+  #pragma unroll 1
+  for (int i = 0; i < n; ++i) {
+    const int par = i & 1;
+    // (the distinct asm markers keep hipcc from merging the two branch bodies back into
+    // one copy that selects the register set through a pointer, i.e. through scratch)
+    if (i + 2 < n) {
+      if (par == 0) {
+        asm volatile("; k_pipeline: load set 0" ::: "memory");
+        load(it_begin + i + 2, IC<0>());
+        asm volatile("; k_pipeline: load set 0 done" ::: "memory");
+      } else {
+        asm volatile("; k_pipeline: load set 1" ::: "memory");
+        load(it_begin + i + 2, IC<1>());
+        asm volatile("; k_pipeline: load set 1 done" ::: "memory");
+      }
+    }
+    mma(par);
+    if (i + 1 < n) {
+      if (par == 0) {
+        asm volatile("; k_pipeline: stage set 1" ::: "memory");
+        stage(IC<1>(), 1);
+        asm volatile("; k_pipeline: stage set 1 done" ::: "memory");
+      } else {
+        asm volatile("; k_pipeline: stage set 0" ::: "memory");
+        stage(IC<0>(), 0);
+        asm volatile("; k_pipeline: stage set 0 done" ::: "memory");
+      }
+    }
+    __syncthreads();
   }
 }
 

@@ -55,6 +55,21 @@ __device__ __forceinline__ void channel_reduce2(int C, long long rows, float* pa
   }
 }
 
+// second stage: one wavefront per channel strides over the row-block partials and finishes
+// with a shuffle tree in double (fixed order -> deterministic); every lane gets the totals
+__device__ __forceinline__ void wave_partial_sums(const float* __restrict__ partial, int nblk, int C, int c,
+                                                  double& s0, double& s1) {
+  const int lane = threadIdx.x & 63;
+  double a = 0.0, b = 0.0;
+  for (int i = lane; i < nblk; i += 64) {
+    a += (double)partial[((long long)i * 2) * C + c];
+    b += (double)partial[((long long)i * 2 + 1) * C + c];
+  }
+  #pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+  s0 = a; s1 = b;
+}
+
 __global__ void bn_stats_partial_kernel(const float* __restrict__ x, long long rows, int C, long long ld,
                                         float* __restrict__ partial) {
   channel_reduce2(C, rows, partial, [&](long long r, int c, float& s0, float& s1) {
@@ -71,17 +86,17 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ partial, int nbl
                                       long long* __restrict__ nbt, float* __restrict__ mean,
                                       float* __restrict__ invstd, float* __restrict__ scale,
                                       float* __restrict__ shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && training && nbt) *nbt += 1;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);     // one wavefront per channel
+  if (c == 0 && (threadIdx.x & 63) == 0 && training && nbt) *nbt += 1;
   if (c >= C) return;
   double mu, var;
   if (training) {
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += partial[((long long)b * 2) * C + c]; ss += partial[((long long)b * 2 + 1) * C + c]; }
+    double s, ss;
+    wave_partial_sums(partial, nblk, C, c, s, ss);
     mu = s / (double)rows;
     var = ss / (double)rows - mu * mu;
     if (var < 0.0) var = 0.0;
-    if (running_mean) {
+    if (running_mean && (threadIdx.x & 63) == 0) {
       const double nu = (double)(unbiased_rows > 0 ? unbiased_rows : rows);
       const double unbiased = nu > 1.0 ? var * nu / (nu - 1.0) : var;
       running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
@@ -90,6 +105,7 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ partial, int nbl
   } else {
     mu = running_mean[c]; var = running_var[c];
   }
+  if ((threadIdx.x & 63) != 0) return;
   const float is = (float)(1.0 / sqrt(var + (double)eps));
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
   mean[c] = (float)mu; invstd[c] = is;
@@ -126,10 +142,11 @@ __global__ void bn_bwd_final_kernel(const float* __restrict__ partial, int nblk,
                                     const float* __restrict__ gamma, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, int training, float* __restrict__ dgamma,
                                     float* __restrict__ dbeta, int accumulate, float* __restrict__ coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);     // one wavefront per channel
   if (c >= C) return;
-  double s = 0.0, sx = 0.0;
-  for (int b = 0; b < nblk; ++b) { s += partial[((long long)b * 2) * C + c]; sx += partial[((long long)b * 2 + 1) * C + c]; }
+  double s, sx;
+  wave_partial_sums(partial, nblk, C, c, s, sx);
+  if ((threadIdx.x & 63) != 0) return;
   if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sx;
   if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
   const double g = gamma ? gamma[c] : 1.0, is = invstd[c], mu = mean[c];
@@ -269,11 +286,11 @@ __global__ void colsum_partial_kernel(const float* __restrict__ x, long long row
 
 __global__ void colsum_final_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out,
                                     int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);     // one wavefront per channel
   if (c >= C) return;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += partial[((long long)b * 2) * C + c];
-  out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+  double s, unused;
+  wave_partial_sums(partial, nblk, C, c, s, unused);
+  if ((threadIdx.x & 63) == 0) out[c] = (accumulate ? out[c] : 0.f) + (float)s;
 }
 
 static inline int red_blocks(long long rows) {
@@ -304,7 +321,7 @@ int sg2im_bn_stats(const float* x, long long rows, int channels, long long ld, c
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nblk), dim3(256), 2 * 256 * sizeof(float), stream, x, rows,
                        channels, ld, partial);
   }
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((channels + 255) / 256), dim3(256), 0, stream, partial, nblk, rows,
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((channels + 3) / 4), dim3(256), 0, stream, partial, nblk, rows,
                      unbiased_rows, channels, gamma, beta, eps, momentum, training, running_mean, running_var,
                      num_batches_tracked, mean, invstd, scale, shift);
   return ok_or(hipGetLastError());
@@ -324,7 +341,7 @@ int sg2im_bn_act_backward(const float* g, long long ld_g, int pool2, int batch, 
   float* coef = partial + (size_t)2 * channels * RED_BLOCKS;     // 3*C floats behind the partials
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk), dim3(256), 2 * 256 * sizeof(float), stream, gs, y, ld_y, rows,
                      channels, mean, invstd, scale, shift, slope, partial);
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((channels + 255) / 256), dim3(256), 0, stream, partial, nblk, rows,
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((channels + 3) / 4), dim3(256), 0, stream, partial, nblk, rows,
                      channels, gamma, mean, invstd, training, dgamma, dbeta, accumulate, coef);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(rows * channels)), dim3(256), 0, stream, gs, y, ld_y, rows,
                      channels, scale, shift, slope, coef, dy);
@@ -429,7 +446,7 @@ int sg2im_column_sum(const float* x, long long rows, int cols, long long ld, flo
   }
   const int nblk = red_blocks(rows);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 2 * 256 * sizeof(float), stream, x, rows, cols, ld, partial);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, stream, partial, nblk, cols, out, accumulate);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 3) / 4), dim3(256), 0, stream, partial, nblk, cols, out, accumulate);
   return ok_or(hipGetLastError());
 }
 
