@@ -52,7 +52,7 @@ class RefinementNetwork(nn.Module):
     self.output_conv = nn.Sequential(*out_layers)
     to_channels_last(self)
 
-  def forward_nhwc(self, layout_nhwc):
+  def forward_nhwc(self, layout_nhwc, layout_grad_channels=None):
     convs, bnps, bns = [], [], []
     for mod in self.refinement_modules:
       c0, n0, _, c1, n1, _ = mod.net
@@ -61,7 +61,7 @@ class RefinementNetwork(nn.Module):
       bns.append((n0, n1))
     o0, o2 = self.output_conv[0], self.output_conv[2]
     params = convs + [o0.weight, o0.bias, o2.weight, o2.bias] + bnps
-    return HF.RefinementFn.apply(layout_nhwc, bns, self.slope, self.training, *params)
+    return HF.RefinementFn.apply(layout_nhwc, bns, self.slope, self.training, layout_grad_channels, *params)
 
   def forward(self, layout):
     return HF.NhwcToNchw.apply(self.forward_nhwc(HF.NchwToNhwc.apply(layout)))

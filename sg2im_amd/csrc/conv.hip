@@ -46,6 +46,7 @@ struct WgradParams {
   int P;            // NB*Ho*Wo (reduction length)
   int iters;        // ceil(P / BK)
   int ntile_c;      // column tiles per tap (VEC=4)
+  int ntiles_n, ntiles_m;   // tile counts (the launch is a 1-D, XCD-swizzled grid)
   Epi e;
 };
 
@@ -99,9 +100,48 @@ __device__ __forceinline__ void locate_chunk(const ConvGeom& g, int ch, int& s, 
     _Pragma("unroll") for (int b_ = 0; b_ < BN / 64; ++b_) zero_acc(acc[a_][b_]);
 
 // ---------------------------------------------------------------------------
+// Fast-path loader conventions (VEC == 4).  Global loads are issued BRANCH-FREE: an
+// out-of-range row / channel chunk reads element 0 of its tensor (always mapped) and is
+// zeroed later through a validity mask.  The pending per-channel affine + LeakyReLU of the
+// source is not applied in the load either: its scale/shift vectors are fetched alongside
+// (identity constants when the source has none) and applied when the register set is
+// written to LDS, two K-chunks later.  This keeps every load of a chunk in flight at once -
+// hipcc otherwise wraps each conditional load in an exec-mask branch followed by
+// `s_waitcnt vmcnt(0)`, which serialises a full memory latency per tile row.
+// Offsets are 32-bit element offsets (tensors < 2^32 elements).
+// ---------------------------------------------------------------------------
+__device__ float k_ones4[4] = {1.f, 1.f, 1.f, 1.f};
+__device__ float k_zeros4[4] = {0.f, 0.f, 0.f, 0.f};
+
+struct Aff { float4 sc, sh; float slope; };
+
+__device__ __forceinline__ float4 apply_aff(float4 v, const Aff& a, bool ok) {
+  v.x = leaky(fmaf(v.x, a.sc.x, a.sh.x), a.slope);
+  v.y = leaky(fmaf(v.y, a.sc.y, a.sh.y), a.slope);
+  v.z = leaky(fmaf(v.z, a.sc.z, a.sh.z), a.slope);
+  v.w = leaky(fmaf(v.w, a.sc.w, a.sh.w), a.slope);
+  return ok ? v : zero4();
+}
+
+__device__ __forceinline__ void fetch_aff(Aff& a, const Src& S, int c, bool cok) {
+  const bool has = S.scale != nullptr && cok;
+  const float* scp = has ? S.scale + c : k_ones4;
+  const float* shp = has ? S.shift + c : k_zeros4;
+  a.sc = *reinterpret_cast<const float4*>(scp);
+  a.sh = *reinterpret_cast<const float4*>(shp);
+  a.slope = has ? S.slope : 1.f;
+}
+
+template <int NVA, int NVB> struct RegSet {
+  float4 a[NVA], b[NVB];
+  Aff aff;
+  unsigned ma, mb;          // validity bits of the A / B rows
+};
+
+// ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int VEC>
+template <int BM, int BN, int VEC, bool GATHER>
 __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NVA = BM / 32, NVB = BN / 32;
@@ -118,6 +158,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
   const int Ktot = ldw;
 
   int rn[NVA], rhb[NVA], rwb[NVA];
+  unsigned wrow[NVB], bmask = 0;
   {
     const int HoWo = g.Ho * g.Wo;
     #pragma unroll
@@ -129,10 +170,18 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
         rn[i] = n; rhb[i] = ho * g.stride - g.pad; rwb[i] = wo * g.stride - g.pad;
       } else { rn[i] = -1; rhb[i] = 0; rwb[i] = 0; }
     }
+    #pragma unroll
+    for (int i = 0; i < NVB; ++i) {
+      const int n = n0 + r0 + 32 * i;
+      const bool ok = n < p.Cout;
+      wrow[i] = ok ? (unsigned)n * (unsigned)ldw : 0u;
+      bmask |= (ok ? 1u : 0u) << i;
+    }
   }
 
-  float4 ra0[NVA], rb0[NVB], ra1[NVA], rb1[NVB];
-  auto load_into = [&](int it, float4 (&ra)[NVA], float4 (&rb)[NVB]) {
+  typedef RegSet<NVA, NVB> RS;
+  RS rs0, rs1;
+  auto load_into = [&](int it, RS& r) {
     if (VEC == 4) {
       const int tap = it / p.nch;
       int s, cstart, cb;
@@ -141,18 +190,31 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
       const int kh = tap / g.KW, kw = tap - kh * g.KW;
       const int c = cb + 4 * col4;
       const bool cok = c < S.C;
+      fetch_aff(r.aff, S, c, cok);
+      const int Hs = g.H >> S.up, Ws = g.W >> S.up;
+      unsigned ma = 0;
+      unsigned pix[NVA];
       #pragma unroll
       for (int i = 0; i < NVA; ++i) {
         const int hi = rhb[i] + kh, wi = rwb[i] + kw;
         const bool ok = cok && rn[i] >= 0 && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-        ra[i] = ok ? load4(g, S, rn[i], hi, wi, c) : zero4();
+        ma |= (ok ? 1u : 0u) << i;
+        if (GATHER) pix[i] = S.gidx ? (unsigned)S.gidx[ok ? rn[i] : 0] : (unsigned)(ok ? rn[i] : 0);
+        else pix[i] = ok ? (unsigned)((rn[i] * Hs + (hi >> S.up)) * Ws + (wi >> S.up)) : 0u;
       }
-      const long long wcol = (long long)tap * g.Ctot + cstart + c;
+      #pragma unroll
+      for (int i = 0; i < NVA; ++i) {
+        const unsigned off = (ma >> i & 1u) ? pix[i] * (unsigned)S.ld + (unsigned)c : 0u;
+        r.a[i] = *reinterpret_cast<const float4*>(S.p + off);
+      }
+      const unsigned wcol = (unsigned)(tap * g.Ctot + cstart + c);
+      const unsigned mb = cok ? bmask : 0u;
       #pragma unroll
       for (int i = 0; i < NVB; ++i) {
-        const int n = n0 + r0 + 32 * i;
-        rb[i] = (cok && n < p.Cout) ? *reinterpret_cast<const float4*>(p.Wt + (long long)n * ldw + wcol) : zero4();
+        const unsigned off = (mb >> i & 1u) ? wrow[i] + wcol : 0u;
+        r.b[i] = *reinterpret_cast<const float4*>(p.Wt + off);
       }
+      r.ma = ma; r.mb = mb;
     } else {
       float av[NVA][4], bv[NVB][4];
       #pragma unroll
@@ -178,10 +240,21 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
         }
       }
       #pragma unroll
-      for (int i = 0; i < NVA; ++i) ra[i] = make_float4(av[i][0], av[i][1], av[i][2], av[i][3]);
+      for (int i = 0; i < NVA; ++i) r.a[i] = make_float4(av[i][0], av[i][1], av[i][2], av[i][3]);
       #pragma unroll
-      for (int i = 0; i < NVB; ++i) rb[i] = make_float4(bv[i][0], bv[i][1], bv[i][2], bv[i][3]);
+      for (int i = 0; i < NVB; ++i) r.b[i] = make_float4(bv[i][0], bv[i][1], bv[i][2], bv[i][3]);
+      r.aff.sc = make_float4(1.f, 1.f, 1.f, 1.f); r.aff.sh = zero4(); r.aff.slope = 1.f;
+      r.ma = ~0u; r.mb = ~0u;
     }
+  };
+  auto stage_from = [&](RS& r, int B_) {
+    float4 ta[NVA], tb[NVB];
+    #pragma unroll
+    for (int i = 0; i < NVA; ++i) ta[i] = apply_aff(r.a[i], r.aff, (r.ma >> i & 1u) != 0);
+    #pragma unroll
+    for (int i = 0; i < NVB; ++i) tb[i] = (r.mb >> i & 1u) ? r.b[i] : zero4();
+    store_tile<BM, false>(smem + B_ * STAGE, ta, tid);
+    store_tile<BN, false>(smem + B_ * STAGE + AF, tb, tid);
   };
 
   SG2IM_ZERO_ACC()
@@ -189,18 +262,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
   wave_origin<BM, BN>(tid, wm0, wn0, lane);
 
   k_pipeline(it_begin, it_end,
-    [&](int it, auto set) {
-      if constexpr (decltype(set)::value == 0) load_into(it, ra0, rb0); else load_into(it, ra1, rb1);
-    },
-    [&](auto set, int B_) {
-      if constexpr (decltype(set)::value == 0) {
-        store_tile<BM, false>(smem + B_ * STAGE, ra0, tid);
-        store_tile<BN, false>(smem + B_ * STAGE + AF, rb0, tid);
-      } else {
-        store_tile<BM, false>(smem + B_ * STAGE, ra1, tid);
-        store_tile<BN, false>(smem + B_ * STAGE + AF, rb1, tid);
-      }
-    },
+    [&](int it, auto set) { if constexpr (decltype(set)::value == 0) load_into(it, rs0); else load_into(it, rs1); },
+    [&](auto set, int B_) { if constexpr (decltype(set)::value == 0) stage_from(rs0, B_); else stage_from(rs1, B_); },
     [&](int B_) {
       mma_chunk<BM, BN, false, false>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, acc);
     });
@@ -281,22 +344,26 @@ __global__ __launch_bounds__(NTHREADS) void conv_dgrad_kernel(const DgradParams 
   }
   constexpr int Q = BN / 4;
   const int bcol4 = tid % Q, bk0 = tid / Q;
+  const int nn = n0 + 4 * bcol4;
+  const bool nok4 = nn < p.Nc;
 
-  auto out_pixel = [&](int i, int kh, int kw, long long& row) -> bool {
+  // output pixel hit by input row i through tap (kh, kw): element row index or invalid
+  auto out_pixel = [&](int i, int kh, int kw, unsigned& row) -> bool {
     const int nh = rh[i] - kh, nw = rw[i] - kw;      // = ho*stride, wo*stride
-    if (rn[i] < 0 || nh < 0 || nw < 0) return false;
     int ho = nh, wo = nw;
+    bool ok = rn[i] >= 0 && nh >= 0 && nw >= 0;
     if (g.stride != 1) {
       ho = nh / g.stride; wo = nw / g.stride;
-      if (ho * g.stride != nh || wo * g.stride != nw) return false;
+      ok = ok && ho * g.stride == nh && wo * g.stride == nw;
     }
-    if (ho >= g.Ho || wo >= g.Wo) return false;
-    row = ((long long)rn[i] * g.Ho + ho) * g.Wo + wo;
-    return true;
+    ok = ok && ho < g.Ho && wo < g.Wo;
+    row = ok ? (unsigned)((rn[i] * g.Ho + ho) * g.Wo + wo) : 0u;
+    return ok;
   };
 
-  float4 ra0[NVA], rb0[NVB], ra1[NVA], rb1[NVB];
-  auto load_into = [&](int it, float4 (&ra)[NVA], float4 (&rb)[NVB]) {
+  typedef RegSet<NVA, NVB> RS;
+  RS rs0, rs1;
+  auto load_into = [&](int it, RS& r) {
     if (VA == 4) {
       const int t = it / nch, cb = (it - t * nch) * BK;
       const int th = t / nkw;
@@ -304,26 +371,41 @@ __global__ __launch_bounds__(NTHREADS) void conv_dgrad_kernel(const DgradParams 
       const int tap = kh * g.KW + kw;
       const int co = cb + 4 * col4;
       const bool cok = co < Cout;
+      unsigned ma = 0, rows[NVA];
       #pragma unroll
       for (int i = 0; i < NVA; ++i) {
-        long long row;
-        const bool ok = cok && out_pixel(i, kh, kw, row);
-        ra[i] = ok ? *reinterpret_cast<const float4*>(dY + row * ldy + co) : zero4();
+        const bool ok = out_pixel(i, kh, kw, rows[i]) && cok;
+        ma |= (ok ? 1u : 0u) << i;
       }
-      const int nn = n0 + 4 * bcol4;
+      #pragma unroll
+      for (int i = 0; i < NVA; ++i) {
+        const unsigned off = (ma >> i & 1u) ? rows[i] * (unsigned)ldy + (unsigned)co : 0u;
+        r.a[i] = *reinterpret_cast<const float4*>(dY + off);
+      }
+      const unsigned wcol = (unsigned)(tap * g.Ctot + p.c_begin);
+      unsigned mb = 0;
       #pragma unroll
       for (int i = 0; i < NVB; ++i) {
         const int cok2 = cb + bk0 + (1024 / BN) * i;
-        const float* wrow = p.Wt + (long long)cok2 * ldw + (long long)tap * g.Ctot + p.c_begin;
+        const bool rok = cok2 < Cout;
+        const unsigned base = rok ? (unsigned)cok2 * (unsigned)ldw + wcol : 0u;
         if (VB == 4) {
-          rb[i] = (cok2 < Cout && nn < p.Nc) ? *reinterpret_cast<const float4*>(wrow + nn) : zero4();
+          const bool ok = rok && nok4;
+          mb |= (ok ? 1u : 0u) << i;
+          r.b[i] = *reinterpret_cast<const float4*>(p.Wt + (ok ? base + (unsigned)nn : 0u));
         } else {
           float bv[4];
           #pragma unroll
-          for (int j = 0; j < 4; ++j) bv[j] = (cok2 < Cout && nn + j < p.Nc) ? wrow[nn + j] : 0.f;
-          rb[i] = make_float4(bv[0], bv[1], bv[2], bv[3]);
+          for (int j = 0; j < 4; ++j) {
+            const bool ok = rok && nn + j < p.Nc;
+            const float v = p.Wt[ok ? base + (unsigned)(nn + j) : 0u];
+            bv[j] = ok ? v : 0.f;
+          }
+          mb |= 1u << i;
+          r.b[i] = make_float4(bv[0], bv[1], bv[2], bv[3]);
         }
       }
+      r.ma = ma; r.mb = mb;
     } else {
       float av[NVA][4];
       #pragma unroll
@@ -334,28 +416,40 @@ __global__ __launch_bounds__(NTHREADS) void conv_dgrad_kernel(const DgradParams 
         const int kh = tap / g.KW, kw = tap - kh * g.KW;
         #pragma unroll
         for (int i = 0; i < NVA; ++i) {
-          long long row;
-          const bool ok = kok && out_pixel(i, kh, kw, row);
-          av[i][j] = ok ? dY[row * ldy + co] : 0.f;
+          unsigned row;
+          const bool ok = out_pixel(i, kh, kw, row) && kok;
+          const float v = dY[ok ? row * (unsigned)ldy + (unsigned)co : 0u];
+          av[i][j] = ok ? v : 0.f;
         }
       }
       #pragma unroll
-      for (int i = 0; i < NVA; ++i) ra[i] = make_float4(av[i][0], av[i][1], av[i][2], av[i][3]);
+      for (int i = 0; i < NVA; ++i) r.a[i] = make_float4(av[i][0], av[i][1], av[i][2], av[i][3]);
       #pragma unroll
       for (int i = 0; i < NVB; ++i) {
         const int k = it * BK + bk0 + (1024 / BN) * i;
         const bool kok = k < Ktot;
         const int tap = kok ? k / Cout : 0, co = kok ? k - tap * Cout : 0;
-        const float* wrow = p.Wt + (long long)co * ldw + (long long)tap * g.Ctot + p.c_begin;
+        const unsigned base = (unsigned)co * (unsigned)ldw + (unsigned)(tap * g.Ctot + p.c_begin);
         float bv[4];
         #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int nn = n0 + 4 * bcol4 + j;
-          bv[j] = (kok && nn < p.Nc) ? wrow[nn] : 0.f;
+          const bool ok = kok && nn + j < p.Nc;
+          const float v = p.Wt[ok ? base + (unsigned)(nn + j) : 0u];
+          bv[j] = ok ? v : 0.f;
         }
-        rb[i] = make_float4(bv[0], bv[1], bv[2], bv[3]);
+        r.b[i] = make_float4(bv[0], bv[1], bv[2], bv[3]);
       }
+      r.ma = ~0u; r.mb = ~0u;
     }
+  };
+  auto stage_from = [&](RS& r, int B_) {
+    float4 ta[NVA], tb[NVB];
+    #pragma unroll
+    for (int i = 0; i < NVA; ++i) ta[i] = (r.ma >> i & 1u) ? r.a[i] : zero4();
+    #pragma unroll
+    for (int i = 0; i < NVB; ++i) tb[i] = (r.mb >> i & 1u) ? r.b[i] : zero4();
+    store_tile<BM, false>(smem + B_ * STAGE, ta, tid);
+    store_tile<BN, true>(smem + B_ * STAGE + AF, tb, tid);
   };
 
   SG2IM_ZERO_ACC()
@@ -363,18 +457,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_dgrad_kernel(const DgradParams 
   wave_origin<BM, BN>(tid, wm0, wn0, lane);
 
   k_pipeline(it_begin, it_end,
-    [&](int it, auto set) {
-      if constexpr (decltype(set)::value == 0) load_into(it, ra0, rb0); else load_into(it, ra1, rb1);
-    },
-    [&](auto set, int B_) {
-      if constexpr (decltype(set)::value == 0) {
-        store_tile<BM, false>(smem + B_ * STAGE, ra0, tid);
-        store_tile<BN, true>(smem + B_ * STAGE + AF, rb0, tid);
-      } else {
-        store_tile<BM, false>(smem + B_ * STAGE, ra1, tid);
-        store_tile<BN, true>(smem + B_ * STAGE + AF, rb1, tid);
-      }
-    },
+    [&](int it, auto set) { if constexpr (decltype(set)::value == 0) load_into(it, rs0); else load_into(it, rs1); },
+    [&](auto set, int B_) { if constexpr (decltype(set)::value == 0) stage_from(rs0, B_); else stage_from(rs1, B_); },
     [&](int B_) {
       mma_chunk<BM, BN, false, true>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, acc);
     });
@@ -388,7 +472,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_dgrad_kernel(const DgradParams 
 // ---------------------------------------------------------------------------
 // weight gradient
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int VEC>
+template <int BM, int BN, int VEC, bool GATHER>
 __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NVA = BM / 32, NVB = BN / 32;
@@ -396,7 +480,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams 
   constexpr int STAGE = AF + BF;
   const ConvGeom& g = p.g;
   const int tid = threadIdx.x;
-  const int m0 = blockIdx.y * BM, split = blockIdx.z;
+  // (an XCD-pinned 1-D grid - every column tile of a reduction slice on one XCD's L2 - was
+  // measured: no gain on the large layers, so the plain 3-D grid stays)
+  const int ntile_x = blockIdx.x, mtile = blockIdx.y, split = blockIdx.z;
+  const int m0 = mtile * BM;
   const int per = (p.iters + p.e.nsplit - 1) / p.e.nsplit;
   const int it_begin = split * per;
   const int it_end = min(p.iters, it_begin + per);
@@ -407,15 +494,17 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams 
   // column tile -> (tap, first concat channel) for VEC=4, flat column for VEC=1
   int n0, tap0 = 0, c0 = 0;
   if (VEC == 4) {
-    tap0 = blockIdx.x / p.ntile_c;
-    c0 = (blockIdx.x - tap0 * p.ntile_c) * BN;
+    tap0 = ntile_x / p.ntile_c;
+    c0 = (ntile_x - tap0 * p.ntile_c) * BN;
     n0 = tap0 * g.Ctot + c0;
   } else {
-    n0 = blockIdx.x * BN;
+    n0 = ntile_x * BN;
   }
   constexpr int QA = BM / 4, QB = BN / 4;
   const int acol4 = tid % QA, ak0 = tid / QA;
   const int bcol4 = tid % QB, bk0 = tid / QB;
+  const int aco = m0 + 4 * acol4;
+  const bool aok = aco < p.Cout;
 
   // per-thread B column(s): fixed for the whole reduction
   int bs = 0, bcs = 0;
@@ -424,6 +513,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams 
   locate_channel(g, bok ? bc : 0, bs, bcs);
   const Src BS = pick_src(g, bs);
   const int bkh = tap0 / g.KW, bkw = tap0 - bkh * g.KW;
+  const int Hs = g.H >> BS.up, Ws = g.W >> BS.up;
+  Aff baff;
+  fetch_aff(baff, BS, bcs, bok);
   int js[4], jcs[4], jkh[4], jkw[4];
   bool jok[4];
   if (VEC != 4) {
@@ -436,47 +528,80 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams 
       jkh[j] = tap / g.KW; jkw[j] = tap - jkh[j] * g.KW;
     }
   }
+  // the B rows are output pixels: (n, ho, wo) of row pix = it*BK + bk0 + (1024/BN)*i is
+  // advanced incrementally (BK pixels per chunk) instead of two integer divisions per row
+  int bn_[NVB], bho[NVB], bwo[NVB];
+  const int dn = BK / HoWo, drem = BK - dn * HoWo, dh = drem / g.Wo, dw = drem - dh * g.Wo;
+  #pragma unroll
+  for (int i = 0; i < NVB; ++i) {
+    const int pix = it_begin * BK + bk0 + (1024 / BN) * i;
+    bn_[i] = pix / HoWo;
+    const int rem = pix - bn_[i] * HoWo;
+    bho[i] = rem / g.Wo; bwo[i] = rem - bho[i] * g.Wo;
+  }
 
-  float4 ra0[NVA], rb0[NVB], ra1[NVA], rb1[NVB];
-  auto load_into = [&](int it, float4 (&ra)[NVA], float4 (&rb)[NVB]) {
+  typedef RegSet<NVA, NVB> RS;
+  RS rs0, rs1;
+  auto load_into = [&](int it, RS& r) {
+    unsigned ma = 0, mb = 0;
     #pragma unroll
     for (int i = 0; i < NVA; ++i) {
       const int pix = it * BK + ak0 + (1024 / BM) * i;
-      const int co = m0 + 4 * acol4;
       if (VEC == 4) {
-        ra[i] = (pix < p.P && co < p.Cout) ? *reinterpret_cast<const float4*>(p.dY + (long long)pix * p.ldy + co)
-                                               : zero4();
+        const bool ok = aok && pix < p.P;
+        ma |= (ok ? 1u : 0u) << i;
+        r.a[i] = *reinterpret_cast<const float4*>(p.dY + (ok ? (unsigned)pix * (unsigned)p.ldy + (unsigned)aco : 0u));
       } else {
         float v[4];
         #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (pix < p.P && co + j < p.Cout) ? p.dY[(long long)pix * p.ldy + co + j] : 0.f;
-        ra[i] = make_float4(v[0], v[1], v[2], v[3]);
+        for (int j = 0; j < 4; ++j) v[j] = (pix < p.P && aco + j < p.Cout) ? p.dY[(long long)pix * p.ldy + aco + j] : 0.f;
+        r.a[i] = make_float4(v[0], v[1], v[2], v[3]);
+        ma |= 1u << i;
       }
     }
     #pragma unroll
     for (int i = 0; i < NVB; ++i) {
       const int pix = it * BK + bk0 + (1024 / BN) * i;
-      float4 v = zero4();
-      if (pix < p.P) {
-        const int n = pix / HoWo, rem = pix - n * HoWo;
-        const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
-        const int hb = ho * g.stride - g.pad, wb = wo * g.stride - g.pad;
-        if (VEC == 4) {
-          const int hi = hb + bkh, wi = wb + bkw;
-          if (bok && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W) v = load4(g, BS, n, hi, wi, bcs);
-        } else {
-          float e[4];
-          #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int hi = hb + jkh[j], wi = wb + jkw[j];
-            e[j] = (jok[j] && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W)
-                     ? load1(g, pick_src(g, js[j]), n, hi, wi, jcs[j]) : 0.f;
-          }
-          v = make_float4(e[0], e[1], e[2], e[3]);
+      const int n = bn_[i], ho = bho[i], wo = bwo[i];
+      const int hb = ho * g.stride - g.pad, wb = wo * g.stride - g.pad;
+      if (VEC == 4) {
+        const int hi = hb + bkh, wi = wb + bkw;
+        const bool ok = bok && pix < p.P && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+        mb |= (ok ? 1u : 0u) << i;
+        unsigned row;
+        if (GATHER) row = BS.gidx ? (unsigned)BS.gidx[ok ? n : 0] : (unsigned)(ok ? n : 0);
+        else row = ok ? (unsigned)((n * Hs + (hi >> BS.up)) * Ws + (wi >> BS.up)) : 0u;
+        r.b[i] = *reinterpret_cast<const float4*>(BS.p + (ok ? row * (unsigned)BS.ld + (unsigned)bcs : 0u));
+      } else {
+        float e[4];
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int hi = hb + jkh[j], wi = wb + jkw[j];
+          e[j] = (pix < p.P && jok[j] && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W)
+                   ? load1(g, pick_src(g, js[j]), n, hi, wi, jcs[j]) : 0.f;
         }
+        r.b[i] = make_float4(e[0], e[1], e[2], e[3]);
+        mb |= 1u << i;
       }
-      rb[i] = v;
+      // advance this row by BK pixels for the next chunk
+      int w2 = wo + dw, h2 = ho + dh, n2 = n + dn;
+      if (w2 >= g.Wo) { w2 -= g.Wo; ++h2; }
+      if (h2 >= g.Ho) { h2 -= g.Ho; ++n2; }
+      bwo[i] = w2; bho[i] = h2; bn_[i] = n2;
     }
+    r.ma = ma; r.mb = mb;
+  };
+  auto stage_from = [&](RS& r, int B_) {
+    float4 ta[NVA], tb[NVB];
+    #pragma unroll
+    for (int i = 0; i < NVA; ++i) ta[i] = (r.ma >> i & 1u) ? r.a[i] : zero4();
+    #pragma unroll
+    for (int i = 0; i < NVB; ++i) {
+      if (VEC == 4) tb[i] = apply_aff(r.b[i], baff, (r.mb >> i & 1u) != 0);
+      else tb[i] = r.b[i];
+    }
+    store_tile<BM, true>(smem + B_ * STAGE, ta, tid);
+    store_tile<BN, true>(smem + B_ * STAGE + AF, tb, tid);
   };
 
   SG2IM_ZERO_ACC()
@@ -484,18 +609,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams 
   wave_origin<BM, BN>(tid, wm0, wn0, lane);
 
   k_pipeline(it_begin, it_end,
-    [&](int it, auto set) {
-      if constexpr (decltype(set)::value == 0) load_into(it, ra0, rb0); else load_into(it, ra1, rb1);
-    },
-    [&](auto set, int B_) {
-      if constexpr (decltype(set)::value == 0) {
-        store_tile<BM, true>(smem + B_ * STAGE, ra0, tid);
-        store_tile<BN, true>(smem + B_ * STAGE + AF, rb0, tid);
-      } else {
-        store_tile<BM, true>(smem + B_ * STAGE, ra1, tid);
-        store_tile<BN, true>(smem + B_ * STAGE + AF, rb1, tid);
-      }
-    },
+    [&](int it, auto set) { if constexpr (decltype(set)::value == 0) load_into(it, rs0); else load_into(it, rs1); },
+    [&](auto set, int B_) { if constexpr (decltype(set)::value == 0) stage_from(rs0, B_); else stage_from(rs1, B_); },
     [&](int B_) {
       mma_chunk<BM, BN, true, true>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, acc);
     });
@@ -633,14 +748,22 @@ static hipError_t finish_split(const Epi& e, long long M, int N, hipStream_t st)
   return hipGetLastError();
 }
 
-template <int BM, int BN, int VEC>
-static hipError_t launch_fwd(FwdParams& p, hipStream_t st) {
+template <int BM, int BN, int VEC, bool GATHER>
+static hipError_t launch_fwd_g(FwdParams& p, hipStream_t st) {
   constexpr size_t lds = 2 * (LdsTile<BM, false>::FLOATS + LdsTile<BN, false>::FLOATS) * sizeof(float);
   static bool once = false;
-  if (!once) { hipError_t e = ensure_lds(conv_fwd_kernel<BM, BN, VEC>, lds); if (e != hipSuccess) return e; once = true; }
+  if (!once) { hipError_t e = ensure_lds(conv_fwd_kernel<BM, BN, VEC, GATHER>, lds); if (e != hipSuccess) return e; once = true; }
   dim3 grid((p.Cout + BN - 1) / BN, (p.M + BM - 1) / BM, p.e.nsplit);
-  hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, VEC>), grid, dim3(NTHREADS), lds, st, p);
+  hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, VEC, GATHER>), grid, dim3(NTHREADS), lds, st, p);
   return hipGetLastError();
+}
+
+static bool any_gather(ConvGeom& g) { for (int i = 0; i < g.nsrc; ++i) if (src_at(g, i)->gidx) return true; return false; }
+
+template <int BM, int BN, int VEC>
+static hipError_t launch_fwd(FwdParams& p, hipStream_t st) {
+  if (VEC == 4 && any_gather(p.g)) return launch_fwd_g<BM, BN, VEC, true>(p, st);
+  return launch_fwd_g<BM, BN, VEC, false>(p, st);
 }
 
 template <int BM, int BN, int VA, int VB>
@@ -653,14 +776,22 @@ static hipError_t launch_dgrad(DgradParams& p, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <int BM, int BN, int VEC>
-static hipError_t launch_wgrad(WgradParams& p, int ntiles_n, hipStream_t st) {
+template <int BM, int BN, int VEC, bool GATHER>
+static hipError_t launch_wgrad_g(WgradParams& p, int ntiles_n, hipStream_t st) {
   constexpr size_t lds = 2 * (LdsTile<BM, true>::FLOATS + LdsTile<BN, true>::FLOATS) * sizeof(float);
   static bool once = false;
-  if (!once) { hipError_t e = ensure_lds(conv_wgrad_kernel<BM, BN, VEC>, lds); if (e != hipSuccess) return e; once = true; }
-  dim3 grid(ntiles_n, (p.Cout + BM - 1) / BM, p.e.nsplit);
-  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, VEC>), grid, dim3(NTHREADS), lds, st, p);
+  if (!once) { hipError_t e = ensure_lds(conv_wgrad_kernel<BM, BN, VEC, GATHER>, lds); if (e != hipSuccess) return e; once = true; }
+  p.ntiles_n = ntiles_n;
+  p.ntiles_m = (p.Cout + BM - 1) / BM;
+  dim3 grid(p.ntiles_n, p.ntiles_m, p.e.nsplit);
+  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, VEC, GATHER>), grid, dim3(NTHREADS), lds, st, p);
   return hipGetLastError();
+}
+
+template <int BM, int BN, int VEC>
+static hipError_t launch_wgrad(WgradParams& p, int ntiles_n, hipStream_t st) {
+  if (VEC == 4 && any_gather(p.g)) return launch_wgrad_g<BM, BN, VEC, true>(p, ntiles_n, st);
+  return launch_wgrad_g<BM, BN, VEC, false>(p, ntiles_n, st);
 }
 
 }  // namespace sg2im

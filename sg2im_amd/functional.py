@@ -30,6 +30,20 @@ def _cl_weight(w):
   return p
 
 
+# ---------------------------------------------------------------------------------------
+# gradient sinks: sg2im_amd.optim.FlatParams registers, for every parameter, a view into its
+# flat gradient arena (keyed by the parameter's data pointer).  Backward kernels then
+# accumulate straight into the arena (beta = 1) and report ``None`` to autograd, which
+# removes ~150 per-parameter "grad += g" launches per step.  Without a registered sink the
+# gradient is returned through autograd as usual.
+# ---------------------------------------------------------------------------------------
+GRAD_SINKS = {}
+
+
+def _sink(param):
+  return GRAD_SINKS.get(param.data_ptr()) if param is not None else None
+
+
 def _cl_grad(dw_phys):
   """[Cout][KH][KW][Cin] gradient -> (Cout,Cin,KH,KW)-shaped channels_last tensor"""
   return dw_phys.permute(0, 3, 1, 2)
@@ -67,19 +81,28 @@ class NhwcToNchw(Function):
 # linear layers
 # ----------------------------------------------------------------------------
 
-def _linear_bwd(desc, W, dpre, need_dx, need_dw, need_db, K):
-  """dpre: dense (M,N) gradient of the pre-activation.  Returns (dx (M,K), dW, db)."""
+def _linear_bwd(desc, W, dpre, need_dx, need_dw, need_db, K, b=None):
+  """dpre: dense (M,N) gradient of the pre-activation.  Returns (dx (M,K), dW, db); a
+  parameter gradient that went straight into its registered sink is reported as None."""
   M, N = dpre.shape
   dx = dw = db = None
   if need_dx:
     dx = _new(dpre, M, K)
     ops.conv2d_backward_data(desc, W, N, dpre, N, 0, K, dx, K)
   if need_dw:
-    dw = _new(dpre, N, K)
-    ops.conv2d_backward_weight(desc, dpre, N, N, dw)
+    sk = _sink(W)
+    if sk is not None:
+      ops.conv2d_backward_weight(desc, dpre, N, N, sk, accumulate=True)
+    else:
+      dw = _new(dpre, N, K)
+      ops.conv2d_backward_weight(desc, dpre, N, N, dw)
   if need_db:
-    db = _new(dpre, N)
-    ops.column_sum(_fptr(dpre), M, N, N, db)
+    sk = _sink(b)
+    if sk is not None:
+      ops.column_sum(_fptr(dpre), M, N, N, sk, accumulate=True)
+    else:
+      db = _new(dpre, N)
+      ops.column_sum(_fptr(dpre), M, N, N, db)
   return dx, dw, db
 
 
@@ -101,17 +124,17 @@ class LinearAct(Function):
     N = W.size(0)
     desc = conv_desc([rows_src(x)], M, 1, 1)
     y = ops.conv2d_forward(desc, W, N, b, _new(x, M, N), N, slope)
-    ctx.save_for_backward(x, W, y)
+    ctx.save_for_backward(x, W, y, b)
     ctx.slope = slope
     return y
 
   @staticmethod
   def backward(ctx, g):
-    x, W, y = ctx.saved_tensors
+    x, W, y, b = ctx.saved_tensors
     dpre = _act_bwd_rows(g, y, ctx.slope)
     desc = conv_desc([rows_src(x)], x.size(0), 1, 1)
     dx, dw, db = _linear_bwd(desc, W, dpre, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                             ctx.needs_input_grad[2], x.size(1))
+                             ctx.needs_input_grad[2], x.size(1), b)
     return dx, dw, db, None
 
 
@@ -125,20 +148,20 @@ class Mlp2(Function):
     h = ops.conv2d_forward(d1, W1, W1.size(0), b1, _new(x, M, W1.size(0)), W1.size(0), 0.0)
     d2 = conv_desc([rows_src(h)], M, 1, 1)
     y = ops.conv2d_forward(d2, W2, W2.size(0), b2, _new(x, M, W2.size(0)), W2.size(0), 0.0)
-    ctx.save_for_backward(x, W1, W2, h, y)
+    ctx.save_for_backward(x, W1, W2, h, y, b1, b2)
     return y
 
   @staticmethod
   def backward(ctx, g):
-    x, W1, W2, h, y = ctx.saved_tensors
+    x, W1, W2, h, y, b1, b2 = ctx.saved_tensors
     M = x.size(0)
     ni = ctx.needs_input_grad
     dp2 = _act_bwd_rows(g, y, 0.0)
     d2 = conv_desc([rows_src(h)], M, 1, 1)
-    dh, dW2, db2 = _linear_bwd(d2, W2, dp2, True, ni[3], ni[4], h.size(1))
+    dh, dW2, db2 = _linear_bwd(d2, W2, dp2, True, ni[3], ni[4], h.size(1), b2)
     dp1 = _act_bwd_rows(dh, h, 0.0)
     d1 = conv_desc([rows_src(x)], M, 1, 1)
-    dx, dW1, db1 = _linear_bwd(d1, W1, dp1, ni[0], ni[1], ni[2], x.size(1))
+    dx, dW1, db1 = _linear_bwd(d1, W1, dp1, ni[0], ni[1], ni[2], x.size(1), b1)
     return dx, dW1, db1, dW2, db2
 
 
@@ -187,13 +210,15 @@ class GraphTripleConvFn(Function):
     h2 = ops.conv2d_forward(conv_desc([rows_src(pooled)], O, 1, 1), W2a, H, b2a, _new(obj_vecs, O, H), H, 0.0)
     new_obj = ops.conv2d_forward(conv_desc([rows_src(h2)], O, 1, 1), W2b, Dout, b2b, _new(obj_vecs, O, Dout),
                                  Dout, 0.0)
-    ctx.save_for_backward(obj_vecs, pred_vecs, s_idx, o_idx, W1a, W1b, W2a, W2b, h1, new_t, pooled, h2, new_obj)
+    ctx.save_for_backward(obj_vecs, pred_vecs, s_idx, o_idx, W1a, W1b, W2a, W2b, h1, new_t, pooled, h2, new_obj,
+                          b1a, b1b, b2a, b2b)
     ctx.csr, ctx.avg = csr, avg
     return new_obj, new_t[:, H:H + Dout]
 
   @staticmethod
   def backward(ctx, g_obj, g_pred):
-    (obj_vecs, pred_vecs, s_idx, o_idx, W1a, W1b, W2a, W2b, h1, new_t, pooled, h2, new_obj) = ctx.saved_tensors
+    (obj_vecs, pred_vecs, s_idx, o_idx, W1a, W1b, W2a, W2b, h1, new_t, pooled, h2, new_obj,
+     b1a, b1b, b2a, b2b) = ctx.saved_tensors
     csr, avg = ctx.csr, ctx.avg
     T, O = pred_vecs.size(0), obj_vecs.size(0)
     Din, H, Dout = obj_vecs.size(1), W2a.size(0), W2b.size(0)
@@ -204,9 +229,9 @@ class GraphTripleConvFn(Function):
     if g_obj is None:
       g_obj = z(O, Dout)
     dp4 = _act_bwd_rows(g_obj, new_obj, 0.0)
-    dh2, dW2b, db2b = _linear_bwd(conv_desc([rows_src(h2)], O, 1, 1), W2b, dp4, True, ni[12], ni[13], H)
+    dh2, dW2b, db2b = _linear_bwd(conv_desc([rows_src(h2)], O, 1, 1), W2b, dp4, True, ni[12], ni[13], H, b2b)
     dp3 = _act_bwd_rows(dh2, h2, 0.0)
-    dpooled, dW2a, db2a = _linear_bwd(conv_desc([rows_src(pooled)], O, 1, 1), W2a, dp3, True, ni[10], ni[11], H)
+    dpooled, dW2a, db2a = _linear_bwd(conv_desc([rows_src(pooled)], O, 1, 1), W2a, dp3, True, ni[10], ni[11], H, b2a)
     # pooling backward: rows of dpooled go back to the s / o column blocks (divided by the count)
     d_new_t = _new(obj_vecs, T, NT)
     cavg = csr if avg else None
@@ -218,11 +243,11 @@ class GraphTripleConvFn(Function):
       ops.copy_2d(g_pred, d_new_t[:, H:H + Dout])
     # net1
     dp2 = ops.act_backward(_fptr(d_new_t), NT, 0, T, 1, 1, new_t, NT, NT, 0.0, d_new_t) if T > 0 else d_new_t
-    dh1, dW1b, db1b = _linear_bwd(conv_desc([rows_src(h1)], T, 1, 1), W1b, dp2, True, ni[8], ni[9], H)
+    dh1, dW1b, db1b = _linear_bwd(conv_desc([rows_src(h1)], T, 1, 1), W1b, dp2, True, ni[8], ni[9], H, b1b)
     dp1 = _act_bwd_rows(dh1, h1, 0.0)
     d1 = conv_desc([rows_src(obj_vecs, s_idx), rows_src(pred_vecs), rows_src(obj_vecs, o_idx)], T, 1, 1)
     need_dx = ni[0] or ni[1]
-    dX, dW1a, db1a = _linear_bwd(d1, W1a, dp1, need_dx, ni[6], ni[7], 3 * Din)
+    dX, dW1a, db1a = _linear_bwd(d1, W1a, dp1, need_dx, ni[6], ni[7], 3 * Din, b1a)
     d_obj = d_pred = None
     if ni[0]:
       d_obj = ops.segment_sum(dX[:, :Din], dX[:, 2 * Din:], csr, Din, False, _new(obj_vecs, O, Din))
@@ -243,21 +268,21 @@ class RelAux(Function):
     h = ops.conv2d_forward(d1, W1, W1.size(0), b1, _new(vecs, T, W1.size(0)), W1.size(0), 0.0)
     y = ops.conv2d_forward(conv_desc([rows_src(h)], T, 1, 1), W2, W2.size(0), b2, _new(vecs, T, W2.size(0)),
                            W2.size(0), 0.0)
-    ctx.save_for_backward(boxes, vecs, s_idx, o_idx, W1, W2, h, y)
+    ctx.save_for_backward(boxes, vecs, s_idx, o_idx, W1, W2, h, y, b1, b2)
     ctx.csr = csr
     return y
 
   @staticmethod
   def backward(ctx, g):
-    boxes, vecs, s_idx, o_idx, W1, W2, h, y = ctx.saved_tensors
+    boxes, vecs, s_idx, o_idx, W1, W2, h, y, b1, b2 = ctx.saved_tensors
     T, E = s_idx.numel(), vecs.size(1)
     ni = ctx.needs_input_grad
     dp2 = _act_bwd_rows(g, y, 0.0)
-    dh, dW2, db2 = _linear_bwd(conv_desc([rows_src(h)], T, 1, 1), W2, dp2, True, ni[7], ni[8], h.size(1))
+    dh, dW2, db2 = _linear_bwd(conv_desc([rows_src(h)], T, 1, 1), W2, dp2, True, ni[7], ni[8], h.size(1), b2)
     dp1 = _act_bwd_rows(dh, h, 0.0)
     d1 = conv_desc([rows_src(boxes, s_idx), rows_src(boxes, o_idx), rows_src(vecs, s_idx), rows_src(vecs, o_idx)],
                    T, 1, 1)
-    dX, dW1, db1 = _linear_bwd(d1, W1, dp1, ni[0] or ni[1], ni[5], ni[6], 8 + 2 * E)
+    dX, dW1, db1 = _linear_bwd(d1, W1, dp1, ni[0] or ni[1], ni[5], ni[6], 8 + 2 * E, b1)
     d_boxes = d_vecs = None
     if ni[0]:
       d_boxes = ops.segment_sum(dX[:, 0:4], dX[:, 4:8], ctx.csr, 4, False, _new(vecs, boxes.size(0), 4))
@@ -333,18 +358,36 @@ class CropFn(Function):
 # conv blocks
 # ----------------------------------------------------------------------------
 
-def _conv_param_grads(desc, dy, cout, w_phys_shape, need_w, need_b):
-  """dy: dense NHWC gradient of the conv output"""
+def _conv_param_grads(desc, dy, cout, w_phys_shape, need_w, need_b, W=None, b=None):
+  """dy: dense NHWC gradient of the conv output.  W / b: the parameters (sink lookup)."""
   dw = db = None
   rows = dy.numel() // cout
   if need_w:
-    dw = _new(dy, *w_phys_shape)
-    ops.conv2d_backward_weight(desc, dy, cout, cout, dw)
-    dw = _cl_grad(dw)
+    sk = _sink(W)
+    if sk is not None:
+      ops.conv2d_backward_weight(desc, dy, cout, cout, sk, accumulate=True)
+    else:
+      dw = _new(dy, *w_phys_shape)
+      ops.conv2d_backward_weight(desc, dy, cout, cout, dw)
+      dw = _cl_grad(dw)
   if need_b:
-    db = _new(dy, cout)
-    ops.column_sum(_fptr(dy), rows, cout, cout, db)
+    sk = _sink(b)
+    if sk is not None:
+      ops.column_sum(_fptr(dy), rows, cout, cout, sk, accumulate=True)
+    else:
+      db = _new(dy, cout)
+      ops.column_sum(_fptr(dy), rows, cout, cout, db)
   return dw, db
+
+
+def _bn_grad_bufs(like, C, gamma, beta, need_g, need_b):
+  """(dgamma buffer, dbeta buffer, accumulate, return_dgamma, return_dbeta)"""
+  sg, sb = _sink(gamma) if need_g else None, _sink(beta) if need_b else None
+  if need_g and need_b and sg is not None and sb is not None:
+    return sg, sb, True, None, None
+  dg = _new(like, C) if need_g else None
+  db = _new(like, C) if need_b else None
+  return dg, db, False, dg, db
 
 
 class RefinementFn(Function):
@@ -357,7 +400,7 @@ class RefinementFn(Function):
   """
 
   @staticmethod
-  def forward(ctx, layout, bns, slope, training, *params):
+  def forward(ctx, layout, bns, slope, training, grad_channels, *params):
     L = len(bns)
     N, H, W, Cl = layout.shape
     convp = params[:4 * L]
@@ -396,7 +439,7 @@ class RefinementFn(Function):
     img = ops.conv2d_forward(do2, _cl_weight(Wo2), Wo2.size(0), bo2, _new(layout, N, H, W, Wo2.size(0)),
                              Wo2.size(0))
     ctx.saved = saved
-    ctx.misc = (L, slope, training, z, do0, do2, Cl, Cf)
+    ctx.misc = (L, slope, training, z, do0, do2, Cl, Cf, grad_channels)
     ctx.save_for_backward(*params)
     ctx.shape = (N, H, W, Cl)
     return img
@@ -404,50 +447,49 @@ class RefinementFn(Function):
   @staticmethod
   def backward(ctx, g):
     params = ctx.saved_tensors
-    L, slope, training, z, do0, do2, Cl, Cf = ctx.misc
+    L, slope, training, z, do0, do2, Cl, Cf, grad_channels = ctx.misc
     N, H, W, _ = ctx.shape
     saved = ctx.saved
     convp = params[:4 * L]
     Wo0, bo0, Wo2, bo2 = params[4 * L:4 * L + 4]
     bnp = params[4 * L + 4:]
-    ni = ctx.needs_input_grad[4:]
+    ni = ctx.needs_input_grad[5:]
     grads = [None] * len(params)
     g = g.contiguous()
     Co = Wo0.size(0)
     # output 1x1 conv
     grads[4 * L + 2], grads[4 * L + 3] = _conv_param_grads(do2, g, Wo2.size(0), (Wo2.size(0), 1, 1, Co),
-                                                           ni[4 * L + 2], ni[4 * L + 3])
+                                                           ni[4 * L + 2], ni[4 * L + 3], Wo2, bo2)
     dz = _new(g, N, H, W, Co)
     ops.conv2d_backward_data(do2, _cl_weight(Wo2), Wo2.size(0), g, Wo2.size(0), 0, Co, dz, Co)
     ops.act_backward(_fptr(dz), Co, 0, N, H, W, z, Co, Co, slope, dz)
-    grads[4 * L], grads[4 * L + 1] = _conv_param_grads(do0, dz, Co, (Co, 3, 3, Cf), ni[4 * L], ni[4 * L + 1])
+    grads[4 * L], grads[4 * L + 1] = _conv_param_grads(do0, dz, Co, (Co, 3, 3, Cf), ni[4 * L], ni[4 * L + 1], Wo0, bo0)
     gz = _new(g, N, H, W, Cf)                      # grad w.r.t. activated feats of the last module
     ops.conv2d_backward_data(do0, _cl_weight(Wo0), Co, dz, Co, 0, Cf, gz, Cf)
     pool2 = 0
     need_layout = ctx.needs_input_grad[0]
-    Cg = Cl                                         # layout channels that need gradients
+    # layout channels that need gradients (the noise channels appended by the model do not)
+    Cg = Cl if grad_channels is None else min(int(grad_channels), Cl)
     dlevels = []
     for i in range(L - 1, -1, -1):
       lay, feat_src, y0, st0, y1, st1, h, w, C = saved[i]
       W0p, b0, W1p, b1 = convp[4 * i:4 * i + 4]
       g0, be0, g1, be1 = bnp[4 * i:4 * i + 4]
       k = 4 * L + 4 + 4 * i
-      dg1 = _new(g, C) if ni[k + 2] else None
-      db1n = _new(g, C) if ni[k + 3] else None
+      dg1, db1n, acc1, grads[k + 2], grads[k + 3] = _bn_grad_bufs(g, C, g1, be1, ni[k + 2], ni[k + 3])
       dy1 = ops.bn_act_backward(_fptr(gz), gz.size(3), pool2, N, h, w, y1, C, C, g1, st1, slope, training,
-                                _new(g, N, h, w, C), dg1, db1n)
-      grads[k + 2], grads[k + 3] = dg1, db1n
+                                _new(g, N, h, w, C), dg1, db1n, acc1)
       d1 = conv_desc([nhwc_src(y0, 0, st0.scale, st0.shift, slope)], N, h, w, 3, 3, 1, 1)
-      grads[4 * i + 2], grads[4 * i + 3] = _conv_param_grads(d1, dy1, C, (C, 3, 3, C), ni[4 * i + 2], ni[4 * i + 3])
+      grads[4 * i + 2], grads[4 * i + 3] = _conv_param_grads(d1, dy1, C, (C, 3, 3, C), ni[4 * i + 2], ni[4 * i + 3],
+                                                              W1p, b1)
       gz0 = _new(g, N, h, w, C)
       ops.conv2d_backward_data(d1, _cl_weight(W1p), C, dy1, C, 0, C, gz0, C)
-      dg0 = _new(g, C) if ni[k] else None
-      db0n = _new(g, C) if ni[k + 1] else None
-      dy0 = ops.bn_act_backward(_fptr(gz0), C, 0, N, h, w, y0, C, C, g0, st0, slope, training, dy1, dg0, db0n)
-      grads[k], grads[k + 1] = dg0, db0n
+      dg0, db0n, acc0, grads[k], grads[k + 1] = _bn_grad_bufs(g, C, g0, be0, ni[k], ni[k + 1])
+      dy0 = ops.bn_act_backward(_fptr(gz0), C, 0, N, h, w, y0, C, C, g0, st0, slope, training, dy1, dg0, db0n, acc0)
       Cprev = feat_src.channels
       d0 = conv_desc([nhwc_src(lay), feat_src], N, h, w, 3, 3, 1, 1)
-      grads[4 * i], grads[4 * i + 1] = _conv_param_grads(d0, dy0, C, (C, 3, 3, Cl + Cprev), ni[4 * i], ni[4 * i + 1])
+      grads[4 * i], grads[4 * i + 1] = _conv_param_grads(d0, dy0, C, (C, 3, 3, Cl + Cprev), ni[4 * i], ni[4 * i + 1],
+                                                          W0p, b0)
       if need_layout:
         dl = _new(g, N, h, w, Cg)
         ops.conv2d_backward_data(d0, _cl_weight(W0p), C, dy0, C, 0, Cg, dl, Cg)
@@ -458,11 +500,11 @@ class RefinementFn(Function):
         pool2 = 1
     dlayout = None
     if need_layout:
-      dlayout = _new(g, N, H, W, Cl)
+      dlayout = _new(g, N, H, W, Cl) if Cg == Cl else torch.zeros(N, H, W, Cl, dtype=torch.float32, device=g.device)
       ops.pyramid_backward([t for t, _ in dlevels], [f for _, f in dlevels], [Cg] * len(dlevels), N, H, W, Cg,
                            dlayout)
     ctx.saved = None
-    return (dlayout, None, None, None) + tuple(grads)
+    return (dlayout, None, None, None, None) + tuple(grads)
 
 
 class MaskNetFn(Function):
@@ -505,7 +547,7 @@ class MaskNetFn(Function):
     grads = [None] * len(params)
     Wf, bf = params[4 * nb:4 * nb + 2]
     ds = ops.sigmoid_backward(masks, g.contiguous(), _new(g, O, s, s, 1))
-    grads[4 * nb], grads[4 * nb + 1] = _conv_param_grads(df, ds, 1, (1, 1, 1, D), ni[4 * nb], ni[4 * nb + 1])
+    grads[4 * nb], grads[4 * nb + 1] = _conv_param_grads(df, ds, 1, (1, 1, 1, D), ni[4 * nb], ni[4 * nb + 1], Wf, bf)
     gz = _new(g, O, s, s, D)
     ops.conv2d_backward_data(df, _cl_weight(Wf), 1, ds, 1, 0, D, gz, D)
     for b in range(nb - 1, -1, -1):
@@ -514,14 +556,13 @@ class MaskNetFn(Function):
       s2 = 2 * sb
       dpre = ops.act_backward(_fptr(gz), D, 0, O, s2, s2, y, D, D, 0.0, gz)
       d = conv_desc([nhwc_src(x, 1, st.scale, st.shift, 1.0)], O, s2, s2, 3, 3, 1, 1)
-      grads[4 * b + 2], grads[4 * b + 3] = _conv_param_grads(d, dpre, D, (D, 3, 3, D), ni[4 * b + 2], ni[4 * b + 3])
+      grads[4 * b + 2], grads[4 * b + 3] = _conv_param_grads(d, dpre, D, (D, 3, 3, D), ni[4 * b + 2], ni[4 * b + 3],
+                                                              Wp, bias)
       gup = _new(g, O, s2, s2, D)
       ops.conv2d_backward_data(d, _cl_weight(Wp), D, dpre, D, 0, D, gup, D)
-      dgam = _new(g, D) if ni[4 * b] else None
-      dbet = _new(g, D) if ni[4 * b + 1] else None
+      dgam, dbet, accb, grads[4 * b], grads[4 * b + 1] = _bn_grad_bufs(g, D, gam, bet, ni[4 * b], ni[4 * b + 1])
       gz = ops.bn_act_backward(_fptr(gup), D, 1, O, sb, sb, x, D, D, gam, st, 1.0, training, _new(g, O, sb, sb, D),
-                               dgam, dbet)
-      grads[4 * b], grads[4 * b + 1] = dgam, dbet
+                               dgam, dbet, accb)
     ctx.saved = None
     d_obj = gz.view(O, D) if ctx.needs_input_grad[0] else None
     return (d_obj, None, None) + tuple(grads)
@@ -576,7 +617,8 @@ class DiscCnnFn(Function):
       else:
         wi = 2 + 4 * (i - 1) + 2
         Wp = params[wi]
-      grads[wi], grads[wi + 1] = _conv_param_grads(d, dy, cout, (cout, k, k, cin), ni[wi], ni[wi + 1])
+      grads[wi], grads[wi + 1] = _conv_param_grads(d, dy, cout, (cout, k, k, cin), ni[wi], ni[wi + 1], Wp,
+                                                   params[wi + 1])
       if i == 0:
         dx = None
         if ctx.needs_input_grad[0]:
@@ -588,11 +630,10 @@ class DiscCnnFn(Function):
       ops.conv2d_backward_data(d, _cl_weight(Wp), cout, dy, cout, 0, cin, gz, cin)
       yp, stp = saved[i - 1][2], saved[i - 1][3]
       gi = 2 + 4 * (i - 1)
-      dgam = _new(g, cin) if ni[gi] else None
-      dbet = _new(g, cin) if ni[gi + 1] else None
+      dgam, dbet, accb, grads[gi], grads[gi + 1] = _bn_grad_bufs(g, cin, params[gi], params[gi + 1], ni[gi],
+                                                                 ni[gi + 1])
       dy = ops.bn_act_backward(_fptr(gz), cin, 0, N, h, w, yp, cin, cin, params[gi], stp, slope, training, gz, dgam,
-                               dbet)
-      grads[gi], grads[gi + 1] = dgam, dbet
+                               dbet, accb)
 
 
 class GapFn(Function):

@@ -114,7 +114,8 @@ class Sg2ImModel(nn.Module):
                           device=obj_vecs.device)
     layout = layout_nhwc(obj_vecs, layout_boxes, layout_masks, obj_to_img, H, W, noise=noise,
                          n_images=num_images, align_corners=self.align_corners)
-    img = self.refinement_net.forward_nhwc(layout)
+    # the appended noise channels need no gradient: only the first D layout channels do
+    img = self.refinement_net.forward_nhwc(layout, layout_grad_channels=obj_vecs.size(1))
     return img, boxes_pred, masks_pred, rel_scores
 
   def forward(self, objs, triples, obj_to_img=None, boxes_gt=None, masks_gt=None, num_images=None):

@@ -8,6 +8,7 @@ buffer - instead of the reference's per-tensor torch.optim.Adam loop
 """
 import torch
 
+from . import functional as HF
 from . import ops
 
 
@@ -34,7 +35,17 @@ class FlatParams(object):
         view.copy_(p.data)
         p.data = view
         p.grad = self._view(self.grad, p, off)
+        # backward kernels accumulate straight into the arena (see functional.GRAD_SINKS)
+        HF.GRAD_SINKS[view.data_ptr()] = self._sink_view(p, off)
     self.numel = total
+
+  def _sink_view(self, p, off):
+    """dense physical view of the parameter's gradient slot: [Cout][KH][KW][Cin] for a
+    channels_last conv weight, the parameter's own shape otherwise"""
+    if p.dim() == 4:
+      co, ci, kh, kw = p.shape
+      return self.grad[off:off + p.numel()].view(co, kh, kw, ci)
+    return self.grad[off:off + p.numel()].view(p.shape)
 
   @staticmethod
   def _view(buf, p, off):

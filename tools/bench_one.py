@@ -1,0 +1,33 @@
+"""Run one conv layer shape repeatedly (for rocprofv3 --pmc passes).
+usage: bench_one.py NAME [iters]   with NAME from tools/bench_conv.py LAYERS"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from sg2im_amd import ops
+from tools.bench_conv import LAYERS, N, D
+name = sys.argv[1]
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+bn = len(sys.argv) > 3 and sys.argv[3] == 'bn'
+for L in LAYERS:
+  if L[0] == name:
+    _, H, C0, C1, Cout, k, s, p = L
+x0 = torch.randn(N, H, H, C0, device=D)
+sc = torch.rand(C0, device=D) + 0.5 if bn else None
+sh = torch.randn(C0, device=D) if bn else None
+srcs = [ops.nhwc_src(x0, 0, sc, sh, 0.2 if bn else 1.0)]
+if C1:
+  srcs.append(ops.nhwc_src(torch.randn(N, H // 2, H // 2, C1, device=D), 1))
+d = ops.conv_desc(srcs, N, H, H, k, k, s, p)
+Ct = C0 + C1
+W = torch.randn(Cout, k, k, Ct, device=D) * 0.01
+b = torch.randn(Cout, device=D)
+y = torch.empty(N, d.out_h, d.out_w, Cout, device=D)
+gy = torch.randn_like(y)
+dx = torch.empty(N, H, H, Ct, device=D)
+dw = torch.empty_like(W)
+for _ in range(iters):
+  ops.conv2d_forward(d, W, Cout, b, y, Cout)
+  ops.conv2d_backward_data(d, W, Cout, gy, Cout, 0, Ct, dx, Ct)
+  ops.conv2d_backward_weight(d, gy, Cout, Cout, dw)
+torch.cuda.synchronize()
