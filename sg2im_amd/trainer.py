@@ -19,6 +19,7 @@ import torch.distributed as dist
 from . import functional as HF
 from . import losses as L
 from .discriminators import AcCropDiscriminator, PatchDiscriminator
+from .distributed import GradReducer
 from .model import Sg2ImModel
 from .optim import FlatAdam, FlatParams
 
@@ -69,13 +70,10 @@ class Trainer(object):
     self.opt_g = FlatAdam(self.flat_g, lr=learning_rate)
     self.opt_do = FlatAdam(self.flat_do, lr=learning_rate)
     self.opt_di = FlatAdam(self.flat_di, lr=learning_rate)
+    self.reducer = GradReducer(world_size)
     self.t = 0
 
   # -- data-parallel helpers --------------------------------------------------
-  def _allreduce(self, flat):
-    if self.world_size > 1:
-      dist.all_reduce(flat.grad)
-
   def set_generator_eval(self):
     """reference scripts/train.py:509-512: eval-mode BN for G and a fresh Adam"""
     self.model.eval()
@@ -88,7 +86,7 @@ class Trainer(object):
     imgs, objs, boxes, masks, triples, obj_to_img = batch[:6]
     w = self.w
     N = imgs.size(0)
-    gs = 1.0 / self.world_size
+    gs = self.reducer.grad_scale
     self.t += 1
     imgs_nhwc = HF.NchwToNhwc.apply(imgs)
 
@@ -111,13 +109,14 @@ class Trainer(object):
     losses['total_loss'] = total
     self.opt_g.zero_grad()
     total.backward()
-    self._allreduce(self.flat_g)
+    # The 112 MB generator exchange starts now and is only waited for after both
+    # discriminator passes (they never read G's parameters), see sg2im_amd/distributed.py.
     # NaN guard of train.py:553-555 without a host sync: every optimiser of this iteration
-    # skips its update when the generator loss is not finite (on any rank)
+    # skips its update when the generator loss is not finite (on any rank).
     guard = total.detach().reshape(1).clone()
-    if self.world_size > 1:
-      dist.all_reduce(guard)
-    self.opt_g.step_guarded(guard, gs)
+    red = self.reducer
+    red.start(self.flat_g.grad)
+    red.start(guard)
 
     # ---- object discriminator (train.py:566-579)
     _set_requires_grad(self.d_obj, True)
@@ -129,8 +128,7 @@ class Trainer(object):
     d_obj_total = losses['d_obj_gan_loss'] + ac_real + ac_fake
     self.opt_do.zero_grad()
     d_obj_total.backward()
-    self._allreduce(self.flat_do)
-    self.opt_do.step_guarded(guard, gs)
+    red.start(self.flat_do.grad)
 
     # ---- image discriminator (train.py:581-592)
     _set_requires_grad(self.d_img, True)
@@ -139,7 +137,12 @@ class Trainer(object):
     losses['d_img_gan_loss'] = L.gan_d_loss(sr, sf)
     self.opt_di.zero_grad()
     losses['d_img_gan_loss'].backward()
-    self._allreduce(self.flat_di)
+    red.start(self.flat_di.grad)
+    # all three updates at the end: same values as the reference's in-order updates because
+    # no network's forward/backward above reads another network's *updated* parameters
+    red.finish()
+    self.opt_g.step_guarded(guard, gs)
+    self.opt_do.step_guarded(guard, gs)
     self.opt_di.step_guarded(guard, gs)
     return {k: v.detach() for k, v in losses.items()}
 

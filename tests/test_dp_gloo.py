@@ -1,0 +1,88 @@
+"""CPU, world_size 2, gloo: the data-parallel exchange.  Each rank takes its shard of a
+collated batch (sg2im_amd.synthetic.shard_batch), computes the reference's per-shard
+gradients with the CPU oracle, packs them into the flat gradient arena of the product's own
+module classes (sg2im_amd.optim.FlatParams) and runs the product's asynchronous reducer.
+Expected: arena * grad_scale == mean over ranks of the per-shard
+reference gradients, identical on every rank; the NaN guard is collective."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.util import load_golden
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  return port
+
+
+def _worker(rank, world, port, ret):
+  os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    from oracle import sg2im_oracle as orc
+    from sg2im_amd.discriminators import PatchDiscriminator
+    from sg2im_amd.distributed import GradReducer
+    from sg2im_amd.optim import FlatParams
+    from sg2im_amd.synthetic import shard_batch
+    from tests.hip_harness import load_params
+    torch.manual_seed(0)
+    fix = load_golden('tiny_coco')
+    dicfg = dict(fix['config']['d_img'])
+    P = fix['state_before']['Di']
+    full = fix['batch']
+    # pad the 3-image golden batch to 4 images so it splits over 2 ranks
+    imgs = torch.cat([full[0], full[0][:1]], 0)
+    fake = torch.cat([fix['outputs']['imgs_pred'], fix['outputs']['imgs_pred'][:1]], 0)
+    lo, hi = rank * 2, rank * 2 + 2
+
+    def shard_grads(r):
+      Pl = {k: v.clone().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in P.items()}
+      sf = orc.patch_discriminator(Pl, dicfg, fake[r * 2:r * 2 + 2], True)
+      sr = orc.patch_discriminator(Pl, dicfg, imgs[r * 2:r * 2 + 2], True)
+      orc.gan_d_loss(sr, sf).backward()
+      return {k: v.grad for k, v in Pl.items() if v.requires_grad and v.grad is not None}
+
+    mine = shard_grads(rank)
+    module = load_params(PatchDiscriminator(**dicfg), P)
+    flat = FlatParams(module)
+    for k, p in module.named_parameters():
+      if k in mine:
+        p.grad.copy_(mine[k])
+    red = GradReducer()
+    assert red.world_size == world
+    red.start(flat.grad)
+    guard = torch.tensor([float('nan') if rank == 1 else 1.0])
+    red.start(guard)
+    red.finish()
+    want = [shard_grads(r) for r in range(world)]
+    worst = 0.0
+    for k, p in module.named_parameters():
+      if k in mine:
+        mean = sum(w[k] for w in want) / world
+        worst = max(worst, float((p.grad * red.grad_scale - mean).abs().max()))
+    ret[rank] = (worst, bool(torch.isfinite(guard).all()))
+    # shard_batch on the 4-image synthetic batch gives each rank 2 whole images
+    from sg2im_amd.synthetic import synthetic_batch
+    sh = shard_batch(synthetic_batch(4, seed=1), rank, world)
+    assert sh[0].size(0) == 2 and int(sh[5].max()) == 1
+  finally:
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_world_size_2():
+  world, port = 2, _free_port()
+  ret = mp.Manager().dict()
+  mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+  assert len(ret) == world
+  for rank in range(world):
+    worst, guard_finite = ret[rank]
+    assert worst <= 1e-7, (rank, worst)
+    assert guard_finite is False          # a NaN loss on ONE rank makes EVERY rank skip the update

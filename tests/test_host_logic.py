@@ -1,0 +1,137 @@
+"""CPU: host-side logic that needs no kernel - batch layout contract, sharding, module /
+state_dict surface, scene-graph encoding, flat parameter arenas."""
+import os
+import sys
+
+import pytest
+import torch
+
+from oracle import sg2im_oracle as orc
+from sg2im_amd.synthetic import make_vocab, shard_batch, synthetic_batch
+
+REF = '/root/reference'
+
+
+@pytest.mark.parametrize('style', ['coco', 'vg'])
+def test_synthetic_batch_follows_collate_contract(style):
+  N = 6
+  imgs, objs, boxes, masks, triples, o2i, t2i = synthetic_batch(N, style=style, seed=4)
+  O, T = objs.numel(), triples.size(0)
+  assert imgs.shape == (N, 3, 64, 64) and boxes.shape == (O, 4) and triples.shape == (T, 3)
+  assert (masks is None) == (style == 'vg')
+  assert bool((o2i[1:] >= o2i[:-1]).all()) and bool((t2i[1:] >= t2i[:-1]).all())
+  for n in range(N):
+    idx = (o2i == n).nonzero().view(-1)
+    assert int(objs[idx[-1]]) == 0 and bool((objs[idx[:-1]] > 0).all())      # __image__ last
+    assert boxes[idx[-1]].tolist() == [0.0, 0.0, 1.0, 1.0]
+    tri = triples[t2i == n]
+    assert bool(((tri[:, 0] >= idx[0]) & (tri[:, 0] <= idx[-1]) & (tri[:, 2] >= idx[0]) & (tri[:, 2] <= idx[-1])).all())
+    k = idx.numel() - 1
+    tail = tri[-k:]                                                            # __in_image__ block
+    assert bool((tail[:, 1] == 0).all()) and bool((tail[:, 2] == idx[-1]).all())
+    assert tail[:, 0].tolist() == idx[:-1].tolist()
+  w = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+  assert float(w.min()) > 0
+
+
+def test_shard_batch_equals_collating_the_shard():
+  full = synthetic_batch(4, seed=9)
+  for r in range(2):
+    sh = shard_batch(full, r, 2)
+    imgs, objs, boxes, masks, triples, o2i, t2i = sh
+    assert imgs.size(0) == 2 and int(o2i.min()) == 0 and int(o2i.max()) == 1
+    assert int(triples[:, [0, 2]].min()) >= 0 and int(triples[:, [0, 2]].max()) < objs.numel()
+    lo = r * 2
+    sel = (full[5] >= lo) & (full[5] < lo + 2)
+    assert torch.equal(objs, full[1][sel]) and torch.equal(boxes, full[2][sel])
+    # a triple's endpoints keep their categories
+    tsel = (full[6] >= lo) & (full[6] < lo + 2)
+    assert torch.equal(objs[triples[:, 0]], full[1][full[4][tsel][:, 0]])
+
+
+def test_generator_state_dict_matches_oracle_and_reference():
+  from sg2im_amd.model import Sg2ImModel
+  from sg2im_amd.trainer import GENERATOR_DEFAULTS
+  vocab = make_vocab(184, 7)
+  m = Sg2ImModel(vocab, **GENERATOR_DEFAULTS)
+  sd = m.state_dict()
+  P = orc.init_generator_params(dict(GENERATOR_DEFAULTS, vocab=vocab))
+  assert set(sd) == set(P)
+  assert all(tuple(sd[k].shape) == tuple(P[k].shape) for k in sd)
+  assert sum(p.numel() for p in m.parameters()) == 28158223
+  if os.path.isdir(REF):
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    from sg2im.model import Sg2ImModel as RefModel
+    r = RefModel(vocab, **GENERATOR_DEFAULTS).state_dict()
+    assert set(r) == set(sd) and all(tuple(r[k].shape) == tuple(sd[k].shape) for k in r)
+    m.load_state_dict(r)                                                   # reference checkpoints load
+  # conv weights are physically channels_last
+  w = m.refinement_net.refinement_modules[1].net[0].weight
+  assert w.permute(0, 2, 3, 1).is_contiguous()
+
+
+def test_discriminator_state_dicts():
+  from sg2im_amd.discriminators import AcCropDiscriminator, PatchDiscriminator
+  from sg2im_amd.trainer import D_IMG_DEFAULTS, D_OBJ_DEFAULTS
+  vocab = make_vocab(184, 7)
+  do = AcCropDiscriminator(vocab, **D_OBJ_DEFAULTS).state_dict()
+  di = PatchDiscriminator(**D_IMG_DEFAULTS).state_dict()
+  Po = orc.init_ac_discriminator_params(dict(D_OBJ_DEFAULTS, vocab=vocab))
+  Pi = orc.init_patch_discriminator_params(dict(D_IMG_DEFAULTS))
+  assert set(do) == set(Po) and set(di) == set(Pi)
+  assert sum(v.numel() for k, v in do.items() if 'running' not in k and 'num_batches' not in k) == 1112057
+  assert sum(v.numel() for k, v in di.items() if 'running' not in k and 'num_batches' not in k) == 659521
+
+
+def test_activation_quirk_and_unsupported_options_fail_loudly():
+  from sg2im_amd import layers
+  assert layers.activation_slope('relu') == 0.01 and layers.activation_slope('leakyrelu-0.2') == 0.2
+  with pytest.raises(ValueError):
+    layers.get_normalization_2d(8, 'bogus')
+  with pytest.raises(NotImplementedError):
+    layers.get_normalization_2d(8, 'instance')
+  with pytest.raises(NotImplementedError):
+    layers.build_cnn('C3-8,R')
+  cnn, c = layers.build_cnn('I3,C4-64-2,C4-128-2,C4-256-2', padding='valid', activation='leakyrelu-0.2')
+  assert c == 256 and cnn.specs == [(4, 64, 2, 0), (4, 128, 2, 0), (4, 256, 2, 0)]
+  assert [k for k in cnn.state_dict()][:3] == ['0.weight', '0.bias', '1.weight']
+
+
+def test_encode_scene_graphs_like_the_reference():
+  import json
+  from sg2im_amd.model import Sg2ImModel
+  vocab = make_vocab(5, 3)
+  vocab['object_name_to_idx'].update({'sheep': 1, 'grass': 2})
+  vocab['pred_name_to_idx'].update({'standing on': 1})
+  m = Sg2ImModel(vocab, image_size=(16, 16), embedding_dim=8, gconv_dim=8, gconv_hidden_dim=16,
+                 gconv_num_layers=1, refinement_dims=(16, 8), mask_size=4)
+  sg = {'objects': ['sheep', 'grass'], 'relationships': [[0, 'standing on', 1]]}
+  objs, triples, o2i = m.encode_scene_graphs([sg])
+  assert objs.tolist() == [1, 2, 0] and o2i.tolist() == [0, 0, 0]
+  assert triples.tolist() == [[0, 1, 1], [0, 0, 2], [1, 0, 2]]
+  assert sg['objects'][-1] == '__image__'                                  # mutates its input
+  with pytest.raises(ValueError):
+    m.encode_scene_graphs({'objects': ['cow'], 'relationships': []})
+  path = os.path.join(REF, 'scene_graphs', 'figure_6_sheep.json')
+  if os.path.exists(path):
+    graphs = json.load(open(path))
+    assert len(graphs) == 7
+
+
+def test_flat_params_alias_parameters_and_grads():
+  from sg2im_amd.optim import FlatParams
+  from sg2im_amd.discriminators import PatchDiscriminator
+  m = PatchDiscriminator(arch='C4-8-2,C4-16-2', padding='valid')
+  before = {k: v.clone() for k, v in m.state_dict().items()}
+  fp = FlatParams(m)
+  for k, v in m.state_dict().items():
+    assert torch.equal(v, before[k])
+  w = m.cnn[0].weight
+  assert w.permute(0, 2, 3, 1).is_contiguous()                              # channels_last kept
+  fp.flat.mul_(2.0)
+  assert torch.equal(m.cnn[0].weight.detach(), before['cnn.0.weight'] * 2)
+  m.cnn[0].bias.grad.fill_(3.0)
+  assert float(fp.grad.sum()) == 3.0 * m.cnn[0].bias.numel()
+  fp.zero_grad()
+  assert float(fp.grad.abs().sum()) == 0.0
