@@ -135,3 +135,14 @@ def test_flat_params_alias_parameters_and_grads():
   assert float(fp.grad.sum()) == 3.0 * m.cnn[0].bias.numel()
   fp.zero_grad()
   assert float(fp.grad.abs().sum()) == 0.0
+
+
+def test_train_script_keeps_the_reference_flag_surface():
+  import re
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  mine = set(re.findall(r"add_argument\('(--\w+)'", open(os.path.join(root, 'scripts', 'train.py')).read()))
+  assert len(mine) >= 63
+  ref_path = os.path.join(REF, 'scripts', 'train.py')
+  if os.path.exists(ref_path):
+    ref = set(re.findall(r"add_argument\('(--\w+)'", open(ref_path).read()))
+    assert not (ref - mine), sorted(ref - mine)
