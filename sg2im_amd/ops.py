@@ -48,7 +48,7 @@ def _i32(t):
 
 
 def workspace(device):
-  key = (device.index, torch.cuda.current_stream().cuda_stream)
+  key = device.index        # one in-order stream per device uses it (also inside graph capture)
   w = _ws.get(key)
   if w is None:
     w = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
@@ -58,7 +58,7 @@ def workspace(device):
 
 def scratch(device, nfloats):
   """Reduction scratch (per device+stream), grown on demand."""
-  key = (device.index, torch.cuda.current_stream().cuda_stream)
+  key = device.index
   s = _scratch.get(key)
   if s is None or s.numel() < nfloats:
     s = torch.empty(max(int(nfloats), 1 << 20), dtype=torch.float32, device=device)

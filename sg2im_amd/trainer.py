@@ -43,7 +43,7 @@ def _set_requires_grad(module, flag):
 
 class Trainer(object):
   def __init__(self, vocab, device, generator_kwargs=None, d_obj_kwargs=None, d_img_kwargs=None,
-               loss_weights=None, learning_rate=1e-4, world_size=1, seed=None):
+               loss_weights=None, learning_rate=1e-4, world_size=1, seed=None, use_graphs=False):
     self.device = device
     self.world_size = world_size
     if seed is not None:
@@ -71,6 +71,8 @@ class Trainer(object):
     self.opt_do = FlatAdam(self.flat_do, lr=learning_rate)
     self.opt_di = FlatAdam(self.flat_di, lr=learning_rate)
     self.reducer = GradReducer(world_size)
+    self.use_graphs = use_graphs
+    self._graphs, self._graph_warm = {}, {}
     self.t = 0
 
   # -- data-parallel helpers --------------------------------------------------
@@ -80,23 +82,20 @@ class Trainer(object):
     self.opt_g.reset_state()
 
   # -- one iteration ----------------------------------------------------------
-  def step(self, batch):
-    """batch: (imgs (N,3,H,W), objs, boxes, masks | None, triples, obj_to_img) on the device.
-    Returns a dict of 0-dim device tensors (no host sync)."""
+  # The iteration is four segments separated by the points where a data-parallel exchange
+  # is started: generator fwd+bwd | D_obj fwd+bwd | D_img fwd+bwd | the three Adam updates.
+  def _seg_generator(self, batch, st):
     imgs, objs, boxes, masks, triples, obj_to_img = batch[:6]
     w = self.w
     N = imgs.size(0)
-    gs = self.reducer.grad_scale
-    self.t += 1
-    imgs_nhwc = HF.NchwToNhwc.apply(imgs)
-
-    # ---- generator (train.py:524-560)
+    st['imgs_nhwc'] = HF.NchwToNhwc.apply(imgs)
+    # train.py:524-560.  The discriminators are frozen here (see module docstring).
     _set_requires_grad(self.d_obj, False)
     _set_requires_grad(self.d_img, False)
     imgs_pred, boxes_pred, masks_pred, rel_scores = self.model.forward_nhwc(
       objs, triples, obj_to_img, boxes_gt=boxes, masks_gt=masks, num_images=N)
-    losses = {}
-    losses['L1_pixel_loss'] = L.l1_loss(imgs_pred, imgs_nhwc, w['l1_pixel_loss_weight'])
+    losses = st['losses']
+    losses['L1_pixel_loss'] = L.l1_loss(imgs_pred, st['imgs_nhwc'], w['l1_pixel_loss_weight'])
     losses['bbox_pred'] = L.mse_loss(boxes_pred, boxes, w['bbox_pred_loss_weight'])
     scores_fake, ac_loss = self.d_obj.forward_nhwc(imgs_pred, objs, boxes, obj_to_img)
     losses['ac_loss'] = ac_loss * w['ac_loss_weight']
@@ -104,47 +103,124 @@ class Trainer(object):
     scores_fake = self.d_img.forward_nhwc(imgs_pred)
     losses['g_gan_img_loss'] = L.gan_g_loss(scores_fake) * (w['discriminator_loss_weight'] * w['d_img_weight'])
     total = None
-    for v in losses.values():
+    for v in list(losses.values()):
       total = v if total is None else total + v
     losses['total_loss'] = total
     self.opt_g.zero_grad()
     total.backward()
-    # The 112 MB generator exchange starts now and is only waited for after both
-    # discriminator passes (they never read G's parameters), see sg2im_amd/distributed.py.
+    st['imgs_fake'] = imgs_pred.detach()
     # NaN guard of train.py:553-555 without a host sync: every optimiser of this iteration
     # skips its update when the generator loss is not finite (on any rank).
-    guard = total.detach().reshape(1).clone()
-    red = self.reducer
-    red.start(self.flat_g.grad)
-    red.start(guard)
-
-    # ---- object discriminator (train.py:566-579)
+    st['guard'] = total.detach().reshape(1).clone()
     _set_requires_grad(self.d_obj, True)
-    imgs_fake = imgs_pred.detach()
-    sf, ac_fake = self.d_obj.forward_nhwc(imgs_fake, objs, boxes, obj_to_img)
-    sr, ac_real = self.d_obj.forward_nhwc(imgs_nhwc, objs, boxes, obj_to_img)
+    _set_requires_grad(self.d_img, True)
+
+  def _seg_d_obj(self, batch, st):
+    imgs, objs, boxes, masks, triples, obj_to_img = batch[:6]
+    losses = st['losses']
+    # train.py:566-579
+    sf, ac_fake = self.d_obj.forward_nhwc(st['imgs_fake'], objs, boxes, obj_to_img)
+    sr, ac_real = self.d_obj.forward_nhwc(st['imgs_nhwc'], objs, boxes, obj_to_img)
     losses['d_obj_gan_loss'] = L.gan_d_loss(sr, sf)
     losses['d_ac_loss_real'], losses['d_ac_loss_fake'] = ac_real, ac_fake
     d_obj_total = losses['d_obj_gan_loss'] + ac_real + ac_fake
     self.opt_do.zero_grad()
     d_obj_total.backward()
-    red.start(self.flat_do.grad)
 
-    # ---- image discriminator (train.py:581-592)
-    _set_requires_grad(self.d_img, True)
-    sf = self.d_img.forward_nhwc(imgs_fake)
-    sr = self.d_img.forward_nhwc(imgs_nhwc)
+  def _seg_d_img(self, batch, st):
+    losses = st['losses']
+    # train.py:581-592
+    sf = self.d_img.forward_nhwc(st['imgs_fake'])
+    sr = self.d_img.forward_nhwc(st['imgs_nhwc'])
     losses['d_img_gan_loss'] = L.gan_d_loss(sr, sf)
     self.opt_di.zero_grad()
     losses['d_img_gan_loss'].backward()
-    red.start(self.flat_di.grad)
+
+  def _seg_adam(self, st):
     # all three updates at the end: same values as the reference's in-order updates because
-    # no network's forward/backward above reads another network's *updated* parameters
-    red.finish()
+    # no forward/backward above reads another network's *updated* parameters
+    gs, guard = self.reducer.grad_scale, st['guard']
     self.opt_g.step_guarded(guard, gs)
     self.opt_do.step_guarded(guard, gs)
     self.opt_di.step_guarded(guard, gs)
-    return {k: v.detach() for k, v in losses.items()}
+    st['out'] = {k: v.detach() for k, v in st['losses'].items()}
+
+  def _run_segments(self, batch, st, run):
+    """run(name, fn) executes (or replays) one segment; exchanges are started in between.
+    The 112 MB generator all-reduce is only waited for after both discriminator passes
+    (they never read G's parameters), see sg2im_amd/distributed.py."""
+    red = self.reducer
+    run('g', lambda: self._seg_generator(batch, st))
+    red.start(self.flat_g.grad)
+    red.start(st['guard'])
+    run('do', lambda: self._seg_d_obj(batch, st))
+    red.start(self.flat_do.grad)
+    run('di', lambda: self._seg_d_img(batch, st))
+    red.start(self.flat_di.grad)
+    red.finish()
+    run('adam', lambda: self._seg_adam(st))
+
+  def step(self, batch):
+    """batch: (imgs (N,3,H,W), objs, boxes, masks | None, triples, obj_to_img) on the device.
+    Returns a dict of 0-dim device tensors (no host sync)."""
+    self.t += 1
+    if self.use_graphs:
+      return self._graph_step(batch)
+    st = {'losses': {}}
+    self._run_segments(batch, st, lambda name, fn: fn())
+    return st['out']
+
+  # -- hipGraph replay for shape-static batches -----------------------------------
+  def _graph_step(self, batch):
+    """The eager step costs ~12 ms of Python/ctypes launch time for ~480 kernels - more
+    than the kernels themselves once they are fast.  For a batch signature (tensor shapes)
+    seen before, the four segments are captured once into hipGraphs (torch.cuda.CUDAGraph
+    records the launches our C ABI makes on the capture stream) and replayed; inputs are
+    copied into the graphs' static buffers.  New signatures run eagerly twice (warm-up:
+    kernel attribute calls, workspace growth) and are then captured.  Collectives stay
+    outside the graphs."""
+    tensors = [t for t in batch[:6] if torch.is_tensor(t)]
+    key = tuple((tuple(t.shape), t.dtype) for t in batch[:6] if torch.is_tensor(t)) + (batch[3] is None,)
+    ent = self._graphs.get(key)
+    if ent is None:
+      seen = self._graph_warm.get(key, 0)
+      if seen < 2:
+        self._graph_warm[key] = seen + 1
+        st = {'losses': {}}
+        self._run_segments(batch, st, lambda name, fn: fn())
+        return st['out']
+      static = tuple(t.clone() if torch.is_tensor(t) else t for t in batch[:6])
+      st = {'losses': {}}
+      graphs = {}
+      pool = [None]
+
+      def capture(name, fn):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=pool[0]):
+          fn()
+        if pool[0] is None:
+          pool[0] = g.pool()
+        graphs[name] = g
+      torch.cuda.synchronize()
+      try:
+        self._run_segments(static, st, capture)
+      except Exception as e:      # capture unsupported here: stay eager, loudly
+        print('WARNING: hipGraph capture failed (%s: %s); falling back to eager launches' % (type(e).__name__, e))
+        self.use_graphs = False
+        torch.cuda.synchronize()
+        st = {'losses': {}}
+        self._run_segments(batch, st, lambda name, fn: fn())
+        return st['out']
+      ent = (static, graphs, st)
+      self._graphs[key] = ent
+      # capture records but does not execute: run the freshly captured graphs once now
+      self._run_segments(static, st, lambda name, fn: graphs[name].replay())
+      return st['out']
+    static, graphs, st = ent
+    for s, t in zip([x for x in static if torch.is_tensor(x)], tensors):
+      s.copy_(t, non_blocking=True)
+    self._run_segments(static, st, lambda name, fn: graphs[name].replay())
+    return st['out']
 
   @staticmethod
   def losses_to_host(losses):
