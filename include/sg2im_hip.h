@@ -90,11 +90,12 @@ int sg2im_csr_build(const long long* keys_a, int n_a, const long long* keys_b, i
 /* out[j][0:width] = sum over row j's entries, in CSR order, starting from +0.0f, of
  *   src_a[e*ld_a + 0:width]            (e <  n_a)
  *   src_b[(e-n_a)*ld_b + 0:width]      (e >= n_a)
- * then, if average != 0, divided by max(1, #entries)  (graph.py:92-114: pooling sum/avg).
+ * then, if average != 0, divided by max(1, #entries)  (graph.py:92-114: pooling sum/avg);
+ * accumulate != 0 adds the result to out instead of overwriting it (gradient arenas).
  * Bit-exact w.r.t. the sequential fp32 order rule (oracle.gconv_pool_sequential). */
 int sg2im_segment_sum(const float* src_a, long long ld_a, int n_a, const float* src_b, long long ld_b,
                       const int* row_ptr, const int* entries, int n_rows, int width, int average,
-                      float* out, long long ld_out, hipStream_t stream);
+                      int accumulate, float* out, long long ld_out, hipStream_t stream);
 /* dst[i][0:width] = src[idx[i]][0:width] (bit-exact copy) ; if row_ptr != NULL the row is
  * divided by max(1, row_ptr[idx[i]+1]-row_ptr[idx[i]])  (backward of the 'avg' pooling). */
 int sg2im_gather_rows(const float* src, long long ld_src, const long long* idx, int n, int width,

@@ -80,7 +80,8 @@ __global__ void csr_ranksort_kernel(const int* __restrict__ row_ptr, const int* 
 __global__ void segment_sum_kernel(const float* __restrict__ src_a, long long ld_a, int n_a,
                                    const float* __restrict__ src_b, long long ld_b,
                                    const int* __restrict__ row_ptr, const int* __restrict__ entries,
-                                   int width, int average, float* __restrict__ out, long long ld_out) {
+                                   int width, int average, int accumulate, float* __restrict__ out,
+                                   long long ld_out) {
   const int row = blockIdx.x;
   const int b = row_ptr[row], e = row_ptr[row + 1];
   const float cnt = (float)max(1, e - b);
@@ -96,7 +97,9 @@ __global__ void segment_sum_kernel(const float* __restrict__ src_a, long long ld
         acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w;
       }
       if (average) { acc.x = acc.x / cnt; acc.y = acc.y / cnt; acc.z = acc.z / cnt; acc.w = acc.w / cnt; }
-      *reinterpret_cast<float4*>(out + (long long)row * ld_out + c) = acc;
+      float4* dst = reinterpret_cast<float4*>(out + (long long)row * ld_out + c);
+      if (accumulate) { const float4 o = *dst; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+      *dst = acc;
     }
   } else {
     for (int c = threadIdx.x; c < width; c += blockDim.x) {
@@ -106,6 +109,7 @@ __global__ void segment_sum_kernel(const float* __restrict__ src_a, long long ld
         acc = acc + (id < n_a ? src_a[(long long)id * ld_a + c] : src_b[(long long)(id - n_a) * ld_b + c]);
       }
       if (average) acc = acc / cnt;
+      if (accumulate) acc += out[(long long)row * ld_out + c];
       out[(long long)row * ld_out + c] = acc;
     }
   }
@@ -175,13 +179,13 @@ int sg2im_csr_build(const long long* keys_a, int n_a, const long long* keys_b, i
 
 int sg2im_segment_sum(const float* src_a, long long ld_a, int n_a, const float* src_b, long long ld_b,
                       const int* row_ptr, const int* entries, int n_rows, int width, int average,
-                      float* out, long long ld_out, hipStream_t stream) {
+                      int accumulate, float* out, long long ld_out, hipStream_t stream) {
   if (n_rows < 0 || width < 1 || !row_ptr || !out || !src_a) return SG2IM_ERR_ARG;
   if (n_rows == 0) return SG2IM_OK;
   if (!src_b) { src_b = src_a; ld_b = ld_a; }
   const int threads = std::min(256, std::max(64, ((width + 3) / 4 + 63) / 64 * 64));
   hipLaunchKernelGGL(segment_sum_kernel, dim3(n_rows), dim3(threads), 0, stream, src_a, ld_a, n_a, src_b, ld_b,
-                     row_ptr, entries, width, average, out, ld_out);
+                     row_ptr, entries, width, average, accumulate, out, ld_out);
   return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
 }
 

@@ -172,15 +172,19 @@ class Embedding(Function):
   @staticmethod
   def forward(ctx, weight, idx):
     out = ops.gather_rows(weight, idx, _new(weight, idx.numel(), weight.size(1)))
-    ctx.save_for_backward(idx)
+    ctx.save_for_backward(idx, weight)
     ctx.rows = weight.size(0)
     return out
 
   @staticmethod
   def backward(ctx, g):
-    idx, = ctx.saved_tensors
+    idx, weight = ctx.saved_tensors
     g = g.contiguous()
     csr = ops.Csr(idx, None, ctx.rows)
+    sk = _sink(weight)
+    if sk is not None:
+      ops.segment_sum(g, None, csr, g.size(1), False, sk, accumulate=True)
+      return None, None
     dw = ops.segment_sum(g, None, csr, g.size(1), False, _new(g, ctx.rows, g.size(1)))
     return dw, None
 

@@ -207,12 +207,12 @@ class Csr(object):
          _i32(self.entries), _i32(tmp), _stream())
 
 
-def segment_sum(src_a, src_b, csr, width, average, out):
+def segment_sum(src_a, src_b, csr, width, average, out, accumulate=False):
   pa, lda = rows_ld(src_a)
   pb, ldb = rows_ld(src_b) if src_b is not None else (None, 0)
   po, ldo = rows_ld(out)
   call('sg2im_segment_sum', pa, lda, csr.n_a, pb, ldb, _i32(csr.row_ptr), _i32(csr.entries), csr.n_rows,
-       int(width), int(average), po, ldo, _stream())
+       int(width), int(average), int(accumulate), po, ldo, _stream())
   return out
 
 

@@ -57,7 +57,7 @@ def test_argument_validation_without_a_gpu(lib):
   d = ConvDesc()
   d.nsrc = 0
   assert lib.sg2im_conv2d_forward(ctypes.byref(d), None, 8, None, 1.0, None, 8, 0, None, 0, None) == SG2IM_ERR_ARG
-  assert lib.sg2im_segment_sum(None, 0, 0, None, 0, None, None, 4, 0, 0, None, 0, None) == SG2IM_ERR_ARG
+  assert lib.sg2im_segment_sum(None, 0, 0, None, 0, None, None, 4, 0, 0, 0, None, 0, None) == SG2IM_ERR_ARG
   assert lib.sg2im_adam_step(None, None, None, None, 0, 1e-4, .9, .999, 1e-8, 1, 1.0, None) == SG2IM_ERR_ARG
 
 

@@ -128,3 +128,24 @@ def test_trainer_two_steps_match_oracle():
       if v.is_floating_point():
         d = float((sd[k].detach().cpu() - v.detach()).abs().max())
         assert d <= 4.1e-4 or 'running_' in k and d <= 1e-3, (name, k, d)
+
+
+def test_graph_replay_matches_eager_steps():
+  """hipGraph replay of the four step segments == eager launches (same kernels, same order);
+  layout noise disabled so both trainers see identical inputs.  Tolerance covers the
+  float atomics of the crop backward (order-dependent at 1e-7)."""
+  from sg2im_amd.synthetic import make_vocab, synthetic_batch
+  from sg2im_amd.trainer import Trainer
+  from tests import hip_harness as hh
+  dev = hh.dev()
+  vocab = make_vocab(184, 7)
+  batch = tuple(t.to(dev) if torch.is_tensor(t) else t for t in synthetic_batch(4, seed=11))
+  kw = dict(generator_kwargs={'layout_noise_dim': 0}, seed=7)
+  a, b = Trainer(vocab, dev, use_graphs=False, **kw), Trainer(vocab, dev, use_graphs=True, **kw)
+  for _ in range(6):                       # b: 2 eager warm-ups, capture (+ first replay), 3 replays
+    la, lb = Trainer.losses_to_host(a.step(batch)), Trainer.losses_to_host(b.step(batch))
+  assert len(b._graphs) == 1
+  for k in la:
+    assert abs(la[k] - lb[k]) <= 2e-4 * max(1.0, abs(la[k])), (k, la[k], lb[k])
+  d = float((a.flat_g.flat - b.flat_g.flat).abs().max())
+  assert d <= 1e-3, d                      # 6 Adam steps of lr 1e-4: sign flips of noise-level grads only
