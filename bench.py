@@ -93,7 +93,7 @@ def main():
                               max_objs=8, mask_size=16, style='coco', seed=args.seed + rank)
   batch = tuple(t.to(device) if torch.is_tensor(t) else t for t in cpu_batch)
   trainer = Trainer(vocab, device, generator_kwargs={'image_size': (S, S)}, world_size=world, seed=1234,
-                    use_graphs=not args.no_graphs)
+                    use_graphs=(world == 1 and not args.no_graphs))   # collectives between replays: eager
 
   def sync():
     torch.cuda.synchronize()
@@ -103,7 +103,7 @@ def main():
 
   # one-time setup outside warm-up/timing: the first steps of a new batch signature run eagerly
   # and are then captured into hipGraphs (sg2im_amd/trainer.py::_graph_step)
-  for _ in range(0 if args.no_graphs else 3):
+  for _ in range(3 if trainer.use_graphs else 0):
     trainer.step(batch)
   for _ in range(args.warmup):
     trainer.step(batch)
@@ -162,7 +162,7 @@ def main():
                  'global_batch': args.batch_size * world, 'image_size': S,
                  'objects': int(batch[1].numel()), 'triples': int(batch[4].size(0)),
                  'parallelism': 'dp%d' % world, 'total_loss': round(host_losses['total_loss'], 5),
-                 'launch': 'eager' if args.no_graphs else 'hipGraph replay (4 segments)'},
+                 'launch': 'hipGraph replay (4 segments)' if (world == 1 and not args.no_graphs) else 'eager'},
       'roofline': roofline, 'cpu_baseline': cpu,
     }
     print(json.dumps(out), flush=True)

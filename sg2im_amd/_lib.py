@@ -99,9 +99,23 @@ def load():
   return lib
 
 
+_TRACE = os.environ.get('SG2IM_TRACE', '') == '1'
+EAGER_EPOCH = 0      # number of launches made through this binding (eager or captured)
+
+
 def call(name, *args):
-  """Invoke an int-returning entry point and raise on a non-zero status."""
+  """Invoke an int-returning entry point and raise on a non-zero status.  SG2IM_TRACE=1
+  prints every call and synchronises after it (debugging aid: pins a device fault to an op)."""
+  global EAGER_EPOCH
+  EAGER_EPOCH += 1            # see sg2im_amd/trainer.py::_graph_step (graph invalidation)
   rc = getattr(load(), name)(*args)
+  if _TRACE:
+    import sys
+    import torch
+    sys.stderr.write('[sg2im] %s\n' % name)
+    sys.stderr.flush()
+    if not torch.cuda.is_current_stream_capturing():
+      torch.cuda.synchronize()
   if rc != SG2IM_OK:
     kind = {SG2IM_ERR_ARG: 'invalid argument', SG2IM_ERR_HIP: 'HIP runtime error'}.get(rc, 'error %d' % rc)
     raise Sg2imHipError('%s failed: %s' % (name, kind))

@@ -16,6 +16,7 @@ import math
 import torch
 import torch.distributed as dist
 
+from . import _lib
 from . import functional as HF
 from . import losses as L
 from .discriminators import AcCropDiscriminator, PatchDiscriminator
@@ -178,10 +179,21 @@ class Trainer(object):
     records the launches our C ABI makes on the capture stream) and replayed; inputs are
     copied into the graphs' static buffers.  New signatures run eagerly twice (warm-up:
     kernel attribute calls, workspace growth) and are then captured.  Collectives stay
-    outside the graphs."""
+    outside the graphs.
+
+    ROCm 7 caveat (measured, tools/graph_check2.py): ONE eager kernel launch from this
+    library after a graph was instantiated makes the next replay of that graph fault
+    (torch's own eager kernels and allocations do not).  Every launch through the binding
+    bumps ``_lib.EAGER_EPOCH``; a graph whose epoch is stale is discarded and re-captured
+    instead of replayed, so interleaving eager use of the library with graph steps is safe,
+    merely slower."""
     tensors = [t for t in batch[:6] if torch.is_tensor(t)]
     key = tuple((tuple(t.shape), t.dtype) for t in batch[:6] if torch.is_tensor(t)) + (batch[3] is None,)
     ent = self._graphs.get(key)
+    if ent is not None and ent[3] != _lib.EAGER_EPOCH:
+      del self._graphs[key]          # the library was used eagerly since the capture
+      ent = None
+      self._graph_warm[key] = 2
     if ent is None:
       seen = self._graph_warm.get(key, 0)
       if seen < 2:
@@ -211,12 +223,11 @@ class Trainer(object):
         st = {'losses': {}}
         self._run_segments(batch, st, lambda name, fn: fn())
         return st['out']
-      ent = (static, graphs, st)
-      self._graphs[key] = ent
+      self._graphs[key] = (static, graphs, st, _lib.EAGER_EPOCH)
       # capture records but does not execute: run the freshly captured graphs once now
       self._run_segments(static, st, lambda name, fn: graphs[name].replay())
       return st['out']
-    static, graphs, st = ent
+    static, graphs, st, _ = ent
     for s, t in zip([x for x in static if torch.is_tensor(x)], tensors):
       s.copy_(t, non_blocking=True)
     self._run_segments(static, st, lambda name, fn: graphs[name].replay())
