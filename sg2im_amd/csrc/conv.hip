@@ -566,7 +566,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams 
       const int hb = ho * g.stride - g.pad, wb = wo * g.stride - g.pad;
       if (VEC == 4) {
         const int hi = hb + bkh, wi = wb + bkw;
-        const bool ok = bok && pix < p.P && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+        // (n < NB: the depth-1 pipeline re-issues the last chunk once more, with the row
+        // coordinates already advanced past the end)
+        const bool ok = bok && pix < p.P && n < g.NB && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
         mb |= (ok ? 1u : 0u) << i;
         unsigned row;
         if (GATHER) row = BS.gidx ? (unsigned)BS.gidx[ok ? n : 0] : (unsigned)(ok ? n : 0);
@@ -577,7 +579,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams 
         #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int hi = hb + jkh[j], wi = wb + jkw[j];
-          e[j] = (pix < p.P && jok[j] && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W)
+          e[j] = (pix < p.P && n < g.NB && jok[j] && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W)
                    ? load1(g, pick_src(g, js[j]), n, hi, wi, jcs[j]) : 0.f;
         }
         r.b[i] = make_float4(e[0], e[1], e[2], e[3]);

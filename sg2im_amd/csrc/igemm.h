@@ -212,6 +212,38 @@ __device__ __forceinline__ void epilogue(const Epi& e, int M, int N, int nlimit,
 // never dynamically indexed, which would demote them to scratch)
 template <int I> struct IC { static constexpr int value = I; };
 
+#ifndef SG2IM_PIPE_DEPTH
+#define SG2IM_PIPE_DEPTH 1
+#endif
+
+#if SG2IM_PIPE_DEPTH == 1
+// Depth-1 variant: ONE register set and a branch-free loop body - the loads of chunk i+1,
+// the MFMAs of chunk i and the LDS stores of chunk i+1 are one basic block, so the compiler
+// can slot the loader's address arithmetic into the 64-cycle shadows of the MFMAs (a wave
+// issues ~8 other instructions per fp32 MFMA for free).  The last chunk is fetched and
+// staged a second time instead of guarding the tail with branches; that copy is never read.
+template <typename Load, typename Stage, typename Mma>
+__device__ __forceinline__ void k_pipeline(int it_begin, int it_end, Load load, Stage stage, Mma mma) {
+  const int n = it_end - it_begin;
+  if (n <= 0) return;
+  load(it_begin, IC<0>());
+  stage(IC<0>(), 0);
+  __syncthreads();
+  int cur = 0;
+  #pragma unroll 1
+  for (int i = 0; i < n; ++i) {
+    const int nxt = i + 1 < n ? i + 1 : n - 1;
+    load(it_begin + nxt, IC<0>());
+    // keep the global loads ahead of the MFMA block: left alone, the scheduler sinks them
+    // to just before their first use (end of the block) and the wave stalls on vmcnt
+    __builtin_amdgcn_sched_barrier(0);
+    mma(cur);
+    stage(IC<0>(), cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+#else
 template <typename Load, typename Stage, typename Mma>
 __device__ __forceinline__ void k_pipeline(int it_begin, int it_end, Load load, Stage stage, Mma mma) {
   const int n = it_end - it_begin;
@@ -255,6 +287,7 @@ __device__ __forceinline__ void k_pipeline(int it_begin, int it_end, Load load, 
     __syncthreads();
   }
 }
+#endif
 
 // wave placement inside the block tile: 2 x 2 wavefronts
 template <int BM, int BN>
