@@ -8,7 +8,7 @@ import os
 from ctypes import c_float, c_int, c_longlong, c_size_t, c_void_p, POINTER, Structure
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libsg2im_hip.so')
+LIB_PATH = os.environ.get('SG2IM_LIB') or os.path.join(_HERE, 'lib', 'libsg2im_hip.so')
 
 SG2IM_OK, SG2IM_ERR_ARG, SG2IM_ERR_HIP = 0, 1, 2
 

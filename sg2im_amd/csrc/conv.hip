@@ -752,7 +752,7 @@ static hipError_t finish_split(const Epi& e, long long M, int N, hipStream_t st)
 
 template <int BM, int BN, int VEC, bool GATHER>
 static hipError_t launch_fwd_g(FwdParams& p, hipStream_t st) {
-  constexpr size_t lds = 2 * (LdsTile<BM, false>::FLOATS + LdsTile<BN, false>::FLOATS) * sizeof(float);
+  constexpr size_t lds = LDS_STAGES * (LdsTile<BM, false>::FLOATS + LdsTile<BN, false>::FLOATS) * sizeof(float);
   static bool once = false;
   if (!once) { hipError_t e = ensure_lds(conv_fwd_kernel<BM, BN, VEC, GATHER>, lds); if (e != hipSuccess) return e; once = true; }
   dim3 grid((p.Cout + BN - 1) / BN, (p.M + BM - 1) / BM, p.e.nsplit);
@@ -770,7 +770,7 @@ static hipError_t launch_fwd(FwdParams& p, hipStream_t st) {
 
 template <int BM, int BN, int VA, int VB>
 static hipError_t launch_dgrad(DgradParams& p, hipStream_t st) {
-  constexpr size_t lds = 2 * (LdsTile<BM, false>::FLOATS + LdsTile<BN, true>::FLOATS) * sizeof(float);
+  constexpr size_t lds = LDS_STAGES * (LdsTile<BM, false>::FLOATS + LdsTile<BN, true>::FLOATS) * sizeof(float);
   static bool once = false;
   if (!once) { hipError_t e = ensure_lds(conv_dgrad_kernel<BM, BN, VA, VB>, lds); if (e != hipSuccess) return e; once = true; }
   dim3 grid((p.Nc + BN - 1) / BN, (p.M + BM - 1) / BM, p.parity ? 4 : p.e.nsplit);
@@ -780,7 +780,7 @@ static hipError_t launch_dgrad(DgradParams& p, hipStream_t st) {
 
 template <int BM, int BN, int VEC, bool GATHER>
 static hipError_t launch_wgrad_g(WgradParams& p, int ntiles_n, hipStream_t st) {
-  constexpr size_t lds = 2 * (LdsTile<BM, true>::FLOATS + LdsTile<BN, true>::FLOATS) * sizeof(float);
+  constexpr size_t lds = LDS_STAGES * (LdsTile<BM, true>::FLOATS + LdsTile<BN, true>::FLOATS) * sizeof(float);
   static bool once = false;
   if (!once) { hipError_t e = ensure_lds(conv_wgrad_kernel<BM, BN, VEC, GATHER>, lds); if (e != hipSuccess) return e; once = true; }
   p.ntiles_n = ntiles_n;

@@ -215,6 +215,10 @@ template <int I> struct IC { static constexpr int value = I; };
 #ifndef SG2IM_PIPE_DEPTH
 #define SG2IM_PIPE_DEPTH 1
 #endif
+#ifndef SG2IM_LDS_STAGES
+#define SG2IM_LDS_STAGES 1
+#endif
+constexpr int LDS_STAGES = SG2IM_LDS_STAGES;
 
 #if SG2IM_PIPE_DEPTH == 1
 // Depth-1 variant: ONE register set and a branch-free loop body - the loads of chunk i+1,
@@ -237,10 +241,19 @@ __device__ __forceinline__ void k_pipeline(int it_begin, int it_end, Load load, 
     // keep the global loads ahead of the MFMA block: left alone, the scheduler sinks them
     // to just before their first use (end of the block) and the wave stalls on vmcnt
     __builtin_amdgcn_sched_barrier(0);
-    mma(cur);
-    stage(IC<0>(), cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
+    if (LDS_STAGES == 2) {
+      mma(cur);
+      stage(IC<0>(), cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    } else {
+      // single LDS image (half the LDS -> twice the resident workgroups): every wave must
+      // be done reading chunk i before it is overwritten, hence the second barrier
+      mma(0);
+      __syncthreads();
+      stage(IC<0>(), 0);
+      __syncthreads();
+    }
   }
 }
 #else
