@@ -384,6 +384,15 @@ def _conv_param_grads(desc, dy, cout, w_phys_shape, need_w, need_b, W=None, b=No
   return dw, db
 
 
+def _shadowed_bias_grad(b, need):
+  """Gradient of a conv bias that feeds a *training-mode* BatchNorm: the batch-mean
+  subtraction cancels the bias, so the gradient is exactly zero.  The reference computes
+  it numerically (sum of dy, ~1e-8 rounding noise); here it is not computed at all."""
+  if not need or _sink(b) is not None:
+    return None                      # the zeroed gradient arena already holds the answer
+  return torch.zeros_like(b)
+
+
 def _bn_grad_bufs(like, C, gamma, beta, need_g, need_b):
   """(dgamma buffer, dbeta buffer, accumulate, return_dgamma, return_dbeta)"""
   sg, sb = _sink(gamma) if need_g else None, _sink(beta) if need_b else None
@@ -484,16 +493,20 @@ class RefinementFn(Function):
       dy1 = ops.bn_act_backward(_fptr(gz), gz.size(3), pool2, N, h, w, y1, C, C, g1, st1, slope, training,
                                 _new(g, N, h, w, C), dg1, db1n, acc1)
       d1 = conv_desc([nhwc_src(y0, 0, st0.scale, st0.shift, slope)], N, h, w, 3, 3, 1, 1)
-      grads[4 * i + 2], grads[4 * i + 3] = _conv_param_grads(d1, dy1, C, (C, 3, 3, C), ni[4 * i + 2], ni[4 * i + 3],
-                                                              W1p, b1)
+      grads[4 * i + 2], grads[4 * i + 3] = _conv_param_grads(d1, dy1, C, (C, 3, 3, C), ni[4 * i + 2],
+                                                              ni[4 * i + 3] and not training, W1p, b1)
+      if training:
+        grads[4 * i + 3] = _shadowed_bias_grad(b1, ni[4 * i + 3])
       gz0 = _new(g, N, h, w, C)
       ops.conv2d_backward_data(d1, _cl_weight(W1p), C, dy1, C, 0, C, gz0, C)
       dg0, db0n, acc0, grads[k], grads[k + 1] = _bn_grad_bufs(g, C, g0, be0, ni[k], ni[k + 1])
       dy0 = ops.bn_act_backward(_fptr(gz0), C, 0, N, h, w, y0, C, C, g0, st0, slope, training, dy1, dg0, db0n, acc0)
       Cprev = feat_src.channels
       d0 = conv_desc([nhwc_src(lay), feat_src], N, h, w, 3, 3, 1, 1)
-      grads[4 * i], grads[4 * i + 1] = _conv_param_grads(d0, dy0, C, (C, 3, 3, Cl + Cprev), ni[4 * i], ni[4 * i + 1],
-                                                          W0p, b0)
+      grads[4 * i], grads[4 * i + 1] = _conv_param_grads(d0, dy0, C, (C, 3, 3, Cl + Cprev), ni[4 * i],
+                                                          ni[4 * i + 1] and not training, W0p, b0)
+      if training:
+        grads[4 * i + 1] = _shadowed_bias_grad(b0, ni[4 * i + 1])
       if need_layout:
         dl = _new(g, N, h, w, Cg)
         ops.conv2d_backward_data(d0, _cl_weight(W0p), C, dy0, C, 0, Cg, dl, Cg)
@@ -621,8 +634,11 @@ class DiscCnnFn(Function):
       else:
         wi = 2 + 4 * (i - 1) + 2
         Wp = params[wi]
-      grads[wi], grads[wi + 1] = _conv_param_grads(d, dy, cout, (cout, k, k, cin), ni[wi], ni[wi + 1], Wp,
-                                                   params[wi + 1])
+      shadowed = training and i + 1 < len(specs)          # followed by a batch-statistics BN
+      grads[wi], grads[wi + 1] = _conv_param_grads(d, dy, cout, (cout, k, k, cin), ni[wi], ni[wi + 1] and not shadowed,
+                                                   Wp, params[wi + 1])
+      if shadowed:
+        grads[wi + 1] = _shadowed_bias_grad(params[wi + 1], ni[wi + 1])
       if i == 0:
         dx = None
         if ctx.needs_input_grad[0]:
