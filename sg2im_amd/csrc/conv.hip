@@ -491,15 +491,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams 
   const int Ntot = taps * g.Ctot;
   const int HoWo = g.Ho * g.Wo;
 
-  // column tile -> (tap, first concat channel) for VEC=4, flat column for VEC=1
-  int n0, tap0 = 0, c0 = 0;
-  if (VEC == 4) {
-    tap0 = ntile_x / p.ntile_c;
-    c0 = (ntile_x - tap0 * p.ntile_c) * BN;
-    n0 = tap0 * g.Ctot + c0;
-  } else {
-    n0 = ntile_x * BN;
-  }
+  // Column tiles run over the FLAT (tap, channel) axis of dW, so a tile may straddle taps;
+  // a thread's float4 never does (Ctot % 4 == 0) and keeps its own (tap, source, channel).
+  const int n0 = ntile_x * BN;
   constexpr int QA = BM / 4, QB = BN / 4;
   const int acol4 = tid % QA, ak0 = tid / QA;
   const int bcol4 = tid % QB, bk0 = tid / QB;
@@ -508,11 +502,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams 
 
   // per-thread B column(s): fixed for the whole reduction
   int bs = 0, bcs = 0;
-  const int bc = c0 + 4 * bcol4;
-  const bool bok = (VEC == 4) && bc < g.Ctot;
-  locate_channel(g, bok ? bc : 0, bs, bcs);
+  const int bcol = n0 + 4 * bcol4;
+  const bool bok = (VEC == 4) && bcol < Ntot;
+  const int btap = bok ? bcol / g.Ctot : 0;
+  locate_channel(g, bok ? bcol - btap * g.Ctot : 0, bs, bcs);
   const Src BS = pick_src(g, bs);
-  const int bkh = tap0 / g.KW, bkw = tap0 - bkh * g.KW;
+  const int bkh = btap / g.KW, bkw = btap - bkh * g.KW;
   const int Hs = g.H >> BS.up, Ws = g.W >> BS.up;
   Aff baff;
   fetch_aff(baff, BS, bcs, bok);
@@ -616,9 +611,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams 
     [&](int B_) {
       mma_chunk<BM, BN, true, true>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, acc);
     });
-  // columns of this tile are [n0, n0 + ncols): in VEC=4 mode clip to the tap's channels
-  const int ncols_end = (VEC == 4) ? tap0 * g.Ctot + g.Ctot : Ntot;
-  epilogue<BM, BN>(p.e, p.Cout, Ntot, ncols_end, m0, n0, wm0, wn0, lane, split, acc);
+  epilogue<BM, BN>(p.e, p.Cout, Ntot, Ntot, m0, n0, wm0, wn0, lane, split, acc);
 }
 
 // ---------------------------------------------------------------------------
@@ -910,12 +903,10 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
   const bool v4 = geom_vec4(p.g) && (cout % 4 == 0) && (ld_dy % 4 == 0) && !((uintptr_t)dy & 15);
   const int Ctot = p.g.Ctot;
   const Plan pl = make_plan(cout, Ntot, p.iters, (long long)cout * Ntot, workspace_bytes, workspace != nullptr, 2,
-                            !v4, [&](int bn) {
-                              return v4 ? (long long)taps * ((Ctot + bn - 1) / bn) : (long long)(Ntot + bn - 1) / bn;
-                            });
-  int ntiles_n;
-  if (v4) { p.ntile_c = (Ctot + pl.bn - 1) / pl.bn; ntiles_n = taps * p.ntile_c; }
-  else { p.ntile_c = 0; ntiles_n = (Ntot + pl.bn - 1) / pl.bn; }
+                            !v4, [&](int bn) { return (long long)(Ntot + bn - 1) / bn; });
+  p.ntile_c = 0;
+  const int ntiles_n = (Ntot + pl.bn - 1) / pl.bn;
+  (void)Ctot;
   p.e = Epi{dweight, (long long)Ntot, nullptr, 1.f, accumulate, workspace, pl.nsplit};
   hipError_t err;
   if (v4) {
