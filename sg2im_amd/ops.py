@@ -18,7 +18,14 @@ _ws = {}
 _scratch = {}
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream():
+  """raw hipStream_t of torch's current stream.  torch.cuda.current_stream() costs ~9 us of
+  Python per call (x ~500 launches per step); the raw query is one C call."""
+  if _raw_stream is not None:
+    return c_void_p(_raw_stream(torch.cuda.current_device()))
   return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
