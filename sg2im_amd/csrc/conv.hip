@@ -115,6 +115,19 @@ __device__ float k_zeros4[4] = {0.f, 0.f, 0.f, 0.f};
 
 struct Aff { float4 sc, sh; float slope; };
 
+// scalar (VEC = 1) element of the virtual tensor, branch-free like the vector path
+__device__ __forceinline__ float load1_bf(const ConvGeom& g, const Src& S, bool ok, int n, int hi, int wi, int c) {
+  const int Hs = g.H >> S.up, Ws = g.W >> S.up;
+  unsigned row;
+  if (S.gidx) row = (unsigned)S.gidx[ok ? n : 0];
+  else row = (unsigned)((n * Hs + (hi >> S.up)) * Ws + (wi >> S.up));
+  const float v = S.p[ok ? row * (unsigned)S.ld + (unsigned)c : 0u];
+  const bool has = ok && S.scale != nullptr;
+  const float sc = *(has ? S.scale + c : k_ones4), sh = *(has ? S.shift + c : k_zeros4);
+  const float r = leaky(fmaf(v, sc, sh), has ? S.slope : 1.f);
+  return ok ? r : 0.f;
+}
+
 __device__ __forceinline__ float4 apply_aff(float4 v, const Aff& a, bool ok) {
   v.x = leaky(fmaf(v.x, a.sc.x, a.sh.x), a.slope);
   v.y = leaky(fmaf(v.y, a.sc.y, a.sh.y), a.slope);
@@ -231,12 +244,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
         for (int i = 0; i < NVA; ++i) {
           const int hi = rhb[i] + kh, wi = rwb[i] + kw;
           const bool ok = kok && rn[i] >= 0 && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-          av[i][j] = ok ? load1(g, S, rn[i], hi, wi, cs) : 0.f;
+          av[i][j] = load1_bf(g, S, ok, rn[i], hi, wi, cs);
         }
         #pragma unroll
         for (int i = 0; i < NVB; ++i) {
           const int n = n0 + r0 + 32 * i;
-          bv[i][j] = (kok && n < p.Cout) ? p.Wt[(long long)n * ldw + k] : 0.f;
+          const bool wok = kok && n < p.Cout;
+          const float wv = p.Wt[wok ? (unsigned)n * (unsigned)ldw + (unsigned)k : 0u];
+          bv[i][j] = wok ? wv : 0.f;
         }
       }
       #pragma unroll
@@ -549,7 +564,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams 
       } else {
         float v[4];
         #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (pix < p.P && aco + j < p.Cout) ? p.dY[(long long)pix * p.ldy + aco + j] : 0.f;
+        for (int j = 0; j < 4; ++j) {
+          const bool ok = pix < p.P && aco + j < p.Cout;
+          const float t = p.dY[ok ? (unsigned)pix * (unsigned)p.ldy + (unsigned)(aco + j) : 0u];
+          v[j] = ok ? t : 0.f;
+        }
         r.a[i] = make_float4(v[0], v[1], v[2], v[3]);
         ma |= 1u << i;
       }
@@ -574,8 +593,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams 
         #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int hi = hb + jkh[j], wi = wb + jkw[j];
-          e[j] = (pix < p.P && n < g.NB && jok[j] && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W)
-                   ? load1(g, pick_src(g, js[j]), n, hi, wi, jcs[j]) : 0.f;
+          const bool ok = pix < p.P && n < g.NB && jok[j] && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+          e[j] = load1_bf(g, pick_src(g, js[j]), ok, n, hi, wi, jcs[j]);
         }
         r.b[i] = make_float4(e[0], e[1], e[2], e[3]);
         mb |= 1u << i;
@@ -617,20 +636,36 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams 
 // ---------------------------------------------------------------------------
 // split-K finish: C = act(sum_s ws[s] + bias) (+ C)
 // ---------------------------------------------------------------------------
+// SL "split lanes" share one output: lane l adds splits l, l+SL, ... (ascending), the SL partials
+// are then added in lane order - a fixed order, so the result does not depend on scheduling.
+// SL > 1 is for tiny outputs reduced over many splits, where one thread per output would walk
+// hundreds of dependent-latency loads.
 __global__ void splitk_finish_kernel(const float* __restrict__ ws, int nsplit, long long MN, int N,
                                      float* __restrict__ C, long long ldc, const float* __restrict__ bias,
-                                     float slope, int accumulate) {
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < MN;
-       idx += (long long)gridDim.x * blockDim.x) {
+                                     float slope, int accumulate, int SL) {
+  __shared__ float part[256];
+  const int per = 256 / SL;                       // outputs per block
+  const int ol = threadIdx.x % per, sl = threadIdx.x / per;
+  for (long long base = (long long)blockIdx.x * per; base < MN; base += (long long)gridDim.x * per) {
+    const long long idx = base + ol;
     float v = 0.f;
-    for (int s = 0; s < nsplit; ++s) v += ws[(long long)s * MN + idx];
-    const long long m = idx / N;
-    const int n = (int)(idx - m * N);
-    if (bias) v += bias[n];
-    v = leaky(v, slope);
-    float* dst = C + m * ldc + n;
-    if (accumulate) v += *dst;
-    *dst = v;
+    if (idx < MN)
+      for (int s = sl; s < nsplit; s += SL) v += ws[(long long)s * MN + idx];
+    if (SL > 1) {
+      __syncthreads();
+      part[threadIdx.x] = v;
+      __syncthreads();
+      if (sl == 0) for (int l = 1; l < SL; ++l) v += part[l * per + ol];
+    }
+    if (sl == 0 && idx < MN) {
+      const long long m = idx / N;
+      const int n = (int)(idx - m * N);
+      if (bias) v += bias[n];
+      v = leaky(v, slope);
+      float* dst = C + m * ldc + n;
+      if (accumulate) v += *dst;
+      *dst = v;
+    }
   }
 }
 
@@ -705,7 +740,9 @@ static int split_for(long long tiles, int iters, long long MN, size_t ws_bytes, 
   ns = std::min(ns, std::max(1, iters / min_iters));
   const long long cap = MN > 0 ? (long long)(ws_bytes / sizeof(float)) / MN : 1;
   ns = (int)std::min<long long>(ns, std::max<long long>(1, cap));
-  ns = std::min(ns, 64);
+  // a tiny output (bias-sized weight gradients of the RGB layers) is latency bound: one short
+  // chunk loop per block, so spread the reduction much wider than the usual cap
+  ns = std::min(ns, MN <= 16384 ? 512 : 64);
   if (ns > 1) {                       // make every split non-empty
     const int per = (iters + ns - 1) / ns;
     ns = (iters + per - 1) / per;
@@ -737,9 +774,12 @@ static Plan make_plan(long long M, long long N, int iters, long long MN, size_t 
 static hipError_t finish_split(const Epi& e, long long M, int N, hipStream_t st) {
   if (e.nsplit <= 1) return hipSuccess;
   const long long MN = M * N;
-  const int blocks = (int)std::min<long long>((MN + 255) / 256, 4096);
+  int SL = 1;
+  while (SL < 16 && 2 * SL <= e.nsplit / 4 && (MN * SL + 255) / 256 < 2 * g_num_cu) SL *= 2;
+  const int per = 256 / SL;
+  const int blocks = (int)std::min<long long>((MN + per - 1) / per, 4096);
   hipLaunchKernelGGL(splitk_finish_kernel, dim3(blocks), dim3(256), 0, st, e.ws, e.nsplit, MN, N, e.C, e.ldc,
-                     e.bias, e.slope, e.accumulate);
+                     e.bias, e.slope, e.accumulate, SL);
   return hipGetLastError();
 }
 
