@@ -14,6 +14,8 @@
 // are never materialised.
 #include <algorithm>
 #include "igemm.h"
+#include <cstdio>
+#include <cstdlib>
 #include "sg2im_hip.h"
 
 namespace sg2im {
@@ -673,6 +675,8 @@ __global__ void splitk_finish_kernel(const float* __restrict__ ws, int nsplit, l
 // host side
 // ---------------------------------------------------------------------------
 static int g_num_cu = 256;
+static const bool g_plan_debug = getenv("SG2IM_PLAN_DEBUG") != nullptr;   // print the launch plans
+static const bool g_plan_tune = getenv("SG2IM_PLAN_TUNE") != nullptr;     // honour SG2IM_FORCE_PLAN
 
 template <typename K>
 static hipError_t ensure_lds(K kernel, size_t bytes) {
@@ -731,43 +735,80 @@ static int check_desc(const sg2im_conv_desc* d) {
 struct Plan { int tile, bm, bn, nsplit; long long tiles; };
 
 static const int kBM[4] = {128, 128, 64, 64}, kBN[4] = {128, 64, 64, 128};
-static const double kEff[4] = {1.0, 0.92, 0.80, 0.90};   // relative MFMA efficiency of the tile shapes
+// relative MFMA efficiency of the tile shapes per pass (forward, data gradient, weight gradient);
+// these and the constants in launch_cost are fitted to tools/plan_sweep.py measurements
+enum { PASS_FWD = 0, PASS_DGRAD = 1, PASS_WGRAD = 2 };
+static const double kEff[3][4] = {{1.0, 0.92, 0.80, 0.935}, {1.0, 0.92, 0.895, 0.966}, {1.0, 0.90, 0.80, 0.90}};
 
-static int split_for(long long tiles, int iters, long long MN, size_t ws_bytes, int min_iters) {
-  const long long target = 2LL * g_num_cu;
-  int ns = 1;
-  if (tiles < target) ns = (int)((target + tiles - 1) / tiles);
-  ns = std::min(ns, std::max(1, iters / min_iters));
-  const long long cap = MN > 0 ? (long long)(ws_bytes / sizeof(float)) / MN : 1;
-  ns = (int)std::min<long long>(ns, std::max<long long>(1, cap));
-  // a tiny output (bias-sized weight gradients of the RGB layers) is latency bound: one short
-  // chunk loop per block, so spread the reduction much wider than the usual cap
-  ns = std::min(ns, MN <= 16384 ? 512 : 64);
-  if (ns > 1) {                       // make every split non-empty
+// Cost model of one launch, in cycles of a CU's MFMA pipes.  The kernels are MFMA bound, so a
+// CU that is handed b workgroups needs b x (chunks x cycles-per-chunk): what matters is the
+// block count of the BUSIEST CU, ceil(blocks / #CU) - 2.05 blocks per CU cost as much as 3.
+// Fewer than ~3 co-resident workgroups leave the loader latency exposed (`hide`); split-K pays
+// for the partial-sum round trip through the workspace and the finish launch.
+static const int kOcc[4] = {3, 4, 6, 4};                  // resident workgroups per CU (VGPR/LDS limited)
+static double launch_cost(int pass, int t, long long tiles, int ns, int iters, long long MN) {
+  const long long blocks = tiles * ns;
+  const int per = (iters + ns - 1) / ns;
+  const double chunk = (double)kBM[t] * kBN[t] * BK * 2.0 / 256.0 / kEff[pass][t];
+  const double fixed = 1700.0;                            // prologue + epilogue of a workgroup
+  const long long rounds = (blocks + g_num_cu - 1) / g_num_cu;
+  const double resident = std::min<double>((double)blocks / g_num_cu, kOcc[t]);
+  const double hide = resident >= 2.9 ? 1.0 : resident >= 1.9 ? 0.925 : 0.51;
+  double c = (double)rounds * (per * chunk + fixed) / hide;
+  if (ns > 1) c += 3800.0 + (double)ns * (double)MN * 8.0 / 2500.0;
+  return c;
+}
+
+static int split_for(int pass, int t, long long tiles, int iters, long long MN, size_t ws_bytes, int min_iters,
+                     double* cost_out = nullptr) {
+  long long cap = std::max(1, iters / min_iters);
+  cap = std::min<long long>(cap, MN > 0 ? std::max<long long>(1, (long long)(ws_bytes / sizeof(float)) / MN) : 1);
+  // (tiny outputs - the weight gradients of the RGB layers - are latency bound and may be
+  // spread much wider than the usual cap)
+  cap = std::min<long long>(cap, MN <= 16384 ? 512 : 64);
+  int best = 1;
+  double best_c = launch_cost(pass, t, tiles, 1, iters, MN);
+  for (int ns = 2; ns <= cap; ++ns) {
     const int per = (iters + ns - 1) / ns;
-    ns = (iters + per - 1) / per;
+    if ((iters + per - 1) / per != ns) continue;          // every split non-empty
+    const double c = launch_cost(pass, t, tiles, ns, iters, MN);
+    if (c < best_c) { best_c = c; best = ns; }
   }
-  return ns;
+  if (cost_out) *cost_out = best_c;
+  return best;
 }
 
 // ntn(bn): number of N tiles for tile width bn (wgrad tiles N per tap)
 template <typename NT>
-static Plan make_plan(long long M, long long N, int iters, long long MN, size_t ws_bytes, bool can_split,
+static Plan make_plan(int pass, long long M, long long N, int iters, long long MN, size_t ws_bytes, bool can_split,
                       int min_iters, bool only64, NT ntn) {
   Plan best{2, 64, 64, 1, 0};
-  double best_score = -1.0;
+  double best_cost = -1.0;
   for (int t = 0; t < 4; ++t) {
     if (only64 && t != 2) continue;
     const long long tm = (M + kBM[t] - 1) / kBM[t], tn = ntn(kBN[t]);
     const long long tiles = tm * tn;
-    const int ns = can_split ? split_for(tiles, iters, MN, ws_bytes, min_iters) : 1;
-    const double useful = (double)(M * N) / (double)(tiles * kBM[t] * kBN[t]);
-    const double blocks = (double)tiles * ns;
-    const double fill = blocks >= 2.0 * g_num_cu ? 1.0 : blocks / (2.0 * g_num_cu);
-    const double split_cost = ns > 1 ? 0.93 : 1.0;
-    const double score = kEff[t] * useful * fill * split_cost;
-    if (score > best_score) { best_score = score; best = Plan{t, kBM[t], kBN[t], ns, tiles}; }
+    double cost;
+    int ns = 1;
+    if (can_split) ns = split_for(pass, t, tiles, iters, MN, ws_bytes, min_iters, &cost);
+    else cost = launch_cost(pass, t, tiles, 1, iters, MN);
+    if (g_plan_debug) fprintf(stderr, "[sg2im plan]   tile %dx%d tiles=%lld ns=%d cost=%.0f\n", kBM[t], kBN[t], tiles, ns, cost);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = Plan{t, kBM[t], kBN[t], ns, tiles}; }
   }
+  if (g_plan_tune) {                 // tools/plan_sweep.py: force "tile,nsplit" for this call
+    const char* f = getenv("SG2IM_FORCE_PLAN");
+    int t = 0, ns = 1;
+    if (f && sscanf(f, "%d,%d", &t, &ns) == 2 && t >= 0 && t < 4 && !(only64 && t != 2)) {
+      const long long tiles = ((M + kBM[t] - 1) / kBM[t]) * ntn(kBN[t]);
+      long long cap = can_split ? std::max(1, iters / min_iters) : 1;
+      if (MN > 0) cap = std::min<long long>(cap, std::max<long long>(1, (long long)(ws_bytes / sizeof(float)) / MN));
+      ns = (int)std::max<long long>(1, std::min<long long>(ns, cap));
+      const int per = (iters + ns - 1) / ns;
+      ns = (iters + per - 1) / per;
+      best = Plan{t, kBM[t], kBN[t], ns, tiles};
+    }
+  }
+  if (g_plan_debug) fprintf(stderr, "[sg2im plan] M=%lld N=%lld iters=%d -> %dx%d x%d\n", M, N, iters, best.bm, best.bn, best.nsplit);
   return best;
 }
 
@@ -854,7 +895,7 @@ int sg2im_conv2d_forward(const sg2im_conv_desc* d, const float* weight, int cout
     p.nch = 0;
     p.iters = (taps * p.g.Ctot + BK - 1) / BK;
   }
-  const Plan pl = make_plan(p.M, cout, p.iters, (long long)p.M * cout, workspace_bytes, workspace != nullptr, 4, !v4,
+  const Plan pl = make_plan(PASS_FWD, p.M, cout, p.iters, (long long)p.M * cout, workspace_bytes, workspace != nullptr, 4, !v4,
                             [&](int bn) { return (long long)(cout + bn - 1) / bn; });
   p.e = Epi{out, ld_out, bias, out_slope, accumulate, workspace, pl.nsplit};
   hipError_t err;
@@ -900,14 +941,15 @@ int sg2im_conv2d_backward_data(const sg2im_conv_desc* d, const float* weight, in
     iters_eff = ((d->kh + 1) / 2) * ((d->kw + 1) / 2) * p.nch;
   }
   p.M = (int)Mrows;
-  Plan pl = make_plan(Mrows, c_count, iters_eff, Mfull * c_count, workspace_bytes,
+  Plan pl = make_plan(PASS_DGRAD, Mrows, c_count, iters_eff, Mfull * c_count, workspace_bytes,
                       workspace != nullptr && !p.parity, 4, !va4,
-                      [&](int bn) { return (long long)(c_count + bn - 1) / bn; });
+                      // (the four parity classes are launched together: 4x the workgroups)
+                      [&](int bn) { return (long long)(c_count + bn - 1) / bn * (p.parity ? 4 : 1); });
   if (va4 && !vb4 && (pl.tile == 0 || pl.tile == 3)) {      // narrow scalar-B outputs: 64-wide tiles only
     const int t = pl.tile == 0 ? 1 : 2;
     pl = Plan{t, kBM[t], kBN[t], 1, 0};
     if (!p.parity && workspace)
-      pl.nsplit = split_for(((Mrows + pl.bm - 1) / pl.bm) * ((c_count + 63) / 64), iters_eff, Mfull * c_count,
+      pl.nsplit = split_for(PASS_DGRAD, t, ((Mrows + pl.bm - 1) / pl.bm) * ((c_count + 63) / 64), iters_eff, Mfull * c_count,
                             workspace_bytes, 4);
   }
   p.e = Epi{dx, ld_dx, nullptr, 1.f, accumulate, workspace, pl.nsplit};
@@ -942,7 +984,7 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
   p.iters = (p.P + BK - 1) / BK;
   const bool v4 = geom_vec4(p.g) && (cout % 4 == 0) && (ld_dy % 4 == 0) && !((uintptr_t)dy & 15);
   const int Ctot = p.g.Ctot;
-  const Plan pl = make_plan(cout, Ntot, p.iters, (long long)cout * Ntot, workspace_bytes, workspace != nullptr, 2,
+  const Plan pl = make_plan(PASS_WGRAD, cout, Ntot, p.iters, (long long)cout * Ntot, workspace_bytes, workspace != nullptr, 2,
                             !v4, [&](int bn) { return (long long)(Ntot + bn - 1) / bn; });
   p.ntile_c = 0;
   const int ntiles_n = (Ntot + pl.bn - 1) / pl.bn;

@@ -220,6 +220,9 @@ template <int I> struct IC { static constexpr int value = I; };
 #endif
 constexpr int LDS_STAGES = SG2IM_LDS_STAGES;
 
+#ifndef SG2IM_ABL
+#define SG2IM_ABL 0        // timing-only ablations (1: no loads/stores in the loop, 2: no barriers)
+#endif
 #if SG2IM_PIPE_DEPTH == 1
 // Depth-1 variant: ONE register set and a branch-free loop body - the loads of chunk i+1,
 // the MFMAs of chunk i and the LDS stores of chunk i+1 are one basic block, so the compiler
@@ -237,7 +240,9 @@ __device__ __forceinline__ void k_pipeline(int it_begin, int it_end, Load load, 
   #pragma unroll 1
   for (int i = 0; i < n; ++i) {
     const int nxt = i + 1 < n ? i + 1 : n - 1;
+#if !(SG2IM_ABL & 1)
     load(it_begin + nxt, IC<0>());
+#endif
     // keep the global loads ahead of the MFMA block: left alone, the scheduler sinks them
     // to just before their first use (end of the block) and the wave stalls on vmcnt
     __builtin_amdgcn_sched_barrier(0);
@@ -250,9 +255,15 @@ __device__ __forceinline__ void k_pipeline(int it_begin, int it_end, Load load, 
       // single LDS image (half the LDS -> twice the resident workgroups): every wave must
       // be done reading chunk i before it is overwritten, hence the second barrier
       mma(0);
+#if !(SG2IM_ABL & 2)
       __syncthreads();
+#endif
+#if !(SG2IM_ABL & 1)
       stage(IC<0>(), 0);
+#endif
+#if !(SG2IM_ABL & 2)
       __syncthreads();
+#endif
     }
   }
 }

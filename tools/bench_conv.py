@@ -10,7 +10,7 @@ import torch
 from sg2im_amd import ops
 
 D = torch.device('cuda', 0)
-N = 32
+NB = 32
 LAYERS = [  # name, H, C0, C1(up), Cout, k, stride, pad
   ('m0.conv0', 4, 160, 1, 1024, 3, 1, 1), ('m0.conv1', 4, 1024, 0, 1024, 3, 1, 1),
   ('m1.conv0', 8, 160, 1024, 512, 3, 1, 1), ('m1.conv1', 8, 512, 0, 512, 3, 1, 1),
@@ -19,6 +19,13 @@ LAYERS = [  # name, H, C0, C1(up), Cout, k, stride, pad
   ('m4.conv0', 64, 160, 128, 64, 3, 1, 1), ('m4.conv1', 64, 64, 0, 64, 3, 1, 1),
   ('out.conv0', 64, 64, 0, 64, 3, 1, 1), ('out.conv1', 64, 64, 0, 3, 1, 1, 0),
   ('d_img.c0', 64, 3, 0, 64, 4, 2, 0), ('d_img.c1', 31, 64, 0, 128, 4, 2, 0), ('d_img.c2', 14, 128, 0, 256, 4, 2, 0),
+  # per-object layers (optional 9th field = batch): ~216 objects and ~640 triples per 32 images
+  ('d_obj.c0', 32, 3, 0, 64, 4, 2, 0, 216), ('d_obj.c1', 15, 64, 0, 128, 4, 2, 0, 216),
+  ('d_obj.c2', 6, 128, 0, 256, 4, 2, 0, 216),
+  ('mask.c1', 4, 0, 128, 128, 3, 1, 1, 216), ('mask.c2', 8, 0, 128, 128, 3, 1, 1, 216),
+  ('mask.c3', 16, 0, 128, 128, 3, 1, 1, 216),
+  ('gconv.n1a', 1, 384, 0, 512, 1, 1, 0, 640), ('gconv.n1b', 1, 512, 0, 1152, 1, 1, 0, 640),
+  ('gconv.n2a', 1, 512, 0, 512, 1, 1, 0, 216), ('gconv.n2b', 1, 512, 0, 128, 1, 1, 0, 216),
 ]
 
 
@@ -38,9 +45,12 @@ def main():
   tot = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
   totf = 0.0
   print('%-10s %9s | %8s %7s | %8s %7s | %8s %7s' % ('layer', 'GFLOP', 'fwd ms', 'TF/s', 'dgrad ms', 'TF/s', 'wgrad ms', 'TF/s'))
-  for name, H, C0, C1, Cout, k, s, p in LAYERS:
-    x0 = torch.randn(N, H, H, C0, device=D)
-    srcs = [ops.nhwc_src(x0)]
+  for L in LAYERS:
+    name, H, C0, C1, Cout, k, s, p = L[:8]
+    N = L[8] if len(L) > 8 else NB
+    srcs = []
+    if C0:
+      srcs.append(ops.nhwc_src(torch.randn(N, H, H, C0, device=D)))
     if C1:
       srcs.append(ops.nhwc_src(torch.randn(N, H // 2, H // 2, C1, device=D), 1))
     d = ops.conv_desc(srcs, N, H, H, k, k, s, p)
