@@ -115,6 +115,9 @@ __device__ __forceinline__ void locate_chunk(const ConvGeom& g, int ch, int& s, 
 __device__ float k_ones4[4] = {1.f, 1.f, 1.f, 1.f};
 __device__ float k_zeros4[4] = {0.f, 0.f, 0.f, 0.f};
 
+// timing-only ablation (SG2IM_ABL & 4): every loader address falls into one 256-byte window
+constexpr unsigned kAblMask = (SG2IM_ABL & 4) ? 60u : ~0u;
+
 struct Aff { float4 sc, sh; float slope; };
 
 // scalar (VEC = 1) element of the virtual tensor, branch-free like the vector path
@@ -219,14 +222,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
       }
       #pragma unroll
       for (int i = 0; i < NVA; ++i) {
-        const unsigned off = (ma >> i & 1u) ? pix[i] * (unsigned)S.ld + (unsigned)c : 0u;
+        const unsigned off = ((ma >> i & 1u) ? pix[i] * (unsigned)S.ld + (unsigned)c : 0u) & kAblMask;
         r.a[i] = *reinterpret_cast<const float4*>(S.p + off);
       }
       const unsigned wcol = (unsigned)(tap * g.Ctot + cstart + c);
       const unsigned mb = cok ? bmask : 0u;
       #pragma unroll
       for (int i = 0; i < NVB; ++i) {
-        const unsigned off = (mb >> i & 1u) ? wrow[i] + wcol : 0u;
+        const unsigned off = ((mb >> i & 1u) ? wrow[i] + wcol : 0u) & kAblMask;
         r.b[i] = *reinterpret_cast<const float4*>(p.Wt + off);
       }
       r.ma = ma; r.mb = mb;

@@ -5,13 +5,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from sg2im_amd import ops
-from tools.bench_conv import LAYERS, N, D
+from tools.bench_conv import LAYERS, NB as N, D
 name = sys.argv[1]
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 bn = len(sys.argv) > 3 and sys.argv[3] == 'bn'
 for L in LAYERS:
   if L[0] == name:
-    _, H, C0, C1, Cout, k, s, p = L
+    _, H, C0, C1, Cout, k, s, p = L[:8]
 x0 = torch.randn(N, H, H, C0, device=D)
 sc = torch.rand(C0, device=D) + 0.5 if bn else None
 sh = torch.randn(C0, device=D) if bn else None
