@@ -67,9 +67,11 @@ int sg2im_conv2d_backward_data(const sg2im_conv_desc* desc, const float* weight,
                                const float* dy, int ld_dy, int c_begin, int c_count, float* dx,
                                long long ld_dx, int accumulate, float* workspace,
                                size_t workspace_bytes, hipStream_t stream);
-/* dW[co][kh][kw][c] = sum_pix dY[pix][co] * X[pix (+) tap][c]  (+ dW if accumulate) */
+/* dW[co][kh][kw][c] = sum_pix dY[pix][co] * X[pix (+) tap][c]  (+ dW if accumulate)
+ * dbias (optional, may be NULL): dB[co] = sum_pix dY[pix][co]  (+ dB if accumulate) - the
+ * bias gradient of the same layer, produced in the same pass over dY. */
 int sg2im_conv2d_backward_weight(const sg2im_conv_desc* desc, const float* dy, int ld_dy, int cout,
-                                 float* dweight, int accumulate, float* workspace,
+                                 float* dweight, float* dbias, int accumulate, float* workspace,
                                  size_t workspace_bytes, hipStream_t stream);
 /* out[n] = sum_m x[m][n] (+ out): bias gradients (autograd of Conv2d/Linear bias) */
 /* partial: scratch float[2 * cols * 256] */

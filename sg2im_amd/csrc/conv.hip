@@ -50,6 +50,8 @@ struct WgradParams {
   int ntile_c;      // column tiles per tap (VEC=4)
   int ntiles_n, ntiles_m;   // tile counts (the launch is a 1-D, XCD-swizzled grid)
   Epi e;
+  float* dbias;     // optional [Cout]: column sums of dY, produced by the column-tile-0 workgroups
+  float* ws_bias;   // split-K partials of dbias: [nsplit][Cout] behind the dW partials
 };
 
 // ---------------------------------------------------------------------------
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
 
   k_pipeline(it_begin, it_end,
     [&](int it, auto set) { if constexpr (decltype(set)::value == 0) load_into(it, rs0); else load_into(it, rs1); },
-    [&](auto set, int B_) { if constexpr (decltype(set)::value == 0) stage_from(rs0, B_); else stage_from(rs1, B_); },
+    [&](auto set, int B_, bool) { if constexpr (decltype(set)::value == 0) stage_from(rs0, B_); else stage_from(rs1, B_); },
     [&](int B_) {
       mma_chunk<BM, BN, false, false>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, acc);
     });
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_dgrad_kernel(const DgradParams 
 
   k_pipeline(it_begin, it_end,
     [&](int it, auto set) { if constexpr (decltype(set)::value == 0) load_into(it, rs0); else load_into(it, rs1); },
-    [&](auto set, int B_) { if constexpr (decltype(set)::value == 0) stage_from(rs0, B_); else stage_from(rs1, B_); },
+    [&](auto set, int B_, bool) { if constexpr (decltype(set)::value == 0) stage_from(rs0, B_); else stage_from(rs1, B_); },
     [&](int B_) {
       mma_chunk<BM, BN, false, true>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, acc);
     });
@@ -612,10 +614,17 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams 
     }
     r.ma = ma; r.mb = mb;
   };
-  auto stage_from = [&](RS& r, int B_) {
+  // bias gradient: this thread's dY values all belong to output channels aco..aco+3
+  const bool want_db = p.dbias != nullptr && ntile_x == 0;
+  float4 dbs = zero4();
+  auto stage_from = [&](RS& r, int B_, bool live) {
     float4 ta[NVA], tb[NVB];
     #pragma unroll
     for (int i = 0; i < NVA; ++i) ta[i] = (r.ma >> i & 1u) ? r.a[i] : zero4();
+    if (want_db && live) {
+      #pragma unroll
+      for (int i = 0; i < NVA; ++i) { dbs.x += ta[i].x; dbs.y += ta[i].y; dbs.z += ta[i].z; dbs.w += ta[i].w; }
+    }
     #pragma unroll
     for (int i = 0; i < NVB; ++i) {
       if (VEC == 4) tb[i] = apply_aff(r.b[i], baff, (r.mb >> i & 1u) != 0);
@@ -631,11 +640,35 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams 
 
   k_pipeline(it_begin, it_end,
     [&](int it, auto set) { if constexpr (decltype(set)::value == 0) load_into(it, rs0); else load_into(it, rs1); },
-    [&](auto set, int B_) { if constexpr (decltype(set)::value == 0) stage_from(rs0, B_); else stage_from(rs1, B_); },
+    [&](auto set, int B_, bool live) {
+      if constexpr (decltype(set)::value == 0) stage_from(rs0, B_, live); else stage_from(rs1, B_, live);
+    },
     [&](int B_) {
       mma_chunk<BM, BN, true, true>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, acc);
     });
   epilogue<BM, BN>(p.e, p.Cout, Ntot, Ntot, m0, n0, wm0, wn0, lane, split, acc);
+  if (want_db) {
+    // the 256 / QA threads that share a channel quad hold sums over disjoint pixel rows:
+    // combine them through LDS in thread order (fixed order -> reproducible)
+    constexpr int GROUPS = NTHREADS / QA;
+    float4* red = reinterpret_cast<float4*>(smem);            // [GROUPS][QA]
+    red[ak0 * QA + acol4] = dbs;                              // (the pipeline ended on a barrier)
+    __syncthreads();
+    if (tid < QA && aco < p.Cout) {
+      float4 t = red[tid];
+      for (int k = 1; k < GROUPS; ++k) {
+        const float4 u = red[k * QA + tid];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      const float tv[4] = {t.x, t.y, t.z, t.w};
+      float* dst = p.e.nsplit > 1 ? p.ws_bias + (size_t)split * p.Cout : p.dbias;
+      for (int j = 0; j < 4; ++j) {
+        if (aco + j >= p.Cout) break;
+        if (p.e.nsplit > 1 || !p.e.accumulate) dst[aco + j] = tv[j];
+        else dst[aco + j] += tv[j];
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -647,8 +680,27 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams 
 // hundreds of dependent-latency loads.
 __global__ void splitk_finish_kernel(const float* __restrict__ ws, int nsplit, long long MN, int N,
                                      float* __restrict__ C, long long ldc, const float* __restrict__ bias,
-                                     float slope, int accumulate, int SL) {
+                                     float slope, int accumulate, int SL,
+                                     const float* __restrict__ ws2, float* __restrict__ C2, int N2) {
+  // second, tiny reduction riding along (weight-gradient launches: the bias gradient partials)
   __shared__ float part[256];
+  if (C2 != nullptr && blockIdx.x == 0) {
+    constexpr int SLB = 8, PERB = 256 / SLB;      // 8 split lanes x 32 columns per round
+    const int jl = threadIdx.x % PERB, sl2 = threadIdx.x / PERB;
+    for (int base = 0; base < N2; base += PERB) {
+      const int j = base + jl;
+      float v = 0.f;
+      if (j < N2)
+        for (int s = sl2; s < nsplit; s += SLB) v += ws2[(size_t)s * N2 + j];
+      part[threadIdx.x] = v;
+      __syncthreads();
+      if (sl2 == 0 && j < N2) {
+        for (int l = 1; l < SLB; ++l) v += part[l * PERB + jl];
+        C2[j] = accumulate ? C2[j] + v : v;
+      }
+      __syncthreads();
+    }
+  }
   const int per = 256 / SL;                       // outputs per block
   const int ol = threadIdx.x % per, sl = threadIdx.x / per;
   for (long long base = (long long)blockIdx.x * per; base < MN; base += (long long)gridDim.x * per) {
@@ -815,7 +867,8 @@ static Plan make_plan(int pass, long long M, long long N, int iters, long long M
   return best;
 }
 
-static hipError_t finish_split(const Epi& e, long long M, int N, hipStream_t st) {
+static hipError_t finish_split(const Epi& e, long long M, int N, hipStream_t st,
+                               const float* ws2 = nullptr, float* C2 = nullptr, int N2 = 0) {
   if (e.nsplit <= 1) return hipSuccess;
   const long long MN = M * N;
   int SL = 1;
@@ -823,7 +876,7 @@ static hipError_t finish_split(const Epi& e, long long M, int N, hipStream_t st)
   const int per = 256 / SL;
   const int blocks = (int)std::min<long long>((MN + per - 1) / per, 4096);
   hipLaunchKernelGGL(splitk_finish_kernel, dim3(blocks), dim3(256), 0, st, e.ws, e.nsplit, MN, N, e.C, e.ldc,
-                     e.bias, e.slope, e.accumulate, SL);
+                     e.bias, e.slope, e.accumulate, SL, ws2, C2, N2);
   return hipGetLastError();
 }
 
@@ -970,7 +1023,7 @@ int sg2im_conv2d_backward_data(const sg2im_conv_desc* d, const float* weight, in
 }
 
 int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int ld_dy, int cout,
-                                 float* dweight, int accumulate, float* workspace,
+                                 float* dweight, float* dbias, int accumulate, float* workspace,
                                  size_t workspace_bytes, hipStream_t stream) {
   if (check_desc(d) || !dy || !dweight || cout < 1 || ld_dy < cout) return SG2IM_ERR_ARG;
   WgradParams p;
@@ -982,17 +1035,24 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
   if (p.P == 0) {
     if (!accumulate && hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)cout * Ntot, stream) != hipSuccess)
       return SG2IM_ERR_HIP;
+    if (!accumulate && dbias && hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)cout, stream) != hipSuccess)
+      return SG2IM_ERR_HIP;
     return SG2IM_OK;
   }
   p.iters = (p.P + BK - 1) / BK;
   const bool v4 = geom_vec4(p.g) && (cout % 4 == 0) && (ld_dy % 4 == 0) && !((uintptr_t)dy & 15);
   const int Ctot = p.g.Ctot;
-  const Plan pl = make_plan(PASS_WGRAD, cout, Ntot, p.iters, (long long)cout * Ntot, workspace_bytes, workspace != nullptr, 2,
-                            !v4, [&](int bn) { return (long long)(Ntot + bn - 1) / bn; });
+  // (room for the bias-gradient partials of up to 512 splits is kept behind the dW partials)
+  const size_t bias_room = dbias ? sizeof(float) * 512 * (size_t)cout : 0;
+  const bool can_split = workspace != nullptr && workspace_bytes > bias_room;
+  const Plan pl = make_plan(PASS_WGRAD, cout, Ntot, p.iters, (long long)cout * Ntot, can_split ? workspace_bytes - bias_room : 0,
+                            can_split, 2, !v4, [&](int bn) { return (long long)(Ntot + bn - 1) / bn; });
   p.ntile_c = 0;
   const int ntiles_n = (Ntot + pl.bn - 1) / pl.bn;
   (void)Ctot;
   p.e = Epi{dweight, (long long)Ntot, nullptr, 1.f, accumulate, workspace, pl.nsplit};
+  p.dbias = dbias;
+  p.ws_bias = pl.nsplit > 1 ? workspace + (size_t)pl.nsplit * cout * Ntot : nullptr;
   hipError_t err;
   if (v4) {
     err = pl.tile == 0 ? launch_wgrad<128, 128, 4>(p, ntiles_n, stream)
@@ -1003,7 +1063,7 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
     err = launch_wgrad<64, 64, 1>(p, ntiles_n, stream);
   }
   if (err != hipSuccess) return SG2IM_ERR_HIP;
-  return finish_split(p.e, cout, Ntot, stream) == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+  return finish_split(p.e, cout, Ntot, stream, p.ws_bias, dbias, cout) == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
 }
 
 }  // extern "C"

@@ -234,7 +234,7 @@ __device__ __forceinline__ void k_pipeline(int it_begin, int it_end, Load load, 
   const int n = it_end - it_begin;
   if (n <= 0) return;
   load(it_begin, IC<0>());
-  stage(IC<0>(), 0);
+  stage(IC<0>(), 0, true);
   __syncthreads();
   int cur = 0;
   #pragma unroll 1
@@ -248,7 +248,7 @@ __device__ __forceinline__ void k_pipeline(int it_begin, int it_end, Load load, 
     __builtin_amdgcn_sched_barrier(0);
     if (LDS_STAGES == 2) {
       mma(cur);
-      stage(IC<0>(), cur ^ 1);
+      stage(IC<0>(), cur ^ 1, i + 1 < n);
       __syncthreads();
       cur ^= 1;
     } else {
@@ -259,7 +259,7 @@ __device__ __forceinline__ void k_pipeline(int it_begin, int it_end, Load load, 
       __syncthreads();
 #endif
 #if !(SG2IM_ABL & 1)
-      stage(IC<0>(), 0);
+      stage(IC<0>(), 0, i + 1 < n);
 #endif
 #if !(SG2IM_ABL & 2)
       __syncthreads();
@@ -274,7 +274,7 @@ __device__ __forceinline__ void k_pipeline(int it_begin, int it_end, Load load, 
   if (n <= 0) return;
   load(it_begin, IC<0>());
   if (n > 1) load(it_begin + 1, IC<1>());
-  stage(IC<0>(), 0);
+  stage(IC<0>(), 0, true);
   __syncthreads();
   // ONE mma call site (runtime LDS buffer index): with the MFMA block instantiated twice
   // hipcc gives each copy its own accumulator registers and doubles the AGPR budget.
@@ -300,11 +300,11 @@ __device__ __forceinline__ void k_pipeline(int it_begin, int it_end, Load load, 
     if (i + 1 < n) {
       if (par == 0) {
         asm volatile("; k_pipeline: stage set 1" ::: "memory");
-        stage(IC<1>(), 1);
+        stage(IC<1>(), 1, true);
         asm volatile("; k_pipeline: stage set 1 done" ::: "memory");
       } else {
         asm volatile("; k_pipeline: stage set 0" ::: "memory");
-        stage(IC<0>(), 0);
+        stage(IC<0>(), 0, true);
         asm volatile("; k_pipeline: stage set 0 done" ::: "memory");
       }
     }

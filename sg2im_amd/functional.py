@@ -91,11 +91,17 @@ def _linear_bwd(desc, W, dpre, need_dx, need_dw, need_db, K, b=None):
     ops.conv2d_backward_data(desc, W, N, dpre, N, 0, K, dx, K)
   if need_dw:
     sk = _sink(W)
+    skb = _sink(b) if need_db else None
     if sk is not None:
-      ops.conv2d_backward_weight(desc, dpre, N, N, sk, accumulate=True)
+      # (with both sinks registered the bias gradient rides along in the same pass over dpre)
+      ops.conv2d_backward_weight(desc, dpre, N, N, sk, accumulate=True, dbias=skb)
+      need_db = need_db and skb is None
     else:
       dw = _new(dpre, N, K)
-      ops.conv2d_backward_weight(desc, dpre, N, N, dw)
+      if need_db and skb is None:
+        db = _new(dpre, N)
+        need_db = False
+      ops.conv2d_backward_weight(desc, dpre, N, N, dw, dbias=db)
   if need_db:
     sk = _sink(b)
     if sk is not None:
@@ -368,11 +374,16 @@ def _conv_param_grads(desc, dy, cout, w_phys_shape, need_w, need_b, W=None, b=No
   rows = dy.numel() // cout
   if need_w:
     sk = _sink(W)
+    skb = _sink(b) if need_b else None
     if sk is not None:
-      ops.conv2d_backward_weight(desc, dy, cout, cout, sk, accumulate=True)
+      ops.conv2d_backward_weight(desc, dy, cout, cout, sk, accumulate=True, dbias=skb)
+      need_b = need_b and skb is None
     else:
       dw = _new(dy, *w_phys_shape)
-      ops.conv2d_backward_weight(desc, dy, cout, cout, dw)
+      if need_b and skb is None:
+        db = _new(dy, cout)
+        need_b = False
+      ops.conv2d_backward_weight(desc, dy, cout, cout, dw, dbias=db)
       dw = _cl_grad(dw)
   if need_b:
     sk = _sink(b)

@@ -178,12 +178,13 @@ def conv2d_backward_data(desc, weight, cout, dy, ld_dy, c_begin, c_count, dx, ld
   return dx
 
 
-def conv2d_backward_weight(desc, dy, ld_dy, cout, dweight, accumulate=False):
+def conv2d_backward_weight(desc, dy, ld_dy, cout, dweight, accumulate=False, dbias=None):
+  """dbias (optional): the layer's bias gradient, produced in the same pass over dy."""
   ws = workspace(dweight.device)
   flops = 2.0 * desc.batch * desc.out_h * desc.out_w * cout * _desc_k(desc)
   _timed('igemm_wgrad', flops, lambda: call(
     'sg2im_conv2d_backward_weight', byref(desc), _f(dy), int(ld_dy), int(cout), _f(dweight),
-    int(accumulate), _f(ws), ws.numel() * 4, _stream()))
+    _f(dbias) if dbias is not None else None, int(accumulate), _f(ws), ws.numel() * 4, _stream()))
   return dweight
 
 

@@ -91,8 +91,14 @@ def conv_case(name, N, H, W, C0, C1, up1, Cout, k, stride, pad, bnact=False, see
   report(name + ' fwd', out.permute(0, 3, 1, 2), y)
   gyd = nhwc(gy)
   dw = torch.empty(Cout, k, k, Ct, device=D)
-  ops.conv2d_backward_weight(d, gyd, Cout, Cout, dw)
+  db = torch.empty(Cout, device=D)
+  ops.conv2d_backward_weight(d, gyd, Cout, Cout, dw, dbias=db)
   report(name + ' wgrad', dw.permute(0, 3, 1, 2), Wr.grad)
+  report(name + ' bias grad (fused in wgrad)', db, br.grad)
+  # accumulate mode: both gradients are added onto the existing buffers
+  ops.conv2d_backward_weight(d, gyd, Cout, Cout, dw, accumulate=True, dbias=db)
+  report(name + ' wgrad accumulate', dw.permute(0, 3, 1, 2), 2 * Wr.grad)
+  report(name + ' bias grad accumulate', db, 2 * br.grad)
   if not bnact:
     dx0 = torch.empty(N, H, W, C0, device=D)
     ops.conv2d_backward_data(d, Wp, Cout, gyd, Cout, 0, C0, dx0, C0)

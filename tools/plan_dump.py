@@ -36,4 +36,4 @@ for L in LAYERS:
     elif what == 'dgrad':
       lib.sg2im_conv2d_backward_data(ctypes.byref(d), P(FAKE), Cout, P(FAKE), Cout, 0, Ct, P(FAKE), Ct, 0, P(FAKE), WS, None)
     else:
-      lib.sg2im_conv2d_backward_weight(ctypes.byref(d), P(FAKE), Cout, Cout, P(FAKE), 0, P(FAKE), WS, None)
+      lib.sg2im_conv2d_backward_weight(ctypes.byref(d), P(FAKE), Cout, Cout, P(FAKE), None, 0, P(FAKE), WS, None)
