@@ -731,6 +731,7 @@ __global__ void splitk_finish_kernel(const float* __restrict__ ws, int nsplit, l
 // ---------------------------------------------------------------------------
 static int g_num_cu = 256;
 static const bool g_plan_debug = getenv("SG2IM_PLAN_DEBUG") != nullptr;   // print the launch plans
+static const size_t g_lds_floor = getenv("SG2IM_LDS_FLOOR") ? (size_t)atol(getenv("SG2IM_LDS_FLOOR")) : 0;
 static const bool g_plan_tune = getenv("SG2IM_PLAN_TUNE") != nullptr;     // honour SG2IM_FORCE_PLAN
 
 template <typename K>
@@ -884,9 +885,10 @@ template <int BM, int BN, int VEC, bool GATHER>
 static hipError_t launch_fwd_g(FwdParams& p, hipStream_t st) {
   constexpr size_t lds = LDS_STAGES * (LdsTile<BM, false>::FLOATS + LdsTile<BN, false>::FLOATS) * sizeof(float);
   static bool once = false;
-  if (!once) { hipError_t e = ensure_lds(conv_fwd_kernel<BM, BN, VEC, GATHER>, lds); if (e != hipSuccess) return e; once = true; }
+  const size_t lds_req = std::max(lds, g_lds_floor);   // (occupancy experiments: SG2IM_LDS_FLOOR)
+  if (!once) { hipError_t e = ensure_lds(conv_fwd_kernel<BM, BN, VEC, GATHER>, std::max(lds, g_lds_floor)); if (e != hipSuccess) return e; once = true; }
   dim3 grid((p.Cout + BN - 1) / BN, (p.M + BM - 1) / BM, p.e.nsplit);
-  hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, VEC, GATHER>), grid, dim3(NTHREADS), lds, st, p);
+  hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, VEC, GATHER>), grid, dim3(NTHREADS), lds_req, st, p);
   return hipGetLastError();
 }
 

@@ -437,12 +437,16 @@ class RefinementFn(Function):
     feats = torch.zeros(N, h0, w0, 1, dtype=torch.float32, device=layout.device)   # crn.py:105
     feat_src = nhwc_src(feats, up=1)
     saved = []
-    pyr = []
+    # layout pyramid (crn.py:62 pools the full-resolution layout once per module): each level is
+    # the 2x2 mean of the next finer one - the same value up to fp32 summation order, with the
+    # 84 MB full-resolution layout read once instead of L - 1 times
+    pyr = [layout]
+    for i in range(1, L):
+      pyr.append(ops.avgpool_forward(pyr[-1], 2, _new(layout, N, H >> i, W >> i, Cl)))
+    pyr = pyr[::-1]
     for i in range(L):
       h, w = H >> (L - 1 - i), W >> (L - 1 - i)
-      f = H // h
-      lay = layout if f == 1 else ops.avgpool_forward(layout, f, _new(layout, N, h, w, Cl))
-      pyr.append(lay)
+      lay = pyr[i]
       W0p, b0, W1p, b1 = convp[4 * i:4 * i + 4]
       C = W0p.size(0)
       bn0, bn1 = bns[i]
