@@ -2,8 +2,8 @@
 //
 // One 256-thread workgroup (4 wavefronts of 64, arranged 2x2) owns a BM x BN output
 // tile.  The reduction runs in chunks of BK = 32; operand tiles are staged through
-// LDS (double buffered, register prefetch of the next chunk while the current one is
-// on the matrix pipe).  Two LDS images exist per operand:
+// LDS (one buffer per operand; the next chunk is prefetched into registers while the
+// current one is on the matrix pipe, and stored between two barriers).  Two LDS layouts:
 //   * "m-major"  [rows][BK+4]  - the reduction index is contiguous in global memory
 //                                (activations NHWC along channels, weight rows);
 //                                fragments are fetched with ds_read_b128.
