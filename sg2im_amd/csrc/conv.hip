@@ -14,11 +14,13 @@
 // are never materialised.
 #include <algorithm>
 #include "igemm.h"
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include "sg2im_hip.h"
 
 namespace sg2im {
+
 
 struct FwdParams {
   ConvGeom g;
@@ -99,6 +101,7 @@ __device__ __forceinline__ void locate_chunk(const ConvGeom& g, int ch, int& s, 
 }
 
 #define SG2IM_ZERO_ACC()                                   \
+  Frags<BM, BN> frags;                                     \
   f32x16 acc[BM / 64][BN / 64];                            \
   _Pragma("unroll") for (int a_ = 0; a_ < BM / 64; ++a_)   \
     _Pragma("unroll") for (int b_ = 0; b_ < BN / 64; ++b_) zero_acc(acc[a_][b_]);
@@ -199,15 +202,43 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
     }
   }
 
+  // Wave-uniform cursor over the reduction order (tap, source, channel chunk).  The loader is
+  // called with consecutive chunk indices, so the cursor is decoded once and then ADVANCED -
+  // a per-chunk decode (two integer divisions, a four-way source select of eight fields) was
+  // ~120 scalar instructions and ~20 branches per chunk in front of the loads.
+  int q_tap = 0, q_kh = 0, q_kw = 0, q_s = 0, q_cstart = 0, q_cb = 0;
+  static_assert(offsetof(FwdParams, g) == 0 && offsetof(ConvGeom, s0) == 0, "kernarg_src layout");
+  Src q_S = kernarg_src(0);
+  if (VEC == 4 && it_begin < it_end) {
+    q_tap = it_begin / p.nch;
+    locate_chunk(g, it_begin - q_tap * p.nch, q_s, q_cstart, q_cb);
+    q_S = kernarg_src(q_s);
+    q_kh = q_tap / g.KW; q_kw = q_tap - q_kh * g.KW;
+  }
+
   typedef RegSet<NVA, NVB> RS;
   RS rs0, rs1;
   auto load_into = [&](int it, RS& r) {
     if (VEC == 4) {
-      const int tap = it / p.nch;
-      int s, cstart, cb;
-      locate_chunk(g, it - tap * p.nch, s, cstart, cb);
-      const Src S = pick_src(g, s);
-      const int kh = tap / g.KW, kw = tap - kh * g.KW;
+      const int tap = q_tap, kh = q_kh, kw = q_kw, cstart = q_cstart, cb = q_cb;
+      const Src S = q_S;
+      {
+        // branch-free advance (scalar selects; the source block is re-read with scalar loads
+        // every chunk) so that the loop body stays one basic block.  The last chunk is
+        // re-issued instead of advancing past the end.
+        const bool adv = it + 1 < it_end;
+        const int ncb = q_cb + BK;
+        const bool wrap_s = adv && ncb >= q_S.C;                 // next source
+        const bool wrap_t = wrap_s && q_s + 1 == g.nsrc;         // next tap
+        const bool wrap_w = wrap_t && q_kw + 1 == g.KW;          // next kernel row
+        q_cb = wrap_s ? 0 : (adv ? ncb : q_cb);
+        q_cstart = wrap_t ? 0 : (wrap_s ? q_cstart + q_S.C : q_cstart);
+        q_s = wrap_t ? 0 : (wrap_s ? q_s + 1 : q_s);
+        q_tap += wrap_t ? 1 : 0;
+        q_kw = wrap_w ? 0 : (wrap_t ? q_kw + 1 : q_kw);
+        q_kh += wrap_w ? 1 : 0;
+        q_S = kernarg_src(q_s);
+      }
       const int c = cb + 4 * col4;
       const bool cok = c < S.C;
       fetch_aff(r.aff, S, c, cok);
@@ -286,8 +317,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
   k_pipeline(it_begin, it_end,
     [&](int it, auto set) { if constexpr (decltype(set)::value == 0) load_into(it, rs0); else load_into(it, rs1); },
     [&](auto set, int B_, bool) { if constexpr (decltype(set)::value == 0) stage_from(rs0, B_); else stage_from(rs1, B_); },
-    [&](int B_) {
-      mma_chunk<BM, BN, false, false>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, acc);
+    [&](int phase, int B_) {
+      if (phase == 0) read_frags<BM, BN, false, false>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, frags);
+      else mma_frags<BM, BN>(frags, acc);
     });
   epilogue<BM, BN>(p.e, p.M, p.Cout, p.Cout, m0, n0, wm0, wn0, lane, split, acc);
 }
@@ -385,12 +417,22 @@ __global__ __launch_bounds__(NTHREADS) void conv_dgrad_kernel(const DgradParams 
 
   typedef RegSet<NVA, NVB> RS;
   RS rs0, rs1;
+  // wave-uniform cursor over (live tap, output-channel chunk), advanced chunk by chunk
+  int q_th = 0, q_tw = 0, q_cb = 0;
+  if (VA == 4 && it_begin < it_end) {
+    const int t = it_begin / nch;
+    q_cb = (it_begin - t * nch) * BK;
+    q_th = t / nkw; q_tw = t - q_th * nkw;
+  }
   auto load_into = [&](int it, RS& r) {
     if (VA == 4) {
-      const int t = it / nch, cb = (it - t * nch) * BK;
-      const int th = t / nkw;
-      const int kh = kh0 + kstep * th, kw = kw0 + kstep * (t - th * nkw);
+      const int cb = q_cb;
+      const int kh = kh0 + kstep * q_th, kw = kw0 + kstep * q_tw;
       const int tap = kh * g.KW + kw;
+      if (it + 1 < it_end) {
+        q_cb += BK;
+        if (q_cb >= Cout) { q_cb = 0; if (++q_tw == nkw) { q_tw = 0; ++q_th; } }
+      }
       const int co = cb + 4 * col4;
       const bool cok = co < Cout;
       unsigned ma = 0, rows[NVA];
@@ -481,8 +523,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_dgrad_kernel(const DgradParams 
   k_pipeline(it_begin, it_end,
     [&](int it, auto set) { if constexpr (decltype(set)::value == 0) load_into(it, rs0); else load_into(it, rs1); },
     [&](auto set, int B_, bool) { if constexpr (decltype(set)::value == 0) stage_from(rs0, B_); else stage_from(rs1, B_); },
-    [&](int B_) {
-      mma_chunk<BM, BN, false, true>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, acc);
+    [&](int phase, int B_) {
+      if (phase == 0) read_frags<BM, BN, false, true>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, frags);
+      else mma_frags<BM, BN>(frags, acc);
     });
   if (p.parity) {
     epilogue<BM, BN>(p.e, M, p.Nc, p.Nc, m0, n0, wm0, wn0, lane, 0, acc, ParityRow{g.H, g.W, Hc, Wc, ph, pw});
@@ -643,8 +686,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams 
     [&](auto set, int B_, bool live) {
       if constexpr (decltype(set)::value == 0) stage_from(rs0, B_, live); else stage_from(rs1, B_, live);
     },
-    [&](int B_) {
-      mma_chunk<BM, BN, true, true>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, acc);
+    [&](int phase, int B_) {
+      if (phase == 0) read_frags<BM, BN, true, true>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, frags);
+      else mma_frags<BM, BN>(frags, acc);
     });
   epilogue<BM, BN>(p.e, p.Cout, Ntot, Ntot, m0, n0, wm0, wn0, lane, split, acc);
   if (want_db) {

@@ -77,6 +77,19 @@ __device__ __forceinline__ Src pick_src(const ConvGeom& g, int s) {
 }
 #undef SG2IM_PICK
 
+// The Src block of source `s`, fetched from the kernel-argument segment with scalar loads.
+// ConvGeom must sit at offset 0 of the kernel's (single, by-value) parameter struct.  Unlike
+// pick_src this keeps no copy of the four sources in SGPRs, so it is the form to use where the
+// index changes inside the main loop.
+__device__ __forceinline__ Src kernarg_src(int s) {
+  typedef __attribute__((address_space(4))) const Src* KSrc;
+  const KSrc k = (KSrc)__builtin_amdgcn_kernarg_segment_ptr() + s;
+  Src S;
+  S.p = k->p; S.gidx = k->gidx; S.scale = k->scale; S.shift = k->shift;
+  S.slope = k->slope; S.C = k->C; S.ld = k->ld; S.up = k->up;
+  return S;
+}
+
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
 
 // channel c of the virtual concat -> (source index, channel within the source)
@@ -118,13 +131,14 @@ __device__ __forceinline__ void store_tile(float* lds, const float4 (&r)[ROWS / 
 // ---------------------------------------------------------------------------
 // one BK chunk of MFMAs for a wave owning TM x TN 32x32 tiles
 // ---------------------------------------------------------------------------
+// the A / B fragments of one BK chunk for a wave owning TM x TN 32x32 tiles
+template <int BM, int BN> struct Frags { float a[BM / 64][16], b[BN / 64][16]; };
+
 template <int BM, int BN, bool AK, bool BKM>
-__device__ __forceinline__ void mma_chunk(const float* __restrict__ As, const float* __restrict__ Bs,
-                                          int wm0, int wn0, int lane,
-                                          f32x16 (&acc)[BM / 64][BN / 64]) {
+__device__ __forceinline__ void read_frags(const float* __restrict__ As, const float* __restrict__ Bs,
+                                           int wm0, int wn0, int lane, Frags<BM, BN>& f) {
   constexpr int TM = BM / 64, TN = BN / 64;
   const int i = lane & 31, h = lane >> 5;
-  float a[TM][16], b[TN][16];
   #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     if (!AK) {
@@ -132,11 +146,11 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ As, const fl
       #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 v = *reinterpret_cast<const float4*>(row + 8 * g);
-        a[tm][4 * g + 0] = v.x; a[tm][4 * g + 1] = v.y; a[tm][4 * g + 2] = v.z; a[tm][4 * g + 3] = v.w;
+        f.a[tm][4 * g + 0] = v.x; f.a[tm][4 * g + 1] = v.y; f.a[tm][4 * g + 2] = v.z; f.a[tm][4 * g + 3] = v.w;
       }
     } else {
       #pragma unroll
-      for (int s = 0; s < 16; ++s) a[tm][s] = As[kperm(s, h) * (BM + KPAD) + wm0 + tm * 32 + i];
+      for (int s = 0; s < 16; ++s) f.a[tm][s] = As[kperm(s, h) * (BM + KPAD) + wm0 + tm * 32 + i];
     }
   }
   #pragma unroll
@@ -146,22 +160,37 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ As, const fl
       #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 v = *reinterpret_cast<const float4*>(row + 8 * g);
-        b[tn][4 * g + 0] = v.x; b[tn][4 * g + 1] = v.y; b[tn][4 * g + 2] = v.z; b[tn][4 * g + 3] = v.w;
+        f.b[tn][4 * g + 0] = v.x; f.b[tn][4 * g + 1] = v.y; f.b[tn][4 * g + 2] = v.z; f.b[tn][4 * g + 3] = v.w;
       }
     } else {
       #pragma unroll
-      for (int s = 0; s < 16; ++s) b[tn][s] = Bs[kperm(s, h) * (BN + KPAD) + wn0 + tn * 32 + i];
+      for (int s = 0; s < 16; ++s) f.b[tn][s] = Bs[kperm(s, h) * (BN + KPAD) + wn0 + tn * 32 + i];
     }
   }
+}
+
+template <int BM, int BN>
+__device__ __forceinline__ void mma_frags(const Frags<BM, BN>& f, f32x16 (&acc)[BM / 64][BN / 64]) {
+  constexpr int TM = BM / 64, TN = BN / 64;
   #pragma unroll
   for (int s = 0; s < 16; ++s) {
     #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[tm][s], f.b[tn][s], acc[tm][tn], 0, 0, 0);
     }
   }
+}
+
+// one BK chunk of MFMAs: fragments from LDS, then the MFMA block
+template <int BM, int BN, bool AK, bool BKM>
+__device__ __forceinline__ void mma_chunk(const float* __restrict__ As, const float* __restrict__ Bs,
+                                          int wm0, int wn0, int lane,
+                                          f32x16 (&acc)[BM / 64][BN / 64]) {
+  Frags<BM, BN> f;
+  read_frags<BM, BN, AK, BKM>(As, Bs, wm0, wn0, lane, f);
+  mma_frags<BM, BN>(f, acc);
 }
 
 // ---------------------------------------------------------------------------
@@ -247,14 +276,14 @@ __device__ __forceinline__ void k_pipeline(int it_begin, int it_end, Load load, 
     // to just before their first use (end of the block) and the wave stalls on vmcnt
     __builtin_amdgcn_sched_barrier(0);
     if (LDS_STAGES == 2) {
-      mma(cur);
+      mma(0, cur); mma(1, cur);
       stage(IC<0>(), cur ^ 1, i + 1 < n);
       __syncthreads();
       cur ^= 1;
     } else {
       // single LDS image (half the LDS -> twice the resident workgroups): every wave must
       // be done reading chunk i before it is overwritten, hence the second barrier
-      mma(0);
+      mma(0, 0); mma(1, 0);
 #if !(SG2IM_ABL & 2)
       __syncthreads();
 #endif
@@ -296,7 +325,7 @@ __device__ __forceinline__ void k_pipeline(int it_begin, int it_end, Load load, 
         asm volatile("; k_pipeline: load set 1 done" ::: "memory");
       }
     }
-    mma(par);
+    mma(0, par); mma(1, par);
     if (i + 1 < n) {
       if (par == 0) {
         asm volatile("; k_pipeline: stage set 1" ::: "memory");
