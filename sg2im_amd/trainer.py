@@ -81,6 +81,7 @@ class Trainer(object):
     """reference scripts/train.py:509-512: eval-mode BN for G and a fresh Adam"""
     self.model.eval()
     self.opt_g.reset_state()
+    self._graphs.clear()           # captured segments baked in the training-mode kernels
 
   # -- one iteration ----------------------------------------------------------
   # The iteration is four segments separated by the points where a data-parallel exchange

@@ -181,6 +181,66 @@ def run_config(name, cfg):
   print('wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.0))
 
 
+def run_eval_config(name, cfg):
+  """Generator in eval() mode (scripts/train.py:509-512 switches to it after
+  `eval_mode_after` iterations): BatchNorm uses its running statistics, the discriminators
+  stay in train mode.  Stored as <name>_eval.pt: state, outputs, generator losses and grads."""
+  bc = cfg['batch']
+  vocab = make_vocab(bc['num_objs'], bc['num_preds'])
+  batch = synthetic_batch(**bc)
+  imgs, objs, boxes, masks, triples, obj_to_img, _ = batch
+  torch.manual_seed(4321)
+  G = Sg2ImModel(vocab, **cfg['g'])
+  Do = quiet(AcCropDiscriminator, vocab, **cfg['d_obj'])
+  Di = quiet(PatchDiscriminator, **cfg['d_img'])
+  g = torch.Generator().manual_seed(77)
+  for m in list(G.modules()) + list(Do.modules()) + list(Di.modules()):
+    if isinstance(m, torch.nn.BatchNorm2d):
+      m.weight.data = 0.5 + torch.rand(m.weight.shape, generator=g)
+      m.bias.data = 0.2 * torch.randn(m.bias.shape, generator=g)
+      # running statistics as after some training: not the (0, 1) initial values
+      m.running_mean.data = 0.3 * torch.randn(m.running_mean.shape, generator=g)
+      m.running_var.data = 0.5 + torch.rand(m.running_var.shape, generator=g)
+  G.eval(); Do.train(); Di.train()
+  sd0 = dict(G=clone_sd(G), Do=clone_sd(Do), Di=clone_sd(Di))
+  nd = cfg['g']['layout_noise_dim']
+  H, Wd = cfg['g']['image_size']
+  noise = torch.randn(imgs.size(0), nd, H, Wd, generator=g) if nd > 0 else None
+  real_randn = torch.randn
+  if nd > 0:
+    torch.randn = lambda *a, **k: noise.clone()
+  try:
+    imgs_pred, boxes_pred, masks_pred, rel_scores = G(objs, triples, obj_to_img, boxes_gt=boxes, masks_gt=masks)
+  finally:
+    torch.randn = real_randn
+  gan_g, _ = get_gan_losses('gan')
+  l1 = F.l1_loss(imgs_pred, imgs) * W['l1']
+  lb = F.mse_loss(boxes_pred, boxes) * W['bbox']
+  sf_obj, ac = Do(imgs_pred, objs, boxes, obj_to_img)
+  sf_img = Di(imgs_pred)
+  total = l1 + lb + ac * W['ac'] + gan_g(sf_obj) * (W['d'] * W['d_obj']) + gan_g(sf_img) * (W['d'] * W['d_img'])
+  for m in (G, Do, Di):
+    m.zero_grad()
+  total.backward()
+  fix = dict(
+    name=name + '_eval', config=cfg, vocab=vocab, batch=batch, noise=noise, weights=W, state_before=sd0,
+    state_after_g_forward=dict(G=clone_sd(G, True)),        # must be unchanged in eval mode
+    outputs=dict(imgs_pred=imgs_pred.detach(), boxes_pred=boxes_pred.detach(),
+                 masks_pred=None if masks_pred is None else masks_pred.detach(),
+                 rel_scores=rel_scores.detach(), d_obj_scores_fake=sf_obj.detach(),
+                 d_img_scores_fake=sf_img.detach()),
+    losses=dict(l1=l1.item(), bbox=lb.item(), ac=(ac * W['ac']).item(), total=total.item()),
+    grads=dict(G=grads_of(G)), torch_version=torch.__version__,
+  )
+  path = os.path.join(HERE, name + '_eval.pt')
+  torch.save(fix, path)
+  print('wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.0))
+
+
 if __name__ == '__main__':
+  which = sys.argv[1:] or ['train', 'eval']
   for n, c in CONFIGS.items():
-    run_config(n, c)
+    if 'train' in which:
+      run_config(n, c)
+    if 'eval' in which:
+      run_eval_config(n, c)

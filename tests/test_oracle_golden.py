@@ -122,3 +122,28 @@ def test_known_answers():
   # (i) boxes_pred >= 0 (final ReLU of build_mlp)
   fix = load_golden('tiny_coco')
   assert float(fix['outputs']['boxes_pred'].min()) >= 0.0
+
+
+@pytest.mark.parametrize('name', GOLDEN_NAMES)
+def test_eval_mode_generator_matches_reference(name):
+  """Generator in eval() mode (train.py:509-512): BN uses running statistics and leaves them
+  untouched; fixtures <name>_eval.pt come from the imported reference."""
+  fix = load_golden(name + '_eval')
+  tr = _trainer(fix)
+  tr.training = False
+  batch = fix['batch'][:6]
+  total, losses, out = tr.g_forward_loss(batch, fix['noise'])
+  want = fix['outputs']
+  assert_close(out[0], want['imgs_pred'], RTOL, ATOL, 'imgs_pred')
+  assert_close(out[1], want['boxes_pred'], RTOL, ATOL, 'boxes_pred')
+  assert_close(out[2], want['masks_pred'], RTOL, ATOL, 'masks_pred')
+  assert abs(float(total) - fix['losses']['total']) <= 1e-5 * max(1.0, abs(fix['losses']['total']))
+  total.backward()
+  for k, g in fix['grads']['G'].items():
+    got = tr.PG[k].grad
+    if g is None:
+      assert got is None or float(got.abs().max()) == 0.0, k
+    else:
+      assert_close(got, g, 1e-4, 1e-6, 'grad G.' + k)
+  for k, v in fix['state_after_g_forward']['G'].items():
+    assert torch.equal(tr.PG[k], v), 'eval mode must not touch ' + k

@@ -330,6 +330,51 @@ def golden_case(name):
       report(name + ' Di.grad ' + k, dict(Di.named_parameters())[k].grad, gref)
 
 
+def golden_eval_case(name):
+  """generator in eval() mode (running BN statistics, scripts/train.py:509-512) against the
+  <name>_eval.pt vectors of the imported reference; the discriminators stay in train mode"""
+  fix = load_golden(name + '_eval')
+  cfg = fix['config']
+  gcfg = dict(cfg['g'], vocab=fix['vocab'])
+  sd = fix['state_before']
+  G = hh.build_generator(gcfg, sd['G'])
+  Do = hh.build_d_obj(dict(cfg['d_obj'], vocab=fix['vocab']), sd['Do'])
+  Di = hh.build_d_img(dict(cfg['d_img']), sd['Di'])
+  G.eval(); Do.train(); Di.train()
+  imgs, objs, boxes, masks, triples, o2i = [hh.to_dev(t) for t in fix['batch'][:6]]
+  from sg2im_amd import losses as L
+  w = fix['weights']
+  name = name + ' eval'
+  with hh.fixed_noise(fix['noise']):
+    ip, bp, mp, rs = G(objs, triples, o2i, boxes_gt=boxes, masks_gt=masks, num_images=imgs.size(0))
+  W = fix['outputs']
+  report(name + ' imgs_pred', ip, W['imgs_pred']); report(name + ' boxes_pred', bp, W['boxes_pred'])
+  report(name + ' masks_pred', mp, W['masks_pred']); report(name + ' rel_scores', rs, W['rel_scores'])
+  sf, ac = Do(ip, objs, boxes, o2i)
+  sfi = Di(ip)
+  report(name + ' d_obj scores', sf, W['d_obj_scores_fake']); report(name + ' d_img scores', sfi, W['d_img_scores_fake'])
+  total = (L.l1_loss(ip, imgs, w['l1']) + L.mse_loss(bp, boxes, w['bbox']) + ac * w['ac']
+           + L.gan_g_loss(sf) * (w['d'] * w['d_obj']) + L.gan_g_loss(sfi) * (w['d'] * w['d_img']))
+  report(name + ' total loss', total, torch.tensor(fix['losses']['total']))
+  total.backward()
+  for k, gref in fix['grads']['G'].items():
+    got = dict(G.named_parameters())[k].grad
+    if gref is None:
+      e0 = 0.0 if got is None else float(got.abs().max()); RESULTS.append((name + ' G.grad ' + k, e0, 'expect None', e0, 0.0))
+      continue
+    if got is None:
+      RESULTS.append((name + ' G.grad ' + k, float('inf'), 'MISSING', float('inf'), 0.0)); print('MISSING grad', k); continue
+    report(name + ' G.grad ' + k, got, gref)
+  for k, v in fix['state_after_g_forward']['G'].items():       # untouched by an eval-mode forward
+    same = torch.equal(G.state_dict()[k].cpu(), v)
+    RESULTS.append((name + ' G.buf unchanged ' + k, 0.0 if same else float('inf'), 'bit-exact' if same else 'CHANGED', 0.0 if same else float('inf'), 0.0))
+
+
+def sec_golden_eval():
+  golden_eval_case('tiny_coco')
+  golden_eval_case('tiny_vg')
+
+
 def sec_golden_coco():
   golden_case('tiny_coco')
 
@@ -341,7 +386,7 @@ def sec_golden_vg():
 if __name__ == '__main__':
   print(torch.cuda.get_device_name(0))
   only = sys.argv[1:]
-  for fn in (sec_pool, sec_linear, sec_conv, sec_gconv, sec_layout, sec_losses, sec_golden_coco, sec_golden_vg):
+  for fn in (sec_pool, sec_linear, sec_conv, sec_gconv, sec_layout, sec_losses, sec_golden_coco, sec_golden_vg, sec_golden_eval):
     if not only or fn.__name__ in only:
       section(fn)
   bad = [r for r in RESULTS if not (r[1] <= 1e-4 or r[3] <= 1e-6)]
