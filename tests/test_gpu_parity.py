@@ -97,16 +97,18 @@ def test_empty_and_ragged_graphs():
   assert float(out0.abs().max()) == 0.0
 
 
-def test_trainer_two_steps_match_oracle():
-  """Two full G + D_obj + D_img iterations (flat arenas, guarded fused Adam) at the
-  reference's default architecture (batch 4) against the CPU oracle's OracleTrainer."""
+@pytest.mark.parametrize('batch_size,steps', [(4, 2), (32, 1)])
+def test_trainer_two_steps_match_oracle(batch_size, steps):
+  """Full G + D_obj + D_img iterations (flat arenas, guarded fused Adam) at the reference's
+  default architecture against the CPU oracle's OracleTrainer: two steps at batch 4, and one
+  step at the FULL bench workload (BASELINE.json configs[1]: COCO-64, batch 32)."""
   from oracle import sg2im_oracle as orc
   from sg2im_amd.synthetic import make_vocab, synthetic_batch
   from sg2im_amd.trainer import Trainer, GENERATOR_DEFAULTS, D_OBJ_DEFAULTS, D_IMG_DEFAULTS
   from tests import hip_harness as hh
   dev = hh.dev()
   vocab = make_vocab(184, 7)
-  cpu_batch = synthetic_batch(4, seed=3)
+  cpu_batch = synthetic_batch(batch_size, seed=3)
   gcfg, docfg, dicfg = dict(GENERATOR_DEFAULTS, vocab=vocab), dict(D_OBJ_DEFAULTS, vocab=vocab), dict(D_IMG_DEFAULTS)
   PG = orc.init_generator_params(gcfg, 0, randomize_bn=True)
   PDo = orc.init_ac_discriminator_params(docfg, 2, randomize_bn=True)
@@ -117,8 +119,8 @@ def test_trainer_two_steps_match_oracle():
                           {k: v.clone() for k, v in PDi.items()}, gcfg, docfg, dicfg)
   batch = tuple(t.to(dev) if torch.is_tensor(t) else t for t in cpu_batch)
   gen = torch.Generator().manual_seed(5)
-  for step in range(2):
-    noise = torch.randn(4, 32, 64, 64, generator=gen)
+  for step in range(steps):
+    noise = torch.randn(batch_size, 32, 64, 64, generator=gen)
     with hh.fixed_noise(noise):
       got = Trainer.losses_to_host(tr.step(batch))
     want = otr.step(tuple(cpu_batch[:6]), noise)
