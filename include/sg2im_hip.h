@@ -206,6 +206,16 @@ int sg2im_mse_loss(const float* pred, const float* target, long long n, float we
 /* mean( max(x,0) - x*t + log(1+exp(-|x|)) ) with a constant target t (losses.py:39-57) */
 int sg2im_bce_logits_loss(const float* x, long long n, float target, float weight, float* loss,
                           float* grad, float* partial, hipStream_t stream);
+/* GAN score terms against a constant target (sg2im/losses.py:72-145), mean over n scores:
+ *   kind 0 'gan'   BCE-with-logits (same as sg2im_bce_logits_loss)
+ *   kind 1 'wgan'  target * x          (target = -1: generator / real term, +1: fake term)
+ *   kind 2 'lsgan' (sigmoid(x) - target)^2 */
+int sg2im_gan_score_loss(const float* x, long long n, int kind, float target, float weight, float* loss,
+                         float* grad, float* partial, hipStream_t stream);
+/* F.binary_cross_entropy(prob, target) on probabilities (mask loss, scripts/train.py:407-410):
+ * logs clamped at -100, gradient (p - t) / max(p (1 - p), 1e-12) */
+int sg2im_bce_prob_loss(const float* prob, const float* target, long long n, float weight, float* loss,
+                        float* grad, float* partial, hipStream_t stream);
 /* mean_i( logsumexp(scores[i]) - scores[i][labels[i]] )  (F.cross_entropy, discriminators.py:74);
  * partial: scratch float[max(256, rows)] (256 floats for the element-wise losses above) */
 int sg2im_cross_entropy_loss(const float* scores, int rows, int classes, const long long* labels,

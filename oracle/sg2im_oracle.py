@@ -397,6 +397,23 @@ DEFAULT_LOSS_WEIGHTS = dict(            # scripts/train.py:108-131
   d_img_weight=1.0, ac_loss_weight=0.1)
 
 
+def get_gan_losses(gan_type):
+  """sg2im/losses.py:21-36, 106-145"""
+  if gan_type == 'gan':
+    return gan_g_loss, gan_d_loss
+  if gan_type == 'wgan':
+    return (lambda f: -f.mean()), (lambda r, f: f.mean() - r.mean())
+  if gan_type == 'lsgan':
+    def g(f):
+      f = f.reshape(-1)
+      return F.mse_loss(f.sigmoid(), torch.full_like(f, 1))
+    def d(r, f):
+      r, f = r.reshape(-1), f.reshape(-1)
+      return F.mse_loss(r.sigmoid(), torch.full_like(r, 1)) + F.mse_loss(f.sigmoid(), torch.full_like(f, 0))
+    return g, d
+  raise ValueError('Unrecognized GAN type "%s"' % gan_type)
+
+
 def generator_losses(w, imgs, imgs_pred, boxes, boxes_pred, masks, masks_pred,
                      predicates, rel_scores):
   """scripts/train.py:387-412 (calculate_model_losses)."""
@@ -426,7 +443,8 @@ class OracleTrainer(object):
   running stats) live in the same dicts without grad."""
 
   def __init__(self, PG, PDo, PDi, gcfg, docfg, dicfg, weights=None, lr=1e-4,
-               align_corners=False):
+               align_corners=False, gan_loss_type='gan'):
+    self.gan_g, self.gan_d = get_gan_losses(gan_loss_type)       # train.py:467
     self.PG, self.PDo, self.PDi = PG, PDo, PDi
     self.gcfg, self.docfg, self.dicfg = gcfg, docfg, dicfg
     self.w = dict(DEFAULT_LOSS_WEIGHTS)
@@ -457,10 +475,10 @@ class OracleTrainer(object):
                                                  obj_to_img, True, self.align_corners)
     losses['ac_loss'] = ac_loss * w['ac_loss_weight']
     total = total + losses['ac_loss']
-    losses['g_gan_obj_loss'] = gan_g_loss(scores_fake) * (w['discriminator_loss_weight'] * w['d_obj_weight'])
+    losses['g_gan_obj_loss'] = self.gan_g(scores_fake) * (w['discriminator_loss_weight'] * w['d_obj_weight'])
     total = total + losses['g_gan_obj_loss']
     scores_fake = patch_discriminator(self.PDi, self.dicfg, imgs_pred, True)
-    losses['g_gan_img_loss'] = gan_g_loss(scores_fake) * (w['discriminator_loss_weight'] * w['d_img_weight'])
+    losses['g_gan_img_loss'] = self.gan_g(scores_fake) * (w['discriminator_loss_weight'] * w['d_img_weight'])
     total = total + losses['g_gan_img_loss']
     losses['total_loss'] = total
     return total, losses, out
@@ -472,7 +490,7 @@ class OracleTrainer(object):
                                      True, self.align_corners)
     sr, ac_r = ac_crop_discriminator(self.PDo, self.docfg, imgs, objs, boxes, obj_to_img,
                                      True, self.align_corners)
-    parts = {'d_obj_gan_loss': gan_d_loss(sr, sf), 'd_ac_loss_real': ac_r, 'd_ac_loss_fake': ac_f}
+    parts = {'d_obj_gan_loss': self.gan_d(sr, sf), 'd_ac_loss_real': ac_r, 'd_ac_loss_fake': ac_f}
     return parts['d_obj_gan_loss'] + ac_r + ac_f, parts
 
   def d_img_loss(self, batch, imgs_fake):
@@ -480,7 +498,7 @@ class OracleTrainer(object):
     # train.py:581-588
     sf = patch_discriminator(self.PDi, self.dicfg, imgs_fake, True)
     sr = patch_discriminator(self.PDi, self.dicfg, imgs, True)
-    loss = gan_d_loss(sr, sf)
+    loss = self.gan_d(sr, sf)
     return loss, {'d_img_gan_loss': loss}
 
   def step(self, batch, noise=None):

@@ -108,8 +108,6 @@ def check_args(args):
     H = H // 2
   if H == 0:
     raise ValueError('Too many layers in refinement network')      # reference train.py:153-158
-  if args.gan_loss_type != 'gan':
-    raise NotImplementedError('--gan_loss_type %s is not on the HIP path yet' % args.gan_loss_type)
   if args.discriminator_loss_weight == 0 or args.d_obj_weight == 0 or args.d_img_weight == 0:
     raise NotImplementedError('training without one of the discriminators is not wired yet')
 
@@ -139,7 +137,8 @@ def main(args):
   trainer = Trainer(vocab, device, generator_kwargs=gk,
                     d_obj_kwargs=dict(dk, arch=args.d_obj_arch, object_size=args.crop_size),
                     d_img_kwargs=dict(dk, arch=args.d_img_arch), loss_weights=lw,
-                    learning_rate=args.learning_rate, world_size=world, seed=args.seed)
+                    learning_rate=args.learning_rate, world_size=world, seed=args.seed,
+                    gan_loss_type=args.gan_loss_type)
   if args.checkpoint_start_from is not None:                        # reference train.py:162-172
     ck = torch.load(args.checkpoint_start_from, map_location='cpu', weights_only=False)
     sd = {(k[7:] if k.startswith('module.') else k): v for k, v in ck['model_state'].items()}

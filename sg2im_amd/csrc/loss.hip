@@ -25,7 +25,7 @@ __device__ __forceinline__ float block_sum(float v) {
   return s;    // valid on thread 0
 }
 
-enum { L_L1 = 0, L_MSE = 1, L_BCE = 2 };
+enum { L_L1 = 0, L_MSE = 1, L_BCE = 2, L_BCE_PROB = 3, L_MEAN = 4, L_LSGAN = 5 };
 
 template <int KIND>
 __global__ void elementwise_loss_kernel(const float* __restrict__ x, const float* __restrict__ t, long long n,
@@ -42,12 +42,26 @@ __global__ void elementwise_loss_kernel(const float* __restrict__ x, const float
     } else if (KIND == L_MSE) {
       const float d = v - t[i];
       l = d * d; g = 2.f * d;
-    } else {
+    } else if (KIND == L_BCE) {
       // losses.py:55-56: max(x,0) - x*t + log(1 + exp(-|x|))
       const float e = expf(-fabsf(v));
       l = fmaxf(v, 0.f) - v * target + logf(1.f + e);
       const float sig = v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
       g = sig - target;
+    } else if (KIND == L_BCE_PROB) {
+      // F.binary_cross_entropy on probabilities (train.py:408): logs clamped at -100,
+      // gradient (p - t) / max(p (1 - p), 1e-12) as ATen computes it
+      const float y = t[i];
+      l = -(y * fmaxf(logf(v), -100.f) + (1.f - y) * fmaxf(logf(1.f - v), -100.f));
+      g = (v - y) / fmaxf((1.f - v) * v, 1e-12f);
+    } else if (KIND == L_MEAN) {
+      // WGAN terms (losses.py:106-124): +-mean(scores); `target` carries the sign
+      l = target * v; g = target;
+    } else {
+      // LSGAN (losses.py:127-145): mse(sigmoid(x), target)
+      const float sg = 1.f / (1.f + expf(-v));
+      const float d = sg - target;
+      l = d * d; g = 2.f * d * sg * (1.f - sg);
     }
     s += l;
     if (grad) grad[i] = g * gscale;
@@ -152,7 +166,8 @@ static inline int ok_or(hipError_t e) { return e == hipSuccess ? SG2IM_OK : SG2I
 template <int KIND>
 static int run_elementwise(const float* x, const float* t, long long n, float target, float weight,
                            float* loss, float* grad, float* partial, hipStream_t stream) {
-  if (!x || !loss || !partial || n < 1 || (KIND != L_BCE && !t)) return SG2IM_ERR_ARG;
+  constexpr bool needs_t = KIND == L_L1 || KIND == L_MSE || KIND == L_BCE_PROB;
+  if (!x || !loss || !partial || n < 1 || (needs_t && !t)) return SG2IM_ERR_ARG;
   const int blocks = (int)std::min<long long>(LOSS_BLOCKS, (n + 255) / 256);
   hipLaunchKernelGGL((elementwise_loss_kernel<KIND>), dim3(blocks), dim3(256), 0, stream, x, t, n, target,
                      (float)((double)weight / (double)n), grad, partial);
@@ -179,6 +194,19 @@ int sg2im_mse_loss(const float* pred, const float* target, long long n, float we
 int sg2im_bce_logits_loss(const float* x, long long n, float target, float weight, float* loss,
                           float* grad, float* partial, hipStream_t stream) {
   return run_elementwise<L_BCE>(x, nullptr, n, target, weight, loss, grad, partial, stream);
+}
+
+int sg2im_gan_score_loss(const float* x, long long n, int kind, float target, float weight, float* loss,
+                         float* grad, float* partial, hipStream_t stream) {
+  if (kind == 0) return run_elementwise<L_BCE>(x, nullptr, n, target, weight, loss, grad, partial, stream);
+  if (kind == 1) return run_elementwise<L_MEAN>(x, nullptr, n, target, weight, loss, grad, partial, stream);
+  if (kind == 2) return run_elementwise<L_LSGAN>(x, nullptr, n, target, weight, loss, grad, partial, stream);
+  return SG2IM_ERR_ARG;
+}
+
+int sg2im_bce_prob_loss(const float* prob, const float* target, long long n, float weight, float* loss,
+                        float* grad, float* partial, hipStream_t stream) {
+  return run_elementwise<L_BCE_PROB>(prob, target, n, 0.f, weight, loss, grad, partial, stream);
 }
 
 int sg2im_cross_entropy_loss(const float* scores, int rows, int classes, const long long* labels,

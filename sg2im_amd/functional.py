@@ -730,6 +730,26 @@ class BceLogitsLoss(_LossFn):
     return _LossFn._finish(ctx, loss, grad)
 
 
+class GanScoreLoss(_LossFn):
+  """kind 1: WGAN mean term `target * mean(x)`, kind 2: LSGAN mse(sigmoid(x), target)"""
+  @staticmethod
+  def forward(ctx, x, kind, target, weight):
+    x = x.contiguous()
+    grad = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+    loss = ops.gan_score_loss(x, kind, target, weight, grad)
+    return _LossFn._finish(ctx, loss, grad)
+
+
+class BceProbLoss(_LossFn):
+  """F.binary_cross_entropy on probabilities (mask loss, scripts/train.py:407-410)"""
+  @staticmethod
+  def forward(ctx, prob, target, weight, _unused=None):
+    prob, target = prob.contiguous(), target.contiguous().float()
+    grad = torch.empty_like(prob) if ctx.needs_input_grad[0] else None
+    loss = ops.bce_prob_loss(prob, target, weight, grad)
+    return _LossFn._finish(ctx, loss, grad)
+
+
 class CrossEntropyLoss(_LossFn):
   @staticmethod
   def forward(ctx, scores, labels, weight, _unused=None):

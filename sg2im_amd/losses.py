@@ -8,8 +8,10 @@ def get_gan_losses(gan_type):
   """reference sg2im/losses.py:21-36"""
   if gan_type == 'gan':
     return gan_g_loss, gan_d_loss
-  if gan_type in ('wgan', 'lsgan'):
-    raise NotImplementedError('"%s" GAN losses are not on the HIP path yet (SURVEY.md 8f rank 3)' % gan_type)
+  if gan_type == 'wgan':
+    return wgan_g_loss, wgan_d_loss
+  if gan_type == 'lsgan':
+    return lsgan_g_loss, lsgan_d_loss
   raise ValueError('Unrecognized GAN type "%s"' % gan_type)
 
 
@@ -38,3 +40,29 @@ def mse_loss(pred, target, weight=1.0):
 
 def cross_entropy(scores, labels, weight=1.0):
   return HF.CrossEntropyLoss.apply(scores, labels, float(weight))
+
+
+def wgan_g_loss(scores_fake):
+  """reference sg2im/losses.py:106-114: -mean(scores_fake)"""
+  return HF.GanScoreLoss.apply(scores_fake, 1, -1.0, 1.0)
+
+
+def wgan_d_loss(scores_real, scores_fake):
+  """reference sg2im/losses.py:117-124: mean(fake) - mean(real)"""
+  return HF.GanScoreLoss.apply(scores_fake, 1, 1.0, 1.0) + HF.GanScoreLoss.apply(scores_real, 1, -1.0, 1.0)
+
+
+def lsgan_g_loss(scores_fake):
+  """reference sg2im/losses.py:127-131: mse(sigmoid(fake), 1)"""
+  return HF.GanScoreLoss.apply(scores_fake, 2, 1.0, 1.0)
+
+
+def lsgan_d_loss(scores_real, scores_fake):
+  """reference sg2im/losses.py:134-145"""
+  assert scores_real.size() == scores_fake.size()
+  return HF.GanScoreLoss.apply(scores_real, 2, 1.0, 1.0) + HF.GanScoreLoss.apply(scores_fake, 2, 0.0, 1.0)
+
+
+def binary_cross_entropy(prob, target, weight=1.0):
+  """F.binary_cross_entropy on probabilities (mask loss of scripts/train.py:407-410)"""
+  return HF.BceProbLoss.apply(prob, target, float(weight))

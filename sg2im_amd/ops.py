@@ -409,6 +409,20 @@ def bce_logits_loss(x, target, weight, grad):
   return loss
 
 
+def gan_score_loss(x, kind, target, weight, grad):
+  loss = _loss_out(x.device)
+  call('sg2im_gan_score_loss', _f(x), x.numel(), int(kind), float(target), float(weight), _f(loss), _f(grad),
+       _f(scratch(x.device, 256)), _stream())
+  return loss
+
+
+def bce_prob_loss(prob, target, weight, grad):
+  loss = _loss_out(prob.device)
+  call('sg2im_bce_prob_loss', _f(prob), _f(target), prob.numel(), float(weight), _f(loss), _f(grad),
+       _f(scratch(prob.device, 256)), _stream())
+  return loss
+
+
 def cross_entropy_loss(scores, labels, weight, grad):
   loss = _loss_out(scores.device)
   R, C = scores.shape

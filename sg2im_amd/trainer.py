@@ -44,7 +44,9 @@ def _set_requires_grad(module, flag):
 
 class Trainer(object):
   def __init__(self, vocab, device, generator_kwargs=None, d_obj_kwargs=None, d_img_kwargs=None,
-               loss_weights=None, learning_rate=1e-4, world_size=1, seed=None, use_graphs=False):
+               loss_weights=None, learning_rate=1e-4, world_size=1, seed=None, use_graphs=False,
+               gan_loss_type='gan'):
+    self.gan_g_loss, self.gan_d_loss = L.get_gan_losses(gan_loss_type)     # train.py:467
     self.device = device
     self.world_size = world_size
     if seed is not None:
@@ -60,8 +62,6 @@ class Trainer(object):
     self.d_img_kwargs = dik
     self.w = dict(LOSS_WEIGHTS)
     self.w.update(loss_weights or {})
-    if self.w['predicate_pred_loss_weight'] > 0 or self.w['mask_loss_weight'] > 0:
-      raise NotImplementedError('predicate / mask auxiliary losses (default weight 0) are not wired yet')
     self.model = Sg2ImModel(vocab, **gk).to(device)
     self.d_obj = AcCropDiscriminator(vocab, **dok).to(device)
     self.d_img = PatchDiscriminator(**dik).to(device)
@@ -99,11 +99,16 @@ class Trainer(object):
     losses = st['losses']
     losses['L1_pixel_loss'] = L.l1_loss(imgs_pred, st['imgs_nhwc'], w['l1_pixel_loss_weight'])
     losses['bbox_pred'] = L.mse_loss(boxes_pred, boxes, w['bbox_pred_loss_weight'])
+    if w['predicate_pred_loss_weight'] > 0:                       # train.py:402-405
+      losses['predicate_pred'] = L.cross_entropy(rel_scores, triples[:, 1].contiguous(),
+                                                 w['predicate_pred_loss_weight'])
+    if w['mask_loss_weight'] > 0 and masks is not None and masks_pred is not None:   # train.py:407-410
+      losses['mask_loss'] = L.binary_cross_entropy(masks_pred, masks, w['mask_loss_weight'])
     scores_fake, ac_loss = self.d_obj.forward_nhwc(imgs_pred, objs, boxes, obj_to_img)
     losses['ac_loss'] = ac_loss * w['ac_loss_weight']
-    losses['g_gan_obj_loss'] = L.gan_g_loss(scores_fake) * (w['discriminator_loss_weight'] * w['d_obj_weight'])
+    losses['g_gan_obj_loss'] = self.gan_g_loss(scores_fake) * (w['discriminator_loss_weight'] * w['d_obj_weight'])
     scores_fake = self.d_img.forward_nhwc(imgs_pred)
-    losses['g_gan_img_loss'] = L.gan_g_loss(scores_fake) * (w['discriminator_loss_weight'] * w['d_img_weight'])
+    losses['g_gan_img_loss'] = self.gan_g_loss(scores_fake) * (w['discriminator_loss_weight'] * w['d_img_weight'])
     total = None
     for v in list(losses.values()):
       total = v if total is None else total + v
@@ -123,7 +128,7 @@ class Trainer(object):
     # train.py:566-579
     sf, ac_fake = self.d_obj.forward_nhwc(st['imgs_fake'], objs, boxes, obj_to_img)
     sr, ac_real = self.d_obj.forward_nhwc(st['imgs_nhwc'], objs, boxes, obj_to_img)
-    losses['d_obj_gan_loss'] = L.gan_d_loss(sr, sf)
+    losses['d_obj_gan_loss'] = self.gan_d_loss(sr, sf)
     losses['d_ac_loss_real'], losses['d_ac_loss_fake'] = ac_real, ac_fake
     d_obj_total = losses['d_obj_gan_loss'] + ac_real + ac_fake
     self.opt_do.zero_grad()
@@ -134,7 +139,7 @@ class Trainer(object):
     # train.py:581-592
     sf = self.d_img.forward_nhwc(st['imgs_fake'])
     sr = self.d_img.forward_nhwc(st['imgs_nhwc'])
-    losses['d_img_gan_loss'] = L.gan_d_loss(sr, sf)
+    losses['d_img_gan_loss'] = self.gan_d_loss(sr, sf)
     self.opt_di.zero_grad()
     losses['d_img_gan_loss'].backward()
 

@@ -140,6 +140,42 @@ def test_trainer_two_steps_match_oracle(batch_size, steps):
         assert d <= 4.1e-4 or 'running_' in k and d <= 2e-3 * max(1.0, float(v.abs().max())), (name, k, d)
 
 
+def test_trainer_aux_losses_and_lsgan_match_oracle():
+  """The optional terms of calculate_model_losses (train.py:402-410: predicate cross-entropy,
+  mask BCE: rel_aux_net and mask_net receive gradients through them) and the
+  'lsgan' objective, one iteration against the oracle."""
+  from oracle import sg2im_oracle as orc
+  from sg2im_amd.synthetic import make_vocab, synthetic_batch
+  from sg2im_amd.trainer import Trainer, GENERATOR_DEFAULTS, D_OBJ_DEFAULTS, D_IMG_DEFAULTS
+  from tests import hip_harness as hh
+  dev = hh.dev()
+  vocab = make_vocab(184, 7)
+  cpu_batch = synthetic_batch(4, seed=21)
+  lw = dict(predicate_pred_loss_weight=0.5, mask_loss_weight=0.3)
+  gcfg, docfg, dicfg = dict(GENERATOR_DEFAULTS, vocab=vocab), dict(D_OBJ_DEFAULTS, vocab=vocab), dict(D_IMG_DEFAULTS)
+  PG = orc.init_generator_params(gcfg, 6, randomize_bn=True)
+  PDo = orc.init_ac_discriminator_params(docfg, 7, randomize_bn=True)
+  PDi = orc.init_patch_discriminator_params(dicfg, 8, randomize_bn=True)
+  tr = Trainer(vocab, dev, seed=0, loss_weights=lw, gan_loss_type='lsgan')
+  hh.load_params(tr.model, PG); hh.load_params(tr.d_obj, PDo); hh.load_params(tr.d_img, PDi)
+  otr = orc.OracleTrainer({k: v.clone() for k, v in PG.items()}, {k: v.clone() for k, v in PDo.items()},
+                          {k: v.clone() for k, v in PDi.items()}, gcfg, docfg, dicfg, weights=lw,
+                          gan_loss_type='lsgan')
+  batch = tuple(t.to(dev) if torch.is_tensor(t) else t for t in cpu_batch)
+  noise = torch.randn(4, 32, 64, 64, generator=torch.Generator().manual_seed(9))
+  with hh.fixed_noise(noise):
+    got = Trainer.losses_to_host(tr.step(batch))
+  want = otr.step(tuple(cpu_batch[:6]), noise)
+  assert 'predicate_pred' in want and 'mask_loss' in want
+  for k, v in want.items():
+    assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, got[k], v)
+  sd = tr.model.state_dict()
+  for k, v in otr.PG.items():
+    if v.is_floating_point() and 'running_' not in k:
+      d = float((sd[k].detach().cpu() - v.detach()).abs().max())
+      assert d <= 2.1e-4, (k, d)
+
+
 def test_trainer_eval_mode_step_matches_oracle():
   """After `eval_mode_after` iterations the reference puts the generator in eval() and gives
   it a fresh Adam (train.py:509-512): one full iteration in that state, graphs re-captured."""

@@ -265,6 +265,28 @@ def sec_losses():
   got = L.cross_entropy(sd, y.to(D))
   got.backward()
   report('loss ce', got, want); report('loss ce grad', sd.grad, sr.grad)
+  # wgan / lsgan score terms (sg2im/losses.py:106-145) and the mask BCE on probabilities
+  for kind in ('wgan', 'lsgan'):
+    og, od = orc.get_gan_losses(kind)
+    hg, hd = L.get_gan_losses(kind)
+    fr, rr = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    want = og(fr) * 1.5 + od(rr, fr)
+    want.backward()
+    fd, rd = a.to(D).requires_grad_(True), b.to(D).requires_grad_(True)
+    got = hg(fd) * 1.5 + hd(rd, fd)
+    got.backward()
+    report('loss %s g+d' % kind, got, want)
+    report('loss %s grad fake' % kind, fd.grad, fr.grad); report('loss %s grad real' % kind, rd.grad, rr.grad)
+  pm = torch.rand(9, 16, 16, generator=g).clamp(1e-4, 1 - 1e-4)
+  pm[0, 0, 0], pm[0, 0, 1] = 0.0, 1.0                 # saturated probabilities hit the log clamp
+  ym = (torch.rand(9, 16, 16, generator=g) > 0.5).long()
+  pr_ = pm.clone().requires_grad_(True)
+  want = F.binary_cross_entropy(pr_, ym.float()) * 0.7
+  want.backward()
+  pd_ = pm.to(D).requires_grad_(True)
+  got = L.binary_cross_entropy(pd_, ym.to(D), 0.7)
+  got.backward()
+  report('loss bce on probabilities', got, want); report('loss bce on probabilities grad', pd_.grad, pr_.grad)
   # adam
   p, gr = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
   pr = p.clone().requires_grad_(True)
