@@ -445,21 +445,27 @@ class OracleTrainer(object):
   def __init__(self, PG, PDo, PDi, gcfg, docfg, dicfg, weights=None, lr=1e-4,
                align_corners=False, gan_loss_type='gan'):
     self.gan_g, self.gan_d = get_gan_losses(gan_loss_type)       # train.py:467
-    self.PG, self.PDo, self.PDi = PG, PDo, PDi
     self.gcfg, self.docfg, self.dicfg = gcfg, docfg, dicfg
     self.w = dict(DEFAULT_LOSS_WEIGHTS)
     if weights:
       self.w.update(weights)
+    # build_obj_discriminator / build_img_discriminator return None when the weight is zero
+    # (train.py:198-200, 221-223): that discriminator and its loss terms do not exist
+    if self.w['discriminator_loss_weight'] == 0 or self.w['d_obj_weight'] == 0:
+      PDo = None
+    if self.w['discriminator_loss_weight'] == 0 or self.w['d_img_weight'] == 0:
+      PDi = None
+    self.PG, self.PDo, self.PDi = PG, PDo, PDi
     self.align_corners = align_corners
     self.training = True
     for P in (PG, PDo, PDi):
-      for k, v in P.items():
+      for k, v in (P or {}).items():
         if v.is_floating_point() and not ('running_' in k):
           v.requires_grad_(True)
     # torch.optim.Adam(model.parameters(), lr) -- train.py:426,436,443
     self.opt_g = torch.optim.Adam([v for v in PG.values() if v.requires_grad], lr=lr)
-    self.opt_do = torch.optim.Adam([v for v in PDo.values() if v.requires_grad], lr=lr)
-    self.opt_di = torch.optim.Adam([v for v in PDi.values() if v.requires_grad], lr=lr)
+    self.opt_do = PDo and torch.optim.Adam([v for v in PDo.values() if v.requires_grad], lr=lr)
+    self.opt_di = PDi and torch.optim.Adam([v for v in PDi.values() if v.requires_grad], lr=lr)
 
   def g_forward_loss(self, batch, noise=None):
     imgs, objs, boxes, masks, triples, obj_to_img = batch
@@ -471,15 +477,17 @@ class OracleTrainer(object):
     total, losses = generator_losses(w, imgs, imgs_pred, boxes, boxes_pred, masks, masks_pred,
                                      triples[:, 1], rel_scores)
     # train.py:538-550
-    scores_fake, ac_loss = ac_crop_discriminator(self.PDo, self.docfg, imgs_pred, objs, boxes,
-                                                 obj_to_img, True, self.align_corners)
-    losses['ac_loss'] = ac_loss * w['ac_loss_weight']
-    total = total + losses['ac_loss']
-    losses['g_gan_obj_loss'] = self.gan_g(scores_fake) * (w['discriminator_loss_weight'] * w['d_obj_weight'])
-    total = total + losses['g_gan_obj_loss']
-    scores_fake = patch_discriminator(self.PDi, self.dicfg, imgs_pred, True)
-    losses['g_gan_img_loss'] = self.gan_g(scores_fake) * (w['discriminator_loss_weight'] * w['d_img_weight'])
-    total = total + losses['g_gan_img_loss']
+    if self.PDo is not None:
+      scores_fake, ac_loss = ac_crop_discriminator(self.PDo, self.docfg, imgs_pred, objs, boxes,
+                                                   obj_to_img, True, self.align_corners)
+      losses['ac_loss'] = ac_loss * w['ac_loss_weight']
+      total = total + losses['ac_loss']
+      losses['g_gan_obj_loss'] = self.gan_g(scores_fake) * (w['discriminator_loss_weight'] * w['d_obj_weight'])
+      total = total + losses['g_gan_obj_loss']
+    if self.PDi is not None:
+      scores_fake = patch_discriminator(self.PDi, self.dicfg, imgs_pred, True)
+      losses['g_gan_img_loss'] = self.gan_g(scores_fake) * (w['discriminator_loss_weight'] * w['d_img_weight'])
+      total = total + losses['g_gan_img_loss']
     losses['total_loss'] = total
     return total, losses, out
 
@@ -510,14 +518,17 @@ class OracleTrainer(object):
     total.backward()
     self.opt_g.step()
     imgs_fake = out[0].detach()
-    ld, parts_o = self.d_obj_loss(batch, imgs_fake)
-    self.opt_do.zero_grad()
-    ld.backward()
-    self.opt_do.step()
-    li, parts_i = self.d_img_loss(batch, imgs_fake)
-    self.opt_di.zero_grad()
-    li.backward()
-    self.opt_di.step()
+    parts_o, parts_i = {}, {}
+    if self.PDo is not None:
+      ld, parts_o = self.d_obj_loss(batch, imgs_fake)
+      self.opt_do.zero_grad()
+      ld.backward()
+      self.opt_do.step()
+    if self.PDi is not None:
+      li, parts_i = self.d_img_loss(batch, imgs_fake)
+      self.opt_di.zero_grad()
+      li.backward()
+      self.opt_di.step()
     res = {k: float(v) for k, v in losses.items()}
     res.update({k: float(v) for k, v in parts_o.items()})
     res.update({k: float(v) for k, v in parts_i.items()})

@@ -108,8 +108,6 @@ def check_args(args):
     H = H // 2
   if H == 0:
     raise ValueError('Too many layers in refinement network')      # reference train.py:153-158
-  if args.discriminator_loss_weight == 0 or args.d_obj_weight == 0 or args.d_img_weight == 0:
-    raise NotImplementedError('training without one of the discriminators is not wired yet')
 
 
 def main(args):
@@ -175,10 +173,10 @@ def main(args):
         checkpoint['losses_ts'].append(t)
       t0 = time.time()
     if t % args.checkpoint_every == 0 and rank == 0:                # reference train.py:611-661
-      checkpoint.update(model_state=trainer.model.state_dict(), d_obj_state=trainer.d_obj.state_dict(),
-                        d_img_state=trainer.d_img.state_dict(), optim_state=trainer.opt_g.state_dict(),
-                        d_obj_optim_state=trainer.opt_do.state_dict(),
-                        d_img_optim_state=trainer.opt_di.state_dict())
+      sd_of = lambda m: None if m is None else m.state_dict()     # reference train.py:634-641
+      checkpoint.update(model_state=trainer.model.state_dict(), d_obj_state=sd_of(trainer.d_obj),
+                        d_img_state=sd_of(trainer.d_img), optim_state=trainer.opt_g.state_dict(),
+                        d_obj_optim_state=sd_of(trainer.opt_do), d_img_optim_state=sd_of(trainer.opt_di))
       checkpoint['counters']['t'] = t
       checkpoint['checkpoint_ts'].append(t)
       path = os.path.join(args.output_dir, '%s_with_model.pt' % args.checkpoint_name)

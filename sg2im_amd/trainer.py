@@ -63,14 +63,20 @@ class Trainer(object):
     self.w = dict(LOSS_WEIGHTS)
     self.w.update(loss_weights or {})
     self.model = Sg2ImModel(vocab, **gk).to(device)
-    self.d_obj = AcCropDiscriminator(vocab, **dok).to(device)
-    self.d_img = PatchDiscriminator(**dik).to(device)
+    # build_obj_discriminator / build_img_discriminator (train.py:194-228): a zero weight means
+    # the discriminator, its optimiser and its loss terms do not exist
+    dw = self.w['discriminator_loss_weight']
+    self.d_obj = AcCropDiscriminator(vocab, **dok).to(device) if dw != 0 and self.w['d_obj_weight'] != 0 else None
+    self.d_img = PatchDiscriminator(**dik).to(device) if dw != 0 and self.w['d_img_weight'] != 0 else None
     for m in (self.model, self.d_obj, self.d_img):
-      m.train()
-    self.flat_g, self.flat_do, self.flat_di = FlatParams(self.model), FlatParams(self.d_obj), FlatParams(self.d_img)
+      if m is not None:
+        m.train()
+    self.flat_g = FlatParams(self.model)
+    self.flat_do = FlatParams(self.d_obj) if self.d_obj is not None else None
+    self.flat_di = FlatParams(self.d_img) if self.d_img is not None else None
     self.opt_g = FlatAdam(self.flat_g, lr=learning_rate)
-    self.opt_do = FlatAdam(self.flat_do, lr=learning_rate)
-    self.opt_di = FlatAdam(self.flat_di, lr=learning_rate)
+    self.opt_do = FlatAdam(self.flat_do, lr=learning_rate) if self.d_obj is not None else None
+    self.opt_di = FlatAdam(self.flat_di, lr=learning_rate) if self.d_img is not None else None
     self.reducer = GradReducer(world_size)
     self.use_graphs = use_graphs
     self._graphs, self._graph_warm = {}, {}
@@ -92,8 +98,9 @@ class Trainer(object):
     N = imgs.size(0)
     st['imgs_nhwc'] = HF.NchwToNhwc.apply(imgs)
     # train.py:524-560.  The discriminators are frozen here (see module docstring).
-    _set_requires_grad(self.d_obj, False)
-    _set_requires_grad(self.d_img, False)
+    for d in (self.d_obj, self.d_img):
+      if d is not None:
+        _set_requires_grad(d, False)
     imgs_pred, boxes_pred, masks_pred, rel_scores = self.model.forward_nhwc(
       objs, triples, obj_to_img, boxes_gt=boxes, masks_gt=masks, num_images=N)
     losses = st['losses']
@@ -104,11 +111,13 @@ class Trainer(object):
                                                  w['predicate_pred_loss_weight'])
     if w['mask_loss_weight'] > 0 and masks is not None and masks_pred is not None:   # train.py:407-410
       losses['mask_loss'] = L.binary_cross_entropy(masks_pred, masks, w['mask_loss_weight'])
-    scores_fake, ac_loss = self.d_obj.forward_nhwc(imgs_pred, objs, boxes, obj_to_img)
-    losses['ac_loss'] = ac_loss * w['ac_loss_weight']
-    losses['g_gan_obj_loss'] = self.gan_g_loss(scores_fake) * (w['discriminator_loss_weight'] * w['d_obj_weight'])
-    scores_fake = self.d_img.forward_nhwc(imgs_pred)
-    losses['g_gan_img_loss'] = self.gan_g_loss(scores_fake) * (w['discriminator_loss_weight'] * w['d_img_weight'])
+    if self.d_obj is not None:
+      scores_fake, ac_loss = self.d_obj.forward_nhwc(imgs_pred, objs, boxes, obj_to_img)
+      losses['ac_loss'] = ac_loss * w['ac_loss_weight']
+      losses['g_gan_obj_loss'] = self.gan_g_loss(scores_fake) * (w['discriminator_loss_weight'] * w['d_obj_weight'])
+    if self.d_img is not None:
+      scores_fake = self.d_img.forward_nhwc(imgs_pred)
+      losses['g_gan_img_loss'] = self.gan_g_loss(scores_fake) * (w['discriminator_loss_weight'] * w['d_img_weight'])
     total = None
     for v in list(losses.values()):
       total = v if total is None else total + v
@@ -119,8 +128,9 @@ class Trainer(object):
     # NaN guard of train.py:553-555 without a host sync: every optimiser of this iteration
     # skips its update when the generator loss is not finite (on any rank).
     st['guard'] = total.detach().reshape(1).clone()
-    _set_requires_grad(self.d_obj, True)
-    _set_requires_grad(self.d_img, True)
+    for d in (self.d_obj, self.d_img):
+      if d is not None:
+        _set_requires_grad(d, True)
 
   def _seg_d_obj(self, batch, st):
     imgs, objs, boxes, masks, triples, obj_to_img = batch[:6]
@@ -148,8 +158,10 @@ class Trainer(object):
     # no forward/backward above reads another network's *updated* parameters
     gs, guard = self.reducer.grad_scale, st['guard']
     self.opt_g.step_guarded(guard, gs)
-    self.opt_do.step_guarded(guard, gs)
-    self.opt_di.step_guarded(guard, gs)
+    if self.opt_do is not None:
+      self.opt_do.step_guarded(guard, gs)
+    if self.opt_di is not None:
+      self.opt_di.step_guarded(guard, gs)
     st['out'] = {k: v.detach() for k, v in st['losses'].items()}
 
   def _run_segments(self, batch, st, run):
@@ -160,10 +172,12 @@ class Trainer(object):
     run('g', lambda: self._seg_generator(batch, st))
     red.start(self.flat_g.grad)
     red.start(st['guard'])
-    run('do', lambda: self._seg_d_obj(batch, st))
-    red.start(self.flat_do.grad)
-    run('di', lambda: self._seg_d_img(batch, st))
-    red.start(self.flat_di.grad)
+    if self.d_obj is not None:
+      run('do', lambda: self._seg_d_obj(batch, st))
+      red.start(self.flat_do.grad)
+    if self.d_img is not None:
+      run('di', lambda: self._seg_d_img(batch, st))
+      red.start(self.flat_di.grad)
     red.finish()
     run('adam', lambda: self._seg_adam(st))
 

@@ -176,6 +176,42 @@ def test_trainer_aux_losses_and_lsgan_match_oracle():
       assert d <= 2.1e-4, (k, d)
 
 
+@pytest.mark.parametrize('zero', ['d_obj_weight', 'd_img_weight', 'discriminator_loss_weight'])
+def test_trainer_without_a_discriminator_matches_oracle(zero):
+  """--d_obj_weight 0 / --d_img_weight 0 / --discriminator_loss_weight 0: the reference does not
+  build that discriminator at all (train.py:198-200, 221-223) and drops its loss terms"""
+  from oracle import sg2im_oracle as orc
+  from sg2im_amd.synthetic import make_vocab, synthetic_batch
+  from sg2im_amd.trainer import Trainer, GENERATOR_DEFAULTS, D_OBJ_DEFAULTS, D_IMG_DEFAULTS
+  from tests import hip_harness as hh
+  dev = hh.dev()
+  vocab = make_vocab(184, 7)
+  cpu_batch = synthetic_batch(2, seed=31)
+  lw = {zero: 0.0}
+  gcfg, docfg, dicfg = dict(GENERATOR_DEFAULTS, vocab=vocab), dict(D_OBJ_DEFAULTS, vocab=vocab), dict(D_IMG_DEFAULTS)
+  PG = orc.init_generator_params(gcfg, 6, randomize_bn=True)
+  PDo = orc.init_ac_discriminator_params(docfg, 7, randomize_bn=True)
+  PDi = orc.init_patch_discriminator_params(dicfg, 8, randomize_bn=True)
+  tr = Trainer(vocab, dev, seed=0, loss_weights=lw)
+  hh.load_params(tr.model, PG)
+  if tr.d_obj is not None:
+    hh.load_params(tr.d_obj, PDo)
+  if tr.d_img is not None:
+    hh.load_params(tr.d_img, PDi)
+  otr = orc.OracleTrainer({k: v.clone() for k, v in PG.items()}, {k: v.clone() for k, v in PDo.items()},
+                          {k: v.clone() for k, v in PDi.items()}, gcfg, docfg, dicfg, weights=lw)
+  assert (tr.d_obj is None) == (otr.PDo is None) and (tr.d_img is None) == (otr.PDi is None)
+  assert tr.d_obj is None or tr.d_img is None
+  batch = tuple(t.to(dev) if torch.is_tensor(t) else t for t in cpu_batch)
+  noise = torch.randn(2, 32, 64, 64, generator=torch.Generator().manual_seed(9))
+  with hh.fixed_noise(noise):
+    got = Trainer.losses_to_host(tr.step(batch))
+  want = otr.step(tuple(cpu_batch[:6]), noise)
+  assert set(got) == set(want), (sorted(got), sorted(want))
+  for k, v in want.items():
+    assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, got[k], v)
+
+
 def test_trainer_eval_mode_step_matches_oracle():
   """After `eval_mode_after` iterations the reference puts the generator in eval() and gives
   it a fresh Adam (train.py:509-512): one full iteration in that state, graphs re-captured."""
