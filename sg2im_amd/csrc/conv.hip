@@ -770,6 +770,52 @@ __global__ void splitk_finish_kernel(const float* __restrict__ ws, int nsplit, l
   }
 }
 
+// float4 form of the SL == 1 case (N, ldc multiples of 4, 16-byte aligned buffers): one thread
+// per four adjacent outputs of a row; same ascending split order per output.
+__global__ void splitk_finish_v4_kernel(const float* __restrict__ ws, int nsplit, long long MN, int N,
+                                        float* __restrict__ C, long long ldc, const float* __restrict__ bias,
+                                        float slope, int accumulate,
+                                        const float* __restrict__ ws2, float* __restrict__ C2, int N2) {
+  if (C2 != nullptr && blockIdx.x == 0) {
+    __shared__ float part[256];
+    constexpr int SLB = 8, PERB = 256 / SLB;
+    const int jl = threadIdx.x % PERB, sl2 = threadIdx.x / PERB;
+    for (int base = 0; base < N2; base += PERB) {
+      const int j = base + jl;
+      float v = 0.f;
+      if (j < N2)
+        for (int s = sl2; s < nsplit; s += SLB) v += ws2[(size_t)s * N2 + j];
+      part[threadIdx.x] = v;
+      __syncthreads();
+      if (sl2 == 0 && j < N2) {
+        for (int l = 1; l < SLB; ++l) v += part[l * PERB + jl];
+        C2[j] = accumulate ? C2[j] + v : v;
+      }
+      __syncthreads();
+    }
+  }
+  const long long Q = MN >> 2;
+  const float4* __restrict__ w4 = reinterpret_cast<const float4*>(ws);
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += (long long)gridDim.x * blockDim.x) {
+    float4 v = w4[q];
+    for (int s = 1; s < nsplit; ++s) {
+      const float4 u = w4[(long long)s * Q + q];
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    const long long idx = q << 2;
+    const long long m = idx / N;
+    const int n = (int)(idx - m * N);
+    if (bias) {
+      const float4 b = *reinterpret_cast<const float4*>(bias + n);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    v.x = leaky(v.x, slope); v.y = leaky(v.y, slope); v.z = leaky(v.z, slope); v.w = leaky(v.w, slope);
+    float4* dst = reinterpret_cast<float4*>(C + m * ldc + n);
+    if (accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+    *dst = v;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -918,6 +964,14 @@ static hipError_t finish_split(const Epi& e, long long M, int N, hipStream_t st,
   const long long MN = M * N;
   int SL = 1;
   while (SL < 16 && 2 * SL <= e.nsplit / 4 && (MN * SL + 255) / 256 < 2 * g_num_cu) SL *= 2;
+  const bool v4 = SL == 1 && N % 4 == 0 && e.ldc % 4 == 0 && !((uintptr_t)e.ws & 15) && !((uintptr_t)e.C & 15) &&
+                  (!e.bias || !((uintptr_t)e.bias & 15));
+  if (v4) {
+    const int blocks4 = (int)std::min<long long>((MN / 4 + 255) / 256, 4096);
+    hipLaunchKernelGGL(splitk_finish_v4_kernel, dim3(blocks4), dim3(256), 0, st, e.ws, e.nsplit, MN, N, e.C, e.ldc,
+                       e.bias, e.slope, e.accumulate, ws2, C2, N2);
+    return hipGetLastError();
+  }
   const int per = 256 / SL;
   const int blocks = (int)std::min<long long>((MN + per - 1) / per, 4096);
   hipLaunchKernelGGL(splitk_finish_kernel, dim3(blocks), dim3(256), 0, st, e.ws, e.nsplit, MN, N, e.C, e.ldc,
