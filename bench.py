@@ -44,6 +44,8 @@ def parse():
   ap.add_argument('--no_roofline', action='store_true')
   ap.add_argument('--no_graphs', action='store_true', help='launch every kernel eagerly instead of hipGraph replay')
   ap.add_argument('--seed', type=int, default=0)
+  ap.add_argument('--force_dist', action='store_true',
+                  help='debug: 1-rank RCCL group with real all-reduces (exercises the N>1 code path on one GPU)')
   return ap.parse_args()
 
 
@@ -80,7 +82,10 @@ def main():
     raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
   torch.cuda.set_device(local_rank)
   device = torch.device('cuda', local_rank)
-  if world > 1:
+  use_dist = world > 1 or args.force_dist
+  if use_dist:
+    if 'MASTER_ADDR' not in os.environ:
+      os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', '29533'
     dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
   from sg2im_amd import ops
@@ -93,11 +98,15 @@ def main():
                               max_objs=8, mask_size=16, style='coco', seed=args.seed + rank)
   batch = tuple(t.to(device) if torch.is_tensor(t) else t for t in cpu_batch)
   trainer = Trainer(vocab, device, generator_kwargs={'image_size': (S, S)}, world_size=world, seed=1234,
-                    use_graphs=(world == 1 and not args.no_graphs))   # collectives between replays: eager
+                    use_graphs=(not use_dist and not args.no_graphs))
+  # (RCCL collectives between hipGraph replays hang on ROCm 7.2 - measured with --force_dist - so
+  # every data-parallel run launches eagerly; the eager step is GPU-bound, ~1 % slower)
+  if args.force_dist:
+    trainer.reducer.force = True
 
   def sync():
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
       dist.barrier()
       torch.cuda.synchronize()
 
@@ -113,15 +122,16 @@ def main():
     losses = trainer.step(batch)
   sync()
   elapsed = time.perf_counter() - t0
-  if world > 1:
+  if use_dist:
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
   host_losses = Trainer.losses_to_host(losses)
 
   roofline = None
-  if rank == 0 and not args.no_roofline:
-    # instrumented pass: HIP events around every implicit-GEMM launch of 3 more steps
+  if not args.no_roofline:
+    # instrumented pass: HIP events around every implicit-GEMM launch of 3 more steps (every
+    # rank runs it - the steps contain the gradient all-reduces - rank 0 reports)
     ops.TIMER = ops.KernelTimer()
     trainer.use_graphs = False          # events need the individual (eager) launches
     n_prof = 3
@@ -134,7 +144,7 @@ def main():
     launches = sum(v['launches'] for v in summ.values())
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     roofline = {
-      'bound': 'mfma', 'kernel': 'implicit-GEMM family conv_fwd/dgrad/wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32)',
+      'bound': 'mfma', 'kernel': 'implicit-GEMM family conv_fwd/dgrad/wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32) incl. split-K finish',
       'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
       'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
       'launches_per_step': launches // n_prof, 'gflop_per_step': round(flops / n_prof / 1e9, 1),
@@ -144,7 +154,7 @@ def main():
                       'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else 0.0}
                   for k, v in summ.items()},
     }
-  if world > 1:
+  if use_dist:
     dist.barrier()
 
   if rank == 0:
@@ -162,12 +172,16 @@ def main():
                  'global_batch': args.batch_size * world, 'image_size': S,
                  'objects': int(batch[1].numel()), 'triples': int(batch[4].size(0)),
                  'parallelism': 'dp%d' % world, 'total_loss': round(host_losses['total_loss'], 5),
-                 'launch': 'hipGraph replay (4 segments)' if (world == 1 and not args.no_graphs) else 'eager'},
+                 'launch': 'hipGraph replay (4 segments)' if (not use_dist and not args.no_graphs) else 'eager'},
       'roofline': roofline, 'cpu_baseline': cpu,
     }
-    print(json.dumps(out), flush=True)
-  if world > 1:
+  if use_dist:
     dist.destroy_process_group()
+  if rank == 0:
+    # RCCL writes a banner through C stdio: flush it first so the JSON line is the LAST line
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

@@ -891,6 +891,12 @@ static const double kEff[3][4] = {{1.0, 0.92, 0.80, 0.935}, {1.0, 0.92, 0.895, 0
 // block count of the BUSIEST CU, ceil(blocks / #CU) - 2.05 blocks per CU cost as much as 3.
 // Fewer than ~3 co-resident workgroups leave the loader latency exposed (`hide`); split-K pays
 // for the partial-sum round trip through the workspace and the finish launch.
+#ifndef SG2IM_FIN0
+#define SG2IM_FIN0 3800.0
+#endif
+#ifndef SG2IM_FINBW
+#define SG2IM_FINBW 2500.0
+#endif
 static const int kOcc[4] = {3, 4, 6, 4};                  // resident workgroups per CU (VGPR/LDS limited)
 static double launch_cost(int pass, int t, long long tiles, int ns, int iters, long long MN) {
   const long long blocks = tiles * ns;
@@ -901,7 +907,7 @@ static double launch_cost(int pass, int t, long long tiles, int ns, int iters, l
   const double resident = std::min<double>((double)blocks / g_num_cu, kOcc[t]);
   const double hide = resident >= 2.9 ? 1.0 : resident >= 1.9 ? 0.925 : 0.51;
   double c = (double)rounds * (per * chunk + fixed) / hide;
-  if (ns > 1) c += 3800.0 + (double)ns * (double)MN * 8.0 / 2500.0;
+  if (ns > 1) c += SG2IM_FIN0 + (double)ns * (double)MN * 8.0 / SG2IM_FINBW;
   return c;
 }
 

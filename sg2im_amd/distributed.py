@@ -21,12 +21,14 @@ import torch.distributed as dist
 class GradReducer(object):
   """Sum-reduces flat gradient arenas across ranks, asynchronously."""
 
-  def __init__(self, world_size=None, group=None):
+  def __init__(self, world_size=None, group=None, force=False):
     if world_size is None:
       world_size = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     self.world_size = world_size
     self.group = group
     self.pending = []
+    # force: issue the collectives even in a 1-rank group (exercises the RCCL path on one GPU)
+    self.force = force
 
   @property
   def grad_scale(self):
@@ -34,7 +36,7 @@ class GradReducer(object):
 
   def start(self, tensor):
     """begin an all-reduce (SUM) of ``tensor`` in place; returns immediately"""
-    if self.world_size > 1:
+    if self.world_size > 1 or self.force:
       self.pending.append(dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
   def finish(self):
