@@ -363,8 +363,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_dgrad_kernel(const DgradParams 
   // row space, live taps and K range of this workgroup
   int split = 0, ph = 0, pw = 0, Hc = g.H, Wc = g.W, kh0 = 0, kw0 = 0, nkw = g.KW, kstep = 1;
   int M = p.M, iters = p.iters, nch = p.nch;
+  int cls = 0;
   if (p.parity) {
-    const int cls = blockIdx.z;
+    cls = blockIdx.z & 3;                 // grid.z = 4 classes x nsplit
+    split = blockIdx.z >> 2;
     ph = cls >> 1; pw = cls & 1;
     Hc = (g.H - ph + 1) >> 1; Wc = (g.W - pw + 1) >> 1;
     M = g.NB * Hc * Wc;
@@ -528,7 +530,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_dgrad_kernel(const DgradParams 
       else mma_frags<BM, BN>(frags, acc);
     });
   if (p.parity) {
-    epilogue<BM, BN>(p.e, M, p.Nc, p.Nc, m0, n0, wm0, wn0, lane, 0, acc, ParityRow{g.H, g.W, Hc, Wc, ph, pw});
+    // split-K slabs of the parity form: [split][class][p.M rows][Nc], finished (and mapped to the
+    // interleaved destination rows) by splitk_finish_parity_kernel
+    Epi e2 = p.e;
+    if (e2.nsplit > 1) e2.ws += ((size_t)split * 4 + cls) * (size_t)p.M * p.Nc;
+    epilogue<BM, BN>(e2, M, p.Nc, p.Nc, m0, n0, wm0, wn0, lane, 0, acc, ParityRow{g.H, g.W, Hc, Wc, ph, pw});
   } else {
     epilogue<BM, BN>(p.e, M, p.Nc, p.Nc, m0, n0, wm0, wn0, lane, split, acc);
   }
@@ -816,6 +822,29 @@ __global__ void splitk_finish_v4_kernel(const float* __restrict__ ws, int nsplit
   }
 }
 
+// finish of the stride-2 parity data gradient: slabs [split][class][Mmax][N]; class (ph, pw) row m
+// is destination pixel (n, 2 hp + ph, 2 wp + pw)
+__global__ void splitk_finish_parity_kernel(const float* __restrict__ ws, int nsplit, int Mmax, int N,
+                                            float* __restrict__ C, long long ldc, int accumulate,
+                                            int NB, int H, int W) {
+  const long long per_split = 4LL * Mmax * N;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < per_split;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(idx % N);
+    const long long t = idx / N;
+    const int m = (int)(t % Mmax), cls = (int)(t / Mmax);
+    const int ph = cls >> 1, pw = cls & 1;
+    const int Hc = (H - ph + 1) >> 1, Wc = (W - pw + 1) >> 1;
+    if (m >= NB * Hc * Wc) continue;
+    float v = 0.f;
+    for (int s = 0; s < nsplit; ++s) v += ws[(long long)s * per_split + idx];
+    const ParityRow map{H, W, Hc, Wc, ph, pw};
+    float* dst = C + map(m) * ldc + n;
+    if (accumulate) v += *dst;
+    *dst = v;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -1009,7 +1038,7 @@ static hipError_t launch_dgrad(DgradParams& p, hipStream_t st) {
   constexpr size_t lds = LDS_STAGES * (LdsTile<BM, false>::FLOATS + LdsTile<BN, true>::FLOATS) * sizeof(float);
   static bool once = false;
   if (!once) { hipError_t e = ensure_lds(conv_dgrad_kernel<BM, BN, VA, VB>, lds); if (e != hipSuccess) return e; once = true; }
-  dim3 grid((p.Nc + BN - 1) / BN, (p.M + BM - 1) / BM, p.parity ? 4 : p.e.nsplit);
+  dim3 grid((p.Nc + BN - 1) / BN, (p.M + BM - 1) / BM, p.parity ? 4 * p.e.nsplit : p.e.nsplit);
   hipLaunchKernelGGL((conv_dgrad_kernel<BM, BN, VA, VB>), grid, dim3(NTHREADS), lds, st, p);
   return hipGetLastError();
 }
@@ -1091,8 +1120,8 @@ int sg2im_conv2d_backward_data(const sg2im_conv_desc* d, const float* weight, in
   const int taps = d->kh * d->kw;
   const bool va4 = (cout % 4 == 0) && (ld_dy % 4 == 0) && !((uintptr_t)dy & 15);
   const bool vb4 = (g.Ctot % 4 == 0) && (c_begin % 4 == 0) && (c_count % 4 == 0) && !((uintptr_t)weight & 15);
-  // stride-2 parity decomposition: needs the chunked (VA=4) K enumeration and writes every
-  // destination row exactly once, so it is not combined with split-K
+  // stride-2 parity decomposition: needs the chunked (VA=4) K enumeration; split-K partials of
+  // this form are laid out per class and finished by splitk_finish_parity_kernel
   p.parity = (d->stride == 2 && va4 && d->kh >= 2 && d->kw >= 2) ? 1 : 0;
   if (va4) { p.nch = (cout + BK - 1) / BK; p.iters = taps * p.nch; }
   else { p.nch = 0; p.iters = (taps * cout + BK - 1) / BK; }
@@ -1103,16 +1132,17 @@ int sg2im_conv2d_backward_data(const sg2im_conv_desc* d, const float* weight, in
     iters_eff = ((d->kh + 1) / 2) * ((d->kw + 1) / 2) * p.nch;
   }
   p.M = (int)Mrows;
-  Plan pl = make_plan(PASS_DGRAD, Mrows, c_count, iters_eff, Mfull * c_count, workspace_bytes,
-                      workspace != nullptr && !p.parity, 4, !va4,
+  const long long MNslab = p.parity ? 4 * Mrows * c_count : Mfull * c_count;      // floats per split
+  Plan pl = make_plan(PASS_DGRAD, Mrows, c_count, iters_eff, MNslab, workspace_bytes,
+                      workspace != nullptr, 4, !va4,
                       // (the four parity classes are launched together: 4x the workgroups)
                       [&](int bn) { return (long long)(c_count + bn - 1) / bn * (p.parity ? 4 : 1); });
   if (va4 && !vb4 && (pl.tile == 0 || pl.tile == 3)) {      // narrow scalar-B outputs: 64-wide tiles only
     const int t = pl.tile == 0 ? 1 : 2;
     pl = Plan{t, kBM[t], kBN[t], 1, 0};
-    if (!p.parity && workspace)
-      pl.nsplit = split_for(PASS_DGRAD, t, ((Mrows + pl.bm - 1) / pl.bm) * ((c_count + 63) / 64), iters_eff, Mfull * c_count,
-                            workspace_bytes, 4);
+    if (workspace)
+      pl.nsplit = split_for(PASS_DGRAD, t, ((Mrows + pl.bm - 1) / pl.bm) * ((c_count + 63) / 64) * (p.parity ? 4 : 1),
+                            iters_eff, MNslab, workspace_bytes, 4);
   }
   p.e = Epi{dx, ld_dx, nullptr, 1.f, accumulate, workspace, pl.nsplit};
   hipError_t err;
@@ -1125,6 +1155,13 @@ int sg2im_conv2d_backward_data(const sg2im_conv_desc* d, const float* weight, in
     err = launch_dgrad<64, 64, 1, 1>(p, stream);
   }
   if (err != hipSuccess) return SG2IM_ERR_HIP;
+  if (p.parity && pl.nsplit > 1) {
+    const long long per_split = 4LL * p.M * c_count;
+    const int blocks = (int)std::min<long long>((per_split + 255) / 256, 4096);
+    hipLaunchKernelGGL(splitk_finish_parity_kernel, dim3(blocks), dim3(256), 0, stream, workspace, pl.nsplit, p.M,
+                       c_count, dx, ld_dx, accumulate, d->batch, d->in_h, d->in_w);
+    return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+  }
   return finish_split(p.e, Mfull, c_count, stream) == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
 }
 

@@ -70,12 +70,15 @@ __global__ void elementwise_loss_kernel(const float* __restrict__ x, const float
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
+// one wavefront: lane l adds partial[l], partial[l + 64], ... (ascending), the 64 lane sums are
+// then folded by a fixed butterfly - a fixed order, reproducible run to run
 __global__ void loss_final_kernel(const float* __restrict__ partial, int n, double scale, float* __restrict__ loss) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    double s = 0.0;
-    for (int i = 0; i < n; ++i) s += partial[i];
-    loss[0] = (float)(s * scale);
-  }
+  const int lane = threadIdx.x;
+  double s = 0.0;
+  for (int i = lane; i < n; i += 64) s += partial[i];
+  #pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) loss[0] = (float)(s * scale);
 }
 
 // one wavefront per row
