@@ -247,11 +247,18 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
       unsigned pix[NVA];
       #pragma unroll
       for (int i = 0; i < NVA; ++i) {
+#if SG2IM_ABL & 8
+        // timing-only: no per-row address arithmetic (wrong addresses, same access pattern class)
+        (void)Hs; (void)Ws;
+        ma |= 1u << i;
+        pix[i] = (unsigned)((rn[i] * 7 + 4 * i + kw + kh) & 255);
+#else
         const int hi = rhb[i] + kh, wi = rwb[i] + kw;
         const bool ok = cok && rn[i] >= 0 && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
         ma |= (ok ? 1u : 0u) << i;
         if (GATHER) pix[i] = S.gidx ? (unsigned)S.gidx[ok ? rn[i] : 0] : (unsigned)(ok ? rn[i] : 0);
         else pix[i] = ok ? (unsigned)((rn[i] * Hs + (hi >> S.up)) * Ws + (wi >> S.up)) : 0u;
+#endif
       }
       #pragma unroll
       for (int i = 0; i < NVA; ++i) {
