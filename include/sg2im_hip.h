@@ -138,7 +138,8 @@ int sg2im_layout_backward(const float* dlayout, long long ld_dlayout, const floa
 int sg2im_crop_forward(const float* imgs, long long ld_img, int n_images, int height, int width,
                        int channels, const float* boxes, const long long* obj_to_img, int n_objs,
                        int size, int align_corners, float* crops, hipStream_t stream);
-/* d_imgs must be zero-initialised by the caller; contributions are added atomically. */
+/* Transpose of the above as a gather per image pixel: every element of d_imgs [N][H][W] (row
+ * stride ld_dimg) is written - zero where no crop touches it - in a fixed summation order. */
 int sg2im_crop_backward(const float* d_crops, int n_images, int height, int width, int channels,
                         const float* boxes, const long long* obj_to_img, int n_objs, int size,
                         int align_corners, float* d_imgs, long long ld_dimg, hipStream_t stream);

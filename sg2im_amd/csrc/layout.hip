@@ -312,22 +312,79 @@ __global__ void crop_fwd_kernel(const float* __restrict__ imgs, long long ld_img
   }
 }
 
-__global__ void crop_bwd_kernel(const float* __restrict__ dcrops, int H, int W, int C,
-                                const float* __restrict__ boxes, const long long* __restrict__ obj_to_img,
-                                int O, int size, int align_corners, float* __restrict__ dimgs, long long ld) {
-  const long long total = (long long)O * size * size;
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
-       t += (long long)gridDim.x * blockDim.x) {
-    const int j = (int)(t % size); const int i = (int)((t / size) % size); const int o = (int)(t / ((long long)size * size));
-    const CropFoot f = crop_foot(boxes + 4LL * o, i, j, size, H, W, align_corners);
-    float* img = dimgs + obj_to_img[o] * H * W * ld;
-    for (int c = 0; c < C; ++c) {
-      const float g = dcrops[t * C + c];
-      if (f.w00 != 0.f) atomicAdd(&img[((long long)f.y0 * W + f.x0) * ld + c], g * f.w00);
-      if (f.w01 != 0.f) atomicAdd(&img[((long long)f.y0 * W + f.x0 + 1) * ld + c], g * f.w01);
-      if (f.w10 != 0.f) atomicAdd(&img[((long long)(f.y0 + 1) * W + f.x0) * ld + c], g * f.w10);
-      if (f.w11 != 0.f) atomicAdd(&img[((long long)(f.y0 + 1) * W + f.x0 + 1) * ld + c], g * f.w11);
+// Gather form of the crop backward: one thread per image pixel sums, over the image's objects
+// (ascending) and the crop samples (i, j ascending) whose bilinear footprint touches the pixel,
+// dcrop * weight - the transpose of crop_fwd_kernel with a FIXED summation order and no
+// atomics (a scatter of the samples serialises on hot pixels: every sample of a small box lands
+// on the same few pixels - 136 us vs 25 us at the bench shape).  The per-axis arithmetic repeats crop_foot's exactly.
+struct CropAxis { int p0; float t; };
+
+__device__ __forceinline__ CropAxis crop_axis(float b0, float b1, int k, int size, int L, int align_corners) {
+  const float a = 2.f * b0 - 1.f, b = 2.f * b1 - 1.f;
+  const float w = lin01(k, size);
+  const float gpos = (1.f - w) * a + w * b;
+  const float ip = unnormalize(gpos, L, align_corners);
+  const float fp = floorf(ip);
+  CropAxis r;
+  r.p0 = (int)fminf(fmaxf(fp, -2.f), (float)L + 1.f);
+  r.t = ip - fp;
+  if (!(ip == ip)) { r.p0 = -2; r.t = 0.f; }
+  return r;
+}
+
+// weight of sample k for pixel p along one axis (0 when the footprint misses p)
+__device__ __forceinline__ float crop_axis_weight(const CropAxis& r, int p) {
+  return r.p0 == p ? 1.f - r.t : (r.p0 + 1 == p ? r.t : 0.f);
+}
+
+// conservative sample range [lo, hi] whose footprint can touch pixel p
+__device__ __forceinline__ void crop_axis_range(float b0, float b1, int p, int size, int L, int align_corners,
+                                                int& lo, int& hi) {
+  const float A = unnormalize(2.f * b0 - 1.f, L, align_corners);
+  const float Z = unnormalize(2.f * b1 - 1.f, L, align_corners);
+  const float B = size > 1 ? (Z - A) / (float)(size - 1) : 0.f;
+  lo = 0; hi = size - 1;
+  if (B > 1e-6f && B == B) {
+    const float l = floorf(((float)p - 1.f - A) / B) - 1.f, h = ceilf(((float)p + 1.f - A) / B) + 1.f;
+    lo = (int)fminf(fmaxf(l, 0.f), (float)size);          // lo == size: empty range
+    hi = (int)fminf(fmaxf(h, -1.f), (float)(size - 1));
+  }
+}
+
+__global__ void crop_bwd_gather_kernel(const float* __restrict__ dcrops, int H, int W, int C,
+                                       const float* __restrict__ boxes, const long long* __restrict__ obj_to_img,
+                                       int O, int size, int align_corners, float* __restrict__ dimgs, long long ld) {
+  const int n = blockIdx.y;
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= H * W) return;
+  const int y = pix / W, x = pix - y * W;
+  float* dst = dimgs + ((long long)n * H * W + pix) * ld;
+  for (int c0 = 0; c0 < C; c0 += 4) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int o = 0; o < O; ++o) {
+      if (obj_to_img[o] != n) continue;                       // wave-uniform
+      const float* box = boxes + 4LL * o;
+      int jl, jh, il, ih;
+      crop_axis_range(box[0], box[2], x, size, W, align_corners, jl, jh);
+      crop_axis_range(box[1], box[3], y, size, H, align_corners, il, ih);
+      for (int i = il; i <= ih; ++i) {
+        const float wy = crop_axis_weight(crop_axis(box[1], box[3], i, size, H, align_corners), y);
+        if (wy == 0.f) continue;
+        for (int j = jl; j <= jh; ++j) {
+          const float wx = crop_axis_weight(crop_axis(box[0], box[2], j, size, W, align_corners), x);
+          if (wx == 0.f) continue;
+          // crop_foot forms the weights as (x factor) * (y factor)
+          const float w = wx * wy;
+          const float* gsrc = dcrops + (((long long)o * size + i) * size + j) * C + c0;
+          #pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (c0 + c < C) acc[c] += gsrc[c] * w;
+        }
+      }
     }
+    #pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c0 + c < C) dst[c0 + c] = acc[c];
   }
 }
 
@@ -410,12 +467,11 @@ int sg2im_crop_forward(const float* imgs, long long ld_img, int n_images, int he
 int sg2im_crop_backward(const float* d_crops, int n_images, int height, int width, int channels,
                         const float* boxes, const long long* obj_to_img, int n_objs, int size,
                         int align_corners, float* d_imgs, long long ld_dimg, hipStream_t stream) {
-  if (!d_crops || !boxes || !obj_to_img || !d_imgs || size < 1 || channels < 1) return SG2IM_ERR_ARG;
-  (void)n_images;
-  const long long total = (long long)n_objs * size * size;
-  if (total == 0) return SG2IM_OK;
-  const int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
-  hipLaunchKernelGGL(crop_bwd_kernel, dim3(blocks), dim3(256), 0, stream, d_crops, height, width, channels, boxes,
+  if ((n_objs > 0 && (!d_crops || !boxes || !obj_to_img)) || !d_imgs || size < 1 || channels < 1) return SG2IM_ERR_ARG;
+  if (n_images < 1 || height < 1 || width < 1) return SG2IM_OK;
+  // every pixel of d_imgs is WRITTEN (zero where no crop touches it): no pre-zeroing needed
+  dim3 grid((height * width + 255) / 256, n_images);
+  hipLaunchKernelGGL(crop_bwd_gather_kernel, grid, dim3(256), 0, stream, d_crops, height, width, channels, boxes,
                      obj_to_img, n_objs, size, align_corners, d_imgs, ld_dimg);
   return ok_or(hipGetLastError());
 }

@@ -359,7 +359,7 @@ class CropFn(Function):
   def backward(ctx, g):
     boxes, obj_to_img = ctx.saved_tensors
     shape, size, ac = ctx.geom
-    d = torch.zeros(shape, dtype=torch.float32, device=g.device)
+    d = torch.empty(shape, dtype=torch.float32, device=g.device)     # every pixel is written
     ops.crop_backward(g.contiguous(), boxes, obj_to_img, size, ac, d)
     return d, None, None, None, None
 

@@ -234,6 +234,27 @@ def sec_layout():
     got.backward(gc.to(D))
     report('crop %s fwd' % tag, got, want)
     report('crop %s dimg' % tag, idv.grad, ir.grad)
+    # stress: boxes partly outside the image, one-pixel and zero-width boxes, unsorted obj_to_img
+    Ob = 23
+    bx = torch.rand(Ob, 4, generator=g) * 1.4 - 0.2
+    sb = torch.stack([torch.minimum(bx[:, 0], bx[:, 2]), torch.minimum(bx[:, 1], bx[:, 3]),
+                      torch.maximum(bx[:, 0], bx[:, 2]), torch.maximum(bx[:, 1], bx[:, 3])], 1)
+    sb[0] = torch.tensor([0.3, 0.3, 0.3 + 1.0 / S, 0.3 + 1.0 / S]); sb[1] = torch.tensor([0.5, 0.2, 0.5, 0.9])
+    o2 = torch.randint(0, N, (Ob,), generator=g)
+    ir = imgs.clone().requires_grad_(True)
+    want = orc.crop_bbox_batch(ir, sb, o2, 8)
+    gc = torch.randn(want.shape, generator=g)
+    want.backward(gc)
+    idv = imgs.to(D).requires_grad_(True)
+    got = crop_bbox_batch(idv, sb.to(D), o2.to(D), 8)
+    got.backward(gc.to(D))
+    report('crop %s stress fwd' % tag, got, want)
+    report('crop %s stress dimg' % tag, idv.grad, ir.grad)
+    first = idv.grad.clone()
+    idv.grad = None
+    got = crop_bbox_batch(idv, sb.to(D), o2.to(D), 8)
+    got.backward(gc.to(D))
+    report('crop %s backward is reproducible' % tag, idv.grad, first, exact=True)
 
 
 def sec_losses():
