@@ -511,7 +511,7 @@ class OracleTrainer(object):
 
   def step(self, batch, noise=None):
     total, losses, out = self.g_forward_loss(batch, noise)
-    if not math.isfinite(float(total)):          # train.py:553-555
+    if not math.isfinite(float(total.detach())):          # train.py:553-555
       return None
     self.opt_g.zero_grad()
     # the reference also deposits (discarded) grads in the D params here (train.py:559)

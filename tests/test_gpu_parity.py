@@ -327,3 +327,102 @@ def test_step_is_bit_reproducible():
     assert other[0] == runs[0][0]
     for a, b in zip(other[1:], runs[0][1:]):
       assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('case', ['vg64', 'vg128_deeper_crn', 'stretch256'])
+def test_other_baseline_shapes_match_oracle(case):
+  """BASELINE.json configs[2..4] as fp32 parity cases (one full iteration against the oracle):
+  VG-shape graphs without GT masks (mask_net trains through the layout), the 128x128 config with
+  a 6-module CRN, and the 256x256 stretch shape (up to 29 objects / ~100 triples per image)."""
+  from oracle import sg2im_oracle as orc
+  from sg2im_amd.synthetic import make_vocab, synthetic_batch
+  from sg2im_amd.trainer import Trainer, GENERATOR_DEFAULTS, D_OBJ_DEFAULTS, D_IMG_DEFAULTS
+  from tests import hip_harness as hh
+  dev = hh.dev()
+  vocab = make_vocab(179, 46)
+  if case == 'vg64':
+    S, bs, gk, bk = 64, 4, {}, dict(min_objs=3, max_objs=10)
+  elif case == 'vg128_deeper_crn':
+    S, bs, gk, bk = 128, 2, dict(refinement_dims=(1024, 512, 256, 128, 64, 64)), dict(min_objs=3, max_objs=10)
+  else:
+    S, bs, gk, bk = 256, 1, dict(refinement_dims=(1024, 512, 256, 128, 64, 64)), dict(min_objs=10, max_objs=29, extra_rels=60)
+  gk = dict(gk, image_size=(S, S))
+  cpu_batch = synthetic_batch(bs, image_size=(S, S), num_objs=179, num_preds=46, mask_size=16, style='vg',
+                              seed=41, **bk)
+  assert cpu_batch[3] is None
+  gcfg = dict(GENERATOR_DEFAULTS, vocab=vocab, **gk)
+  docfg, dicfg = dict(D_OBJ_DEFAULTS, vocab=vocab), dict(D_IMG_DEFAULTS)
+  PG = orc.init_generator_params(gcfg, 11, randomize_bn=True)
+  PDo = orc.init_ac_discriminator_params(docfg, 12, randomize_bn=True)
+  PDi = orc.init_patch_discriminator_params(dicfg, 13, randomize_bn=True)
+  tr = Trainer(vocab, dev, seed=0, generator_kwargs=gk)
+  hh.load_params(tr.model, PG); hh.load_params(tr.d_obj, PDo); hh.load_params(tr.d_img, PDi)
+  otr = orc.OracleTrainer({k: v.clone() for k, v in PG.items()}, {k: v.clone() for k, v in PDo.items()},
+                          {k: v.clone() for k, v in PDi.items()}, gcfg, docfg, dicfg)
+  batch = tuple(t.to(dev) if torch.is_tensor(t) else t for t in cpu_batch)
+  noise = torch.randn(bs, 32, S, S, generator=torch.Generator().manual_seed(2))
+  with hh.fixed_noise(noise):
+    got = Trainer.losses_to_host(tr.step(batch))
+  want = otr.step(tuple(cpu_batch[:6]), noise)
+  for k, v in want.items():
+    assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (case, k, got[k], v)
+  sd = tr.model.state_dict()
+  for k, v in otr.PG.items():
+    if v.is_floating_point() and 'running_' not in k:
+      d = float((sd[k].detach().cpu() - v.detach()).abs().max())
+      assert d <= 2.1e-4, (case, k, d)
+
+
+def test_forward_json_inference_path_matches_oracle():
+  """BASELINE.json configs[0] (the reference's scripts/run_model.py plumbing case): a handful of
+  scene-graph dicts through `forward_json` on a random-init 64x64 model in eval() mode - layout
+  from PREDICTED boxes and masks (no ground truth), BatchNorm on running statistics."""
+  from oracle import sg2im_oracle as orc
+  from sg2im_amd.model import Sg2ImModel
+  from sg2im_amd.trainer import GENERATOR_DEFAULTS
+  from tests import hip_harness as hh
+  dev = hh.dev()
+  names = ['__image__', 'sky', 'grass', 'sheep', 'tree', 'mountain', 'ocean', 'boat', 'cloud']
+  preds = ['__in_image__', 'above', 'below', 'left of', 'right of', 'standing on', 'behind', 'inside']
+  vocab = {'object_idx_to_name': names, 'object_name_to_idx': {n: i for i, n in enumerate(names)},
+           'pred_idx_to_name': preds, 'pred_name_to_idx': {n: i for i, n in enumerate(preds)}}
+  graphs = [
+    {'objects': ['sky', 'grass', 'sheep'], 'relationships': [[0, 'above', 1], [2, 'standing on', 1]]},
+    {'objects': ['sky', 'grass', 'sheep', 'sheep'],
+     'relationships': [[0, 'above', 1], [2, 'standing on', 1], [3, 'right of', 2]]},
+    {'objects': ['sky', 'grass', 'sheep', 'sheep', 'tree'],
+     'relationships': [[0, 'above', 1], [2, 'standing on', 1], [3, 'right of', 2], [4, 'behind', 2]]},
+    {'objects': ['sky', 'ocean', 'boat'], 'relationships': [[0, 'above', 1], [2, 'inside', 1]]},
+    {'objects': ['sky', 'ocean', 'boat', 'cloud'],
+     'relationships': [[0, 'above', 1], [2, 'inside', 1], [3, 'above', 2]]},
+    {'objects': ['mountain', 'grass', 'sheep', 'tree', 'cloud', 'sky'],
+     'relationships': [[0, 'behind', 3], [2, 'standing on', 1], [4, 'above', 0], [5, 'above', 0], [3, 'left of', 2]]},
+    {'objects': ['sheep'], 'relationships': []},
+  ]
+  gcfg = dict(GENERATOR_DEFAULTS, vocab=vocab)
+  P = orc.init_generator_params(gcfg, 21, randomize_bn=True)
+  gen = torch.Generator().manual_seed(3)
+  for k in list(P):
+    if 'running_mean' in k:
+      P[k] = 0.2 * torch.randn(P[k].shape, generator=gen)
+    elif 'running_var' in k:
+      P[k] = 0.5 + torch.rand(P[k].shape, generator=gen)
+  # keep the predicted boxes proper (x1 > x0, y1 > y0): the reference divides by their extent
+  last = max(k for k in P if k.startswith('box_net.') and k.endswith('.bias'))
+  P[last.replace('.bias', '.weight')] *= 0.01
+  P[last] = torch.tensor([0.1, 0.15, 0.7, 0.8])
+  model = Sg2ImModel(**gcfg).to(dev)
+  hh.load_params(model, P)
+  model.eval()
+  import copy
+  objs, triples, o2i = model.encode_scene_graphs(copy.deepcopy(graphs))
+  noise = torch.randn(len(graphs), 32, 64, 64, generator=gen)
+  with hh.fixed_noise(noise), torch.no_grad():
+    img, boxes, masks, rel = model.forward_json(copy.deepcopy(graphs))
+  with torch.no_grad():
+    want = orc.generator_forward({k: v.clone() for k, v in P.items()}, gcfg, objs.cpu(), triples.cpu(), o2i.cpu(),
+                                 noise=noise, training=False)
+  from tests.util import max_rel_err
+  for name, a, b in (('img', img, want[0]), ('boxes', boxes, want[1]), ('masks', masks, want[2]), ('rel', rel, want[3])):
+    assert a.shape == b.shape, name
+    assert max_rel_err(a.cpu(), b) <= 1e-4, (name, max_rel_err(a.cpu(), b))
