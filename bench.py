@@ -138,6 +138,7 @@ def main():
     for _ in range(n_prof):
       trainer.step(batch)
     summ = ops.TIMER.summary()
+    crn = ops.TIMER.summary('crn')       # the launches of the refinement network alone
     ops.TIMER = None
     flops = sum(v['flops'] for v in summ.values())
     ms = sum(v['ms'] for v in summ.values())
@@ -149,6 +150,10 @@ def main():
       'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
       'launches_per_step': launches // n_prof, 'gflop_per_step': round(flops / n_prof / 1e9, 1),
       'ms_per_step_in_kernel': round(ms / n_prof, 3),
+      'crn_only': (lambda f, m: {'gflop_per_step': round(f / n_prof / 1e9, 1), 'ms_per_step': round(m / n_prof, 3),
+                                 'tflops': round(f / (m * 1e-3) / 1e12, 2) if m > 0 else 0.0,
+                                 'frac': round(f / (m * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if m > 0 else 0.0})(
+                    sum(v['flops'] for v in crn.values()), sum(v['ms'] for v in crn.values())),
       'by_kind': {k: {'launches_per_step': v['launches'] // n_prof, 'gflop_per_step': round(v['flops'] / n_prof / 1e9, 1),
                       'ms_per_step': round(v['ms'] / n_prof, 3),
                       'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else 0.0}

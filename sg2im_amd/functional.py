@@ -425,6 +425,14 @@ class RefinementFn(Function):
 
   @staticmethod
   def forward(ctx, layout, bns, slope, training, grad_channels, *params):
+    ops.TIMER_TAG = 'crn'
+    try:
+      return RefinementFn._forward(ctx, layout, bns, slope, training, grad_channels, *params)
+    finally:
+      ops.TIMER_TAG = None
+
+  @staticmethod
+  def _forward(ctx, layout, bns, slope, training, grad_channels, *params):
     L = len(bns)
     N, H, W, Cl = layout.shape
     convp = params[:4 * L]
@@ -474,6 +482,14 @@ class RefinementFn(Function):
 
   @staticmethod
   def backward(ctx, g):
+    ops.TIMER_TAG = 'crn'
+    try:
+      return RefinementFn._backward(ctx, g)
+    finally:
+      ops.TIMER_TAG = None
+
+  @staticmethod
+  def _backward(ctx, g):
     params = ctx.saved_tensors
     L, slope, training, z, do0, do2, Cl, Cf, grad_channels = ctx.misc
     N, H, W, _ = ctx.shape

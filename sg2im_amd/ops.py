@@ -130,12 +130,15 @@ class KernelTimer(object):
   so ``elapsed_time`` is the device-side duration of the launch (incl. its split-K finish)."""
 
   def __init__(self):
-    self.records = []        # (kind, flops, start_event, end_event)
+    self.records = []        # (kind, flops, start_event, end_event, tag)
 
-  def summary(self):
+  def summary(self, tag=None):
+    """per-kind totals; tag: only the launches made inside that network (TIMER_TAG)"""
     torch.cuda.synchronize()
     out = {}
-    for kind, flops, e0, e1 in self.records:
+    for kind, flops, e0, e1, tg in self.records:
+      if tag is not None and tg != tag:
+        continue
       d = out.setdefault(kind, {'launches': 0, 'flops': 0.0, 'ms': 0.0})
       d['launches'] += 1
       d['flops'] += flops
@@ -144,6 +147,7 @@ class KernelTimer(object):
 
 
 TIMER = None     # set to a KernelTimer to time every conv / linear launch
+TIMER_TAG = None # set by a network around its launches (e.g. 'crn') to attribute them
 
 
 def _timed(kind, flops, fn):
@@ -153,7 +157,7 @@ def _timed(kind, flops, fn):
   e0.record()
   fn()
   e1.record()
-  TIMER.records.append((kind, flops, e0, e1))
+  TIMER.records.append((kind, flops, e0, e1, TIMER_TAG))
 
 
 def _desc_k(desc):
