@@ -858,6 +858,7 @@ __global__ void splitk_finish_parity_kernel(const float* __restrict__ ws, int ns
 static int g_num_cu = 256;
 static const bool g_plan_debug = getenv("SG2IM_PLAN_DEBUG") != nullptr;   // print the launch plans
 static const size_t g_lds_floor = getenv("SG2IM_LDS_FLOOR") ? (size_t)atol(getenv("SG2IM_LDS_FLOOR")) : 0;
+static const int g_min_iters = getenv("SG2IM_MIN_ITERS") ? atoi(getenv("SG2IM_MIN_ITERS")) : 0;   // experiments
 static const bool g_plan_tune = getenv("SG2IM_PLAN_TUNE") != nullptr;     // honour SG2IM_FORCE_PLAN
 
 template <typename K>
@@ -949,6 +950,7 @@ static double launch_cost(int pass, int t, long long tiles, int ns, int iters, l
 
 static int split_for(int pass, int t, long long tiles, int iters, long long MN, size_t ws_bytes, int min_iters,
                      double* cost_out = nullptr) {
+  if (g_min_iters > 0) min_iters = g_min_iters;
   long long cap = std::max(1, iters / min_iters);
   cap = std::min<long long>(cap, MN > 0 ? std::max<long long>(1, (long long)(ws_bytes / sizeof(float)) / MN) : 1);
   // (tiny outputs - the weight gradients of the RGB layers - are latency bound and may be
@@ -988,7 +990,7 @@ static Plan make_plan(int pass, long long M, long long N, int iters, long long M
     int t = 0, ns = 1;
     if (f && sscanf(f, "%d,%d", &t, &ns) == 2 && t >= 0 && t < 4 && !(only64 && t != 2)) {
       const long long tiles = ((M + kBM[t] - 1) / kBM[t]) * ntn(kBN[t]);
-      long long cap = can_split ? std::max(1, iters / min_iters) : 1;
+      long long cap = can_split ? std::max(1, iters / (g_min_iters > 0 ? g_min_iters : min_iters)) : 1;
       if (MN > 0) cap = std::min<long long>(cap, std::max<long long>(1, (long long)(ws_bytes / sizeof(float)) / MN));
       ns = (int)std::max<long long>(1, std::min<long long>(ns, cap));
       const int per = (iters + ns - 1) / ns;

@@ -54,8 +54,13 @@ def _i32(t):
   return c_void_p(t.data_ptr())
 
 
+LANE = 0       # execution lane of the caller: work captured on a side stream (Trainer's
+               # overlapped discriminator steps) sets LANE = 1 and gets its own split-K
+               # workspace / reduction scratch, so concurrently running lanes never share them
+
+
 def workspace(device):
-  key = device.index        # one in-order stream per device uses it (also inside graph capture)
+  key = (device.index, LANE)  # one in-order stream per lane uses it (also inside graph capture)
   w = _ws.get(key)
   if w is None:
     w = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
@@ -64,8 +69,8 @@ def workspace(device):
 
 
 def scratch(device, nfloats):
-  """Reduction scratch (per device+stream), grown on demand."""
-  key = device.index
+  """Reduction scratch (per device and lane), grown on demand."""
+  key = (device.index, LANE)
   s = _scratch.get(key)
   if s is None or s.numel() < nfloats:
     s = torch.empty(max(int(nfloats), 1 << 20), dtype=torch.float32, device=device)

@@ -45,7 +45,7 @@ def _set_requires_grad(module, flag):
 class Trainer(object):
   def __init__(self, vocab, device, generator_kwargs=None, d_obj_kwargs=None, d_img_kwargs=None,
                loss_weights=None, learning_rate=1e-4, world_size=1, seed=None, use_graphs=False,
-               gan_loss_type='gan'):
+               gan_loss_type='gan', overlap_d=None):
     self.gan_g_loss, self.gan_d_loss = L.get_gan_losses(gan_loss_type)     # train.py:467
     self.device = device
     self.world_size = world_size
@@ -79,6 +79,11 @@ class Trainer(object):
     self.opt_di = FlatAdam(self.flat_di, lr=learning_rate) if self.d_img is not None else None
     self.reducer = GradReducer(world_size)
     self.use_graphs = use_graphs
+    # single-GPU graph mode: capture the whole iteration as ONE graph in which the two
+    # discriminator steps run on a side stream concurrently with the generator's backward
+    # (they only need imgs_pred; their small kernels fill the CUs the GCN / MLP backward leaves idle)
+    self.overlap_d = (world_size == 1) if overlap_d is None else bool(overlap_d)
+    self._side = None
     self._graphs, self._graph_warm = {}, {}
     self.t = 0
 
@@ -93,6 +98,10 @@ class Trainer(object):
   # The iteration is four segments separated by the points where a data-parallel exchange
   # is started: generator fwd+bwd | D_obj fwd+bwd | D_img fwd+bwd | the three Adam updates.
   def _seg_generator(self, batch, st):
+    self._seg_generator_forward(batch, st)
+    self._seg_generator_backward(st)
+
+  def _seg_generator_forward(self, batch, st):
     imgs, objs, boxes, masks, triples, obj_to_img = batch[:6]
     w = self.w
     N = imgs.size(0)
@@ -122,8 +131,7 @@ class Trainer(object):
     for v in list(losses.values()):
       total = v if total is None else total + v
     losses['total_loss'] = total
-    self.opt_g.zero_grad()
-    total.backward()
+    st['total'] = total
     st['imgs_fake'] = imgs_pred.detach()
     # NaN guard of train.py:553-555 without a host sync: every optimiser of this iteration
     # skips its update when the generator loss is not finite (on any rank).
@@ -131,6 +139,10 @@ class Trainer(object):
     for d in (self.d_obj, self.d_img):
       if d is not None:
         _set_requires_grad(d, True)
+
+  def _seg_generator_backward(self, st):
+    self.opt_g.zero_grad()
+    st.pop('total').backward()
 
   def _seg_d_obj(self, batch, st):
     imgs, objs, boxes, masks, triples, obj_to_img = batch[:6]
@@ -225,6 +237,8 @@ class Trainer(object):
       st = {'losses': {}}
       graphs = {}
       pool = [None]
+      if self.overlap_d and self.world_size == 1:
+        return self._capture_overlapped(key, static, st)
 
       def capture(name, fn):
         g = torch.cuda.CUDAGraph()
@@ -250,7 +264,39 @@ class Trainer(object):
     static, graphs, st, _ = ent
     for s, t in zip([x for x in static if torch.is_tensor(x)], tensors):
       s.copy_(t, non_blocking=True)
+    if 'all' in graphs:
+      graphs['all'].replay()
+      return st['out']
     self._run_segments(static, st, lambda name, fn: graphs[name].replay())
+    return st['out']
+
+  def _capture_overlapped(self, key, static, st):
+    """One graph for the whole iteration (single GPU): generator forward, then a fork - the
+    generator's backward on the capture stream, both discriminator steps on a side stream
+    (own split-K workspace / scratch: ops.LANE) - joined before the three Adam updates."""
+    from . import ops
+    if self._side is None:
+      self._side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+      main = torch.cuda.current_stream()
+      self._seg_generator_forward(static, st)
+      self._side.wait_stream(main)
+      with torch.cuda.stream(self._side):
+        ops.LANE = 1
+        try:
+          if self.d_obj is not None:
+            self._seg_d_obj(static, st)
+          if self.d_img is not None:
+            self._seg_d_img(static, st)
+        finally:
+          ops.LANE = 0
+      self._seg_generator_backward(st)
+      main.wait_stream(self._side)
+      self._seg_adam(st)
+    self._graphs[key] = (static, {'all': g}, st, _lib.EAGER_EPOCH)
+    g.replay()
     return st['out']
 
   @staticmethod
