@@ -84,6 +84,8 @@ class Trainer(object):
     # (they only need imgs_pred; their small kernels fill the CUs the GCN / MLP backward leaves idle)
     self.overlap_d = (world_size == 1) if overlap_d is None else bool(overlap_d)
     self._side = None
+    import os
+    self.overlap_eager = os.environ.get('SG2IM_OVERLAP_EAGER', '0') == '1'
     self._graphs, self._graph_warm = {}, {}
     self.t = 0
 
@@ -193,6 +195,38 @@ class Trainer(object):
     red.finish()
     run('adam', lambda: self._seg_adam(st))
 
+  def _run_overlapped_eager(self, batch, st):
+    """Eager form of the overlap: the generator's backward is enqueued on the current stream
+    first, then the discriminator steps on a side stream (the host runs ahead of the GPU, so
+    they execute next to the tail of the backward); gradient exchanges are started on the
+    stream that produced them."""
+    from . import ops
+    if self._side is None:
+      self._n_side = 1
+      self._side = (torch.cuda.Stream(),)
+    side, main, red = self._side[0], torch.cuda.current_stream(), self.reducer
+    self._seg_generator_forward(batch, st)
+    side.wait_stream(main)
+    self._seg_generator_backward(st)
+    red.start(self.flat_g.grad)
+    red.start(st['guard'])
+    with torch.cuda.stream(side):
+      ops.LANE = 1
+      try:
+        for t in (st['imgs_fake'], st['imgs_nhwc']):
+          t.record_stream(side)
+        if self.d_obj is not None:
+          self._seg_d_obj(batch, st)
+          red.start(self.flat_do.grad)
+        if self.d_img is not None:
+          self._seg_d_img(batch, st)
+          red.start(self.flat_di.grad)
+      finally:
+        ops.LANE = 0
+    main.wait_stream(side)
+    red.finish()
+    self._seg_adam(st)
+
   def step(self, batch):
     """batch: (imgs (N,3,H,W), objs, boxes, masks | None, triples, obj_to_img) on the device.
     Returns a dict of 0-dim device tensors (no host sync)."""
@@ -200,7 +234,10 @@ class Trainer(object):
     if self.use_graphs:
       return self._graph_step(batch)
     st = {'losses': {}}
-    self._run_segments(batch, st, lambda name, fn: fn())
+    if self.overlap_eager:
+      self._run_overlapped_eager(batch, st)
+    else:
+      self._run_segments(batch, st, lambda name, fn: fn())
     return st['out']
 
   # -- hipGraph replay for shape-static batches -----------------------------------
@@ -272,28 +309,34 @@ class Trainer(object):
 
   def _capture_overlapped(self, key, static, st):
     """One graph for the whole iteration (single GPU): generator forward, then a fork - the
-    generator's backward on the capture stream, both discriminator steps on a side stream
+    generator's backward on the capture stream, each discriminator step on its own side stream
     (own split-K workspace / scratch: ops.LANE) - joined before the three Adam updates."""
     from . import ops
     if self._side is None:
-      self._side = torch.cuda.Stream()
+      import os
+      self._n_side = int(os.environ.get('SG2IM_SIDE_STREAMS', '1'))   # (2 measured slower: 11.1 vs 10.65 ms)
+      self._side = tuple(torch.cuda.Stream() for _ in range(self._n_side))
     g = torch.cuda.CUDAGraph()
     torch.cuda.synchronize()
     with torch.cuda.graph(g):
       main = torch.cuda.current_stream()
       self._seg_generator_forward(static, st)
-      self._side.wait_stream(main)
-      with torch.cuda.stream(self._side):
-        ops.LANE = 1
-        try:
-          if self.d_obj is not None:
-            self._seg_d_obj(static, st)
-          if self.d_img is not None:
-            self._seg_d_img(static, st)
-        finally:
-          ops.LANE = 0
+      lanes = ((1, self.d_obj, self._seg_d_obj), (2, self.d_img, self._seg_d_img))
+      for lane, net, seg in lanes:
+        if net is None:
+          continue
+        side = self._side[(lane - 1) % self._n_side]
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+          ops.LANE = lane
+          try:
+            seg(static, st)
+          finally:
+            ops.LANE = 0
       self._seg_generator_backward(st)
-      main.wait_stream(self._side)
+      for lane, net, seg in lanes:
+        if net is not None:
+          main.wait_stream(self._side[(lane - 1) % self._n_side])
       self._seg_adam(st)
     self._graphs[key] = (static, {'all': g}, st, _lib.EAGER_EPOCH)
     g.replay()
