@@ -321,7 +321,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
   int wm0, wn0, lane;
   wave_origin<BM, BN>(tid, wm0, wn0, lane);
 
-  k_pipeline(it_begin, it_end,
+  k_pipeline<TilePipe<BM, BN>::DEPTH>(it_begin, it_end,
     [&](int it, auto set) { if constexpr (decltype(set)::value == 0) load_into(it, rs0); else load_into(it, rs1); },
     [&](auto set, int B_, bool) { if constexpr (decltype(set)::value == 0) stage_from(rs0, B_); else stage_from(rs1, B_); },
     [&](int phase, int B_) {
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_dgrad_kernel(const DgradParams 
   int wm0, wn0, lane;
   wave_origin<BM, BN>(tid, wm0, wn0, lane);
 
-  k_pipeline(it_begin, it_end,
+  k_pipeline<TilePipe<BM, BN>::DEPTH>(it_begin, it_end,
     [&](int it, auto set) { if constexpr (decltype(set)::value == 0) load_into(it, rs0); else load_into(it, rs1); },
     [&](auto set, int B_, bool) { if constexpr (decltype(set)::value == 0) stage_from(rs0, B_); else stage_from(rs1, B_); },
     [&](int phase, int B_) {
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams 
   int wm0, wn0, lane;
   wave_origin<BM, BN>(tid, wm0, wn0, lane);
 
-  k_pipeline(it_begin, it_end,
+  k_pipeline<TilePipe<BM, BN>::DEPTH>(it_begin, it_end,
     [&](int it, auto set) { if constexpr (decltype(set)::value == 0) load_into(it, rs0); else load_into(it, rs1); },
     [&](auto set, int B_, bool live) {
       if constexpr (decltype(set)::value == 0) stage_from(rs0, B_, live); else stage_from(rs1, B_, live);
@@ -1025,7 +1025,7 @@ static hipError_t finish_split(const Epi& e, long long M, int N, hipStream_t st,
 
 template <int BM, int BN, int VEC, bool GATHER>
 static hipError_t launch_fwd_g(FwdParams& p, hipStream_t st) {
-  constexpr size_t lds = LDS_STAGES * (LdsTile<BM, false>::FLOATS + LdsTile<BN, false>::FLOATS) * sizeof(float);
+  constexpr size_t lds = TilePipe<BM, BN>::LDS_IMAGES * (LdsTile<BM, false>::FLOATS + LdsTile<BN, false>::FLOATS) * sizeof(float);
   static bool once = false;
   const size_t lds_req = std::max(lds, g_lds_floor);   // (occupancy experiments: SG2IM_LDS_FLOOR)
   if (!once) { hipError_t e = ensure_lds(conv_fwd_kernel<BM, BN, VEC, GATHER>, std::max(lds, g_lds_floor)); if (e != hipSuccess) return e; once = true; }
@@ -1044,7 +1044,7 @@ static hipError_t launch_fwd(FwdParams& p, hipStream_t st) {
 
 template <int BM, int BN, int VA, int VB>
 static hipError_t launch_dgrad(DgradParams& p, hipStream_t st) {
-  constexpr size_t lds = LDS_STAGES * (LdsTile<BM, false>::FLOATS + LdsTile<BN, true>::FLOATS) * sizeof(float);
+  constexpr size_t lds = TilePipe<BM, BN>::LDS_IMAGES * (LdsTile<BM, false>::FLOATS + LdsTile<BN, true>::FLOATS) * sizeof(float);
   static bool once = false;
   if (!once) { hipError_t e = ensure_lds(conv_dgrad_kernel<BM, BN, VA, VB>, lds); if (e != hipSuccess) return e; once = true; }
   dim3 grid((p.Nc + BN - 1) / BN, (p.M + BM - 1) / BM, p.parity ? 4 * p.e.nsplit : p.e.nsplit);
@@ -1054,7 +1054,7 @@ static hipError_t launch_dgrad(DgradParams& p, hipStream_t st) {
 
 template <int BM, int BN, int VEC, bool GATHER>
 static hipError_t launch_wgrad_g(WgradParams& p, int ntiles_n, hipStream_t st) {
-  constexpr size_t lds = LDS_STAGES * (LdsTile<BM, true>::FLOATS + LdsTile<BN, true>::FLOATS) * sizeof(float);
+  constexpr size_t lds = TilePipe<BM, BN>::LDS_IMAGES * (LdsTile<BM, true>::FLOATS + LdsTile<BN, true>::FLOATS) * sizeof(float);
   static bool once = false;
   if (!once) { hipError_t e = ensure_lds(conv_wgrad_kernel<BM, BN, VEC, GATHER>, lds); if (e != hipSuccess) return e; once = true; }
   p.ntiles_n = ntiles_n;

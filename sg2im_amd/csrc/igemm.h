@@ -241,8 +241,8 @@ __device__ __forceinline__ void epilogue(const Epi& e, int M, int N, int nlimit,
 // never dynamically indexed, which would demote them to scratch)
 template <int I> struct IC { static constexpr int value = I; };
 
-#ifndef SG2IM_PIPE_DEPTH
-#define SG2IM_PIPE_DEPTH 1
+#ifndef SG2IM_SMALL_TILE_DEPTH
+#define SG2IM_SMALL_TILE_DEPTH 1   // (2 measured: no gain on the tiny GEMMs, fewer resident waves)
 #endif
 #ifndef SG2IM_LDS_STAGES
 #define SG2IM_LDS_STAGES 1
@@ -252,14 +252,13 @@ constexpr int LDS_STAGES = SG2IM_LDS_STAGES;
 #ifndef SG2IM_ABL
 #define SG2IM_ABL 0        // timing-only ablations (1: no loads/stores in the loop, 2: no barriers)
 #endif
-#if SG2IM_PIPE_DEPTH == 1
 // Depth-1 variant: ONE register set and a branch-free loop body - the loads of chunk i+1,
 // the MFMAs of chunk i and the LDS stores of chunk i+1 are one basic block, so the compiler
 // can slot the loader's address arithmetic into the 64-cycle shadows of the MFMAs (a wave
 // issues ~8 other instructions per fp32 MFMA for free).  The last chunk is fetched and
 // staged a second time instead of guarding the tail with branches; that copy is never read.
 template <typename Load, typename Stage, typename Mma>
-__device__ __forceinline__ void k_pipeline(int it_begin, int it_end, Load load, Stage stage, Mma mma) {
+__device__ __forceinline__ void k_pipeline_d1(int it_begin, int it_end, Load load, Stage stage, Mma mma) {
   const int n = it_end - it_begin;
   if (n <= 0) return;
   load(it_begin, IC<0>());
@@ -296,9 +295,12 @@ __device__ __forceinline__ void k_pipeline(int it_begin, int it_end, Load load, 
     }
   }
 }
-#else
+// Depth-2 variant (used for the 64x64 tile): TWO register sets and TWO LDS images, one barrier
+// per chunk - two chunks of global loads stay in flight.  The small-tile launches are tiny
+// GEMMs with few workgroups per CU, where nothing else hides the load -> store -> barrier ->
+// MFMA latency chain of each chunk (measured ~1.2 us per chunk with the depth-1 loop).
 template <typename Load, typename Stage, typename Mma>
-__device__ __forceinline__ void k_pipeline(int it_begin, int it_end, Load load, Stage stage, Mma mma) {
+__device__ __forceinline__ void k_pipeline_d2(int it_begin, int it_end, Load load, Stage stage, Mma mma) {
   const int n = it_end - it_begin;
   if (n <= 0) return;
   load(it_begin, IC<0>());
@@ -340,7 +342,20 @@ __device__ __forceinline__ void k_pipeline(int it_begin, int it_end, Load load, 
     __syncthreads();
   }
 }
-#endif
+
+// PD = 1: single LDS image / one register set (large tiles, occupancy bound)
+// PD = 2: double LDS image / two register sets (small tiles, latency bound)
+template <int PD, typename Load, typename Stage, typename Mma>
+__device__ __forceinline__ void k_pipeline(int it_begin, int it_end, Load load, Stage stage, Mma mma) {
+  if constexpr (PD == 2) k_pipeline_d2(it_begin, it_end, load, stage, mma);
+  else k_pipeline_d1(it_begin, it_end, load, stage, mma);
+}
+
+// pipeline depth / LDS images per tile shape
+template <int BM, int BN> struct TilePipe {
+  static constexpr int DEPTH = (BM * BN <= 64 * 64) ? SG2IM_SMALL_TILE_DEPTH : 1;
+  static constexpr int LDS_IMAGES = DEPTH == 2 ? 2 : LDS_STAGES;
+};
 
 // wave placement inside the block tile: 2 x 2 wavefronts
 template <int BM, int BN>
