@@ -829,6 +829,62 @@ __global__ void splitk_finish_v4_kernel(const float* __restrict__ ws, int nsplit
   }
 }
 
+// Data gradient w.r.t. a few (<= 4) input channels - the RGB input of the discriminators'
+// first convolution.  An MFMA tile would be 64 columns wide for 3 useful ones (120 us at the
+// bench shape); this is a plain gather: one thread per input pixel, the weights of the
+// requested channels in LDS as [tap][co][NC], each live tap a dot product over co.
+template <int NC>
+__global__ void conv_dgrad_fewc_kernel(const float* __restrict__ dY, int ldy, const float* __restrict__ Wt,
+                                       int Cout, int Ctot, int c_begin, int NB, int H, int W, int Ho, int Wo,
+                                       int KH, int KW, int stride, int pad, float* __restrict__ dx,
+                                       long long ld_dx, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) float wsh[];
+  const int taps = KH * KW;
+  for (int idx = threadIdx.x; idx < taps * Cout * NC; idx += blockDim.x) {
+    const int c = idx % NC, co = (idx / NC) % Cout, tap = idx / (NC * Cout);
+    wsh[idx] = Wt[((long long)co * taps + tap) * Ctot + c_begin + c];
+  }
+  __syncthreads();
+  const long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= (long long)NB * H * W) return;
+  const int w = (int)(pix % W), h = (int)((pix / W) % H), n = (int)(pix / ((long long)W * H));
+  float acc[NC];
+  #pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+  const bool v4 = (Cout % 4 == 0) && (ldy % 4 == 0) && !((uintptr_t)dY & 15);
+  for (int kh = 0; kh < KH; ++kh) {
+    const int hh = h + pad - kh;
+    if (hh < 0 || hh % stride) continue;
+    const int ho = hh / stride;
+    if (ho >= Ho) continue;
+    for (int kw = 0; kw < KW; ++kw) {
+      const int ww = w + pad - kw;
+      if (ww < 0 || ww % stride) continue;
+      const int wo = ww / stride;
+      if (wo >= Wo) continue;
+      const float* row = dY + (((long long)n * Ho + ho) * Wo + wo) * ldy;
+      const float* wt = wsh + (kh * KW + kw) * Cout * NC;
+      if (v4) {
+        for (int co = 0; co < Cout; co += 4) {
+          const float4 g4 = *reinterpret_cast<const float4*>(row + co);
+          const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+          #pragma unroll
+          for (int j = 0; j < 4; ++j)
+            #pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = fmaf(gv[j], wt[(co + j) * NC + c], acc[c]);
+        }
+      } else {
+        for (int co = 0; co < Cout; ++co)
+          #pragma unroll
+          for (int c = 0; c < NC; ++c) acc[c] = fmaf(row[co], wt[co * NC + c], acc[c]);
+      }
+    }
+  }
+  float* dst = dx + pix * ld_dx;
+  #pragma unroll
+  for (int c = 0; c < NC; ++c) dst[c] = accumulate ? dst[c] + acc[c] : acc[c];
+}
+
 // finish of the stride-2 parity data gradient: slabs [split][class][Mmax][N]; class (ph, pw) row m
 // is destination pixel (n, 2 hp + ph, 2 wp + pw)
 __global__ void splitk_finish_parity_kernel(const float* __restrict__ ws, int nsplit, int Mmax, int N,
@@ -1127,6 +1183,18 @@ int sg2im_conv2d_backward_data(const sg2im_conv_desc* d, const float* weight, in
   const long long Mfull = (long long)d->batch * d->in_h * d->in_w;
   if (Mfull == 0) return SG2IM_OK;
   const int taps = d->kh * d->kw;
+  if (c_count <= 4 && (size_t)taps * cout * c_count * sizeof(float) <= 48 * 1024) {
+    const size_t lds = (size_t)taps * cout * c_count * sizeof(float);
+    dim3 grid((unsigned)((Mfull + 255) / 256));
+#define SG2IM_FEWC(NC)                                                                                        \
+    hipLaunchKernelGGL((conv_dgrad_fewc_kernel<NC>), grid, dim3(256), lds, stream, dy, ld_dy, weight, cout,   \
+                       g.Ctot, c_begin, d->batch, d->in_h, d->in_w, d->out_h, d->out_w, d->kh, d->kw,        \
+                       d->stride, d->pad, dx, ld_dx, accumulate)
+    if (c_count == 1) SG2IM_FEWC(1); else if (c_count == 2) SG2IM_FEWC(2); else if (c_count == 3) SG2IM_FEWC(3);
+    else SG2IM_FEWC(4);
+#undef SG2IM_FEWC
+    return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+  }
   const bool va4 = (cout % 4 == 0) && (ld_dy % 4 == 0) && !((uintptr_t)dy & 15);
   const bool vb4 = (g.Ctot % 4 == 0) && (c_begin % 4 == 0) && (c_count % 4 == 0) && !((uintptr_t)weight & 15);
   // stride-2 parity decomposition: needs the chunked (VA=4) K enumeration; split-K partials of
