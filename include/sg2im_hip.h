@@ -138,11 +138,15 @@ int sg2im_layout_backward(const float* dlayout, long long ld_dlayout, const floa
 int sg2im_crop_forward(const float* imgs, long long ld_img, int n_images, int height, int width,
                        int channels, const float* boxes, const long long* obj_to_img, int n_objs,
                        int size, int align_corners, float* crops, hipStream_t stream);
-/* Transpose of the above as a gather per image pixel: every element of d_imgs [N][H][W] (row
- * stride ld_dimg) is written - zero where no crop touches it - in a fixed summation order. */
+/* Transpose of the above without atomics, in a fixed summation order: per-object partial planes
+ * (workspace: sg2im_crop_backward_workspace bytes) are summed per image pixel over the image's
+ * objects in ascending order.  Every element of d_imgs [N][H][W] (row stride ld_dimg) is
+ * written - zero where no crop touches it. */
+size_t sg2im_crop_backward_workspace(int n_objs, int height, int width, int channels);
 int sg2im_crop_backward(const float* d_crops, int n_images, int height, int width, int channels,
                         const float* boxes, const long long* obj_to_img, int n_objs, int size,
-                        int align_corners, float* d_imgs, long long ld_dimg, hipStream_t stream);
+                        int align_corners, float* d_imgs, long long ld_dimg, float* workspace,
+                        hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * BatchNorm2d (training statistics), pooling, layout-pyramid helpers

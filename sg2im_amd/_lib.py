@@ -47,7 +47,8 @@ _SIGNATURES = {
   'sg2im_layout_backward': [_P, _L, _P, _L, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P,
                             _P, _P],
   'sg2im_crop_forward': [_P, _L, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _P],
-  'sg2im_crop_backward': [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _L, _P],
+  'sg2im_crop_backward_workspace': [_I, _I, _I, _I],
+  'sg2im_crop_backward': [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _L, _P, _P],
   'sg2im_bn_stats': [_P, _L, _I, _L, _P, _P, _F, _F, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P],
   'sg2im_bn_act_backward': [_P, _L, _I, _I, _I, _I, _P, _L, _I, _P, _P, _P, _P, _P, _F, _I, _P, _P, _P, _I,
                             _P, _P],
@@ -71,7 +72,7 @@ _SIGNATURES = {
   'sg2im_adam_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
   'sg2im_adam_step_guarded': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P, _P],
 }
-_RESTYPE = {'sg2im_layout_backward_workspace': c_size_t}
+_RESTYPE = {'sg2im_layout_backward_workspace': c_size_t, 'sg2im_crop_backward_workspace': c_size_t}
 EXPORTS = tuple(sorted(_SIGNATURES))
 
 _lib = None

@@ -345,46 +345,137 @@ __device__ __forceinline__ void crop_axis_range(float b0, float b1, int p, int s
   const float B = size > 1 ? (Z - A) / (float)(size - 1) : 0.f;
   lo = 0; hi = size - 1;
   if (B > 1e-6f && B == B) {
-    const float l = floorf(((float)p - 1.f - A) / B) - 1.f, h = ceilf(((float)p + 1.f - A) / B) + 1.f;
+    // sample k sits at A + B k up to rounding of a few ulp (crop_axis forms it as a blend of the
+    // two box edges): a margin of 0.02 samples covers that without visiting dead samples
+    const float l = floorf(((float)p - 1.f - A) / B - 0.02f), h = ceilf(((float)p + 1.f - A) / B + 0.02f);
     lo = (int)fminf(fmaxf(l, 0.f), (float)size);          // lo == size: empty range
     hi = (int)fminf(fmaxf(h, -1.f), (float)(size - 1));
   }
 }
 
-__global__ void crop_bwd_gather_kernel(const float* __restrict__ dcrops, int H, int W, int C,
-                                       const float* __restrict__ boxes, const long long* __restrict__ obj_to_img,
-                                       int O, int size, int align_corners, float* __restrict__ dimgs, long long ld) {
-  const int n = blockIdx.y;
-  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pix >= H * W) return;
-  const int y = pix / W, x = pix - y * W;
-  float* dst = dimgs + ((long long)n * H * W + pix) * ld;
-  for (int c0 = 0; c0 < C; c0 += 4) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int o = 0; o < O; ++o) {
-      if (obj_to_img[o] != n) continue;                       // wave-uniform
-      const float* box = boxes + 4LL * o;
-      int jl, jh, il, ih;
-      crop_axis_range(box[0], box[2], x, size, W, align_corners, jl, jh);
-      crop_axis_range(box[1], box[3], y, size, H, align_corners, il, ih);
+// Two passes, both free of atomics and with a fixed summation order:
+//  1. one workgroup per OBJECT: its threads own the pixels of the object's footprint rectangle
+//     and sum the crop samples (i, j ascending) that touch them - all threads of a workgroup
+//     walk sample ranges of the same size (a per-pixel gather over all objects diverges badly:
+//     a pixel inside a tiny box visits ~500 samples, its neighbours none) - into a per-object
+//     image-sized plane of the workspace (only the rectangle is written);
+//  2. one thread per image pixel adds the planes of the image's objects in ascending order.
+constexpr int CB_MAXSIZE = 64;
+
+struct CropRect { int x0, x1, y0, y1; };     // inclusive pixel rectangle touched by the crop
+
+__device__ __forceinline__ CropRect crop_rect(const float* box, int size, int H, int W, int align_corners) {
+  // sample positions are monotone in the sample index: the extreme samples bound the footprint
+  const CropAxis xa = crop_axis(box[0], box[2], 0, size, W, align_corners);
+  const CropAxis xb = crop_axis(box[0], box[2], size - 1, size, W, align_corners);
+  const CropAxis ya = crop_axis(box[1], box[3], 0, size, H, align_corners);
+  const CropAxis yb = crop_axis(box[1], box[3], size - 1, size, H, align_corners);
+  CropRect r;
+  r.x0 = max(0, min(xa.p0, xb.p0)); r.x1 = min(W - 1, max(xa.p0, xb.p0) + 1);
+  r.y0 = max(0, min(ya.p0, yb.p0)); r.y1 = min(H - 1, max(ya.p0, yb.p0) + 1);
+  return r;
+}
+
+__global__ void crop_bwd_object_kernel(const float* __restrict__ dcrops, int H, int W, int C,
+                                       const float* __restrict__ boxes, int size, int align_corners,
+                                       float* __restrict__ planes) {
+  __shared__ int s_p0[2][CB_MAXSIZE];
+  __shared__ float s_t[2][CB_MAXSIZE];
+  const int o = blockIdx.x, tid = threadIdx.x;
+  const float* box = boxes + 4LL * o;
+  for (int k = tid; k < 2 * size; k += blockDim.x) {
+    const int smp = k % size, ax = k / size;
+    const CropAxis r = ax == 0 ? crop_axis(box[0], box[2], smp, size, W, align_corners)
+                               : crop_axis(box[1], box[3], smp, size, H, align_corners);
+    s_p0[ax][smp] = r.p0; s_t[ax][smp] = r.t;
+  }
+  __syncthreads();
+  const CropRect R = crop_rect(box, size, H, W, align_corners);
+  const int rw = R.x1 - R.x0 + 1, rh = R.y1 - R.y0 + 1;
+  if (rw <= 0 || rh <= 0) return;
+  const float* gobj = dcrops + (long long)o * size * size * C;
+  float* plane = planes + (long long)o * H * W * C;
+  for (int q = tid; q < rw * rh; q += blockDim.x) {
+    const int y = R.y0 + q / rw, x = R.x0 + q % rw;
+    int jl, jh, il, ih;
+    crop_axis_range(box[0], box[2], x, size, W, align_corners, jl, jh);
+    crop_axis_range(box[1], box[3], y, size, H, align_corners, il, ih);
+    for (int c0 = 0; c0 < C; c0 += 4) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
       for (int i = il; i <= ih; ++i) {
-        const float wy = crop_axis_weight(crop_axis(box[1], box[3], i, size, H, align_corners), y);
+        const int py = s_p0[1][i];
+        const float ty = s_t[1][i];
+        const float wy = py == y ? 1.f - ty : (py + 1 == y ? ty : 0.f);
         if (wy == 0.f) continue;
         for (int j = jl; j <= jh; ++j) {
-          const float wx = crop_axis_weight(crop_axis(box[0], box[2], j, size, W, align_corners), x);
+          const int px = s_p0[0][j];
+          const float tx = s_t[0][j];
+          const float wx = px == x ? 1.f - tx : (px + 1 == x ? tx : 0.f);
           if (wx == 0.f) continue;
-          // crop_foot forms the weights as (x factor) * (y factor)
-          const float w = wx * wy;
-          const float* gsrc = dcrops + (((long long)o * size + i) * size + j) * C + c0;
-          #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            if (c0 + c < C) acc[c] += gsrc[c] * w;
+          const float w = wx * wy;                         // crop_foot: (x factor) * (y factor)
+          const float* gsrc = gobj + ((long long)i * size + j) * C + c0;
+          a0 += gsrc[0] * w;
+          if (c0 + 1 < C) a1 += gsrc[1] * w;
+          if (c0 + 2 < C) a2 += gsrc[2] * w;
+          if (c0 + 3 < C) a3 += gsrc[3] * w;
         }
       }
+      float* dst = plane + ((long long)y * W + x) * C + c0;
+      dst[0] = a0;
+      if (c0 + 1 < C) dst[1] = a1;
+      if (c0 + 2 < C) dst[2] = a2;
+      if (c0 + 3 < C) dst[3] = a3;
     }
+  }
+}
+
+__global__ void crop_bwd_sum_kernel(const float* __restrict__ planes, int H, int W, int C,
+                                    const float* __restrict__ boxes, const long long* __restrict__ obj_to_img,
+                                    int O, int size, int align_corners, float* __restrict__ dimgs, long long ld) {
+  __shared__ int s_obj[256];
+  __shared__ CropRect s_rect[256];
+  __shared__ unsigned char s_flag[256];
+  __shared__ int s_cnt;
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const int pix = blockIdx.x * blockDim.x + tid;
+  const bool live = pix < H * W;
+  const int y = live ? pix / W : 0, x = live ? pix - y * W : 0;
+  float acc[8];
+  for (int c0 = 0; c0 < C; c0 += 8) {
     #pragma unroll
-    for (int c = 0; c < 4; ++c)
-      if (c0 + c < C) dst[c0 + c] = acc[c];
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    for (int start = 0; start < O; start += 256) {
+      // membership of the next 256 objects in parallel, compacted in ascending order from LDS
+      s_flag[tid] = (start + tid < O && obj_to_img[start + tid] == n) ? 1 : 0;
+      __syncthreads();
+      if (tid == 0) {
+        int cnt = 0;
+        for (int k = 0; k < min(256, O - start); ++k)
+          if (s_flag[k]) s_obj[cnt++] = start + k;
+        s_cnt = cnt;
+      }
+      __syncthreads();
+      const int cnt = s_cnt;
+      if (tid < cnt) s_rect[tid] = crop_rect(boxes + 4LL * s_obj[tid], size, H, W, align_corners);
+      __syncthreads();
+      if (live) {
+        for (int q = 0; q < cnt; ++q) {
+          const CropRect R = s_rect[q];
+          if (x < R.x0 || x > R.x1 || y < R.y0 || y > R.y1) continue;
+          const float* src = planes + (((long long)s_obj[q] * H + y) * W + x) * C + c0;
+          #pragma unroll
+          for (int c = 0; c < 8; ++c)
+            if (c0 + c < C) acc[c] += src[c];
+        }
+      }
+      __syncthreads();
+    }
+    if (live) {
+      float* dst = dimgs + ((long long)n * H * W + pix) * ld + c0;
+      #pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c0 + c < C) dst[c] = acc[c];
+    }
   }
 }
 
@@ -464,14 +555,24 @@ int sg2im_crop_forward(const float* imgs, long long ld_img, int n_images, int he
   return ok_or(hipGetLastError());
 }
 
+size_t sg2im_crop_backward_workspace(int n_objs, int height, int width, int channels) {
+  return sizeof(float) * (size_t)n_objs * (size_t)height * (size_t)width * (size_t)channels;
+}
+
 int sg2im_crop_backward(const float* d_crops, int n_images, int height, int width, int channels,
                         const float* boxes, const long long* obj_to_img, int n_objs, int size,
-                        int align_corners, float* d_imgs, long long ld_dimg, hipStream_t stream) {
-  if ((n_objs > 0 && (!d_crops || !boxes || !obj_to_img)) || !d_imgs || size < 1 || channels < 1) return SG2IM_ERR_ARG;
+                        int align_corners, float* d_imgs, long long ld_dimg, float* workspace,
+                        hipStream_t stream) {
+  if ((n_objs > 0 && (!d_crops || !boxes || !obj_to_img || !workspace)) || !d_imgs || size < 1 || size > CB_MAXSIZE ||
+      channels < 1)
+    return SG2IM_ERR_ARG;
   if (n_images < 1 || height < 1 || width < 1) return SG2IM_OK;
+  if (n_objs > 0)
+    hipLaunchKernelGGL(crop_bwd_object_kernel, dim3(n_objs), dim3(256), 0, stream, d_crops, height, width, channels,
+                       boxes, size, align_corners, workspace);
   // every pixel of d_imgs is WRITTEN (zero where no crop touches it): no pre-zeroing needed
   dim3 grid((height * width + 255) / 256, n_images);
-  hipLaunchKernelGGL(crop_bwd_gather_kernel, grid, dim3(256), 0, stream, d_crops, height, width, channels, boxes,
+  hipLaunchKernelGGL(crop_bwd_sum_kernel, grid, dim3(256), 0, stream, workspace, height, width, channels, boxes,
                      obj_to_img, n_objs, size, align_corners, d_imgs, ld_dimg);
   return ok_or(hipGetLastError());
 }

@@ -294,8 +294,10 @@ def crop_forward(imgs_nhwc, boxes, obj_to_img, size, align_corners, out):
 
 def crop_backward(d_crops, boxes, obj_to_img, size, align_corners, d_imgs_nhwc):
   N, H, W, C = d_imgs_nhwc.shape
-  call('sg2im_crop_backward', _f(d_crops), N, H, W, C, _f(boxes), _i64(obj_to_img), boxes.size(0), int(size),
-       int(align_corners), _f(d_imgs_nhwc), C, _stream())
+  O = boxes.size(0)
+  ws = scratch(d_crops.device, max(1, O * H * W * C))        # per-object partial planes
+  call('sg2im_crop_backward', _f(d_crops), N, H, W, C, _f(boxes), _i64(obj_to_img), O, int(size),
+       int(align_corners), _f(d_imgs_nhwc), C, _f(ws), _stream())
   return d_imgs_nhwc
 
 
