@@ -21,6 +21,10 @@
 
 namespace sg2im {
 
+#ifndef SG2IM_TAP_INNER
+#define SG2IM_TAP_INNER 0   // (1 measured: 940 -> fewer MB fetched, but no faster - slower on the two-source layers)
+#endif
+
 
 struct FwdParams {
   ConvGeom g;
@@ -209,9 +213,20 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
   int q_tap = 0, q_kh = 0, q_kw = 0, q_s = 0, q_cstart = 0, q_cb = 0;
   static_assert(offsetof(FwdParams, g) == 0 && offsetof(ConvGeom, s0) == 0, "kernarg_src layout");
   Src q_S = kernarg_src(0);
+  const int taps_total = g.KH * g.KW;
   if (VEC == 4 && it_begin < it_end) {
+#if SG2IM_TAP_INNER
+    // reduction order: (source, channel chunk) outer, tap INNER - the KH*KW taps re-read the same
+    // pixels of one 32-channel slab back to back, so the re-reads hit L1/L2 instead of going
+    // out to the Infinity Cache (tap-outer order: 940 MB fetched per launch of m4.conv0 for
+    // 151 MB of input, the per-XCD working set of a full tap sweep is ~20 MB against a 4 MB L2)
+    const int q = it_begin / taps_total;
+    q_tap = it_begin - q * taps_total;
+    locate_chunk(g, q, q_s, q_cstart, q_cb);
+#else
     q_tap = it_begin / p.nch;
     locate_chunk(g, it_begin - q_tap * p.nch, q_s, q_cstart, q_cb);
+#endif
     q_S = kernarg_src(q_s);
     q_kh = q_tap / g.KW; q_kw = q_tap - q_kh * g.KW;
   }
@@ -227,6 +242,18 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
         // every chunk) so that the loop body stays one basic block.  The last chunk is
         // re-issued instead of advancing past the end.
         const bool adv = it + 1 < it_end;
+#if SG2IM_TAP_INNER
+        const bool wrap_w = adv && q_kw + 1 == g.KW;             // next kernel row
+        const bool wrap_t = wrap_w && q_kh + 1 == g.KH;          // all taps done: next channel chunk
+        const int ncb = q_cb + BK;
+        const bool wrap_s = wrap_t && ncb >= q_S.C;              // next source
+        q_kw = wrap_w ? 0 : (adv ? q_kw + 1 : q_kw);
+        q_kh = wrap_t ? 0 : (wrap_w ? q_kh + 1 : q_kh);
+        q_tap = wrap_t ? 0 : (adv ? q_tap + 1 : q_tap);
+        q_cb = wrap_s ? 0 : (wrap_t ? ncb : q_cb);
+        q_cstart += wrap_s ? q_S.C : 0;
+        q_s += wrap_s ? 1 : 0;
+#else
         const int ncb = q_cb + BK;
         const bool wrap_s = adv && ncb >= q_S.C;                 // next source
         const bool wrap_t = wrap_s && q_s + 1 == g.nsrc;         // next tap
@@ -237,6 +264,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
         q_tap += wrap_t ? 1 : 0;
         q_kw = wrap_w ? 0 : (wrap_t ? q_kw + 1 : q_kw);
         q_kh += wrap_w ? 1 : 0;
+#endif
         q_S = kernarg_src(q_s);
       }
       const int c = cb + 4 * col4;
