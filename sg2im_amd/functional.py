@@ -327,6 +327,8 @@ class LayoutFn(Function):
 
   @staticmethod
   def backward(ctx, g):
+    if ops.TAIL_EVENT is not None and ops.TAIL_EVENT_AT < 0:   # Trainer: the refinement network is done
+      ops.TAIL_EVENT.record()
     vecs, boxes, masks, obj_to_img = ctx.saved_tensors
     n_images, H, W, ac = ctx.geom
     ni = ctx.needs_input_grad
@@ -516,6 +518,8 @@ class RefinementFn(Function):
     Cg = Cl if grad_channels is None else min(int(grad_channels), Cl)
     dlevels = []
     for i in range(L - 1, -1, -1):
+      if ops.TAIL_EVENT is not None and i == ops.TAIL_EVENT_AT:
+        ops.TAIL_EVENT.record()          # Trainer: from this module on the kernels are small
       lay, feat_src, y0, st0, y1, st1, h, w, C = saved[i]
       W0p, b0, W1p, b1 = convp[4 * i:4 * i + 4]
       g0, be0, g1, be1 = bnp[4 * i:4 * i + 4]

@@ -54,6 +54,8 @@ def _i32(t):
   return c_void_p(t.data_ptr())
 
 
+TAIL_EVENT = None   # optional torch.cuda.Event recorded when the generator backward reaches ...
+TAIL_EVENT_AT = -1  # ... refinement module TAIL_EVENT_AT (counting down), or the layout (-1)
 LANE = 0       # execution lane of the caller: work captured on a side stream (Trainer's
                # overlapped discriminator steps) sets LANE = 1 and gets its own split-K
                # workspace / reduction scratch, so concurrently running lanes never share them

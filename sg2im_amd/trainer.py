@@ -322,18 +322,39 @@ class Trainer(object):
       main = torch.cuda.current_stream()
       self._seg_generator_forward(static, st)
       lanes = ((1, self.d_obj, self._seg_d_obj), (2, self.d_img, self._seg_d_img))
-      for lane, net, seg in lanes:
+      import os
+      split_tail = os.environ.get('SG2IM_TAIL_SPLIT', '2') != '0' and self.d_obj is not None and self.d_img is not None
+      if os.environ.get('SG2IM_TAIL_SPLIT', '2') == '2':   # measured best: D_img first, D_obj at the tail
+        lanes = (lanes[1], lanes[0])
+
+      def run_lane(lane, net, seg, wait_ev=None):
         if net is None:
-          continue
+          return
         side = self._side[(lane - 1) % self._n_side]
-        side.wait_stream(main)
+        if wait_ev is not None:
+          side.wait_event(wait_ev)
+        else:
+          side.wait_stream(main)
         with torch.cuda.stream(side):
           ops.LANE = lane
           try:
             seg(static, st)
           finally:
             ops.LANE = 0
-      self._seg_generator_backward(st)
+      run_lane(*lanes[0])
+      if split_tail:
+        # D_img waits until the generator backward has left the refinement network: it then
+        # runs next to the small layout / graph-convolution backward kernels at the tail
+        ops.TAIL_EVENT = torch.cuda.Event()
+        ops.TAIL_EVENT_AT = int(os.environ.get('SG2IM_TAIL_AT', '-1'))
+        try:
+          self._seg_generator_backward(st)
+        finally:
+          ev, ops.TAIL_EVENT = ops.TAIL_EVENT, None
+        run_lane(*lanes[1], wait_ev=ev)
+      else:
+        run_lane(*lanes[1])
+        self._seg_generator_backward(st)
       for lane, net, seg in lanes:
         if net is not None:
           main.wait_stream(self._side[(lane - 1) % self._n_side])
