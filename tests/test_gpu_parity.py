@@ -426,3 +426,27 @@ def test_forward_json_inference_path_matches_oracle():
   for name, a, b in (('img', img, want[0]), ('boxes', boxes, want[1]), ('masks', masks, want[2]), ('rel', rel, want[3])):
     assert a.shape == b.shape, name
     assert max_rel_err(a.cpu(), b) <= 1e-4, (name, max_rel_err(a.cpu(), b))
+
+
+def test_graph_iteration_vg_style_and_aux_losses_match_eager():
+  """The one-graph iteration (side-stream discriminator steps) on a VG-style batch - predicted
+  masks feed the layout, so mask_net trains - with the auxiliary losses on, against the plain
+  eager launches.  (The mask gradient accumulates through LDS float atomics inside one
+  workgroup, so this case is compared with a tolerance instead of bit for bit.)"""
+  from sg2im_amd.synthetic import make_vocab, synthetic_batch
+  from sg2im_amd.trainer import Trainer
+  from tests import hip_harness as hh
+  dev = hh.dev()
+  vocab = make_vocab(179, 46)
+  cpu = synthetic_batch(4, num_objs=179, num_preds=46, style='vg', min_objs=3, max_objs=10, seed=19)
+  batch = tuple(t.to(dev) if torch.is_tensor(t) else t for t in cpu)
+  kw = dict(generator_kwargs={'layout_noise_dim': 0}, seed=3,
+            loss_weights=dict(predicate_pred_loss_weight=0.2, mask_loss_weight=0.0))
+  runs = []
+  for use_graphs in (False, True):
+    tr = Trainer(vocab, dev, use_graphs=use_graphs, **kw)
+    runs.append([Trainer.losses_to_host(tr.step(batch)) for _ in range(5)])
+  for a, b in zip(*runs):
+    assert set(a) == set(b)
+    for k in a:
+      assert abs(a[k] - b[k]) <= 2e-3 * max(1.0, abs(a[k])), (k, a[k], b[k])
