@@ -147,6 +147,10 @@ class Trainer(object):
     st.pop('total').backward()
 
   def _seg_d_obj(self, batch, st):
+    self._seg_d_obj_forward(batch, st)
+    self._seg_d_obj_backward(batch, st)
+
+  def _seg_d_obj_forward(self, batch, st):
     imgs, objs, boxes, masks, triples, obj_to_img = batch[:6]
     losses = st['losses']
     # train.py:566-579
@@ -154,9 +158,11 @@ class Trainer(object):
     sr, ac_real = self.d_obj.forward_nhwc(st['imgs_nhwc'], objs, boxes, obj_to_img)
     losses['d_obj_gan_loss'] = self.gan_d_loss(sr, sf)
     losses['d_ac_loss_real'], losses['d_ac_loss_fake'] = ac_real, ac_fake
-    d_obj_total = losses['d_obj_gan_loss'] + ac_real + ac_fake
+    st['d_obj_total'] = losses['d_obj_gan_loss'] + ac_real + ac_fake
+
+  def _seg_d_obj_backward(self, batch, st):
     self.opt_do.zero_grad()
-    d_obj_total.backward()
+    st.pop('d_obj_total').backward()
 
   def _seg_d_img(self, batch, st):
     losses = st['losses']
@@ -309,28 +315,22 @@ class Trainer(object):
 
   def _capture_overlapped(self, key, static, st):
     """One graph for the whole iteration (single GPU): generator forward, then a fork - the
-    generator's backward on the capture stream, each discriminator step on its own side stream
-    (own split-K workspace / scratch: ops.LANE) - joined before the three Adam updates."""
+    generator's backward on the capture stream, the discriminator steps on a side stream (own
+    split-K workspace / scratch: ops.LANE) - joined before the three Adam updates."""
     from . import ops
     if self._side is None:
       import os
-      self._n_side = int(os.environ.get('SG2IM_SIDE_STREAMS', '1'))   # (2 measured slower: 11.1 vs 10.65 ms)
-      self._side = tuple(torch.cuda.Stream() for _ in range(self._n_side))
+      self._n_side = 1               # (a second side stream for D_img measured slower: 11.1 vs 10.65 ms)
+      self._side = (torch.cuda.Stream(),)
     g = torch.cuda.CUDAGraph()
     torch.cuda.synchronize()
     with torch.cuda.graph(g):
       main = torch.cuda.current_stream()
       self._seg_generator_forward(static, st)
-      lanes = ((1, self.d_obj, self._seg_d_obj), (2, self.d_img, self._seg_d_img))
       import os
-      split_tail = os.environ.get('SG2IM_TAIL_SPLIT', '2') != '0' and self.d_obj is not None and self.d_img is not None
-      if os.environ.get('SG2IM_TAIL_SPLIT', '2') == '2':   # measured best: D_img first, D_obj at the tail
-        lanes = (lanes[1], lanes[0])
+      side = self._side[0]
 
-      def run_lane(lane, net, seg, wait_ev=None):
-        if net is None:
-          return
-        side = self._side[(lane - 1) % self._n_side]
+      def on_side(lane, seg, wait_ev=None):
         if wait_ev is not None:
           side.wait_event(wait_ev)
         else:
@@ -341,23 +341,34 @@ class Trainer(object):
             seg(static, st)
           finally:
             ops.LANE = 0
-      run_lane(*lanes[0])
-      if split_tail:
-        # D_img waits until the generator backward has left the refinement network: it then
-        # runs next to the small layout / graph-convolution backward kernels at the tail
-        ops.TAIL_EVENT = torch.cuda.Event()
-        ops.TAIL_EVENT_AT = int(os.environ.get('SG2IM_TAIL_AT', '-1'))
-        try:
-          self._seg_generator_backward(st)
-        finally:
-          ev, ops.TAIL_EVENT = ops.TAIL_EVENT, None
-        run_lane(*lanes[1], wait_ev=ev)
-      else:
-        run_lane(*lanes[1])
+      # Schedule (measured; SG2IM_SCHEDULE selects the variants that were
+      # compared): right after the generator forward the side stream runs the D_img step next to the
+      # refinement network's backward; the D_obj step is held back until the generator backward
+      # reaches the layout, where it runs next to the small layout / graph-convolution backward
+      # kernels.  0: both steps at once, 10.65 ms; 1: D_obj first / D_img at the tail, 10.39;
+      # 2: this one, 10.33; 3: as 2 but the D_obj forward passes early, 10.42.
+      mode = os.environ.get('SG2IM_SCHEDULE', '2')
+      if self.d_img is not None and mode != '1':
+        on_side(2, self._seg_d_img)
+      if self.d_obj is not None:
+        if mode == '3':
+          on_side(1, self._seg_d_obj_forward)
+        elif mode == '0':
+          on_side(1, self._seg_d_obj)
+      if self.d_img is not None and mode == '1':
+        on_side(2, self._seg_d_img)
+      ops.TAIL_EVENT = torch.cuda.Event()
+      ops.TAIL_EVENT_AT = -1
+      try:
         self._seg_generator_backward(st)
-      for lane, net, seg in lanes:
-        if net is not None:
-          main.wait_stream(self._side[(lane - 1) % self._n_side])
+      finally:
+        ev, ops.TAIL_EVENT = ops.TAIL_EVENT, None
+      if self.d_obj is not None:
+        if mode == '3':
+          on_side(1, self._seg_d_obj_backward, wait_ev=ev)
+        elif mode in ('1', '2'):
+          on_side(1, self._seg_d_obj, wait_ev=ev)
+      main.wait_stream(side)
       self._seg_adam(st)
     self._graphs[key] = (static, {'all': g}, st, _lib.EAGER_EPOCH)
     g.replay()
