@@ -44,6 +44,7 @@ def parse():
   ap.add_argument('--no_roofline', action='store_true')
   ap.add_argument('--no_graphs', action='store_true', help='launch every kernel eagerly instead of hipGraph replay')
   ap.add_argument('--seed', type=int, default=0)
+  ap.add_argument('--dist_graphs', action='store_true', help='debug: hipGraph segments with collectives in between')
   ap.add_argument('--force_dist', action='store_true',
                   help='debug: 1-rank RCCL group with real all-reduces (exercises the N>1 code path on one GPU)')
   return ap.parse_args()
@@ -98,7 +99,7 @@ def main():
                               max_objs=8, mask_size=16, style='coco', seed=args.seed + rank)
   batch = tuple(t.to(device) if torch.is_tensor(t) else t for t in cpu_batch)
   trainer = Trainer(vocab, device, generator_kwargs={'image_size': (S, S)}, world_size=world, seed=1234,
-                    use_graphs=(not use_dist and not args.no_graphs))
+                    use_graphs=((not use_dist or args.dist_graphs) and not args.no_graphs))
   # (RCCL collectives between hipGraph replays hang on ROCm 7.2 - measured with --force_dist - so
   # every data-parallel run launches eagerly; the eager step is GPU-bound, ~1 % slower)
   if args.force_dist:

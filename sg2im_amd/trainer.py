@@ -19,6 +19,7 @@ import torch.distributed as dist
 from . import _lib
 from . import functional as HF
 from . import losses as L
+from . import ops
 from .discriminators import AcCropDiscriminator, PatchDiscriminator
 from .distributed import GradReducer
 from .model import Sg2ImModel
@@ -35,6 +36,11 @@ D_IMG_DEFAULTS = dict(arch='C4-64-2,C4-128-2,C4-256-2', normalization='batch', a
 LOSS_WEIGHTS = dict(l1_pixel_loss_weight=1.0, bbox_pred_loss_weight=10.0, predicate_pred_loss_weight=0.0,
                     mask_loss_weight=0.0, discriminator_loss_weight=0.01, d_obj_weight=1.0, d_img_weight=1.0,
                     ac_loss_weight=0.1)                          # train.py:108-131
+
+
+# 'thread_local': other threads (the RCCL watchdog polls events) may call into HIP while this
+# thread captures; the default 'global' mode treats that as a capture error
+_CAPTURE_MODE = 'thread_local'
 
 
 def _set_requires_grad(module, flag):
@@ -189,17 +195,44 @@ class Trainer(object):
     The 112 MB generator all-reduce is only waited for after both discriminator passes
     (they never read G's parameters), see sg2im_amd/distributed.py."""
     red = self.reducer
-    run('g', lambda: self._seg_generator(batch, st))
-    red.start(self.flat_g.grad)
-    red.start(st['guard'])
+    if self.use_graphs and self.overlap_d and self.d_img is not None:
+      # graph segments of the data-parallel step: the D_img step runs on the side stream INSIDE
+      # the generator segment (next to the generator backward), the D_obj step is its own segment
+      # and executes while the generator's all-reduce is in flight
+      run('g+di', lambda: self._seg_generator_with_d_img(batch, st))
+      red.start(self.flat_g.grad)
+      red.start(st['guard'])
+      red.start(self.flat_di.grad)
+    else:
+      run('g', lambda: self._seg_generator(batch, st))
+      red.start(self.flat_g.grad)
+      red.start(st['guard'])
+      if self.d_img is not None:
+        run('di', lambda: self._seg_d_img(batch, st))
+        red.start(self.flat_di.grad)
     if self.d_obj is not None:
       run('do', lambda: self._seg_d_obj(batch, st))
       red.start(self.flat_do.grad)
-    if self.d_img is not None:
-      run('di', lambda: self._seg_d_img(batch, st))
-      red.start(self.flat_di.grad)
     red.finish()
     run('adam', lambda: self._seg_adam(st))
+
+  def _seg_generator_with_d_img(self, batch, st):
+    """generator forward, then fork: generator backward on the current stream, the D_img step on
+    the side stream (own workspace lane), joined at the end"""
+    if self._side is None:
+      self._n_side = 1
+      self._side = (torch.cuda.Stream(),)
+    side, main = self._side[0], torch.cuda.current_stream()
+    self._seg_generator_forward(batch, st)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+      ops.LANE = 2
+      try:
+        self._seg_d_img(batch, st)
+      finally:
+        ops.LANE = 0
+    self._seg_generator_backward(st)
+    main.wait_stream(side)
 
   def _run_overlapped_eager(self, batch, st):
     """Eager form of the overlap: the generator's backward is enqueued on the current stream
@@ -280,12 +313,13 @@ class Trainer(object):
       st = {'losses': {}}
       graphs = {}
       pool = [None]
-      if self.overlap_d and self.world_size == 1:
+      import os
+      if self.overlap_d and self.world_size == 1 and not self.reducer.force and os.environ.get('SG2IM_DP_SCHEDULE', '0') != '1':
         return self._capture_overlapped(key, static, st)
 
       def capture(name, fn):
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=pool[0]):
+        with torch.cuda.graph(g, pool=pool[0], capture_error_mode=_CAPTURE_MODE):
           fn()
         if pool[0] is None:
           pool[0] = g.pool()
@@ -324,7 +358,7 @@ class Trainer(object):
       self._side = (torch.cuda.Stream(),)
     g = torch.cuda.CUDAGraph()
     torch.cuda.synchronize()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
       main = torch.cuda.current_stream()
       self._seg_generator_forward(static, st)
       import os
