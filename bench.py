@@ -100,8 +100,9 @@ def main():
   batch = tuple(t.to(device) if torch.is_tensor(t) else t for t in cpu_batch)
   trainer = Trainer(vocab, device, generator_kwargs={'image_size': (S, S)}, world_size=world, seed=1234,
                     use_graphs=((not use_dist or args.dist_graphs) and not args.no_graphs))
-  # (RCCL collectives between hipGraph replays hang on ROCm 7.2 - measured with --force_dist - so
-  # every data-parallel run launches eagerly; the eager step is GPU-bound, ~1 % slower)
+  # (data-parallel runs launch eagerly by default: the graph schedule of the DP step, --dist_graphs,
+  # works in a 1-rank RCCL group but could not be exercised on several GPUs - see DESIGN.md section 6)
+  trainer_graphs = trainer.use_graphs
   if args.force_dist:
     trainer.reducer.force = True
 
@@ -178,7 +179,8 @@ def main():
                  'global_batch': args.batch_size * world, 'image_size': S,
                  'objects': int(batch[1].numel()), 'triples': int(batch[4].size(0)),
                  'parallelism': 'dp%d' % world, 'total_loss': round(host_losses['total_loss'], 5),
-                 'launch': 'hipGraph replay (4 segments)' if (not use_dist and not args.no_graphs) else 'eager'},
+                 'launch': ('eager' if not trainer_graphs else 'hipGraph replay (one graph, D steps on a side stream)' if not use_dist
+                            else 'hipGraph replay (DP segments)')},
       'roofline': roofline, 'cpu_baseline': cpu,
     }
   if use_dist:
