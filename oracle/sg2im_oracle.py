@@ -214,8 +214,9 @@ def crop_bbox_batch(feats, bbox, bbox_to_feats, HH, WW=None, align_corners=False
 # generator (sg2im/model.py, sg2im/crn.py)
 # ----------------------------------------------------------------------------
 
-def refinement_network(P, prefix, layout, n_modules, slope, training):
-  """sg2im/crn.py:88-111 (+ RefinementModule.forward crn.py:53-65), 'batch' norm."""
+def refinement_network(P, prefix, layout, n_modules, slope, training, normalization='batch'):
+  """sg2im/crn.py:88-111 (+ RefinementModule.forward crn.py:53-65); normalization 'batch' or
+  'none' (crn.py:41-47 then drops the norm layers, so the second conv is net.2 instead of net.3)."""
   N, _, H, W = layout.size()
   h, w = H, W
   for _ in range(n_modules):
@@ -233,6 +234,10 @@ def refinement_network(P, prefix, layout, n_modules, slope, training):
     x = torch.cat([lay, feats], dim=1)
     p = '%s.refinement_modules.%d.net' % (prefix, i)
     x = F.conv2d(x, P[p + '.0.weight'], P[p + '.0.bias'], padding=1)
+    if normalization == 'none':
+      x = F.leaky_relu(x, slope)
+      feats = F.leaky_relu(F.conv2d(x, P[p + '.2.weight'], P[p + '.2.bias'], padding=1), slope)
+      continue
     x = F.leaky_relu(batch_norm(P, p + '.1', x, training), slope)
     x = F.conv2d(x, P[p + '.3.weight'], P[p + '.3.bias'], padding=1)
     feats = F.leaky_relu(batch_norm(P, p + '.4', x, training), slope)
@@ -309,9 +314,10 @@ def generator_forward(P, cfg, objs, triples, obj_to_img=None, boxes_gt=None,
     layout = torch.cat([layout, noise], dim=1)
   n_modules = len(cfg.get('refinement_dims', (1024, 512, 256, 128, 64)))
   slope = activation_slope(cfg.get('activation', 'leakyrelu-0.2'))
-  if cfg.get('normalization', 'batch') != 'batch':
-    raise NotImplementedError('oracle restates the default normalization only')
-  img = refinement_network(P, 'refinement_net', layout, n_modules, slope, training)
+  norm = cfg.get('normalization', 'batch')
+  if norm not in ('batch', 'none'):
+    raise NotImplementedError('oracle restates the batch / none normalizations only')
+  img = refinement_network(P, 'refinement_net', layout, n_modules, slope, training, norm)
   return img, boxes_pred, masks_pred, rel_scores
 
 
@@ -606,6 +612,9 @@ def init_generator_params(cfg, seed=0, randomize_bn=False):
     cin = 1 if i == 1 else dims[i - 1]
     p = 'refinement_net.refinement_modules.%d.net' % (i - 1)
     _conv(P, p + '.0', dims[i], dims[0] + cin, 3, g, True)
+    if cfg.get('normalization', 'batch') == 'none':
+      _conv(P, p + '.2', dims[i], dims[i], 3, g, True)
+      continue
     _bn(P, p + '.1', dims[i], g, randomize_bn)
     _conv(P, p + '.3', dims[i], dims[i], 3, g, True)
     _bn(P, p + '.4', dims[i], g, randomize_bn)

@@ -559,6 +559,111 @@ class RefinementFn(Function):
     return (dlayout, None, None, None, None) + tuple(grads)
 
 
+class RefinementNoNormFn(Function):
+  """RefinementNetwork with normalization='none' (reference sg2im/crn.py:41-47 drops the norm
+  layers): conv3x3 + LeakyReLU fused in the conv epilogue, twice per module.
+  params (flat): per module [W0, b0, W1, b1] ..., then [Wo0, bo0, Wo2, bo2]."""
+
+  @staticmethod
+  def forward(ctx, layout, n_modules, slope, grad_channels, *params):
+    ops.TIMER_TAG = 'crn'
+    try:
+      L = n_modules
+      N, H, W, Cl = layout.shape
+      h0, w0 = H >> L, W >> L
+      if h0 == 0 or w0 == 0:
+        raise AssertionError('too many refinement modules for this image size')     # crn.py:103-104
+      layout = layout.contiguous()
+      feats = torch.zeros(N, h0, w0, 1, dtype=torch.float32, device=layout.device)   # crn.py:105
+      feat_src = nhwc_src(feats, up=1)
+      pyr = [layout]
+      for i in range(1, L):
+        pyr.append(ops.avgpool_forward(pyr[-1], 2, _new(layout, N, H >> i, W >> i, Cl)))
+      pyr = pyr[::-1]
+      saved = []
+      for i in range(L):
+        h, w = H >> (L - 1 - i), W >> (L - 1 - i)
+        W0p, b0, W1p, b1 = params[4 * i:4 * i + 4]
+        C = W0p.size(0)
+        d0 = conv_desc([nhwc_src(pyr[i]), feat_src], N, h, w, 3, 3, 1, 1)
+        a0 = ops.conv2d_forward(d0, _cl_weight(W0p), C, b0, _new(layout, N, h, w, C), C, slope)
+        d1 = conv_desc([nhwc_src(a0)], N, h, w, 3, 3, 1, 1)
+        a1 = ops.conv2d_forward(d1, _cl_weight(W1p), C, b1, _new(layout, N, h, w, C), C, slope)
+        saved.append((pyr[i], feat_src, a0, a1, h, w, C))
+        feat_src = nhwc_src(a1, 1)
+      Wo0, bo0, Wo2, bo2 = params[4 * L:4 * L + 4]
+      Cf = saved[-1][6]
+      do0 = conv_desc([nhwc_src(saved[-1][3])], N, H, W, 3, 3, 1, 1)
+      z = ops.conv2d_forward(do0, _cl_weight(Wo0), Wo0.size(0), bo0, _new(layout, N, H, W, Wo0.size(0)),
+                             Wo0.size(0), slope)
+      do2 = conv_desc([nhwc_src(z)], N, H, W, 1, 1, 1, 0)
+      img = ops.conv2d_forward(do2, _cl_weight(Wo2), Wo2.size(0), bo2, _new(layout, N, H, W, Wo2.size(0)),
+                               Wo2.size(0))
+      ctx.saved = saved
+      ctx.misc = (L, slope, z, do0, do2, Cl, Cf, grad_channels, (N, H, W))
+      ctx.save_for_backward(*params)
+      return img
+    finally:
+      ops.TIMER_TAG = None
+
+  @staticmethod
+  def backward(ctx, g):
+    ops.TIMER_TAG = 'crn'
+    try:
+      params = ctx.saved_tensors
+      L, slope, z, do0, do2, Cl, Cf, grad_channels, (N, H, W) = ctx.misc
+      saved = ctx.saved
+      ni = ctx.needs_input_grad[4:]
+      grads = [None] * len(params)
+      Wo0, bo0, Wo2, bo2 = params[4 * L:4 * L + 4]
+      g = g.contiguous()
+      Co = Wo0.size(0)
+      grads[4 * L + 2], grads[4 * L + 3] = _conv_param_grads(do2, g, Wo2.size(0), (Wo2.size(0), 1, 1, Co),
+                                                             ni[4 * L + 2], ni[4 * L + 3], Wo2, bo2)
+      dz = _new(g, N, H, W, Co)
+      ops.conv2d_backward_data(do2, _cl_weight(Wo2), Wo2.size(0), g, Wo2.size(0), 0, Co, dz, Co)
+      ops.act_backward(_fptr(dz), Co, 0, N, H, W, z, Co, Co, slope, dz)
+      grads[4 * L], grads[4 * L + 1] = _conv_param_grads(do0, dz, Co, (Co, 3, 3, Cf), ni[4 * L], ni[4 * L + 1], Wo0, bo0)
+      gz = _new(g, N, H, W, Cf)
+      ops.conv2d_backward_data(do0, _cl_weight(Wo0), Co, dz, Co, 0, Cf, gz, Cf)
+      pool2 = 0
+      need_layout = ctx.needs_input_grad[0]
+      Cg = Cl if grad_channels is None else min(int(grad_channels), Cl)
+      dlevels = []
+      for i in range(L - 1, -1, -1):
+        lay, feat_src, a0, a1, h, w, C = saved[i]
+        W0p, b0, W1p, b1 = params[4 * i:4 * i + 4]
+        # through the second activation (with the 2x2 sum of the nearest-upsample backward)
+        dy1 = ops.act_backward(_fptr(gz), gz.size(3), pool2, N, h, w, a1, C, C, slope, _new(g, N, h, w, C))
+        d1 = conv_desc([nhwc_src(a0)], N, h, w, 3, 3, 1, 1)
+        grads[4 * i + 2], grads[4 * i + 3] = _conv_param_grads(d1, dy1, C, (C, 3, 3, C), ni[4 * i + 2],
+                                                                ni[4 * i + 3], W1p, b1)
+        gz0 = _new(g, N, h, w, C)
+        ops.conv2d_backward_data(d1, _cl_weight(W1p), C, dy1, C, 0, C, gz0, C)
+        dy0 = ops.act_backward(_fptr(gz0), C, 0, N, h, w, a0, C, C, slope, gz0)
+        Cprev = feat_src.channels
+        d0 = conv_desc([nhwc_src(lay), feat_src], N, h, w, 3, 3, 1, 1)
+        grads[4 * i], grads[4 * i + 1] = _conv_param_grads(d0, dy0, C, (C, 3, 3, Cl + Cprev), ni[4 * i],
+                                                            ni[4 * i + 1], W0p, b0)
+        if need_layout:
+          dl = _new(g, N, h, w, Cg)
+          ops.conv2d_backward_data(d0, _cl_weight(W0p), C, dy0, C, 0, Cg, dl, Cg)
+          dlevels.append((dl, H // h))
+        if i > 0:
+          gz = _new(g, N, h, w, Cprev)
+          ops.conv2d_backward_data(d0, _cl_weight(W0p), C, dy0, C, Cl, Cprev, gz, Cprev)
+          pool2 = 1
+      dlayout = None
+      if need_layout:
+        dlayout = _new(g, N, H, W, Cl) if Cg == Cl else torch.zeros(N, H, W, Cl, dtype=torch.float32, device=g.device)
+        ops.pyramid_backward([t for t, _ in dlevels], [f for _, f in dlevels], [Cg] * len(dlevels), N, H, W, Cg,
+                             dlayout)
+      ctx.saved = None
+      return (dlayout, None, None, None) + tuple(grads)
+    finally:
+      ops.TIMER_TAG = None
+
+
 class MaskNetFn(Function):
   """mask_net (reference sg2im/model.py:94-106,146-147): [up2, BN, conv3x3, ReLU] x k, conv1x1,
   sigmoid.  params: per block [gamma, beta, W, b] ..., then [Wf, bf]."""

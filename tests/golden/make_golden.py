@@ -47,6 +47,18 @@ CONFIGS = {
     d_img=dict(arch='C4-8-2,C4-16-2', normalization='batch', activation='leakyrelu-0.2',
                padding='valid'),
   ),
+  # generator without normalisation layers in the refinement network (--normalization none)
+  'tiny_coco_nonorm': dict(
+    batch=dict(batch_size=2, image_size=(16, 16), num_objs=10, num_preds=4, min_objs=2,
+               max_objs=3, mask_size=4, style='coco', seed=37),
+    g=dict(image_size=(16, 16), embedding_dim=16, gconv_dim=16, gconv_hidden_dim=32,
+           gconv_num_layers=2, refinement_dims=(24, 16, 8), normalization='none',
+           activation='leakyrelu-0.2', mask_size=4, layout_noise_dim=4),
+    d_obj=dict(arch='C4-8-2,C4-16-2', normalization='batch', activation='leakyrelu-0.2',
+               padding='valid', object_size=16),
+    d_img=dict(arch='C4-8-2,C4-16-2', normalization='batch', activation='leakyrelu-0.2',
+               padding='valid'),
+  ),
   # VG-style: no GT masks -> masks_pred feeds the layout and mask_net trains.
   'tiny_vg': dict(
     batch=dict(batch_size=2, image_size=(32, 32), num_objs=9, num_preds=6, min_objs=3,
@@ -239,8 +251,11 @@ def run_eval_config(name, cfg):
 
 if __name__ == '__main__':
   which = sys.argv[1:] or ['train', 'eval']
+  only = [w for w in which if w in CONFIGS]
   for n, c in CONFIGS.items():
-    if 'train' in which:
+    if only and n not in only:
+      continue
+    if 'train' in which or only:
       run_config(n, c)
-    if 'eval' in which:
+    if 'eval' in which and 'nonorm' not in n:
       run_eval_config(n, c)

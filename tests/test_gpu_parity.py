@@ -58,7 +58,7 @@ def test_losses_and_adam():
   _run('sec_losses')
 
 
-@pytest.mark.parametrize('section', ['sec_golden_coco', 'sec_golden_vg'])
+@pytest.mark.parametrize('section', ['sec_golden_coco', 'sec_golden_vg', 'sec_golden_nonorm'])
 def test_full_step_against_reference_golden(section):
   """generator forward, all losses, every parameter gradient of G / D_obj / D_img and the
   BatchNorm running statistics against vectors produced by the imported reference"""
@@ -329,7 +329,7 @@ def test_step_is_bit_reproducible():
       assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize('case', ['vg64', 'vg128_deeper_crn', 'stretch256'])
+@pytest.mark.parametrize('case', ['vg64', 'vg128_deeper_crn', 'stretch256', 'vg64_no_normalization'])
 def test_other_baseline_shapes_match_oracle(case):
   """BASELINE.json configs[2..4] as fp32 parity cases (one full iteration against the oracle):
   VG-shape graphs without GT masks (mask_net trains through the layout), the 128x128 config with
@@ -342,6 +342,8 @@ def test_other_baseline_shapes_match_oracle(case):
   vocab = make_vocab(179, 46)
   if case == 'vg64':
     S, bs, gk, bk = 64, 4, {}, dict(min_objs=3, max_objs=10)
+  elif case == 'vg64_no_normalization':        # --normalization none
+    S, bs, gk, bk = 64, 3, dict(normalization='none'), dict(min_objs=3, max_objs=10)
   elif case == 'vg128_deeper_crn':
     S, bs, gk, bk = 128, 2, dict(refinement_dims=(1024, 512, 256, 128, 64, 64)), dict(min_objs=3, max_objs=10)
   else:

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import sg2im_oracle as orc
-from tests.util import GOLDEN_NAMES, load_golden, clone_params, assert_close
+from tests.util import GOLDEN_NAMES, GOLDEN_TRAIN_NAMES, load_golden, clone_params, assert_close
 
 # fp32 CPU vs fp32 CPU, same library: differences come only from op ordering
 RTOL, ATOL = 1e-5, 1e-6
@@ -21,7 +21,7 @@ def _trainer(fix):
   return tr
 
 
-@pytest.mark.parametrize('name', GOLDEN_NAMES)
+@pytest.mark.parametrize('name', GOLDEN_TRAIN_NAMES)
 def test_generator_step_matches_reference(name):
   fix = load_golden(name)
   tr = _trainer(fix)

@@ -5,6 +5,7 @@ import torch
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 GOLDEN_NAMES = ('tiny_coco', 'tiny_vg')
+GOLDEN_TRAIN_NAMES = GOLDEN_NAMES + ('tiny_coco_nonorm',)     # (no eval-mode fixture for the last one)
 
 
 def load_golden(name):
