@@ -340,15 +340,18 @@ def parse_conv_arch(arch):
   return out
 
 
-def disc_cnn(P, prefix, x, arch, slope, padding, training):
-  """build_cnn with C-tokens only, normalization='batch': every conv except the first
-  is preceded by BN + activation, nothing follows the last (layers.py:166-169).
-  Sequential indices: conv i sits at 3i, its preceding BN at 3i-2."""
+def disc_cnn(P, prefix, x, arch, slope, padding, training, normalization='batch'):
+  """build_cnn with C-tokens only: every conv except the first is preceded by [BN +] activation,
+  nothing follows the last (layers.py:166-169).  Sequential indices with normalization='batch':
+  conv i at 3i, its preceding BN at 3i-2; with 'none' the norm layers are absent: conv i at 2i."""
   for i, (k, c, stride) in enumerate(parse_conv_arch(arch)):
+    step = 3 if normalization == 'batch' else 2
     if i > 0:
-      x = F.leaky_relu(batch_norm(P, '%s.%d' % (prefix, 3 * i - 2), x, training), slope)
+      if normalization == 'batch':
+        x = batch_norm(P, '%s.%d' % (prefix, 3 * i - 2), x, training)
+      x = F.leaky_relu(x, slope)
     pad = 0 if padding == 'valid' else (k - 1) // 2
-    x = F.conv2d(x, P['%s.%d.weight' % (prefix, 3 * i)], P['%s.%d.bias' % (prefix, 3 * i)],
+    x = F.conv2d(x, P['%s.%d.weight' % (prefix, step * i)], P['%s.%d.bias' % (prefix, step * i)],
                  stride=stride, padding=pad)
   return x
 
@@ -357,7 +360,8 @@ def patch_discriminator(P, dcfg, x, training=True):
   """sg2im/discriminators.py:42-45: returns the raw CNN features; ``classifier``
   (line 40) is never applied."""
   slope = activation_slope(dcfg.get('activation', 'leakyrelu-0.2'))
-  return disc_cnn(P, 'cnn', x, dcfg['arch'], slope, dcfg.get('padding', 'same'), training)
+  return disc_cnn(P, 'cnn', x, dcfg['arch'], slope, dcfg.get('padding', 'same'), training,
+                  dcfg.get('normalization', 'batch'))
 
 
 def ac_crop_discriminator(P, dcfg, imgs, objs, boxes, obj_to_img, training=True,
@@ -367,7 +371,7 @@ def ac_crop_discriminator(P, dcfg, imgs, objs, boxes, obj_to_img, training=True,
                           align_corners=align_corners)
   slope = activation_slope(dcfg.get('activation', 'relu'))
   feats = disc_cnn(P, 'discriminator.cnn.0', crops, dcfg['arch'], slope,
-                   dcfg.get('padding', 'same'), training)
+                   dcfg.get('padding', 'same'), training, dcfg.get('normalization', 'none'))
   vecs = feats.view(feats.size(0), feats.size(1), -1).mean(dim=2)     # GlobalAvgPool layers.py:83-86
   vecs = F.linear(vecs, P['discriminator.cnn.2.weight'], P['discriminator.cnn.2.bias'])
   real = F.linear(vecs, P['discriminator.real_classifier.weight'], P['discriminator.real_classifier.bias'])
@@ -623,12 +627,13 @@ def init_generator_params(cfg, seed=0, randomize_bn=False):
   return P
 
 
-def _init_disc_cnn(P, prefix, arch, cin, gen, randomize_bn):
+def _init_disc_cnn(P, prefix, arch, cin, gen, randomize_bn, normalization='batch'):
   c = cin
+  step = 3 if normalization == 'batch' else 2
   for i, (k, cout, _s) in enumerate(parse_conv_arch(arch)):
-    if i > 0:
+    if i > 0 and normalization == 'batch':
       _bn(P, '%s.%d' % (prefix, 3 * i - 2), c, gen, randomize_bn)
-    _conv(P, '%s.%d' % (prefix, 3 * i), cout, c, k, gen)
+    _conv(P, '%s.%d' % (prefix, step * i), cout, c, k, gen)
     c = cout
   return c
 
@@ -636,7 +641,7 @@ def _init_disc_cnn(P, prefix, arch, cin, gen, randomize_bn):
 def init_patch_discriminator_params(dcfg, seed=1, randomize_bn=False):
   g = torch.Generator().manual_seed(seed)
   P = {}
-  c = _init_disc_cnn(P, 'cnn', dcfg['arch'], 3, g, randomize_bn)
+  c = _init_disc_cnn(P, 'cnn', dcfg['arch'], 3, g, randomize_bn, dcfg.get('normalization', 'batch'))
   _conv(P, 'classifier', 1, c, 1, g)         # discriminators.py:40 (present, unused)
   return P
 
@@ -644,7 +649,7 @@ def init_patch_discriminator_params(dcfg, seed=1, randomize_bn=False):
 def init_ac_discriminator_params(dcfg, seed=2, randomize_bn=False):
   g = torch.Generator().manual_seed(seed)
   P = {}
-  c = _init_disc_cnn(P, 'discriminator.cnn.0', dcfg['arch'], 3, g, randomize_bn)
+  c = _init_disc_cnn(P, 'discriminator.cnn.0', dcfg['arch'], 3, g, randomize_bn, dcfg.get('normalization', 'none'))
   _lin(P, 'discriminator.cnn.2', 1024, c, g)
   _lin(P, 'discriminator.real_classifier', 1, 1024, g)
   _lin(P, 'discriminator.obj_classifier', len(dcfg['vocab']['object_idx_to_name']), 1024, g)

@@ -729,7 +729,8 @@ class DiscCnnFn(Function):
   """build_cnn with 'CK-X-S' tokens, batch norm, valid/same padding (reference
   sg2im/layers.py:129-213): conv, then [BN, LeakyReLU, conv] ... on an NHWC input.
   specs: list of (k, cout, stride, pad); params: [W0, b0], then per later conv
-  [gamma, beta, W, b]."""
+  [gamma, beta, W, b] - or, with normalization='none' (bns is None), just [W, b] per conv:
+  the LeakyReLU in front of conv i+1 is then fused into conv i's epilogue."""
 
   @staticmethod
   def forward(ctx, x, bns, specs, slope, training, *params):
@@ -738,28 +739,35 @@ class DiscCnnFn(Function):
     saved = []
     src = nhwc_src(x)
     h, w = H, W
+    nonorm = bns is None
     for i, (k, cout, stride, pad) in enumerate(specs):
-      if i == 0:
+      if nonorm:
+        Wp, bias = params[2 * i:2 * i + 2]
+      elif i == 0:
         Wp, bias = params[0:2]
       else:
         Wp, bias = params[2 + 4 * (i - 1) + 2:2 + 4 * (i - 1) + 4]
       d = conv_desc([src], N, h, w, k, k, stride, pad)
-      y = ops.conv2d_forward(d, _cl_weight(Wp), cout, bias, _new(x, N, d.out_h, d.out_w, cout), cout)
+      last = i + 1 == len(specs)
+      y = ops.conv2d_forward(d, _cl_weight(Wp), cout, bias, _new(x, N, d.out_h, d.out_w, cout), cout,
+                             slope if (nonorm and not last) else 1.0)
       st = None
-      if i + 1 < len(specs):
+      if not last and not nonorm:
         st = ops.bn_stats(y, N * d.out_h * d.out_w, cout, cout, bns[i], training, BN_EPS, BN_MOMENTUM)
       saved.append((src, d, y, st, h, w))
       h, w = d.out_h, d.out_w
       if st is not None:
         src = nhwc_src(y, 0, st.scale, st.shift, slope)
-    ctx.saved, ctx.misc = saved, (specs, slope, training, tuple(x.shape))
+      elif nonorm:
+        src = nhwc_src(y)
+    ctx.saved, ctx.misc = saved, (specs, slope, training, tuple(x.shape), nonorm)
     ctx.save_for_backward(*params)
     return saved[-1][2]
 
   @staticmethod
   def backward(ctx, g):
     params = ctx.saved_tensors
-    specs, slope, training, xshape = ctx.misc
+    specs, slope, training, xshape, nonorm = ctx.misc
     saved = ctx.saved
     N = xshape[0]
     ni = ctx.needs_input_grad[5:]
@@ -769,12 +777,15 @@ class DiscCnnFn(Function):
       k, cout, stride, pad = specs[i]
       src, d, y, st, h, w = saved[i]
       cin = src.channels
-      if i == 0:
+      if nonorm:
+        wi = 2 * i
+        Wp = params[wi]
+      elif i == 0:
         Wp, wi = params[0], 0
       else:
         wi = 2 + 4 * (i - 1) + 2
         Wp = params[wi]
-      shadowed = training and i + 1 < len(specs)          # followed by a batch-statistics BN
+      shadowed = training and i + 1 < len(specs) and not nonorm     # followed by a batch-statistics BN
       grads[wi], grads[wi + 1] = _conv_param_grads(d, dy, cout, (cout, k, k, cin), ni[wi], ni[wi + 1] and not shadowed,
                                                    Wp, params[wi + 1])
       if shadowed:
@@ -789,6 +800,9 @@ class DiscCnnFn(Function):
       gz = _new(g, N, h, w, cin)
       ops.conv2d_backward_data(d, _cl_weight(Wp), cout, dy, cout, 0, cin, gz, cin)
       yp, stp = saved[i - 1][2], saved[i - 1][3]
+      if nonorm:                                          # yp is the activated output of conv i-1
+        dy = ops.act_backward(_fptr(gz), cin, 0, N, h, w, yp, cin, cin, slope, gz)
+        continue
       gi = 2 + 4 * (i - 1)
       dgam, dbet, accb, grads[gi], grads[gi + 1] = _bn_grad_bufs(g, cin, params[gi], params[gi + 1], ni[gi],
                                                                  ni[gi + 1])

@@ -100,8 +100,13 @@ class DiscCnn(nn.Sequential):
   def forward(self, x_nhwc):
     convs = [m for m in self if isinstance(m, nn.Conv2d)]
     bns = [m for m in self if isinstance(m, nn.BatchNorm2d)]
+    if not bns:                       # normalization='none': conv, act, conv, act, ..., conv
+      params = []
+      for cv in convs:
+        params += [cv.weight, cv.bias]
+      return HF.DiscCnnFn.apply(x_nhwc, None, self.specs, self.slope, self.training, *params)
     if len(bns) != len(convs) - 1:
-      raise NotImplementedError('discriminator CNN needs batch normalization between its convolutions')
+      raise NotImplementedError('discriminator CNN with a partial set of normalization layers')
     params = [convs[0].weight, convs[0].bias]
     for bn, cv in zip(bns, convs[1:]):
       params += [bn.weight, bn.bias, cv.weight, cv.bias]

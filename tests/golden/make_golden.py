@@ -54,10 +54,10 @@ CONFIGS = {
     g=dict(image_size=(16, 16), embedding_dim=16, gconv_dim=16, gconv_hidden_dim=32,
            gconv_num_layers=2, refinement_dims=(24, 16, 8), normalization='none',
            activation='leakyrelu-0.2', mask_size=4, layout_noise_dim=4),
-    d_obj=dict(arch='C4-8-2,C4-16-2', normalization='batch', activation='leakyrelu-0.2',
+    d_obj=dict(arch='C4-8-2,C4-16-2', normalization='none', activation='leakyrelu-0.2',
                padding='valid', object_size=16),
-    d_img=dict(arch='C4-8-2,C4-16-2', normalization='batch', activation='leakyrelu-0.2',
-               padding='valid'),
+    d_img=dict(arch='C3-8-2,C3-16-2,C3-16', normalization='none', activation='leakyrelu-0.2',
+               padding='same'),
   ),
   # VG-style: no GT masks -> masks_pred feeds the layout and mask_net trains.
   'tiny_vg': dict(

@@ -49,7 +49,7 @@ def test_generator_step_matches_reference(name):
     assert_close(tr.PG[k].float(), v.float(), RTOL, ATOL, 'buffer G.' + k)
 
 
-@pytest.mark.parametrize('name', GOLDEN_NAMES)
+@pytest.mark.parametrize('name', GOLDEN_TRAIN_NAMES)
 def test_discriminator_steps_match_reference(name):
   fix = load_golden(name)
   tr = _trainer(fix)
