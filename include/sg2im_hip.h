@@ -122,15 +122,17 @@ int sg2im_layout_forward(const float* vecs, long long ld_vecs, const float* boxe
                          long long ld_layout, hipStream_t stream);
 /* d_vecs[o][d] = sum_{y,x} dlayout[n_o][y][x][d] * S_o(y,x)  (deterministic two-stage sum;
  * workspace: sg2im_layout_backward_workspace() bytes);  optional d_masks [O][M][M] for float
- * (predicted) masks: d_masks[o][i][j] = sum_{y,x} <dlayout[n_o][y][x], vecs[o]> * dS_o/dm_ij. */
+ * (predicted) masks: d_masks[o][i][j] = sum_{y,x} <dlayout[n_o][y][x], vecs[o]> * dS_o/dm_ij;
+ * optional d_boxes [O][4]: the gradient w.r.t. the boxes through the sampling grid
+ * (layout.py:117-127; Sg2ImModel.forward with boxes_gt=None lays out the PREDICTED boxes). */
 size_t sg2im_layout_backward_workspace(int n_objs, int dim, int height, int width);
 int sg2im_layout_backward(const float* dlayout, long long ld_dlayout, const float* vecs,
                           long long ld_vecs, const float* boxes, const float* masks,
                           const long long* masks_i64, int mask_size, const long long* obj_to_img,
                           const int* img_row_ptr, const int* img_entries, int n_images,
                           int n_objs, int dim, int height, int width, int align_corners,
-                          float* d_vecs, long long ld_dvecs, float* d_masks, float* workspace,
-                          hipStream_t stream);
+                          float* d_vecs, long long ld_dvecs, float* d_masks, float* d_boxes,
+                          float* workspace, hipStream_t stream);
 
 /* Object crops for the object discriminator (sg2im/bilinear.py:28-132, 'cudnn' path):
  * crops[o] = bilinear sample of image obj_to_img[o] on linspace(2*x0-1, 2*x1-1, size).

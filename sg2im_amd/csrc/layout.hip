@@ -36,7 +36,8 @@ __device__ __forceinline__ float mask_at(const MaskRef& m, int o, int y, int x) 
 }
 
 // bilinear footprint of one output pixel in the object's M x M map
-struct Foot { int x0, y0; float wx0, wx1, wy0, wy1; };   // weights already zeroed when out of bounds
+struct Foot { int x0, y0; float wx0, wx1, wy0, wy1, tx, ty; };   // weights already zeroed when out of bounds;
+                                                                  // tx, ty: the raw fractions
 
 __device__ __forceinline__ Foot footprint(const float* box, int y, int x, int H, int W, int Min,
                                           int align_corners) {
@@ -52,6 +53,7 @@ __device__ __forceinline__ Foot footprint(const float* box, int y, int x, int H,
   f.x0 = (int)fminf(fmaxf(fx, -2.f), (float)Min + 1.f);
   f.y0 = (int)fminf(fmaxf(fy, -2.f), (float)Min + 1.f);
   const float tx = ix - fx, ty = iy - fy;
+  f.tx = tx; f.ty = ty;
   f.wx0 = (f.x0 >= 0 && f.x0 < Min) ? 1.f - tx : 0.f;
   f.wx1 = (f.x0 + 1 >= 0 && f.x0 + 1 < Min) ? tx : 0.f;
   f.wy0 = (f.y0 >= 0 && f.y0 < Min) ? 1.f - ty : 0.f;
@@ -230,38 +232,86 @@ __global__ void layout_bwd_reduce_kernel(const float* __restrict__ part, int n_t
   dvecs[(i / D) * ld_dvecs + (i % D)] = s;
 }
 
-// ---- backward w.r.t. (soft) masks: one workgroup per object ---------------------------
+// ---- backward w.r.t. (soft) masks and boxes: one workgroup per object ----------------------
+// With G(y,x) = <dL[n,:,y,x], v_o> the mask gradient is the bilinear transpose of G, and the
+// box gradient follows from ix = unnormalize(2 (X - x0)/(x1 - x0) - 1):
+//   dL/dx0 = sum_px G dS/dix (Min or Min-1)/2 * 2 (X - x1)/(x1 - x0)^2,   dL/dx1 = ... * -2 (X - x0)/(x1 - x0)^2
+// (same in y), dS/dix being the x-difference of the map under the footprint with zero padding -
+// exactly what grid_sample's backward gives the reference (layout.py:60-61,87-88,117-127).
 __global__ __launch_bounds__(256) void layout_bwd_masks_kernel(const float* __restrict__ dl, long long ld_dl,
                                                                const float* __restrict__ vecs, long long ld_vecs,
-                                                               const float* __restrict__ boxes, int M,
+                                                               const float* __restrict__ boxes, MaskRef mk,
                                                                const long long* __restrict__ obj_to_img, int D,
                                                                int H, int W, int align_corners,
-                                                               float* __restrict__ dmasks) {
-  extern __shared__ float sm[];            // [D] vec + [M*M] grad
+                                                               float* __restrict__ dmasks, float* __restrict__ dboxes) {
+  extern __shared__ float sm[];            // [D] vec + [M*M] grad + [4 * 256] box partials
+  const int M = mk.M, Min = M > 0 ? M : 8;
   float* v = sm;
   float* gm = sm + D;
+  float* bp = gm + (dmasks ? M * M : 0);
   const int o = blockIdx.x, tid = threadIdx.x, HW = H * W;
   const long long n = obj_to_img[o];
   for (int i = tid; i < D; i += 256) v[i] = vecs[(long long)o * ld_vecs + i];
-  for (int i = tid; i < M * M; i += 256) gm[i] = 0.f;
+  if (dmasks)
+    for (int i = tid; i < M * M; i += 256) gm[i] = 0.f;
   __syncthreads();
+  const float* box = boxes + 4LL * o;
+  const float bw = box[2] - box[0], bh = box[3] - box[1];
+  const float mult = align_corners ? 0.5f * (float)(Min - 1) : 0.5f * (float)Min;
+  float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
   for (int px = tid; px < HW; px += 256) {
-    const Foot f = footprint(boxes + 4LL * o, px / W, px % W, H, W, M, align_corners);
+    const int y = px / W, x = px % W;
+    const Foot f = footprint(box, y, x, H, W, Min, align_corners);
     if ((f.wx0 == 0.f && f.wx1 == 0.f) || (f.wy0 == 0.f && f.wy1 == 0.f)) continue;
     const float* g = dl + (n * HW + px) * ld_dl;
     float ds = 0.f;
     for (int d = 0; d < D; ++d) ds = fmaf(g[d], v[d], ds);
-    if (f.wy0 != 0.f) {
-      if (f.wx0 != 0.f) atomicAdd(&gm[f.y0 * M + f.x0], ds * (f.wx0 * f.wy0));
-      if (f.wx1 != 0.f) atomicAdd(&gm[f.y0 * M + f.x0 + 1], ds * (f.wx1 * f.wy0));
+    if (dmasks) {
+      if (f.wy0 != 0.f) {
+        if (f.wx0 != 0.f) atomicAdd(&gm[f.y0 * M + f.x0], ds * (f.wx0 * f.wy0));
+        if (f.wx1 != 0.f) atomicAdd(&gm[f.y0 * M + f.x0 + 1], ds * (f.wx1 * f.wy0));
+      }
+      if (f.wy1 != 0.f) {
+        if (f.wx0 != 0.f) atomicAdd(&gm[(f.y0 + 1) * M + f.x0], ds * (f.wx0 * f.wy1));
+        if (f.wx1 != 0.f) atomicAdd(&gm[(f.y0 + 1) * M + f.x0 + 1], ds * (f.wx1 * f.wy1));
+      }
     }
-    if (f.wy1 != 0.f) {
-      if (f.wx0 != 0.f) atomicAdd(&gm[(f.y0 + 1) * M + f.x0], ds * (f.wx0 * f.wy1));
-      if (f.wx1 != 0.f) atomicAdd(&gm[(f.y0 + 1) * M + f.x0 + 1], ds * (f.wx1 * f.wy1));
+    if (dboxes) {
+      // corner values with zero padding (the weights are already zero for out-of-range corners)
+      const float m00 = (f.wx0 != 0.f && f.wy0 != 0.f) ? mask_at(mk, o, f.y0, f.x0) : 0.f;
+      const float m01 = (f.wx1 != 0.f && f.wy0 != 0.f) ? mask_at(mk, o, f.y0, f.x0 + 1) : 0.f;
+      const float m10 = (f.wx0 != 0.f && f.wy1 != 0.f) ? mask_at(mk, o, f.y0 + 1, f.x0) : 0.f;
+      const float m11 = (f.wx1 != 0.f && f.wy1 != 0.f) ? mask_at(mk, o, f.y0 + 1, f.x0 + 1) : 0.f;
+      // d/dix, d/diy of the bilinear blend; a corner outside the map contributes nothing (ATen's
+      // grid_sampler backward skips it) while the other axis keeps its raw fraction
+      const float X = lin01(x, W), Y = lin01(y, H);
+      const float fx = f.tx, fy = f.ty;
+      const bool xa = f.x0 >= 0 && f.x0 < Min, xb = f.x0 + 1 >= 0 && f.x0 + 1 < Min;
+      const bool ya = f.y0 >= 0 && f.y0 < Min, yb = f.y0 + 1 >= 0 && f.y0 + 1 < Min;
+      float dix = 0.f, diy = 0.f;
+      if (xa && ya) { dix -= m00 * (1.f - fy); diy -= m00 * (1.f - fx); }
+      if (xb && ya) { dix += m01 * (1.f - fy); diy -= m01 * fx; }
+      if (xa && yb) { dix -= m10 * fy;         diy += m10 * (1.f - fx); }
+      if (xb && yb) { dix += m11 * fy;         diy += m11 * fx; }
+      const float gx = ds * dix * mult, gy = ds * diy * mult;     // dL/d(grid x), dL/d(grid y)
+      b0 += gx * (2.f * (X - box[2]) / (bw * bw));
+      b2 += gx * (-2.f * (X - box[0]) / (bw * bw));
+      b1 += gy * (2.f * (Y - box[3]) / (bh * bh));
+      b3 += gy * (-2.f * (Y - box[1]) / (bh * bh));
     }
   }
   __syncthreads();
-  for (int i = tid; i < M * M; i += 256) dmasks[(long long)o * M * M + i] = gm[i];
+  if (dmasks)
+    for (int i = tid; i < M * M; i += 256) dmasks[(long long)o * M * M + i] = gm[i];
+  if (dboxes) {
+    bp[tid] = b0; bp[256 + tid] = b1; bp[512 + tid] = b2; bp[768 + tid] = b3;
+    __syncthreads();
+    if (tid < 4) {                           // fixed-order sum of the 256 thread partials
+      float s = 0.f;
+      for (int k = 0; k < 256; ++k) s += bp[tid * 256 + k];
+      dboxes[4LL * o + tid] = s;
+    }
+  }
 }
 
 // ---- crops ---------------------------------------------------------------------------
@@ -513,8 +563,8 @@ int sg2im_layout_backward(const float* dlayout, long long ld_dlayout, const floa
                           const long long* masks_i64, int mask_size, const long long* obj_to_img,
                           const int* img_row_ptr, const int* img_entries, int n_images,
                           int n_objs, int dim, int height, int width, int align_corners,
-                          float* d_vecs, long long ld_dvecs, float* d_masks, float* workspace,
-                          hipStream_t stream) {
+                          float* d_vecs, long long ld_dvecs, float* d_masks, float* d_boxes,
+                          float* workspace, hipStream_t stream) {
   if (!dlayout || !boxes || !img_row_ptr || dim < 1 || height < 1 || width < 1) return SG2IM_ERR_ARG;
   if (n_objs == 0) return SG2IM_OK;
   const MaskRef mk{masks, masks_i64, (masks || masks_i64) ? mask_size : 0};
@@ -533,11 +583,11 @@ int sg2im_layout_backward(const float* dlayout, long long ld_dlayout, const floa
     hipLaunchKernelGGL(layout_bwd_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, workspace,
                        n_tiles, n_objs, dim, d_vecs, ld_dvecs);
   }
-  if (d_masks) {
-    if (!masks || !vecs || !obj_to_img || mask_size < 1) return SG2IM_ERR_ARG;
-    const size_t lds = sizeof(float) * (size_t)(dim + mask_size * mask_size);
+  if (d_masks || d_boxes) {
+    if (!vecs || !obj_to_img || (d_masks && (!masks || mask_size < 1))) return SG2IM_ERR_ARG;
+    const size_t lds = sizeof(float) * (size_t)(dim + (d_masks ? mask_size * mask_size : 0) + (d_boxes ? 4 * 256 : 0));
     hipLaunchKernelGGL(layout_bwd_masks_kernel, dim3(n_objs), dim3(256), lds, stream, dlayout, ld_dlayout, vecs,
-                       ld_vecs, boxes, mask_size, obj_to_img, dim, height, width, align_corners, d_masks);
+                       ld_vecs, boxes, mk, obj_to_img, dim, height, width, align_corners, d_masks, d_boxes);
   }
   return ok_or(hipGetLastError());
 }

@@ -332,17 +332,16 @@ class LayoutFn(Function):
     vecs, boxes, masks, obj_to_img = ctx.saved_tensors
     n_images, H, W, ac = ctx.geom
     ni = ctx.needs_input_grad
-    if ni[1]:
-      raise NotImplementedError('gradient of the layout w.r.t. the boxes is not implemented yet '
-                                '(the training loop always passes boxes_gt, reference scripts/train.py:526)')
     g = g.contiguous()
     d_vecs = _new(vecs, vecs.size(0), vecs.size(1)) if ni[0] else None
+    d_boxes = _new(vecs, boxes.size(0), 4) if ni[1] else None      # predicted boxes laid out (boxes_gt=None)
     d_masks = None
     if ni[2] and masks is not None and masks.is_floating_point():
       d_masks = _new(vecs, *masks.shape)
-    if d_vecs is not None or d_masks is not None:
-      ops.layout_backward(g, vecs, boxes, masks, obj_to_img, ctx.img_csr, n_images, H, W, ac, d_vecs, d_masks)
-    return d_vecs, None, d_masks, None, None, None, None, None, None
+    if d_vecs is not None or d_masks is not None or d_boxes is not None:
+      ops.layout_backward(g, vecs, boxes, masks, obj_to_img, ctx.img_csr, n_images, H, W, ac, d_vecs, d_masks,
+                          d_boxes)
+    return d_vecs, d_boxes, d_masks, None, None, None, None, None, None
 
 
 class CropFn(Function):

@@ -273,7 +273,7 @@ def layout_forward(vecs, boxes, masks, img_csr, n_images, H, W, align_corners, o
 
 
 def layout_backward(dlayout, vecs, boxes, masks, obj_to_img, img_csr, n_images, H, W, align_corners,
-                    d_vecs, d_masks):
+                    d_vecs, d_masks, d_boxes=None):
   pv, ldv = rows_ld(vecs)
   mf, mi, M = _mask_args(masks)
   O, D = vecs.size(0), vecs.size(1)
@@ -284,7 +284,7 @@ def layout_backward(dlayout, vecs, boxes, masks, obj_to_img, img_csr, n_images, 
   pd, ldd = rows_ld(d_vecs) if d_vecs is not None else (None, 0)
   call('sg2im_layout_backward', _f(dlayout), dlayout.size(3), pv, ldv, _f(boxes), mf, mi, M, _i64(obj_to_img),
        _i32(img_csr.row_ptr), _i32(img_csr.entries), int(n_images), O, D, int(H), int(W), int(align_corners),
-       pd, ldd, _f(d_masks), _f(ws), _stream())
+       pd, ldd, _f(d_masks), _f(d_boxes), _f(ws), _stream())
 
 
 def crop_forward(imgs_nhwc, boxes, obj_to_img, size, align_corners, out):

@@ -452,3 +452,42 @@ def test_graph_iteration_vg_style_and_aux_losses_match_eager():
     assert set(a) == set(b)
     for k in a:
       assert abs(a[k] - b[k]) <= 2e-3 * max(1.0, abs(a[k])), (k, a[k], b[k])
+
+
+def test_generator_gradients_with_predicted_boxes():
+  """Sg2ImModel.forward(boxes_gt=None, masks_gt=None) under grad: the layout
+  is built from the PREDICTED boxes and masks, so the image loss reaches box_net and mask_net
+  through the sampling grid (layout.py:117-127) - every generator gradient against the oracle."""
+  from oracle import sg2im_oracle as orc
+  from sg2im_amd.model import Sg2ImModel
+  from sg2im_amd.synthetic import make_vocab, synthetic_batch
+  from tests import hip_harness as hh
+  from tests.util import max_rel_err
+  dev = hh.dev()
+  vocab = make_vocab(30, 6)
+  gcfg = dict(vocab=vocab, image_size=(32, 32), embedding_dim=32, gconv_dim=32, gconv_hidden_dim=64,
+              gconv_num_layers=2, refinement_dims=(64, 32, 16), normalization='batch',
+              activation='leakyrelu-0.2', mask_size=8, layout_noise_dim=0)
+  P = orc.init_generator_params(gcfg, 5, randomize_bn=True)
+  last = max(k for k in P if k.startswith('box_net.') and k.endswith('.bias'))
+  P[last.replace('.bias', '.weight')] *= 0.05
+  P[last] = torch.tensor([0.15, 0.1, 0.65, 0.75])          # proper boxes: x1 > x0, y1 > y0
+  imgs, objs, boxes, masks, triples, o2i, _ = synthetic_batch(3, image_size=(32, 32), num_objs=30, num_preds=6,
+                                                              mask_size=8, seed=4)
+  model = Sg2ImModel(**gcfg).to(dev).train()
+  hh.load_params(model, P)
+  img, bp, mp, rs = model(objs.to(dev), triples.to(dev), o2i.to(dev), num_images=3)
+  (img - imgs.to(dev)).abs().mean().backward()
+  Pr = {k: v.clone().requires_grad_(v.is_floating_point() and 'running_' not in k) for k, v in P.items()}
+  want = orc.generator_forward(Pr, gcfg, objs, triples, o2i, training=True)
+  assert max_rel_err(img.detach().cpu(), want[0].detach()) <= 1e-4
+  (want[0] - imgs).abs().mean().backward()
+  checked = 0
+  for k, p in model.named_parameters():
+    ref = Pr[k].grad
+    if ref is None:
+      continue
+    e = max_rel_err(p.grad.cpu(), ref)
+    assert e <= 2e-4 or float((p.grad.cpu() - ref).abs().max()) <= 1e-6, (k, e)
+    checked += 1
+  assert checked > 30 and any(k.startswith('box_net') for k, _ in model.named_parameters())

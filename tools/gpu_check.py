@@ -211,18 +211,21 @@ def sec_layout():
     from sg2im_amd.layout import layout_nhwc
     for name, mk in (('gtmask', masks), ('softmask', soft), ('boxes', None)):
       vr = vecs.clone().requires_grad_(True)
+      br = boxes.clone().requires_grad_(True)
       mr = mk.clone().requires_grad_(True) if (mk is not None and mk.is_floating_point()) else mk
-      want = orc.masks_to_layout(vr, boxes, mr, o2i, S) if mk is not None else orc.boxes_to_layout(vr, boxes, o2i, S)
+      want = orc.masks_to_layout(vr, br, mr, o2i, S) if mk is not None else orc.boxes_to_layout(vr, br, o2i, S)
       gl = torch.randn(want.shape, generator=g)
       want.backward(gl)
       vd = vecs.to(D).requires_grad_(True)
+      bd = boxes.to(D).requires_grad_(True)
       md = mk.to(D) if mk is not None else None
       if md is not None and md.is_floating_point():
         md.requires_grad_(True)
-      got = layout_nhwc(vd, boxes.to(D), md, o2i.to(D), S, n_images=N)
+      got = layout_nhwc(vd, bd, md, o2i.to(D), S, n_images=N)
       got.backward(gl.permute(0, 2, 3, 1).contiguous().to(D))
       report('layout %s %s fwd' % (tag, name), got.permute(0, 3, 1, 2), want)
       report('layout %s %s dvecs' % (tag, name), vd.grad, vr.grad)
+      report('layout %s %s dboxes' % (tag, name), bd.grad, br.grad)
       if md is not None and md.is_floating_point():
         report('layout %s %s dmasks' % (tag, name), md.grad, mr.grad)
     # crops
