@@ -116,7 +116,7 @@ __device__ __forceinline__ void locate_chunk(const ConvGeom& g, int ch, int& s, 
 // zeroed later through a validity mask.  The pending per-channel affine + LeakyReLU of the
 // source is not applied in the load either: its scale/shift vectors are fetched alongside
 // (identity constants when the source has none) and applied when the register set is
-// written to LDS, two K-chunks later.  This keeps every load of a chunk in flight at once -
+// written to LDS, one K-chunk later.  This keeps every load of a chunk in flight at once -
 // hipcc otherwise wraps each conditional load in an exec-mask branch followed by
 // `s_waitcnt vmcnt(0)`, which serialises a full memory latency per tile row.
 // Offsets are 32-bit element offsets (tensors < 2^32 elements).

@@ -232,13 +232,13 @@ __device__ __forceinline__ void epilogue(const Epi& e, int M, int N, int nlimit,
   }
 }
 
-// Software pipeline shared by the three kernels: two K-chunks of global loads are kept in
-// flight in registers (sets 0/1) while the matrix cores work on the chunk staged in LDS,
-// so a load has two chunk-times (~4-8k cycles) to land instead of one.
-//   load(it, set)   : global -> register set        stage(set, buf) : registers -> LDS buffer
-//   mma(buf)        : one BK chunk of MFMAs out of LDS buffer `buf`
+// Software pipeline shared by the three kernels: the global loads of the next K-chunk are kept
+// in flight in registers while the matrix cores work on the chunk staged in LDS.
+//   load(it, set)        : global -> register set     stage(set, buf, live) : registers -> LDS buffer
+//   mma(0, buf) / (1, buf): fragments of LDS buffer `buf` -> registers / the BK chunk of MFMAs
 // (register sets / LDS buffers are selected by compile-time tags so the register arrays are
-// never dynamically indexed, which would demote them to scratch)
+// never dynamically indexed, which would demote them to scratch; `live` is false for the
+// re-staged copy of the last chunk, see k_pipeline_d1)
 template <int I> struct IC { static constexpr int value = I; };
 
 #ifndef SG2IM_SMALL_TILE_DEPTH
