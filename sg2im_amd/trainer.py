@@ -110,17 +110,26 @@ class Trainer(object):
     self._seg_generator_backward(st)
 
   def _seg_generator_forward(self, batch, st):
+    self._seg_generator_model(batch, st)
+    self._seg_generator_losses(batch, st)
+
+  def _seg_generator_model(self, batch, st):
+    """train.py:524-530: the generator itself; `imgs_fake` is all the discriminator steps need"""
+    imgs, objs, boxes, masks, triples, obj_to_img = batch[:6]
+    st['imgs_nhwc'] = HF.NchwToNhwc.apply(imgs)
+    st['gen_out'] = self.model.forward_nhwc(objs, triples, obj_to_img, boxes_gt=boxes, masks_gt=masks,
+                                            num_images=imgs.size(0))
+    st['imgs_fake'] = st['gen_out'][0].detach()
+
+  def _seg_generator_losses(self, batch, st):
     imgs, objs, boxes, masks, triples, obj_to_img = batch[:6]
     w = self.w
-    N = imgs.size(0)
-    st['imgs_nhwc'] = HF.NchwToNhwc.apply(imgs)
-    # train.py:524-560.  The discriminators are frozen here (see module docstring).
+    imgs_pred, boxes_pred, masks_pred, rel_scores = st.pop('gen_out')
+    # train.py:531-560.  The discriminators are frozen here (see module docstring).
     for d in (self.d_obj, self.d_img):
       if d is not None:
         _set_requires_grad(d, False)
-    imgs_pred, boxes_pred, masks_pred, rel_scores = self.model.forward_nhwc(
-      objs, triples, obj_to_img, boxes_gt=boxes, masks_gt=masks, num_images=N)
-    losses = st['losses']
+    losses = {}          # the generator's own terms (st['losses'] may already hold a D step's)
     losses['L1_pixel_loss'] = L.l1_loss(imgs_pred, st['imgs_nhwc'], w['l1_pixel_loss_weight'])
     losses['bbox_pred'] = L.mse_loss(boxes_pred, boxes, w['bbox_pred_loss_weight'])
     if w['predicate_pred_loss_weight'] > 0:                       # train.py:402-405
@@ -139,8 +148,8 @@ class Trainer(object):
     for v in list(losses.values()):
       total = v if total is None else total + v
     losses['total_loss'] = total
+    st['losses'].update(losses)
     st['total'] = total
-    st['imgs_fake'] = imgs_pred.detach()
     # NaN guard of train.py:553-555 without a host sync: every optimiser of this iteration
     # skips its update when the generator loss is not finite (on any rank).
     st['guard'] = total.detach().reshape(1).clone()
@@ -360,9 +369,10 @@ class Trainer(object):
     torch.cuda.synchronize()
     with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
       main = torch.cuda.current_stream()
-      self._seg_generator_forward(static, st)
       import os
       side = self._side[0]
+      mode = os.environ.get('SG2IM_SCHEDULE', '2')
+      self._seg_generator_forward(static, st)
 
       def on_side(lane, seg, wait_ev=None):
         if wait_ev is not None:
@@ -380,8 +390,9 @@ class Trainer(object):
       # refinement network's backward; the D_obj step is held back until the generator backward
       # reaches the layout, where it runs next to the small layout / graph-convolution backward
       # kernels.  0: both steps at once, 10.65 ms; 1: D_obj first / D_img at the tail, 10.39;
-      # 2: this one, 10.33; 3: as 2 but the D_obj forward passes early, 10.42.
-      mode = os.environ.get('SG2IM_SCHEDULE', '2')
+      # 2: this one, 10.33; 3: as 2 but the D_obj forward passes early, 10.42.  (Forking already at
+      # imgs_pred, with the side stream's BatchNorm running-statistics updates deferred to keep
+      # the reference's order, was also tried: 10.29 - not worth the machinery.)
       if self.d_img is not None and mode != '1':
         on_side(2, self._seg_d_img)
       if self.d_obj is not None:
