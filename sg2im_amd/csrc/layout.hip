@@ -232,30 +232,72 @@ __global__ void layout_bwd_reduce_kernel(const float* __restrict__ part, int n_t
   dvecs[(i / D) * ld_dvecs + (i % D)] = s;
 }
 
-// ---- backward w.r.t. (soft) masks and boxes: one workgroup per object ----------------------
-// With G(y,x) = <dL[n,:,y,x], v_o> the mask gradient is the bilinear transpose of G, and the
+// ---- backward w.r.t. (soft) masks and boxes ------------------------------------------------
+// With G_o(y,x) = <dL[n_o,:,y,x], v_o> the mask gradient is the bilinear transpose of G, and the
 // box gradient follows from ix = unnormalize(2 (X - x0)/(x1 - x0) - 1):
 //   dL/dx0 = sum_px G dS/dix (Min or Min-1)/2 * 2 (X - x1)/(x1 - x0)^2,   dL/dx1 = ... * -2 (X - x0)/(x1 - x0)^2
 // (same in y), dS/dix being the x-difference of the map under the footprint with zero padding -
 // exactly what grid_sample's backward gives the reference (layout.py:60-61,87-88,117-127).
-__global__ __launch_bounds__(256) void layout_bwd_masks_kernel(const float* __restrict__ dl, long long ld_dl,
-                                                               const float* __restrict__ vecs, long long ld_vecs,
+// Two kernels, no atomics, fixed summation order:
+//   layout_bwd_g_kernel    G_o for every pixel of the object's image -> workspace [O][H*W]
+//   layout_bwd_masks_kernel one workgroup per object: every thread OWNS mask cells and gathers the
+//                          pixels whose footprint touches them (y, x ascending); the four box
+//                          partials are summed over pixels per thread, then over threads in order.
+__global__ void layout_bwd_g_kernel(const float* __restrict__ dl, long long ld_dl, const float* __restrict__ vecs,
+                                    long long ld_vecs, const long long* __restrict__ obj_to_img, int D, int HW,
+                                    float* __restrict__ G) {
+  const int o = blockIdx.y;
+  const int px = blockIdx.x * blockDim.x + threadIdx.x;
+  if (px >= HW) return;
+  const float* g = dl + (obj_to_img[o] * HW + px) * ld_dl;
+  const float* v = vecs + (long long)o * ld_vecs;
+  float ds = 0.f;
+  for (int d = 0; d < D; ++d) ds = fmaf(g[d], v[d], ds);
+  G[(long long)o * HW + px] = ds;
+}
+
+// pixel range [lo, hi] along one axis whose footprint can touch map cell `cell`
+__device__ __forceinline__ void layout_axis_range(float b0, float b1, int cell, int L, int Min, int align_corners,
+                                                  int& lo, int& hi) {
+  // map coordinate of pixel p: unnormalize(2 (lin01(p) - b0) / (b1 - b0) - 1) = A + B p (p in [0, L-1])
+  const float A = unnormalize(2.f * (0.f - b0) / (b1 - b0) - 1.f, Min, align_corners);
+  const float Z = unnormalize(2.f * (1.f - b0) / (b1 - b0) - 1.f, Min, align_corners);
+  const float B = L > 1 ? (Z - A) / (float)(L - 1) : 0.f;
+  lo = 0; hi = L - 1;
+  if (B > 1e-6f && B == B && fabsf(A) < 1e8f) {
+    const float l = floorf(((float)cell - 1.f - A) / B - 0.02f), h = ceilf(((float)cell + 1.f - A) / B + 0.02f);
+    lo = (int)fminf(fmaxf(l, 0.f), (float)L);
+    hi = (int)fminf(fmaxf(h, -1.f), (float)(L - 1));
+  }
+}
+
+__global__ __launch_bounds__(256) void layout_bwd_masks_kernel(const float* __restrict__ G,
                                                                const float* __restrict__ boxes, MaskRef mk,
-                                                               const long long* __restrict__ obj_to_img, int D,
                                                                int H, int W, int align_corners,
                                                                float* __restrict__ dmasks, float* __restrict__ dboxes) {
-  extern __shared__ float sm[];            // [D] vec + [M*M] grad + [4 * 256] box partials
+  __shared__ float bp[4 * 256];
   const int M = mk.M, Min = M > 0 ? M : 8;
-  float* v = sm;
-  float* gm = sm + D;
-  float* bp = gm + (dmasks ? M * M : 0);
   const int o = blockIdx.x, tid = threadIdx.x, HW = H * W;
-  const long long n = obj_to_img[o];
-  for (int i = tid; i < D; i += 256) v[i] = vecs[(long long)o * ld_vecs + i];
-  if (dmasks)
-    for (int i = tid; i < M * M; i += 256) gm[i] = 0.f;
-  __syncthreads();
+  const float* Go = G + (long long)o * HW;
   const float* box = boxes + 4LL * o;
+  if (dmasks) {
+    for (int cell = tid; cell < M * M; cell += 256) {
+      const int ci = cell / M, cj = cell - ci * M;
+      int xl, xh, yl, yh;
+      layout_axis_range(box[0], box[2], cj, W, Min, align_corners, xl, xh);
+      layout_axis_range(box[1], box[3], ci, H, Min, align_corners, yl, yh);
+      float acc = 0.f;
+      for (int y = yl; y <= yh; ++y)
+        for (int x = xl; x <= xh; ++x) {
+          const Foot f = footprint(box, y, x, H, W, Min, align_corners);
+          const float wx = f.x0 == cj ? f.wx0 : (f.x0 + 1 == cj ? f.wx1 : 0.f);
+          const float wy = f.y0 == ci ? f.wy0 : (f.y0 + 1 == ci ? f.wy1 : 0.f);
+          if (wx != 0.f && wy != 0.f) acc += Go[y * W + x] * (wx * wy);
+        }
+      dmasks[(long long)o * M * M + cell] = acc;
+    }
+  }
+  if (!dboxes) return;
   const float bw = box[2] - box[0], bh = box[3] - box[1];
   const float mult = align_corners ? 0.5f * (float)(Min - 1) : 0.5f * (float)Min;
   float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
@@ -263,54 +305,30 @@ __global__ __launch_bounds__(256) void layout_bwd_masks_kernel(const float* __re
     const int y = px / W, x = px % W;
     const Foot f = footprint(box, y, x, H, W, Min, align_corners);
     if ((f.wx0 == 0.f && f.wx1 == 0.f) || (f.wy0 == 0.f && f.wy1 == 0.f)) continue;
-    const float* g = dl + (n * HW + px) * ld_dl;
-    float ds = 0.f;
-    for (int d = 0; d < D; ++d) ds = fmaf(g[d], v[d], ds);
-    if (dmasks) {
-      if (f.wy0 != 0.f) {
-        if (f.wx0 != 0.f) atomicAdd(&gm[f.y0 * M + f.x0], ds * (f.wx0 * f.wy0));
-        if (f.wx1 != 0.f) atomicAdd(&gm[f.y0 * M + f.x0 + 1], ds * (f.wx1 * f.wy0));
-      }
-      if (f.wy1 != 0.f) {
-        if (f.wx0 != 0.f) atomicAdd(&gm[(f.y0 + 1) * M + f.x0], ds * (f.wx0 * f.wy1));
-        if (f.wx1 != 0.f) atomicAdd(&gm[(f.y0 + 1) * M + f.x0 + 1], ds * (f.wx1 * f.wy1));
-      }
-    }
-    if (dboxes) {
-      // corner values with zero padding (the weights are already zero for out-of-range corners)
-      const float m00 = (f.wx0 != 0.f && f.wy0 != 0.f) ? mask_at(mk, o, f.y0, f.x0) : 0.f;
-      const float m01 = (f.wx1 != 0.f && f.wy0 != 0.f) ? mask_at(mk, o, f.y0, f.x0 + 1) : 0.f;
-      const float m10 = (f.wx0 != 0.f && f.wy1 != 0.f) ? mask_at(mk, o, f.y0 + 1, f.x0) : 0.f;
-      const float m11 = (f.wx1 != 0.f && f.wy1 != 0.f) ? mask_at(mk, o, f.y0 + 1, f.x0 + 1) : 0.f;
-      // d/dix, d/diy of the bilinear blend; a corner outside the map contributes nothing (ATen's
-      // grid_sampler backward skips it) while the other axis keeps its raw fraction
-      const float X = lin01(x, W), Y = lin01(y, H);
-      const float fx = f.tx, fy = f.ty;
-      const bool xa = f.x0 >= 0 && f.x0 < Min, xb = f.x0 + 1 >= 0 && f.x0 + 1 < Min;
-      const bool ya = f.y0 >= 0 && f.y0 < Min, yb = f.y0 + 1 >= 0 && f.y0 + 1 < Min;
-      float dix = 0.f, diy = 0.f;
-      if (xa && ya) { dix -= m00 * (1.f - fy); diy -= m00 * (1.f - fx); }
-      if (xb && ya) { dix += m01 * (1.f - fy); diy -= m01 * fx; }
-      if (xa && yb) { dix -= m10 * fy;         diy += m10 * (1.f - fx); }
-      if (xb && yb) { dix += m11 * fy;         diy += m11 * fx; }
-      const float gx = ds * dix * mult, gy = ds * diy * mult;     // dL/d(grid x), dL/d(grid y)
-      b0 += gx * (2.f * (X - box[2]) / (bw * bw));
-      b2 += gx * (-2.f * (X - box[0]) / (bw * bw));
-      b1 += gy * (2.f * (Y - box[3]) / (bh * bh));
-      b3 += gy * (-2.f * (Y - box[1]) / (bh * bh));
-    }
+    const float ds = Go[px];
+    // corner values with zero padding; a corner outside the map contributes nothing (ATen's
+    // grid_sampler backward skips it) while the other axis keeps its raw fraction
+    const bool xa = f.x0 >= 0 && f.x0 < Min, xb = f.x0 + 1 >= 0 && f.x0 + 1 < Min;
+    const bool ya = f.y0 >= 0 && f.y0 < Min, yb = f.y0 + 1 >= 0 && f.y0 + 1 < Min;
+    const float fx = f.tx, fy = f.ty;
+    float dix = 0.f, diy = 0.f;
+    if (xa && ya) { const float m = mask_at(mk, o, f.y0, f.x0);         dix -= m * (1.f - fy); diy -= m * (1.f - fx); }
+    if (xb && ya) { const float m = mask_at(mk, o, f.y0, f.x0 + 1);     dix += m * (1.f - fy); diy -= m * fx; }
+    if (xa && yb) { const float m = mask_at(mk, o, f.y0 + 1, f.x0);     dix -= m * fy;         diy += m * (1.f - fx); }
+    if (xb && yb) { const float m = mask_at(mk, o, f.y0 + 1, f.x0 + 1); dix += m * fy;         diy += m * fx; }
+    const float X = lin01(x, W), Y = lin01(y, H);
+    const float gx = ds * dix * mult, gy = ds * diy * mult;     // dL/d(grid x), dL/d(grid y)
+    b0 += gx * (2.f * (X - box[2]) / (bw * bw));
+    b2 += gx * (-2.f * (X - box[0]) / (bw * bw));
+    b1 += gy * (2.f * (Y - box[3]) / (bh * bh));
+    b3 += gy * (-2.f * (Y - box[1]) / (bh * bh));
   }
+  bp[tid] = b0; bp[256 + tid] = b1; bp[512 + tid] = b2; bp[768 + tid] = b3;
   __syncthreads();
-  if (dmasks)
-    for (int i = tid; i < M * M; i += 256) dmasks[(long long)o * M * M + i] = gm[i];
-  if (dboxes) {
-    bp[tid] = b0; bp[256 + tid] = b1; bp[512 + tid] = b2; bp[768 + tid] = b3;
-    __syncthreads();
-    if (tid < 4) {                           // fixed-order sum of the 256 thread partials
-      float s = 0.f;
-      for (int k = 0; k < 256; ++k) s += bp[tid * 256 + k];
-      dboxes[4LL * o + tid] = s;
-    }
+  if (tid < 4) {                           // fixed-order sum of the 256 thread partials
+    float s = 0.f;
+    for (int k = 0; k < 256; ++k) s += bp[tid * 256 + k];
+    dboxes[4LL * o + tid] = s;
   }
 }
 
@@ -555,7 +573,9 @@ int sg2im_layout_forward(const float* vecs, long long ld_vecs, const float* boxe
 }
 
 size_t sg2im_layout_backward_workspace(int n_objs, int dim, int height, int width) {
-  return sizeof(float) * (size_t)((height * width + BP - 1) / BP) * (size_t)n_objs * (size_t)dim;
+  const size_t vec_part = sizeof(float) * (size_t)((height * width + BP - 1) / BP) * (size_t)n_objs * (size_t)dim;
+  const size_t g_planes = sizeof(float) * (size_t)n_objs * (size_t)height * (size_t)width;   // mask / box gradients
+  return vec_part > g_planes ? vec_part : g_planes;
 }
 
 int sg2im_layout_backward(const float* dlayout, long long ld_dlayout, const float* vecs,
@@ -572,7 +592,8 @@ int sg2im_layout_backward(const float* dlayout, long long ld_dlayout, const floa
     if (!workspace) return SG2IM_ERR_ARG;
     const int n_tiles = (height * width + BP - 1) / BP;
     // objects that belong to no image (cannot happen with a valid obj_to_img) keep zero grads
-    if (hipMemsetAsync(workspace, 0, sg2im_layout_backward_workspace(n_objs, dim, height, width), stream) != hipSuccess)
+    const size_t vec_part = sizeof(float) * (size_t)((height * width + BP - 1) / BP) * (size_t)n_objs * (size_t)dim;
+    if (hipMemsetAsync(workspace, 0, vec_part, stream) != hipSuccess)
       return SG2IM_ERR_HIP;
     const int TC = dim < 256 ? dim : 256, TR = 256 / TC;
     const size_t lds = sizeof(float) * (size_t)BO * TR * TC;
@@ -584,10 +605,15 @@ int sg2im_layout_backward(const float* dlayout, long long ld_dlayout, const floa
                        n_tiles, n_objs, dim, d_vecs, ld_dvecs);
   }
   if (d_masks || d_boxes) {
-    if (!vecs || !obj_to_img || (d_masks && (!masks || mask_size < 1))) return SG2IM_ERR_ARG;
-    const size_t lds = sizeof(float) * (size_t)(dim + (d_masks ? mask_size * mask_size : 0) + (d_boxes ? 4 * 256 : 0));
-    hipLaunchKernelGGL(layout_bwd_masks_kernel, dim3(n_objs), dim3(256), lds, stream, dlayout, ld_dlayout, vecs,
-                       ld_vecs, boxes, mk, obj_to_img, dim, height, width, align_corners, d_masks, d_boxes);
+    if (!vecs || !obj_to_img || !workspace || (d_masks && (!masks || mask_size < 1))) return SG2IM_ERR_ARG;
+    // G_o(y, x) for all objects: [O][H*W] floats at the start of the workspace (the d_vecs partials,
+    // if any, were consumed by layout_bwd_reduce_kernel above - same stream)
+    const int HW = height * width;
+    dim3 gg((HW + 255) / 256, n_objs);
+    hipLaunchKernelGGL(layout_bwd_g_kernel, gg, dim3(256), 0, stream, dlayout, ld_dlayout, vecs, ld_vecs, obj_to_img,
+                       dim, HW, workspace);
+    hipLaunchKernelGGL(layout_bwd_masks_kernel, dim3(n_objs), dim3(256), 0, stream, workspace, boxes, mk, height, width,
+                       align_corners, d_masks, d_boxes);
   }
   return ok_or(hipGetLastError());
 }

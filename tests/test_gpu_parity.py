@@ -448,14 +448,9 @@ def test_graph_iteration_vg_style_and_aux_losses_match_eager():
   for use_graphs in (False, True):
     tr = Trainer(vocab, dev, use_graphs=use_graphs, **kw)
     runs.append([Trainer.losses_to_host(tr.step(batch)) for _ in range(5)])
-  # Two EAGER runs of this configuration already drift apart (1e-5 at step 3, up to ~1e-2 by step 5:
-  # summation-order noise in the mask gradient, then Adam turning noise-level gradients into +-lr
-  # steps - tools/vg_repro.py), so only the first steps are compared tightly.
+  # (no kernel on this path uses atomics either: the mask / box gradients are gathers)
   for i, (a, b) in enumerate(zip(*runs)):
-    assert set(a) == set(b)
-    tol = 5e-4 if i < 3 else 5e-2
-    for k in a:
-      assert abs(a[k] - b[k]) <= tol * max(1.0, abs(a[k])), (i, k, a[k], b[k])
+    assert a == b, (i, a, b)
 
 
 def test_generator_gradients_with_predicted_boxes():
