@@ -44,6 +44,8 @@ def parse():
   ap.add_argument('--no_roofline', action='store_true')
   ap.add_argument('--no_graphs', action='store_true', help='launch every kernel eagerly instead of hipGraph replay')
   ap.add_argument('--seed', type=int, default=0)
+  ap.add_argument('--style', default='coco', choices=['coco', 'vg'],
+                  help="'vg': VG-shape graphs without GT masks (BASELINE configs[2] shape, fp32) instead of the COCO headline workload")
   ap.add_argument('--dist_graphs', action='store_true', help='debug: hipGraph segments with collectives in between')
   ap.add_argument('--force_dist', action='store_true',
                   help='debug: 1-rank RCCL group with real all-reduces (exercises the N>1 code path on one GPU)')
@@ -94,9 +96,14 @@ def main():
   from sg2im_amd.trainer import Trainer
 
   S = args.image_size
-  vocab = make_vocab(184, 7)            # COCO-Stuff: 184 object ids incl. __image__, 7 predicates
-  cpu_batch = synthetic_batch(args.batch_size, image_size=(S, S), num_objs=184, num_preds=7, min_objs=3,
-                              max_objs=8, mask_size=16, style='coco', seed=args.seed + rank)
+  if args.style == 'vg':
+    vocab = make_vocab(179, 46)
+    cpu_batch = synthetic_batch(args.batch_size, image_size=(S, S), num_objs=179, num_preds=46, min_objs=3,
+                                max_objs=10, mask_size=16, style='vg', seed=args.seed + rank)
+  else:
+    vocab = make_vocab(184, 7)            # COCO-Stuff: 184 object ids incl. __image__, 7 predicates
+    cpu_batch = synthetic_batch(args.batch_size, image_size=(S, S), num_objs=184, num_preds=7, min_objs=3,
+                                max_objs=8, mask_size=16, style='coco', seed=args.seed + rank)
   batch = tuple(t.to(device) if torch.is_tensor(t) else t for t in cpu_batch)
   trainer = Trainer(vocab, device, generator_kwargs={'image_size': (S, S)}, world_size=world, seed=1234,
                     use_graphs=((not use_dist or args.dist_graphs) and not args.no_graphs))
@@ -174,8 +181,9 @@ def main():
       'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
       'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
       'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-      'config': {'workload': 'COCO-%d synthetic scene graphs (3-8 objects + __image__, <=16 triples per image), '
-                             'batch %d per GPU, full G + D_obj + D_img step with 3x Adam' % (S, args.batch_size),
+      'config': {'workload': ('COCO-%d synthetic scene graphs (3-8 objects + __image__, <=16 triples per image), '
+                              if args.style == 'coco' else 'VG-%d synthetic scene graphs (3-10 objects, no GT masks), ') % S +
+                             'batch %d per GPU, full G + D_obj + D_img step with 3x Adam' % args.batch_size,
                  'global_batch': args.batch_size * world, 'image_size': S,
                  'objects': int(batch[1].numel()), 'triples': int(batch[4].size(0)),
                  'parallelism': 'dp%d' % world, 'total_loss': round(host_losses['total_loss'], 5),
