@@ -149,6 +149,9 @@ def main():
     summ = ops.TIMER.summary()
     crn = ops.TIMER.summary('crn')       # the launches of the refinement network alone
     ops.TIMER = None
+    hbm = {k[4:]: v for k, v in summ.items() if k.startswith('hbm_')}       # the HBM-bound kernels
+    summ = {k: v for k, v in summ.items() if not k.startswith('hbm_')}
+    crn = {k: v for k, v in crn.items() if not k.startswith('hbm_')}
     flops = sum(v['flops'] for v in summ.values())
     ms = sum(v['ms'] for v in summ.values())
     launches = sum(v['launches'] for v in summ.values())
@@ -163,6 +166,12 @@ def main():
                                  'tflops': round(f / (m * 1e-3) / 1e12, 2) if m > 0 else 0.0,
                                  'frac': round(f / (m * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if m > 0 else 0.0})(
                     sum(v['flops'] for v in crn.values()), sum(v['ms'] for v in crn.values())),
+      # second roofline: kernels bound by HBM bandwidth, algorithmic bytes / event time
+      'hbm_bound': {k: {'launches_per_step': v['launches'] // n_prof, 'mbytes_per_launch': round(v['flops'] / v['launches'] / 1e6, 2),
+                        'us_per_launch': round(v['ms'] / v['launches'] * 1e3, 1),
+                        'gb_per_s': round(v['flops'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] > 0 else 0.0,
+                        'frac_of_8TBps': round(v['flops'] / (v['ms'] * 1e-3) / 8e12, 4) if v['ms'] > 0 else 0.0}
+                    for k, v in hbm.items()},
       'by_kind': {k: {'launches_per_step': v['launches'] // n_prof, 'gflop_per_step': round(v['flops'] / n_prof / 1e9, 1),
                       'ms_per_step': round(v['ms'] / n_prof, 3),
                       'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else 0.0}

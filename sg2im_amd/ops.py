@@ -230,8 +230,12 @@ def segment_sum(src_a, src_b, csr, width, average, out, accumulate=False):
   pa, lda = rows_ld(src_a)
   pb, ldb = rows_ld(src_b) if src_b is not None else (None, 0)
   po, ldo = rows_ld(out)
-  call('sg2im_segment_sum', pa, lda, csr.n_a, pb, ldb, _i32(csr.row_ptr), _i32(csr.entries), csr.n_rows,
-       int(width), int(average), int(accumulate), po, ldo, _stream())
+  # algorithmic bytes: every entry row read once, every destination row written once, the CSR read
+  n_entries = src_a.size(0) + (src_b.size(0) if src_b is not None else 0)
+  nbytes = 4.0 * (n_entries * width + csr.n_rows * width + n_entries + csr.n_rows + 1)
+  _timed('hbm_pool_segment_sum', nbytes, lambda: call(
+    'sg2im_segment_sum', pa, lda, csr.n_a, pb, ldb, _i32(csr.row_ptr), _i32(csr.entries), csr.n_rows,
+    int(width), int(average), int(accumulate), po, ldo, _stream()))
   return out
 
 
@@ -266,9 +270,12 @@ def layout_forward(vecs, boxes, masks, img_csr, n_images, H, W, align_corners, o
   """out: NHWC (N,H,W,ld) tensor; channels [0, D) are written."""
   pv, ldv = rows_ld(vecs)
   mf, mi, M = _mask_args(masks)
-  call('sg2im_layout_forward', pv, ldv, _f(boxes), mf, mi, M, _i32(img_csr.row_ptr), _i32(img_csr.entries),
-       int(n_images), vecs.size(0), vecs.size(1), int(H), int(W), int(align_corners), _f(out), out.size(3),
-       _stream())
+  O, D = vecs.size(0), vecs.size(1)
+  # algorithmic bytes (SURVEY.md 8d): the layout written once + vectors, boxes and masks read once
+  nbytes = 4.0 * (n_images * H * W * D + O * (D + 4 + M * M))
+  _timed('hbm_layout_fwd', nbytes, lambda: call(
+    'sg2im_layout_forward', pv, ldv, _f(boxes), mf, mi, M, _i32(img_csr.row_ptr), _i32(img_csr.entries),
+    int(n_images), O, D, int(H), int(W), int(align_corners), _f(out), out.size(3), _stream()))
   return out
 
 
@@ -457,5 +464,7 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, gra
 def adam_step_guarded(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, state, guard, grad_scale=1.0):
   """Adam with the step counter in ``state`` (float[4] on the device); skipped entirely
   when ``guard`` (a device scalar, e.g. the generator loss) is not finite."""
-  call('sg2im_adam_step_guarded', _f(param), _f(grad), _f(exp_avg), _f(exp_avg_sq), param.numel(), float(lr),
-       float(beta1), float(beta2), float(eps), float(grad_scale), _f(state), _f(guard), _stream())
+  # algorithmic bytes: p, g, m, v read + p, m, v written (SURVEY.md 8a row 15)
+  _timed('hbm_adam', 28.0 * param.numel(), lambda: call(
+    'sg2im_adam_step_guarded', _f(param), _f(grad), _f(exp_avg), _f(exp_avg_sq), param.numel(), float(lr),
+    float(beta1), float(beta2), float(eps), float(grad_scale), _f(state), _f(guard), _stream()))
