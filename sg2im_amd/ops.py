@@ -56,13 +56,18 @@ def _i32(t):
 
 TAIL_EVENT = None   # optional torch.cuda.Event recorded when the generator backward reaches ...
 TAIL_EVENT_AT = -1  # ... refinement module TAIL_EVENT_AT (counting down), or the layout (-1)
-LANE = 0       # execution lane of the caller: work captured on a side stream (Trainer's
-               # overlapped discriminator steps) sets LANE = 1 and gets its own split-K
-               # workspace / reduction scratch, so concurrently running lanes never share them
+def _lane(device):
+  """Work buffers are per (device, stream): kernels of one in-order stream use them one after
+  the other, concurrently running streams (the Trainer's side stream, autograd branches that
+  ran their forward on it) never share them.  Inside graph capture the same holds per captured
+  stream."""
+  if _raw_stream is not None:
+    return (device.index, _raw_stream(device.index))
+  return (device.index, torch.cuda.current_stream(device).cuda_stream)
 
 
 def workspace(device):
-  key = (device.index, LANE)  # one in-order stream per lane uses it (also inside graph capture)
+  key = _lane(device)
   w = _ws.get(key)
   if w is None:
     w = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
@@ -71,8 +76,8 @@ def workspace(device):
 
 
 def scratch(device, nfloats):
-  """Reduction scratch (per device and lane), grown on demand."""
-  key = (device.index, LANE)
+  """Reduction scratch (per device and stream), grown on demand."""
+  key = _lane(device)
   s = _scratch.get(key)
   if s is None or s.numel() < nfloats:
     s = torch.empty(max(int(nfloats), 1 << 20), dtype=torch.float32, device=device)

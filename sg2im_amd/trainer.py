@@ -235,11 +235,7 @@ class Trainer(object):
     self._seg_generator_forward(batch, st)
     side.wait_stream(main)
     with torch.cuda.stream(side):
-      ops.LANE = 2
-      try:
-        self._seg_d_img(batch, st)
-      finally:
-        ops.LANE = 0
+      self._seg_d_img(batch, st)
     self._seg_generator_backward(st)
     main.wait_stream(side)
 
@@ -259,18 +255,14 @@ class Trainer(object):
     red.start(self.flat_g.grad)
     red.start(st['guard'])
     with torch.cuda.stream(side):
-      ops.LANE = 1
-      try:
-        for t in (st['imgs_fake'], st['imgs_nhwc']):
-          t.record_stream(side)
-        if self.d_obj is not None:
-          self._seg_d_obj(batch, st)
-          red.start(self.flat_do.grad)
-        if self.d_img is not None:
-          self._seg_d_img(batch, st)
-          red.start(self.flat_di.grad)
-      finally:
-        ops.LANE = 0
+      for t in (st['imgs_fake'], st['imgs_nhwc']):
+        t.record_stream(side)
+      if self.d_obj is not None:
+        self._seg_d_obj(batch, st)
+        red.start(self.flat_do.grad)
+      if self.d_img is not None:
+        self._seg_d_img(batch, st)
+        red.start(self.flat_di.grad)
     main.wait_stream(side)
     red.finish()
     self._seg_adam(st)
@@ -359,7 +351,7 @@ class Trainer(object):
   def _capture_overlapped(self, key, static, st):
     """One graph for the whole iteration (single GPU): generator forward, then a fork - the
     generator's backward on the capture stream, the discriminator steps on a side stream (own
-    split-K workspace / scratch: ops.LANE) - joined before the three Adam updates."""
+    split-K workspace / scratch, which ops keys by stream) - joined before the three Adam updates."""
     from . import ops
     if self._side is None:
       import os
@@ -380,11 +372,7 @@ class Trainer(object):
         else:
           side.wait_stream(main)
         with torch.cuda.stream(side):
-          ops.LANE = lane
-          try:
-            seg(static, st)
-          finally:
-            ops.LANE = 0
+          seg(static, st)
       # Schedule (measured; SG2IM_SCHEDULE selects the variants that were
       # compared): right after the generator forward the side stream runs the D_img step next to the
       # refinement network's backward; the D_obj step is held back until the generator backward
