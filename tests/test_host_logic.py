@@ -146,3 +146,33 @@ def test_train_script_keeps_the_reference_flag_surface():
   if os.path.exists(ref_path):
     ref = set(re.findall(r"add_argument\('(--\w+)'", open(ref_path).read()))
     assert not (ref - mine), sorted(ref - mine)
+
+
+def test_launch_planner_choices_are_valid_without_a_gpu():
+  """The launch planner is host code inside libsg2im_hip.so: tools/plan_dump.py drives the three conv entry
+  points with dummy pointers (the launches themselves fail without a GPU) and SG2IM_PLAN_DEBUG prints the
+  chosen tile / split-K per layer.  Every plan must use one of the four tiles, a split count within the
+  reduction length, and the big CRN layers must not fall back to the 64x64 tile."""
+  import re
+  import subprocess
+  import sys
+  tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools')
+  out = subprocess.run([sys.executable, os.path.join(tools, 'plan_dump.py')], cwd=tools, capture_output=True,
+                       text=True, timeout=300).stderr
+  plans = {}
+  cur = None
+  for line in out.splitlines():
+    m = re.match(r'== (\S+) (\S+)', line)
+    if m:
+      cur = (m.group(1), m.group(2))
+    m = re.match(r'\[sg2im plan\] M=(\d+) N=(\d+) iters=(\d+) -> (\d+)x(\d+) x(\d+)', line)
+    if m and cur:
+      plans[cur] = tuple(int(v) for v in m.groups())
+  assert len(plans) >= 60, len(plans)
+  for (layer, what), (M, N, iters, bm, bn, ns) in plans.items():
+    assert (bm, bn) in ((128, 128), (128, 64), (64, 64), (64, 128)), (layer, what, bm, bn)
+    assert 1 <= ns <= max(1, iters), (layer, what, ns, iters)
+  for layer in ('m1.conv0', 'm2.conv0', 'm3.conv0', 'm4.conv0'):
+    for what in ('fwd', 'dgrad', 'wgrad'):
+      bm, bn = plans[(layer, what)][3:5]
+      assert bm * bn > 64 * 64, (layer, what, bm, bn)
