@@ -61,9 +61,10 @@ def _lane(device):
   the other, concurrently running streams (the Trainer's side stream, autograd branches that
   ran their forward on it) never share them.  Inside graph capture the same holds per captured
   stream."""
+  idx = device.index if device.index is not None else torch.cuda.current_device()
   if _raw_stream is not None:
-    return (device.index, _raw_stream(device.index))
-  return (device.index, torch.cuda.current_stream(device).cuda_stream)
+    return (idx, _raw_stream(idx))
+  return (idx, torch.cuda.current_stream(idx).cuda_stream)
 
 
 def workspace(device):
