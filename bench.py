@@ -46,7 +46,6 @@ def parse():
   ap.add_argument('--seed', type=int, default=0)
   ap.add_argument('--style', default='coco', choices=['coco', 'vg'],
                   help="'vg': VG-shape graphs without GT masks (BASELINE configs[2] shape, fp32) instead of the COCO headline workload")
-  ap.add_argument('--dist_graphs', action='store_true', help='debug: hipGraph segments with collectives in between')
   ap.add_argument('--force_dist', action='store_true',
                   help='debug: 1-rank RCCL group with real all-reduces (exercises the N>1 code path on one GPU)')
   return ap.parse_args()
@@ -106,9 +105,9 @@ def main():
                                 max_objs=8, mask_size=16, style='coco', seed=args.seed + rank)
   batch = tuple(t.to(device) if torch.is_tensor(t) else t for t in cpu_batch)
   trainer = Trainer(vocab, device, generator_kwargs={'image_size': (S, S)}, world_size=world, seed=1234,
-                    use_graphs=((not use_dist or args.dist_graphs) and not args.no_graphs))
-  # (data-parallel runs launch eagerly by default: the graph schedule of the DP step, --dist_graphs,
-  # works in a 1-rank RCCL group but could not be exercised on several GPUs - see DESIGN.md section 6)
+                    use_graphs=not args.no_graphs)
+  # (data parallel: the same overlapped graph without its Adam updates, the four all-reduces issued
+  # eagerly, then an Adam graph - DESIGN.md section 6; --no_graphs selects the eager segments)
   trainer_graphs = trainer.use_graphs
   if args.force_dist:
     trainer.reducer.force = True
@@ -197,7 +196,7 @@ def main():
                  'objects': int(batch[1].numel()), 'triples': int(batch[4].size(0)),
                  'parallelism': 'dp%d' % world, 'total_loss': round(host_losses['total_loss'], 5),
                  'launch': ('eager' if not trainer_graphs else 'hipGraph replay (one graph, D steps on a side stream)' if not use_dist
-                            else 'hipGraph replay (DP segments)')},
+                            else 'hipGraph replay (iteration graph + eager all-reduces + Adam graph)')},
       'roofline': roofline, 'cpu_baseline': cpu,
     }
   if use_dist:
