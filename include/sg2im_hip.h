@@ -178,6 +178,12 @@ int sg2im_bn_act_backward(const float* g, long long ld_g, int pool2, int batch, 
                           const float* shift, float slope, int training, float* dy,
                           float* dgamma, float* dbeta, int accumulate, float* partial,
                           hipStream_t stream);
+/* out[r][c] = leaky_slope(scale[c] * x[r][c] + shift[c]): BatchNorm-apply + activation that must be
+ * materialised - BatchNorm1d + ReLU inside build_mlp (sg2im/layers.py:216-232 with batch_norm='batch')
+ * when the result feeds a gather / pooling instead of another GEMM's loader. */
+int sg2im_affine_act_forward(const float* x, long long ld_x, long long rows, int channels, const float* scale,
+                             const float* shift, float slope, float* out, long long ld_out,
+                             hipStream_t stream);
 /* dx = g * leaky'(y): backward of a fused output activation (y is the activated output for
  * slope >= 0: sign(y) == sign(pre-activation)); pool2 as above. */
 int sg2im_act_backward(const float* g, long long ld_g, int pool2, int batch, int h, int w,

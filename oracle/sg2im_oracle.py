@@ -49,18 +49,24 @@ def activation_slope(name):
   return slope
 
 
-def mlp(P, prefix, x, n_linear=2):
-  """sg2im/layers.py:216-232 with the defaults the model uses (activation='relu',
-  batch_norm='none', final_nonlinearity=True): Linear-ReLU-...-Linear-ReLU.  With
-  no BatchNorm1d the Sequential indices of the Linear layers are 0, 2, 4, ..."""
+def mlp(P, prefix, x, n_linear=2, training=True):
+  """sg2im/layers.py:216-232 with activation='relu', final_nonlinearity=True:
+  Linear [-BatchNorm1d] -ReLU per layer.  Without BatchNorm1d (batch_norm='none', the
+  default) the Sequential indices of the Linear layers are 0, 2, 4, ...; with it
+  (batch_norm='batch', layers.py:224-225) they are 0, 3, 6, ... and the norm of layer i sits
+  at 3i+1.  Which one applies is read off the parameter names."""
+  with_bn = ('%s.1.weight' % prefix) in P
   for i in range(n_linear):
-    k = 2 * i
-    x = F.relu(F.linear(x, P['%s.%d.weight' % (prefix, k)], P['%s.%d.bias' % (prefix, k)]))
+    k = 3 * i if with_bn else 2 * i
+    x = F.linear(x, P['%s.%d.weight' % (prefix, k)], P['%s.%d.bias' % (prefix, k)])
+    if with_bn:
+      x = batch_norm(P, '%s.%d' % (prefix, k + 1), x, training)
+    x = F.relu(x)
   return x
 
 
 def batch_norm(P, prefix, x, training):
-  """nn.BatchNorm2d forward (sg2im/layers.py:26).  In training mode the running
+  """nn.BatchNorm2d / nn.BatchNorm1d forward (sg2im/layers.py:26, 225).  In training mode the running
   statistics in ``P`` are updated in place, like the module does."""
   rm, rv = P.get(prefix + '.running_mean'), P.get(prefix + '.running_var')
   y = F.batch_norm(x, rm, rv, P[prefix + '.weight'], P[prefix + '.bias'],
@@ -121,15 +127,15 @@ def gconv_pool_sequential(new_t, s_idx, o_idx, O, H, Dout, pooling='avg'):
 
 
 def graph_triple_conv(P, prefix, obj_vecs, pred_vecs, edges, hidden_dim, out_dim,
-                      pooling='avg'):
+                      pooling='avg', training=True):
   """sg2im/graph.py:56-120 (one GraphTripleConv layer)."""
   O = obj_vecs.size(0)
   s_idx = edges[:, 0].contiguous()
   o_idx = edges[:, 1].contiguous()
   triple_in = torch.cat([obj_vecs[s_idx], pred_vecs, obj_vecs[o_idx]], dim=1)
-  new_t = mlp(P, prefix + '.net1', triple_in)
+  new_t = mlp(P, prefix + '.net1', triple_in, training=training)
   pooled, new_p = gconv_pool(new_t, s_idx, o_idx, O, hidden_dim, out_dim, pooling)
-  new_obj = mlp(P, prefix + '.net2', pooled)
+  new_obj = mlp(P, prefix + '.net2', pooled, training=training)
   return new_obj, new_p
 
 
@@ -285,11 +291,11 @@ def generator_forward(P, cfg, objs, triples, obj_to_img=None, boxes_gt=None,
   if L == 0:
     obj_vecs = F.linear(obj_vecs, P['gconv.weight'], P['gconv.bias'])   # model.py:53-54
   else:
-    obj_vecs, pred_vecs = graph_triple_conv(P, 'gconv', obj_vecs, pred_vecs, edges, Hd, Dg, pooling)
+    obj_vecs, pred_vecs = graph_triple_conv(P, 'gconv', obj_vecs, pred_vecs, edges, Hd, Dg, pooling, training)
   for i in range(L - 1):
     obj_vecs, pred_vecs = graph_triple_conv(P, 'gconv_net.gconvs.%d' % i, obj_vecs,
-                                            pred_vecs, edges, Hd, Dg, pooling)
-  boxes_pred = mlp(P, 'box_net', obj_vecs)
+                                            pred_vecs, edges, Hd, Dg, pooling, training)
+  boxes_pred = mlp(P, 'box_net', obj_vecs, training=training)
 
   masks_pred = None
   mask_size = cfg.get('mask_size', None)
@@ -297,7 +303,7 @@ def generator_forward(P, cfg, objs, triples, obj_to_img=None, boxes_gt=None,
     masks_pred = mask_net(P, 'mask_net', obj_vecs, mask_size, training)
 
   rel_in = torch.cat([boxes_pred[s], boxes_pred[o], obj_vecs_orig[s], obj_vecs_orig[o]], dim=1)
-  rel_scores = mlp(P, 'rel_aux_net', rel_in)
+  rel_scores = mlp(P, 'rel_aux_net', rel_in, training=training)
 
   H, W = cfg.get('image_size', (64, 64))
   layout_boxes = boxes_pred if boxes_gt is None else boxes_gt
@@ -587,19 +593,24 @@ def init_generator_params(cfg, seed=0, randomize_bn=False):
   P = {}
   P['obj_embeddings.weight'] = torch.randn(C + 1, E, generator=g)      # model.py:50
   P['pred_embeddings.weight'] = torch.randn(Pn, E, generator=g)
+  mbn = cfg.get('mlp_normalization', 'none') == 'batch'
+  def mlp2(prefix, d0, d1, d2, kaiming=False):
+    """build_mlp([d0, d1, d2], batch_norm=mlp_normalization) parameter names"""
+    step = 3 if mbn else 2
+    for i, (din, dout) in enumerate(((d0, d1), (d1, d2))):
+      _lin(P, '%s.%d' % (prefix, step * i), dout, din, g, kaiming)
+      if mbn:
+        _bn(P, '%s.%d' % (prefix, step * i + 1), dout, g, randomize_bn)
   def gconv(prefix, din, dout):
-    _lin(P, prefix + '.net1.0', Hd, 3 * din, g, True)
-    _lin(P, prefix + '.net1.2', 2 * Hd + dout, Hd, g, True)
-    _lin(P, prefix + '.net2.0', Hd, Hd, g, True)
-    _lin(P, prefix + '.net2.2', dout, Hd, g, True)
+    mlp2(prefix + '.net1', 3 * din, Hd, 2 * Hd + dout, True)
+    mlp2(prefix + '.net2', Hd, Hd, dout, True)
   if L == 0:
     _lin(P, 'gconv', Dg, E, g)
   else:
     gconv('gconv', E, Dg)
   for i in range(L - 1):
     gconv('gconv_net.gconvs.%d' % i, Dg, Dg)
-  _lin(P, 'box_net.0', Hd, Dg, g)
-  _lin(P, 'box_net.2', 4, Hd, g)
+  mlp2('box_net', Dg, Hd, 4)
   ms = cfg.get('mask_size', None)
   if ms is not None and ms > 0:
     size, b = 1, 0
@@ -609,8 +620,7 @@ def init_generator_params(cfg, seed=0, randomize_bn=False):
       size *= 2
       b += 1
     _conv(P, 'mask_net.%d' % (4 * b), 1, Dg, 1, g)
-  _lin(P, 'rel_aux_net.0', Hd, 2 * E + 8, g)
-  _lin(P, 'rel_aux_net.2', Pn, Hd, g)
+  mlp2('rel_aux_net', 2 * E + 8, Hd, Pn)
   dims = (Dg + cfg.get('layout_noise_dim', 0),) + tuple(cfg.get('refinement_dims', (1024, 512, 256, 128, 64)))
   for i in range(1, len(dims)):
     cin = 1 if i == 1 else dims[i - 1]

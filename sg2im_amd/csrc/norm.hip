@@ -184,6 +184,20 @@ __global__ void act_bwd_kernel(GradSrc gs, const float* __restrict__ y, long lon
   }
 }
 
+// out = leaky_slope(scale[c] * x + shift[c]): a normalisation + activation that has to be
+// materialised (BatchNorm1d + ReLU of an MLP whose output feeds a gather / pooling, not a GEMM)
+__global__ void affine_act_kernel(const float* __restrict__ x, long long ld_x, long long rows, int C,
+                                  const float* __restrict__ scale, const float* __restrict__ shift, float slope,
+                                  float* __restrict__ out, long long ld_out) {
+  const long long total = rows * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / C; const int c = (int)(i - r * C);
+    const float v = fmaf(x[r * ld_x + c], scale[c], shift[c]);
+    out[r * ld_out + c] = v > 0.f ? v : v * slope;
+  }
+}
+
 __global__ void avgpool_kernel(const float* __restrict__ x, int B, int H, int W, int C, int f,
                                float* __restrict__ out) {
   const int Ho = H / f, Wo = W / f;
@@ -536,6 +550,16 @@ int sg2im_act_backward(const float* g, long long ld_g, int pool2, int batch, int
   else
     hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(rows * channels)), dim3(256), 0, stream, gs, y, ld_y, rows,
                        channels, slope, dx);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_affine_act_forward(const float* x, long long ld_x, long long rows, int channels, const float* scale,
+                             const float* shift, float slope, float* out, long long ld_out,
+                             hipStream_t stream) {
+  if (!x || !scale || !shift || !out || channels < 1 || rows < 0) return SG2IM_ERR_ARG;
+  if (rows == 0) return SG2IM_OK;
+  hipLaunchKernelGGL(affine_act_kernel, dim3(ew_blocks(rows * channels)), dim3(256), 0, stream, x, ld_x, rows, channels,
+                     scale, shift, slope, out, ld_out);
   return ok_or(hipGetLastError());
 }
 

@@ -125,23 +125,26 @@ class LinearAct(Function):
   """y = leaky_slope(x W^T + b)   (nn.Linear [+ ReLU], reference sg2im/layers.py:216-232)"""
 
   @staticmethod
-  def forward(ctx, x, W, b, slope):
+  def forward(ctx, x, W, b, slope, shadowed=False):
+    """shadowed: a training-mode BatchNorm consumes y, so db is exactly zero (_shadowed_bias_grad)"""
     M, K = x.shape
     N = W.size(0)
     desc = conv_desc([rows_src(x)], M, 1, 1)
     y = ops.conv2d_forward(desc, W, N, b, _new(x, M, N), N, slope)
     ctx.save_for_backward(x, W, y, b)
-    ctx.slope = slope
+    ctx.slope, ctx.shadowed = slope, shadowed
     return y
 
   @staticmethod
   def backward(ctx, g):
     x, W, y, b = ctx.saved_tensors
+    ni = ctx.needs_input_grad
     dpre = _act_bwd_rows(g, y, ctx.slope)
     desc = conv_desc([rows_src(x)], x.size(0), 1, 1)
-    dx, dw, db = _linear_bwd(desc, W, dpre, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                             ctx.needs_input_grad[2], x.size(1), b)
-    return dx, dw, db, None
+    dx, dw, db = _linear_bwd(desc, W, dpre, ni[0], ni[1], ni[2] and not ctx.shadowed, x.size(1), b)
+    if ctx.shadowed:
+      db = _shadowed_bias_grad(b, ni[2])
+    return dx, dw, db, None, None
 
 
 class Mlp2(Function):
@@ -169,6 +172,127 @@ class Mlp2(Function):
     d1 = conv_desc([rows_src(x)], M, 1, 1)
     dx, dW1, db1 = _linear_bwd(d1, W1, dp1, ni[0], ni[1], ni[2], x.size(1), b1)
     return dx, dW1, db1, dW2, db2
+
+
+# ---- composable pieces for MLPs with BatchNorm1d (build_mlp(batch_norm='batch'), reference
+# sg2im/layers.py:216-232).  The default configuration has no norm and runs through the fused
+# Mlp2 / GraphTripleConvFn / RelAux above; with a BatchNorm between every Linear and its ReLU the
+# layers are chained from these instead: LinearAct(slope=1) -> BnActRows -> ...
+
+class BnActRows(Function):
+  """z = relu(batch_norm_1d(y)) materialised, y: (rows, C)"""
+
+  @staticmethod
+  def forward(ctx, y, bn, training, gamma, beta):
+    y = y.contiguous()
+    st = ops.bn_stats(y, y.size(0), y.size(1), y.size(1), bn, training, BN_EPS, BN_MOMENTUM)
+    z = ops.affine_act_forward(y, st, 0.0, _new(y, *y.shape))
+    ctx.save_for_backward(y, gamma, beta)
+    ctx.st, ctx.training = st, training
+    return z
+
+  @staticmethod
+  def backward(ctx, g):
+    y, gamma, beta = ctx.saved_tensors
+    rows, C = y.shape
+    g = g.contiguous()
+    ni = ctx.needs_input_grad
+    dgam, dbet, acc, ggam, gbet = _bn_grad_bufs(g, C, gamma, beta, ni[3], ni[4])
+    dy = ops.bn_act_backward(_fptr(g), C, 0, rows, 1, 1, y, C, C, gamma, ctx.st, 0.0, ctx.training,
+                             _new(g, rows, C), dgam, dbet, acc)
+    return dy, None, None, ggam, gbet
+
+
+class TripleLinear(Function):
+  """W [obj[s], pred, obj[o]] + b for every triple (the first Linear of GraphTripleConv.net1,
+  reference sg2im/graph.py:73-83), no activation; the gather + concat is the GEMM's loader."""
+
+  @staticmethod
+  def forward(ctx, obj_vecs, pred_vecs, s_idx, o_idx, csr, W, b, shadowed=False):
+    T = pred_vecs.size(0)
+    obj_vecs, pred_vecs = obj_vecs.contiguous(), pred_vecs.contiguous()
+    d = conv_desc([rows_src(obj_vecs, s_idx), rows_src(pred_vecs), rows_src(obj_vecs, o_idx)], T, 1, 1)
+    y = ops.conv2d_forward(d, W, W.size(0), b, _new(obj_vecs, T, W.size(0)), W.size(0))
+    ctx.save_for_backward(obj_vecs, pred_vecs, s_idx, o_idx, W, b)
+    ctx.csr, ctx.shadowed = csr, shadowed
+    return y
+
+  @staticmethod
+  def backward(ctx, g):
+    obj_vecs, pred_vecs, s_idx, o_idx, W, b = ctx.saved_tensors
+    T, Din, O = pred_vecs.size(0), obj_vecs.size(1), obj_vecs.size(0)
+    ni = ctx.needs_input_grad
+    d = conv_desc([rows_src(obj_vecs, s_idx), rows_src(pred_vecs), rows_src(obj_vecs, o_idx)], T, 1, 1)
+    dX, dW, db = _linear_bwd(d, W, g.contiguous(), ni[0] or ni[1], ni[5], ni[6] and not ctx.shadowed, 3 * Din, b)
+    if ctx.shadowed:
+      db = _shadowed_bias_grad(b, ni[6])
+    d_obj = d_pred = None
+    if ni[0]:
+      d_obj = ops.segment_sum(dX[:, :Din], dX[:, 2 * Din:], ctx.csr, Din, False, _new(obj_vecs, O, Din))
+    if ni[1]:
+      d_pred = dX[:, Din:2 * Din]
+    return d_obj, d_pred, None, None, None, dW, db, None
+
+
+class TriplePool(Function):
+  """pooled[j] = sum / avg of new_t[t, :H] over s_t = j and new_t[t, H+Dout:] over o_t = j
+  (reference sg2im/graph.py:87-114), plus the predicate slice new_t[:, H:H+Dout]."""
+
+  @staticmethod
+  def forward(ctx, new_t, s_idx, o_idx, csr, avg, H, Dout, O):
+    pooled = ops.segment_sum(new_t[:, :H], new_t[:, H + Dout:], csr, H, avg, _new(new_t, O, H))
+    ctx.save_for_backward(s_idx, o_idx)
+    ctx.misc = (csr, avg, H, Dout, tuple(new_t.shape))
+    return pooled, new_t[:, H:H + Dout].contiguous()
+
+  @staticmethod
+  def backward(ctx, g_pooled, g_pred):
+    s_idx, o_idx = ctx.saved_tensors
+    csr, avg, H, Dout, shape = ctx.misc
+    d = torch.zeros(shape, dtype=torch.float32, device=s_idx.device)
+    if g_pooled is not None:
+      g_pooled = g_pooled.contiguous()
+      cavg = csr if avg else None
+      ops.gather_rows(g_pooled, s_idx, d[:, :H], cavg)
+      ops.gather_rows(g_pooled, o_idx, d[:, H + Dout:], cavg)
+    if g_pred is not None:
+      ops.copy_2d(g_pred.contiguous(), d[:, H:H + Dout])
+    return d, None, None, None, None, None, None, None
+
+
+class RelAuxLinear(Function):
+  """W cat[boxes[s], boxes[o], vecs[s], vecs[o]] + b, no activation: the first Linear of
+  rel_aux_net (reference sg2im/model.py:149-152) when a BatchNorm1d follows it."""
+
+  @staticmethod
+  def _desc(boxes, vecs, s_idx, o_idx):
+    return conv_desc([rows_src(boxes, s_idx), rows_src(boxes, o_idx), rows_src(vecs, s_idx),
+                      rows_src(vecs, o_idx)], s_idx.numel(), 1, 1)
+
+  @staticmethod
+  def forward(ctx, boxes, vecs, s_idx, o_idx, csr, W, b, shadowed=False):
+    boxes, vecs = boxes.contiguous(), vecs.contiguous()
+    y = ops.conv2d_forward(RelAuxLinear._desc(boxes, vecs, s_idx, o_idx), W, W.size(0), b,
+                           _new(vecs, s_idx.numel(), W.size(0)), W.size(0))
+    ctx.save_for_backward(boxes, vecs, s_idx, o_idx, W, b)
+    ctx.csr, ctx.shadowed = csr, shadowed
+    return y
+
+  @staticmethod
+  def backward(ctx, g):
+    boxes, vecs, s_idx, o_idx, W, b = ctx.saved_tensors
+    E = vecs.size(1)
+    ni = ctx.needs_input_grad
+    dX, dW, db = _linear_bwd(RelAuxLinear._desc(boxes, vecs, s_idx, o_idx), W, g.contiguous(), ni[0] or ni[1],
+                             ni[5], ni[6] and not ctx.shadowed, 8 + 2 * E, b)
+    if ctx.shadowed:
+      db = _shadowed_bias_grad(b, ni[6])
+    d_boxes = d_vecs = None
+    if ni[0]:
+      d_boxes = ops.segment_sum(dX[:, 0:4], dX[:, 4:8], ctx.csr, 4, False, _new(vecs, boxes.size(0), 4))
+    if ni[1]:
+      d_vecs = ops.segment_sum(dX[:, 8:8 + E], dX[:, 8 + E:], ctx.csr, E, False, _new(vecs, vecs.size(0), E))
+    return d_boxes, d_vecs, None, None, None, dW, db, None
 
 
 class Embedding(Function):

@@ -44,6 +44,14 @@ class GraphTripleConv(nn.Module):
     s_idx, o_idx, csr = edges
     a, b = self.net1.linears()
     c, d = self.net2.linears()
+    if self.net1.norms():              # mlp_normalization='batch': chained from the composable pieces
+      H, Dout = self.hidden_dim, self.output_dim
+      t = self.net1.tail(HF.TripleLinear.apply(obj_vecs, pred_vecs, s_idx, o_idx, csr, a.weight, a.bias,
+                                                  self.training), 0)
+      new_t = self.net1.tail(HF.LinearAct.apply(t, b.weight, b.bias, 1.0, self.training), 1)
+      pooled, new_p = HF.TriplePool.apply(new_t, s_idx, o_idx, csr, self.pooling == 'avg', H, Dout,
+                                          obj_vecs.size(0))
+      return self.net2(pooled), new_p
     return HF.GraphTripleConvFn.apply(obj_vecs, pred_vecs, s_idx, o_idx, csr, self.pooling == 'avg',
                                       a.weight, a.bias, b.weight, b.bias, c.weight, c.bias, d.weight, d.bias)
 

@@ -60,8 +60,21 @@ class Mlp(nn.Sequential):
   def linears(self):
     return [m for m in self if isinstance(m, nn.Linear)]
 
+  def norms(self):
+    return [m for m in self if isinstance(m, nn.BatchNorm1d)]
+
+  def tail(self, y, i):
+    """what follows Linear i: [BatchNorm1d +] ReLU.  Only needed with batch norm - without it the
+    ReLU is fused into the GEMM epilogue by the callers."""
+    bn = self.norms()[i]
+    return HF.BnActRows.apply(y, bn, self.training, bn.weight, bn.bias)
+
   def forward(self, x):
     lin = self.linears()
+    if self.norms():                   # Linear, BatchNorm1d, ReLU, ...
+      for i, l in enumerate(lin):
+        x = self.tail(HF.LinearAct.apply(x, l.weight, l.bias, 1.0, self.training), i)
+      return x
     if len(lin) == 2:
       return HF.Mlp2.apply(x, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias)
     for l in lin:
@@ -70,12 +83,15 @@ class Mlp(nn.Sequential):
 
 
 def build_mlp(dim_list, activation='relu', batch_norm='none', dropout=0, final_nonlinearity=True):
-  if batch_norm != 'none' or dropout > 0 or activation != 'relu' or not final_nonlinearity:
-    raise NotImplementedError('only the build_mlp configuration the model uses is on the HIP path '
-                              '(relu, no norm, no dropout, final nonlinearity)')
+  """reference sg2im/layers.py:216-232: Linear [, BatchNorm1d], ReLU per layer"""
+  if batch_norm not in ('none', 'batch') or dropout > 0 or activation != 'relu' or not final_nonlinearity:
+    raise NotImplementedError('only the build_mlp configurations the model uses are on the HIP path '
+                              '(relu, batch_norm none/batch, no dropout, final nonlinearity)')
   layers = []
   for i in range(len(dim_list) - 1):
     layers.append(nn.Linear(dim_list[i], dim_list[i + 1]))
+    if batch_norm == 'batch':
+      layers.append(nn.BatchNorm1d(dim_list[i + 1]))
     layers.append(nn.ReLU())
   return Mlp(*layers)
 

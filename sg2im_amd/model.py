@@ -99,7 +99,12 @@ class Sg2ImModel(nn.Module):
       masks_pred = self._run_mask_net(obj_vecs)
 
     r1, r2 = self.rel_aux_net.linears()
-    rel_scores = HF.RelAux.apply(boxes_pred, obj_vecs_orig, s, o, edges[2], r1.weight, r1.bias, r2.weight, r2.bias)
+    if self.rel_aux_net.norms():       # mlp_normalization='batch'
+      h = self.rel_aux_net.tail(HF.RelAuxLinear.apply(boxes_pred, obj_vecs_orig, s, o, edges[2], r1.weight,
+                                                      r1.bias, self.training), 0)
+      rel_scores = self.rel_aux_net.tail(HF.LinearAct.apply(h, r2.weight, r2.bias, 1.0, self.training), 1)
+    else:
+      rel_scores = HF.RelAux.apply(boxes_pred, obj_vecs_orig, s, o, edges[2], r1.weight, r1.bias, r2.weight, r2.bias)
 
     H, W = self.image_size
     layout_boxes = boxes_pred if boxes_gt is None else boxes_gt

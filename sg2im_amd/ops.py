@@ -350,6 +350,15 @@ def bn_act_backward(g, ld_g, pool2, batch, h, w, y, ld_y, C, gamma, st, slope, t
   return dy
 
 
+def affine_act_forward(x, st, slope, out):
+  """out = leaky_slope(st.scale * x + st.shift) for row matrices"""
+  px, ldx = rows_ld(x)
+  po, ldo = rows_ld(out)
+  call('sg2im_affine_act_forward', px, ldx, x.size(0), x.size(1), _f(st.scale), _f(st.shift), float(slope), po, ldo,
+       _stream())
+  return out
+
+
 def act_backward(g, ld_g, pool2, batch, h, w, y, ld_y, C, slope, dx):
   call('sg2im_act_backward', g, int(ld_g), int(pool2), int(batch), int(h), int(w), _f(y), int(ld_y), int(C),
        float(slope), _f(dx), _stream())

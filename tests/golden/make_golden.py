@@ -59,6 +59,18 @@ CONFIGS = {
     d_img=dict(arch='C3-8-2,C3-16-2,C3-16', normalization='none', activation='leakyrelu-0.2',
                padding='same'),
   ),
+  # BatchNorm1d inside every build_mlp (--mlp_normalization batch, sg2im/layers.py:224-225)
+  'tiny_coco_mlpbn': dict(
+    batch=dict(batch_size=4, image_size=(16, 16), num_objs=10, num_preds=4, min_objs=3,
+               max_objs=5, mask_size=4, style='coco', seed=53),
+    g=dict(image_size=(16, 16), embedding_dim=16, gconv_dim=16, gconv_hidden_dim=32,
+           gconv_num_layers=2, mlp_normalization='batch', refinement_dims=(24, 16),
+           normalization='batch', activation='leakyrelu-0.2', mask_size=4, layout_noise_dim=4),
+    d_obj=dict(arch='C4-8-2,C4-16-2', normalization='batch', activation='leakyrelu-0.2',
+               padding='valid', object_size=16),
+    d_img=dict(arch='C4-8-2,C4-16-2', normalization='batch', activation='leakyrelu-0.2',
+               padding='valid'),
+  ),
   # VG-style: no GT masks -> masks_pred feeds the layout and mask_net trains.
   'tiny_vg': dict(
     batch=dict(batch_size=2, image_size=(32, 32), num_objs=9, num_preds=6, min_objs=3,
@@ -102,7 +114,7 @@ def run_config(name, cfg):
   # non-trivial BN affine parameters so gamma/beta paths are exercised
   g = torch.Generator().manual_seed(99)
   for m in list(G.modules()) + list(Do.modules()) + list(Di.modules()):
-    if isinstance(m, torch.nn.BatchNorm2d):
+    if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
       m.weight.data = 0.5 + torch.rand(m.weight.shape, generator=g)
       m.bias.data = 0.2 * torch.randn(m.bias.shape, generator=g)
   for m in (G, Do, Di):
@@ -207,7 +219,7 @@ def run_eval_config(name, cfg):
   Di = quiet(PatchDiscriminator, **cfg['d_img'])
   g = torch.Generator().manual_seed(77)
   for m in list(G.modules()) + list(Do.modules()) + list(Di.modules()):
-    if isinstance(m, torch.nn.BatchNorm2d):
+    if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
       m.weight.data = 0.5 + torch.rand(m.weight.shape, generator=g)
       m.bias.data = 0.2 * torch.randn(m.bias.shape, generator=g)
       # running statistics as after some training: not the (0, 1) initial values
@@ -257,5 +269,5 @@ if __name__ == '__main__':
       continue
     if 'train' in which or only:
       run_config(n, c)
-    if 'eval' in which and 'nonorm' not in n:
+    if 'eval' in which and 'nonorm' not in n and 'mlpbn' not in n:
       run_eval_config(n, c)
