@@ -20,9 +20,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.distributed as dist
 
+from sg2im_amd import losses as L
+from sg2im_amd.metrics import jaccard
 from sg2im_amd.synthetic import make_vocab, synthetic_batch
 from sg2im_amd.trainer import Trainer
-from sg2im_amd.utils import bool_flag, int_tuple, str_tuple, timeit
+from sg2im_amd.utils import bool_flag, imagenet_deprocess_batch, int_tuple, str_tuple, timeit
 
 VG_DIR = os.path.expanduser('datasets/vg')
 COCO_DIR = os.path.expanduser('datasets/coco')
@@ -110,6 +112,59 @@ def check_args(args):
     raise ValueError('Too many layers in refinement network')      # reference train.py:153-158
 
 
+def calculate_model_losses(args, skip_pixel_loss, img, img_pred, bbox, bbox_pred, masks, masks_pred,
+                           predicates, predicate_scores):
+  """reference train.py:387-412 on the fused loss kernels; values come back as host floats"""
+  total, losses = None, {}
+  def add(name, v):
+    nonlocal total
+    total = v if total is None else total + v
+    losses[name] = v
+  if not skip_pixel_loss:
+    add('L1_pixel_loss', L.l1_loss(img_pred, img, args.l1_pixel_loss_weight))
+  add('bbox_pred', L.mse_loss(bbox_pred, bbox, args.bbox_pred_loss_weight))
+  if args.predicate_pred_loss_weight > 0:
+    add('predicate_pred', L.cross_entropy(predicate_scores, predicates, args.predicate_pred_loss_weight))
+  if args.mask_loss_weight > 0 and masks is not None and masks_pred is not None:
+    add('mask_loss', L.binary_cross_entropy(masks_pred, masks.float(), args.mask_loss_weight))
+  return total, {k: float(v) for k, v in losses.items()}
+
+
+def check_model(args, t, loader, model):
+  """reference train.py:309-384: mean losses and box IoU over ``num_val_samples`` images plus
+  sample images of the last batch under the three box / mask supervision modes.  The model is
+  run as it is during training (so training-mode BatchNorm keeps updating its running stats)."""
+  num_samples, total_iou, total_boxes = 0, 0.0, 0
+  all_losses = defaultdict(list)
+  with torch.no_grad():
+    for batch in loader:
+      imgs, objs, boxes, masks, triples, obj_to_img, triple_to_img = batch
+      predicates = triples[:, 1].contiguous()
+      N = imgs.size(0)
+      imgs_pred, boxes_pred, masks_pred, predicate_scores = model(objs, triples, obj_to_img, boxes_gt=boxes,
+                                                                  masks_gt=masks, num_images=N)
+      _, losses = calculate_model_losses(args, False, imgs, imgs_pred, boxes, boxes_pred, masks, masks_pred,
+                                         predicates, predicate_scores)
+      total_iou += float(jaccard(boxes_pred, boxes))
+      total_boxes += boxes_pred.size(0)
+      for name, val in losses.items():
+        all_losses[name].append(val)
+      num_samples += N
+      if num_samples >= args.num_val_samples:
+        break
+    samples = {'gt_img': imgs,
+               'gt_box_gt_mask': model(objs, triples, obj_to_img, boxes_gt=boxes, masks_gt=masks, num_images=N)[0],
+               'gt_box_pred_mask': model(objs, triples, obj_to_img, boxes_gt=boxes, num_images=N)[0],
+               'pred_box_pred_mask': model(objs, triples, obj_to_img, num_images=N)[0]}
+    samples = {k: imagenet_deprocess_batch(v) for k, v in samples.items()}
+  mean_losses = {k: sum(v) / len(v) for k, v in all_losses.items()}
+  host = lambda x: None if x is None else x.detach().cpu().clone()
+  batch_data = {'objs': host(objs), 'boxes_gt': host(boxes), 'masks_gt': host(masks), 'triples': host(triples),
+                'obj_to_img': host(obj_to_img), 'triple_to_img': host(triple_to_img),
+                'boxes_pred': host(boxes_pred), 'masks_pred': host(masks_pred)}
+  return mean_losses, samples, batch_data, total_iou / total_boxes
+
+
 def main(args):
   check_args(args)
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -141,20 +196,57 @@ def main(args):
     ck = torch.load(args.checkpoint_start_from, map_location='cpu', weights_only=False)
     sd = {(k[7:] if k.startswith('module.') else k): v for k, v in ck['model_state'].items()}
     trainer.model.load_state_dict(sd)
-  checkpoint = {'args': args.__dict__, 'vocab': vocab, 'model_kwargs': trainer.model_kwargs,
-                'd_obj_kwargs': trainer.d_obj_kwargs, 'd_img_kwargs': trainer.d_img_kwargs, 'losses_ts': [],
-                'losses': defaultdict(list), 'checkpoint_ts': [], 'counters': {'t': None, 'epoch': None}}
-  t, t0 = 0, time.time()
-  style = args.dataset
+
+  def batches(split, start):
+    """endless seeded synthetic stand-in for the train / val DataLoader"""
+    i = start
+    while True:
+      i += 1
+      seed = args.seed + 1000003 * i + rank + (0 if split == 'train' else 500000009)
+      cpu_batch = synthetic_batch(args.batch_size, image_size=args.image_size, num_objs=num_objs,
+                                  num_preds=num_preds, mask_size=max(args.mask_size, 1), style=args.dataset, seed=seed)
+      yield tuple(x.to(device, non_blocking=True) if torch.is_tensor(x) else x for x in cpu_batch)
+
+  sd_of = lambda m: None if m is None else m.state_dict()           # reference train.py:634-641
+  restore_path = None
+  if args.restore_from_checkpoint:                                  # reference train.py:445-467
+    restore_path = os.path.join(args.output_dir, '%s_with_model.pt' % args.checkpoint_name)
+  if restore_path is not None and os.path.isfile(restore_path):
+    print('Restoring from checkpoint:')
+    print(restore_path)
+    checkpoint = torch.load(restore_path, map_location='cpu', weights_only=False)
+    trainer.model.load_state_dict(checkpoint['model_state'])
+    trainer.opt_g.load_state_dict(checkpoint['optim_state'])
+    for d, opt, key in ((trainer.d_obj, trainer.opt_do, 'd_obj'), (trainer.d_img, trainer.opt_di, 'd_img')):
+      if d is not None:
+        d.load_state_dict(checkpoint[key + '_state'])
+        opt.load_state_dict(checkpoint[key + '_optim_state'])
+    t = checkpoint['counters']['t']
+    if 0 <= args.eval_mode_after <= t:
+      trainer.model.eval()
+    else:
+      trainer.model.train()
+    epoch = checkpoint['counters']['epoch']
+  else:
+    t, epoch = 0, 0
+    checkpoint = {'args': args.__dict__, 'vocab': vocab, 'model_kwargs': trainer.model_kwargs,
+                  'd_obj_kwargs': trainer.d_obj_kwargs, 'd_img_kwargs': trainer.d_img_kwargs, 'losses_ts': [],
+                  'losses': defaultdict(list), 'd_losses': defaultdict(list), 'checkpoint_ts': [],
+                  'train_batch_data': [], 'train_samples': [], 'train_iou': [], 'val_batch_data': [],
+                  'val_samples': [], 'val_losses': defaultdict(list), 'val_iou': [], 'norm_d': [], 'norm_g': [],
+                  'counters': {'t': None, 'epoch': None},
+                  'model_state': None, 'model_best_state': None, 'optim_state': None,
+                  'd_obj_state': None, 'd_obj_best_state': None, 'd_obj_optim_state': None,
+                  'd_img_state': None, 'd_img_best_state': None, 'd_img_optim_state': None, 'best_t': []}
+  t0 = time.time()
+  train_loader = batches('train', t)
   while t < args.num_iterations:
     if t == args.eval_mode_after:                                   # reference train.py:509-512
       if rank == 0:
         print('switching to eval mode')
       trainer.set_generator_eval()
     t += 1
-    cpu_batch = synthetic_batch(args.batch_size, image_size=args.image_size, num_objs=num_objs, num_preds=num_preds,
-                                mask_size=max(args.mask_size, 1), style=style, seed=args.seed + 1000003 * t + rank)
-    batch = tuple(x.to(device, non_blocking=True) if torch.is_tensor(x) else x for x in cpu_batch)
+    batch = next(train_loader)
     with timeit('step', args.timing):
       losses = trainer.step(batch)
     if t % args.print_every == 0:
@@ -167,21 +259,39 @@ def main(args):
         ips = args.batch_size * world * args.print_every / (time.time() - t0)
         print('t = %d / %d  (%.1f images/sec)' % (t, args.num_iterations, ips))
         for name, val in vals.items():
-          tag = 'G' if not name.startswith('d_') else 'D'
-          print(' %s [%s]: %.4f' % (tag, name, val))
-          checkpoint['losses'][name].append(val)
+          is_d = name.startswith('d_')
+          print(' %s [%s]: %.4f' % ('D' if is_d else 'G', name, val))
+          checkpoint['d_losses' if is_d else 'losses'][name].append(val)
         checkpoint['losses_ts'].append(t)
       t0 = time.time()
     if t % args.checkpoint_every == 0 and rank == 0:                # reference train.py:611-661
-      sd_of = lambda m: None if m is None else m.state_dict()     # reference train.py:634-641
+      print('checking on train')
+      t_losses, t_samples, t_batch_data, t_avg_iou = check_model(args, t, batches('train', t), trainer.model)
+      checkpoint['train_batch_data'].append(t_batch_data)
+      checkpoint['train_samples'].append(t_samples)
+      checkpoint['checkpoint_ts'].append(t)
+      checkpoint['train_iou'].append(t_avg_iou)
+      print('checking on val')
+      val_losses, val_samples, val_batch_data, val_avg_iou = check_model(args, t, batches('val', 0), trainer.model)
+      checkpoint['val_samples'].append(val_samples)
+      checkpoint['val_batch_data'].append(val_batch_data)
+      checkpoint['val_iou'].append(val_avg_iou)
+      print('train iou: ', t_avg_iou)
+      print('val iou: ', val_avg_iou)
+      for k, v in val_losses.items():
+        checkpoint['val_losses'][k].append(v)
       checkpoint.update(model_state=trainer.model.state_dict(), d_obj_state=sd_of(trainer.d_obj),
                         d_img_state=sd_of(trainer.d_img), optim_state=trainer.opt_g.state_dict(),
                         d_obj_optim_state=sd_of(trainer.opt_do), d_img_optim_state=sd_of(trainer.opt_di))
       checkpoint['counters']['t'] = t
-      checkpoint['checkpoint_ts'].append(t)
+      checkpoint['counters']['epoch'] = epoch
       path = os.path.join(args.output_dir, '%s_with_model.pt' % args.checkpoint_name)
+      print('Saving checkpoint to ', path)
       torch.save(checkpoint, path)
-      print('Saved checkpoint to', path)
+      # a second checkpoint without any model or optimiser state (reference train.py:651-661)
+      small = {k: v for k, v in checkpoint.items()
+               if not (k.endswith('_state') or k.endswith('_best_state'))}
+      torch.save(small, os.path.join(args.output_dir, '%s_no_model.pt' % args.checkpoint_name))
   if world > 1:
     dist.destroy_process_group()
 

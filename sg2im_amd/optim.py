@@ -92,10 +92,38 @@ class FlatAdam(object):
     ops.adam_step_guarded(self.flat.flat, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0],
                           self.betas[1], self.eps, self.state, guard, grad_scale)
 
+  def _steps_taken(self):
+    # the guarded path counts on the device (a skipped non-finite step does not count)
+    return max(int(self.t), int(round(float(self.state[0].item()))))
+
   def state_dict(self):
-    return {'t': self.t, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq, 'lr': self.lr}
+    """The torch.optim.Adam layout the reference checkpoints hold (scripts/train.py:642-650:
+    ``optimizer.state_dict()``): per-parameter ``step / exp_avg / exp_avg_sq`` keyed by the
+    index in ``module.parameters()`` order plus one param group, so either side can resume the
+    other's checkpoint.  Moments are exported in the parameter's logical (OIHW) layout."""
+    step = self._steps_taken()
+    state = {}
+    if step > 0:
+      for i, (p, off) in enumerate(zip(self.flat.params, self.flat.offsets)):
+        state[i] = {'step': torch.tensor(float(step)),
+                    'exp_avg': FlatParams._view(self.exp_avg, p, off).clone(memory_format=torch.contiguous_format),
+                    'exp_avg_sq': FlatParams._view(self.exp_avg_sq, p, off).clone(memory_format=torch.contiguous_format)}
+    group = {'lr': self.lr, 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': 0, 'amsgrad': False,
+             'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+             'params': list(range(len(self.flat.params)))}
+    return {'state': state, 'param_groups': [group]}
 
   def load_state_dict(self, sd):
-    self.t = sd['t']
-    self.exp_avg.copy_(sd['exp_avg'])
-    self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+    """accepts ``torch.optim.Adam.state_dict()`` of the same module (parameters the reference never
+    stepped have no entry there and keep zero moments)"""
+    self.reset_state()
+    step = 0
+    for i, ent in sd['state'].items():
+      p, off = self.flat.params[int(i)], self.flat.offsets[int(i)]
+      FlatParams._view(self.exp_avg, p, off).copy_(ent['exp_avg'])
+      FlatParams._view(self.exp_avg_sq, p, off).copy_(ent['exp_avg_sq'])
+      step = max(step, int(round(float(ent['step']))))
+    groups = sd.get('param_groups') or [{}]
+    self.lr = groups[0].get('lr', self.lr)
+    self.t = step
+    self.state[0] = float(step)

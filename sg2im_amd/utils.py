@@ -52,3 +52,23 @@ class LossManager(object):
 
   def items(self):
     return [(k, float(v)) for k, v in self.all_losses.items()]
+
+
+IMAGENET_MEAN = [0.485, 0.456, 0.406]
+IMAGENET_STD = [0.229, 0.224, 0.225]
+
+
+def imagenet_deprocess_batch(imgs, rescale=True):
+  """(N, 3, H, W) normalised floats -> uint8 images on the host, one image at a time like
+  reference sg2im/data/utils.py:50-68 (x * std + mean, optional per-image min/max rescale)."""
+  imgs = imgs.detach().float().cpu()
+  mean = torch.tensor(IMAGENET_MEAN).view(3, 1, 1)
+  std = torch.tensor(IMAGENET_STD).view(3, 1, 1)
+  out = []
+  for img in imgs:
+    img = img * std + mean
+    if rescale:
+      lo, hi = img.min(), img.max()
+      img = (img - lo) / (hi - lo)
+    out.append(img.mul(255).clamp(0, 255).byte()[None])
+  return torch.cat(out, dim=0)

@@ -137,6 +137,42 @@ def test_flat_params_alias_parameters_and_grads():
   assert float(fp.grad.abs().sum()) == 0.0
 
 
+def test_optimizer_state_round_trips_through_torch_adam_layout():
+  """checkpoints carry ``optimizer.state_dict()`` (reference scripts/train.py:642-650): the arena
+  optimiser must read a torch.optim.Adam state of the same module and write one torch can read"""
+  import copy
+  from sg2im_amd.optim import FlatParams, FlatAdam
+  from sg2im_amd.discriminators import PatchDiscriminator
+  torch.manual_seed(3)
+  m = PatchDiscriminator(arch='C4-8-2,C4-16-2', padding='valid')
+  ref = copy.deepcopy(m)
+  ref_opt = torch.optim.Adam(ref.parameters(), lr=1e-4)
+  for _ in range(3):                       # any gradients will do; the unused classifier gets none
+    ref_opt.zero_grad()
+    for name, p in ref.named_parameters():
+      if not name.startswith('classifier'):
+        p.grad = torch.randn_like(p)
+    ref_opt.step()
+  sd = ref_opt.state_dict()
+  opt = FlatAdam(FlatParams(m), lr=5e-4)
+  opt.load_state_dict(sd)
+  assert opt.t == 3 and opt.lr == 1e-4
+  names = [n for n, _ in m.named_parameters()]
+  out = opt.state_dict()
+  assert out['param_groups'][0]['params'] == list(range(len(names)))
+  for i, n in enumerate(names):
+    if i in sd['state']:
+      for k in ('exp_avg', 'exp_avg_sq'):
+        assert torch.equal(out['state'][i][k], sd['state'][i][k]), (n, k)
+        assert out['state'][i][k].is_contiguous()
+      assert float(out['state'][i]['step']) == 3.0
+    else:                                  # never stepped by torch: zero moments here
+      assert float(out['state'][i]['exp_avg'].abs().sum()) == 0.0
+  fresh = torch.optim.Adam(copy.deepcopy(ref).parameters(), lr=1e-4)
+  fresh.load_state_dict(out)               # torch accepts what we write
+  assert FlatAdam(FlatParams(copy.deepcopy(ref))).state_dict()['state'] == {}
+
+
 def test_train_script_keeps_the_reference_flag_surface():
   import re
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
