@@ -184,6 +184,19 @@ int sg2im_bn_act_backward(const float* g, long long ld_g, int pool2, int batch, 
 int sg2im_affine_act_forward(const float* x, long long ld_x, long long rows, int channels, const float* scale,
                              const float* shift, float slope, float* out, long long ld_out,
                              hipStream_t stream);
+/* InstanceNorm2d(channels) as get_normalization_2d(.., 'instance') builds it (sg2im/layers.py:27-28:
+ * affine=False, no running statistics, eps 1e-5) on a dense NHWC tensor x[batch][hw][channels]:
+ *   stats:    scale[n][c] = 1/sqrt(var_hw(x) + eps) (biased variance), shift[n][c] = -mean_hw(x) * scale
+ *   forward:  out = leaky_slope(scale[n][c] * x + shift[n][c])        (norm + the activation after it)
+ *   backward: dyn = gradient w.r.t. the normalised value (i.e. after the activation's backward);
+ *             dx = scale * (dyn - mean_hw(dyn) - yn * mean_hw(dyn * yn)); dx may alias dyn.
+ * Replaces autograd through nn.InstanceNorm2d at sg2im/crn.py:42-47 and sg2im/layers.py:166-168. */
+int sg2im_instnorm_stats(const float* x, int batch, int hw, int channels, float eps, float* scale, float* shift,
+                         hipStream_t stream);
+int sg2im_instnorm_act_forward(const float* x, int batch, int hw, int channels, const float* scale,
+                               const float* shift, float slope, float* out, hipStream_t stream);
+int sg2im_instnorm_backward(const float* dyn, const float* x, int batch, int hw, int channels, const float* scale,
+                            const float* shift, float* dx, hipStream_t stream);
 /* dx = g * leaky'(y): backward of a fused output activation (y is the activated output for
  * slope >= 0: sign(y) == sign(pre-activation)); pool2 as above. */
 int sg2im_act_backward(const float* g, long long ld_g, int pool2, int batch, int h, int w,

@@ -244,6 +244,11 @@ def refinement_network(P, prefix, layout, n_modules, slope, training, normalizat
       x = F.leaky_relu(x, slope)
       feats = F.leaky_relu(F.conv2d(x, P[p + '.2.weight'], P[p + '.2.bias'], padding=1), slope)
       continue
+    if normalization == 'instance':     # nn.InstanceNorm2d(C): no affine, no running stats (layers.py:27-28)
+      x = F.leaky_relu(F.instance_norm(x, eps=BN_EPS), slope)
+      x = F.conv2d(x, P[p + '.3.weight'], P[p + '.3.bias'], padding=1)
+      feats = F.leaky_relu(F.instance_norm(x, eps=BN_EPS), slope)
+      continue
     x = F.leaky_relu(batch_norm(P, p + '.1', x, training), slope)
     x = F.conv2d(x, P[p + '.3.weight'], P[p + '.3.bias'], padding=1)
     feats = F.leaky_relu(batch_norm(P, p + '.4', x, training), slope)
@@ -321,8 +326,8 @@ def generator_forward(P, cfg, objs, triples, obj_to_img=None, boxes_gt=None,
   n_modules = len(cfg.get('refinement_dims', (1024, 512, 256, 128, 64)))
   slope = activation_slope(cfg.get('activation', 'leakyrelu-0.2'))
   norm = cfg.get('normalization', 'batch')
-  if norm not in ('batch', 'none'):
-    raise NotImplementedError('oracle restates the batch / none normalizations only')
+  if norm not in ('batch', 'none', 'instance'):
+    raise ValueError('Unrecognized normalization type "%s"' % norm)
   img = refinement_network(P, 'refinement_net', layout, n_modules, slope, training, norm)
   return img, boxes_pred, masks_pred, rel_scores
 
@@ -351,10 +356,12 @@ def disc_cnn(P, prefix, x, arch, slope, padding, training, normalization='batch'
   nothing follows the last (layers.py:166-169).  Sequential indices with normalization='batch':
   conv i at 3i, its preceding BN at 3i-2; with 'none' the norm layers are absent: conv i at 2i."""
   for i, (k, c, stride) in enumerate(parse_conv_arch(arch)):
-    step = 3 if normalization == 'batch' else 2
+    step = 2 if normalization == 'none' else 3      # 'instance' keeps its (parameter-free) module slot
     if i > 0:
       if normalization == 'batch':
         x = batch_norm(P, '%s.%d' % (prefix, 3 * i - 2), x, training)
+      elif normalization == 'instance':
+        x = F.instance_norm(x, eps=BN_EPS)
       x = F.leaky_relu(x, slope)
     pad = 0 if padding == 'valid' else (k - 1) // 2
     x = F.conv2d(x, P['%s.%d.weight' % (prefix, step * i)], P['%s.%d.bias' % (prefix, step * i)],
@@ -629,6 +636,9 @@ def init_generator_params(cfg, seed=0, randomize_bn=False):
     if cfg.get('normalization', 'batch') == 'none':
       _conv(P, p + '.2', dims[i], dims[i], 3, g, True)
       continue
+    if cfg.get('normalization', 'batch') == 'instance':
+      _conv(P, p + '.3', dims[i], dims[i], 3, g, True)
+      continue
     _bn(P, p + '.1', dims[i], g, randomize_bn)
     _conv(P, p + '.3', dims[i], dims[i], 3, g, True)
     _bn(P, p + '.4', dims[i], g, randomize_bn)
@@ -639,7 +649,7 @@ def init_generator_params(cfg, seed=0, randomize_bn=False):
 
 def _init_disc_cnn(P, prefix, arch, cin, gen, randomize_bn, normalization='batch'):
   c = cin
-  step = 3 if normalization == 'batch' else 2
+  step = 2 if normalization == 'none' else 3
   for i, (k, cout, _s) in enumerate(parse_conv_arch(arch)):
     if i > 0 and normalization == 'batch':
       _bn(P, '%s.%d' % (prefix, 3 * i - 2), c, gen, randomize_bn)

@@ -53,6 +53,9 @@ _SIGNATURES = {
   'sg2im_bn_act_backward': [_P, _L, _I, _I, _I, _I, _P, _L, _I, _P, _P, _P, _P, _P, _F, _I, _P, _P, _P, _I,
                             _P, _P],
   'sg2im_affine_act_forward': [_P, _L, _L, _I, _P, _P, _F, _P, _L, _P],
+  'sg2im_instnorm_stats': [_P, _I, _I, _I, _F, _P, _P, _P],
+  'sg2im_instnorm_act_forward': [_P, _I, _I, _I, _P, _P, _F, _P, _P],
+  'sg2im_instnorm_backward': [_P, _P, _I, _I, _I, _P, _P, _P, _P],
   'sg2im_act_backward': [_P, _L, _I, _I, _I, _I, _P, _L, _I, _F, _P, _P],
   'sg2im_avgpool_forward': [_P, _I, _I, _I, _I, _I, _P, _P],
   'sg2im_pyramid_backward': [POINTER(c_void_p), POINTER(c_int), POINTER(c_longlong), _I, _I, _I, _I, _I, _P,

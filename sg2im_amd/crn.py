@@ -33,8 +33,8 @@ class RefinementNetwork(nn.Module):
 
   def __init__(self, dims, normalization='instance', activation='leakyrelu'):
     super(RefinementNetwork, self).__init__()
-    if normalization not in ('batch', 'none'):
-      raise NotImplementedError('instance normalization is not on the HIP path (SURVEY.md 8f rank 3)')
+    if normalization not in ('batch', 'none', 'instance'):
+      raise ValueError('Unrecognized normalization type "%s"' % normalization)
     self.normalization = normalization
     layout_dim = dims[0]
     self.slope = activation_slope(activation)
@@ -55,14 +55,14 @@ class RefinementNetwork(nn.Module):
 
   def forward_nhwc(self, layout_nhwc, layout_grad_channels=None):
     o0, o2 = self.output_conv[0], self.output_conv[2]
-    if self.normalization == 'none':
+    if self.normalization in ('none', 'instance'):      # no norm parameters, no running statistics
       convs = []
       for mod in self.refinement_modules:
-        c0, _, c1, _ = mod.net
+        c0, c1 = [m for m in mod.net if isinstance(m, nn.Conv2d)]
         convs += [c0.weight, c0.bias, c1.weight, c1.bias]
       params = convs + [o0.weight, o0.bias, o2.weight, o2.bias]
       return HF.RefinementNoNormFn.apply(layout_nhwc, len(self.refinement_modules), self.slope,
-                                         layout_grad_channels, *params)
+                                         layout_grad_channels, self.normalization == 'instance', *params)
     convs, bnps, bns = [], [], []
     for mod in self.refinement_modules:
       c0, n0, _, c1, n1, _ = mod.net

@@ -198,6 +198,87 @@ __global__ void affine_act_kernel(const float* __restrict__ x, long long ld_x, l
   }
 }
 
+// ---- InstanceNorm2d (affine=False, no running statistics; reference sg2im/layers.py:27-28) ----
+// One workgroup owns the (image n, 64-channel block) slice of an NHWC tensor: kInRows row lanes x
+// 64 channel lanes, partial sums combined through LDS in a fixed order (deterministic).
+constexpr int kInRows = 8;
+
+template <int NV>
+__device__ inline void in_reduce(float (&v)[NV], float (*red)[kInRows][64], int rl, int cl) {
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) red[k][rl][cl] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < kInRows; ++r) s += red[k][r][cl];
+    v[k] = s;
+  }
+}
+
+// scale[n][c] = 1/sqrt(var+eps), shift[n][c] = -mean*scale (biased variance over the HW pixels)
+__global__ void __launch_bounds__(kInRows * 64)
+instnorm_stats_kernel(const float* __restrict__ x, int HW, int C, float eps, float* __restrict__ scale,
+                      float* __restrict__ shift) {
+  __shared__ float red[1][kInRows][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl, n = blockIdx.y;
+  const bool live = c < C;
+  const float* xp = x + (long long)n * HW * C + (live ? c : 0);
+  float a[1] = {0.f};
+  if (live) for (int r = rl; r < HW; r += kInRows) a[0] += xp[(long long)r * C];
+  in_reduce<1>(a, red, rl, cl);
+  const float mean = a[0] / (float)HW;
+  float q[1] = {0.f};
+  if (live) for (int r = rl; r < HW; r += kInRows) { const float d = xp[(long long)r * C] - mean; q[0] = fmaf(d, d, q[0]); }
+  in_reduce<1>(q, red, rl, cl);
+  if (live && rl == 0) {
+    const float is = 1.f / sqrtf(q[0] / (float)HW + eps);
+    scale[(long long)n * C + c] = is;
+    shift[(long long)n * C + c] = -mean * is;
+  }
+}
+
+// out = leaky_slope(scale[n][c] * x + shift[n][c])
+__global__ void instnorm_act_kernel(const float* __restrict__ x, long long total, int HW, int C,
+                                    const float* __restrict__ scale, const float* __restrict__ shift, float slope,
+                                    float* __restrict__ out) {
+  const long long per = (long long)HW * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long n = i / per; const int c = (int)(i % C);
+    const float v = fmaf(x[i], scale[n * C + c], shift[n * C + c]);
+    out[i] = v > 0.f ? v : v * slope;
+  }
+}
+
+// dyn = gradient w.r.t. the normalised value yn = scale*x + shift  ->  gradient w.r.t. x:
+// dx = scale * (dyn - mean_hw(dyn) - yn * mean_hw(dyn * yn));  dx may alias dyn.
+__global__ void __launch_bounds__(kInRows * 64)
+instnorm_backward_kernel(const float* dyn, const float* __restrict__ x, int HW, int C,
+                         const float* __restrict__ scale, const float* __restrict__ shift, float* dx) {
+  __shared__ float red[2][kInRows][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl, n = blockIdx.y;
+  const bool live = c < C;
+  const long long base = (long long)n * HW * C + (live ? c : 0);
+  const float sc = live ? scale[(long long)n * C + c] : 0.f, sh = live ? shift[(long long)n * C + c] : 0.f;
+  float a[2] = {0.f, 0.f};
+  if (live) for (int r = rl; r < HW; r += kInRows) {
+    const float g = dyn[base + (long long)r * C], yn = fmaf(x[base + (long long)r * C], sc, sh);
+    a[0] += g; a[1] = fmaf(g, yn, a[1]);
+  }
+  in_reduce<2>(a, red, rl, cl);
+  const float m0 = a[0] / (float)HW, m1 = a[1] / (float)HW;
+  if (live) for (int r = rl; r < HW; r += kInRows) {
+    const long long o = base + (long long)r * C;
+    const float yn = fmaf(x[o], sc, sh);
+    dx[o] = sc * (dyn[o] - m0 - yn * m1);
+  }
+}
+
 __global__ void avgpool_kernel(const float* __restrict__ x, int B, int H, int W, int C, int f,
                                float* __restrict__ out) {
   const int Ho = H / f, Wo = W / f;
@@ -560,6 +641,34 @@ int sg2im_affine_act_forward(const float* x, long long ld_x, long long rows, int
   if (rows == 0) return SG2IM_OK;
   hipLaunchKernelGGL(affine_act_kernel, dim3(ew_blocks(rows * channels)), dim3(256), 0, stream, x, ld_x, rows, channels,
                      scale, shift, slope, out, ld_out);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_instnorm_stats(const float* x, int batch, int hw, int channels, float eps, float* scale, float* shift,
+                         hipStream_t stream) {
+  if (!x || !scale || !shift || batch < 0 || hw < 1 || channels < 1) return SG2IM_ERR_ARG;
+  if (batch == 0) return SG2IM_OK;
+  hipLaunchKernelGGL(instnorm_stats_kernel, dim3((channels + 63) / 64, batch), dim3(kInRows * 64), 0, stream, x, hw,
+                     channels, eps, scale, shift);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_instnorm_act_forward(const float* x, int batch, int hw, int channels, const float* scale,
+                               const float* shift, float slope, float* out, hipStream_t stream) {
+  if (!x || !scale || !shift || !out || batch < 0 || hw < 1 || channels < 1) return SG2IM_ERR_ARG;
+  const long long total = (long long)batch * hw * channels;
+  if (total == 0) return SG2IM_OK;
+  hipLaunchKernelGGL(instnorm_act_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, x, total, hw, channels, scale,
+                     shift, slope, out);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_instnorm_backward(const float* dyn, const float* x, int batch, int hw, int channels, const float* scale,
+                            const float* shift, float* dx, hipStream_t stream) {
+  if (!dyn || !x || !scale || !shift || !dx || batch < 0 || hw < 1 || channels < 1) return SG2IM_ERR_ARG;
+  if (batch == 0) return SG2IM_OK;
+  hipLaunchKernelGGL(instnorm_backward_kernel, dim3((channels + 63) / 64, batch), dim3(kInRows * 64), 0, stream, dyn,
+                     x, hw, channels, scale, shift, dx);
   return ok_or(hipGetLastError());
 }
 

@@ -688,7 +688,7 @@ class RefinementNoNormFn(Function):
   params (flat): per module [W0, b0, W1, b1] ..., then [Wo0, bo0, Wo2, bo2]."""
 
   @staticmethod
-  def forward(ctx, layout, n_modules, slope, grad_channels, *params):
+  def forward(ctx, layout, n_modules, slope, grad_channels, inorm, *params):
     ops.TIMER_TAG = 'crn'
     try:
       L = n_modules
@@ -709,10 +709,19 @@ class RefinementNoNormFn(Function):
         W0p, b0, W1p, b1 = params[4 * i:4 * i + 4]
         C = W0p.size(0)
         d0 = conv_desc([nhwc_src(pyr[i]), feat_src], N, h, w, 3, 3, 1, 1)
-        a0 = ops.conv2d_forward(d0, _cl_weight(W0p), C, b0, _new(layout, N, h, w, C), C, slope)
+        # 'none': the activation rides in the conv epilogue; 'instance': the conv output is kept
+        # (y), normalised per image and activated into a separate tensor (a)
+        y0 = st0 = y1 = st1 = None
+        a0 = ops.conv2d_forward(d0, _cl_weight(W0p), C, b0, _new(layout, N, h, w, C), C, 1.0 if inorm else slope)
+        if inorm:
+          y0, st0 = a0, ops.instnorm_stats(a0, BN_EPS)
+          a0 = ops.instnorm_act_forward(y0, st0, slope, _new(layout, N, h, w, C))
         d1 = conv_desc([nhwc_src(a0)], N, h, w, 3, 3, 1, 1)
-        a1 = ops.conv2d_forward(d1, _cl_weight(W1p), C, b1, _new(layout, N, h, w, C), C, slope)
-        saved.append((pyr[i], feat_src, a0, a1, h, w, C))
+        a1 = ops.conv2d_forward(d1, _cl_weight(W1p), C, b1, _new(layout, N, h, w, C), C, 1.0 if inorm else slope)
+        if inorm:
+          y1, st1 = a1, ops.instnorm_stats(a1, BN_EPS)
+          a1 = ops.instnorm_act_forward(y1, st1, slope, _new(layout, N, h, w, C))
+        saved.append((pyr[i], feat_src, a0, a1, h, w, C, y0, st0, y1, st1))
         feat_src = nhwc_src(a1, 1)
       Wo0, bo0, Wo2, bo2 = params[4 * L:4 * L + 4]
       Cf = saved[-1][6]
@@ -723,7 +732,7 @@ class RefinementNoNormFn(Function):
       img = ops.conv2d_forward(do2, _cl_weight(Wo2), Wo2.size(0), bo2, _new(layout, N, H, W, Wo2.size(0)),
                                Wo2.size(0))
       ctx.saved = saved
-      ctx.misc = (L, slope, z, do0, do2, Cl, Cf, grad_channels, (N, H, W))
+      ctx.misc = (L, slope, z, do0, do2, Cl, Cf, grad_channels, (N, H, W), inorm)
       ctx.save_for_backward(*params)
       return img
     finally:
@@ -734,9 +743,9 @@ class RefinementNoNormFn(Function):
     ops.TIMER_TAG = 'crn'
     try:
       params = ctx.saved_tensors
-      L, slope, z, do0, do2, Cl, Cf, grad_channels, (N, H, W) = ctx.misc
+      L, slope, z, do0, do2, Cl, Cf, grad_channels, (N, H, W), inorm = ctx.misc
       saved = ctx.saved
-      ni = ctx.needs_input_grad[4:]
+      ni = ctx.needs_input_grad[5:]
       grads = [None] * len(params)
       Wo0, bo0, Wo2, bo2 = params[4 * L:4 * L + 4]
       g = g.contiguous()
@@ -754,20 +763,29 @@ class RefinementNoNormFn(Function):
       Cg = Cl if grad_channels is None else min(int(grad_channels), Cl)
       dlevels = []
       for i in range(L - 1, -1, -1):
-        lay, feat_src, a0, a1, h, w, C = saved[i]
+        lay, feat_src, a0, a1, h, w, C, y0, st0, y1, st1 = saved[i]
         W0p, b0, W1p, b1 = params[4 * i:4 * i + 4]
         # through the second activation (with the 2x2 sum of the nearest-upsample backward)
         dy1 = ops.act_backward(_fptr(gz), gz.size(3), pool2, N, h, w, a1, C, C, slope, _new(g, N, h, w, C))
+        if inorm:
+          ops.instnorm_backward(dy1, y1, st1, dy1)
         d1 = conv_desc([nhwc_src(a0)], N, h, w, 3, 3, 1, 1)
+        # (a bias in front of an instance norm is cancelled by the mean subtraction: zero gradient)
         grads[4 * i + 2], grads[4 * i + 3] = _conv_param_grads(d1, dy1, C, (C, 3, 3, C), ni[4 * i + 2],
-                                                                ni[4 * i + 3], W1p, b1)
+                                                                ni[4 * i + 3] and not inorm, W1p, b1)
+        if inorm:
+          grads[4 * i + 3] = _shadowed_bias_grad(b1, ni[4 * i + 3])
         gz0 = _new(g, N, h, w, C)
         ops.conv2d_backward_data(d1, _cl_weight(W1p), C, dy1, C, 0, C, gz0, C)
         dy0 = ops.act_backward(_fptr(gz0), C, 0, N, h, w, a0, C, C, slope, gz0)
+        if inorm:
+          ops.instnorm_backward(dy0, y0, st0, dy0)
         Cprev = feat_src.channels
         d0 = conv_desc([nhwc_src(lay), feat_src], N, h, w, 3, 3, 1, 1)
         grads[4 * i], grads[4 * i + 1] = _conv_param_grads(d0, dy0, C, (C, 3, 3, Cl + Cprev), ni[4 * i],
-                                                            ni[4 * i + 1], W0p, b0)
+                                                            ni[4 * i + 1] and not inorm, W0p, b0)
+        if inorm:
+          grads[4 * i + 1] = _shadowed_bias_grad(b0, ni[4 * i + 1])
         if need_layout:
           dl = _new(g, N, h, w, Cg)
           ops.conv2d_backward_data(d0, _cl_weight(W0p), C, dy0, C, 0, Cg, dl, Cg)
@@ -782,7 +800,7 @@ class RefinementNoNormFn(Function):
         ops.pyramid_backward([t for t, _ in dlevels], [f for _, f in dlevels], [Cg] * len(dlevels), N, H, W, Cg,
                              dlayout)
       ctx.saved = None
-      return (dlayout, None, None, None) + tuple(grads)
+      return (dlayout, None, None, None, None) + tuple(grads)
     finally:
       ops.TIMER_TAG = None
 
@@ -862,7 +880,8 @@ class DiscCnnFn(Function):
     saved = []
     src = nhwc_src(x)
     h, w = H, W
-    nonorm = bns is None
+    inorm = isinstance(bns, str) and bns == 'instance'    # InstanceNorm2d: no parameters either
+    nonorm = bns is None or inorm
     for i, (k, cout, stride, pad) in enumerate(specs):
       if nonorm:
         Wp, bias = params[2 * i:2 * i + 2]
@@ -873,24 +892,27 @@ class DiscCnnFn(Function):
       d = conv_desc([src], N, h, w, k, k, stride, pad)
       last = i + 1 == len(specs)
       y = ops.conv2d_forward(d, _cl_weight(Wp), cout, bias, _new(x, N, d.out_h, d.out_w, cout), cout,
-                             slope if (nonorm and not last) else 1.0)
-      st = None
+                             slope if (nonorm and not inorm and not last) else 1.0)
+      st = ypre = ist = None
+      if inorm and not last:           # materialised norm + activation; y becomes the activated tensor
+        ypre, ist = y, ops.instnorm_stats(y, BN_EPS)
+        y = ops.instnorm_act_forward(ypre, ist, slope, _new(x, N, d.out_h, d.out_w, cout))
       if not last and not nonorm:
         st = ops.bn_stats(y, N * d.out_h * d.out_w, cout, cout, bns[i], training, BN_EPS, BN_MOMENTUM)
-      saved.append((src, d, y, st, h, w))
+      saved.append((src, d, y, st, h, w, ypre, ist))
       h, w = d.out_h, d.out_w
       if st is not None:
         src = nhwc_src(y, 0, st.scale, st.shift, slope)
       elif nonorm:
         src = nhwc_src(y)
-    ctx.saved, ctx.misc = saved, (specs, slope, training, tuple(x.shape), nonorm)
+    ctx.saved, ctx.misc = saved, (specs, slope, training, tuple(x.shape), nonorm, inorm)
     ctx.save_for_backward(*params)
     return saved[-1][2]
 
   @staticmethod
   def backward(ctx, g):
     params = ctx.saved_tensors
-    specs, slope, training, xshape, nonorm = ctx.misc
+    specs, slope, training, xshape, nonorm, inorm = ctx.misc
     saved = ctx.saved
     N = xshape[0]
     ni = ctx.needs_input_grad[5:]
@@ -898,7 +920,7 @@ class DiscCnnFn(Function):
     dy = g.contiguous()
     for i in range(len(specs) - 1, -1, -1):
       k, cout, stride, pad = specs[i]
-      src, d, y, st, h, w = saved[i]
+      src, d, y, st, h, w = saved[i][:6]
       cin = src.channels
       if nonorm:
         wi = 2 * i
@@ -908,7 +930,8 @@ class DiscCnnFn(Function):
       else:
         wi = 2 + 4 * (i - 1) + 2
         Wp = params[wi]
-      shadowed = training and i + 1 < len(specs) and not nonorm     # followed by a batch-statistics BN
+      # followed by a batch-statistics BN or an instance norm: the bias is cancelled by the mean
+      shadowed = i + 1 < len(specs) and (inorm or (training and not nonorm))
       grads[wi], grads[wi + 1] = _conv_param_grads(d, dy, cout, (cout, k, k, cin), ni[wi], ni[wi + 1] and not shadowed,
                                                    Wp, params[wi + 1])
       if shadowed:
@@ -925,6 +948,8 @@ class DiscCnnFn(Function):
       yp, stp = saved[i - 1][2], saved[i - 1][3]
       if nonorm:                                          # yp is the activated output of conv i-1
         dy = ops.act_backward(_fptr(gz), cin, 0, N, h, w, yp, cin, cin, slope, gz)
+        if inorm:
+          ops.instnorm_backward(dy, saved[i - 1][6], saved[i - 1][7], dy)
         continue
       gi = 2 + 4 * (i - 1)
       dgam, dbet, accb, grads[gi], grads[gi + 1] = _bn_grad_bufs(g, cin, params[gi], params[gi + 1], ni[gi],

@@ -27,7 +27,7 @@ def get_normalization_2d(channels, normalization):
   if normalization == 'none':
     return None
   if normalization == 'instance':
-    raise NotImplementedError('instance normalization is not on the MI355X hot path yet (SURVEY.md 8f rank 3)')
+    return nn.InstanceNorm2d(channels)      # parameter-free marker; computed by sg2im_instnorm_*
   raise ValueError('Unrecognized normalization type "%s"' % normalization)
 
 
@@ -116,11 +116,12 @@ class DiscCnn(nn.Sequential):
   def forward(self, x_nhwc):
     convs = [m for m in self if isinstance(m, nn.Conv2d)]
     bns = [m for m in self if isinstance(m, nn.BatchNorm2d)]
-    if not bns:                       # normalization='none': conv, act, conv, act, ..., conv
+    if not bns:                       # 'none': conv, act, conv, ...; 'instance': conv, IN, act, conv, ...
+      inorm = any(isinstance(m, nn.InstanceNorm2d) for m in self)
       params = []
       for cv in convs:
         params += [cv.weight, cv.bias]
-      return HF.DiscCnnFn.apply(x_nhwc, None, self.specs, self.slope, self.training, *params)
+      return HF.DiscCnnFn.apply(x_nhwc, 'instance' if inorm else None, self.specs, self.slope, self.training, *params)
     if len(bns) != len(convs) - 1:
       raise NotImplementedError('discriminator CNN with a partial set of normalization layers')
     params = [convs[0].weight, convs[0].bias]

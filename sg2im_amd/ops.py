@@ -359,6 +359,26 @@ def affine_act_forward(x, st, slope, out):
   return out
 
 
+def instnorm_stats(x, eps=1e-5):
+  """x: dense NHWC; returns (scale, shift), each (N, C): the InstanceNorm2d affine of every image"""
+  N, H, W, C = x.shape
+  st = torch.empty(2, N, C, dtype=torch.float32, device=x.device)
+  call('sg2im_instnorm_stats', _f(x), N, H * W, C, float(eps), _f(st[0]), _f(st[1]), _stream())
+  return st
+
+
+def instnorm_act_forward(x, st, slope, out):
+  N, H, W, C = x.shape
+  call('sg2im_instnorm_act_forward', _f(x), N, H * W, C, _f(st[0]), _f(st[1]), float(slope), _f(out), _stream())
+  return out
+
+
+def instnorm_backward(dyn, x, st, dx):
+  N, H, W, C = x.shape
+  call('sg2im_instnorm_backward', _f(dyn), _f(x), N, H * W, C, _f(st[0]), _f(st[1]), _f(dx), _stream())
+  return dx
+
+
 def act_backward(g, ld_g, pool2, batch, h, w, y, ld_y, C, slope, dx):
   call('sg2im_act_backward', g, int(ld_g), int(pool2), int(batch), int(h), int(w), _f(y), int(ld_y), int(C),
        float(slope), _f(dx), _stream())

@@ -71,6 +71,19 @@ CONFIGS = {
     d_img=dict(arch='C4-8-2,C4-16-2', normalization='batch', activation='leakyrelu-0.2',
                padding='valid'),
   ),
+  # InstanceNorm2d in the refinement network and both discriminators (--normalization instance,
+  # --d_normalization instance; sg2im/layers.py:27-28)
+  'tiny_coco_instnorm': dict(
+    batch=dict(batch_size=3, image_size=(16, 16), num_objs=10, num_preds=4, min_objs=2,
+               max_objs=4, mask_size=4, style='coco', seed=71),
+    g=dict(image_size=(16, 16), embedding_dim=16, gconv_dim=16, gconv_hidden_dim=32,
+           gconv_num_layers=2, refinement_dims=(24, 16, 8), normalization='instance',
+           activation='leakyrelu-0.2', mask_size=4, layout_noise_dim=4),
+    d_obj=dict(arch='C4-8-2,C4-16-2', normalization='instance', activation='leakyrelu-0.2',
+               padding='valid', object_size=16),
+    d_img=dict(arch='C4-8-2,C4-16-2', normalization='instance', activation='leakyrelu-0.2',
+               padding='valid'),
+  ),
   # VG-style: no GT masks -> masks_pred feeds the layout and mask_net trains.
   'tiny_vg': dict(
     batch=dict(batch_size=2, image_size=(32, 32), num_objs=9, num_preds=6, min_objs=3,
@@ -269,5 +282,5 @@ if __name__ == '__main__':
       continue
     if 'train' in which or only:
       run_config(n, c)
-    if 'eval' in which and 'nonorm' not in n and 'mlpbn' not in n:
+    if 'eval' in which and n in ('tiny_coco', 'tiny_vg'):
       run_eval_config(n, c)

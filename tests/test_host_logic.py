@@ -89,8 +89,10 @@ def test_activation_quirk_and_unsupported_options_fail_loudly():
   assert layers.activation_slope('relu') == 0.01 and layers.activation_slope('leakyrelu-0.2') == 0.2
   with pytest.raises(ValueError):
     layers.get_normalization_2d(8, 'bogus')
-  with pytest.raises(NotImplementedError):
-    layers.get_normalization_2d(8, 'instance')
+  inorm = layers.get_normalization_2d(8, 'instance')      # reference layers.py:27-28: no affine, no buffers
+  assert isinstance(inorm, torch.nn.InstanceNorm2d) and not inorm.state_dict()
+  cnn_i, _ = layers.build_cnn('I3,C4-8-2,C4-16-2', normalization='instance', padding='valid')
+  assert sorted(cnn_i.state_dict()) == ['0.bias', '0.weight', '3.bias', '3.weight']
   with pytest.raises(NotImplementedError):
     layers.build_cnn('C3-8,R')
   cnn, c = layers.build_cnn('I3,C4-64-2,C4-128-2,C4-256-2', padding='valid', activation='leakyrelu-0.2')

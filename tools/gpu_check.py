@@ -427,6 +427,10 @@ def sec_golden_nonorm():
   golden_case('tiny_coco_nonorm')       # refinement network with --normalization none
 
 
+def sec_golden_instnorm():
+  golden_case('tiny_coco_instnorm')     # InstanceNorm2d in the refinement network and both discriminators
+
+
 def sec_golden_mlpbn():
   golden_case('tiny_coco_mlpbn')        # BatchNorm1d in every MLP (--mlp_normalization batch)
 
@@ -442,7 +446,7 @@ def sec_golden_vg():
 if __name__ == '__main__':
   print(torch.cuda.get_device_name(0))
   only = sys.argv[1:]
-  for fn in (sec_pool, sec_linear, sec_conv, sec_gconv, sec_layout, sec_losses, sec_golden_coco, sec_golden_vg, sec_golden_eval, sec_golden_nonorm, sec_golden_mlpbn):
+  for fn in (sec_pool, sec_linear, sec_conv, sec_gconv, sec_layout, sec_losses, sec_golden_coco, sec_golden_vg, sec_golden_eval, sec_golden_nonorm, sec_golden_mlpbn, sec_golden_instnorm):
     if not only or fn.__name__ in only:
       section(fn)
   bad = [r for r in RESULTS if not (r[1] <= 1e-4 or r[3] <= 1e-6)]
