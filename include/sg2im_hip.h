@@ -197,6 +197,27 @@ int sg2im_instnorm_act_forward(const float* x, int batch, int hw, int channels, 
                                const float* shift, float slope, float* out, hipStream_t stream);
 int sg2im_instnorm_backward(const float* dyn, const float* x, int batch, int hw, int channels, const float* scale,
                             const float* shift, float* dx, hipStream_t stream);
+/* The spatial / elementwise tokens of build_cnn architecture strings (sg2im/layers.py:184-196) and
+ * ResidualBlock (sg2im/layers.py:88-117), dense NHWC tensors:
+ *   resample_nearest_up: out[b][y][x][c] = alpha * x[b][y/f][x/f][c], out is (out_h, out_w) (0 outside the
+ *                        f-scaled input) - nn.Upsample(scale_factor=f, 'nearest'); with alpha = 1/f^2 the
+ *                        backward of AvgPool2d(f)
+ *   pool_sum_forward:    out = alpha * (sum of each f x f window), floor(h/f) x floor(w/f) outputs -
+ *                        nn.AvgPool2d(f, f) with alpha = 1/f^2; with alpha = 1 the backward of the upsample
+ *   maxpool_forward / _backward: nn.MaxPool2d(f, f); the first maximum of the row-major window scan takes
+ *                        the gradient (ATen's rule), dx has the input's shape
+ *   leaky_forward:       out = x > 0 ? x : slope * x  (a LeakyReLU with no norm / GEMM to fuse it into)
+ *   add_forward:         out = a + b  (the residual sum, layers.py:117) */
+int sg2im_resample_nearest_up(const float* x, int batch, int h, int w, int channels, int factor, int out_h,
+                              int out_w, float alpha, float* out, hipStream_t stream);
+int sg2im_pool_sum_forward(const float* x, int batch, int h, int w, int channels, int factor, float alpha,
+                           float* out, hipStream_t stream);
+int sg2im_maxpool_forward(const float* x, int batch, int h, int w, int channels, int factor, float* out,
+                          hipStream_t stream);
+int sg2im_maxpool_backward(const float* x, const float* dy, int batch, int h, int w, int channels, int factor,
+                           float* dx, hipStream_t stream);
+int sg2im_leaky_forward(const float* x, long long n, float slope, float* out, hipStream_t stream);
+int sg2im_add_forward(const float* a, const float* b, long long n, float* out, hipStream_t stream);
 /* dx = g * leaky'(y): backward of a fused output activation (y is the activated output for
  * slope >= 0: sign(y) == sign(pre-activation)); pool2 as above. */
 int sg2im_act_backward(const float* g, long long ld_g, int pool2, int batch, int h, int w,

@@ -336,36 +336,111 @@ def generator_forward(P, cfg, objs, triples, obj_to_img=None, boxes_gt=None,
 # discriminators (sg2im/discriminators.py, sg2im/layers.py:129-213)
 # ----------------------------------------------------------------------------
 
-def parse_conv_arch(arch):
-  """The 'CK-X-S' tokens of build_cnn (layers.py:160-182).  Other tokens (R, U, P,
-  FC) are outside the default flag surface and not restated."""
-  out = []
-  for tok in arch.split(','):
-    if tok[0] == 'I':
-      continue
-    if tok[0] != 'C':
-      raise NotImplementedError('arch token "%s" not restated' % tok)
-    vals = [int(v) for v in tok[1:].split('-')]
-    k, c = vals[0], vals[1]
-    out.append((k, c, vals[2] if len(vals) == 3 else 1))
-  return out
+def _norm2d(P, name, x, normalization, training):
+  """get_normalization_2d (layers.py:22-31) applied: 'batch' reads P[name.*], 'instance' is parameter free"""
+  if normalization == 'batch':
+    return batch_norm(P, name, x, training)
+  if normalization == 'instance':
+    return F.instance_norm(x, eps=BN_EPS)
+  raise ValueError('Unrecognized normalization type "%s"' % normalization)
 
 
-def disc_cnn(P, prefix, x, arch, slope, padding, training, normalization='batch'):
-  """build_cnn with C-tokens only: every conv except the first is preceded by [BN +] activation,
-  nothing follows the last (layers.py:166-169).  Sequential indices with normalization='batch':
-  conv i at 3i, its preceding BN at 3i-2; with 'none' the norm layers are absent: conv i at 2i."""
-  for i, (k, c, stride) in enumerate(parse_conv_arch(arch)):
-    step = 2 if normalization == 'none' else 3      # 'instance' keeps its (parameter-free) module slot
-    if i > 0:
-      if normalization == 'batch':
-        x = batch_norm(P, '%s.%d' % (prefix, 3 * i - 2), x, training)
-      elif normalization == 'instance':
-        x = F.instance_norm(x, eps=BN_EPS)
+def cnn_layers(arch, normalization):
+  """The module list build_cnn (layers.py:129-213) produces for ``arch``, as (kind, Sequential index,
+  args) tuples - the index is what the state_dict keys carry.  A 'none' normalization adds no
+  module (layers.py:208 drops the None entries), 'batch' and 'instance' each take a slot."""
+  toks = arch.split(',') if isinstance(arch, str) else list(arch)
+  cur = 3
+  if toks and toks[0][0] == 'I':
+    cur = int(toks[0][1:])
+    toks = toks[1:]
+  out, idx, first_conv, flat = [], 0, True, False
+  def push(kind, *args):
+    nonlocal idx
+    out.append((kind, idx) + args)
+    idx += 1
+  for i, t in enumerate(toks):
+    if t[0] == 'C':
+      vals = [int(v) for v in t[1:].split('-')]
+      k, c = vals[0], vals[1]
+      stride = vals[2] if len(vals) == 3 else 1
+      if not first_conv:
+        if normalization != 'none':
+          push('norm', cur)
+        push('act')
+      first_conv = False
+      push('conv', cur, c, k, stride)
+      cur = c
+    elif t[0] == 'R':
+      push('res', cur, 'none' if first_conv else normalization)
+      first_conv = False
+    elif t[0] == 'U':
+      push('up', int(t[1:]))
+    elif t[0] == 'P':
+      push('pool', int(t[1:]))
+    elif t[:2] == 'FC':
+      _, din, dout = t.split('-')
+      if not flat:
+        push('flatten')
+      flat = True
+      push('fc', int(din), int(dout))
+      if i + 1 < len(toks):
+        push('act')
+      cur = int(dout)
+    else:
+      raise ValueError('Invalid layer "%s"' % t)
+  return out, cur
+
+
+def residual_block(P, prefix, x, C, normalization, slope, padding, training):
+  """ResidualBlock (layers.py:88-117), kernel 3: net = [norm, act, conv, norm, act, conv] minus absent
+  norms.  forward computes ``self.net(x)`` TWICE (:116-117) and uses the second value - the first
+  call only matters for the BatchNorm running statistics, which move twice."""
+  pad = 0 if padding == 'valid' else 1
+  def net(t):
+    j = 0
+    for _ in range(2):
+      if normalization != 'none':
+        t = _norm2d(P, '%s.net.%d' % (prefix, j), t, normalization, training)
+        j += 1
+      t = F.leaky_relu(t, slope)
+      j += 1
+      t = F.conv2d(t, P['%s.net.%d.weight' % (prefix, j)], P['%s.net.%d.bias' % (prefix, j)], padding=pad)
+      j += 1
+    return t
+  shortcut = x
+  if pad == 0:
+    shortcut = x[:, :, pad:-pad, pad:-pad]        # (:113-114) empty for P = 0: the reference fails in the add
+  net(x)
+  return shortcut + net(x)
+
+
+def disc_cnn(P, prefix, x, arch, slope, padding, training, normalization='batch', pooling='max'):
+  """Forward of the Sequential build_cnn makes (layers.py:129-213): every conv except the first is
+  preceded by [norm +] activation, nothing follows the last (:166-169); R / U / P / FC as documented
+  there.  With C tokens only and normalization='batch' conv i sits at index 3i, its BN at 3i-2."""
+  layers, _ = cnn_layers(arch, normalization)
+  for lay in layers:
+    kind, idx = lay[0], lay[1]
+    name = '%s.%d' % (prefix, idx)
+    if kind == 'norm':
+      x = _norm2d(P, name, x, normalization, training)
+    elif kind == 'act':
       x = F.leaky_relu(x, slope)
-    pad = 0 if padding == 'valid' else (k - 1) // 2
-    x = F.conv2d(x, P['%s.%d.weight' % (prefix, step * i)], P['%s.%d.bias' % (prefix, step * i)],
-                 stride=stride, padding=pad)
+    elif kind == 'conv':
+      _cin, _cout, k, stride = lay[2:]
+      pad = 0 if padding == 'valid' else (k - 1) // 2
+      x = F.conv2d(x, P[name + '.weight'], P[name + '.bias'], stride=stride, padding=pad)
+    elif kind == 'res':
+      x = residual_block(P, name, x, lay[2], lay[3], slope, padding, training)
+    elif kind == 'up':
+      x = F.interpolate(x, scale_factor=lay[2], mode='nearest')
+    elif kind == 'pool':
+      x = (F.max_pool2d if pooling == 'max' else F.avg_pool2d)(x, kernel_size=lay[2], stride=lay[2])
+    elif kind == 'flatten':
+      x = x.reshape(x.size(0), -1)
+    elif kind == 'fc':
+      x = F.linear(x, P[name + '.weight'], P[name + '.bias'])
   return x
 
 
@@ -374,7 +449,7 @@ def patch_discriminator(P, dcfg, x, training=True):
   (line 40) is never applied."""
   slope = activation_slope(dcfg.get('activation', 'leakyrelu-0.2'))
   return disc_cnn(P, 'cnn', x, dcfg['arch'], slope, dcfg.get('padding', 'same'), training,
-                  dcfg.get('normalization', 'batch'))
+                  dcfg.get('normalization', 'batch'), dcfg.get('pooling', 'avg'))     # discriminators.py:27
 
 
 def ac_crop_discriminator(P, dcfg, imgs, objs, boxes, obj_to_img, training=True,
@@ -384,7 +459,8 @@ def ac_crop_discriminator(P, dcfg, imgs, objs, boxes, obj_to_img, training=True,
                           align_corners=align_corners)
   slope = activation_slope(dcfg.get('activation', 'relu'))
   feats = disc_cnn(P, 'discriminator.cnn.0', crops, dcfg['arch'], slope,
-                   dcfg.get('padding', 'same'), training, dcfg.get('normalization', 'none'))
+                   dcfg.get('padding', 'same'), training, dcfg.get('normalization', 'none'),
+                   dcfg.get('pooling', 'avg'))                                        # discriminators.py:50
   vecs = feats.view(feats.size(0), feats.size(1), -1).mean(dim=2)     # GlobalAvgPool layers.py:83-86
   vecs = F.linear(vecs, P['discriminator.cnn.2.weight'], P['discriminator.cnn.2.bias'])
   real = F.linear(vecs, P['discriminator.real_classifier.weight'], P['discriminator.real_classifier.bias'])
@@ -648,14 +724,31 @@ def init_generator_params(cfg, seed=0, randomize_bn=False):
 
 
 def _init_disc_cnn(P, prefix, arch, cin, gen, randomize_bn, normalization='batch'):
-  c = cin
-  step = 2 if normalization == 'none' else 3
-  for i, (k, cout, _s) in enumerate(parse_conv_arch(arch)):
-    if i > 0 and normalization == 'batch':
-      _bn(P, '%s.%d' % (prefix, 3 * i - 2), c, gen, randomize_bn)
-    _conv(P, '%s.%d' % (prefix, step * i), cout, c, k, gen)
-    c = cout
-  return c
+  """parameters of build_cnn's Sequential in module order (the draw order for C-only strings is
+  BN then conv, as before)"""
+  if not arch.startswith('I'):
+    arch = 'I%d,%s' % (cin, arch)
+  layers, cout = cnn_layers(arch, normalization)
+  for lay in layers:
+    kind, name = lay[0], '%s.%d' % (prefix, lay[1])
+    if kind == 'norm' and normalization == 'batch':
+      _bn(P, name, lay[2], gen, randomize_bn)
+    elif kind == 'conv':
+      _conv(P, name, lay[3], lay[2], lay[4], gen)
+    elif kind == 'fc':
+      _lin(P, name, lay[3], lay[2], gen)
+    elif kind == 'res':
+      C, norm = lay[2], lay[3]
+      j = 0
+      for _ in range(2):
+        if norm != 'none':
+          if norm == 'batch':
+            _bn(P, '%s.net.%d' % (name, j), C, gen, randomize_bn)
+          j += 1
+        j += 1
+        _conv(P, '%s.net.%d' % (name, j), C, C, 3, gen)
+        j += 1
+  return cout
 
 
 def init_patch_discriminator_params(dcfg, seed=1, randomize_bn=False):

@@ -53,6 +53,12 @@ _SIGNATURES = {
   'sg2im_bn_act_backward': [_P, _L, _I, _I, _I, _I, _P, _L, _I, _P, _P, _P, _P, _P, _F, _I, _P, _P, _P, _I,
                             _P, _P],
   'sg2im_affine_act_forward': [_P, _L, _L, _I, _P, _P, _F, _P, _L, _P],
+  'sg2im_resample_nearest_up': [_P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P],
+  'sg2im_pool_sum_forward': [_P, _I, _I, _I, _I, _I, _F, _P, _P],
+  'sg2im_maxpool_forward': [_P, _I, _I, _I, _I, _I, _P, _P],
+  'sg2im_maxpool_backward': [_P, _P, _I, _I, _I, _I, _I, _P, _P],
+  'sg2im_leaky_forward': [_P, _L, _F, _P, _P],
+  'sg2im_add_forward': [_P, _P, _L, _P, _P],
   'sg2im_instnorm_stats': [_P, _I, _I, _I, _F, _P, _P, _P],
   'sg2im_instnorm_act_forward': [_P, _I, _I, _I, _P, _P, _F, _P, _P],
   'sg2im_instnorm_backward': [_P, _P, _I, _I, _I, _P, _P, _P, _P],

@@ -279,6 +279,102 @@ instnorm_backward_kernel(const float* dyn, const float* __restrict__ x, int HW, 
   }
 }
 
+// ---- the spatial tokens of build_cnn architecture strings (reference sg2im/layers.py:184-196) ----
+// out[b][y][x][c] = alpha * in[b][y/f][x/f][c]   (nn.Upsample nearest; backward of a sum / average pool)
+__global__ void resample_up_kernel(const float* __restrict__ x, int B, int H, int W, int C, int f, int Ho, int Wo,
+                                   float alpha, float* __restrict__ out) {
+  const long long total = (long long)B * Ho * Wo * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); long long t = i / C;
+    const int xo = (int)(t % Wo); t /= Wo;
+    const int yo = (int)(t % Ho); const long long n = t / Ho;
+    const int yi = yo / f, xi = xo / f;
+    out[i] = (yi < H && xi < W) ? alpha * x[((n * H + yi) * W + xi) * C + c] : 0.f;
+  }
+}
+
+// out[b][yo][xo][c] = alpha * sum of the f x f window (floor(H/f) x floor(W/f) outputs: nn.AvgPool2d with
+// alpha = 1/f^2; backward of the nearest upsample with alpha = 1)
+__global__ void pool_sum_kernel(const float* __restrict__ x, int B, int H, int W, int C, int f, float alpha,
+                                float* __restrict__ out) {
+  const int Ho = H / f, Wo = W / f;
+  const long long total = (long long)B * Ho * Wo * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); long long t = i / C;
+    const int xo = (int)(t % Wo); t /= Wo;
+    const int yo = (int)(t % Ho); const long long n = t / Ho;
+    float s = 0.f;
+    for (int dy = 0; dy < f; ++dy)
+      for (int dx = 0; dx < f; ++dx)
+        s += x[((n * H + yo * f + dy) * W + xo * f + dx) * C + c];
+    out[i] = alpha * s;
+  }
+}
+
+// nn.MaxPool2d(f, f): the FIRST maximum of the row-major window scan wins (ATen's `val > max`)
+__device__ inline int maxpool_argmax(const float* __restrict__ x, long long n, int H, int W, int C, int f, int yo,
+                                     int xo, int c, float& best) {
+  int arg = 0; best = x[((n * H + yo * f) * W + xo * f) * C + c];
+  for (int k = 1; k < f * f; ++k) {
+    const int dy = k / f, dx = k - dy * f;
+    const float v = x[((n * H + yo * f + dy) * W + xo * f + dx) * C + c];
+    if (v > best || v != v) { best = v; arg = k; }
+  }
+  return arg;
+}
+
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, int B, int H, int W, int C, int f,
+                                   float* __restrict__ out) {
+  const int Ho = H / f, Wo = W / f;
+  const long long total = (long long)B * Ho * Wo * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); long long t = i / C;
+    const int xo = (int)(t % Wo); t /= Wo;
+    const int yo = (int)(t % Ho); const long long n = t / Ho;
+    float best;
+    maxpool_argmax(x, n, H, W, C, f, yo, xo, c, best);
+    out[i] = best;
+  }
+}
+
+// dx has the input's shape: the window's gradient goes to its arg-max, every other position gets 0
+__global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int H, int W,
+                                   int C, int f, float* __restrict__ dx) {
+  const int Ho = H / f, Wo = W / f;
+  const long long total = (long long)B * H * W * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); long long t = i / C;
+    const int xi = (int)(t % W); t /= W;
+    const int yi = (int)(t % H); const long long n = t / H;
+    const int yo = yi / f, xo = xi / f;
+    float g = 0.f;
+    if (yo < Ho && xo < Wo) {
+      float best;
+      const int arg = maxpool_argmax(x, n, H, W, C, f, yo, xo, c, best);
+      if (arg == (yi - yo * f) * f + (xi - xo * f)) g = dy[((n * Ho + yo) * Wo + xo) * C + c];
+    }
+    dx[i] = g;
+  }
+}
+
+// out = leaky_slope(x) and out = a + b (the residual sum of ResidualBlock, sg2im/layers.py:112-117)
+__global__ void leaky_fwd_kernel(const float* __restrict__ x, long long n, float slope, float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    out[i] = v > 0.f ? v : v * slope;
+  }
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n,
+                           float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    out[i] = a[i] + b[i];
+}
+
 __global__ void avgpool_kernel(const float* __restrict__ x, int B, int H, int W, int C, int f,
                                float* __restrict__ out) {
   const int Ho = H / f, Wo = W / f;
@@ -669,6 +765,60 @@ int sg2im_instnorm_backward(const float* dyn, const float* x, int batch, int hw,
   if (batch == 0) return SG2IM_OK;
   hipLaunchKernelGGL(instnorm_backward_kernel, dim3((channels + 63) / 64, batch), dim3(kInRows * 64), 0, stream, dyn,
                      x, hw, channels, scale, shift, dx);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_resample_nearest_up(const float* x, int batch, int h, int w, int channels, int factor, int out_h,
+                              int out_w, float alpha, float* out, hipStream_t stream) {
+  if (!x || !out || factor < 1 || out_h < 0 || out_w < 0 || channels < 1) return SG2IM_ERR_ARG;
+  const long long total = (long long)batch * out_h * out_w * channels;
+  if (total == 0) return SG2IM_OK;
+  hipLaunchKernelGGL(resample_up_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, x, batch, h, w, channels, factor,
+                     out_h, out_w, alpha, out);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_pool_sum_forward(const float* x, int batch, int h, int w, int channels, int factor, float alpha,
+                           float* out, hipStream_t stream) {
+  if (!x || !out || factor < 1 || channels < 1) return SG2IM_ERR_ARG;
+  const long long total = (long long)batch * (h / factor) * (w / factor) * channels;
+  if (total == 0) return SG2IM_OK;
+  hipLaunchKernelGGL(pool_sum_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, x, batch, h, w, channels, factor,
+                     alpha, out);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_maxpool_forward(const float* x, int batch, int h, int w, int channels, int factor, float* out,
+                          hipStream_t stream) {
+  if (!x || !out || factor < 1 || channels < 1) return SG2IM_ERR_ARG;
+  const long long total = (long long)batch * (h / factor) * (w / factor) * channels;
+  if (total == 0) return SG2IM_OK;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, x, batch, h, w, channels, factor,
+                     out);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_maxpool_backward(const float* x, const float* dy, int batch, int h, int w, int channels, int factor,
+                           float* dx, hipStream_t stream) {
+  if (!x || !dy || !dx || factor < 1 || channels < 1) return SG2IM_ERR_ARG;
+  const long long total = (long long)batch * h * w * channels;
+  if (total == 0) return SG2IM_OK;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, x, dy, batch, h, w, channels,
+                     factor, dx);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_leaky_forward(const float* x, long long n, float slope, float* out, hipStream_t stream) {
+  if (!x || !out || n < 0) return SG2IM_ERR_ARG;
+  if (n == 0) return SG2IM_OK;
+  hipLaunchKernelGGL(leaky_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, x, n, slope, out);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_add_forward(const float* a, const float* b, long long n, float* out, hipStream_t stream) {
+  if (!a || !b || !out || n < 0) return SG2IM_ERR_ARG;
+  if (n == 0) return SG2IM_OK;
+  hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, a, b, n, out);
   return ok_or(hipGetLastError());
 }
 

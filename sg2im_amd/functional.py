@@ -180,27 +180,32 @@ class Mlp2(Function):
 # layers are chained from these instead: LinearAct(slope=1) -> BnActRows -> ...
 
 class BnActRows(Function):
-  """z = relu(batch_norm_1d(y)) materialised, y: (rows, C)"""
+  """z = leaky_slope(batch_norm(y)) materialised; y is any dense tensor with the channels last:
+  (rows, C) for BatchNorm1d + ReLU, NHWC for a BatchNorm2d + LeakyReLU that cannot ride in a
+  neighbouring conv (the layer-by-layer build_cnn path)"""
 
   @staticmethod
-  def forward(ctx, y, bn, training, gamma, beta):
+  def forward(ctx, y, bn, training, gamma, beta, slope=0.0):
     y = y.contiguous()
-    st = ops.bn_stats(y, y.size(0), y.size(1), y.size(1), bn, training, BN_EPS, BN_MOMENTUM)
-    z = ops.affine_act_forward(y, st, 0.0, _new(y, *y.shape))
+    C = y.size(-1)
+    rows = y.numel() // C
+    st = ops.bn_stats(y, rows, C, C, bn, training, BN_EPS, BN_MOMENTUM)
+    z = ops.affine_act_forward(y.view(rows, C), st, slope, _new(y, rows, C)).view(y.shape)
     ctx.save_for_backward(y, gamma, beta)
-    ctx.st, ctx.training = st, training
+    ctx.st, ctx.training, ctx.slope = st, training, slope
     return z
 
   @staticmethod
   def backward(ctx, g):
     y, gamma, beta = ctx.saved_tensors
-    rows, C = y.shape
+    C = y.size(-1)
+    rows = y.numel() // C
     g = g.contiguous()
     ni = ctx.needs_input_grad
     dgam, dbet, acc, ggam, gbet = _bn_grad_bufs(g, C, gamma, beta, ni[3], ni[4])
-    dy = ops.bn_act_backward(_fptr(g), C, 0, rows, 1, 1, y, C, C, gamma, ctx.st, 0.0, ctx.training,
-                             _new(g, rows, C), dgam, dbet, acc)
-    return dy, None, None, ggam, gbet
+    dy = ops.bn_act_backward(_fptr(g), C, 0, rows, 1, 1, y, C, C, gamma, ctx.st, ctx.slope, ctx.training,
+                             _new(g, *y.shape), dgam, dbet, acc)
+    return dy, None, None, ggam, gbet, None
 
 
 class TripleLinear(Function):
@@ -956,6 +961,144 @@ class DiscCnnFn(Function):
                                                                  ni[gi + 1])
       dy = ops.bn_act_backward(_fptr(gz), cin, 0, N, h, w, yp, cin, cin, params[gi], stp, slope, training, gz, dgam,
                                dbet, accb)
+
+
+# ---- layer-by-layer pieces for build_cnn architecture strings with R / U / P / FC tokens
+# (reference sg2im/layers.py:129-213).  The default 'C' only strings run through DiscCnnFn above.
+
+class Conv2dFn(Function):
+  """one nn.Conv2d (square kernel, same stride / padding on both axes) on an NHWC tensor"""
+
+  @staticmethod
+  def _desc(x, W, stride, pad):
+    N, H, Wd, _ = x.shape
+    return conv_desc([nhwc_src(x)], N, H, Wd, W.size(2), W.size(3), stride, pad)
+
+  @staticmethod
+  def forward(ctx, x, W, b, stride, pad, shadowed=False):
+    x = x.contiguous()
+    d = Conv2dFn._desc(x, W, stride, pad)
+    cout = W.size(0)
+    y = ops.conv2d_forward(d, _cl_weight(W), cout, b, _new(x, x.size(0), d.out_h, d.out_w, cout), cout)
+    ctx.save_for_backward(x, W, b)
+    ctx.geom = (stride, pad, shadowed)
+    return y
+
+  @staticmethod
+  def backward(ctx, g):
+    x, W, b = ctx.saved_tensors
+    stride, pad, shadowed = ctx.geom
+    ni = ctx.needs_input_grad
+    g = g.contiguous()
+    cout, cin, k = W.size(0), W.size(1), W.size(2)
+    d = Conv2dFn._desc(x, W, stride, pad)
+    dW, db = _conv_param_grads(d, g, cout, (cout, k, k, cin), ni[1], ni[2] and not shadowed, W, b)
+    if shadowed:
+      db = _shadowed_bias_grad(b, ni[2])
+    dx = None
+    if ni[0]:
+      dx = ops.conv2d_backward_data(d, _cl_weight(W), cout, g, cout, 0, cin, _new(g, *x.shape), cin)
+    return dx, dW, db, None, None, None
+
+
+class InstNormAct(Function):
+  """leaky_slope(InstanceNorm2d(y)) on an NHWC tensor"""
+
+  @staticmethod
+  def forward(ctx, y, slope):
+    y = y.contiguous()
+    st = ops.instnorm_stats(y, BN_EPS)
+    z = ops.instnorm_act_forward(y, st, slope, _new(y, *y.shape))
+    ctx.save_for_backward(y, st, z)
+    ctx.slope = slope
+    return z
+
+  @staticmethod
+  def backward(ctx, g):
+    y, st, z = ctx.saved_tensors
+    N, H, W, C = y.shape
+    g = g.contiguous()
+    dyn = ops.act_backward(_fptr(g), C, 0, N, H, W, z, C, C, ctx.slope, _new(g, *y.shape))
+    return ops.instnorm_backward(dyn, y, st, dyn), None
+
+
+class LeakyFn(Function):
+  """a LeakyReLU on its own (any dense tensor)"""
+
+  @staticmethod
+  def forward(ctx, x, slope):
+    x = x.contiguous()
+    z = ops.leaky_forward(x, slope, _new(x, *x.shape))
+    ctx.save_for_backward(z)
+    ctx.slope = slope
+    return z
+
+  @staticmethod
+  def backward(ctx, g):
+    z, = ctx.saved_tensors
+    C = z.size(-1)
+    g = g.contiguous()
+    return ops.act_backward(_fptr(g), C, 0, z.numel() // C, 1, 1, z, C, C, ctx.slope, _new(g, *z.shape)), None
+
+
+class UpsampleFn(Function):
+  """nn.Upsample(scale_factor=f, mode='nearest') on NHWC"""
+
+  @staticmethod
+  def forward(ctx, x, f):
+    x = x.contiguous()
+    N, H, W, C = x.shape
+    ctx.f, ctx.shape = f, tuple(x.shape)
+    return ops.resample_up(x, f, 1.0, _new(x, N, H * f, W * f, C))
+
+  @staticmethod
+  def backward(ctx, g):
+    return ops.pool_sum(g.contiguous(), ctx.f, 1.0, _new(g, *ctx.shape)), None
+
+
+class AvgPoolFn(Function):
+  """nn.AvgPool2d(f, f) on NHWC (floor(H/f) x floor(W/f) windows)"""
+
+  @staticmethod
+  def forward(ctx, x, f):
+    x = x.contiguous()
+    N, H, W, C = x.shape
+    ctx.f, ctx.shape = f, tuple(x.shape)
+    return ops.pool_sum(x, f, 1.0 / (f * f), _new(x, N, H // f, W // f, C))
+
+  @staticmethod
+  def backward(ctx, g):
+    return ops.resample_up(g.contiguous(), ctx.f, 1.0 / (ctx.f * ctx.f), _new(g, *ctx.shape)), None
+
+
+class MaxPoolFn(Function):
+  """nn.MaxPool2d(f, f) on NHWC"""
+
+  @staticmethod
+  def forward(ctx, x, f):
+    x = x.contiguous()
+    N, H, W, C = x.shape
+    ctx.f = f
+    ctx.save_for_backward(x)
+    return ops.maxpool_forward(x, f, _new(x, N, H // f, W // f, C))
+
+  @staticmethod
+  def backward(ctx, g):
+    x, = ctx.saved_tensors
+    return ops.maxpool_backward(x, g.contiguous(), ctx.f, _new(g, *x.shape)), None
+
+
+class AddFn(Function):
+  """a + b (the residual sum of reference sg2im/layers.py:117)"""
+
+  @staticmethod
+  def forward(ctx, a, b):
+    a, b = a.contiguous(), b.contiguous()
+    return ops.add_forward(a, b, _new(a, *a.shape))
+
+  @staticmethod
+  def backward(ctx, g):
+    return g, g
 
 
 class GapFn(Function):

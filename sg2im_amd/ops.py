@@ -359,6 +359,42 @@ def affine_act_forward(x, st, slope, out):
   return out
 
 
+def resample_up(x, factor, alpha, out):
+  """out (N, Ho, Wo, C) = alpha * nearest-upsample_factor(x), zero beyond the scaled input"""
+  N, H, W, C = x.shape
+  call('sg2im_resample_nearest_up', _f(x), N, H, W, C, int(factor), out.size(1), out.size(2), float(alpha), _f(out),
+       _stream())
+  return out
+
+
+def pool_sum(x, factor, alpha, out):
+  N, H, W, C = x.shape
+  call('sg2im_pool_sum_forward', _f(x), N, H, W, C, int(factor), float(alpha), _f(out), _stream())
+  return out
+
+
+def maxpool_forward(x, factor, out):
+  N, H, W, C = x.shape
+  call('sg2im_maxpool_forward', _f(x), N, H, W, C, int(factor), _f(out), _stream())
+  return out
+
+
+def maxpool_backward(x, dy, factor, dx):
+  N, H, W, C = x.shape
+  call('sg2im_maxpool_backward', _f(x), _f(dy), N, H, W, C, int(factor), _f(dx), _stream())
+  return dx
+
+
+def leaky_forward(x, slope, out):
+  call('sg2im_leaky_forward', _f(x), x.numel(), float(slope), _f(out), _stream())
+  return out
+
+
+def add_forward(a, b, out):
+  call('sg2im_add_forward', _f(a), _f(b), a.numel(), _f(out), _stream())
+  return out
+
+
 def instnorm_stats(x, eps=1e-5):
   """x: dense NHWC; returns (scale, shift), each (N, C): the InstanceNorm2d affine of every image"""
   N, H, W, C = x.shape

@@ -84,6 +84,18 @@ CONFIGS = {
     d_img=dict(arch='C4-8-2,C4-16-2', normalization='instance', activation='leakyrelu-0.2',
                padding='valid'),
   ),
+  # discriminators built from the other build_cnn tokens (R, P, U, FC; sg2im/layers.py:183-206)
+  'tiny_coco_archtokens': dict(
+    batch=dict(batch_size=3, image_size=(16, 16), num_objs=10, num_preds=4, min_objs=2,
+               max_objs=4, mask_size=4, style='coco', seed=83),
+    g=dict(image_size=(16, 16), embedding_dim=16, gconv_dim=16, gconv_hidden_dim=32,
+           gconv_num_layers=2, refinement_dims=(24, 16), normalization='batch',
+           activation='leakyrelu-0.2', mask_size=4, layout_noise_dim=4),
+    d_obj=dict(arch='R,C3-8-2,P2,FC-128-32', normalization='batch', activation='leakyrelu-0.2',
+               padding='same', object_size=16, pooling='max'),
+    d_img=dict(arch='C3-8,R,P2,C3-16-2,U2,R', normalization='batch', activation='leakyrelu-0.2',
+               padding='same', pooling='avg'),
+  ),
   # VG-style: no GT masks -> masks_pred feeds the layout and mask_net trains.
   'tiny_vg': dict(
     batch=dict(batch_size=2, image_size=(32, 32), num_objs=9, num_preds=6, min_objs=3,

@@ -58,7 +58,7 @@ def test_losses_and_adam():
   _run('sec_losses')
 
 
-@pytest.mark.parametrize('section', ['sec_golden_coco', 'sec_golden_vg', 'sec_golden_nonorm', 'sec_golden_mlpbn', 'sec_golden_instnorm'])
+@pytest.mark.parametrize('section', ['sec_golden_coco', 'sec_golden_vg', 'sec_golden_nonorm', 'sec_golden_mlpbn', 'sec_golden_instnorm', 'sec_golden_archtokens'])
 def test_full_step_against_reference_golden(section):
   """generator forward, all losses, every parameter gradient of G / D_obj / D_img and the
   BatchNorm running statistics against vectors produced by the imported reference"""

@@ -93,8 +93,12 @@ def test_activation_quirk_and_unsupported_options_fail_loudly():
   assert isinstance(inorm, torch.nn.InstanceNorm2d) and not inorm.state_dict()
   cnn_i, _ = layers.build_cnn('I3,C4-8-2,C4-16-2', normalization='instance', padding='valid')
   assert sorted(cnn_i.state_dict()) == ['0.bias', '0.weight', '3.bias', '3.weight']
-  with pytest.raises(NotImplementedError):
-    layers.build_cnn('C3-8,R')
+  with pytest.raises(ValueError):
+    layers.build_cnn('C3-8,X2')                           # reference layers.py:207
+  seq, c = layers.build_cnn('I3,C3-8,R,P2,C3-16-2,U2,R,FC-64-10,FC-10-4', activation='leakyrelu-0.2')
+  assert c == 4 and isinstance(seq, layers.SeqCnn) and isinstance(seq[2], torch.nn.MaxPool2d)
+  assert [k for k in seq.state_dict() if k.startswith('1.net.')][:2] == ['1.net.0.weight', '1.net.0.bias']
+  assert '9.weight' in seq.state_dict() and '11.bias' in seq.state_dict()
   cnn, c = layers.build_cnn('I3,C4-64-2,C4-128-2,C4-256-2', padding='valid', activation='leakyrelu-0.2')
   assert c == 256 and cnn.specs == [(4, 64, 2, 0), (4, 128, 2, 0), (4, 256, 2, 0)]
   assert [k for k in cnn.state_dict()][:3] == ['0.weight', '0.bias', '1.weight']

@@ -47,6 +47,11 @@ def test_generator_step_matches_reference(name):
   # BN running statistics after one training-mode forward
   for k, v in fix['state_after_g_forward']['G'].items():
     assert_close(tr.PG[k].float(), v.float(), RTOL, ATOL, 'buffer G.' + k)
+  # ... and the discriminators' after their one pass inside the generator loss (a ResidualBlock's
+  # BatchNorm has moved twice there: sg2im/layers.py:116-117)
+  for net, P in (('Do', tr.PDo), ('Di', tr.PDi)):
+    for k, v in fix['state_after_g_forward'].get(net, {}).items():
+      assert_close(P[k].float(), v.float(), RTOL, ATOL, 'buffer %s.%s' % (net, k))
 
 
 @pytest.mark.parametrize('name', GOLDEN_TRAIN_NAMES)

@@ -5,7 +5,7 @@ import torch
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 GOLDEN_NAMES = ('tiny_coco', 'tiny_vg')
-GOLDEN_TRAIN_NAMES = GOLDEN_NAMES + ('tiny_coco_nonorm', 'tiny_coco_mlpbn', 'tiny_coco_instnorm')     # (no eval-mode fixtures for these)
+GOLDEN_TRAIN_NAMES = GOLDEN_NAMES + ('tiny_coco_nonorm', 'tiny_coco_mlpbn', 'tiny_coco_instnorm', 'tiny_coco_archtokens')     # (no eval-mode fixtures for these)
 
 
 def load_golden(name):

@@ -362,6 +362,9 @@ def golden_case(name):
     report(name + ' G.grad ' + k, got, gref)
   for k, v in fix['state_after_g_forward']['G'].items():
     report(name + ' G.buf ' + k, G.state_dict()[k].float(), v.float())
+  for tag, net in (('Do', Do), ('Di', Di)):            # after their single pass inside the generator loss
+    for k, v in fix['state_after_g_forward'].get(tag, {}).items():
+      report(name + ' %s.buf %s' % (tag, k), net.state_dict()[k].float(), v.float())
   fake = ip.detach()
   Do.zero_grad(); Di.zero_grad()
   sf, acf = Do(fake, objs, boxes, o2i); sr, acr = Do(imgs, objs, boxes, o2i)
@@ -431,6 +434,10 @@ def sec_golden_instnorm():
   golden_case('tiny_coco_instnorm')     # InstanceNorm2d in the refinement network and both discriminators
 
 
+def sec_golden_archtokens():
+  golden_case('tiny_coco_archtokens')   # discriminators from R / P / U / FC build_cnn tokens
+
+
 def sec_golden_mlpbn():
   golden_case('tiny_coco_mlpbn')        # BatchNorm1d in every MLP (--mlp_normalization batch)
 
@@ -446,7 +453,7 @@ def sec_golden_vg():
 if __name__ == '__main__':
   print(torch.cuda.get_device_name(0))
   only = sys.argv[1:]
-  for fn in (sec_pool, sec_linear, sec_conv, sec_gconv, sec_layout, sec_losses, sec_golden_coco, sec_golden_vg, sec_golden_eval, sec_golden_nonorm, sec_golden_mlpbn, sec_golden_instnorm):
+  for fn in (sec_pool, sec_linear, sec_conv, sec_gconv, sec_layout, sec_losses, sec_golden_coco, sec_golden_vg, sec_golden_eval, sec_golden_nonorm, sec_golden_mlpbn, sec_golden_instnorm, sec_golden_archtokens):
     if not only or fn.__name__ in only:
       section(fn)
   bad = [r for r in RESULTS if not (r[1] <= 1e-4 or r[3] <= 1e-6)]
