@@ -8,6 +8,8 @@ Tolerances (fp32 throughout, stated per SURVEY.md section 8c):
   * tensors that are analytically zero (bias gradients of a convolution that feeds a
     training-mode BatchNorm) are pure rounding noise (~1e-8) on both sides: ABS <= 1e-6.
 """
+import os
+
 import pytest
 import torch
 
@@ -430,11 +432,57 @@ def test_forward_json_inference_path_matches_oracle():
     assert max_rel_err(a.cpu(), b) <= 1e-4, (name, max_rel_err(a.cpu(), b))
 
 
+def test_run_model_script_writes_the_oracles_images(tmp_path):
+  """scripts/run_model.py (the reference's inference entry point): checkpoint -> forward_json ->
+  de-normalised PNGs, against the oracle's eval-mode forward of the same checkpoint (<= 1 grey level)."""
+  import copy, importlib.util, json
+  import numpy as np
+  from PIL import Image
+  from oracle import sg2im_oracle as orc
+  from sg2im_amd.model import Sg2ImModel
+  from sg2im_amd.utils import imagenet_deprocess_batch
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  sg_path = os.path.join(root, 'scene_graphs', 'example_meadow.json')
+  graphs = json.load(open(sg_path))
+  names = ['__image__'] + sorted({o for g in graphs for o in g['objects']})
+  preds = ['__in_image__'] + sorted({r[1] for g in graphs for r in g['relationships']})
+  vocab = {'object_idx_to_name': names, 'object_name_to_idx': {n: i for i, n in enumerate(names)},
+           'pred_idx_to_name': preds, 'pred_name_to_idx': {n: i for i, n in enumerate(preds)}}
+  gcfg = dict(vocab=vocab, image_size=(32, 32), embedding_dim=32, gconv_dim=32, gconv_hidden_dim=64,
+              gconv_num_layers=2, refinement_dims=(64, 32, 16), normalization='batch', activation='leakyrelu-0.2',
+              mask_size=8, layout_noise_dim=0)
+  P = orc.init_generator_params(gcfg, 5, randomize_bn=True)
+  last = max(k for k in P if k.startswith('box_net.') and k.endswith('.bias'))
+  P[last.replace('.bias', '.weight')] *= 0.01
+  P[last] = torch.tensor([0.1, 0.15, 0.7, 0.8])          # proper predicted boxes
+  ckpt = tmp_path / 'model.pt'
+  torch.save({'model_kwargs': gcfg, 'model_state': P}, ckpt)
+  spec = importlib.util.spec_from_file_location('run_model', os.path.join(root, 'scripts', 'run_model.py'))
+  run_model = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(run_model)
+  out_dir = tmp_path / 'out'
+  args = run_model.parser.parse_args(['--checkpoint', str(ckpt), '--scene_graphs_json', sg_path,
+                                      '--output_dir', str(out_dir)])
+  assert run_model.main(args) == 0
+  enc = Sg2ImModel(**gcfg)                                # host-side encoding only
+  objs, triples, o2i = [t.cpu() for t in enc.encode_scene_graphs(copy.deepcopy(graphs))]
+  with torch.no_grad():
+    want = orc.generator_forward({k: v.clone() for k, v in P.items()}, gcfg, objs, triples, o2i, training=False)[0]
+  want = imagenet_deprocess_batch(want)
+  for i in range(len(graphs)):
+    got = np.asarray(Image.open(out_dir / ('img%06d.png' % i)))
+    ref = want[i].numpy().transpose(1, 2, 0)
+    assert got.shape == ref.shape == (32, 32, 3)
+    diff = np.abs(got.astype(np.int16) - ref.astype(np.int16))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.02, (i, diff.max(), (diff > 0).mean())
+  with pytest.raises(RuntimeError):
+    run_model.main(run_model.parser.parse_args(['--checkpoint', str(ckpt), '--device', 'cpu']))
+
+
 def test_graph_iteration_vg_style_and_aux_losses_match_eager():
   """The one-graph iteration (side-stream discriminator steps) on a VG-style batch - predicted
   masks feed the layout, so mask_net trains - with the auxiliary losses on, against the plain
-  eager launches.  (The mask gradient accumulates through LDS float atomics inside one
-  workgroup, so this case is compared with a tolerance instead of bit for bit.)"""
+  eager launches, bit for bit (no kernel on the path uses floating-point atomics)."""
   from sg2im_amd.synthetic import make_vocab, synthetic_batch
   from sg2im_amd.trainer import Trainer
   from tests import hip_harness as hh
