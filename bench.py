@@ -1,7 +1,7 @@
 """bench.py - training images/sec of one full G+D step (reference scripts/train.py:524-592)
 on MI355X.
 
-  python bench.py --gpus 1 --steps 30 --warmup 5
+  python bench.py --gpus 1 --steps 50 --warmup 10
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -36,8 +36,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_m
 def parse():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=30)
-  ap.add_argument('--warmup', type=int, default=5)
+  ap.add_argument('--steps', type=int, default=50)      # >= 50 warm steps
+  ap.add_argument('--warmup', type=int, default=10)
   ap.add_argument('--batch_size', type=int, default=32, help='images per GPU (reference default, train.py:51)')
   ap.add_argument('--image_size', type=int, default=64)
   ap.add_argument('--cpu_baseline_steps', type=int, default=3, help='0 disables the CPU-oracle leg')
