@@ -147,6 +147,7 @@ def main():
       trainer.step(batch)
     summ = ops.TIMER.summary()
     crn = ops.TIMER.summary('crn')       # the launches of the refinement network alone
+    alg_bytes = sum(v for k, v in ops.TIMER.alg_bytes.items() if k.startswith('igemm')) / n_prof
     ops.TIMER = None
     hbm = {k[4:]: v for k, v in summ.items() if k.startswith('hbm_')}       # the HBM-bound kernels
     summ = {k: v for k, v in summ.items() if not k.startswith('hbm_')}
@@ -159,6 +160,7 @@ def main():
       'bound': 'mfma', 'kernel': 'implicit-GEMM family conv_fwd/dgrad/wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32) incl. split-K finish',
       'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
       'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+      'algorithmic_mb_per_step': round(alg_bytes / 1e6, 1),     # every operand read once, every result written once
       'launches_per_step': launches // n_prof, 'gflop_per_step': round(flops / n_prof / 1e9, 1),
       'ms_per_step_in_kernel': round(ms / n_prof, 3),
       'crn_only': (lambda f, m: {'gflop_per_step': round(f / n_prof / 1e9, 1), 'ms_per_step': round(m / n_prof, 3),
@@ -176,6 +178,18 @@ def main():
                       'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else 0.0}
                   for k, v in summ.items()},
     }
+    # memory-side traffic of the same family cannot be counted from inside this process: it comes from the
+    # committed rocprofv3 --pmc passes over this workload (tools/pmc_step.sh -> profiles/r1_pmc_step_traffic.json)
+    pmc_path = os.path.join(ROOT, 'profiles', 'r1_pmc_step_traffic.json')
+    if args.style == 'coco' and S == 64 and args.batch_size == 32 and os.path.exists(pmc_path):
+      pmc = json.load(open(pmc_path))
+      per_step = (pmc['fetch_mb_per_step'] + pmc['write_mb_per_step']) * 1e6
+      roofline['traffic'] = round(per_step / max(roofline['launches_per_step'], 1))     # bytes per GEMM launch
+      roofline['traffic_detail'] = {'source': 'profiles/r1_pmc_step_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+                                              'separate passes, FETCH_SIZE x2 per the gfx950 note; counts L2 misses, '
+                                              'most of which the 256 MB Infinity Cache serves)',
+                                    'fetch_mb_per_step': pmc['fetch_mb_per_step'], 'write_mb_per_step': pmc['write_mb_per_step'],
+                                    'over_algorithmic': round(per_step / alg_bytes, 2) if alg_bytes else None}
   if use_dist:
     dist.barrier()
 

@@ -144,6 +144,7 @@ class KernelTimer(object):
 
   def __init__(self):
     self.records = []        # (kind, flops, start_event, end_event, tag)
+    self.alg_bytes = {}      # kind -> algorithmic HBM bytes of its launches (operands read once, result written once)
 
   def summary(self, tag=None):
     """per-kind totals; tag: only the launches made inside that network (TIMER_TAG)"""
@@ -177,9 +178,24 @@ def _desc_k(desc):
   return desc.kh * desc.kw * sum(desc.src[i].channels for i in range(desc.nsrc))
 
 
+def _desc_src_floats(desc):
+  """stored elements behind the (virtual) input: an upsampled source is read at its own size"""
+  n = 0
+  for i in range(desc.nsrc):
+    s = desc.src[i]
+    n += desc.batch * (desc.in_h >> s.upsample_log2) * (desc.in_w >> s.upsample_log2) * s.channels
+  return n
+
+
+def _note_bytes(kind, nfloats):
+  if TIMER is not None:
+    TIMER.alg_bytes[kind] = TIMER.alg_bytes.get(kind, 0.0) + 4.0 * nfloats
+
+
 def conv2d_forward(desc, weight, cout, bias, out, ld_out, out_slope=1.0, accumulate=False):
   ws = workspace(out.device)
   flops = 2.0 * desc.batch * desc.out_h * desc.out_w * cout * _desc_k(desc)
+  _note_bytes('igemm_fwd', _desc_src_floats(desc) + cout * _desc_k(desc) + desc.batch * desc.out_h * desc.out_w * cout)
   _timed('igemm_fwd', flops, lambda: call(
     'sg2im_conv2d_forward', byref(desc), _f(weight), int(cout), _f(bias), float(out_slope), _f(out),
     int(ld_out), int(accumulate), _f(ws), ws.numel() * 4, _stream()))
@@ -189,6 +205,8 @@ def conv2d_forward(desc, weight, cout, bias, out, ld_out, out_slope=1.0, accumul
 def conv2d_backward_data(desc, weight, cout, dy, ld_dy, c_begin, c_count, dx, ld_dx, accumulate=False):
   ws = workspace(dx.device)
   flops = 2.0 * desc.batch * desc.out_h * desc.out_w * cout * desc.kh * desc.kw * c_count
+  _note_bytes('igemm_dgrad', desc.batch * desc.out_h * desc.out_w * cout + cout * desc.kh * desc.kw * c_count +
+              desc.batch * desc.in_h * desc.in_w * c_count)
   _timed('igemm_dgrad', flops, lambda: call(
     'sg2im_conv2d_backward_data', byref(desc), _f(weight), int(cout), _f(dy), int(ld_dy), int(c_begin),
     int(c_count), _f(dx), int(ld_dx), int(accumulate), _f(ws), ws.numel() * 4, _stream()))
@@ -199,6 +217,7 @@ def conv2d_backward_weight(desc, dy, ld_dy, cout, dweight, accumulate=False, dbi
   """dbias (optional): the layer's bias gradient, produced in the same pass over dy."""
   ws = workspace(dweight.device)
   flops = 2.0 * desc.batch * desc.out_h * desc.out_w * cout * _desc_k(desc)
+  _note_bytes('igemm_wgrad', _desc_src_floats(desc) + desc.batch * desc.out_h * desc.out_w * cout + cout * _desc_k(desc))
   _timed('igemm_wgrad', flops, lambda: call(
     'sg2im_conv2d_backward_weight', byref(desc), _f(dy), int(ld_dy), int(cout), _f(dweight),
     _f(dbias) if dbias is not None else None, int(accumulate), _f(ws), ws.numel() * 4, _stream()))
