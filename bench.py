@@ -46,6 +46,9 @@ def parse():
   ap.add_argument('--seed', type=int, default=0)
   ap.add_argument('--style', default='coco', choices=['coco', 'vg'],
                   help="'vg': VG-shape graphs without GT masks (BASELINE configs[2] shape, fp32) instead of the COCO headline workload")
+  ap.add_argument('--eval_generator', action='store_true',
+                  help='generator in eval() mode (running BatchNorm statistics), as the reference trains after '
+                       '--eval_mode_after iterations (train.py:509-512); not the headline workload')
   ap.add_argument('--force_dist', action='store_true',
                   help='debug: 1-rank RCCL group with real all-reduces (exercises the N>1 code path on one GPU)')
   return ap.parse_args()
@@ -109,6 +112,8 @@ def main():
   # (data parallel: the same overlapped graph without its Adam updates, the four all-reduces issued
   # eagerly, then an Adam graph - DESIGN.md section 6; --no_graphs selects the eager segments)
   trainer_graphs = trainer.use_graphs
+  if args.eval_generator:
+    trainer.set_generator_eval()
   if args.force_dist:
     trainer.reducer.force = True
 
@@ -205,7 +210,8 @@ def main():
       'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
       'config': {'workload': ('COCO-%d synthetic scene graphs (3-8 objects + __image__, <=16 triples per image), '
                               if args.style == 'coco' else 'VG-%d synthetic scene graphs (3-10 objects, no GT masks), ') % S +
-                             'batch %d per GPU, full G + D_obj + D_img step with 3x Adam' % args.batch_size,
+                             'batch %d per GPU, full G + D_obj + D_img step with 3x Adam' % args.batch_size +
+                             (' (generator in eval mode)' if args.eval_generator else ''),
                  'global_batch': args.batch_size * world, 'image_size': S,
                  'objects': int(batch[1].numel()), 'triples': int(batch[4].size(0)),
                  'parallelism': 'dp%d' % world, 'total_loss': round(host_losses['total_loss'], 5),
