@@ -432,6 +432,58 @@ def test_forward_json_inference_path_matches_oracle():
     assert max_rel_err(a.cpu(), b) <= 1e-4, (name, max_rel_err(a.cpu(), b))
 
 
+@pytest.mark.parametrize('H,W,f', [(7, 9, 2), (8, 8, 2), (10, 7, 3), (5, 5, 1)])
+def test_spatial_tokens_on_ragged_sizes(H, W, f):
+  """The U / P tokens of build_cnn (reference layers.py:189-198) on sizes the pooling window does not
+  divide (floor semantics: trailing rows / columns are dropped and get zero gradient), forward and
+  backward against the ATen CPU ops the reference calls; max-pool ties resolve to the first maximum."""
+  import torch.nn.functional as F
+  from sg2im_amd import functional as HF
+  from tests import hip_harness as hh
+  dev = hh.dev()
+  gen = torch.Generator().manual_seed(H * 100 + W * 10 + f)
+  x = torch.randn(3, 5, H, W, generator=gen)
+  x[0, 0, :2, :2] = 1.5                                  # a tie inside the first window
+  cases = (('max', HF.MaxPoolFn, lambda t: F.max_pool2d(t, f, f)),
+           ('avg', HF.AvgPoolFn, lambda t: F.avg_pool2d(t, f, f)),
+           ('up', HF.UpsampleFn, lambda t: F.interpolate(t, scale_factor=f, mode='nearest')))
+  for name, fn, ref in cases:
+    if name != 'up' and (H < f or W < f):
+      continue
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    g = torch.randn(yr.shape, generator=gen)
+    yr.backward(g)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+    yh = fn.apply(xh, f)
+    yh.backward(g.permute(0, 2, 3, 1).contiguous().to(dev))
+    assert torch.equal(yh.detach().cpu().permute(0, 3, 1, 2), yr.detach()) or \
+        torch.allclose(yh.detach().cpu().permute(0, 3, 1, 2), yr.detach(), rtol=1e-6, atol=1e-7), name
+    assert torch.allclose(xh.grad.cpu().permute(0, 3, 1, 2), xr.grad, rtol=1e-6, atol=1e-7), name
+
+
+def test_instance_norm_kernels_match_torch():
+  """sg2im_instnorm_* against F.instance_norm + leaky_relu (forward and input gradient), channel counts
+  that do not fill a 64-lane block and a single-pixel-row image"""
+  import torch.nn.functional as F
+  from sg2im_amd import functional as HF
+  from tests import hip_harness as hh
+  from tests.util import max_rel_err
+  dev = hh.dev()
+  gen = torch.Generator().manual_seed(9)
+  for (N, C, H, W), slope in (((2, 3, 5, 7), 0.2), ((3, 70, 4, 4), 0.01), ((1, 130, 1, 9), 0.0)):
+    x = torch.randn(N, C, H, W, generator=gen) * 2 + 0.5
+    xr = x.clone().requires_grad_(True)
+    yr = F.leaky_relu(F.instance_norm(xr, eps=1e-5), slope)
+    g = torch.randn(yr.shape, generator=gen)
+    yr.backward(g)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+    yh = HF.InstNormAct.apply(xh, slope)
+    yh.backward(g.permute(0, 2, 3, 1).contiguous().to(dev))
+    assert max_rel_err(yh.detach().cpu().permute(0, 3, 1, 2), yr.detach()) <= 1e-5
+    assert max_rel_err(xh.grad.cpu().permute(0, 3, 1, 2), xr.grad) <= 1e-4
+
+
 def test_run_model_script_writes_the_oracles_images(tmp_path):
   """scripts/run_model.py (the reference's inference entry point): checkpoint -> forward_json ->
   de-normalised PNGs, against the oracle's eval-mode forward of the same checkpoint (<= 1 grey level)."""
