@@ -65,3 +65,66 @@ def test_default_architecture_forward_and_input_gradients():
   assert abs(float(ac2) - float(ac)) < 1e-4
   PI = {k: v.clone() for k, v in Di.state_dict().items()}
   assert_close(orc.patch_discriminator(PI, dict(D_IMG_DEFAULTS), ip), Di(ip), 2e-5, 2e-5, 'd_img scores')
+
+
+def test_build_cnn_state_dict_matches_reference_for_random_arch_strings():
+  """drop-in check for arbitrary --d_obj_arch / --d_img_arch strings: the module list (and so the
+  checkpoint keys and shapes) of sg2im_amd.layers.build_cnn and of the oracle's parameter walker equal
+  the reference's build_cnn (layers.py:129-213) for random token sequences and every normalization"""
+  import random
+  _ref()
+  from sg2im.layers import build_cnn as ref_build_cnn
+  from sg2im_amd.layers import build_cnn
+  rng = random.Random(7)
+  for trial in range(40):
+    toks, flat = [], False
+    if rng.random() < 0.5:
+      toks.append('I%d' % rng.choice([1, 3, 4]))
+    cin = int(toks[0][1:]) if toks else 3
+    for _ in range(rng.randint(1, 6)):
+      kind = rng.choice(['C', 'C', 'C', 'R', 'U', 'P'])
+      if kind == 'C':
+        k, c = rng.choice([1, 3, 5]), rng.choice([4, 8, 12])
+        toks.append('C%d-%d' % (k, c) if rng.random() < 0.5 else 'C%d-%d-%d' % (k, c, rng.choice([1, 2])))
+      elif kind == 'R':
+        toks.append('R')
+      else:
+        toks.append('%s%d' % (kind, rng.choice([2, 3])))
+    for _ in range(rng.randint(0, 2)):
+      toks.append('FC-%d-%d' % (rng.choice([16, 32]), rng.choice([8, 10])))
+    arch = ','.join(toks)
+    norm = rng.choice(['batch', 'instance', 'none'])
+    pool = rng.choice(['max', 'avg'])
+    with contextlib.redirect_stdout(io.StringIO()):
+      ref, ref_c = ref_build_cnn(arch, normalization=norm, activation='leakyrelu-0.2', padding='same', pooling=pool)
+    mine, my_c = build_cnn(arch, normalization=norm, activation='leakyrelu-0.2', padding='same', pooling=pool)
+    assert my_c == ref_c, arch
+    want = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    got = {k: tuple(v.shape) for k, v in mine.state_dict().items()}
+    assert got == want, (arch, norm)
+    assert [type(m).__name__ for m in mine] == [type(m).__name__ for m in ref], (arch, norm)
+    P = {}
+    body = arch if arch.startswith('I') else 'I%d,%s' % (cin, arch)
+    assert orc._init_disc_cnn(P, 'cnn', body, cin, torch.Generator().manual_seed(0), False, norm) == ref_c
+    assert {('cnn.' + k): s for k, s in want.items()} == {k: tuple(v.shape) for k, v in P.items()}, (arch, norm)
+
+
+def test_oracle_cnn_forward_matches_reference_for_arch_tokens():
+  """numerical check of the oracle's build_cnn restatement (R / U / P / FC, all normalizations, including
+  the doubled BatchNorm running-statistics update inside ResidualBlock) against the live reference"""
+  _ref()
+  from sg2im.layers import build_cnn as ref_build_cnn
+  cases = [('I3,C3-8,R,P2,C3-12-2,U2,R', 'batch', 'avg'), ('I3,R,C3-8-2,P2,FC-128-16,FC-16-4', 'batch', 'max'),
+           ('I4,C5-8,P3,R,U3,C1-6', 'instance', 'max'), ('I3,C3-8,R,R,P2', 'none', 'avg')]
+  for arch, norm, pool in cases:
+    torch.manual_seed(11)
+    with contextlib.redirect_stdout(io.StringIO()):
+      ref, _ = ref_build_cnn(arch, normalization=norm, activation='leakyrelu-0.2', padding='same', pooling=pool)
+    ref.train()
+    P = {'cnn.' + k: v.clone() for k, v in ref.state_dict().items()}
+    x = torch.randn(4, int(arch.split(',')[0][1:]), 16, 16)
+    want = ref(x)
+    got = orc.disc_cnn(P, 'cnn', x, arch, 0.2, 'same', True, norm, pool)
+    assert_close(got, want, 2e-5, 2e-5, arch)
+    for k, v in ref.state_dict().items():          # running statistics after ONE forward (moved twice in R)
+      assert_close(P['cnn.' + k].float(), v.float(), 2e-5, 2e-5, arch + ' ' + k)
