@@ -462,6 +462,49 @@ def test_spatial_tokens_on_ragged_sizes(H, W, f):
     assert torch.allclose(xh.grad.cpu().permute(0, 3, 1, 2), xr.grad, rtol=1e-6, atol=1e-7), name
 
 
+@pytest.mark.parametrize('arch,norm,pool', [
+  ('I3,C3-8,R,P2,C3-12-2,U2,R', 'batch', 'avg'), ('I3,R,C3-8-2,P2,FC-128-16,FC-16-4', 'batch', 'max'),
+  ('I4,C5-8,P3,R,U3,C1-6', 'instance', 'max'), ('I3,C3-8,R,R,P2', 'none', 'avg')])
+def test_build_cnn_arch_tokens_match_oracle(arch, norm, pool):
+  """build_cnn strings beyond the 'C' token (reference layers.py:183-206) on the layer-by-layer HIP
+  path: output, input gradient, every parameter gradient and the BatchNorm running statistics (moved
+  twice inside a ResidualBlock) against the oracle's autograd"""
+  from oracle import sg2im_oracle as orc
+  from sg2im_amd.layers import build_cnn
+  from tests import hip_harness as hh
+  from tests.util import max_rel_err
+  dev = hh.dev()
+  cin = int(arch.split(',')[0][1:])
+  gen = torch.Generator().manual_seed(17)
+  P = {}
+  orc._init_disc_cnn(P, 'cnn', arch, cin, gen, True, norm)
+  x = torch.randn(4, cin, 16, 16, generator=gen)
+  Po = {k: v.clone().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in P.items()}
+  xo = x.clone().requires_grad_(True)
+  want = orc.disc_cnn(Po, 'cnn', xo, arch, 0.2, 'same', True, norm, pool)
+  g = torch.randn(want.shape, generator=gen)
+  want.backward(g)
+  cnn, _ = build_cnn(arch, normalization=norm, activation='leakyrelu-0.2', padding='same', pooling=pool)
+  hh.load_params(cnn, {k[4:]: v for k, v in P.items()})
+  cnn = cnn.to(dev).train()
+  xh = x.permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+  got = cnn(xh)
+  gh = g.to(dev) if got.dim() == 2 else g.permute(0, 2, 3, 1).contiguous().to(dev)
+  got.backward(gh)
+  out = got.detach().cpu() if got.dim() == 2 else got.detach().cpu().permute(0, 3, 1, 2)
+  assert max_rel_err(out, want.detach()) <= REL
+  assert max_rel_err(xh.grad.cpu().permute(0, 3, 1, 2), xo.grad) <= REL
+  # (a bias whose effect a later batch / instance norm cancels has an analytically zero gradient: both
+  # sides hold rounding noise there, so the floor is relative to the largest gradient in the network)
+  scale = max(float(Po['cnn.' + k].grad.abs().max()) for k, _ in cnn.named_parameters())
+  for k, p in cnn.named_parameters():
+    ref = Po['cnn.' + k].grad
+    err_abs = float((p.grad.cpu() - ref).abs().max())
+    assert max_rel_err(p.grad.cpu(), ref) <= REL or err_abs <= max(ABS, REL * scale), (k, err_abs, scale)
+  for k, b in cnn.named_buffers():
+    assert max_rel_err(b.float().cpu(), Po['cnn.' + k].detach().float()) <= REL, k
+
+
 def test_instance_norm_kernels_match_torch():
   """sg2im_instnorm_* against F.instance_norm + leaky_relu (forward and input gradient), channel counts
   that do not fill a 64-lane block and a single-pixel-row image"""
