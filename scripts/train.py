@@ -9,7 +9,6 @@ that reproduces the collate layout (``--dataset coco|vg`` selects the graph styl
 reference flag is accepted; flags whose feature is not on the HIP path yet fail loudly.
 """
 import argparse
-import math
 import os
 import sys
 import time

@@ -14,7 +14,6 @@ Gradient semantics (tested in tests/test_dp_gloo.py): every rank computes the re
 per-shard loss (means over ITS objects / pixels), so the applied gradient is the mean over
 ranks of the per-shard gradients - not the gradient of the concatenated batch.
 """
-import torch
 import torch.distributed as dist
 
 

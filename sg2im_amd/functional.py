@@ -9,7 +9,7 @@ import torch
 from torch.autograd import Function
 
 from . import ops
-from .ops import conv_desc, nhwc_src, rows_src, SrcSpec
+from .ops import conv_desc, nhwc_src, rows_src
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 

@@ -5,7 +5,6 @@ stream and shapes.  Every function enqueues HIP kernels from libsg2im_hip.so on
 ``torch.cuda.current_stream()`` and returns immediately.  Inputs must live on the GPU;
 anything else raises - there is no CPU path.
 """
-import ctypes
 from ctypes import byref, c_int, c_longlong, c_void_p
 
 import torch

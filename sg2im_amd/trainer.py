@@ -14,7 +14,6 @@ Differences from the reference that do not change the mathematics:
 import math
 
 import torch
-import torch.distributed as dist
 
 from . import _lib
 from . import functional as HF
