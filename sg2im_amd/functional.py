@@ -631,15 +631,24 @@ class RefinementFn(Function):
     grads = [None] * len(params)
     g = g.contiguous()
     Co = Wo0.size(0)
+    # weight gradients go to a second stream when they accumulate straight into registered sinks
+    # (otherwise their results would be allocated on that stream and handed to autograd from it)
+    side = ops.SideLane(g.device)
+    side.on = side.on and all(_sink(p) is not None for p in params[:4 * L + 4])
+    def wgrad(desc, dy, cout, shape, need_w, need_b, Wp, bp):
+      return side.run(lambda: _conv_param_grads(desc, dy, cout, shape, need_w, need_b, Wp, bp), dy, desc)
+    # Order per layer: data gradient (big, alone on the GPU), then its weight gradient on the side
+    # stream underneath the small kernels that lead to the next data gradient, which waits for it.
     # output 1x1 conv
-    grads[4 * L + 2], grads[4 * L + 3] = _conv_param_grads(do2, g, Wo2.size(0), (Wo2.size(0), 1, 1, Co),
-                                                           ni[4 * L + 2], ni[4 * L + 3], Wo2, bo2)
     dz = _new(g, N, H, W, Co)
     ops.conv2d_backward_data(do2, _cl_weight(Wo2), Wo2.size(0), g, Wo2.size(0), 0, Co, dz, Co)
+    grads[4 * L + 2], grads[4 * L + 3] = wgrad(do2, g, Wo2.size(0), (Wo2.size(0), 1, 1, Co),
+                                               ni[4 * L + 2], ni[4 * L + 3], Wo2, bo2)
     ops.act_backward(_fptr(dz), Co, 0, N, H, W, z, Co, Co, slope, dz)
-    grads[4 * L], grads[4 * L + 1] = _conv_param_grads(do0, dz, Co, (Co, 3, 3, Cf), ni[4 * L], ni[4 * L + 1], Wo0, bo0)
     gz = _new(g, N, H, W, Cf)                      # grad w.r.t. activated feats of the last module
+    side.barrier()
     ops.conv2d_backward_data(do0, _cl_weight(Wo0), Co, dz, Co, 0, Cf, gz, Cf)
+    grads[4 * L], grads[4 * L + 1] = wgrad(do0, dz, Co, (Co, 3, 3, Cf), ni[4 * L], ni[4 * L + 1], Wo0, bo0)
     pool2 = 0
     need_layout = ctx.needs_input_grad[0]
     # layout channels that need gradients (the noise channels appended by the model do not)
@@ -656,20 +665,20 @@ class RefinementFn(Function):
       dy1 = ops.bn_act_backward(_fptr(gz), gz.size(3), pool2, N, h, w, y1, C, C, g1, st1, slope, training,
                                 _new(g, N, h, w, C), dg1, db1n, acc1)
       d1 = conv_desc([nhwc_src(y0, 0, st0.scale, st0.shift, slope)], N, h, w, 3, 3, 1, 1)
-      grads[4 * i + 2], grads[4 * i + 3] = _conv_param_grads(d1, dy1, C, (C, 3, 3, C), ni[4 * i + 2],
-                                                              ni[4 * i + 3] and not training, W1p, b1)
+      gz0 = _new(g, N, h, w, C)
+      side.barrier()
+      ops.conv2d_backward_data(d1, _cl_weight(W1p), C, dy1, C, 0, C, gz0, C)
+      grads[4 * i + 2], grads[4 * i + 3] = wgrad(d1, dy1, C, (C, 3, 3, C), ni[4 * i + 2],
+                                                  ni[4 * i + 3] and not training, W1p, b1)
       if training:
         grads[4 * i + 3] = _shadowed_bias_grad(b1, ni[4 * i + 3])
-      gz0 = _new(g, N, h, w, C)
-      ops.conv2d_backward_data(d1, _cl_weight(W1p), C, dy1, C, 0, C, gz0, C)
       dg0, db0n, acc0, grads[k], grads[k + 1] = _bn_grad_bufs(g, C, g0, be0, ni[k], ni[k + 1])
-      dy0 = ops.bn_act_backward(_fptr(gz0), C, 0, N, h, w, y0, C, C, g0, st0, slope, training, dy1, dg0, db0n, acc0)
+      # (dy1's buffer is recycled for dy0 unless a side-stream weight gradient may still be reading it)
+      dy0 = ops.bn_act_backward(_fptr(gz0), C, 0, N, h, w, y0, C, C, g0, st0, slope, training,
+                                _new(g, N, h, w, C) if side.on else dy1, dg0, db0n, acc0)
       Cprev = feat_src.channels
       d0 = conv_desc([nhwc_src(lay), feat_src], N, h, w, 3, 3, 1, 1)
-      grads[4 * i], grads[4 * i + 1] = _conv_param_grads(d0, dy0, C, (C, 3, 3, Cl + Cprev), ni[4 * i],
-                                                          ni[4 * i + 1] and not training, W0p, b0)
-      if training:
-        grads[4 * i + 1] = _shadowed_bias_grad(b0, ni[4 * i + 1])
+      side.barrier()
       if need_layout:
         dl = _new(g, N, h, w, Cg)
         ops.conv2d_backward_data(d0, _cl_weight(W0p), C, dy0, C, 0, Cg, dl, Cg)
@@ -678,11 +687,16 @@ class RefinementFn(Function):
         gz = _new(g, N, h, w, Cprev)               # at this (upsampled) resolution; summed 2x2 next
         ops.conv2d_backward_data(d0, _cl_weight(W0p), C, dy0, C, Cl, Cprev, gz, Cprev)
         pool2 = 1
+      grads[4 * i], grads[4 * i + 1] = wgrad(d0, dy0, C, (C, 3, 3, Cl + Cprev), ni[4 * i],
+                                              ni[4 * i + 1] and not training, W0p, b0)
+      if training:
+        grads[4 * i + 1] = _shadowed_bias_grad(b0, ni[4 * i + 1])
     dlayout = None
     if need_layout:
       dlayout = _new(g, N, H, W, Cl) if Cg == Cl else torch.zeros(N, H, W, Cl, dtype=torch.float32, device=g.device)
       ops.pyramid_backward([t for t, _ in dlevels], [f for _, f in dlevels], [Cg] * len(dlevels), N, H, W, Cg,
                            dlayout)
+    side.join()
     ctx.saved = None
     return (dlayout, None, None, None, None) + tuple(grads)
 

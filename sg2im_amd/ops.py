@@ -5,6 +5,7 @@ stream and shapes.  Every function enqueues HIP kernels from libsg2im_hip.so on
 ``torch.cuda.current_stream()`` and returns immediately.  Inputs must live on the GPU;
 anything else raises - there is no CPU path.
 """
+import os
 from ctypes import byref, c_int, c_longlong, c_void_p
 
 import torch
@@ -64,6 +65,55 @@ def _lane(device):
   if _raw_stream is not None:
     return (idx, _raw_stream(idx))
   return (idx, torch.cuda.current_stream(idx).cuda_stream)
+
+
+_wgrad_streams = {}
+WGRAD_SIDE = os.environ.get('SG2IM_WGRAD_SIDE', '1') != '0'
+
+
+class SideLane(object):
+  """Runs the weight-gradient launches of a backward pass on a second stream.  They are leaves of
+  the backward graph (nothing downstream reads dW before the optimiser), so the small kernels of
+  the data-gradient chain on the calling stream - BatchNorm backward, split-K finishes - execute
+  underneath them instead of alone on an otherwise idle GPU [measured: tools/overlap_probe.py].
+  Every tensor a side launch reads is kept referenced until ``join`` so the caching allocator
+  cannot hand its memory to the calling stream while the side stream still uses it."""
+
+  def __init__(self, device):
+    self.on = WGRAD_SIDE
+    self.used = False
+    self.keep = []
+    if self.on:
+      idx = device.index if device.index is not None else torch.cuda.current_device()
+      self.main = torch.cuda.current_stream(idx)
+      key = (idx, self.main.cuda_stream)
+      if key not in _wgrad_streams:
+        _wgrad_streams[key] = torch.cuda.Stream(device=idx)
+      self.side = _wgrad_streams[key]
+
+  def run(self, fn, *reads):
+    """fn() on the side stream, ordered after everything launched so far on the calling stream"""
+    if not self.on:
+      return fn()
+    ev = torch.cuda.Event()
+    ev.record(self.main)
+    self.side.wait_event(ev)
+    with torch.cuda.stream(self.side):
+      out = fn()
+    self.keep.extend(reads)
+    self.used = True
+    return out
+
+  def barrier(self):
+    """the calling stream waits for the side launches so far (the next big kernel runs alone)"""
+    if self.on and self.used:
+      self.main.wait_stream(self.side)
+
+  def join(self):
+    if self.used:
+      self.main.wait_stream(self.side)
+      self.keep = []
+      self.used = False
 
 
 def workspace(device):
