@@ -80,7 +80,9 @@ class SideLane(object):
   cannot hand its memory to the calling stream while the side stream still uses it."""
 
   def __init__(self, device):
-    self.on = WGRAD_SIDE
+    # only while a hipGraph is being captured: launched eagerly, the extra event / stream switches
+    # cost more host time (the eager step is launch bound) than the overlap returns
+    self.on = WGRAD_SIDE and torch.cuda.is_current_stream_capturing()
     self.used = False
     self.keep = []
     if self.on:
