@@ -268,6 +268,9 @@ int sg2im_bce_prob_loss(const float* prob, const float* target, long long n, flo
 int sg2im_cross_entropy_loss(const float* scores, int rows, int classes, const long long* labels,
                              float weight, float* loss, float* grad, float* partial,
                              hipStream_t stream);
+/* out[0] = terms[0][0] + terms[1][0] + ... (1 <= n <= 8, left to right): the total of the weighted loss
+ * terms, scripts/train.py:387-412 `total_loss += ...`, :538-550; `terms` is a HOST array of device pointers */
+int sg2im_sum_scalars(const float* const* terms, int n, float* out, hipStream_t stream);
 /* y = a * x[0..n) with a read from device memory (chains an upstream scalar gradient) */
 int sg2im_scale_by_scalar(const float* x, const float* a_dev, long long n, float* y, hipStream_t stream);
 

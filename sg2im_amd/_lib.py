@@ -79,6 +79,7 @@ _SIGNATURES = {
   'sg2im_bce_prob_loss': [_P, _P, _L, _F, _P, _P, _P, _P],
   'sg2im_cross_entropy_loss': [_P, _I, _I, _P, _F, _P, _P, _P, _P],
   'sg2im_scale_by_scalar': [_P, _P, _L, _P, _P],
+  'sg2im_sum_scalars': [_P, _I, _P, _P],
   'sg2im_adam_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
   'sg2im_adam_step_guarded': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P, _P],
 }

@@ -113,6 +113,17 @@ __global__ void scale_by_scalar_kernel(const float* __restrict__ x, const float*
     y[i] = x[i] * s;
 }
 
+struct ScalarPtrs { const float* p[8]; };
+
+// out = p[0][0] + p[1][0] + ... in that order (the total of the weighted loss terms)
+__global__ void sum_scalars_kernel(ScalarPtrs t, int n, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = t.p[0][0];
+    for (int i = 1; i < n; ++i) s += t.p[i][0];
+    out[0] = s;
+  }
+}
+
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float one_minus_b1, float b2, float one_minus_b2,
                             float step_size, float inv_bc2_sqrt, float eps, float gscale) {
@@ -227,6 +238,15 @@ int sg2im_scale_by_scalar(const float* x, const float* a_dev, long long n, float
   if (n == 0) return SG2IM_OK;
   const int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
   hipLaunchKernelGGL(scale_by_scalar_kernel, dim3(blocks), dim3(256), 0, stream, x, a_dev, n, y);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_sum_scalars(const float* const* terms, int n, float* out, hipStream_t stream) {
+  if (!terms || !out || n < 1 || n > 8) return SG2IM_ERR_ARG;
+  ScalarPtrs t;
+  for (int i = 0; i < 8; ++i) t.p[i] = i < n ? terms[i] : nullptr;
+  for (int i = 0; i < n; ++i) if (!t.p[i]) return SG2IM_ERR_ARG;
+  hipLaunchKernelGGL(sum_scalars_kernel, dim3(1), dim3(64), 0, stream, t, n, out);
   return ok_or(hipGetLastError());
 }
 

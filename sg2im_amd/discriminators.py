@@ -47,9 +47,9 @@ class AcDiscriminator(nn.Module):
     cls = HF.LinearAct.apply(vecs, self.obj_classifier.weight, self.obj_classifier.bias, 1.0)
     return real, cls
 
-  def forward_nhwc(self, x_nhwc, y):
+  def forward_nhwc(self, x_nhwc, y, ac_weight=1.0):
     real, cls = self.scores_nhwc(x_nhwc)
-    return real, HF.CrossEntropyLoss.apply(cls, y, 1.0)      # reference sg2im/discriminators.py:74
+    return real, HF.CrossEntropyLoss.apply(cls, y, float(ac_weight))      # reference sg2im/discriminators.py:74
 
   def forward(self, x, y):
     if x.dim() == 3:
@@ -66,10 +66,11 @@ class AcCropDiscriminator(nn.Module):
     self.object_size = object_size
     self.align_corners = ALIGN_CORNERS
 
-  def forward_nhwc(self, imgs_nhwc, objs, boxes, obj_to_img):
+  def forward_nhwc(self, imgs_nhwc, objs, boxes, obj_to_img, ac_weight=1.0):
+    """ac_weight: loss weight folded into the classification loss (the Trainer's ac_loss_weight)"""
     crops = crop_bbox_batch_nhwc(imgs_nhwc, boxes, obj_to_img, self.object_size,
                                  align_corners=self.align_corners)
-    return self.discriminator.forward_nhwc(crops, objs)
+    return self.discriminator.forward_nhwc(crops, objs, ac_weight)
 
   def forward(self, imgs, objs, boxes, obj_to_img):
     """imgs (N,3,H,W) -> (real_scores (O,1), ac_loss scalar)  (reference :87-90)"""

@@ -15,19 +15,32 @@ def get_gan_losses(gan_type):
   raise ValueError('Unrecognized GAN type "%s"' % gan_type)
 
 
-def bce_loss(input, target):
+def bce_loss(input, target, weight=1.0):
   """Numerically stable BCE-with-logits against a constant target (reference
-  sg2im/losses.py:39-57): mean(max(x,0) - x*t + log(1+exp(-|x|)))."""
-  return HF.BceLogitsLoss.apply(input, float(target), 1.0)
+  sg2im/losses.py:39-57): mean(max(x,0) - x*t + log(1+exp(-|x|))).  ``weight`` (all losses here):
+  the loss weight of scripts/train.py folded into the kernel instead of a separate multiply."""
+  return HF.BceLogitsLoss.apply(input, float(target), float(weight))
 
 
-def gan_g_loss(scores_fake):
-  return bce_loss(scores_fake, 1.0)
+def _sum(*terms):
+  return HF.SumScalars.apply(*terms)
+
+
+def gan_g_loss(scores_fake, weight=1.0):
+  return bce_loss(scores_fake, 1.0, weight)
 
 
 def gan_d_loss(scores_real, scores_fake):
+  return _sum(*gan_d_loss.terms(scores_real, scores_fake))
+
+
+def _gan_d_terms(scores_real, scores_fake):
+  """the addends of the discriminator loss, for a caller that sums them with further terms itself"""
   assert scores_real.size() == scores_fake.size()
-  return bce_loss(scores_real, 1.0) + bce_loss(scores_fake, 0.0)
+  return bce_loss(scores_real, 1.0), bce_loss(scores_fake, 0.0)
+
+
+gan_d_loss.terms = _gan_d_terms
 
 
 def l1_loss(pred, target, weight=1.0):
@@ -42,25 +55,33 @@ def cross_entropy(scores, labels, weight=1.0):
   return HF.CrossEntropyLoss.apply(scores, labels, float(weight))
 
 
-def wgan_g_loss(scores_fake):
+def wgan_g_loss(scores_fake, weight=1.0):
   """reference sg2im/losses.py:106-114: -mean(scores_fake)"""
-  return HF.GanScoreLoss.apply(scores_fake, 1, -1.0, 1.0)
+  return HF.GanScoreLoss.apply(scores_fake, 1, -1.0, float(weight))
 
 
 def wgan_d_loss(scores_real, scores_fake):
   """reference sg2im/losses.py:117-124: mean(fake) - mean(real)"""
-  return HF.GanScoreLoss.apply(scores_fake, 1, 1.0, 1.0) + HF.GanScoreLoss.apply(scores_real, 1, -1.0, 1.0)
+  return _sum(*wgan_d_loss.terms(scores_real, scores_fake))
 
 
-def lsgan_g_loss(scores_fake):
+wgan_d_loss.terms = lambda scores_real, scores_fake: (HF.GanScoreLoss.apply(scores_fake, 1, 1.0, 1.0),
+                                                      HF.GanScoreLoss.apply(scores_real, 1, -1.0, 1.0))
+
+
+def lsgan_g_loss(scores_fake, weight=1.0):
   """reference sg2im/losses.py:127-131: mse(sigmoid(fake), 1)"""
-  return HF.GanScoreLoss.apply(scores_fake, 2, 1.0, 1.0)
+  return HF.GanScoreLoss.apply(scores_fake, 2, 1.0, float(weight))
 
 
 def lsgan_d_loss(scores_real, scores_fake):
   """reference sg2im/losses.py:134-145"""
   assert scores_real.size() == scores_fake.size()
-  return HF.GanScoreLoss.apply(scores_real, 2, 1.0, 1.0) + HF.GanScoreLoss.apply(scores_fake, 2, 0.0, 1.0)
+  return _sum(*lsgan_d_loss.terms(scores_real, scores_fake))
+
+
+lsgan_d_loss.terms = lambda scores_real, scores_fake: (HF.GanScoreLoss.apply(scores_real, 2, 1.0, 1.0),
+                                                       HF.GanScoreLoss.apply(scores_fake, 2, 0.0, 1.0))
 
 
 def binary_cross_entropy(prob, target, weight=1.0):

@@ -137,15 +137,15 @@ class Trainer(object):
     if w['mask_loss_weight'] > 0 and masks is not None and masks_pred is not None:   # train.py:407-410
       losses['mask_loss'] = L.binary_cross_entropy(masks_pred, masks, w['mask_loss_weight'])
     if self.d_obj is not None:
-      scores_fake, ac_loss = self.d_obj.forward_nhwc(imgs_pred, objs, boxes, obj_to_img)
-      losses['ac_loss'] = ac_loss * w['ac_loss_weight']
-      losses['g_gan_obj_loss'] = self.gan_g_loss(scores_fake) * (w['discriminator_loss_weight'] * w['d_obj_weight'])
+      # (loss weights are folded into the loss kernels; the terms are summed by ONE launch and the
+      # backward pass is seeded with ops.unit, so no term pays a multiply / scaling launch)
+      scores_fake, ac_loss = self.d_obj.forward_nhwc(imgs_pred, objs, boxes, obj_to_img, w['ac_loss_weight'])
+      losses['ac_loss'] = ac_loss
+      losses['g_gan_obj_loss'] = self.gan_g_loss(scores_fake, weight=w['discriminator_loss_weight'] * w['d_obj_weight'])
     if self.d_img is not None:
       scores_fake = self.d_img.forward_nhwc(imgs_pred)
-      losses['g_gan_img_loss'] = self.gan_g_loss(scores_fake) * (w['discriminator_loss_weight'] * w['d_img_weight'])
-    total = None
-    for v in list(losses.values()):
-      total = v if total is None else total + v
+      losses['g_gan_img_loss'] = self.gan_g_loss(scores_fake, weight=w['discriminator_loss_weight'] * w['d_img_weight'])
+    total = HF.SumScalars.apply(*losses.values())
     losses['total_loss'] = total
     st['losses'].update(losses)
     st['total'] = total
@@ -158,7 +158,7 @@ class Trainer(object):
 
   def _seg_generator_backward(self, st):
     self.opt_g.zero_grad()
-    st.pop('total').backward()
+    st.pop('total').backward(ops.unit(self.device))
 
   def _seg_d_obj(self, batch, st):
     self._seg_d_obj_forward(batch, st)
@@ -170,13 +170,14 @@ class Trainer(object):
     # train.py:566-579
     sf, ac_fake = self.d_obj.forward_nhwc(st['imgs_fake'], objs, boxes, obj_to_img)
     sr, ac_real = self.d_obj.forward_nhwc(st['imgs_nhwc'], objs, boxes, obj_to_img)
-    losses['d_obj_gan_loss'] = self.gan_d_loss(sr, sf)
+    gan_terms = self.gan_d_loss.terms(sr, sf)
+    losses['d_obj_gan_loss'] = HF.SumScalars.apply(*gan_terms).detach()      # (reported value only)
     losses['d_ac_loss_real'], losses['d_ac_loss_fake'] = ac_real, ac_fake
-    st['d_obj_total'] = losses['d_obj_gan_loss'] + ac_real + ac_fake
+    st['d_obj_total'] = HF.SumScalars.apply(*gan_terms, ac_real, ac_fake)
 
   def _seg_d_obj_backward(self, batch, st):
     self.opt_do.zero_grad()
-    st.pop('d_obj_total').backward()
+    st.pop('d_obj_total').backward(ops.unit(self.device))
 
   def _seg_d_img(self, batch, st):
     losses = st['losses']
@@ -185,7 +186,7 @@ class Trainer(object):
     sr = self.d_img.forward_nhwc(st['imgs_nhwc'])
     losses['d_img_gan_loss'] = self.gan_d_loss(sr, sf)
     self.opt_di.zero_grad()
-    losses['d_img_gan_loss'].backward()
+    losses['d_img_gan_loss'].backward(ops.unit(self.device))
 
   def _seg_adam(self, st):
     # all three updates at the end: same values as the reference's in-order updates because
