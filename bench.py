@@ -8,7 +8,11 @@ on MI355X.
 Workload (BASELINE.json configs[1], SURVEY.md section 8d "C1"): 64x64 COCO-shape synthetic
 scene graphs (3..8 objects + __image__ per image, <= 16 triples), batch 32 PER GPU (weak
 scaling), fp32, generator kwargs = the reference's train.py defaults, both discriminators,
-three Adam optimisers.  Inputs are resident in HBM before the timed region starts.
+three Adam optimisers.  Inputs are resident in HBM before the timed region starts.  The timed
+loop cycles through --n_batches (default 16) DIFFERENTLY SEEDED batches - distinct object /
+triple counts every step, as a real loader produces (reference sg2im/data/coco.py:286-359) -
+which the Trainer pads into shape buckets and replays as one hipGraph per bucket
+(sg2im_amd/bucketing.py); the padding copies are inside the timed region.
 
 Prints ONE JSON line on rank 0: the driver's contract fields plus
   roofline     - the implicit-GEMM (conv + linear) kernel family against the fp32 MFMA peak,
@@ -44,6 +48,9 @@ def parse():
   ap.add_argument('--no_roofline', action='store_true')
   ap.add_argument('--no_graphs', action='store_true', help='launch every kernel eagerly instead of hipGraph replay')
   ap.add_argument('--seed', type=int, default=0)
+  ap.add_argument('--n_batches', type=int, default=16,
+                  help='distinct synthetic batches (seeds seed+rank+1000*i) cycled through by the timed loop')
+  ap.add_argument('--bucket', default='32,64', help='object,triple padding multiples of the hipGraph shape buckets')
   ap.add_argument('--style', default='coco', choices=['coco', 'vg'],
                   help="'vg': VG-shape graphs without GT masks (BASELINE configs[2] shape, fp32) instead of the COCO headline workload")
   ap.add_argument('--eval_generator', action='store_true',
@@ -54,10 +61,37 @@ def parse():
   return ap.parse_args()
 
 
+def host_cpu():
+  """(physical cores available to this process, CPU model string)"""
+  model = 'unknown'
+  try:
+    for line in open('/proc/cpuinfo'):
+      if line.startswith('model name'):
+        model = line.split(':', 1)[1].strip()
+        break
+  except OSError:
+    pass
+  cores = None
+  try:
+    import psutil
+    cores = psutil.cpu_count(logical=False)
+  except Exception:
+    pass
+  avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+  cores = min(cores, avail) if cores else avail
+  return max(1, cores), model
+
+
 def cpu_baseline(vocab, batch, steps):
-  """Oracle ('port' of the reference loop body) on the host cores, same batch."""
+  """The CPU path timed beside the GPU number, on the same first batch.  kind 'reference': the
+  reference's own modules (imported from /root/reference when that tree exists - the build
+  container) driven by the restated loop body of scripts/train.py:524-592; kind 'port': the oracle
+  (oracle/sg2im_oracle.py), the same arithmetic restated functionally - what runs on the GPU box,
+  where the reference tree does not exist.  One thread per PHYSICAL core."""
   from oracle import sg2im_oracle as orc
   from sg2im_amd.trainer import GENERATOR_DEFAULTS, D_OBJ_DEFAULTS, D_IMG_DEFAULTS
+  cores, cpu_model = host_cpu()
+  torch.set_num_threads(cores)
   gcfg = dict(GENERATOR_DEFAULTS, vocab=vocab)
   docfg = dict(D_OBJ_DEFAULTS, vocab=vocab)
   dicfg = dict(D_IMG_DEFAULTS)
@@ -69,10 +103,11 @@ def cpu_baseline(vocab, batch, steps):
   for _ in range(steps):
     tr.step(cpu_batch)
   dt = (time.time() - t0) / steps
-  return {'value': round(cpu_batch[0].size(0) / dt, 2), 'unit': 'images/sec', 'cores': torch.get_num_threads(),
+  return {'value': round(cpu_batch[0].size(0) / dt, 2), 'unit': 'images/sec', 'cores': cores, 'cpu': cpu_model,
           'kind': 'port',
-          'sample': '%d warm G+D steps of the same batch-%d COCO-64 workload (%.2f s/step)' % (
-            steps, cpu_batch[0].size(0), dt)}
+          'sample': '%d warm G+D steps of the first batch of the stream (batch %d, O=%d, T=%d; %.2f s/step), '
+                    '%d threads = physical cores' % (steps, cpu_batch[0].size(0), cpu_batch[1].numel(),
+                                                      cpu_batch[4].size(0), dt, cores)}
 
 
 def main():
@@ -98,17 +133,23 @@ def main():
   from sg2im_amd.trainer import Trainer
 
   S = args.image_size
+  nb = max(1, args.n_batches)
   if args.style == 'vg':
     vocab = make_vocab(179, 46)
-    cpu_batch = synthetic_batch(args.batch_size, image_size=(S, S), num_objs=179, num_preds=46, min_objs=3,
-                                max_objs=10, mask_size=16, style='vg', seed=args.seed + rank)
+    cpu_batches = [synthetic_batch(args.batch_size, image_size=(S, S), num_objs=179, num_preds=46, min_objs=3,
+                                   max_objs=10, mask_size=16, style='vg', seed=args.seed + rank + 1000 * i)
+                   for i in range(nb)]
   else:
     vocab = make_vocab(184, 7)            # COCO-Stuff: 184 object ids incl. __image__, 7 predicates
-    cpu_batch = synthetic_batch(args.batch_size, image_size=(S, S), num_objs=184, num_preds=7, min_objs=3,
-                                max_objs=8, mask_size=16, style='coco', seed=args.seed + rank)
-  batch = tuple(t.to(device) if torch.is_tensor(t) else t for t in cpu_batch)
+    cpu_batches = [synthetic_batch(args.batch_size, image_size=(S, S), num_objs=184, num_preds=7, min_objs=3,
+                                   max_objs=8, mask_size=16, style='coco', seed=args.seed + rank + 1000 * i)
+                   for i in range(nb)]
+  cpu_batch = cpu_batches[0]
+  batches = [tuple(t.to(device) if torch.is_tensor(t) else t for t in b) for b in cpu_batches]
+  batch = batches[0]
+  bucket = tuple(int(v) for v in args.bucket.split(','))
   trainer = Trainer(vocab, device, generator_kwargs={'image_size': (S, S)}, world_size=world, seed=1234,
-                    use_graphs=not args.no_graphs)
+                    use_graphs=not args.no_graphs, bucket=bucket, rank=rank)
   # (data parallel: the same overlapped graph without its Adam updates, the four all-reduces issued
   # eagerly, then an Adam graph - DESIGN.md section 6; --no_graphs selects the eager segments)
   trainer_graphs = trainer.use_graphs
@@ -123,18 +164,21 @@ def main():
       dist.barrier()
       torch.cuda.synchronize()
 
-  # one-time setup outside warm-up/timing: the first steps of a new batch signature run eagerly
-  # and are then captured into hipGraphs (sg2im_amd/trainer.py::_graph_step)
-  for _ in range(3 if trainer.use_graphs else 0):
-    trainer.step(batch)
-  for _ in range(args.warmup):
-    trainer.step(batch)
+  # one-time setup outside warm-up/timing: one pass over the stream captures the hipGraph of every
+  # shape bucket that occurs (sg2im_amd/trainer.py::_graph_step)
+  for b in (batches if trainer.use_graphs else []):
+    trainer.step(b)
+  for i in range(args.warmup):
+    trainer.step(batches[i % nb])
   sync()
+  stats0 = dict(trainer.graph_stats)
   t0 = time.perf_counter()
-  for _ in range(args.steps):
-    losses = trainer.step(batch)
+  for i in range(args.steps):
+    losses = trainer.step(batches[(args.warmup + i) % nb])
   sync()
   elapsed = time.perf_counter() - t0
+  stats1 = dict(trainer.graph_stats)
+  n_graphs = len(trainer._graphs)
   if use_dist:
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -146,13 +190,27 @@ def main():
     # instrumented pass: HIP events around every implicit-GEMM launch of 3 more steps (every
     # rank runs it - the steps contain the gradient all-reduces - rank 0 reports)
     ops.TIMER = ops.KernelTimer()
-    trainer.use_graphs = False          # events need the individual (eager) launches
+    trainer.use_graphs = False          # events need the individual (eager) launches (same padded shapes)
     n_prof = 3
-    for _ in range(n_prof):
-      trainer.step(batch)
+    for i in range(n_prof):
+      trainer.step(batches[i % nb])
     summ = ops.TIMER.summary()
     crn = ops.TIMER.summary('crn')       # the launches of the refinement network alone
     alg_bytes = sum(v for k, v in ops.TIMER.alg_bytes.items() if k.startswith('igemm')) / n_prof
+    # ALGORITHMIC work: the same batches without the bucket padding (FLOPs / bytes counted, not timed)
+    padded_flops = sum(v['flops'] for k, v in summ.items() if not k.startswith('hbm_'))
+    ops.TIMER = ops.KernelTimer()
+    keep_bucketer, trainer.bucketer = trainer.bucketer, None
+    for i in range(n_prof):
+      trainer.step(batches[i % nb])
+    trainer.bucketer = keep_bucketer
+    alg = ops.TIMER.summary()
+    alg_flops = sum(v['flops'] for k, v in alg.items() if not k.startswith('hbm_'))
+    alg_crn_flops = sum(v['flops'] for k, v in ops.TIMER.summary('crn').items() if not k.startswith('hbm_'))
+    alg_bytes = sum(v for k, v in ops.TIMER.alg_bytes.items() if k.startswith('igemm')) / n_prof
+    for k, v in summ.items():            # per-kind FLOPs: the algorithmic (unpadded) count
+      if k in alg and not k.startswith('hbm_'):
+        v['flops'] = alg[k]['flops']
     ops.TIMER = None
     hbm = {k[4:]: v for k, v in summ.items() if k.startswith('hbm_')}       # the HBM-bound kernels
     summ = {k: v for k, v in summ.items() if not k.startswith('hbm_')}
@@ -167,11 +225,12 @@ def main():
       'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
       'algorithmic_mb_per_step': round(alg_bytes / 1e6, 1),     # every operand read once, every result written once
       'launches_per_step': launches // n_prof, 'gflop_per_step': round(flops / n_prof / 1e9, 1),
+      'gflop_per_step_incl_bucket_padding': round(padded_flops / n_prof / 1e9, 1),
       'ms_per_step_in_kernel': round(ms / n_prof, 3),
       'crn_only': (lambda f, m: {'gflop_per_step': round(f / n_prof / 1e9, 1), 'ms_per_step': round(m / n_prof, 3),
                                  'tflops': round(f / (m * 1e-3) / 1e12, 2) if m > 0 else 0.0,
                                  'frac': round(f / (m * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if m > 0 else 0.0})(
-                    sum(v['flops'] for v in crn.values()), sum(v['ms'] for v in crn.values())),
+                    alg_crn_flops, sum(v['ms'] for v in crn.values())),
       # second roofline: kernels bound by HBM bandwidth, algorithmic bytes / event time
       'hbm_bound': {k: {'launches_per_step': v['launches'] // n_prof, 'mbytes_per_launch': round(v['flops'] / v['launches'] / 1e6, 2),
                         'us_per_launch': round(v['ms'] / v['launches'] * 1e3, 1),
@@ -203,6 +262,8 @@ def main():
     if world == 1 and args.cpu_baseline_steps > 0:
       cpu = cpu_baseline(vocab, cpu_batch, args.cpu_baseline_steps)
     imgs = args.batch_size * world * args.steps
+    shapes = sorted(set((int(b[1].numel()), int(b[4].size(0))) for b in cpu_batches))
+    buckets = sorted(set(trainer.bucketer.bucket(o, t) for o, t in shapes)) if trainer.bucketer else []
     out = {
       'metric': 'training images/sec (G+D step)', 'value': round(imgs / elapsed, 2), 'unit': 'images/sec',
       'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -213,7 +274,13 @@ def main():
                              'batch %d per GPU, full G + D_obj + D_img step with 3x Adam' % args.batch_size +
                              (' (generator in eval mode)' if args.eval_generator else ''),
                  'global_batch': args.batch_size * world, 'image_size': S,
-                 'objects': int(batch[1].numel()), 'triples': int(batch[4].size(0)),
+                 'batch_stream': {'distinct_batches': nb, 'distinct_object_triple_shapes': len(shapes),
+                                  'objects_min_max': [shapes[0][0], shapes[-1][0]],
+                                  'triples_min_max': [min(t for _, t in shapes), max(t for _, t in shapes)],
+                                  'shape_buckets': [list(b) for b in buckets], 'graphs_alive': n_graphs,
+                                  'captures_in_timed_loop': stats1['captures'] - stats0['captures'],
+                                  'recaptures_in_timed_loop': stats1['invalidated'] - stats0['invalidated'],
+                                  'replays_in_timed_loop': stats1['replays'] - stats0['replays']},
                  'parallelism': 'dp%d' % world, 'total_loss': round(host_losses['total_loss'], 5),
                  'launch': ('eager' if not trainer_graphs else 'hipGraph replay (one graph, D steps on a side stream)' if not use_dist
                             else 'hipGraph replay (iteration graph + eager all-reduces + Adam graph)')},

@@ -6,7 +6,10 @@
  * (file:line under /root/reference) whose ATen operator sequence it replaces.  All
  * pointers are device pointers (HBM) unless stated; tensors are fp32, indices int64,
  * image-like activations are NHWC; every function is asynchronous on `stream`, keeps no
- * state and returns SG2IM_OK (0) or an error code.  No torch types appear here; the
+ * per-call state (the only process-wide state is the one-time kernel-attribute set-up that
+ * sg2im_init() performs; it is not guarded against concurrent first calls from several host
+ * threads - call sg2im_init() once before launching from more than one thread) and returns
+ * SG2IM_OK (0) or an error code.  No torch types appear here; the
  * Python host (sg2im_amd/) binds this with ctypes.
  */
 #ifndef SG2IM_HIP_H
@@ -24,6 +27,14 @@ extern "C" {
 #define SG2IM_ERR_HIP 2   /* a HIP runtime call failed; see hipGetLastError() */
 
 int sg2im_abi_version(void);
+
+/* One-time, idempotent set-up (kernel attributes of every implicit-GEMM instantiation, loading of
+ * the library's code object).  Without it the same work happens lazily on first launches; with it
+ * the entry points below only enqueue kernels / async memsets on `stream`, so they can be issued
+ * inside a hipStreamBeginCapture region from the very first call (sg2im_amd/trainer.py captures
+ * one hipGraph per batch-shape bucket).  The reference has no counterpart (eager ATen launches,
+ * scripts/train.py:524-592). */
+int sg2im_init(void);
 
 /* ------------------------------------------------------------------------------------
  * Convolution / linear layers (implicit GEMM on the fp32 matrix cores).
@@ -160,24 +171,29 @@ int sg2im_crop_backward(const float* d_crops, int n_images, int height, int widt
  * with `momentum` like nn.BatchNorm2d.  training == 0: running stats are used instead.
  * unbiased_rows (0 = rows): sample count used for the unbiased running_var factor - mask_net
  * normalises a x2-upsampled tensor (model.py:98-99) whose statistics equal the source's.
- * partial: scratch float[2 * C * 256]. */
+ * partial: scratch float[2 * C * 256].
+ * count / count_unit (count may be NULL = every row is real): a padded row batch - only the first
+ * count[0] * count_unit rows are real, the statistics run over those (sg2im_amd/bucketing.py: object /
+ * triple axes padded to a bucket size so one captured hipGraph serves every batch of the bucket; the
+ * true sizes live in device memory, which a graph replay re-reads). */
 int sg2im_bn_stats(const float* x, long long rows, int channels, long long ld, const float* gamma,
                    const float* beta, float eps, float momentum, int training, float* running_mean,
                    float* running_var, long long* num_batches_tracked, long long unbiased_rows,
                    float* mean, float* invstd, float* scale, float* shift, float* partial,
-                   hipStream_t stream);
+                   const int* count, int count_unit, hipStream_t stream);
 /* Backward through z = leaky_slope(scale*y+shift) and the batch statistics:
  *   dz is read from `g` [rows][ld_g] (channel offset already applied by the caller), or, when
  *   pool2 != 0, as the 2x2 sum of g laid out [batch][2h][2w][ld_g] (nearest-upsample backward).
  *   outputs: dy [rows][C] dense, dgamma[C], dbeta[C] (+= if accumulate).
  *   training == 0 -> statistics are constants (eval-mode BN).
- *   partial: scratch float[2 * C * 256 + 3 * C]. */
+ *   partial: scratch float[2 * C * 256 + 3 * C].
+ *   count / count_unit: as for sg2im_bn_stats; padding rows get dy = 0. */
 int sg2im_bn_act_backward(const float* g, long long ld_g, int pool2, int batch, int h, int w,
                           const float* y, long long ld_y, int channels, const float* gamma,
                           const float* mean, const float* invstd, const float* scale,
                           const float* shift, float slope, int training, float* dy,
                           float* dgamma, float* dbeta, int accumulate, float* partial,
-                          hipStream_t stream);
+                          const int* count, int count_unit, hipStream_t stream);
 /* out[r][c] = leaky_slope(scale[c] * x[r][c] + shift[c]): BatchNorm-apply + activation that must be
  * materialised - BatchNorm1d + ReLU inside build_mlp (sg2im/layers.py:216-232 with batch_norm='batch')
  * when the result feeds a gather / pooling instead of another GEMM's loader. */
@@ -245,29 +261,31 @@ int sg2im_sigmoid_backward(const float* y, const float* dy, long long n, float* 
 /* ------------------------------------------------------------------------------------
  * Losses (sg2im/losses.py:39-103, scripts/train.py:387-412) - each writes the scalar loss
  * (already multiplied by `weight`) to loss[0] and d(loss)/d(input) to grad (may be NULL).
+ * count / count_unit (count may be NULL): padded row batches (see sg2im_bn_stats) - the mean runs
+ * over the first count[0] * count_unit elements (rows for the cross entropy), the rest gets grad 0.
  * ---------------------------------------------------------------------------------- */
 int sg2im_l1_loss(const float* pred, const float* target, long long n, float weight, float* loss,
                   float* grad, float* partial, hipStream_t stream);
 int sg2im_mse_loss(const float* pred, const float* target, long long n, float weight, float* loss,
-                   float* grad, float* partial, hipStream_t stream);
+                   float* grad, float* partial, const int* count, int count_unit, hipStream_t stream);
 /* mean( max(x,0) - x*t + log(1+exp(-|x|)) ) with a constant target t (losses.py:39-57) */
 int sg2im_bce_logits_loss(const float* x, long long n, float target, float weight, float* loss,
-                          float* grad, float* partial, hipStream_t stream);
+                          float* grad, float* partial, const int* count, int count_unit, hipStream_t stream);
 /* GAN score terms against a constant target (sg2im/losses.py:72-145), mean over n scores:
  *   kind 0 'gan'   BCE-with-logits (same as sg2im_bce_logits_loss)
  *   kind 1 'wgan'  target * x          (target = -1: generator / real term, +1: fake term)
  *   kind 2 'lsgan' (sigmoid(x) - target)^2 */
 int sg2im_gan_score_loss(const float* x, long long n, int kind, float target, float weight, float* loss,
-                         float* grad, float* partial, hipStream_t stream);
+                         float* grad, float* partial, const int* count, int count_unit, hipStream_t stream);
 /* F.binary_cross_entropy(prob, target) on probabilities (mask loss, scripts/train.py:407-410):
  * logs clamped at -100, gradient (p - t) / max(p (1 - p), 1e-12) */
 int sg2im_bce_prob_loss(const float* prob, const float* target, long long n, float weight, float* loss,
-                        float* grad, float* partial, hipStream_t stream);
+                        float* grad, float* partial, const int* count, int count_unit, hipStream_t stream);
 /* mean_i( logsumexp(scores[i]) - scores[i][labels[i]] )  (F.cross_entropy, discriminators.py:74);
  * partial: scratch float[max(256, rows)] (256 floats for the element-wise losses above) */
 int sg2im_cross_entropy_loss(const float* scores, int rows, int classes, const long long* labels,
                              float weight, float* loss, float* grad, float* partial,
-                             hipStream_t stream);
+                             const int* count, int count_unit, hipStream_t stream);
 /* out[0] = terms[0][0] + terms[1][0] + ... (1 <= n <= 8, left to right): the total of the weighted loss
  * terms, scripts/train.py:387-412 `total_loss += ...`, :538-550; `terms` is a HOST array of device pointers */
 int sg2im_sum_scalars(const float* const* terms, int n, float* out, hipStream_t stream);

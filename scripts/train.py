@@ -101,6 +101,33 @@ parser.add_argument('--checkpoint_start_from', default=None)
 parser.add_argument('--restore_from_checkpoint', default=False, type=bool_flag)
 # launcher-level additions
 parser.add_argument('--seed', default=0, type=int)
+# one captured hipGraph per batch-shape bucket (object / triple axes padded to these multiples with
+# exactly neutral rows, sg2im_amd/bucketing.py); --use_graphs 0 launches every kernel from Python
+parser.add_argument('--use_graphs', default=True, type=bool_flag)
+parser.add_argument('--bucket_objects', default=32, type=int)
+parser.add_argument('--bucket_triples', default=64, type=int)
+parser.add_argument('--align_corners', default=False, type=bool_flag,
+                    help='bilinear sampling convention of layout / crops: False = F.grid_sample of torch >= 1.3, '
+                         'True = torch 0.4 (what the reference authors trained with)')
+
+
+_DATASET_FLAGS = ('vg_image_dir', 'train_h5', 'val_h5', 'vocab_json', 'coco_train_image_dir', 'coco_val_image_dir',
+                  'coco_train_instances_json', 'coco_train_stuff_json', 'coco_val_instances_json',
+                  'coco_val_stuff_json', 'num_train_samples', 'instance_whitelist', 'stuff_whitelist')
+
+
+def warn_synthetic_data(args):
+  """The COCO / VG loaders are outside this build (no torchvision / h5py / pycocotools / data here):
+  batches are seeded synthetic scene graphs.  Say so loudly - above all when the caller pointed the
+  dataset flags somewhere, which would otherwise be ignored silently."""
+  given = [f for f in _DATASET_FLAGS if getattr(args, f) != parser.get_default(f)]
+  print('=' * 100)
+  print('WARNING: training on SYNTHETIC scene graphs (--dataset %s shape) with a fabricated vocabulary;' % args.dataset)
+  print('         the reference data loaders (sg2im/data/coco.py, vg.py) are not part of this build.')
+  if given:
+    print('         IGNORED dataset flags: ' + ', '.join('--' + f for f in given))
+  print('=' * 100)
+  return given
 
 
 def check_args(args):
@@ -175,6 +202,7 @@ def main(args):
     dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
   if rank == 0:
     print(args)
+    warn_synthetic_data(args)
   num_objs, num_preds = (184, 7) if args.dataset == 'coco' else (179, 46)
   vocab = make_vocab(num_objs, num_preds)
   gk = dict(image_size=args.image_size, embedding_dim=args.embedding_dim, gconv_dim=args.gconv_dim,
@@ -189,12 +217,18 @@ def main(args):
   trainer = Trainer(vocab, device, generator_kwargs=gk,
                     d_obj_kwargs=dict(dk, arch=args.d_obj_arch, object_size=args.crop_size),
                     d_img_kwargs=dict(dk, arch=args.d_img_arch), loss_weights=lw,
-                    learning_rate=args.learning_rate, world_size=world, seed=args.seed,
-                    gan_loss_type=args.gan_loss_type)
+                    learning_rate=args.learning_rate, world_size=world, seed=args.seed, rank=rank,
+                    gan_loss_type=args.gan_loss_type, use_graphs=args.use_graphs,
+                    bucket=(args.bucket_objects, args.bucket_triples) if args.use_graphs else None)
+  if args.align_corners:
+    trainer.model.align_corners = True
+    if trainer.d_obj is not None:
+      trainer.d_obj.align_corners = True
   if args.checkpoint_start_from is not None:                        # reference train.py:162-172
     ck = torch.load(args.checkpoint_start_from, map_location='cpu', weights_only=False)
     sd = {(k[7:] if k.startswith('module.') else k): v for k, v in ck['model_state'].items()}
     trainer.model.load_state_dict(sd)
+    trainer.broadcast_state()
 
   def batches(split, start):
     """endless seeded synthetic stand-in for the train / val DataLoader"""
@@ -226,6 +260,7 @@ def main(args):
     else:
       trainer.model.train()
     epoch = checkpoint['counters']['epoch']
+    trainer.broadcast_state()
   else:
     t, epoch = 0, 0
     checkpoint = {'args': args.__dict__, 'vocab': vocab, 'model_kwargs': trainer.model_kwargs,
@@ -291,6 +326,12 @@ def main(args):
       small = {k: v for k, v in checkpoint.items()
                if not (k.endswith('_state') or k.endswith('_best_state'))}
       torch.save(small, os.path.join(args.output_dir, '%s_no_model.pt' % args.checkpoint_name))
+    if t % args.checkpoint_every == 0 and world > 1:
+      # rank 0's check_model ran the networks in training mode (like the reference's): its BatchNorm
+      # running statistics moved; bring every replica back in line
+      trainer.broadcast_state()
+  if rank == 0 and args.use_graphs:
+    print('hipGraph statistics:', trainer.graph_stats)
   if world > 1:
     dist.destroy_process_group()
 

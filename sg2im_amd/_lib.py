@@ -34,6 +34,7 @@ _D = POINTER(ConvDesc)
 # name -> argtypes (return type is int for all but the two noted)
 _SIGNATURES = {
   'sg2im_abi_version': [],
+  'sg2im_init': [],
   'sg2im_conv2d_forward': [_D, _P, _I, _P, _F, _P, _L, _I, _P, _Z, _P],
   'sg2im_conv2d_backward_data': [_D, _P, _I, _P, _I, _I, _I, _P, _L, _I, _P, _Z, _P],
   'sg2im_conv2d_backward_weight': [_D, _P, _I, _I, _P, _P, _I, _P, _Z, _P],
@@ -49,9 +50,9 @@ _SIGNATURES = {
   'sg2im_crop_forward': [_P, _L, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _P],
   'sg2im_crop_backward_workspace': [_I, _I, _I, _I],
   'sg2im_crop_backward': [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _L, _P, _P],
-  'sg2im_bn_stats': [_P, _L, _I, _L, _P, _P, _F, _F, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P],
+  'sg2im_bn_stats': [_P, _L, _I, _L, _P, _P, _F, _F, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _I, _P],
   'sg2im_bn_act_backward': [_P, _L, _I, _I, _I, _I, _P, _L, _I, _P, _P, _P, _P, _P, _F, _I, _P, _P, _P, _I,
-                            _P, _P],
+                            _P, _P, _I, _P],
   'sg2im_affine_act_forward': [_P, _L, _L, _I, _P, _P, _F, _P, _L, _P],
   'sg2im_resample_nearest_up': [_P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P],
   'sg2im_pool_sum_forward': [_P, _I, _I, _I, _I, _I, _F, _P, _P],
@@ -73,11 +74,11 @@ _SIGNATURES = {
   'sg2im_sigmoid_forward': [_P, _L, _P, _P],
   'sg2im_sigmoid_backward': [_P, _P, _L, _P, _P],
   'sg2im_l1_loss': [_P, _P, _L, _F, _P, _P, _P, _P],
-  'sg2im_mse_loss': [_P, _P, _L, _F, _P, _P, _P, _P],
-  'sg2im_bce_logits_loss': [_P, _L, _F, _F, _P, _P, _P, _P],
-  'sg2im_gan_score_loss': [_P, _L, _I, _F, _F, _P, _P, _P, _P],
-  'sg2im_bce_prob_loss': [_P, _P, _L, _F, _P, _P, _P, _P],
-  'sg2im_cross_entropy_loss': [_P, _I, _I, _P, _F, _P, _P, _P, _P],
+  'sg2im_mse_loss': [_P, _P, _L, _F, _P, _P, _P, _P, _I, _P],
+  'sg2im_bce_logits_loss': [_P, _L, _F, _F, _P, _P, _P, _P, _I, _P],
+  'sg2im_gan_score_loss': [_P, _L, _I, _F, _F, _P, _P, _P, _P, _I, _P],
+  'sg2im_bce_prob_loss': [_P, _P, _L, _F, _P, _P, _P, _P, _I, _P],
+  'sg2im_cross_entropy_loss': [_P, _I, _I, _P, _F, _P, _P, _P, _P, _I, _P],
   'sg2im_scale_by_scalar': [_P, _P, _L, _P, _P],
   'sg2im_sum_scalars': [_P, _I, _P, _P],
   'sg2im_adam_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
@@ -114,14 +115,29 @@ def load():
 
 
 _TRACE = os.environ.get('SG2IM_TRACE', '') == '1'
-EAGER_EPOCH = 0      # number of launches made through this binding (eager or captured)
+EAGER_EPOCH = 0      # number of EAGER launches made through this binding (captured ones do not count)
+CAPTURING = False    # set by the Trainer around a stream capture: launches are recorded, not executed
+_inited = False
+
+
+def init():
+  """sg2im_init(): kernel attributes + code-object load, once, before the first launch (so that a
+  first launch may already sit inside a stream capture)."""
+  global _inited
+  if not _inited:
+    if load().sg2im_init() != SG2IM_OK:
+      raise Sg2imHipError('sg2im_init failed')
+    _inited = True
 
 
 def call(name, *args):
   """Invoke an int-returning entry point and raise on a non-zero status.  SG2IM_TRACE=1
   prints every call and synchronises after it (debugging aid: pins a device fault to an op)."""
   global EAGER_EPOCH
-  EAGER_EPOCH += 1            # see sg2im_amd/trainer.py::_graph_step (graph invalidation)
+  if not _inited:
+    init()
+  if not CAPTURING:
+    EAGER_EPOCH += 1          # see sg2im_amd/trainer.py::_graph_step (graph invalidation)
   rc = getattr(load(), name)(*args)
   if _TRACE:
     import sys

@@ -1,0 +1,108 @@
+"""Shape buckets for the collated scene-graph batch.
+
+Every batch the reference's loaders emit has its own object / triple count (3-8 objects per
+COCO image, reference sg2im/data/coco.py:286-359; scripts/train.py:508-514 just feeds whatever
+``coco_collate_fn`` concatenated), while a captured hipGraph bakes tensor shapes and addresses
+in.  The Trainer therefore pads the object axis O and the triple axis T up to a bucket size
+and replays one graph per bucket; the true sizes travel in device memory (``counts``), which
+a replay re-reads.
+
+Padding is constructed so that it is *exactly* neutral:
+
+  * dummy objects: category 0, box (2, 2, 3, 3) - outside the unit square, so every bilinear
+    sample of their layout footprint and of their crop is an out-of-range zero
+    (sg2im_layout_forward / sg2im_crop_forward add exactly +0 for them and read no pixel);
+    they belong to the last image, which keeps ``obj_to_img`` sorted;
+  * dummy triples: (O_pad-1, 0, O_pad-1) - they only touch the last dummy object, so the
+    pooled vectors (and avg-pool counts) of real objects are bit-identical;
+  * every cross-row reduction takes the true row count from ``counts``: BatchNorm statistics
+    and their backward in D_obj / mask_net, the means of the box / score / classification /
+    predicate / mask losses (sg2im_bn_stats, sg2im_bn_act_backward and the loss kernels'
+    ``count`` argument).  Padding rows receive a zero loss gradient there, hence zero
+    gradients everywhere upstream (row-wise GEMMs map zero rows to zero rows, and a weight
+    gradient sums x^T dy over rows with dy = 0).
+
+Only the path with ground-truth boxes laid out (what scripts/train.py:526 does) is supported:
+predicted boxes of dummy objects would not stay outside the image.
+"""
+import torch
+
+
+def round_up(n, m):
+  return (int(n) + m - 1) // m * m
+
+
+class Bucketer(object):
+  """(O, T) -> (O_pad, T_pad).  At least one dummy object always exists (dummy triples need it)."""
+
+  def __init__(self, obj_multiple=32, triple_multiple=64):
+    self.obj_multiple, self.triple_multiple = int(obj_multiple), int(triple_multiple)
+
+  def bucket(self, num_objs, num_triples):
+    return (round_up(num_objs + 1, self.obj_multiple), round_up(max(num_triples, 1), self.triple_multiple))
+
+
+FAR_BOX = (2.0, 2.0, 3.0, 3.0)
+
+
+def pad_batch(batch, o_pad, t_pad):
+  """Functional form (host logic + tests): returns the padded 6-tuple and an int32 ``counts``
+  tensor [O, T] on the batch's device."""
+  imgs, objs, boxes, masks, triples, obj_to_img = batch[:6]
+  O, T, N = objs.numel(), triples.size(0), imgs.size(0)
+  if o_pad <= O or t_pad < T:
+    raise ValueError('bucket (%d, %d) too small for O=%d, T=%d' % (o_pad, t_pad, O, T))
+  dev = objs.device
+  po, pt = o_pad - O, t_pad - T
+  objs_p = torch.cat([objs, torch.zeros(po, dtype=objs.dtype, device=dev)])
+  boxes_p = torch.cat([boxes, torch.tensor(FAR_BOX, dtype=boxes.dtype, device=dev).expand(po, 4)])
+  masks_p = None
+  if masks is not None:
+    masks_p = torch.cat([masks, torch.zeros((po,) + tuple(masks.shape[1:]), dtype=masks.dtype, device=dev)])
+  dummy = torch.tensor([o_pad - 1, 0, o_pad - 1], dtype=triples.dtype, device=dev).expand(pt, 3)
+  triples_p = torch.cat([triples.reshape(T, 3), dummy])
+  o2i_p = torch.cat([obj_to_img, torch.full((po,), N - 1, dtype=obj_to_img.dtype, device=dev)])
+  counts = torch.tensor([O, T], dtype=torch.int32, device=dev)
+  return (imgs, objs_p, boxes_p, masks_p, triples_p, o2i_p), counts
+
+
+class StaticBatch(object):
+  """The static input buffers one captured graph reads: allocated once per bucket, refilled in
+  place from every batch of that bucket (a handful of tiny copy / fill launches)."""
+
+  def __init__(self, batch, o_pad, t_pad):
+    (imgs, objs, boxes, masks, triples, o2i), counts = pad_batch(batch, o_pad, t_pad)
+    self.o_pad, self.t_pad, self.n_images = o_pad, t_pad, imgs.size(0)
+    self.imgs, self.objs, self.boxes, self.masks = imgs.clone(), objs, boxes, masks
+    self.triples, self.obj_to_img = triples.contiguous(), o2i
+    self.counts = counts
+    self.obj_count = (self.counts[0:1], 1)
+    self.triple_count = (self.counts[1:2], 1)
+    dev = objs.device
+    self._far = torch.tensor([FAR_BOX], dtype=boxes.dtype, device=dev)
+    self._dummy = torch.tensor([[o_pad - 1, 0, o_pad - 1]], dtype=triples.dtype, device=dev)
+
+  def tensors(self):
+    return (self.imgs, self.objs, self.boxes, self.masks, self.triples, self.obj_to_img)
+
+  def load(self, batch):
+    imgs, objs, boxes, masks, triples, o2i = batch[:6]
+    O, T = objs.numel(), triples.size(0)
+    if O >= self.o_pad or T > self.t_pad or imgs.shape != self.imgs.shape or (masks is None) != (self.masks is None):
+      raise ValueError('batch does not fit this bucket')
+    self.imgs.copy_(imgs, non_blocking=True)
+    self.objs[:O].copy_(objs, non_blocking=True)
+    self.objs[O:].zero_()
+    self.boxes[:O].copy_(boxes, non_blocking=True)
+    self.boxes[O:].copy_(self._far)
+    if masks is not None:
+      self.masks[:O].copy_(masks, non_blocking=True)
+      self.masks[O:].zero_()
+    if T > 0:
+      self.triples[:T].copy_(triples, non_blocking=True)
+    if T < self.t_pad:
+      self.triples[T:].copy_(self._dummy)
+    self.obj_to_img[:O].copy_(o2i, non_blocking=True)
+    self.obj_to_img[O:].fill_(self.n_images - 1)
+    self.counts[0:1].fill_(O)
+    self.counts[1:2].fill_(T)

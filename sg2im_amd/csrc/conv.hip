@@ -1107,12 +1107,47 @@ static hipError_t finish_split(const Epi& e, long long M, int N, hipStream_t st,
   return hipGetLastError();
 }
 
+// Per-instantiation "attributes set" flags.  sg2im_init() sets every one of them up front, so that
+// no hipFuncSetAttribute call is left for a first launch that may happen inside a stream capture;
+// a caller that skipped sg2im_init() still gets them lazily.
+template <int BM, int BN, int VEC, bool GATHER> bool g_fwd_ready = false;
+template <int BM, int BN, int VA, int VB> bool g_dgrad_ready = false;
+template <int BM, int BN, int VEC, bool GATHER> bool g_wgrad_ready = false;
+
+template <int BM, int BN> constexpr size_t fwd_lds() {
+  return TilePipe<BM, BN>::LDS_IMAGES * (LdsTile<BM, false>::FLOATS + LdsTile<BN, false>::FLOATS) * sizeof(float);
+}
+template <int BM, int BN> constexpr size_t dgrad_lds() {
+  return TilePipe<BM, BN>::LDS_IMAGES * (LdsTile<BM, false>::FLOATS + LdsTile<BN, true>::FLOATS) * sizeof(float);
+}
+template <int BM, int BN> constexpr size_t wgrad_lds() {
+  return TilePipe<BM, BN>::LDS_IMAGES * (LdsTile<BM, true>::FLOATS + LdsTile<BN, true>::FLOATS) * sizeof(float);
+}
+
+template <int BM, int BN, int VEC, bool GATHER> static hipError_t prepare_fwd() {
+  if (g_fwd_ready<BM, BN, VEC, GATHER>) return hipSuccess;
+  const hipError_t e = ensure_lds(conv_fwd_kernel<BM, BN, VEC, GATHER>, std::max(fwd_lds<BM, BN>(), g_lds_floor));
+  if (e == hipSuccess) g_fwd_ready<BM, BN, VEC, GATHER> = true;
+  return e;
+}
+template <int BM, int BN, int VA, int VB> static hipError_t prepare_dgrad() {
+  if (g_dgrad_ready<BM, BN, VA, VB>) return hipSuccess;
+  const hipError_t e = ensure_lds(conv_dgrad_kernel<BM, BN, VA, VB>, dgrad_lds<BM, BN>());
+  if (e == hipSuccess) g_dgrad_ready<BM, BN, VA, VB> = true;
+  return e;
+}
+template <int BM, int BN, int VEC, bool GATHER> static hipError_t prepare_wgrad() {
+  if (g_wgrad_ready<BM, BN, VEC, GATHER>) return hipSuccess;
+  const hipError_t e = ensure_lds(conv_wgrad_kernel<BM, BN, VEC, GATHER>, wgrad_lds<BM, BN>());
+  if (e == hipSuccess) g_wgrad_ready<BM, BN, VEC, GATHER> = true;
+  return e;
+}
+
 template <int BM, int BN, int VEC, bool GATHER>
 static hipError_t launch_fwd_g(FwdParams& p, hipStream_t st) {
-  constexpr size_t lds = TilePipe<BM, BN>::LDS_IMAGES * (LdsTile<BM, false>::FLOATS + LdsTile<BN, false>::FLOATS) * sizeof(float);
-  static bool once = false;
+  constexpr size_t lds = fwd_lds<BM, BN>();
   const size_t lds_req = std::max(lds, g_lds_floor);   // (occupancy experiments: SG2IM_LDS_FLOOR)
-  if (!once) { hipError_t e = ensure_lds(conv_fwd_kernel<BM, BN, VEC, GATHER>, std::max(lds, g_lds_floor)); if (e != hipSuccess) return e; once = true; }
+  { hipError_t e = prepare_fwd<BM, BN, VEC, GATHER>(); if (e != hipSuccess) return e; }
   dim3 grid((p.Cout + BN - 1) / BN, (p.M + BM - 1) / BM, p.e.nsplit);
   hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, VEC, GATHER>), grid, dim3(NTHREADS), lds_req, st, p);
   return hipGetLastError();
@@ -1128,9 +1163,8 @@ static hipError_t launch_fwd(FwdParams& p, hipStream_t st) {
 
 template <int BM, int BN, int VA, int VB>
 static hipError_t launch_dgrad(DgradParams& p, hipStream_t st) {
-  constexpr size_t lds = TilePipe<BM, BN>::LDS_IMAGES * (LdsTile<BM, false>::FLOATS + LdsTile<BN, true>::FLOATS) * sizeof(float);
-  static bool once = false;
-  if (!once) { hipError_t e = ensure_lds(conv_dgrad_kernel<BM, BN, VA, VB>, lds); if (e != hipSuccess) return e; once = true; }
+  constexpr size_t lds = dgrad_lds<BM, BN>();
+  { hipError_t e = prepare_dgrad<BM, BN, VA, VB>(); if (e != hipSuccess) return e; }
   dim3 grid((p.Nc + BN - 1) / BN, (p.M + BM - 1) / BM, p.parity ? 4 * p.e.nsplit : p.e.nsplit);
   hipLaunchKernelGGL((conv_dgrad_kernel<BM, BN, VA, VB>), grid, dim3(NTHREADS), lds, st, p);
   return hipGetLastError();
@@ -1138,9 +1172,8 @@ static hipError_t launch_dgrad(DgradParams& p, hipStream_t st) {
 
 template <int BM, int BN, int VEC, bool GATHER>
 static hipError_t launch_wgrad_g(WgradParams& p, int ntiles_n, hipStream_t st) {
-  constexpr size_t lds = TilePipe<BM, BN>::LDS_IMAGES * (LdsTile<BM, true>::FLOATS + LdsTile<BN, true>::FLOATS) * sizeof(float);
-  static bool once = false;
-  if (!once) { hipError_t e = ensure_lds(conv_wgrad_kernel<BM, BN, VEC, GATHER>, lds); if (e != hipSuccess) return e; once = true; }
+  constexpr size_t lds = wgrad_lds<BM, BN>();
+  { hipError_t e = prepare_wgrad<BM, BN, VEC, GATHER>(); if (e != hipSuccess) return e; }
   p.ntiles_n = ntiles_n;
   p.ntiles_m = (p.Cout + BM - 1) / BM;
   dim3 grid(p.ntiles_n, p.ntiles_m, p.e.nsplit);
@@ -1154,11 +1187,44 @@ static hipError_t launch_wgrad(WgradParams& p, int ntiles_n, hipStream_t st) {
   return launch_wgrad_g<BM, BN, VEC, false>(p, ntiles_n, st);
 }
 
+__global__ void init_probe_kernel(int* flag) { if (flag) flag[0] = 1; }
+
 }  // namespace sg2im
 
 using namespace sg2im;
 
 extern "C" {
+
+// One-time set-up of everything the launchers would otherwise do lazily on a first launch:
+// the dynamic-LDS attribute of every implicit-GEMM instantiation and the loading of this
+// library's code object (one empty launch on the null stream, synchronised).  After it the
+// entry points make no HIP call other than kernel launches / async memsets on `stream`, so
+// a first launch may happen inside a stream capture.  Idempotent; call it before capturing.
+int sg2im_init(void) {
+  static bool done = false;
+  if (done) return SG2IM_OK;
+  hipError_t e = hipSuccess;
+#define SG2IM_PREP(call) do { if (e == hipSuccess) e = (call); } while (0)
+#define SG2IM_PREP_TILES(fn, ...)                                                   \
+  SG2IM_PREP((fn<128, 128, __VA_ARGS__>())); SG2IM_PREP((fn<128, 64, __VA_ARGS__>())); \
+  SG2IM_PREP((fn<64, 64, __VA_ARGS__>())); SG2IM_PREP((fn<64, 128, __VA_ARGS__>()))
+  SG2IM_PREP_TILES(prepare_fwd, 4, false);
+  SG2IM_PREP_TILES(prepare_fwd, 4, true);
+  SG2IM_PREP((prepare_fwd<64, 64, 1, false>()));
+  SG2IM_PREP_TILES(prepare_dgrad, 4, 4);
+  SG2IM_PREP((prepare_dgrad<64, 64, 4, 1>())); SG2IM_PREP((prepare_dgrad<128, 64, 4, 1>()));
+  SG2IM_PREP((prepare_dgrad<64, 64, 1, 1>()));
+  SG2IM_PREP_TILES(prepare_wgrad, 4, false);
+  SG2IM_PREP_TILES(prepare_wgrad, 4, true);
+  SG2IM_PREP((prepare_wgrad<64, 64, 1, false>()));
+#undef SG2IM_PREP_TILES
+#undef SG2IM_PREP
+  if (e != hipSuccess) return SG2IM_ERR_HIP;
+  hipLaunchKernelGGL(init_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)0, (int*)nullptr);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize((hipStream_t)0) != hipSuccess) return SG2IM_ERR_HIP;
+  done = true;
+  return SG2IM_OK;
+}
 
 int sg2im_conv2d_forward(const sg2im_conv_desc* d, const float* weight, int cout, const float* bias,
                          float out_slope, float* out, long long ld_out, int accumulate,

@@ -25,15 +25,27 @@ __device__ __forceinline__ float block_sum(float v) {
   return s;    // valid on thread 0
 }
 
+// Padded row batches (sg2im_amd/bucketing.py): only the first count[0] * unit of the n elements /
+// rows are real; the mean runs over those and the padding gets a zero gradient.  count == nullptr:
+// everything is real.
+__device__ __forceinline__ long long live_count(long long n, const int* __restrict__ count, int unit) {
+  if (!count) return n;
+  const long long t = (long long)count[0] * unit;
+  return t < n ? (t > 0 ? t : 1) : n;
+}
+
 enum { L_L1 = 0, L_MSE = 1, L_BCE = 2, L_BCE_PROB = 3, L_MEAN = 4, L_LSGAN = 5 };
 
 template <int KIND>
 __global__ void elementwise_loss_kernel(const float* __restrict__ x, const float* __restrict__ t, long long n,
-                                        float target, float gscale, float* __restrict__ grad,
-                                        float* __restrict__ partial) {
+                                        float target, float weight, float* __restrict__ grad,
+                                        float* __restrict__ partial, const int* __restrict__ count, int unit) {
   float s = 0.f;
+  const long long live = live_count(n, count, unit);
+  const float gscale = (float)((double)weight / (double)live);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
+    if (i >= live) { if (grad) grad[i] = 0.f; continue; }
     const float v = x[i];
     float l, g;
     if (KIND == L_L1) {
@@ -72,8 +84,10 @@ __global__ void elementwise_loss_kernel(const float* __restrict__ x, const float
 
 // one wavefront: lane l adds partial[l], partial[l + 64], ... (ascending), the 64 lane sums are
 // then folded by a fixed butterfly - a fixed order, reproducible run to run
-__global__ void loss_final_kernel(const float* __restrict__ partial, int n, double scale, float* __restrict__ loss) {
+__global__ void loss_final_kernel(const float* __restrict__ partial, int n, double weight, long long total,
+                                  const int* __restrict__ count, int unit, float* __restrict__ loss) {
   const int lane = threadIdx.x;
+  const double scale = weight / (double)live_count(total, count, unit);
   double s = 0.0;
   for (int i = lane; i < n; i += 64) s += partial[i];
   #pragma unroll
@@ -83,9 +97,17 @@ __global__ void loss_final_kernel(const float* __restrict__ partial, int n, doub
 
 // one wavefront per row
 __global__ void cross_entropy_kernel(const float* __restrict__ scores, int rows, int C,
-                                     const long long* __restrict__ labels, float gscale,
-                                     float* __restrict__ grad, float* __restrict__ partial) {
+                                     const long long* __restrict__ labels, float weight,
+                                     float* __restrict__ grad, float* __restrict__ partial,
+                                     const int* __restrict__ count, int unit) {
   const int r = blockIdx.x, lane = threadIdx.x;
+  const long long live = live_count(rows, count, unit);
+  const float gscale = (float)((double)weight / (double)live);
+  if (r >= live) {                                   // padding row: no loss, no gradient
+    if (lane == 0) partial[r] = 0.f;
+    if (grad) for (int c = lane; c < C; c += 64) grad[(long long)r * C + c] = 0.f;
+    return;
+  }
   const float* s = scores + (long long)r * C;
   float mx = -INFINITY;
   for (int c = lane; c < C; c += 64) mx = fmaxf(mx, s[c]);
@@ -179,13 +201,14 @@ static inline int ok_or(hipError_t e) { return e == hipSuccess ? SG2IM_OK : SG2I
 
 template <int KIND>
 static int run_elementwise(const float* x, const float* t, long long n, float target, float weight,
-                           float* loss, float* grad, float* partial, hipStream_t stream) {
+                           float* loss, float* grad, float* partial, hipStream_t stream,
+                           const int* count = nullptr, int unit = 1) {
   constexpr bool needs_t = KIND == L_L1 || KIND == L_MSE || KIND == L_BCE_PROB;
   if (!x || !loss || !partial || n < 1 || (needs_t && !t)) return SG2IM_ERR_ARG;
   const int blocks = (int)std::min<long long>(LOSS_BLOCKS, (n + 255) / 256);
   hipLaunchKernelGGL((elementwise_loss_kernel<KIND>), dim3(blocks), dim3(256), 0, stream, x, t, n, target,
-                     (float)((double)weight / (double)n), grad, partial);
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, stream, partial, blocks, (double)weight / (double)n, loss);
+                     weight, grad, partial, count, unit);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, stream, partial, blocks, (double)weight, n, count, unit, loss);
   return ok_or(hipGetLastError());
 }
 
@@ -201,35 +224,36 @@ int sg2im_l1_loss(const float* pred, const float* target, long long n, float wei
 }
 
 int sg2im_mse_loss(const float* pred, const float* target, long long n, float weight, float* loss,
-                   float* grad, float* partial, hipStream_t stream) {
-  return run_elementwise<L_MSE>(pred, target, n, 0.f, weight, loss, grad, partial, stream);
+                   float* grad, float* partial, const int* count, int count_unit, hipStream_t stream) {
+  return run_elementwise<L_MSE>(pred, target, n, 0.f, weight, loss, grad, partial, stream, count, count_unit);
 }
 
 int sg2im_bce_logits_loss(const float* x, long long n, float target, float weight, float* loss,
-                          float* grad, float* partial, hipStream_t stream) {
-  return run_elementwise<L_BCE>(x, nullptr, n, target, weight, loss, grad, partial, stream);
+                          float* grad, float* partial, const int* count, int count_unit, hipStream_t stream) {
+  return run_elementwise<L_BCE>(x, nullptr, n, target, weight, loss, grad, partial, stream, count, count_unit);
 }
 
 int sg2im_gan_score_loss(const float* x, long long n, int kind, float target, float weight, float* loss,
-                         float* grad, float* partial, hipStream_t stream) {
-  if (kind == 0) return run_elementwise<L_BCE>(x, nullptr, n, target, weight, loss, grad, partial, stream);
-  if (kind == 1) return run_elementwise<L_MEAN>(x, nullptr, n, target, weight, loss, grad, partial, stream);
-  if (kind == 2) return run_elementwise<L_LSGAN>(x, nullptr, n, target, weight, loss, grad, partial, stream);
+                         float* grad, float* partial, const int* count, int count_unit, hipStream_t stream) {
+  if (kind == 0) return run_elementwise<L_BCE>(x, nullptr, n, target, weight, loss, grad, partial, stream, count, count_unit);
+  if (kind == 1) return run_elementwise<L_MEAN>(x, nullptr, n, target, weight, loss, grad, partial, stream, count, count_unit);
+  if (kind == 2) return run_elementwise<L_LSGAN>(x, nullptr, n, target, weight, loss, grad, partial, stream, count, count_unit);
   return SG2IM_ERR_ARG;
 }
 
 int sg2im_bce_prob_loss(const float* prob, const float* target, long long n, float weight, float* loss,
-                        float* grad, float* partial, hipStream_t stream) {
-  return run_elementwise<L_BCE_PROB>(prob, target, n, 0.f, weight, loss, grad, partial, stream);
+                        float* grad, float* partial, const int* count, int count_unit, hipStream_t stream) {
+  return run_elementwise<L_BCE_PROB>(prob, target, n, 0.f, weight, loss, grad, partial, stream, count, count_unit);
 }
 
 int sg2im_cross_entropy_loss(const float* scores, int rows, int classes, const long long* labels,
                              float weight, float* loss, float* grad, float* partial,
-                             hipStream_t stream) {
+                             const int* count, int count_unit, hipStream_t stream) {
   if (!scores || !labels || !loss || !partial || rows < 1 || classes < 1) return SG2IM_ERR_ARG;
   hipLaunchKernelGGL(cross_entropy_kernel, dim3(rows), dim3(64), 0, stream, scores, rows, classes, labels,
-                     (float)((double)weight / (double)rows), grad, partial);
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, stream, partial, rows, (double)weight / (double)rows, loss);
+                     weight, grad, partial, count, count_unit);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, stream, partial, rows, (double)weight, (long long)rows,
+                     count, count_unit, loss);
   return ok_or(hipGetLastError());
 }
 

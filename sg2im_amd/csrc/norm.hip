@@ -13,6 +13,15 @@ constexpr int RED_BLOCKS = 256;   // row blocks of the two-stage per-channel red
 
 __device__ __forceinline__ float leakyf(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// Padded row batches (sg2im_amd/bucketing.py): a launch is sized for `rows` rows but only the
+// first count[0] * unit of them are real - the rest is padding that must not enter a statistic.
+// count == nullptr: every row is real.
+__device__ __forceinline__ long long live_rows(long long rows, const int* __restrict__ count, int unit) {
+  if (!count) return rows;
+  const long long t = (long long)count[0] * unit;
+  return t < rows ? t : rows;
+}
+
 // thread -> (channel lane tx, row group ty); channels covered: tx, tx + TC, ...
 struct ChanMap { int TC, TR, tx, ty; };
 __device__ __forceinline__ ChanMap chan_map(int C) {
@@ -71,30 +80,39 @@ __device__ __forceinline__ void wave_partial_sums(const float* __restrict__ part
 }
 
 __global__ void bn_stats_partial_kernel(const float* __restrict__ x, long long rows, int C, long long ld,
-                                        float* __restrict__ partial) {
+                                        float* __restrict__ partial, const int* __restrict__ count, int unit) {
+  rows = live_rows(rows, count, unit);
+  // shifted sums: d = x - x[row 0] keeps var = E[d^2] - E[d]^2 free of the catastrophic
+  // cancellation a large |mean| / std ratio causes in E[x^2] - mean^2
   channel_reduce2(C, rows, partial, [&](long long r, int c, float& s0, float& s1) {
-    const float v = x[r * ld + c];
+    const float v = x[r * ld + c] - x[c];
     s0 += v; s1 = fmaf(v, v, s1);
   });
 }
 
-__global__ void bn_stats_final_kernel(const float* __restrict__ partial, int nblk, long long rows,
+__global__ void bn_stats_final_kernel(const float* __restrict__ x, const float* __restrict__ partial, int nblk, long long rows,
                                       long long unbiased_rows, int C,
                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                       float eps, float momentum, int training,
                                       float* __restrict__ running_mean, float* __restrict__ running_var,
                                       long long* __restrict__ nbt, float* __restrict__ mean,
                                       float* __restrict__ invstd, float* __restrict__ scale,
-                                      float* __restrict__ shift) {
+                                      float* __restrict__ shift, const int* __restrict__ count, int unit) {
   const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);     // one wavefront per channel
   if (c == 0 && (threadIdx.x & 63) == 0 && training && nbt) *nbt += 1;
+  if (count) {
+    const long long live = live_rows(rows, count, unit);
+    if (unbiased_rows > 0) unbiased_rows = unbiased_rows / rows * live;   // (a whole multiple of rows)
+    rows = live > 0 ? live : 1;
+  }
   if (c >= C) return;
   double mu, var;
   if (training) {
     double s, ss;
     wave_partial_sums(partial, nblk, C, c, s, ss);
-    mu = s / (double)rows;
-    var = ss / (double)rows - mu * mu;
+    const double dm = s / (double)rows;                 // mean of the pivot-shifted values
+    mu = (double)x[c] + dm;
+    var = ss / (double)rows - dm * dm;
     if (var < 0.0) var = 0.0;
     if (running_mean && (threadIdx.x & 63) == 0) {
       const double nu = (double)(unbiased_rows > 0 ? unbiased_rows : rows);
@@ -128,7 +146,9 @@ __device__ __forceinline__ float read_dz(const GradSrc& s, long long r, int c) {
 __global__ void bn_bwd_partial_kernel(GradSrc gs, const float* __restrict__ y, long long ld_y, long long rows,
                                       int C, const float* __restrict__ mean, const float* __restrict__ invstd,
                                       const float* __restrict__ scale, const float* __restrict__ shift,
-                                      float slope, float* __restrict__ partial) {
+                                      float slope, float* __restrict__ partial, const int* __restrict__ count,
+                                      int unit) {
+  rows = live_rows(rows, count, unit);
   channel_reduce2(C, rows, partial, [&](long long r, int c, float& s0, float& s1) {
     const float yv = y[r * ld_y + c];
     const float u = fmaf(yv, scale[c], shift[c]);
@@ -141,9 +161,11 @@ __global__ void bn_bwd_partial_kernel(GradSrc gs, const float* __restrict__ y, l
 __global__ void bn_bwd_final_kernel(const float* __restrict__ partial, int nblk, long long rows, int C,
                                     const float* __restrict__ gamma, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, int training, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta, int accumulate, float* __restrict__ coef) {
+                                    float* __restrict__ dbeta, int accumulate, float* __restrict__ coef,
+                                    const int* __restrict__ count, int unit) {
   const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);     // one wavefront per channel
   if (c >= C) return;
+  if (count) { rows = live_rows(rows, count, unit); if (rows < 1) rows = 1; }
   double s, sx;
   wave_partial_sums(partial, nblk, C, c, s, sx);
   if ((threadIdx.x & 63) != 0) return;
@@ -162,11 +184,14 @@ __global__ void bn_bwd_final_kernel(const float* __restrict__ partial, int nblk,
 
 __global__ void bn_bwd_apply_kernel(GradSrc gs, const float* __restrict__ y, long long ld_y, long long rows,
                                     int C, const float* __restrict__ scale, const float* __restrict__ shift,
-                                    float slope, const float* __restrict__ coef, float* __restrict__ dy) {
+                                    float slope, const float* __restrict__ coef, float* __restrict__ dy,
+                                    const int* __restrict__ count, int unit) {
   const long long total = rows * C;
+  const long long live = live_rows(rows, count, unit);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const long long r = i / C; const int c = (int)(i - r * C);
+    if (r >= live) { dy[i] = 0.f; continue; }        // padding row: no gradient
     const float yv = y[r * ld_y + c];
     const float u = fmaf(yv, scale[c], shift[c]);
     const float du = read_dz(gs, r, c) * (u > 0.f ? 1.f : slope);
@@ -534,9 +559,11 @@ __device__ __forceinline__ void channel_reduce2_v4(int C, long long rows, float*
 }
 
 __global__ void bn_stats_partial_v4_kernel(const float* __restrict__ x, long long rows, int C, long long ld,
-                                           float* __restrict__ partial) {
+                                           float* __restrict__ partial, const int* __restrict__ count, int unit) {
+  rows = live_rows(rows, count, unit);
   channel_reduce2_v4(C, rows, partial, [&](long long r, int c, float4& s0, float4& s1) {
-    const float4 v = ld4(x + r * ld + c);
+    const float4 t = ld4(x + r * ld + c), p = ld4(x + c);          // (pivot = row 0, see the scalar form)
+    const float4 v = make_float4(t.x - p.x, t.y - p.y, t.z - p.z, t.w - p.w);
     s0 = f4add(s0, v);
     s1.x = fmaf(v.x, v.x, s1.x); s1.y = fmaf(v.y, v.y, s1.y); s1.z = fmaf(v.z, v.z, s1.z); s1.w = fmaf(v.w, v.w, s1.w);
   });
@@ -554,7 +581,9 @@ __device__ __forceinline__ float du1(float dz, float yv, float sc, float sh, flo
 __global__ void bn_bwd_partial_v4_kernel(GradSrc gs, const float* __restrict__ y, long long ld_y, long long rows,
                                          int C, const float* __restrict__ mean, const float* __restrict__ invstd,
                                          const float* __restrict__ scale, const float* __restrict__ shift,
-                                         float slope, float* __restrict__ partial) {
+                                         float slope, float* __restrict__ partial, const int* __restrict__ count,
+                                         int unit) {
+  rows = live_rows(rows, count, unit);
   channel_reduce2_v4(C, rows, partial, [&](long long r, int c, float4& s0, float4& s1) {
     const float4 yv = ld4(y + r * ld_y + c), dz = read_dz4(gs, r, c);
     const float4 sc = ld4(scale + c), sh = ld4(shift + c), mu = ld4(mean + c), is = ld4(invstd + c);
@@ -568,12 +597,15 @@ __global__ void bn_bwd_partial_v4_kernel(GradSrc gs, const float* __restrict__ y
 
 __global__ void bn_bwd_apply_v4_kernel(GradSrc gs, const float* __restrict__ y, long long ld_y, long long rows,
                                        int C, const float* __restrict__ scale, const float* __restrict__ shift,
-                                       float slope, const float* __restrict__ coef, float* __restrict__ dy) {
+                                       float slope, const float* __restrict__ coef, float* __restrict__ dy,
+                                       const int* __restrict__ count, int unit) {
   const int CQ = C >> 2;
   const long long total = rows * CQ;
+  const long long live = live_rows(rows, count, unit);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const long long r = i / CQ; const int c = 4 * (int)(i - r * CQ);
+    if (r >= live) { *reinterpret_cast<float4*>(dy + r * C + c) = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
     const float4 yv = ld4(y + r * ld_y + c), dz = read_dz4(gs, r, c);
     const float4 sc = ld4(scale + c), sh = ld4(shift + c);
     const float4 a = ld4(coef + c), k1 = ld4(coef + C + c), k0 = ld4(coef + 2 * C + c);
@@ -663,7 +695,7 @@ int sg2im_bn_stats(const float* x, long long rows, int channels, long long ld, c
                    const float* beta, float eps, float momentum, int training, float* running_mean,
                    float* running_var, long long* num_batches_tracked, long long unbiased_rows,
                    float* mean, float* invstd, float* scale, float* shift, float* partial,
-                   hipStream_t stream) {
+                   const int* count, int count_unit, hipStream_t stream) {
   if (channels < 1 || rows < 1 || !mean || !invstd || !scale || !shift) return SG2IM_ERR_ARG;
   if (training && (!x || !partial)) return SG2IM_ERR_ARG;
   if (!training && (!running_mean || !running_var)) return SG2IM_ERR_ARG;
@@ -672,14 +704,14 @@ int sg2im_bn_stats(const float* x, long long rows, int channels, long long ld, c
     nblk = red_blocks(rows);
     if (channels % 4 == 0 && ld % 4 == 0 && al16(x) && al16(partial))
       hipLaunchKernelGGL(bn_stats_partial_v4_kernel, dim3(nblk), dim3(256), 8 * 256 * sizeof(float), stream, x, rows,
-                         channels, ld, partial);
+                         channels, ld, partial, count, count_unit);
     else
       hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nblk), dim3(256), 2 * 256 * sizeof(float), stream, x, rows,
-                         channels, ld, partial);
+                         channels, ld, partial, count, count_unit);
   }
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((channels + 3) / 4), dim3(256), 0, stream, partial, nblk, rows,
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((channels + 3) / 4), dim3(256), 0, stream, x, partial, nblk, rows,
                      unbiased_rows, channels, gamma, beta, eps, momentum, training, running_mean, running_var,
-                     num_batches_tracked, mean, invstd, scale, shift);
+                     num_batches_tracked, mean, invstd, scale, shift, count, count_unit);
   return ok_or(hipGetLastError());
 }
 
@@ -688,7 +720,7 @@ int sg2im_bn_act_backward(const float* g, long long ld_g, int pool2, int batch, 
                           const float* mean, const float* invstd, const float* scale,
                           const float* shift, float slope, int training, float* dy,
                           float* dgamma, float* dbeta, int accumulate, float* partial,
-                          hipStream_t stream) {
+                          const int* count, int count_unit, hipStream_t stream) {
   if (!g || !y || !dy || !partial || channels < 1 || !mean || !invstd || !scale || !shift) return SG2IM_ERR_ARG;
   const long long rows = (long long)batch * h * w;
   if (rows < 1) return SG2IM_ERR_ARG;
@@ -699,18 +731,18 @@ int sg2im_bn_act_backward(const float* g, long long ld_g, int pool2, int batch, 
                   al16(partial) && al16(mean) && al16(invstd) && al16(scale) && al16(shift);
   if (v4)
     hipLaunchKernelGGL(bn_bwd_partial_v4_kernel, dim3(nblk), dim3(256), 8 * 256 * sizeof(float), stream, gs, y, ld_y,
-                       rows, channels, mean, invstd, scale, shift, slope, partial);
+                       rows, channels, mean, invstd, scale, shift, slope, partial, count, count_unit);
   else
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk), dim3(256), 2 * 256 * sizeof(float), stream, gs, y, ld_y, rows,
-                       channels, mean, invstd, scale, shift, slope, partial);
+                       channels, mean, invstd, scale, shift, slope, partial, count, count_unit);
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((channels + 3) / 4), dim3(256), 0, stream, partial, nblk, rows,
-                     channels, gamma, mean, invstd, training, dgamma, dbeta, accumulate, coef);
+                     channels, gamma, mean, invstd, training, dgamma, dbeta, accumulate, coef, count, count_unit);
   if (v4 && al16(coef))
     hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(ew_blocks(rows * channels / 4)), dim3(256), 0, stream, gs, y, ld_y,
-                       rows, channels, scale, shift, slope, coef, dy);
+                       rows, channels, scale, shift, slope, coef, dy, count, count_unit);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(rows * channels)), dim3(256), 0, stream, gs, y, ld_y, rows,
-                       channels, scale, shift, slope, coef, dy);
+                       channels, scale, shift, slope, coef, dy, count, count_unit);
   return ok_or(hipGetLastError());
 }
 

@@ -38,8 +38,8 @@ class AcDiscriminator(nn.Module):
     self.real_classifier = nn.Linear(1024, 1)
     self.obj_classifier = nn.Linear(1024, num_objects)
 
-  def scores_nhwc(self, x_nhwc):
-    feats = self.cnn[0](x_nhwc)
+  def scores_nhwc(self, x_nhwc, count=None):
+    feats = self.cnn[0](x_nhwc, count) if count is not None else self.cnn[0](x_nhwc)
     vecs = self.cnn[1](feats)
     fc = self.cnn[2]
     vecs = HF.LinearAct.apply(vecs, fc.weight, fc.bias, 1.0)
@@ -47,9 +47,9 @@ class AcDiscriminator(nn.Module):
     cls = HF.LinearAct.apply(vecs, self.obj_classifier.weight, self.obj_classifier.bias, 1.0)
     return real, cls
 
-  def forward_nhwc(self, x_nhwc, y, ac_weight=1.0):
-    real, cls = self.scores_nhwc(x_nhwc)
-    return real, HF.CrossEntropyLoss.apply(cls, y, float(ac_weight))      # reference sg2im/discriminators.py:74
+  def forward_nhwc(self, x_nhwc, y, ac_weight=1.0, count=None):
+    real, cls = self.scores_nhwc(x_nhwc, count)
+    return real, HF.CrossEntropyLoss.apply(cls, y, float(ac_weight), count)   # reference sg2im/discriminators.py:74
 
   def forward(self, x, y):
     if x.dim() == 3:
@@ -66,11 +66,12 @@ class AcCropDiscriminator(nn.Module):
     self.object_size = object_size
     self.align_corners = ALIGN_CORNERS
 
-  def forward_nhwc(self, imgs_nhwc, objs, boxes, obj_to_img, ac_weight=1.0):
-    """ac_weight: loss weight folded into the classification loss (the Trainer's ac_loss_weight)"""
+  def forward_nhwc(self, imgs_nhwc, objs, boxes, obj_to_img, ac_weight=1.0, obj_count=None):
+    """ac_weight: loss weight folded into the classification loss (the Trainer's ac_loss_weight);
+    obj_count: (int32 device scalar, 1) when the object axis is padded (sg2im_amd/bucketing.py)"""
     crops = crop_bbox_batch_nhwc(imgs_nhwc, boxes, obj_to_img, self.object_size,
                                  align_corners=self.align_corners)
-    return self.discriminator.forward_nhwc(crops, objs, ac_weight)
+    return self.discriminator.forward_nhwc(crops, objs, ac_weight, obj_count)
 
   def forward(self, imgs, objs, boxes, obj_to_img):
     """imgs (N,3,H,W) -> (real_scores (O,1), ac_loss scalar)  (reference :87-90)"""

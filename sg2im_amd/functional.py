@@ -32,16 +32,33 @@ def _cl_weight(w):
 
 # ---------------------------------------------------------------------------------------
 # gradient sinks: sg2im_amd.optim.FlatParams registers, for every parameter, a view into its
-# flat gradient arena (keyed by the parameter's data pointer).  Backward kernels then
-# accumulate straight into the arena (beta = 1) and report ``None`` to autograd, which
-# removes ~150 per-parameter "grad += g" launches per step.  Without a registered sink the
-# gradient is returned through autograd as usual.
+# flat gradient arena.  Backward kernels then accumulate straight into the arena (beta = 1)
+# and report ``None`` to autograd, which removes ~150 per-parameter "grad += g" launches per
+# step.  Without a registered sink the gradient is returned through autograd as usual.
+#
+# The registry maps a parameter's data pointer to a WEAK reference of the owning FlatParams,
+# which holds the views: an entry is only honoured while its owner (hence the arena the
+# address lies in) is alive, so a freed arena can neither be kept alive by the registry nor be
+# mistaken for the home of a later tensor that the allocator placed at the same address.
 # ---------------------------------------------------------------------------------------
 GRAD_SINKS = {}
 
 
 def _sink(param):
-  return GRAD_SINKS.get(param.data_ptr()) if param is not None else None
+  if param is None:
+    return None
+  ptr = param.data_ptr()
+  ref = GRAD_SINKS.get(ptr)
+  if ref is None:
+    return None
+  owner = ref()
+  if owner is None:                       # the arena is gone: a stale address
+    GRAD_SINKS.pop(ptr, None)
+    return None
+  view = owner.sinks.get(ptr)
+  if view is None or view.numel() != param.numel():
+    return None
+  return view
 
 
 def _cl_grad(dw_phys):
@@ -829,9 +846,11 @@ class MaskNetFn(Function):
   sigmoid.  params: per block [gamma, beta, W, b] ..., then [Wf, bf]."""
 
   @staticmethod
-  def forward(ctx, obj_vecs, bns, training, *params):
+  def forward(ctx, obj_vecs, bns, training, count, *params):
+    """count: None or (int32 device scalar, 1) - the number of real objects of a padded batch"""
     nb = len(bns)
     O, D = obj_vecs.shape
+    cnt = lambda unit: None if count is None else (count[0], count[1] * unit)
     x = obj_vecs.contiguous().view(O, 1, 1, D)
     saved = []
     s = 1
@@ -839,7 +858,8 @@ class MaskNetFn(Function):
       gam, bet, Wp, bias = params[4 * b:4 * b + 4]
       # statistics of the upsampled tensor == statistics of x (each value repeated 4x);
       # only the unbiased running_var factor sees the repeated count
-      st = ops.bn_stats(x, O * s * s, D, D, bns[b], training, BN_EPS, BN_MOMENTUM, unbiased_rows=4 * O * s * s)
+      st = ops.bn_stats(x, O * s * s, D, D, bns[b], training, BN_EPS, BN_MOMENTUM, unbiased_rows=4 * O * s * s,
+                        count=cnt(s * s))
       d = conv_desc([nhwc_src(x, 1, st.scale, st.shift, 1.0)], O, 2 * s, 2 * s, 3, 3, 1, 1)
       y = ops.conv2d_forward(d, _cl_weight(Wp), D, bias, _new(x, O, 2 * s, 2 * s, D), D, 0.0)
       saved.append((x, st, y, s))
@@ -849,7 +869,7 @@ class MaskNetFn(Function):
     df = conv_desc([nhwc_src(x)], O, s, s, 1, 1, 1, 0)
     scores = ops.conv2d_forward(df, _cl_weight(Wf), 1, bf, _new(x, O, s, s, 1), 1)
     masks = ops.sigmoid_forward(scores, _new(x, O, s, s))
-    ctx.saved, ctx.misc = saved, (nb, training, x, df, s)
+    ctx.saved, ctx.misc = saved, (nb, training, x, df, s, count)
     ctx.save_for_backward(masks, *params)
     return masks
 
@@ -857,10 +877,10 @@ class MaskNetFn(Function):
   def backward(ctx, g):
     masks = ctx.saved_tensors[0]
     params = ctx.saved_tensors[1:]
-    nb, training, xl, df, s = ctx.misc
+    nb, training, xl, df, s, count = ctx.misc
     saved = ctx.saved
     O, D = masks.size(0), xl.size(3)
-    ni = ctx.needs_input_grad[3:]
+    ni = ctx.needs_input_grad[4:]
     grads = [None] * len(params)
     Wf, bf = params[4 * nb:4 * nb + 2]
     ds = ops.sigmoid_backward(masks, g.contiguous(), _new(g, O, s, s, 1))
@@ -879,10 +899,10 @@ class MaskNetFn(Function):
       ops.conv2d_backward_data(d, _cl_weight(Wp), D, dpre, D, 0, D, gup, D)
       dgam, dbet, accb, grads[4 * b], grads[4 * b + 1] = _bn_grad_bufs(g, D, gam, bet, ni[4 * b], ni[4 * b + 1])
       gz = ops.bn_act_backward(_fptr(gup), D, 1, O, sb, sb, x, D, D, gam, st, 1.0, training, _new(g, O, sb, sb, D),
-                               dgam, dbet, accb)
+                               dgam, dbet, accb, count=None if count is None else (count[0], count[1] * sb * sb))
     ctx.saved = None
     d_obj = gz.view(O, D) if ctx.needs_input_grad[0] else None
-    return (d_obj, None, None) + tuple(grads)
+    return (d_obj, None, None, None) + tuple(grads)
 
 
 class DiscCnnFn(Function):
@@ -893,7 +913,9 @@ class DiscCnnFn(Function):
   the LeakyReLU in front of conv i+1 is then fused into conv i's epilogue."""
 
   @staticmethod
-  def forward(ctx, x, bns, specs, slope, training, *params):
+  def forward(ctx, x, bns, specs, slope, training, count, *params):
+    """count: None or (int32 device scalar, 1) - the number of real batch entries (objects) of a
+    padded batch: BatchNorm statistics and their backward only see those"""
     x = x.contiguous()
     N, H, W, Cin = x.shape
     saved = []
@@ -917,24 +939,27 @@ class DiscCnnFn(Function):
         ypre, ist = y, ops.instnorm_stats(y, BN_EPS)
         y = ops.instnorm_act_forward(ypre, ist, slope, _new(x, N, d.out_h, d.out_w, cout))
       if not last and not nonorm:
-        st = ops.bn_stats(y, N * d.out_h * d.out_w, cout, cout, bns[i], training, BN_EPS, BN_MOMENTUM)
+        st = ops.bn_stats(y, N * d.out_h * d.out_w, cout, cout, bns[i], training, BN_EPS, BN_MOMENTUM,
+                          count=None if count is None else (count[0], count[1] * d.out_h * d.out_w))
       saved.append((src, d, y, st, h, w, ypre, ist))
       h, w = d.out_h, d.out_w
       if st is not None:
         src = nhwc_src(y, 0, st.scale, st.shift, slope)
       elif nonorm:
         src = nhwc_src(y)
-    ctx.saved, ctx.misc = saved, (specs, slope, training, tuple(x.shape), nonorm, inorm)
+    if count is not None and inorm:
+      raise NotImplementedError('padded batches with instance normalisation')
+    ctx.saved, ctx.misc = saved, (specs, slope, training, tuple(x.shape), nonorm, inorm, count)
     ctx.save_for_backward(*params)
     return saved[-1][2]
 
   @staticmethod
   def backward(ctx, g):
     params = ctx.saved_tensors
-    specs, slope, training, xshape, nonorm, inorm = ctx.misc
+    specs, slope, training, xshape, nonorm, inorm, count = ctx.misc
     saved = ctx.saved
     N = xshape[0]
-    ni = ctx.needs_input_grad[5:]
+    ni = ctx.needs_input_grad[6:]
     grads = [None] * len(params)
     dy = g.contiguous()
     for i in range(len(specs) - 1, -1, -1):
@@ -961,7 +986,7 @@ class DiscCnnFn(Function):
           dx = _new(g, *xshape)
           ops.conv2d_backward_data(d, _cl_weight(Wp), cout, dy, cout, 0, cin, dx, cin)
         ctx.saved = None
-        return (dx, None, None, None, None) + tuple(grads)
+        return (dx, None, None, None, None, None) + tuple(grads)
       gz = _new(g, N, h, w, cin)
       ops.conv2d_backward_data(d, _cl_weight(Wp), cout, dy, cout, 0, cin, gz, cin)
       yp, stp = saved[i - 1][2], saved[i - 1][3]
@@ -974,7 +999,7 @@ class DiscCnnFn(Function):
       dgam, dbet, accb, grads[gi], grads[gi + 1] = _bn_grad_bufs(g, cin, params[gi], params[gi + 1], ni[gi],
                                                                  ni[gi + 1])
       dy = ops.bn_act_backward(_fptr(gz), cin, 0, N, h, w, yp, cin, cin, params[gi], stp, slope, training, gz, dgam,
-                               dbet, accb)
+                               dbet, accb, count=None if count is None else (count[0], count[1] * h * w))
 
 
 # ---- layer-by-layer pieces for build_cnn architecture strings with R / U / P / FC tokens
@@ -1174,46 +1199,50 @@ class L1Loss(_LossFn):
 
 class MseLoss(_LossFn):
   @staticmethod
-  def forward(ctx, pred, target, weight, _unused=None):
+  def forward(ctx, pred, target, weight, count=None):
     pred, target = pred.contiguous(), target.contiguous()
     grad = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
-    loss = ops.mse_loss(pred, target, weight, grad)
+    loss = ops.mse_loss(pred, target, weight, grad, count)
     return _LossFn._finish(ctx, loss, grad)
 
 
 class BceLogitsLoss(_LossFn):
   @staticmethod
-  def forward(ctx, x, target, weight, _unused=None):
+  def forward(ctx, x, target, weight, count=None):
     x = x.contiguous()
     grad = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-    loss = ops.bce_logits_loss(x, target, weight, grad)
+    loss = ops.bce_logits_loss(x, target, weight, grad, count)
     return _LossFn._finish(ctx, loss, grad)
 
 
 class GanScoreLoss(_LossFn):
   """kind 1: WGAN mean term `target * mean(x)`, kind 2: LSGAN mse(sigmoid(x), target)"""
   @staticmethod
-  def forward(ctx, x, kind, target, weight):
+  def forward(ctx, x, kind, target, weight, count=None):
     x = x.contiguous()
     grad = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-    loss = ops.gan_score_loss(x, kind, target, weight, grad)
+    loss = ops.gan_score_loss(x, kind, target, weight, grad, count)
     return _LossFn._finish(ctx, loss, grad)
+
+  @staticmethod
+  def backward(ctx, g):
+    return _LossFn.backward(ctx, g) + (None,)
 
 
 class BceProbLoss(_LossFn):
   """F.binary_cross_entropy on probabilities (mask loss, scripts/train.py:407-410)"""
   @staticmethod
-  def forward(ctx, prob, target, weight, _unused=None):
+  def forward(ctx, prob, target, weight, count=None):
     prob, target = prob.contiguous(), target.contiguous().float()
     grad = torch.empty_like(prob) if ctx.needs_input_grad[0] else None
-    loss = ops.bce_prob_loss(prob, target, weight, grad)
+    loss = ops.bce_prob_loss(prob, target, weight, grad, count)
     return _LossFn._finish(ctx, loss, grad)
 
 
 class CrossEntropyLoss(_LossFn):
   @staticmethod
-  def forward(ctx, scores, labels, weight, _unused=None):
+  def forward(ctx, scores, labels, weight, count=None):
     scores = scores.contiguous()
     grad = torch.empty_like(scores) if ctx.needs_input_grad[0] else None
-    loss = ops.cross_entropy_loss(scores, labels, weight, grad)
+    loss = ops.cross_entropy_loss(scores, labels, weight, grad, count)
     return _LossFn._finish(ctx, loss, grad)

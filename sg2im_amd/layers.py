@@ -115,7 +115,8 @@ class DiscCnn(nn.Sequential):
     self.specs, self.slope = specs, slope
     return self
 
-  def forward(self, x_nhwc):
+  def forward(self, x_nhwc, count=None):
+    """count: None or (int32 device scalar, 1) - real entries of a padded batch (sg2im_amd/bucketing.py)"""
     convs = [m for m in self if isinstance(m, nn.Conv2d)]
     bns = [m for m in self if isinstance(m, nn.BatchNorm2d)]
     if not bns:                       # 'none': conv, act, conv, ...; 'instance': conv, IN, act, conv, ...
@@ -123,13 +124,14 @@ class DiscCnn(nn.Sequential):
       params = []
       for cv in convs:
         params += [cv.weight, cv.bias]
-      return HF.DiscCnnFn.apply(x_nhwc, 'instance' if inorm else None, self.specs, self.slope, self.training, *params)
+      return HF.DiscCnnFn.apply(x_nhwc, 'instance' if inorm else None, self.specs, self.slope, self.training, count,
+                                *params)
     if len(bns) != len(convs) - 1:
       raise NotImplementedError('discriminator CNN with a partial set of normalization layers')
     params = [convs[0].weight, convs[0].bias]
     for bn, cv in zip(bns, convs[1:]):
       params += [bn.weight, bn.bias, cv.weight, cv.bias]
-    return HF.DiscCnnFn.apply(x_nhwc, bns, self.specs, self.slope, self.training, *params)
+    return HF.DiscCnnFn.apply(x_nhwc, bns, self.specs, self.slope, self.training, count, *params)
 
 
 def _init_conv(layer, method):

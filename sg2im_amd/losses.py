@@ -15,29 +15,32 @@ def get_gan_losses(gan_type):
   raise ValueError('Unrecognized GAN type "%s"' % gan_type)
 
 
-def bce_loss(input, target, weight=1.0):
+def bce_loss(input, target, weight=1.0, count=None):
   """Numerically stable BCE-with-logits against a constant target (reference
   sg2im/losses.py:39-57): mean(max(x,0) - x*t + log(1+exp(-|x|))).  ``weight`` (all losses here):
   the loss weight of scripts/train.py folded into the kernel instead of a separate multiply."""
-  return HF.BceLogitsLoss.apply(input, float(target), float(weight))
+  return HF.BceLogitsLoss.apply(input, float(target), float(weight), count)
 
 
 def _sum(*terms):
   return HF.SumScalars.apply(*terms)
 
 
-def gan_g_loss(scores_fake, weight=1.0):
-  return bce_loss(scores_fake, 1.0, weight)
+# ``count`` (every GAN loss below): None or (int32 device scalar, unit) - the scores of a padded object
+# batch (sg2im_amd/bucketing.py): the mean runs over the first count * unit scores only.
+
+def gan_g_loss(scores_fake, weight=1.0, count=None):
+  return bce_loss(scores_fake, 1.0, weight, count)
 
 
-def gan_d_loss(scores_real, scores_fake):
-  return _sum(*gan_d_loss.terms(scores_real, scores_fake))
+def gan_d_loss(scores_real, scores_fake, count=None):
+  return _sum(*gan_d_loss.terms(scores_real, scores_fake, count))
 
 
-def _gan_d_terms(scores_real, scores_fake):
+def _gan_d_terms(scores_real, scores_fake, count=None):
   """the addends of the discriminator loss, for a caller that sums them with further terms itself"""
   assert scores_real.size() == scores_fake.size()
-  return bce_loss(scores_real, 1.0), bce_loss(scores_fake, 0.0)
+  return bce_loss(scores_real, 1.0, 1.0, count), bce_loss(scores_fake, 0.0, 1.0, count)
 
 
 gan_d_loss.terms = _gan_d_terms
@@ -47,43 +50,43 @@ def l1_loss(pred, target, weight=1.0):
   return HF.L1Loss.apply(pred, target, float(weight))
 
 
-def mse_loss(pred, target, weight=1.0):
-  return HF.MseLoss.apply(pred, target, float(weight))
+def mse_loss(pred, target, weight=1.0, count=None):
+  return HF.MseLoss.apply(pred, target, float(weight), count)
 
 
-def cross_entropy(scores, labels, weight=1.0):
-  return HF.CrossEntropyLoss.apply(scores, labels, float(weight))
+def cross_entropy(scores, labels, weight=1.0, count=None):
+  return HF.CrossEntropyLoss.apply(scores, labels, float(weight), count)
 
 
-def wgan_g_loss(scores_fake, weight=1.0):
+def wgan_g_loss(scores_fake, weight=1.0, count=None):
   """reference sg2im/losses.py:106-114: -mean(scores_fake)"""
-  return HF.GanScoreLoss.apply(scores_fake, 1, -1.0, float(weight))
+  return HF.GanScoreLoss.apply(scores_fake, 1, -1.0, float(weight), count)
 
 
-def wgan_d_loss(scores_real, scores_fake):
+def wgan_d_loss(scores_real, scores_fake, count=None):
   """reference sg2im/losses.py:117-124: mean(fake) - mean(real)"""
-  return _sum(*wgan_d_loss.terms(scores_real, scores_fake))
+  return _sum(*wgan_d_loss.terms(scores_real, scores_fake, count))
 
 
-wgan_d_loss.terms = lambda scores_real, scores_fake: (HF.GanScoreLoss.apply(scores_fake, 1, 1.0, 1.0),
-                                                      HF.GanScoreLoss.apply(scores_real, 1, -1.0, 1.0))
+wgan_d_loss.terms = lambda scores_real, scores_fake, count=None: (
+  HF.GanScoreLoss.apply(scores_fake, 1, 1.0, 1.0, count), HF.GanScoreLoss.apply(scores_real, 1, -1.0, 1.0, count))
 
 
-def lsgan_g_loss(scores_fake, weight=1.0):
+def lsgan_g_loss(scores_fake, weight=1.0, count=None):
   """reference sg2im/losses.py:127-131: mse(sigmoid(fake), 1)"""
-  return HF.GanScoreLoss.apply(scores_fake, 2, 1.0, float(weight))
+  return HF.GanScoreLoss.apply(scores_fake, 2, 1.0, float(weight), count)
 
 
-def lsgan_d_loss(scores_real, scores_fake):
+def lsgan_d_loss(scores_real, scores_fake, count=None):
   """reference sg2im/losses.py:134-145"""
   assert scores_real.size() == scores_fake.size()
-  return _sum(*lsgan_d_loss.terms(scores_real, scores_fake))
+  return _sum(*lsgan_d_loss.terms(scores_real, scores_fake, count))
 
 
-lsgan_d_loss.terms = lambda scores_real, scores_fake: (HF.GanScoreLoss.apply(scores_real, 2, 1.0, 1.0),
-                                                       HF.GanScoreLoss.apply(scores_fake, 2, 0.0, 1.0))
+lsgan_d_loss.terms = lambda scores_real, scores_fake, count=None: (
+  HF.GanScoreLoss.apply(scores_real, 2, 1.0, 1.0, count), HF.GanScoreLoss.apply(scores_fake, 2, 0.0, 1.0, count))
 
 
-def binary_cross_entropy(prob, target, weight=1.0):
+def binary_cross_entropy(prob, target, weight=1.0, count=None):
   """F.binary_cross_entropy on probabilities (mask loss of scripts/train.py:407-410)"""
-  return HF.BceProbLoss.apply(prob, target, float(weight))
+  return HF.BceProbLoss.apply(prob, target, float(weight), count)

@@ -61,19 +61,22 @@ class Sg2ImModel(nn.Module):
     layers.append(nn.Conv2d(dim, 1, kernel_size=1))
     return to_channels_last(nn.Sequential(*layers))
 
-  def _run_mask_net(self, obj_vecs):
+  def _run_mask_net(self, obj_vecs, obj_count=None):
     bns = [m for m in self.mask_net if isinstance(m, nn.BatchNorm2d)]
     convs = [m for m in self.mask_net if isinstance(m, nn.Conv2d)]
     params = []
     for bn, cv in zip(bns, convs[:-1]):
       params += [bn.weight, bn.bias, cv.weight, cv.bias]
     params += [convs[-1].weight, convs[-1].bias]
-    return HF.MaskNetFn.apply(obj_vecs, bns, self.training, *params)
+    return HF.MaskNetFn.apply(obj_vecs, bns, self.training, obj_count, *params)
 
-  def forward_nhwc(self, objs, triples, obj_to_img=None, boxes_gt=None, masks_gt=None, num_images=None):
+  def forward_nhwc(self, objs, triples, obj_to_img=None, boxes_gt=None, masks_gt=None, num_images=None,
+                   obj_count=None):
     """Same computation as ``forward`` (reference sg2im/model.py:108-171) but the image
     is returned NHWC, the internal layout of the kernels.  ``num_images`` avoids the host
-    sync of reference sg2im/layout.py:143 (N = obj_to_img.max()+1)."""
+    sync of reference sg2im/layout.py:143 (N = obj_to_img.max()+1).  ``obj_count``: (int32 device
+    scalar, 1) when the object / triple axes are padded to a bucket size (sg2im_amd/bucketing.py):
+    the batch statistics of mask_net then only see the real objects."""
     O = objs.size(0)
     s = triples[:, 0].contiguous()
     p = triples[:, 1].contiguous()
@@ -96,7 +99,7 @@ class Sg2ImModel(nn.Module):
     boxes_pred = self.box_net(obj_vecs)
     masks_pred = None
     if self.mask_net is not None:
-      masks_pred = self._run_mask_net(obj_vecs)
+      masks_pred = self._run_mask_net(obj_vecs, obj_count)
 
     r1, r2 = self.rel_aux_net.linears()
     if self.rel_aux_net.norms():       # mlp_normalization='batch'

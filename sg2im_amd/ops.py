@@ -399,24 +399,37 @@ class BnState(object):
     self.mean, self.invstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
 
 
-def bn_stats(x, rows, C, ld, bn, training, eps=1e-5, momentum=0.1, unbiased_rows=0):
+def _count_args(count):
+  """count: None or (int32 device tensor [1], unit): only the first count[0] * unit rows / elements of
+  a padded batch are real (sg2im_amd/bucketing.py).  -> (pointer, unit) for the C ABI."""
+  if count is None:
+    return None, 1
+  t, unit = count
+  if not (t.is_cuda and t.dtype == torch.int32):
+    raise TypeError('row counts must be int32 tensors on the GPU')
+  return c_void_p(t.data_ptr()), int(unit)
+
+
+def bn_stats(x, rows, C, ld, bn, training, eps=1e-5, momentum=0.1, unbiased_rows=0, count=None):
   """x: any float tensor viewed as [rows][ld]; bn: a module holding weight/bias/running_*."""
   st = BnState(C, x.device)
+  cp, cu = _count_args(count)
   part = scratch(x.device, 2 * C * 256)
   nbt = bn.num_batches_tracked
   call('sg2im_bn_stats', _f(x), int(rows), int(C), int(ld), _f(bn.weight), _f(bn.bias), float(eps),
        float(momentum), int(training), _f(bn.running_mean), _f(bn.running_var),
        c_void_p(nbt.data_ptr()) if nbt is not None else None, int(unbiased_rows), _f(st.mean), _f(st.invstd), _f(st.scale),
-       _f(st.shift), _f(part), _stream())
+       _f(st.shift), _f(part), cp, cu, _stream())
   return st
 
 
 def bn_act_backward(g, ld_g, pool2, batch, h, w, y, ld_y, C, gamma, st, slope, training, dy, dgamma, dbeta,
-                    accumulate=False):
+                    accumulate=False, count=None):
   part = scratch(y.device, 2 * C * 256 + 3 * C)
+  cp, cu = _count_args(count)
   call('sg2im_bn_act_backward', g, int(ld_g), int(pool2), int(batch), int(h), int(w), _f(y), int(ld_y), int(C),
        _f(gamma), _f(st.mean), _f(st.invstd), _f(st.scale), _f(st.shift), float(slope), int(training), _f(dy),
-       _f(dgamma), _f(dbeta), int(accumulate), _f(part), _stream())
+       _f(dgamma), _f(dbeta), int(accumulate), _f(part), cp, cu, _stream())
   return dy
 
 
@@ -556,39 +569,44 @@ def l1_loss(pred, target, weight, grad):
   return loss
 
 
-def mse_loss(pred, target, weight, grad):
+def mse_loss(pred, target, weight, grad, count=None):
   loss = _loss_out(pred.device)
+  cp, cu = _count_args(count)
   call('sg2im_mse_loss', _f(pred), _f(target), pred.numel(), float(weight), _f(loss), _f(grad),
-       _f(scratch(pred.device, 256)), _stream())
+       _f(scratch(pred.device, 256)), cp, cu, _stream())
   return loss
 
 
-def bce_logits_loss(x, target, weight, grad):
+def bce_logits_loss(x, target, weight, grad, count=None):
   loss = _loss_out(x.device)
+  cp, cu = _count_args(count)
   call('sg2im_bce_logits_loss', _f(x), x.numel(), float(target), float(weight), _f(loss), _f(grad),
-       _f(scratch(x.device, 256)), _stream())
+       _f(scratch(x.device, 256)), cp, cu, _stream())
   return loss
 
 
-def gan_score_loss(x, kind, target, weight, grad):
+def gan_score_loss(x, kind, target, weight, grad, count=None):
   loss = _loss_out(x.device)
+  cp, cu = _count_args(count)
   call('sg2im_gan_score_loss', _f(x), x.numel(), int(kind), float(target), float(weight), _f(loss), _f(grad),
-       _f(scratch(x.device, 256)), _stream())
+       _f(scratch(x.device, 256)), cp, cu, _stream())
   return loss
 
 
-def bce_prob_loss(prob, target, weight, grad):
+def bce_prob_loss(prob, target, weight, grad, count=None):
   loss = _loss_out(prob.device)
+  cp, cu = _count_args(count)
   call('sg2im_bce_prob_loss', _f(prob), _f(target), prob.numel(), float(weight), _f(loss), _f(grad),
-       _f(scratch(prob.device, 256)), _stream())
+       _f(scratch(prob.device, 256)), cp, cu, _stream())
   return loss
 
 
-def cross_entropy_loss(scores, labels, weight, grad):
+def cross_entropy_loss(scores, labels, weight, grad, count=None):
   loss = _loss_out(scores.device)
   R, C = scores.shape
+  cp, cu = _count_args(count)
   call('sg2im_cross_entropy_loss', _f(scores), R, C, _i64(labels), float(weight), _f(loss), _f(grad),
-       _f(scratch(scores.device, max(256, R))), _stream())
+       _f(scratch(scores.device, max(256, R))), cp, cu, _stream())
   return loss
 
 

@@ -6,6 +6,8 @@ in a second one), so the optimiser is a single HIP kernel launch over the arena
 buffer - instead of the reference's per-tensor torch.optim.Adam loop
 (scripts/train.py:426-443, ~150 tensors for the generator).
 """
+import weakref
+
 import torch
 
 from . import functional as HF
@@ -29,6 +31,8 @@ class FlatParams(object):
     self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
     self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
     self.params, self.offsets = params, offs
+    self.sinks = {}                  # parameter data pointer -> dense view of its gradient slot
+    me = weakref.ref(self)
     with torch.no_grad():
       for p, off in zip(params, offs):
         view = self._view(self.flat, p, off)
@@ -36,8 +40,23 @@ class FlatParams(object):
         p.data = view
         p.grad = self._view(self.grad, p, off)
         # backward kernels accumulate straight into the arena (see functional.GRAD_SINKS)
-        HF.GRAD_SINKS[view.data_ptr()] = self._sink_view(p, off)
+        self.sinks[view.data_ptr()] = self._sink_view(p, off)
+        HF.GRAD_SINKS[view.data_ptr()] = me
     self.numel = total
+
+  def close(self):
+    """forget the gradient sinks (also done when the object is collected)"""
+    for ptr in list(self.sinks):
+      ref = HF.GRAD_SINKS.get(ptr)
+      if ref is not None and ref() in (self, None):
+        HF.GRAD_SINKS.pop(ptr, None)
+    self.sinks = {}
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
 
   def _sink_view(self, p, off):
     """dense physical view of the parameter's gradient slot: [Cout][KH][KW][Cin] for a

@@ -11,7 +11,9 @@ Differences from the reference that do not change the mathematics:
   * under data parallelism the gradient of every network is summed with one all-reduce
     over its flat gradient arena and scaled by 1/world_size inside the Adam kernel.
 """
+import collections
 import math
+import os
 
 import torch
 
@@ -19,6 +21,7 @@ from . import _lib
 from . import functional as HF
 from . import losses as L
 from . import ops
+from .bucketing import Bucketer, StaticBatch, pad_batch
 from .discriminators import AcCropDiscriminator, PatchDiscriminator
 from .distributed import GradReducer
 from .model import Sg2ImModel
@@ -50,10 +53,17 @@ def _set_requires_grad(module, flag):
 class Trainer(object):
   def __init__(self, vocab, device, generator_kwargs=None, d_obj_kwargs=None, d_img_kwargs=None,
                loss_weights=None, learning_rate=1e-4, world_size=1, seed=None, use_graphs=False,
-               gan_loss_type='gan', overlap_d=None):
+               gan_loss_type='gan', overlap_d=None, bucket='auto', max_graphs=32, rank=0):
+    """use_graphs: replay one captured hipGraph per batch-shape BUCKET instead of launching ~480
+    kernels from Python.  bucket = (object multiple, triple multiple): the object / triple axes of
+    every batch are padded to those multiples with exactly neutral rows (sg2im_amd/bucketing.py);
+    'auto' = (32, 64) in graph mode and no padding in eager mode; an explicit bucket also pads the
+    eager launches, which then run the same kernels on the same shapes as the graph (bit-identical
+    results).  Batches of any (O, T) are accepted either way."""
     self.gan_g_loss, self.gan_d_loss = L.get_gan_losses(gan_loss_type)     # train.py:467
     self.device = device
     self.world_size = world_size
+    self.rank = rank
     if seed is not None:
       torch.manual_seed(seed)            # identical initial weights on every rank
     gk = dict(GENERATOR_DEFAULTS)
@@ -83,18 +93,44 @@ class Trainer(object):
     self.opt_do = FlatAdam(self.flat_do, lr=learning_rate) if self.d_obj is not None else None
     self.opt_di = FlatAdam(self.flat_di, lr=learning_rate) if self.d_img is not None else None
     self.reducer = GradReducer(world_size)
+    if world_size > 1:
+      # replicas must start from identical weights / buffers whatever the seeds were, and draw
+      # different layout noise (model.py:164-168) per rank
+      self.broadcast_state()
+      if seed is not None:
+        torch.cuda.manual_seed(seed * 1000003 + 7919 * (rank + 1))
     self.use_graphs = use_graphs
+    if bucket == 'auto':
+      bucket = (32, 64) if use_graphs else None
+    self.bucketer = Bucketer(*bucket) if bucket else None
+    self.max_graphs = max_graphs
+    self.graph_stats = {'captures': 0, 'replays': 0, 'invalidated': 0, 'evicted': 0}
+    self._cap_stream = None
     # single-GPU graph mode: capture the whole iteration as ONE graph in which the two
     # discriminator steps run on a side stream concurrently with the generator's backward
     # (they only need imgs_pred; their small kernels fill the CUs the GCN / MLP backward leaves idle)
     self.overlap_d = True if overlap_d is None else bool(overlap_d)
     self._side = None
-    import os
     self.overlap_eager = os.environ.get('SG2IM_OVERLAP_EAGER', '0') == '1'
-    self._graphs, self._graph_warm = {}, {}
+    self._graphs = collections.OrderedDict()
     self.t = 0
 
   # -- data-parallel helpers --------------------------------------------------
+  def broadcast_state(self, src=0):
+    """rank ``src``'s parameters, optimiser moments and BatchNorm buffers to every rank (after
+    construction and after a checkpoint restore)"""
+    import torch.distributed as dist
+    if self.world_size <= 1 or not dist.is_initialized():
+      return
+    for flat, opt in ((self.flat_g, self.opt_g), (self.flat_do, self.opt_do), (self.flat_di, self.opt_di)):
+      if flat is not None:
+        for t in (flat.flat, opt.exp_avg, opt.exp_avg_sq, opt.state):
+          dist.broadcast(t, src)
+    for m in (self.model, self.d_obj, self.d_img):
+      if m is not None:
+        for b in m.buffers():
+          dist.broadcast(b, src)
+
   def set_generator_eval(self):
     """reference scripts/train.py:509-512: eval-mode BN for G and a fresh Adam"""
     self.model.eval()
@@ -117,31 +153,36 @@ class Trainer(object):
     imgs, objs, boxes, masks, triples, obj_to_img = batch[:6]
     st['imgs_nhwc'] = HF.NchwToNhwc.apply(imgs)
     st['gen_out'] = self.model.forward_nhwc(objs, triples, obj_to_img, boxes_gt=boxes, masks_gt=masks,
-                                            num_images=imgs.size(0))
+                                            num_images=imgs.size(0), obj_count=st.get('ocnt'))
     st['imgs_fake'] = st['gen_out'][0].detach()
 
   def _seg_generator_losses(self, batch, st):
     imgs, objs, boxes, masks, triples, obj_to_img = batch[:6]
     w = self.w
     imgs_pred, boxes_pred, masks_pred, rel_scores = st.pop('gen_out')
+    # padded batch (graph mode): the means over objects / triples run over the real rows only
+    oc, tc = st.get('ocnt'), st.get('tcnt')
+    cnt = lambda c, unit: None if c is None else (c[0], c[1] * unit)
     # train.py:531-560.  The discriminators are frozen here (see module docstring).
     for d in (self.d_obj, self.d_img):
       if d is not None:
         _set_requires_grad(d, False)
     losses = {}          # the generator's own terms (st['losses'] may already hold a D step's)
     losses['L1_pixel_loss'] = L.l1_loss(imgs_pred, st['imgs_nhwc'], w['l1_pixel_loss_weight'])
-    losses['bbox_pred'] = L.mse_loss(boxes_pred, boxes, w['bbox_pred_loss_weight'])
+    losses['bbox_pred'] = L.mse_loss(boxes_pred, boxes, w['bbox_pred_loss_weight'], cnt(oc, 4))
     if w['predicate_pred_loss_weight'] > 0:                       # train.py:402-405
       losses['predicate_pred'] = L.cross_entropy(rel_scores, triples[:, 1].contiguous(),
-                                                 w['predicate_pred_loss_weight'])
+                                                 w['predicate_pred_loss_weight'], cnt(tc, 1))
     if w['mask_loss_weight'] > 0 and masks is not None and masks_pred is not None:   # train.py:407-410
-      losses['mask_loss'] = L.binary_cross_entropy(masks_pred, masks, w['mask_loss_weight'])
+      losses['mask_loss'] = L.binary_cross_entropy(masks_pred, masks, w['mask_loss_weight'],
+                                                   cnt(oc, masks_pred.size(1) * masks_pred.size(2)))
     if self.d_obj is not None:
       # (loss weights are folded into the loss kernels; the terms are summed by ONE launch and the
       # backward pass is seeded with ops.unit, so no term pays a multiply / scaling launch)
-      scores_fake, ac_loss = self.d_obj.forward_nhwc(imgs_pred, objs, boxes, obj_to_img, w['ac_loss_weight'])
+      scores_fake, ac_loss = self.d_obj.forward_nhwc(imgs_pred, objs, boxes, obj_to_img, w['ac_loss_weight'], oc)
       losses['ac_loss'] = ac_loss
-      losses['g_gan_obj_loss'] = self.gan_g_loss(scores_fake, weight=w['discriminator_loss_weight'] * w['d_obj_weight'])
+      losses['g_gan_obj_loss'] = self.gan_g_loss(scores_fake, weight=w['discriminator_loss_weight'] * w['d_obj_weight'],
+                                                 count=oc)
     if self.d_img is not None:
       scores_fake = self.d_img.forward_nhwc(imgs_pred)
       losses['g_gan_img_loss'] = self.gan_g_loss(scores_fake, weight=w['discriminator_loss_weight'] * w['d_img_weight'])
@@ -168,9 +209,10 @@ class Trainer(object):
     imgs, objs, boxes, masks, triples, obj_to_img = batch[:6]
     losses = st['losses']
     # train.py:566-579
-    sf, ac_fake = self.d_obj.forward_nhwc(st['imgs_fake'], objs, boxes, obj_to_img)
-    sr, ac_real = self.d_obj.forward_nhwc(st['imgs_nhwc'], objs, boxes, obj_to_img)
-    gan_terms = self.gan_d_loss.terms(sr, sf)
+    oc = st.get('ocnt')
+    sf, ac_fake = self.d_obj.forward_nhwc(st['imgs_fake'], objs, boxes, obj_to_img, obj_count=oc)
+    sr, ac_real = self.d_obj.forward_nhwc(st['imgs_nhwc'], objs, boxes, obj_to_img, obj_count=oc)
+    gan_terms = self.gan_d_loss.terms(sr, sf, oc)
     losses['d_obj_gan_loss'] = HF.SumScalars.apply(*gan_terms).detach()      # (reported value only)
     losses['d_ac_loss_real'], losses['d_ac_loss_fake'] = ac_real, ac_fake
     st['d_obj_total'] = HF.SumScalars.apply(*gan_terms, ac_real, ac_fake)
@@ -272,93 +314,125 @@ class Trainer(object):
     Returns a dict of 0-dim device tensors (no host sync)."""
     self.t += 1
     if self.use_graphs:
+      if self.bucketer is None:
+        self.bucketer = Bucketer(32, 64)
       return self._graph_step(batch)
     st = {'losses': {}}
+    if self.bucketer is not None:       # eager launches on the padded batch (what a graph would replay)
+      o_pad, t_pad = self.bucketer.bucket(batch[1].numel(), batch[4].size(0))
+      batch, counts = pad_batch(batch, o_pad, t_pad)
+      st['ocnt'], st['tcnt'] = (counts[0:1], 1), (counts[1:2], 1)
     if self.overlap_eager:
       self._run_overlapped_eager(batch, st)
     else:
       self._run_segments(batch, st, lambda name, fn: fn())
     return st['out']
 
-  # -- hipGraph replay for shape-static batches -----------------------------------
+  # -- hipGraph replay, one graph per batch-shape bucket ---------------------------
+  def _prepare_lanes(self, scratch_floats):
+    """Streams and work buffers of every execution lane a capture uses, created EAGERLY (outside
+    any capture, so that no captured graph's private memory pool ends up owning them): the capture
+    stream, the side stream of the discriminator steps and the side stream the refinement network's
+    weight gradients run on (ops.SideLane)."""
+    dev = self.device
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if self._cap_stream is None:
+      _lib.init()
+      self._cap_stream = torch.cuda.Stream(device=idx)
+      self._n_side = 1               # (a second side stream for D_img measured slower: 11.1 vs 10.65 ms)
+      self._side = (torch.cuda.Stream(device=idx),)
+      key = (idx, self._cap_stream.cuda_stream)
+      if key not in ops._wgrad_streams:
+        ops._wgrad_streams[key] = torch.cuda.Stream(device=idx)
+    for s in (self._cap_stream, self._side[0], ops._wgrad_streams[(idx, self._cap_stream.cuda_stream)]):
+      with torch.cuda.stream(s):
+        ops.workspace(dev)
+        ops.scratch(dev, scratch_floats)
+    ops.unit(dev)                    # (cached process-wide: must not be born inside a capture)
+
   def _graph_step(self, batch):
-    """The eager step costs ~12 ms of Python/ctypes launch time for ~480 kernels - more
-    than the kernels themselves once they are fast.  For a batch signature (tensor shapes)
-    seen before, the four segments are captured once into hipGraphs (torch.cuda.CUDAGraph
-    records the launches our C ABI makes on the capture stream) and replayed; inputs are
-    copied into the graphs' static buffers.  New signatures run eagerly twice (warm-up:
-    kernel attribute calls, workspace growth) and are then captured.  Collectives stay
-    outside the graphs.
+    """The eager step costs ~12 ms of Python/ctypes launch time for ~480 kernels - more than the
+    kernels themselves.  In graph mode the object / triple axes of the batch are padded to a bucket
+    size (sg2im_amd/bucketing.py: exactly neutral padding, true sizes in device memory), the whole
+    iteration of a bucket is captured ONCE as a hipGraph (torch.cuda.CUDAGraph records the launches
+    our C ABI makes on the capture stream) and every later batch of that bucket is copied into the
+    graph's static input buffers and replayed.  A new bucket is captured directly - no eager warm-up
+    steps: sg2im_init() and _prepare_lanes() did everything a first launch would do lazily.
+    Collectives stay outside the graphs.
 
-    ROCm 7 caveat (measured, tools/graph_check2.py): ONE eager kernel launch from this
-    library after a graph was instantiated makes the next replay of that graph fault
-    (torch's own eager kernels and allocations do not).  Every launch through the binding
-    bumps ``_lib.EAGER_EPOCH``; a graph whose epoch is stale is discarded and re-captured
-    instead of replayed, so interleaving eager use of the library with graph steps is safe,
-    merely slower."""
-    tensors = [t for t in batch[:6] if torch.is_tensor(t)]
-    key = tuple((tuple(t.shape), t.dtype) for t in batch[:6] if torch.is_tensor(t)) + (batch[3] is None,)
+    ROCm 7 caveat (measured, tools/graph_fault_probe.py): an EAGER kernel launch from this library
+    after a graph was instantiated makes the next replay of that graph fault.  Eager launches through
+    the binding bump ``_lib.EAGER_EPOCH`` (captured ones do not); a graph whose epoch is stale is
+    dropped and re-captured at its next use, so validation passes / eager use of the library between
+    training steps are safe and cost one re-capture per bucket."""
+    imgs, objs, masks, triples = batch[0], batch[1], batch[3], batch[4]
+    o_pad, t_pad = self.bucketer.bucket(objs.numel(), triples.size(0))
+    key = (o_pad, t_pad, tuple(imgs.shape), None if masks is None else (masks.dtype,) + tuple(masks.shape[1:]))
+    if self._graphs and os.environ.get('SG2IM_IGNORE_EPOCH', '0') != '1':     # (tools/graph_fault_probe.py)
+      stale = [k for k, e in self._graphs.items() if e[3] != _lib.EAGER_EPOCH]
+      for k in stale:                # the library ran eagerly since these were instantiated
+        del self._graphs[k]
+      self.graph_stats['invalidated'] += len(stale)
     ent = self._graphs.get(key)
-    if ent is not None and ent[3] != _lib.EAGER_EPOCH:
-      del self._graphs[key]          # the library was used eagerly since the capture
-      ent = None
-      self._graph_warm[key] = 2
     if ent is None:
-      seen = self._graph_warm.get(key, 0)
-      if seen < 2:
-        self._graph_warm[key] = seen + 1
-        st = {'losses': {}}
-        self._run_segments(batch, st, lambda name, fn: fn())
-        return st['out']
-      static = tuple(t.clone() if torch.is_tensor(t) else t for t in batch[:6])
-      st = {'losses': {}}
-      graphs = {}
-      pool = [None]
-      import os
-      dp = self.world_size > 1 or self.reducer.force
-      if self.overlap_d and os.environ.get('SG2IM_DP_SCHEDULE', '0') != '1':
-        try:
-          return self._capture_overlapped(key, static, st, dp)
-        except Exception as e:    # capture unsupported here: stay eager, loudly
-          print('WARNING: hipGraph capture failed (%s: %s); falling back to eager launches' % (type(e).__name__, e))
-          self.use_graphs = False
-          torch.cuda.synchronize()
-          st = {'losses': {}}
-          self._run_segments(batch, st, lambda name, fn: fn())
-          return st['out']
-
-      def capture(name, fn):
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=pool[0], capture_error_mode=_CAPTURE_MODE):
-          fn()
-        if pool[0] is None:
-          pool[0] = g.pool()
-        graphs[name] = g
-      torch.cuda.synchronize()
+      sb = StaticBatch(batch, o_pad, t_pad)
       try:
-        self._run_segments(static, st, capture)
-      except Exception as e:      # capture unsupported here: stay eager, loudly
+        ent = self._capture(sb)
+      except Exception as e:    # capture unsupported here: stay eager, loudly
         print('WARNING: hipGraph capture failed (%s: %s); falling back to eager launches' % (type(e).__name__, e))
+        _lib.CAPTURING = False
         self.use_graphs = False
         torch.cuda.synchronize()
         st = {'losses': {}}
         self._run_segments(batch, st, lambda name, fn: fn())
         return st['out']
-      self._graphs[key] = (static, graphs, st, _lib.EAGER_EPOCH)
-      # capture records but does not execute: run the freshly captured graphs once now
-      self._run_segments(static, st, lambda name, fn: graphs[name].replay())
-      return st['out']
-    static, graphs, st, _ = ent
-    for s, t in zip([x for x in static if torch.is_tensor(x)], tensors):
-      s.copy_(t, non_blocking=True)
+      self._graphs[key] = ent
+      self.graph_stats['captures'] += 1
+      while len(self._graphs) > self.max_graphs:
+        self._graphs.popitem(last=False)
+        self.graph_stats['evicted'] += 1
+    else:
+      self._graphs.move_to_end(key)
+      ent[0].load(batch)
+    sb, graphs, st, _ = ent
+    self.graph_stats['replays'] += 1
     if 'all' in graphs:
       graphs['all'].replay()
       if 'adam' in graphs:          # data parallel: gradient exchange between the two graphs
         self._exchange_all(st)
         graphs['adam'].replay()
       return st['out']
-    self._run_segments(static, st, lambda name, fn: graphs[name].replay())
+    self._run_segments(sb.tensors(), st, lambda name, fn: graphs[name].replay())
     return st['out']
+
+  def _capture(self, sb):
+    """Capture the iteration for the bucket whose static buffers are ``sb``; returns the cache entry
+    (static batch, graphs, state dict with the output tensors, launch epoch)."""
+    imgs = sb.imgs
+    # reduction scratch the crop backward wants: one image-sized plane per (padded) object
+    self._prepare_lanes(max(1 << 24, sb.o_pad * imgs.size(2) * imgs.size(3) * imgs.size(1) + (1 << 20)))
+    st = {'losses': {}, 'ocnt': sb.obj_count, 'tcnt': sb.triple_count}
+    static = sb.tensors()
+    dp = self.world_size > 1 or self.reducer.force
+    torch.cuda.synchronize()
+    _lib.CAPTURING = True
+    try:
+      if self.overlap_d and os.environ.get('SG2IM_DP_SCHEDULE', '0') != '1':
+        graphs = self._capture_overlapped(static, st, dp)
+      else:
+        graphs, pool = {}, [None]
+
+        def capture(name, fn):
+          g = torch.cuda.CUDAGraph()
+          with torch.cuda.graph(g, pool=pool[0], stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
+            fn()
+          if pool[0] is None:
+            pool[0] = g.pool()
+          graphs[name] = g
+        self._run_segments(static, st, capture)
+    finally:
+      _lib.CAPTURING = False
+    return (sb, graphs, st, _lib.EAGER_EPOCH)
 
   def _exchange_all(self, st):
     red = self.reducer
@@ -370,23 +444,16 @@ class Trainer(object):
       red.start(self.flat_di.grad)
     red.finish()
 
-  def _capture_overlapped(self, key, static, st, dp=False):
+  def _capture_overlapped(self, static, st, dp=False):
     """One graph for the whole iteration: generator forward, then a fork - the generator's backward
     on the capture stream, the discriminator steps on a side stream (own split-K workspace /
     scratch, which ops keys by stream) - joined before the three Adam updates.  Data parallel
     (dp): the Adam updates are a second graph and the four all-reduces are issued between the two
     replays (the exchange is then not hidden behind compute, but the overlapped graph is 1.3 ms
     shorter than the sequential segments that could hide it)."""
-    from . import ops
-    if self._side is None:
-      import os
-      self._n_side = 1               # (a second side stream for D_img measured slower: 11.1 vs 10.65 ms)
-      self._side = (torch.cuda.Stream(),)
     g = torch.cuda.CUDAGraph()
-    torch.cuda.synchronize()
-    with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
+    with torch.cuda.graph(g, stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
       main = torch.cuda.current_stream()
-      import os
       side = self._side[0]
       mode = os.environ.get('SG2IM_SCHEDULE', '2')
       self._seg_generator_forward(static, st)
@@ -432,15 +499,10 @@ class Trainer(object):
     graphs = {'all': g}
     if dp:
       ga = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(ga, pool=g.pool(), capture_error_mode=_CAPTURE_MODE):
+      with torch.cuda.graph(ga, pool=g.pool(), stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
         self._seg_adam(st)
       graphs['adam'] = ga
-    self._graphs[key] = (static, graphs, st, _lib.EAGER_EPOCH)
-    g.replay()
-    if dp:
-      self._exchange_all(st)
-      ga.replay()
-    return st['out']
+    return graphs
 
   @staticmethod
   def losses_to_host(losses):

@@ -262,10 +262,11 @@ def test_graph_replay_matches_eager_steps():
   dev = hh.dev()
   vocab = make_vocab(184, 7)
   batch = tuple(t.to(dev) if torch.is_tensor(t) else t for t in synthetic_batch(4, seed=11))
-  kw = dict(generator_kwargs={'layout_noise_dim': 0}, seed=7)
+  # (an explicit bucket makes the eager trainer launch on the same padded shapes the graph replays)
+  kw = dict(generator_kwargs={'layout_noise_dim': 0}, seed=7, bucket=(32, 64))
   b = Trainer(vocab, dev, use_graphs=True, **kw)
-  lb = [Trainer.losses_to_host(b.step(batch)) for _ in range(5)]    # 2 eager, capture, 2 replays
-  assert len(b._graphs) == 1
+  lb = [Trainer.losses_to_host(b.step(batch)) for _ in range(5)]    # capture + replay, 4 replays
+  assert len(b._graphs) == 1 and b.graph_stats['captures'] == 1 and b.graph_stats['replays'] == 5
   a = Trainer(vocab, dev, use_graphs=False, **kw)
   la = [Trainer.losses_to_host(a.step(batch)) for _ in range(5)]
   for i in range(5):
@@ -275,9 +276,11 @@ def test_graph_replay_matches_eager_steps():
   # the eager trainer above used the library: the old graph must not be replayed
   out = Trainer.losses_to_host(b.step(batch))
   assert all(v == v for v in out.values())
+  assert b.graph_stats['invalidated'] == 1 and b.graph_stats['captures'] == 2
   out = Trainer.losses_to_host(b.step(batch))          # replay of the re-captured graph
   torch.cuda.synchronize()
   assert all(v == v for v in out.values())
+  assert b.graph_stats['captures'] == 2
 
 
 def test_rccl_path_single_rank():
@@ -296,7 +299,7 @@ def test_rccl_path_single_rank():
   try:
     vocab = make_vocab(184, 7)
     batch = tuple(t.to(dev) if torch.is_tensor(t) else t for t in synthetic_batch(4, seed=13))
-    kw = dict(generator_kwargs={'layout_noise_dim': 0}, seed=5)
+    kw = dict(generator_kwargs={'layout_noise_dim': 0}, seed=5, bucket=(32, 64))
     b = Trainer(vocab, dev, **kw)
     lb = [Trainer.losses_to_host(b.step(batch)) for _ in range(5)]
     for use_graphs in (False, True):     # eager segments / iteration graph + all-reduces + Adam graph
@@ -319,7 +322,7 @@ def test_step_is_bit_reproducible():
   dev = hh.dev()
   vocab = make_vocab(184, 7)
   batch = tuple(t.to(dev) if torch.is_tensor(t) else t for t in synthetic_batch(4, seed=17))
-  kw = dict(generator_kwargs={'layout_noise_dim': 0}, seed=3)
+  kw = dict(generator_kwargs={'layout_noise_dim': 0}, seed=3, bucket=(32, 64))
   runs = []
   for use_graphs in (False, False, True):
     tr = Trainer(vocab, dev, use_graphs=use_graphs, **kw)
@@ -585,7 +588,7 @@ def test_graph_iteration_vg_style_and_aux_losses_match_eager():
   vocab = make_vocab(179, 46)
   cpu = synthetic_batch(4, num_objs=179, num_preds=46, style='vg', min_objs=3, max_objs=10, seed=19)
   batch = tuple(t.to(dev) if torch.is_tensor(t) else t for t in cpu)
-  kw = dict(generator_kwargs={'layout_noise_dim': 0}, seed=3,
+  kw = dict(generator_kwargs={'layout_noise_dim': 0}, seed=3, bucket=(32, 64),
             loss_weights=dict(predicate_pred_loss_weight=0.2, mask_loss_weight=0.0))
   runs = []
   for use_graphs in (False, True):
@@ -633,3 +636,110 @@ def test_generator_gradients_with_predicted_boxes():
     assert e <= 2e-4 or float((p.grad.cpu() - ref).abs().max()) <= 1e-6, (k, e)
     checked += 1
   assert checked > 30 and any(k.startswith('box_net') for k, _ in model.named_parameters())
+
+
+def _oracle_pair(vocab, gk, lw, lr, seed_g=0):
+  """(HIP Trainer kwargs, OracleTrainer) starting from the same parameters"""
+  from oracle import sg2im_oracle as orc
+  from sg2im_amd.trainer import GENERATOR_DEFAULTS, D_OBJ_DEFAULTS, D_IMG_DEFAULTS
+  gcfg = dict(GENERATOR_DEFAULTS, vocab=vocab)
+  gcfg.update(gk)
+  docfg, dicfg = dict(D_OBJ_DEFAULTS, vocab=vocab), dict(D_IMG_DEFAULTS)
+  PG = orc.init_generator_params(gcfg, seed_g, randomize_bn=True)
+  PDo = orc.init_ac_discriminator_params(docfg, 2, randomize_bn=True)
+  PDi = orc.init_patch_discriminator_params(dicfg, 1, randomize_bn=True)
+  otr = orc.OracleTrainer({k: v.clone() for k, v in PG.items()}, {k: v.clone() for k, v in PDo.items()},
+                          {k: v.clone() for k, v in PDi.items()}, gcfg, docfg, dicfg, weights=dict(lw), lr=lr)
+  return (PG, PDo, PDi), otr
+
+
+@pytest.mark.parametrize('style', ['coco', 'vg'])
+def test_padded_batch_step_matches_oracle_on_the_unpadded_batch(style):
+  """sg2im_amd/bucketing.py: the object / triple axes padded to a bucket (dummy objects outside the
+  image, dummy triples on a dummy object, true row counts in device memory for the BatchNorm
+  statistics of D_obj / mask_net and for every loss mean) must give the reference's result for the
+  UNPADDED batch - losses, every parameter after the Adam updates, running statistics.  COCO style
+  with the mask + predicate losses on (all counted means), VG style (mask_net trains through its
+  counted BatchNorms)."""
+  from sg2im_amd.synthetic import make_vocab, synthetic_batch
+  from sg2im_amd.trainer import Trainer
+  from tests import hip_harness as hh
+  dev = hh.dev()
+  if style == 'coco':
+    vocab = make_vocab(184, 7)
+    cpu_batch = synthetic_batch(4, seed=23)
+    lw = dict(predicate_pred_loss_weight=0.3, mask_loss_weight=0.7)
+  else:
+    vocab = make_vocab(179, 46)
+    cpu_batch = synthetic_batch(4, num_objs=179, num_preds=46, style='vg', min_objs=3, max_objs=10, seed=29)
+    lw = dict(predicate_pred_loss_weight=0.3)
+  gk = {'layout_noise_dim': 0}
+  (PG, PDo, PDi), otr = _oracle_pair(vocab, gk, lw, 1e-4)
+  tr = Trainer(vocab, dev, seed=0, generator_kwargs=gk, loss_weights=lw, bucket=(32, 64))
+  hh.load_params(tr.model, PG); hh.load_params(tr.d_obj, PDo); hh.load_params(tr.d_img, PDi)
+  batch = tuple(t.to(dev) if torch.is_tensor(t) else t for t in cpu_batch)
+  O, T = cpu_batch[1].numel(), cpu_batch[4].size(0)
+  assert tr.bucketer.bucket(O, T) != (O, T)
+  got = Trainer.losses_to_host(tr.step(batch))
+  want = otr.step(tuple(cpu_batch[:6]), None)
+  for k, v in want.items():
+    assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, got[k], v)
+  for name, mod, P in (('G', tr.model, otr.PG), ('Do', tr.d_obj, otr.PDo), ('Di', tr.d_img, otr.PDi)):
+    sd = mod.state_dict()
+    for k, v in P.items():
+      if v.is_floating_point():
+        d = float((sd[k].detach().cpu() - v.detach()).abs().max())
+        assert d <= 2.05e-4 or 'running_' in k and d <= 1e-3 * max(1.0, float(v.abs().max())), (name, k, d)
+
+
+def test_bucketed_graphs_interleaved_signatures_match_oracle():
+  """differently shaped batches (distinct object / triple counts, three distinct
+  buckets) interleaved for 12 iterations in graph mode: one capture per bucket, no re-capture, no
+  stale graph, and every iteration's losses equal the CPU oracle's on the same (unpadded) stream."""
+  from sg2im_amd.synthetic import make_vocab, synthetic_batch
+  from sg2im_amd.trainer import Trainer
+  from tests import hip_harness as hh
+  dev = hh.dev()
+  vocab = make_vocab(184, 7)
+  gk = {'layout_noise_dim': 0}
+  lr = 1e-6        # (Adam turns rounding-noise gradients into +-lr steps: keep 12 iterations comparable)
+  (PG, PDo, PDi), otr = _oracle_pair(vocab, gk, {}, lr)
+  tr = Trainer(vocab, dev, seed=0, generator_kwargs=gk, learning_rate=lr, use_graphs=True, bucket=(8, 16))
+  hh.load_params(tr.model, PG); hh.load_params(tr.d_obj, PDo); hh.load_params(tr.d_img, PDi)
+  # five distinct (O, T) shapes falling into three buckets
+  cpu = [synthetic_batch(4, seed=s, min_objs=lo, max_objs=hi) for s, lo, hi in
+         ((31, 3, 4), (32, 3, 4), (33, 5, 6), (34, 7, 8), (35, 7, 8))]
+  shapes = [(b[1].numel(), b[4].size(0)) for b in cpu]
+  buckets = set(tr.bucketer.bucket(o, t) for o, t in shapes)
+  assert len(set(shapes)) >= 4 and len(buckets) == 3, (shapes, buckets)
+  gpu = [tuple(t.to(dev) if torch.is_tensor(t) else t for t in b) for b in cpu]
+  order = [0, 2, 3, 1, 4, 2, 0, 3, 1, 4, 2, 0]
+  for it, i in enumerate(order):
+    got = Trainer.losses_to_host(tr.step(gpu[i]))
+    want = otr.step(tuple(cpu[i][:6]), None)
+    for k, v in want.items():
+      assert abs(got[k] - v) <= 2e-3 * max(1.0, abs(v)), (it, i, k, got[k], v)
+  assert tr.graph_stats == {'captures': 3, 'replays': 12, 'invalidated': 0, 'evicted': 0}, tr.graph_stats
+  assert len(tr._graphs) == 3
+
+
+def test_train_script_runs_in_graph_mode(tmp_path):
+  """scripts/train.py (the reference's option surface) trains in hipGraph mode by default: a few
+  iterations on a stream of differently shaped synthetic batches, checkpoint written with the
+  reference's keys, no graph re-captured."""
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  out = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'train.py'), '--batch_size', '4',
+                        '--num_iterations', '8', '--print_every', '4', '--checkpoint_every', '8',
+                        '--num_val_samples', '4', '--output_dir', str(tmp_path), '--bucket_objects', '8',
+                        '--bucket_triples', '16'],
+                       capture_output=True, text=True, timeout=600)
+  assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+  assert 'SYNTHETIC scene graphs' in out.stdout
+  line = [l for l in out.stdout.splitlines() if l.startswith('hipGraph statistics:')]
+  assert line, out.stdout[-2000:]
+  stats = eval(line[0].split(':', 1)[1])
+  assert stats['replays'] == 8 and stats['captures'] >= 1 and stats['invalidated'] == 0, stats
+  ck = torch.load(os.path.join(str(tmp_path), 'checkpoint_with_model.pt'), map_location='cpu', weights_only=False)
+  assert ck['counters']['t'] == 8 and 'model_state' in ck and 'd_obj_state' in ck and 'optim_state' in ck

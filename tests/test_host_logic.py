@@ -218,3 +218,41 @@ def test_launch_planner_choices_are_valid_without_a_gpu():
     for what in ('fwd', 'dgrad', 'wgrad'):
       bm, bn = plans[(layer, what)][3:5]
       assert bm * bn > 64 * 64, (layer, what, bm, bn)
+
+
+def test_bucketing_pads_with_neutral_rows():
+  """sg2im_amd/bucketing.py: structure of a padded batch, and - on the CPU oracle, which restates the
+  reference's own arithmetic - that the dummy objects / triples leave the generated images and the
+  real objects' boxes untouched (dummy boxes lie outside the image, dummy triples only touch a dummy
+  object)."""
+  from oracle import sg2im_oracle as orc
+  from sg2im_amd.bucketing import Bucketer, pad_batch, FAR_BOX
+  from sg2im_amd.synthetic import make_vocab, synthetic_batch
+  b = Bucketer(32, 64)
+  assert b.bucket(31, 64) == (32, 64) and b.bucket(32, 65) == (64, 128) and b.bucket(5, 0) == (32, 64)
+  batch = synthetic_batch(3, seed=4)
+  O, T = batch[1].numel(), batch[4].size(0)
+  o_pad, t_pad = b.bucket(O, T)
+  (imgs, objs, boxes, masks, triples, o2i), counts = pad_batch(batch, o_pad, t_pad)
+  assert objs.shape == (o_pad,) and boxes.shape == (o_pad, 4) and masks.shape[0] == o_pad
+  assert triples.shape == (t_pad, 3) and o2i.shape == (o_pad,) and counts.tolist() == [O, T]
+  assert torch.equal(objs[:O], batch[1]) and torch.equal(triples[:T], batch[4]) and torch.equal(boxes[:O], batch[2])
+  assert bool((objs[O:] == 0).all()) and bool((o2i[O:] == imgs.size(0) - 1).all()) and bool((masks[O:] == 0).all())
+  assert boxes[O:].tolist() == [list(FAR_BOX)] * (o_pad - O)
+  assert bool((triples[T:, 0] == o_pad - 1).all()) and bool((triples[T:, 2] == o_pad - 1).all())
+  assert bool((o2i[1:] >= o2i[:-1]).all())                     # still sorted by image
+  with pytest.raises(ValueError):
+    pad_batch(batch, O, t_pad)                                 # no room for a dummy object
+  # neutrality under the reference's arithmetic (generator in eval mode: mask_net's BatchNorm then
+  # has no cross-object coupling; in training mode the HIP kernels take the true count instead)
+  vocab = make_vocab(184, 7)
+  from sg2im_amd.trainer import GENERATOR_DEFAULTS
+  cfg = dict(GENERATOR_DEFAULTS, vocab=vocab, layout_noise_dim=0)
+  P = orc.init_generator_params(cfg, 0)
+  with torch.no_grad():
+    a = orc.generator_forward(P, cfg, batch[1], batch[4], batch[5], boxes_gt=batch[2], masks_gt=batch[3],
+                              training=False)
+    c = orc.generator_forward(P, cfg, objs, triples, o2i, boxes_gt=boxes, masks_gt=masks, training=False)
+  assert torch.equal(a[0], c[0])                               # images: bit-identical
+  assert torch.equal(a[1], c[1][:O])                           # boxes of the real objects
+  assert torch.equal(a[3], c[3][:T])                           # relationship scores of the real triples
