@@ -219,11 +219,8 @@ def main(args):
                     d_img_kwargs=dict(dk, arch=args.d_img_arch), loss_weights=lw,
                     learning_rate=args.learning_rate, world_size=world, seed=args.seed, rank=rank,
                     gan_loss_type=args.gan_loss_type, use_graphs=args.use_graphs,
-                    bucket=(args.bucket_objects, args.bucket_triples) if args.use_graphs else None)
-  if args.align_corners:
-    trainer.model.align_corners = True
-    if trainer.d_obj is not None:
-      trainer.d_obj.align_corners = True
+                    bucket=(args.bucket_objects, args.bucket_triples) if args.use_graphs else None,
+                    align_corners=args.align_corners)
   if args.checkpoint_start_from is not None:                        # reference train.py:162-172
     ck = torch.load(args.checkpoint_start_from, map_location='cpu', weights_only=False)
     sd = {(k[7:] if k.startswith('module.') else k): v for k, v in ck['model_state'].items()}

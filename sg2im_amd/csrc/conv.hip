@@ -168,15 +168,18 @@ template <int NVA, int NVB> struct RegSet {
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int VEC, bool GATHER>
-__global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// PP: ping-pong form (k_pipeline_pp): 512 threads, the two halves own M tiles 2*blockIdx.y + {0, 1}
+template <int BM, int BN, int VEC, bool GATHER, bool PP = false>
+__global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(const FwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem_all[];
   constexpr int NVA = BM / 32, NVB = BN / 32;
   constexpr int AF = LdsTile<BM, false>::FLOATS, BF = LdsTile<BN, false>::FLOATS;
   constexpr int STAGE = AF + BF;
   const ConvGeom& g = p.g;
-  const int tid = threadIdx.x;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, split = blockIdx.z;
+  const int half = PP ? (int)(threadIdx.x >> 8) : 0;
+  const int tid = threadIdx.x & (NTHREADS - 1);
+  float* const smem = smem_all + half * (TilePipe<BM, BN>::LDS_IMAGES * STAGE);
+  const int m0 = (blockIdx.y * (PP ? 2 : 1) + half) * BM, n0 = blockIdx.x * BN, split = blockIdx.z;
   const int per = (p.iters + p.e.nsplit - 1) / p.e.nsplit;
   const int it_begin = split * per;
   const int it_end = min(p.iters, it_begin + per);
@@ -349,13 +352,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
   int wm0, wn0, lane;
   wave_origin<BM, BN>(tid, wm0, wn0, lane);
 
-  k_pipeline<TilePipe<BM, BN>::DEPTH>(it_begin, it_end,
-    [&](int it, auto set) { if constexpr (decltype(set)::value == 0) load_into(it, rs0); else load_into(it, rs1); },
-    [&](auto set, int B_, bool) { if constexpr (decltype(set)::value == 0) stage_from(rs0, B_); else stage_from(rs1, B_); },
-    [&](int phase, int B_) {
-      if (phase == 0) read_frags<BM, BN, false, false>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, frags);
-      else mma_frags<BM, BN>(frags, acc);
-    });
+  auto do_load = [&](int it, auto set) { if constexpr (decltype(set)::value == 0) load_into(it, rs0); else load_into(it, rs1); };
+  auto do_stage = [&](auto set, int B_, bool) { if constexpr (decltype(set)::value == 0) stage_from(rs0, B_); else stage_from(rs1, B_); };
+  auto do_mma = [&](int phase, int B_) {
+    if (phase == 0) read_frags<BM, BN, false, false>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, frags);
+    else mma_frags<BM, BN>(frags, acc);
+  };
+  if constexpr (PP) k_pipeline_pp(half, it_begin, it_end, do_load, do_stage, do_mma);
+  else k_pipeline<TilePipe<BM, BN>::DEPTH>(it_begin, it_end, do_load, do_stage, do_mma);
   epilogue<BM, BN>(p.e, p.M, p.Cout, p.Cout, m0, n0, wm0, wn0, lane, split, acc);
 }
 
@@ -380,15 +384,17 @@ struct ParityRow {
   }
 };
 
-template <int BM, int BN, int VA, int VB>
-__global__ __launch_bounds__(NTHREADS) void conv_dgrad_kernel(const DgradParams p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+template <int BM, int BN, int VA, int VB, bool PP = false>
+__global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kernel(const DgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem_all[];
   constexpr int NVA = BM / 32, NVB = BN / 32;
   constexpr int AF = LdsTile<BM, false>::FLOATS, BF = LdsTile<BN, true>::FLOATS;
   constexpr int STAGE = AF + BF;
   const ConvGeom& g = p.g;
-  const int tid = threadIdx.x;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int half = PP ? (int)(threadIdx.x >> 8) : 0;
+  const int tid = threadIdx.x & (NTHREADS - 1);
+  float* const smem = smem_all + half * (TilePipe<BM, BN>::LDS_IMAGES * STAGE);
+  const int m0 = (blockIdx.y * (PP ? 2 : 1) + half) * BM, n0 = blockIdx.x * BN;
   const int col4 = tid & 7, r0 = tid >> 3;
   const int taps = g.KH * g.KW;
   const int ldw = taps * g.Ctot;
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_dgrad_kernel(const DgradParams 
     nkw = (g.KW - kw0 + 1) >> 1;
     nch = (Cout + BK - 1) / BK;
     iters = nkh * nkw * nch;
-    if (m0 >= M) return;
+    if (!PP && m0 >= M) return;       // (the ping-pong form is never launched in parity mode)
   } else {
     split = blockIdx.z;
   }
@@ -557,13 +563,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_dgrad_kernel(const DgradParams 
   int wm0, wn0, lane;
   wave_origin<BM, BN>(tid, wm0, wn0, lane);
 
-  k_pipeline<TilePipe<BM, BN>::DEPTH>(it_begin, it_end,
-    [&](int it, auto set) { if constexpr (decltype(set)::value == 0) load_into(it, rs0); else load_into(it, rs1); },
-    [&](auto set, int B_, bool) { if constexpr (decltype(set)::value == 0) stage_from(rs0, B_); else stage_from(rs1, B_); },
-    [&](int phase, int B_) {
-      if (phase == 0) read_frags<BM, BN, false, true>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, frags);
-      else mma_frags<BM, BN>(frags, acc);
-    });
+  auto do_load = [&](int it, auto set) { if constexpr (decltype(set)::value == 0) load_into(it, rs0); else load_into(it, rs1); };
+  auto do_stage = [&](auto set, int B_, bool) { if constexpr (decltype(set)::value == 0) stage_from(rs0, B_); else stage_from(rs1, B_); };
+  auto do_mma = [&](int phase, int B_) {
+    if (phase == 0) read_frags<BM, BN, false, true>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, frags);
+    else mma_frags<BM, BN>(frags, acc);
+  };
+  if constexpr (PP) k_pipeline_pp(half, it_begin, it_end, do_load, do_stage, do_mma);
+  else k_pipeline<TilePipe<BM, BN>::DEPTH>(it_begin, it_end, do_load, do_stage, do_mma);
   if (p.parity) {
     // split-K slabs of the parity form: [split][class][p.M rows][Nc], finished (and mapped to the
     // interleaved destination rows) by splitk_finish_parity_kernel
@@ -578,17 +585,20 @@ __global__ __launch_bounds__(NTHREADS) void conv_dgrad_kernel(const DgradParams 
 // ---------------------------------------------------------------------------
 // weight gradient
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int VEC, bool GATHER>
-__global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// PP: the two halves own the column tiles 2*blockIdx.x + {0, 1} of the same row tile / K split
+template <int BM, int BN, int VEC, bool GATHER, bool PP = false>
+__global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_wgrad_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem_all[];
   constexpr int NVA = BM / 32, NVB = BN / 32;
   constexpr int AF = LdsTile<BM, true>::FLOATS, BF = LdsTile<BN, true>::FLOATS;
   constexpr int STAGE = AF + BF;
   const ConvGeom& g = p.g;
-  const int tid = threadIdx.x;
+  const int half = PP ? (int)(threadIdx.x >> 8) : 0;
+  const int tid = threadIdx.x & (NTHREADS - 1);
+  float* const smem = smem_all + half * (TilePipe<BM, BN>::LDS_IMAGES * STAGE);
   // (an XCD-pinned 1-D grid - every column tile of a reduction slice on one XCD's L2 - was
   // measured: no gain on the large layers, so the plain 3-D grid stays)
-  const int ntile_x = blockIdx.x, mtile = blockIdx.y, split = blockIdx.z;
+  const int ntile_x = blockIdx.x * (PP ? 2 : 1) + half, mtile = blockIdx.y, split = blockIdx.z;
   const int m0 = mtile * BM;
   const int per = (p.iters + p.e.nsplit - 1) / p.e.nsplit;
   const int it_begin = split * per;
@@ -722,24 +732,27 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams 
   int wm0, wn0, lane;
   wave_origin<BM, BN>(tid, wm0, wn0, lane);
 
-  k_pipeline<TilePipe<BM, BN>::DEPTH>(it_begin, it_end,
-    [&](int it, auto set) { if constexpr (decltype(set)::value == 0) load_into(it, rs0); else load_into(it, rs1); },
-    [&](auto set, int B_, bool live) {
-      if constexpr (decltype(set)::value == 0) stage_from(rs0, B_, live); else stage_from(rs1, B_, live);
-    },
-    [&](int phase, int B_) {
-      if (phase == 0) read_frags<BM, BN, true, true>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, frags);
-      else mma_frags<BM, BN>(frags, acc);
-    });
+  auto do_load = [&](int it, auto set) { if constexpr (decltype(set)::value == 0) load_into(it, rs0); else load_into(it, rs1); };
+  auto do_stage = [&](auto set, int B_, bool live) {
+    if constexpr (decltype(set)::value == 0) stage_from(rs0, B_, live); else stage_from(rs1, B_, live);
+  };
+  auto do_mma = [&](int phase, int B_) {
+    if (phase == 0) read_frags<BM, BN, true, true>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, frags);
+    else mma_frags<BM, BN>(frags, acc);
+  };
+  if constexpr (PP) k_pipeline_pp(half, it_begin, it_end, do_load, do_stage, do_mma);
+  else k_pipeline<TilePipe<BM, BN>::DEPTH>(it_begin, it_end, do_load, do_stage, do_mma);
   epilogue<BM, BN>(p.e, p.Cout, Ntot, Ntot, m0, n0, wm0, wn0, lane, split, acc);
-  if (want_db) {
+  // (workgroup-uniform condition: in the ping-pong form both halves must reach the barrier below)
+  if (p.dbias != nullptr && blockIdx.x == 0) {
     // the 256 / QA threads that share a channel quad hold sums over disjoint pixel rows:
     // combine them through LDS in thread order (fixed order -> reproducible)
     constexpr int GROUPS = NTHREADS / QA;
-    float4* red = reinterpret_cast<float4*>(smem);            // [GROUPS][QA]
-    red[ak0 * QA + acol4] = dbs;                              // (the pipeline ended on a barrier)
+    float4* red = reinterpret_cast<float4*>(smem);            // [GROUPS][QA]  (the half's own LDS image)
+    __syncthreads();                                          // (every wave is done with its last chunk)
+    if (want_db) red[ak0 * QA + acol4] = dbs;
     __syncthreads();
-    if (tid < QA && aco < p.Cout) {
+    if (want_db && tid < QA && aco < p.Cout) {
       float4 t = red[tid];
       for (int k = 1; k < GROUPS; ++k) {
         const float4 u = red[k * QA + tid];
@@ -1110,9 +1123,9 @@ static hipError_t finish_split(const Epi& e, long long M, int N, hipStream_t st,
 // Per-instantiation "attributes set" flags.  sg2im_init() sets every one of them up front, so that
 // no hipFuncSetAttribute call is left for a first launch that may happen inside a stream capture;
 // a caller that skipped sg2im_init() still gets them lazily.
-template <int BM, int BN, int VEC, bool GATHER> bool g_fwd_ready = false;
-template <int BM, int BN, int VA, int VB> bool g_dgrad_ready = false;
-template <int BM, int BN, int VEC, bool GATHER> bool g_wgrad_ready = false;
+template <int BM, int BN, int VEC, bool GATHER, bool PP> bool g_fwd_ready = false;
+template <int BM, int BN, int VA, int VB, bool PP> bool g_dgrad_ready = false;
+template <int BM, int BN, int VEC, bool GATHER, bool PP> bool g_wgrad_ready = false;
 
 template <int BM, int BN> constexpr size_t fwd_lds() {
   return TilePipe<BM, BN>::LDS_IMAGES * (LdsTile<BM, false>::FLOATS + LdsTile<BN, false>::FLOATS) * sizeof(float);
@@ -1124,67 +1137,81 @@ template <int BM, int BN> constexpr size_t wgrad_lds() {
   return TilePipe<BM, BN>::LDS_IMAGES * (LdsTile<BM, true>::FLOATS + LdsTile<BN, true>::FLOATS) * sizeof(float);
 }
 
-template <int BM, int BN, int VEC, bool GATHER> static hipError_t prepare_fwd() {
-  if (g_fwd_ready<BM, BN, VEC, GATHER>) return hipSuccess;
-  const hipError_t e = ensure_lds(conv_fwd_kernel<BM, BN, VEC, GATHER>, std::max(fwd_lds<BM, BN>(), g_lds_floor));
-  if (e == hipSuccess) g_fwd_ready<BM, BN, VEC, GATHER> = true;
+// (PP: the ping-pong form holds one LDS image per half)
+template <int BM, int BN, int VEC, bool GATHER, bool PP = false> static hipError_t prepare_fwd() {
+  if (g_fwd_ready<BM, BN, VEC, GATHER, PP>) return hipSuccess;
+  const hipError_t e = ensure_lds(conv_fwd_kernel<BM, BN, VEC, GATHER, PP>,
+                                  std::max((PP ? 2 : 1) * fwd_lds<BM, BN>(), g_lds_floor));
+  if (e == hipSuccess) g_fwd_ready<BM, BN, VEC, GATHER, PP> = true;
   return e;
 }
-template <int BM, int BN, int VA, int VB> static hipError_t prepare_dgrad() {
-  if (g_dgrad_ready<BM, BN, VA, VB>) return hipSuccess;
-  const hipError_t e = ensure_lds(conv_dgrad_kernel<BM, BN, VA, VB>, dgrad_lds<BM, BN>());
-  if (e == hipSuccess) g_dgrad_ready<BM, BN, VA, VB> = true;
+template <int BM, int BN, int VA, int VB, bool PP = false> static hipError_t prepare_dgrad() {
+  if (g_dgrad_ready<BM, BN, VA, VB, PP>) return hipSuccess;
+  const hipError_t e = ensure_lds(conv_dgrad_kernel<BM, BN, VA, VB, PP>, (PP ? 2 : 1) * dgrad_lds<BM, BN>());
+  if (e == hipSuccess) g_dgrad_ready<BM, BN, VA, VB, PP> = true;
   return e;
 }
-template <int BM, int BN, int VEC, bool GATHER> static hipError_t prepare_wgrad() {
-  if (g_wgrad_ready<BM, BN, VEC, GATHER>) return hipSuccess;
-  const hipError_t e = ensure_lds(conv_wgrad_kernel<BM, BN, VEC, GATHER>, wgrad_lds<BM, BN>());
-  if (e == hipSuccess) g_wgrad_ready<BM, BN, VEC, GATHER> = true;
+template <int BM, int BN, int VEC, bool GATHER, bool PP = false> static hipError_t prepare_wgrad() {
+  if (g_wgrad_ready<BM, BN, VEC, GATHER, PP>) return hipSuccess;
+  const hipError_t e = ensure_lds(conv_wgrad_kernel<BM, BN, VEC, GATHER, PP>, (PP ? 2 : 1) * wgrad_lds<BM, BN>());
+  if (e == hipSuccess) g_wgrad_ready<BM, BN, VEC, GATHER, PP> = true;
   return e;
 }
 
-template <int BM, int BN, int VEC, bool GATHER>
+template <int BM, int BN, int VEC, bool GATHER, bool PP = false>
 static hipError_t launch_fwd_g(FwdParams& p, hipStream_t st) {
-  constexpr size_t lds = fwd_lds<BM, BN>();
+  constexpr size_t lds = (PP ? 2 : 1) * fwd_lds<BM, BN>();
   const size_t lds_req = std::max(lds, g_lds_floor);   // (occupancy experiments: SG2IM_LDS_FLOOR)
-  { hipError_t e = prepare_fwd<BM, BN, VEC, GATHER>(); if (e != hipSuccess) return e; }
-  dim3 grid((p.Cout + BN - 1) / BN, (p.M + BM - 1) / BM, p.e.nsplit);
-  hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, VEC, GATHER>), grid, dim3(NTHREADS), lds_req, st, p);
+  { hipError_t e = prepare_fwd<BM, BN, VEC, GATHER, PP>(); if (e != hipSuccess) return e; }
+  const int mt = (p.M + BM - 1) / BM;
+  dim3 grid((p.Cout + BN - 1) / BN, PP ? (mt + 1) / 2 : mt, p.e.nsplit);
+  hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, VEC, GATHER, PP>), grid, dim3(PP ? 2 * NTHREADS : NTHREADS), lds_req, st, p);
   return hipGetLastError();
 }
 
 static bool any_gather(ConvGeom& g) { for (int i = 0; i < g.nsrc; ++i) if (src_at(g, i)->gidx) return true; return false; }
 
-template <int BM, int BN, int VEC>
+template <int BM, int BN, int VEC, bool PP = false>
 static hipError_t launch_fwd(FwdParams& p, hipStream_t st) {
-  if (VEC == 4 && any_gather(p.g)) return launch_fwd_g<BM, BN, VEC, true>(p, st);
-  return launch_fwd_g<BM, BN, VEC, false>(p, st);
+  if (VEC == 4 && any_gather(p.g)) return launch_fwd_g<BM, BN, VEC, true>(p, st);     // (row gathers: tiny GEMMs, never ping-pong)
+  return launch_fwd_g<BM, BN, VEC, false, PP>(p, st);
 }
 
-template <int BM, int BN, int VA, int VB>
+template <int BM, int BN, int VA, int VB, bool PP = false>
 static hipError_t launch_dgrad(DgradParams& p, hipStream_t st) {
-  constexpr size_t lds = dgrad_lds<BM, BN>();
-  { hipError_t e = prepare_dgrad<BM, BN, VA, VB>(); if (e != hipSuccess) return e; }
-  dim3 grid((p.Nc + BN - 1) / BN, (p.M + BM - 1) / BM, p.parity ? 4 * p.e.nsplit : p.e.nsplit);
-  hipLaunchKernelGGL((conv_dgrad_kernel<BM, BN, VA, VB>), grid, dim3(NTHREADS), lds, st, p);
+  constexpr size_t lds = (PP ? 2 : 1) * dgrad_lds<BM, BN>();
+  { hipError_t e = prepare_dgrad<BM, BN, VA, VB, PP>(); if (e != hipSuccess) return e; }
+  const int mt = (p.M + BM - 1) / BM;
+  dim3 grid((p.Nc + BN - 1) / BN, PP ? (mt + 1) / 2 : mt, p.parity ? 4 * p.e.nsplit : p.e.nsplit);
+  hipLaunchKernelGGL((conv_dgrad_kernel<BM, BN, VA, VB, PP>), grid, dim3(PP ? 2 * NTHREADS : NTHREADS), lds, st, p);
   return hipGetLastError();
 }
 
-template <int BM, int BN, int VEC, bool GATHER>
+template <int BM, int BN, int VEC, bool GATHER, bool PP = false>
 static hipError_t launch_wgrad_g(WgradParams& p, int ntiles_n, hipStream_t st) {
-  constexpr size_t lds = wgrad_lds<BM, BN>();
-  { hipError_t e = prepare_wgrad<BM, BN, VEC, GATHER>(); if (e != hipSuccess) return e; }
+  constexpr size_t lds = (PP ? 2 : 1) * wgrad_lds<BM, BN>();
+  { hipError_t e = prepare_wgrad<BM, BN, VEC, GATHER, PP>(); if (e != hipSuccess) return e; }
   p.ntiles_n = ntiles_n;
   p.ntiles_m = (p.Cout + BM - 1) / BM;
-  dim3 grid(p.ntiles_n, p.ntiles_m, p.e.nsplit);
-  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, VEC, GATHER>), grid, dim3(NTHREADS), lds, st, p);
+  dim3 grid(PP ? (p.ntiles_n + 1) / 2 : p.ntiles_n, p.ntiles_m, p.e.nsplit);
+  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, VEC, GATHER, PP>), grid, dim3(PP ? 2 * NTHREADS : NTHREADS), lds, st, p);
   return hipGetLastError();
 }
 
-template <int BM, int BN, int VEC>
+template <int BM, int BN, int VEC, bool PP = false>
 static hipError_t launch_wgrad(WgradParams& p, int ntiles_n, hipStream_t st) {
   if (VEC == 4 && any_gather(p.g)) return launch_wgrad_g<BM, BN, VEC, true>(p, ntiles_n, st);
-  return launch_wgrad_g<BM, BN, VEC, false>(p, ntiles_n, st);
+  return launch_wgrad_g<BM, BN, VEC, false, PP>(p, ntiles_n, st);
+}
+
+// Ping-pong form (512-thread workgroups, k_pipeline_pp) for launches that fill the chip anyway:
+// at least g_pp_min 512-thread workgroups per CU after pairing.  SG2IM_PP=0 disables it.
+static const int g_pp = getenv("SG2IM_PP") ? atoi(getenv("SG2IM_PP")) : 1;
+static const double g_pp_min = getenv("SG2IM_PP_MIN") ? atof(getenv("SG2IM_PP_MIN")) : 1.0;
+static bool use_pp(const Plan& pl, long long pair_tiles, long long other_tiles, bool gather) {
+  if (!g_pp || gather || pl.tile == 2 || pair_tiles < 2) return false;
+  const double wgs = (double)((pair_tiles + 1) / 2) * (double)other_tiles * pl.nsplit;
+  return wgs >= g_pp_min * g_num_cu;
 }
 
 __global__ void init_probe_kernel(int* flag) { if (flag) flag[0] = 1; }
@@ -1210,6 +1237,12 @@ int sg2im_init(void) {
   SG2IM_PREP((fn<64, 64, __VA_ARGS__>())); SG2IM_PREP((fn<64, 128, __VA_ARGS__>()))
   SG2IM_PREP_TILES(prepare_fwd, 4, false);
   SG2IM_PREP_TILES(prepare_fwd, 4, true);
+  SG2IM_PREP((prepare_fwd<128, 128, 4, false, true>())); SG2IM_PREP((prepare_fwd<128, 64, 4, false, true>()));
+  SG2IM_PREP((prepare_fwd<64, 128, 4, false, true>()));
+  SG2IM_PREP((prepare_dgrad<128, 128, 4, 4, true>())); SG2IM_PREP((prepare_dgrad<128, 64, 4, 4, true>()));
+  SG2IM_PREP((prepare_dgrad<64, 128, 4, 4, true>()));
+  SG2IM_PREP((prepare_wgrad<128, 128, 4, false, true>())); SG2IM_PREP((prepare_wgrad<128, 64, 4, false, true>()));
+  SG2IM_PREP((prepare_wgrad<64, 128, 4, false, true>()));
   SG2IM_PREP((prepare_fwd<64, 64, 1, false>()));
   SG2IM_PREP_TILES(prepare_dgrad, 4, 4);
   SG2IM_PREP((prepare_dgrad<64, 64, 4, 1>())); SG2IM_PREP((prepare_dgrad<128, 64, 4, 1>()));
@@ -1249,7 +1282,10 @@ int sg2im_conv2d_forward(const sg2im_conv_desc* d, const float* weight, int cout
                             [&](int bn) { return (long long)(cout + bn - 1) / bn; });
   p.e = Epi{out, ld_out, bias, out_slope, accumulate, workspace, pl.nsplit};
   hipError_t err;
-  if (v4) {
+  if (v4 && use_pp(pl, (p.M + pl.bm - 1) / pl.bm, (cout + pl.bn - 1) / pl.bn, any_gather(p.g))) {
+    err = pl.tile == 0 ? launch_fwd<128, 128, 4, true>(p, stream) : pl.tile == 1 ? launch_fwd<128, 64, 4, true>(p, stream)
+                       : launch_fwd<64, 128, 4, true>(p, stream);
+  } else if (v4) {
     err = pl.tile == 0 ? launch_fwd<128, 128, 4>(p, stream) : pl.tile == 1 ? launch_fwd<128, 64, 4>(p, stream)
         : pl.tile == 2 ? launch_fwd<64, 64, 4>(p, stream) : launch_fwd<64, 128, 4>(p, stream);
   } else {
@@ -1317,7 +1353,11 @@ int sg2im_conv2d_backward_data(const sg2im_conv_desc* d, const float* weight, in
   }
   p.e = Epi{dx, ld_dx, nullptr, 1.f, accumulate, workspace, pl.nsplit};
   hipError_t err;
-  if (va4 && vb4) {
+  if (va4 && vb4 && !p.parity &&
+      use_pp(pl, (Mrows + pl.bm - 1) / pl.bm, (c_count + pl.bn - 1) / pl.bn, false)) {
+    err = pl.tile == 0 ? launch_dgrad<128, 128, 4, 4, true>(p, stream) : pl.tile == 1 ? launch_dgrad<128, 64, 4, 4, true>(p, stream)
+                       : launch_dgrad<64, 128, 4, 4, true>(p, stream);
+  } else if (va4 && vb4) {
     err = pl.tile == 0 ? launch_dgrad<128, 128, 4, 4>(p, stream) : pl.tile == 1 ? launch_dgrad<128, 64, 4, 4>(p, stream)
         : pl.tile == 2 ? launch_dgrad<64, 64, 4, 4>(p, stream) : launch_dgrad<64, 128, 4, 4>(p, stream);
   } else if (va4) {
@@ -1368,7 +1408,11 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
   p.dbias = dbias;
   p.ws_bias = pl.nsplit > 1 ? workspace + (size_t)pl.nsplit * cout * Ntot : nullptr;
   hipError_t err;
-  if (v4) {
+  if (v4 && use_pp(pl, ntiles_n, (cout + pl.bm - 1) / pl.bm, any_gather(p.g))) {
+    err = pl.tile == 0 ? launch_wgrad<128, 128, 4, true>(p, ntiles_n, stream)
+        : pl.tile == 1 ? launch_wgrad<128, 64, 4, true>(p, ntiles_n, stream)
+                       : launch_wgrad<64, 128, 4, true>(p, ntiles_n, stream);
+  } else if (v4) {
     err = pl.tile == 0 ? launch_wgrad<128, 128, 4>(p, ntiles_n, stream)
         : pl.tile == 1 ? launch_wgrad<128, 64, 4>(p, ntiles_n, stream)
         : pl.tile == 2 ? launch_wgrad<64, 64, 4>(p, ntiles_n, stream)

@@ -252,6 +252,9 @@ constexpr int LDS_STAGES = SG2IM_LDS_STAGES;
 #ifndef SG2IM_ABL
 #define SG2IM_ABL 0        // timing-only ablations (1: no loads/stores in the loop, 2: no barriers)
 #endif
+// (Measured and dropped, round 2: delaying the co-resident workgroups of a CU by 1-3k cycles at
+// kernel start - by linear block id or by the hardware wave slot - to de-phase their loader / MFMA
+// phases changed nothing, 86.9 vs 86.0-86.7 TFLOP/s forward over the layer table.)
 // Depth-1 variant: ONE register set and a branch-free loop body - the loads of chunk i+1,
 // the MFMAs of chunk i and the LDS stores of chunk i+1 are one basic block, so the compiler
 // can slot the loader's address arithmetic into the 64-cycle shadows of the MFMAs (a wave
@@ -341,6 +344,44 @@ __device__ __forceinline__ void k_pipeline_d2(int it_begin, int it_end, Load loa
     }
     __syncthreads();
   }
+}
+
+// Ping-pong variant: a 512-thread workgroup = two 256-thread HALVES, each with its own output tile,
+// LDS image and register set, running the depth-1 loop one barrier apart: while half 0 is in its
+// MFMA block, half 1 converts / stores its next chunk to LDS and issues the global loads of the one
+// after, and vice versa - the two waves that share a SIMD are, by construction, never both in their
+// loader phase (which left the matrix pipe idle: time per K chunk was N x MFMA block + one full
+// loader phase for N = 1..4 co-resident 256-thread workgroups, i.e. the loader phases of co-resident
+// waves coincided instead of hiding under each other's MFMAs).  Every s_barrier is workgroup-wide
+// (all 8 waves); the halves execute the same NUMBER of barriers, half 1 offset by one.
+//   barrier #     half 0                          half 1
+//   0             (prologue: chunk 0 staged, chunk 1 in registers - both halves)
+//   1             MFMA(0)                          -
+//   2             stage(1), load(2)                MFMA(0)
+//   3             MFMA(1)                          stage(1), load(2)
+//   ...
+// `half` must be wave-uniform and the K range identical for both halves.
+template <typename Load, typename Stage, typename Mma>
+__device__ __forceinline__ void k_pipeline_pp(int half, int it_begin, int it_end, Load load, Stage stage, Mma mma) {
+  const int n = it_end - it_begin;
+  if (n <= 0) return;
+  load(it_begin, IC<0>());
+  stage(IC<0>(), 0, true);
+  load(it_begin + (n > 1 ? 1 : 0), IC<0>());
+  __syncthreads();                                  // # 0
+  if (half) __syncthreads();                        // # 1 (half 1 sits out half 0's first MFMA block)
+  #pragma unroll 1
+  for (int i = 0; i < n; ++i) {
+    mma(0, 0); mma(1, 0);
+    __syncthreads();
+    // chunk i+1 to LDS (after the last chunk: a copy that is never read), then the loads of chunk
+    // i+2 - a whole MFMA block + loader phase ahead of their use
+    stage(IC<0>(), 0, i + 1 < n);
+    load(it_begin + (i + 2 < n ? i + 2 : n - 1), IC<0>());
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  }
+  if (!half) __syncthreads();                       // (same barrier count as half 1)
 }
 
 // PD = 1: single LDS image / one register set (large tiles, occupancy bound)

@@ -59,12 +59,14 @@ class AcDiscriminator(nn.Module):
 
 class AcCropDiscriminator(nn.Module):
   def __init__(self, vocab, arch, normalization='none', activation='relu', object_size=64, padding='same',
-               pooling='avg'):
+               pooling='avg', align_corners=ALIGN_CORNERS):
+    """align_corners (not a reference argument): sampling convention of the crops
+    (reference sg2im/bilinear.py:132), see Sg2ImModel"""
     super(AcCropDiscriminator, self).__init__()
     self.vocab = vocab
     self.discriminator = AcDiscriminator(vocab, arch, normalization, activation, padding, pooling)
     self.object_size = object_size
-    self.align_corners = ALIGN_CORNERS
+    self.align_corners = bool(align_corners)
 
   def forward_nhwc(self, imgs_nhwc, objs, boxes, obj_to_img, ac_weight=1.0, obj_count=None):
     """ac_weight: loss weight folded into the classification loss (the Trainer's ac_loss_weight);

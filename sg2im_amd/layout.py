@@ -23,15 +23,19 @@ def layout_nhwc(vecs, boxes, masks, obj_to_img, H, W=None, noise=None, n_images=
                            int(align_corners))
 
 
-def boxes_to_layout(vecs, boxes, obj_to_img, H, W=None, pooling='sum', n_images=None):
+def boxes_to_layout(vecs, boxes, obj_to_img, H, W=None, pooling='sum', n_images=None,
+                    align_corners=ALIGN_CORNERS):
   """reference sg2im/layout.py:30-63 -> (N, D, H, W)"""
   if pooling != 'sum':
     raise ValueError('Invalid pooling "%s"' % pooling)
-  return HF.NhwcToNchw.apply(layout_nhwc(vecs, boxes, None, obj_to_img, H, W, n_images=n_images))
+  return HF.NhwcToNchw.apply(layout_nhwc(vecs, boxes, None, obj_to_img, H, W, n_images=n_images,
+                                         align_corners=align_corners))
 
 
-def masks_to_layout(vecs, boxes, masks, obj_to_img, H, W=None, pooling='sum', n_images=None):
+def masks_to_layout(vecs, boxes, masks, obj_to_img, H, W=None, pooling='sum', n_images=None,
+                    align_corners=ALIGN_CORNERS):
   """reference sg2im/layout.py:66-91 -> (N, D, H, W)"""
   if pooling != 'sum':
     raise ValueError('Invalid pooling "%s"' % pooling)
-  return HF.NhwcToNchw.apply(layout_nhwc(vecs, boxes, masks, obj_to_img, H, W, n_images=n_images))
+  return HF.NhwcToNchw.apply(layout_nhwc(vecs, boxes, masks, obj_to_img, H, W, n_images=n_images,
+                                         align_corners=align_corners))

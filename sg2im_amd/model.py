@@ -15,14 +15,18 @@ class Sg2ImModel(nn.Module):
   def __init__(self, vocab, image_size=(64, 64), embedding_dim=64, gconv_dim=128, gconv_hidden_dim=512,
                gconv_pooling='avg', gconv_num_layers=5, refinement_dims=(1024, 512, 256, 128, 64),
                normalization='batch', activation='leakyrelu-0.2', mask_size=None,
-               mlp_normalization='none', layout_noise_dim=0, **kwargs):
+               mlp_normalization='none', layout_noise_dim=0, align_corners=ALIGN_CORNERS, **kwargs):
+    """align_corners (not a reference argument): the bilinear sampling convention of the layout
+    (reference sg2im/layout.py:53,88 call F.grid_sample without it): False = torch >= 1.3, what the
+    reference computes under a current torch; True = torch 0.4, what the authors trained their
+    released checkpoints with (SURVEY.md section 8c caveat i)."""
     super(Sg2ImModel, self).__init__()
     if len(kwargs) > 0:      # reference sg2im/model.py:41-42
       print('WARNING: Model got unexpected kwargs ', kwargs)
     self.vocab = vocab
     self.image_size = image_size
     self.layout_noise_dim = layout_noise_dim
-    self.align_corners = ALIGN_CORNERS
+    self.align_corners = bool(align_corners)
 
     num_objs = len(vocab['object_idx_to_name'])
     num_preds = len(vocab['pred_idx_to_name'])

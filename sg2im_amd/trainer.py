@@ -53,7 +53,7 @@ def _set_requires_grad(module, flag):
 class Trainer(object):
   def __init__(self, vocab, device, generator_kwargs=None, d_obj_kwargs=None, d_img_kwargs=None,
                loss_weights=None, learning_rate=1e-4, world_size=1, seed=None, use_graphs=False,
-               gan_loss_type='gan', overlap_d=None, bucket='auto', max_graphs=32, rank=0):
+               gan_loss_type='gan', overlap_d=None, bucket='auto', max_graphs=32, rank=0, align_corners=False):
     """use_graphs: replay one captured hipGraph per batch-shape BUCKET instead of launching ~480
     kernels from Python.  bucket = (object multiple, triple multiple): the object / triple axes of
     every batch are padded to those multiples with exactly neutral rows (sg2im_amd/bucketing.py);
@@ -72,6 +72,9 @@ class Trainer(object):
     dok.update(d_obj_kwargs or {})
     dik = dict(D_IMG_DEFAULTS)
     dik.update(d_img_kwargs or {})
+    if align_corners:            # torch-0.4 sampling convention for layout + crops (see Sg2ImModel)
+      gk['align_corners'] = True
+      dok['align_corners'] = True
     self.model_kwargs = dict(gk, vocab=vocab)
     self.d_obj_kwargs = dict(dok, vocab=vocab)
     self.d_img_kwargs = dik
@@ -410,7 +413,16 @@ class Trainer(object):
     (static batch, graphs, state dict with the output tensors, launch epoch)."""
     imgs = sb.imgs
     # reduction scratch the crop backward wants: one image-sized plane per (padded) object
-    self._prepare_lanes(max(1 << 24, sb.o_pad * imgs.size(2) * imgs.size(3) * imgs.size(1) + (1 << 20)))
+    if os.environ.get('SG2IM_PROBE_LANES_IN_CAPTURE', '0') != '1':
+      self._prepare_lanes(max(1 << 24, sb.o_pad * imgs.size(2) * imgs.size(3) * imgs.size(1) + (1 << 20)))
+    elif self._cap_stream is None:
+      # tools/graph_fault_probe.py: the round-1 behaviour - work buffers of the capture lanes are
+      # first touched (allocated) INSIDE the capture, i.e. out of the graph's private memory pool
+      self._cap_stream, self._n_side, self._side = torch.cuda.Stream(), 1, (torch.cuda.Stream(),)
+    if os.environ.get('SG2IM_PROBE_EAGER_WARMUP', '0') == '1':      # round 1: two eager steps first
+      for _ in range(2):
+        self._run_segments(sb.tensors(), {'losses': {}, 'ocnt': sb.obj_count, 'tcnt': sb.triple_count},
+                           lambda name, fn: fn())
     st = {'losses': {}, 'ocnt': sb.obj_count, 'tcnt': sb.triple_count}
     static = sb.tensors()
     dp = self.world_size > 1 or self.reducer.force

@@ -6,7 +6,9 @@ Tolerances (fp32 throughout, stated per SURVEY.md section 8c):
   * every floating-point op, forward and backward, whole-tensor error relative to the
     tensor's max magnitude <= REL (1e-4); measured values are <= 1e-5 (profiles/);
   * tensors that are analytically zero (bias gradients of a convolution that feeds a
-    training-mode BatchNorm) are pure rounding noise (~1e-8) on both sides: ABS <= 1e-6.
+    training-mode BatchNorm) are pure rounding noise (~1e-8) on both sides: ABS <= 1e-6 -
+    accepted ONLY when the reference tensor itself is below 1e-6 everywhere, so a small tensor
+    that is simply wrong cannot slip through.
 """
 import os
 
@@ -25,7 +27,7 @@ def _run(section_name):
   torch.cuda.synchronize()
   rows = list(gc.RESULTS)
   assert rows, 'section produced no checks'
-  bad = [r for r in rows if not (r[1] <= REL or r[3] <= ABS)]
+  bad = [r for r in rows if not (r[1] <= REL or (r[3] <= ABS and r[4] < ABS))]
   assert not bad, 'out of tolerance:\n' + '\n'.join('%s rel %.3e (%s)' % r[:3] for r in bad)
   return rows
 
@@ -54,6 +56,12 @@ def test_graph_triple_conv_layer():
 
 def test_layout_and_crops():
   _run('sec_layout')
+
+
+def test_layout_and_crops_align_corners_true():
+  """the torch-0.4 sampling convention (what the reference authors' checkpoints
+  were trained with) - layout forward / d_vecs / d_boxes / d_masks and crop forward / d_imgs"""
+  _run('sec_layout_align_corners')
 
 
 def test_losses_and_adam():
@@ -743,3 +751,71 @@ def test_train_script_runs_in_graph_mode(tmp_path):
   assert stats['replays'] == 8 and stats['captures'] >= 1 and stats['invalidated'] == 0, stats
   ck = torch.load(os.path.join(str(tmp_path), 'checkpoint_with_model.pt'), map_location='cpu', weights_only=False)
   assert ck['counters']['t'] == 8 and 'model_state' in ck and 'd_obj_state' in ck and 'optim_state' in ck
+
+
+@pytest.mark.parametrize('plan', ['0,2', '1,1', '3,3'])
+def test_ping_pong_gemm_kernels_all_geometries(plan):
+  """The 512-thread ping-pong form of the implicit-GEMM kernels (csrc/igemm.h k_pipeline_pp) only
+  takes over launches that fill the chip; here it is forced onto EVERY vectorised launch of the conv
+  / linear sections (SG2IM_PP_MIN=0) for each of its tile shapes - 128x128 with split-K 2, 128x64,
+  64x128 with split-K 3 (SG2IM_FORCE_PLAN) - including odd tile counts (a half without a tile)."""
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, SG2IM_PP='1', SG2IM_PP_MIN='0', SG2IM_PLAN_TUNE='1', SG2IM_FORCE_PLAN=plan)
+  out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'gpu_check.py'), 'sec_conv', 'sec_linear', 'sec_gconv'],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+  assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+  tail = [l for l in out.stdout.splitlines() if l.startswith('====')]
+  assert tail and ' 0 above' in tail[-1], out.stdout[-4000:]
+
+
+def test_config0_figure_6_sheep_through_forward_json():
+  """BASELINE.json configs[0], exactly as the reference's scripts/run_model.py:56-69 drives it: a
+  checkpoint dict {'model_kwargs', 'model_state'} with a vocabulary holding the names of
+  scene_graphs/figure_6_sheep.json (committed copy: tests/golden/figure_6_sheep.json), a random-init
+  64x64 model with the train.py generator defaults, eval(), forward_json on the 7 graphs of the file
+  (O = 42 objects incl. the image nodes, T = 63 triples) - against the oracle, in both bilinear
+  sampling conventions."""
+  import copy
+  import json
+  from oracle import sg2im_oracle as orc
+  from sg2im_amd.model import Sg2ImModel
+  from sg2im_amd.trainer import GENERATOR_DEFAULTS
+  from tests import hip_harness as hh
+  from tests.util import GOLDEN_DIR, max_rel_err
+  dev = hh.dev()
+  graphs = json.load(open(os.path.join(GOLDEN_DIR, 'figure_6_sheep.json')))
+  assert len(graphs) == 7
+  names = ['__image__'] + sorted(set(n for sg in graphs for n in sg['objects']))
+  preds = ['__in_image__'] + sorted(set(r[1] for sg in graphs for r in sg['relationships']))
+  vocab = {'object_idx_to_name': names, 'object_name_to_idx': {n: i for i, n in enumerate(names)},
+           'pred_idx_to_name': preds, 'pred_name_to_idx': {n: i for i, n in enumerate(preds)}}
+  gcfg = dict(GENERATOR_DEFAULTS, vocab=vocab)
+  P = orc.init_generator_params(gcfg, 33, randomize_bn=True)
+  gen = torch.Generator().manual_seed(4)
+  for k in list(P):
+    if 'running_mean' in k:
+      P[k] = 0.2 * torch.randn(P[k].shape, generator=gen)
+    elif 'running_var' in k:
+      P[k] = 0.5 + torch.rand(P[k].shape, generator=gen)
+  last = max(k for k in P if k.startswith('box_net.') and k.endswith('.bias'))
+  P[last.replace('.bias', '.weight')] *= 0.01          # proper predicted boxes (x1 > x0, y1 > y0)
+  P[last] = torch.tensor([0.1, 0.15, 0.7, 0.8])
+  checkpoint = {'model_kwargs': gcfg, 'model_state': P}          # what run_model.py loads (:56-58)
+  noise = torch.randn(len(graphs), 32, 64, 64, generator=gen)
+  for ac in (False, True):
+    model = Sg2ImModel(**dict(checkpoint['model_kwargs'], align_corners=ac))
+    model.load_state_dict(checkpoint['model_state'])
+    model.eval()
+    model.to(dev)
+    objs, triples, o2i = model.encode_scene_graphs(copy.deepcopy(graphs))
+    assert objs.numel() == 42 and triples.size(0) == 63
+    with hh.fixed_noise(noise), torch.no_grad():
+      img, boxes, masks, rel = model.forward_json(copy.deepcopy(graphs))
+    with torch.no_grad():
+      want = orc.generator_forward({k: v.clone() for k, v in P.items()}, gcfg, objs.cpu(), triples.cpu(), o2i.cpu(),
+                                   noise=noise, training=False, align_corners=ac)
+    for name, a, b in (('img', img, want[0]), ('boxes', boxes, want[1]), ('masks', masks, want[2]), ('rel', rel, want[3])):
+      assert a.shape == b.shape, name
+      assert max_rel_err(a.cpu(), b) <= 1e-4, (ac, name, max_rel_err(a.cpu(), b))

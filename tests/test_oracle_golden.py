@@ -152,3 +152,16 @@ def test_eval_mode_generator_matches_reference(name):
       assert_close(got, g, 1e-4, 1e-6, 'grad G.' + k)
   for k, v in fix['state_after_g_forward']['G'].items():
     assert torch.equal(tr.PG[k], v), 'eval mode must not touch ' + k
+
+
+@pytest.mark.parametrize('align_corners', [False, True])
+def test_layout_known_answer_in_both_sampling_conventions(align_corners):
+  """SURVEY.md section 8c known-answer fact (a): boxes_to_layout(ones(1,1), [[.25,.25,.75,.75]], [0], 8)
+  is a 4x4 block of exactly 1.0 centred in an 8x8 zero map - under BOTH F.grid_sample conventions
+  (torch >= 1.3 default and the torch-0.4 one the reference authors trained with)."""
+  from oracle import sg2im_oracle as orc
+  out = orc.boxes_to_layout(torch.ones(1, 1), torch.tensor([[.25, .25, .75, .75]]), torch.zeros(1, dtype=torch.long), 8,
+                            align_corners=align_corners)
+  want = torch.zeros(1, 1, 8, 8)
+  want[0, 0, 2:6, 2:6] = 1.0
+  assert torch.equal(out, want)

@@ -128,3 +128,48 @@ def test_oracle_cnn_forward_matches_reference_for_arch_tokens():
     assert_close(got, want, 2e-5, 2e-5, arch)
     for k, v in ref.state_dict().items():          # running statistics after ONE forward (moved twice in R)
       assert_close(P['cnn.' + k].float(), v.float(), 2e-5, 2e-5, arch + ' ' + k)
+
+
+def test_oracle_align_corners_true_matches_reference_under_torch04_sampling():
+  """The authors trained under torch 0.4, whose F.grid_sample had today's align_corners=True
+  semantics (SURVEY.md section 8c caveat i).  The reference calls F.grid_sample without the argument
+  (sg2im/layout.py:53,88, sg2im/bilinear.py:132); forcing the old semantics into those calls gives the
+  pin for the oracle's ``align_corners=True`` mode: layouts (masks, boxes-only), crops, and their
+  gradients."""
+  _ref()
+  import torch.nn.functional as F
+  import sg2im.layout as ref_layout
+  import sg2im.bilinear as ref_bilinear
+  imgs, objs, boxes, masks, triples, o2i, _ = synthetic_batch(3, seed=12)
+  g = torch.Generator().manual_seed(2)
+  vecs = torch.randn(objs.numel(), 24, generator=g)
+  soft = torch.rand(objs.numel(), 16, 16, generator=g)
+  real = F.grid_sample
+  patched = lambda inp, grid, *a, **k: real(inp, grid, *a, **dict(k, align_corners=True))
+  for mode in (True, False):
+    F.grid_sample = patched if mode else real
+    try:
+      vr, br, mr = vecs.clone().requires_grad_(True), boxes.clone().requires_grad_(True), soft.clone().requires_grad_(True)
+      want_m = ref_layout.masks_to_layout(vr, br, mr, o2i, 32)
+      want_b = ref_layout.boxes_to_layout(vr, br, o2i, 32)
+      ir = imgs.clone().requires_grad_(True)
+      want_c = ref_bilinear.crop_bbox_batch(ir, boxes, o2i, 16)
+      (want_m.sum() * 0.5 + want_b.square().sum() + want_c.square().sum()).backward()
+    finally:
+      F.grid_sample = real
+    vo, bo, mo = vecs.clone().requires_grad_(True), boxes.clone().requires_grad_(True), soft.clone().requires_grad_(True)
+    io_ = imgs.clone().requires_grad_(True)
+    got_m = orc.masks_to_layout(vo, bo, mo, o2i, 32, align_corners=mode)
+    got_b = orc.boxes_to_layout(vo, bo, o2i, 32, align_corners=mode)
+    got_c = orc.crop_bbox_batch(io_, boxes, o2i, 16, align_corners=mode)
+    (got_m.sum() * 0.5 + got_b.square().sum() + got_c.square().sum()).backward()
+    for a, b, name in ((got_m, want_m, 'masks_to_layout'), (got_b, want_b, 'boxes_to_layout'), (got_c, want_c, 'crops'),
+                       (vo.grad, vr.grad, 'd_vecs'), (bo.grad, br.grad, 'd_boxes'), (mo.grad, mr.grad, 'd_masks'),
+                       (io_.grad, ir.grad, 'd_imgs')):
+      assert_close(a, b, 2e-5, 2e-5, '%s (align_corners=%s)' % (name, mode))
+  # the two conventions really differ (an identity-box crop is the identity only under the old one)
+  eye = torch.tensor([[0., 0., 1., 1.]])
+  one = torch.zeros(1, dtype=torch.long)
+  x = torch.randn(1, 3, 8, 8, generator=g)
+  assert torch.allclose(orc.crop_bbox_batch(x, eye, one, 8, align_corners=True), x, atol=1e-6)
+  assert not torch.allclose(orc.crop_bbox_batch(x, eye, one, 8, align_corners=False), x, atol=1e-3)
