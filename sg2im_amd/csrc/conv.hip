@@ -165,6 +165,31 @@ template <int NVA, int NVB> struct RegSet {
   unsigned ma, mb;          // validity bits of the A / B rows
 };
 
+// (Experiment, OFF: pins the use of a prefetched register set BEHIND the point where this is called.
+// The arithmetic of a stage - pending affine, mask selects - is pure and only depends on the loaded
+// registers, so hipcc emits it right behind the loads, interleaved with the MFMA block of the previous
+// chunk, together with an `s_waitcnt vmcnt(2)` in FRONT of that block for loads issued a few
+// instructions earlier (found in the ISA, round 2).  Forcing the consumers behind the MFMA block with
+// an opaque `asm volatile` - so that the loads get a whole MFMA block to land - measured SLOWER:
+// forward 83.1 -> 77.4 TFLOP/s over the layer table, m4.conv0 100.7 -> 93.1
+// (profiles/r2_launder_ab.log): the loader VALU that hipcc had slotted between the MFMAs is worth
+// more than the exposed load latency, which the other resident waves cover.)
+#ifndef SG2IM_LAUNDER
+#define SG2IM_LAUNDER 0
+#endif
+__device__ __forceinline__ void launder4(float4& v) {
+#if SG2IM_LAUNDER
+  asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+#endif
+}
+template <int NVA, int NVB> __device__ __forceinline__ void launder(RegSet<NVA, NVB>& r) {
+  #pragma unroll
+  for (int i = 0; i < NVA; ++i) launder4(r.a[i]);
+  #pragma unroll
+  for (int i = 0; i < NVB; ++i) launder4(r.b[i]);
+  launder4(r.aff.sc); launder4(r.aff.sh);
+}
+
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
@@ -340,6 +365,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(
   };
   auto stage_from = [&](RS& r, int B_) {
     float4 ta[NVA], tb[NVB];
+    launder(r);
     #pragma unroll
     for (int i = 0; i < NVA; ++i) ta[i] = apply_aff(r.a[i], r.aff, (r.ma >> i & 1u) != 0);
     #pragma unroll
@@ -551,6 +577,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kerne
   };
   auto stage_from = [&](RS& r, int B_) {
     float4 ta[NVA], tb[NVB];
+    launder(r);
     #pragma unroll
     for (int i = 0; i < NVA; ++i) ta[i] = (r.ma >> i & 1u) ? r.a[i] : zero4();
     #pragma unroll
@@ -713,6 +740,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_wgrad_kerne
   float4 dbs = zero4();
   auto stage_from = [&](RS& r, int B_, bool live) {
     float4 ta[NVA], tb[NVB];
+    launder(r);
     #pragma unroll
     for (int i = 0; i < NVA; ++i) ta[i] = (r.ma >> i & 1u) ? r.a[i] : zero4();
     if (want_db && live) {
@@ -1205,8 +1233,11 @@ static hipError_t launch_wgrad(WgradParams& p, int ntiles_n, hipStream_t st) {
 }
 
 // Ping-pong form (512-thread workgroups, k_pipeline_pp) for launches that fill the chip anyway:
-// at least g_pp_min 512-thread workgroups per CU after pairing.  SG2IM_PP=0 disables it.
-static const int g_pp = getenv("SG2IM_PP") ? atoi(getenv("SG2IM_PP")) : 1;
+// at least g_pp_min 512-thread workgroups per CU after pairing.  OFF by default (SG2IM_PP=1 enables
+// it): measured SLOWER than the plain form on every layer of the table (forward 82.9 -> 71.6
+// TFLOP/s over the 25 layers, m4.conv0 100.9 -> 96.6; profiles/r2_pingpong_ab.log), i.e. the idle
+// matrix-pipe time is NOT the co-resident waves' loader phases coinciding.
+static const int g_pp = getenv("SG2IM_PP") ? atoi(getenv("SG2IM_PP")) : 0;
 static const double g_pp_min = getenv("SG2IM_PP_MIN") ? atof(getenv("SG2IM_PP_MIN")) : 1.0;
 static bool use_pp(const Plan& pl, long long pair_tiles, long long other_tiles, bool gather) {
   if (!g_pp || gather || pl.tile == 2 || pair_tiles < 2) return false;

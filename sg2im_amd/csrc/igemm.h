@@ -249,6 +249,9 @@ template <int I> struct IC { static constexpr int value = I; };
 #endif
 constexpr int LDS_STAGES = SG2IM_LDS_STAGES;
 
+#ifndef SG2IM_SCHED_FENCE
+#define SG2IM_SCHED_FENCE 0      // (see SG2IM_LAUNDER in conv.hip: measured slower)
+#endif
 #ifndef SG2IM_ABL
 #define SG2IM_ABL 0        // timing-only ablations (1: no loads/stores in the loop, 2: no barriers)
 #endif
@@ -286,6 +289,9 @@ __device__ __forceinline__ void k_pipeline_d1(int it_begin, int it_end, Load loa
       // single LDS image (half the LDS -> twice the resident workgroups): every wave must
       // be done reading chunk i before it is overwritten, hence the second barrier
       mma(0, 0); mma(1, 0);
+#if SG2IM_SCHED_FENCE
+      __builtin_amdgcn_sched_barrier(0);       // (experiment: keep stage(i+1) out of the MFMA block)
+#endif
 #if !(SG2IM_ABL & 2)
       __syncthreads();
 #endif
