@@ -179,6 +179,48 @@ def main():
   elapsed = time.perf_counter() - t0
   stats1 = dict(trainer.graph_stats)
   n_graphs = len(trainer._graphs)
+
+  comm = None
+  if use_dist:
+    # the gradient exchange on its own (the four all-reduces of a step, back to back), and the step
+    # with the collectives muted: exposed = step - step_without_exchange, overlap = 1 - exposed / exchange
+    def timed(fn, n):
+      sync()
+      t = time.perf_counter()
+      for i in range(n):
+        fn(i)
+      sync()
+      dt = time.perf_counter() - t
+      if use_dist:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+      return dt / n * 1e3
+    guard = torch.ones(1, device=device)
+
+    def exchange(_):
+      red = trainer.reducer
+      red.start(trainer.flat_g.grad); red.start(guard)
+      if trainer.flat_di is not None:
+        red.start(trainer.flat_di.grad)
+      if trainer.flat_do is not None:
+        red.start(trainer.flat_do.grad)
+      red.finish()
+    exchange(0)
+    ar_ms = timed(exchange, 10)
+    trainer.reducer.mute = True
+    nocomm_ms = timed(lambda i: trainer.step(batches[i % nb]), max(8, args.steps // 2))
+    trainer.reducer.mute = False
+    step_ms = elapsed / args.steps * 1e3
+    exposed = max(0.0, step_ms - nocomm_ms)
+    payload = 4.0 * (trainer.flat_g.grad.numel() + (trainer.flat_di.grad.numel() if trainer.flat_di is not None else 0) +
+                     (trainer.flat_do.grad.numel() if trainer.flat_do is not None else 0))
+    comm = {'allreduce_ms': round(ar_ms, 3), 'payload_mb': round(payload / 1e6, 1),
+            'allreduce_bus_gb_per_s': round(payload * 2 * (world - 1) / max(world, 1) / (ar_ms * 1e-3) / 1e9, 1) if world > 1 else None,
+            'step_ms_without_exchange': round(nocomm_ms, 3), 'exposed_ms': round(exposed, 3),
+            'overlap_frac': round(min(1.0, max(0.0, 1.0 - exposed / ar_ms)), 3) if ar_ms > 0 else None,
+            'schedule': 'graphs [G fwd+bwd | D_img] -> all-reduce(G, guard, D_img) || graph [D_obj step] -> all-reduce(D_obj) -> graph [3x Adam]'
+                        if trainer_graphs else 'eager segments, exchanges started after each backward'}
   if use_dist:
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -282,10 +324,13 @@ def main():
                                   'recaptures_in_timed_loop': stats1['invalidated'] - stats0['invalidated'],
                                   'replays_in_timed_loop': stats1['replays'] - stats0['replays']},
                  'parallelism': 'dp%d' % world, 'total_loss': round(host_losses['total_loss'], 5),
-                 'launch': ('eager' if not trainer_graphs else 'hipGraph replay (one graph, D steps on a side stream)' if not use_dist
-                            else 'hipGraph replay (iteration graph + eager all-reduces + Adam graph)')},
+                 'launch': ('eager' if not trainer_graphs else
+                            'hipGraph replay, one graph per shape bucket (D steps on a side stream inside the graph)' if not use_dist
+                            else 'hipGraph replay per shape bucket: [G + D_img] graph, all-reduces overlapped with the [D_obj] graph, [Adam] graph')},
       'roofline': roofline, 'cpu_baseline': cpu,
     }
+    if comm is not None:
+      out['gradient_exchange'] = comm
   if use_dist:
     dist.destroy_process_group()
   if rank == 0:

@@ -7,8 +7,13 @@ step needs exactly one SUM all-reduce per network (generator 112.6 MB, D_obj 4.4
 2.6 MB) plus a 1-element reduce of the NaN guard.  The generator's all-reduce is launched
 asynchronously right after its backward pass and only waited for after BOTH discriminator
 passes: those never read the generator's parameters (they consume ``imgs_pred.detach()``),
-so ~4 ms of discriminator compute hides the 112 MB exchange.  The 1/world_size factor is
-folded into the fused Adam kernel (``grad_scale``), not a separate pass over the arena.
+so discriminator compute hides the 112 MB exchange - in graph mode: the D_obj step's graph is
+replayed while the generator / D_img exchanges are in flight (sg2im_amd/trainer.py::_capture).
+The 1/world_size factor is folded into the fused Adam kernel (``grad_scale``), not a separate
+pass over the arena.  Replicas are brought in line by a broadcast of parameters, optimiser
+moments and BatchNorm buffers at construction and after a checkpoint restore
+(Trainer.broadcast_state); BatchNorm statistics stay per replica (the reference's batch-32
+semantics on every rank).
 
 Gradient semantics (tested in tests/test_dp_gloo.py): every rank computes the reference's
 per-shard loss (means over ITS objects / pixels), so the applied gradient is the mean over
@@ -28,6 +33,9 @@ class GradReducer(object):
     self.pending = []
     # force: issue the collectives even in a 1-rank group (exercises the RCCL path on one GPU)
     self.force = force
+    # mute: skip the collectives (while a graph is being captured; bench.py's "step without the
+    # exchange" timing leg)
+    self.mute = False
 
   @property
   def grad_scale(self):
@@ -35,7 +43,7 @@ class GradReducer(object):
 
   def start(self, tensor):
     """begin an all-reduce (SUM) of ``tensor`` in place; returns immediately"""
-    if self.world_size > 1 or self.force:
+    if (self.world_size > 1 or self.force) and not self.mute:
       self.pending.append(dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
   def finish(self):

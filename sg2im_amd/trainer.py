@@ -426,10 +426,17 @@ class Trainer(object):
     st = {'losses': {}, 'ocnt': sb.obj_count, 'tcnt': sb.triple_count}
     static = sb.tensors()
     dp = self.world_size > 1 or self.reducer.force
+    # Data parallel (default, SG2IM_DP_SCHEDULE=1): three graphs with the gradient exchanges started
+    # between them - [generator fwd + bwd, D_img step on the side stream] -> all-reduce(G, guard,
+    # D_img) started -> [D_obj step] replayed while those are in flight -> all-reduce(D_obj) ->
+    # wait -> [3 x Adam].  The 112.6 MB generator exchange hides behind the D_obj step instead of
+    # sitting exposed between the iteration graph and the Adam graph (SG2IM_DP_SCHEDULE=0: that
+    # older form - one overlapped iteration graph, then all four exchanges, then Adam).
+    segmented = dp and os.environ.get('SG2IM_DP_SCHEDULE', '1') == '1'
     torch.cuda.synchronize()
     _lib.CAPTURING = True
     try:
-      if self.overlap_d and os.environ.get('SG2IM_DP_SCHEDULE', '0') != '1':
+      if self.overlap_d and not segmented:
         graphs = self._capture_overlapped(static, st, dp)
       else:
         graphs, pool = {}, [None]
@@ -441,7 +448,11 @@ class Trainer(object):
           if pool[0] is None:
             pool[0] = g.pool()
           graphs[name] = g
-        self._run_segments(static, st, capture)
+        mute, self.reducer.mute = self.reducer.mute, True       # (no collectives while capturing)
+        try:
+          self._run_segments(static, st, capture)
+        finally:
+          self.reducer.mute = mute
     finally:
       _lib.CAPTURING = False
     return (sb, graphs, st, _lib.EAGER_EPOCH)

@@ -256,3 +256,35 @@ def test_bucketing_pads_with_neutral_rows():
   assert torch.equal(a[0], c[0])                               # images: bit-identical
   assert torch.equal(a[1], c[1][:O])                           # boxes of the real objects
   assert torch.equal(a[3], c[3][:T])                           # relationship scores of the real triples
+
+
+def test_dp_reference_with_one_rank_is_the_oracle_step():
+  """tests/dp_reference.dp_step (the CPU reference tests/test_dp_rccl.py checks two GPUs against) with
+  a single rank must be OracleTrainer.step; with two ranks holding the same shard, too (the mean of two
+  identical gradients)."""
+  from tests.dp_reference import dp_step
+  from sg2im_amd.trainer import GENERATOR_DEFAULTS, D_OBJ_DEFAULTS, D_IMG_DEFAULTS
+  vocab = make_vocab(20, 5)
+  gcfg = dict(GENERATOR_DEFAULTS, vocab=vocab, layout_noise_dim=0, image_size=(16, 16), refinement_dims=(32, 16),
+              gconv_num_layers=2, gconv_hidden_dim=32, gconv_dim=16, embedding_dim=16, mask_size=4)
+  docfg = dict(D_OBJ_DEFAULTS, vocab=vocab, arch='C4-8-2,C4-16-2', object_size=16)
+  dicfg = dict(D_IMG_DEFAULTS, arch='C4-8-2,C4-16-2')
+  batch = tuple(synthetic_batch(2, image_size=(16, 16), num_objs=20, num_preds=5, mask_size=4, seed=3)[:6])
+
+  def make():
+    return orc.OracleTrainer(orc.init_generator_params(gcfg, 0, randomize_bn=True),
+                             orc.init_ac_discriminator_params(docfg, 2, randomize_bn=True),
+                             orc.init_patch_discriminator_params(dicfg, 1, randomize_bn=True), gcfg, docfg, dicfg)
+  ref = make()
+  want = ref.step(batch)
+  one = make()
+  got = dp_step([one], [batch])[0]
+  for k, v in want.items():
+    assert abs(got[k] - v) <= 1e-6 * max(1.0, abs(v)), k
+  two = [make(), make()]
+  dp_step(two, [batch, batch])
+  for P, Q, R, S in ((ref.PG, one.PG, two[0].PG, two[1].PG), (ref.PDo, one.PDo, two[0].PDo, two[1].PDo),
+                     (ref.PDi, one.PDi, two[0].PDi, two[1].PDi)):
+    for k in P:
+      assert torch.allclose(P[k], Q[k], atol=1e-7), k
+      assert torch.allclose(P[k], R[k], atol=2e-6) and torch.equal(R[k], S[k]), k
