@@ -219,8 +219,10 @@ def main():
             'allreduce_bus_gb_per_s': round(payload * 2 * (world - 1) / max(world, 1) / (ar_ms * 1e-3) / 1e9, 1) if world > 1 else None,
             'step_ms_without_exchange': round(nocomm_ms, 3), 'exposed_ms': round(exposed, 3),
             'overlap_frac': round(min(1.0, max(0.0, 1.0 - exposed / ar_ms)), 3) if ar_ms > 0 else None,
-            'schedule': 'graphs [G fwd+bwd | D_img] -> all-reduce(G, guard, D_img) || graph [D_obj step] -> all-reduce(D_obj) -> graph [3x Adam]'
-                        if trainer_graphs else 'eager segments, exchanges started after each backward'}
+            'schedule': ('eager segments, exchanges started after each backward' if not trainer_graphs else
+                         'graphs [G fwd+bwd | D_img] -> all-reduce(G, guard, D_img) || graph [D_obj step] -> all-reduce(D_obj) -> graph [3x Adam]'
+                         if os.environ.get('SG2IM_DP_SCHEDULE', '0') == '1' else
+                         'one iteration graph (D steps on a side stream) -> 4 all-reduces (exposed) -> Adam graph')}
   if use_dist:
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -326,7 +328,7 @@ def main():
                  'parallelism': 'dp%d' % world, 'total_loss': round(host_losses['total_loss'], 5),
                  'launch': ('eager' if not trainer_graphs else
                             'hipGraph replay, one graph per shape bucket (D steps on a side stream inside the graph)' if not use_dist
-                            else 'hipGraph replay per shape bucket: [G + D_img] graph, all-reduces overlapped with the [D_obj] graph, [Adam] graph')},
+                            else 'hipGraph replay per shape bucket: iteration graph + all-reduces + Adam graph')},
       'roofline': roofline, 'cpu_baseline': cpu,
     }
     if comm is not None:

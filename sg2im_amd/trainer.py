@@ -426,13 +426,16 @@ class Trainer(object):
     st = {'losses': {}, 'ocnt': sb.obj_count, 'tcnt': sb.triple_count}
     static = sb.tensors()
     dp = self.world_size > 1 or self.reducer.force
-    # Data parallel (default, SG2IM_DP_SCHEDULE=1): three graphs with the gradient exchanges started
-    # between them - [generator fwd + bwd, D_img step on the side stream] -> all-reduce(G, guard,
-    # D_img) started -> [D_obj step] replayed while those are in flight -> all-reduce(D_obj) ->
-    # wait -> [3 x Adam].  The 112.6 MB generator exchange hides behind the D_obj step instead of
-    # sitting exposed between the iteration graph and the Adam graph (SG2IM_DP_SCHEDULE=0: that
-    # older form - one overlapped iteration graph, then all four exchanges, then Adam).
-    segmented = dp and os.environ.get('SG2IM_DP_SCHEDULE', '1') == '1'
+    # Data parallel, two forms:
+    #  SG2IM_DP_SCHEDULE=0 (default): ONE iteration graph (discriminator steps on the side stream next
+    #    to the generator backward, as at N = 1) -> the four all-reduces -> Adam graph.  The exchange
+    #    (119.7 MB) is exposed, but the iteration graph is the short one.
+    #  SG2IM_DP_SCHEDULE=1: [G fwd + bwd | D_img] graph -> all-reduce(G, guard, D_img) started ->
+    #    [D_obj step] graph replayed while they are in flight -> all-reduce(D_obj) -> Adam graph.
+    #    Hides the exchange behind the D_obj step, but that step then no longer runs next to the
+    #    generator backward: measured 11.55 ms/step of compute against 10.4 for the one-graph form on
+    #    one GPU (bench.py --force_dist), i.e. it only wins if the exchange costs > 1.1 ms.
+    segmented = dp and os.environ.get('SG2IM_DP_SCHEDULE', '0') == '1'
     torch.cuda.synchronize()
     _lib.CAPTURING = True
     try:
