@@ -35,6 +35,7 @@ import torch
 import torch.distributed as dist
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: v_mfma_f32_32x32x16_bf16 dense peak (2495 measured)
 
 
 def parse():
@@ -51,6 +52,9 @@ def parse():
   ap.add_argument('--n_batches', type=int, default=16,
                   help='distinct synthetic batches (seeds seed+rank+1000*i) cycled through by the timed loop')
   ap.add_argument('--bucket', default='32,64', help='object,triple padding multiples of the hipGraph shape buckets')
+  ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                  help="'bf16': spatial convolutions on the bf16 matrix cores (bf16-rounded operands, fp32 accumulation, fp32 "
+                       "tensors) - BASELINE configs[2..4]; a SECONDARY line, the headline metric is quoted in fp32")
   ap.add_argument('--style', default='coco', choices=['coco', 'vg'],
                   help="'vg': VG-shape graphs without GT masks (BASELINE configs[2] shape, fp32) instead of the COCO headline workload")
   ap.add_argument('--eval_generator', action='store_true',
@@ -149,7 +153,8 @@ def main():
   batch = batches[0]
   bucket = tuple(int(v) for v in args.bucket.split(','))
   trainer = Trainer(vocab, device, generator_kwargs={'image_size': (S, S)}, world_size=world, seed=1234,
-                    use_graphs=not args.no_graphs, bucket=bucket, rank=rank)
+                    use_graphs=not args.no_graphs, bucket=bucket, rank=rank, compute_dtype=args.dtype)
+  peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == 'bf16' else FP32_MFMA_PEAK_TFLOPS
   # (data parallel: the same overlapped graph without its Adam updates, the four all-reduces issued
   # eagerly, then an Adam graph - DESIGN.md section 6; --no_graphs selects the eager segments)
   trainer_graphs = trainer.use_graphs
@@ -264,16 +269,18 @@ def main():
     launches = sum(v['launches'] for v in summ.values())
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     roofline = {
-      'bound': 'mfma', 'kernel': 'implicit-GEMM family conv_fwd/dgrad/wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32) incl. split-K finish',
-      'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-      'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+      'bound': 'mfma', 'kernel': 'implicit-GEMM family conv_fwd/dgrad/wgrad_kernel (%s) incl. split-K finish' % (
+        'bf16 operands v_mfma_f32_32x32x16_bf16 for the spatial convolutions, fp32 v_mfma_f32_32x32x2_f32 for the linear layers; '
+        'priced against the bf16 peak' if args.dtype == 'bf16' else 'fp32 v_mfma_f32_32x32x2_f32'),
+      'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+      'frac': round(achieved / peak, 4), 'traffic': None,
       'algorithmic_mb_per_step': round(alg_bytes / 1e6, 1),     # every operand read once, every result written once
       'launches_per_step': launches // n_prof, 'gflop_per_step': round(flops / n_prof / 1e9, 1),
       'gflop_per_step_incl_bucket_padding': round(padded_flops / n_prof / 1e9, 1),
       'ms_per_step_in_kernel': round(ms / n_prof, 3),
       'crn_only': (lambda f, m: {'gflop_per_step': round(f / n_prof / 1e9, 1), 'ms_per_step': round(m / n_prof, 3),
                                  'tflops': round(f / (m * 1e-3) / 1e12, 2) if m > 0 else 0.0,
-                                 'frac': round(f / (m * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if m > 0 else 0.0})(
+                                 'frac': round(f / (m * 1e-3) / 1e12 / peak, 4) if m > 0 else 0.0})(
                     alg_crn_flops, sum(v['ms'] for v in crn.values())),
       # second roofline: kernels bound by HBM bandwidth, algorithmic bytes / event time
       'hbm_bound': {k: {'launches_per_step': v['launches'] // n_prof, 'mbytes_per_launch': round(v['flops'] / v['launches'] / 1e6, 2),
@@ -289,7 +296,7 @@ def main():
     # memory-side traffic of the same family cannot be counted from inside this process: it comes from the
     # committed rocprofv3 --pmc passes over this workload (tools/pmc_step.sh -> profiles/r1_pmc_step_traffic.json)
     pmc_path = os.path.join(ROOT, 'profiles', 'r1_pmc_step_traffic.json')
-    if args.style == 'coco' and S == 64 and args.batch_size == 32 and os.path.exists(pmc_path):
+    if args.style == 'coco' and S == 64 and args.batch_size == 32 and args.dtype == 'f32' and os.path.exists(pmc_path):
       pmc = json.load(open(pmc_path))
       per_step = (pmc['fetch_mb_per_step'] + pmc['write_mb_per_step']) * 1e6
       roofline['traffic'] = round(per_step / max(roofline['launches_per_step'], 1))     # bytes per GEMM launch
@@ -312,7 +319,9 @@ def main():
       'metric': 'training images/sec (G+D step)', 'value': round(imgs / elapsed, 2), 'unit': 'images/sec',
       'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
       'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-      'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+      'vs_baseline': None,
+      'dtype': 'f32' if args.dtype == 'f32' else 'bf16 (matrix-core operands of the spatial convolutions; fp32 accumulation, tensors, statistics and Adam)',
+      'data': 'synthetic',
       'config': {'workload': ('COCO-%d synthetic scene graphs (3-8 objects + __image__, <=16 triples per image), '
                               if args.style == 'coco' else 'VG-%d synthetic scene graphs (3-10 objects, no GT masks), ') % S +
                              'batch %d per GPU, full G + D_obj + D_img step with 3x Adam' % args.batch_size +

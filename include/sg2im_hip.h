@@ -65,6 +65,11 @@ typedef struct sg2im_conv_desc {
   int batch, in_h, in_w;    /* logical input size (after upsampling) */
   int out_h, out_w;
   int kh, kw, stride, pad;
+  int compute_dtype;        /* 0: fp32 matrix cores (v_mfma_f32_32x32x2_f32, bit-equal to an fmaf chain);
+                             * 1: operands rounded to bf16 (RNE) on their way into LDS, multiplied with
+                             *    v_mfma_f32_32x32x16_bf16, fp32 accumulate - tensors in memory stay fp32.
+                             *    Taken by vectorisable, gather-free launches (channels % 4 == 0, aligned);
+                             *    the rest silently computes in fp32.  BASELINE.json configs[2..4]. */
 } sg2im_conv_desc;
 
 /* out[pix][co] = leaky_{out_slope}( conv(X, W)[pix][co] + bias[co] ) (+ out if accumulate) */

@@ -106,6 +106,7 @@ __device__ __forceinline__ void locate_chunk(const ConvGeom& g, int ch, int& s, 
 
 #define SG2IM_ZERO_ACC()                                   \
   Frags<BM, BN> frags;                                     \
+  FragsH<BM, BN> fragsh;                                   \
   f32x16 acc[BM / 64][BN / 64];                            \
   _Pragma("unroll") for (int a_ = 0; a_ < BM / 64; ++a_)   \
     _Pragma("unroll") for (int b_ = 0; b_ < BN / 64; ++b_) zero_acc(acc[a_][b_]);
@@ -194,11 +195,12 @@ template <int NVA, int NVB> __device__ __forceinline__ void launder(RegSet<NVA, 
 // forward
 // ---------------------------------------------------------------------------
 // PP: ping-pong form (k_pipeline_pp): 512 threads, the two halves own M tiles 2*blockIdx.y + {0, 1}
-template <int BM, int BN, int VEC, bool GATHER, bool PP = false>
+// H: bf16 operand path (igemm.h): operands rounded to bf16 on their way into LDS, v_mfma_f32_32x32x16_bf16
+template <int BM, int BN, int VEC, bool GATHER, bool PP = false, bool H = false>
 __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(const FwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem_all[];
   constexpr int NVA = BM / 32, NVB = BN / 32;
-  constexpr int AF = LdsTile<BM, false>::FLOATS, BF = LdsTile<BN, false>::FLOATS;
+  constexpr int AF = TileBytes<H, BM, false>::value / 4, BF = TileBytes<H, BN, false>::value / 4;   // (in floats)
   constexpr int STAGE = AF + BF;
   const ConvGeom& g = p.g;
   const int half = PP ? (int)(threadIdx.x >> 8) : 0;
@@ -370,8 +372,13 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(
     for (int i = 0; i < NVA; ++i) ta[i] = apply_aff(r.a[i], r.aff, (r.ma >> i & 1u) != 0);
     #pragma unroll
     for (int i = 0; i < NVB; ++i) tb[i] = (r.mb >> i & 1u) ? r.b[i] : zero4();
-    store_tile<BM, false>(smem + B_ * STAGE, ta, tid);
-    store_tile<BN, false>(smem + B_ * STAGE + AF, tb, tid);
+    if constexpr (H) {
+      store_tile_h<BM, false>(reinterpret_cast<bf16_t*>(smem + B_ * STAGE), ta, tid);
+      store_tile_h<BN, false>(reinterpret_cast<bf16_t*>(smem + B_ * STAGE + AF), tb, tid);
+    } else {
+      store_tile<BM, false>(smem + B_ * STAGE, ta, tid);
+      store_tile<BN, false>(smem + B_ * STAGE + AF, tb, tid);
+    }
   };
 
   SG2IM_ZERO_ACC()
@@ -381,8 +388,14 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(
   auto do_load = [&](int it, auto set) { if constexpr (decltype(set)::value == 0) load_into(it, rs0); else load_into(it, rs1); };
   auto do_stage = [&](auto set, int B_, bool) { if constexpr (decltype(set)::value == 0) stage_from(rs0, B_); else stage_from(rs1, B_); };
   auto do_mma = [&](int phase, int B_) {
-    if (phase == 0) read_frags<BM, BN, false, false>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, frags);
-    else mma_frags<BM, BN>(frags, acc);
+    if constexpr (H) {
+      if (phase == 0) read_frags_h<BM, BN, false, false>(reinterpret_cast<const bf16_t*>(smem + B_ * STAGE),
+                                                         reinterpret_cast<const bf16_t*>(smem + B_ * STAGE + AF), wm0, wn0, lane, fragsh);
+      else mma_frags_h<BM, BN>(fragsh, acc);
+    } else {
+      if (phase == 0) read_frags<BM, BN, false, false>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, frags);
+      else mma_frags<BM, BN>(frags, acc);
+    }
   };
   if constexpr (PP) k_pipeline_pp(half, it_begin, it_end, do_load, do_stage, do_mma);
   else k_pipeline<TilePipe<BM, BN>::DEPTH>(it_begin, it_end, do_load, do_stage, do_mma);
@@ -410,11 +423,11 @@ struct ParityRow {
   }
 };
 
-template <int BM, int BN, int VA, int VB, bool PP = false>
+template <int BM, int BN, int VA, int VB, bool PP = false, bool H = false>
 __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kernel(const DgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem_all[];
   constexpr int NVA = BM / 32, NVB = BN / 32;
-  constexpr int AF = LdsTile<BM, false>::FLOATS, BF = LdsTile<BN, true>::FLOATS;
+  constexpr int AF = TileBytes<H, BM, false>::value / 4, BF = TileBytes<H, BN, true>::value / 4;
   constexpr int STAGE = AF + BF;
   const ConvGeom& g = p.g;
   const int half = PP ? (int)(threadIdx.x >> 8) : 0;
@@ -582,8 +595,13 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kerne
     for (int i = 0; i < NVA; ++i) ta[i] = (r.ma >> i & 1u) ? r.a[i] : zero4();
     #pragma unroll
     for (int i = 0; i < NVB; ++i) tb[i] = (r.mb >> i & 1u) ? r.b[i] : zero4();
-    store_tile<BM, false>(smem + B_ * STAGE, ta, tid);
-    store_tile<BN, true>(smem + B_ * STAGE + AF, tb, tid);
+    if constexpr (H) {
+      store_tile_h<BM, false>(reinterpret_cast<bf16_t*>(smem + B_ * STAGE), ta, tid);
+      store_tile_h<BN, true>(reinterpret_cast<bf16_t*>(smem + B_ * STAGE + AF), tb, tid);
+    } else {
+      store_tile<BM, false>(smem + B_ * STAGE, ta, tid);
+      store_tile<BN, true>(smem + B_ * STAGE + AF, tb, tid);
+    }
   };
 
   SG2IM_ZERO_ACC()
@@ -593,8 +611,14 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kerne
   auto do_load = [&](int it, auto set) { if constexpr (decltype(set)::value == 0) load_into(it, rs0); else load_into(it, rs1); };
   auto do_stage = [&](auto set, int B_, bool) { if constexpr (decltype(set)::value == 0) stage_from(rs0, B_); else stage_from(rs1, B_); };
   auto do_mma = [&](int phase, int B_) {
-    if (phase == 0) read_frags<BM, BN, false, true>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, frags);
-    else mma_frags<BM, BN>(frags, acc);
+    if constexpr (H) {
+      if (phase == 0) read_frags_h<BM, BN, false, true>(reinterpret_cast<const bf16_t*>(smem + B_ * STAGE),
+                                                        reinterpret_cast<const bf16_t*>(smem + B_ * STAGE + AF), wm0, wn0, lane, fragsh);
+      else mma_frags_h<BM, BN>(fragsh, acc);
+    } else {
+      if (phase == 0) read_frags<BM, BN, false, true>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, frags);
+      else mma_frags<BM, BN>(frags, acc);
+    }
   };
   if constexpr (PP) k_pipeline_pp(half, it_begin, it_end, do_load, do_stage, do_mma);
   else k_pipeline<TilePipe<BM, BN>::DEPTH>(it_begin, it_end, do_load, do_stage, do_mma);
@@ -613,11 +637,11 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kerne
 // weight gradient
 // ---------------------------------------------------------------------------
 // PP: the two halves own the column tiles 2*blockIdx.x + {0, 1} of the same row tile / K split
-template <int BM, int BN, int VEC, bool GATHER, bool PP = false>
+template <int BM, int BN, int VEC, bool GATHER, bool PP = false, bool H = false>
 __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_wgrad_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem_all[];
   constexpr int NVA = BM / 32, NVB = BN / 32;
-  constexpr int AF = LdsTile<BM, true>::FLOATS, BF = LdsTile<BN, true>::FLOATS;
+  constexpr int AF = TileBytes<H, BM, true>::value / 4, BF = TileBytes<H, BN, true>::value / 4;
   constexpr int STAGE = AF + BF;
   const ConvGeom& g = p.g;
   const int half = PP ? (int)(threadIdx.x >> 8) : 0;
@@ -752,8 +776,13 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_wgrad_kerne
       if (VEC == 4) tb[i] = apply_aff(r.b[i], baff, (r.mb >> i & 1u) != 0);
       else tb[i] = r.b[i];
     }
-    store_tile<BM, true>(smem + B_ * STAGE, ta, tid);
-    store_tile<BN, true>(smem + B_ * STAGE + AF, tb, tid);
+    if constexpr (H) {
+      store_tile_h<BM, true>(reinterpret_cast<bf16_t*>(smem + B_ * STAGE), ta, tid);
+      store_tile_h<BN, true>(reinterpret_cast<bf16_t*>(smem + B_ * STAGE + AF), tb, tid);
+    } else {
+      store_tile<BM, true>(smem + B_ * STAGE, ta, tid);
+      store_tile<BN, true>(smem + B_ * STAGE + AF, tb, tid);
+    }
   };
 
   SG2IM_ZERO_ACC()
@@ -765,8 +794,14 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_wgrad_kerne
     if constexpr (decltype(set)::value == 0) stage_from(rs0, B_, live); else stage_from(rs1, B_, live);
   };
   auto do_mma = [&](int phase, int B_) {
-    if (phase == 0) read_frags<BM, BN, true, true>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, frags);
-    else mma_frags<BM, BN>(frags, acc);
+    if constexpr (H) {
+      if (phase == 0) read_frags_h<BM, BN, true, true>(reinterpret_cast<const bf16_t*>(smem + B_ * STAGE),
+                                                       reinterpret_cast<const bf16_t*>(smem + B_ * STAGE + AF), wm0, wn0, lane, fragsh);
+      else mma_frags_h<BM, BN>(fragsh, acc);
+    } else {
+      if (phase == 0) read_frags<BM, BN, true, true>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, frags);
+      else mma_frags<BM, BN>(frags, acc);
+    }
   };
   if constexpr (PP) k_pipeline_pp(half, it_begin, it_end, do_load, do_stage, do_mma);
   else k_pipeline<TilePipe<BM, BN>::DEPTH>(it_begin, it_end, do_load, do_stage, do_mma);
@@ -1024,6 +1059,7 @@ static void fill_geom(ConvGeom& g, const sg2im_conv_desc* d) {
 static int check_desc(const sg2im_conv_desc* d) {
   if (!d || d->nsrc < 1 || d->nsrc > 4) return 1;
   if (d->stride < 1 || d->kh < 1 || d->kw < 1) return 1;
+  if (d->compute_dtype != 0 && d->compute_dtype != 1) return 1;
   const int eh = (d->in_h + 2 * d->pad - d->kh) / d->stride + 1;
   const int ew = (d->in_w + 2 * d->pad - d->kw) / d->stride + 1;
   if (eh != d->out_h || ew != d->out_w) return 1;
@@ -1232,6 +1268,32 @@ static hipError_t launch_wgrad(WgradParams& p, int ntiles_n, hipStream_t st) {
   return launch_wgrad_g<BM, BN, VEC, false, PP>(p, ntiles_n, st);
 }
 
+// bf16 operand path (desc->compute_dtype == 1): vectorised, gather-free launches only (spatial convs);
+// everything else stays on the fp32 kernels.  Largest LDS image: 128x128 m-major = 2 x 10 KB.
+template <int BM, int BN>
+static hipError_t launch_fwd_h(FwdParams& p, hipStream_t st) {
+  constexpr size_t lds = TileBytes<true, BM, false>::value + TileBytes<true, BN, false>::value;
+  dim3 grid((p.Cout + BN - 1) / BN, (p.M + BM - 1) / BM, p.e.nsplit);
+  hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, 4, false, false, true>), grid, dim3(NTHREADS), lds, st, p);
+  return hipGetLastError();
+}
+template <int BM, int BN>
+static hipError_t launch_dgrad_h(DgradParams& p, hipStream_t st) {
+  constexpr size_t lds = TileBytes<true, BM, false>::value + TileBytes<true, BN, true>::value;
+  dim3 grid((p.Nc + BN - 1) / BN, (p.M + BM - 1) / BM, p.parity ? 4 * p.e.nsplit : p.e.nsplit);
+  hipLaunchKernelGGL((conv_dgrad_kernel<BM, BN, 4, 4, false, true>), grid, dim3(NTHREADS), lds, st, p);
+  return hipGetLastError();
+}
+template <int BM, int BN>
+static hipError_t launch_wgrad_h(WgradParams& p, int ntiles_n, hipStream_t st) {
+  constexpr size_t lds = TileBytes<true, BM, true>::value + TileBytes<true, BN, true>::value;
+  p.ntiles_n = ntiles_n;
+  p.ntiles_m = (p.Cout + BM - 1) / BM;
+  dim3 grid(p.ntiles_n, p.ntiles_m, p.e.nsplit);
+  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, 4, false, false, true>), grid, dim3(NTHREADS), lds, st, p);
+  return hipGetLastError();
+}
+
 // Ping-pong form (512-thread workgroups, k_pipeline_pp) for launches that fill the chip anyway:
 // at least g_pp_min 512-thread workgroups per CU after pairing.  OFF by default (SG2IM_PP=1 enables
 // it): measured SLOWER than the plain form on every layer of the table (forward 82.9 -> 71.6
@@ -1313,7 +1375,10 @@ int sg2im_conv2d_forward(const sg2im_conv_desc* d, const float* weight, int cout
                             [&](int bn) { return (long long)(cout + bn - 1) / bn; });
   p.e = Epi{out, ld_out, bias, out_slope, accumulate, workspace, pl.nsplit};
   hipError_t err;
-  if (v4 && use_pp(pl, (p.M + pl.bm - 1) / pl.bm, (cout + pl.bn - 1) / pl.bn, any_gather(p.g))) {
+  if (v4 && d->compute_dtype == 1 && !any_gather(p.g)) {
+    err = pl.tile == 0 ? launch_fwd_h<128, 128>(p, stream) : pl.tile == 1 ? launch_fwd_h<128, 64>(p, stream)
+        : pl.tile == 2 ? launch_fwd_h<64, 64>(p, stream) : launch_fwd_h<64, 128>(p, stream);
+  } else if (v4 && use_pp(pl, (p.M + pl.bm - 1) / pl.bm, (cout + pl.bn - 1) / pl.bn, any_gather(p.g))) {
     err = pl.tile == 0 ? launch_fwd<128, 128, 4, true>(p, stream) : pl.tile == 1 ? launch_fwd<128, 64, 4, true>(p, stream)
                        : launch_fwd<64, 128, 4, true>(p, stream);
   } else if (v4) {
@@ -1384,7 +1449,10 @@ int sg2im_conv2d_backward_data(const sg2im_conv_desc* d, const float* weight, in
   }
   p.e = Epi{dx, ld_dx, nullptr, 1.f, accumulate, workspace, pl.nsplit};
   hipError_t err;
-  if (va4 && vb4 && !p.parity &&
+  if (va4 && vb4 && d->compute_dtype == 1) {
+    err = pl.tile == 0 ? launch_dgrad_h<128, 128>(p, stream) : pl.tile == 1 ? launch_dgrad_h<128, 64>(p, stream)
+        : pl.tile == 2 ? launch_dgrad_h<64, 64>(p, stream) : launch_dgrad_h<64, 128>(p, stream);
+  } else if (va4 && vb4 && !p.parity &&
       use_pp(pl, (Mrows + pl.bm - 1) / pl.bm, (c_count + pl.bn - 1) / pl.bn, false)) {
     err = pl.tile == 0 ? launch_dgrad<128, 128, 4, 4, true>(p, stream) : pl.tile == 1 ? launch_dgrad<128, 64, 4, 4, true>(p, stream)
                        : launch_dgrad<64, 128, 4, 4, true>(p, stream);
@@ -1439,7 +1507,12 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
   p.dbias = dbias;
   p.ws_bias = pl.nsplit > 1 ? workspace + (size_t)pl.nsplit * cout * Ntot : nullptr;
   hipError_t err;
-  if (v4 && use_pp(pl, ntiles_n, (cout + pl.bm - 1) / pl.bm, any_gather(p.g))) {
+  if (v4 && d->compute_dtype == 1 && !any_gather(p.g)) {
+    err = pl.tile == 0 ? launch_wgrad_h<128, 128>(p, ntiles_n, stream)
+        : pl.tile == 1 ? launch_wgrad_h<128, 64>(p, ntiles_n, stream)
+        : pl.tile == 2 ? launch_wgrad_h<64, 64>(p, ntiles_n, stream)
+                       : launch_wgrad_h<64, 128>(p, ntiles_n, stream);
+  } else if (v4 && use_pp(pl, ntiles_n, (cout + pl.bm - 1) / pl.bm, any_gather(p.g))) {
     err = pl.tile == 0 ? launch_wgrad<128, 128, 4, true>(p, ntiles_n, stream)
         : pl.tile == 1 ? launch_wgrad<128, 64, 4, true>(p, ntiles_n, stream)
                        : launch_wgrad<64, 128, 4, true>(p, ntiles_n, stream);

@@ -232,6 +232,108 @@ __device__ __forceinline__ void epilogue(const Epi& e, int M, int N, int nlimit,
   }
 }
 
+// ---------------------------------------------------------------------------
+// bf16 operand path (compute_dtype 1): the SAME loaders / staging registers / pipeline, but the
+// operands are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) when they are written to LDS and multiplied
+// with v_mfma_f32_32x32x16_bf16 (fp32 accumulate) - 16x the fp32 matrix rate, half the LDS bytes.
+// Tensors in HBM stay fp32 (activations, gradients, master weights), so BatchNorm statistics, losses
+// and Adam are untouched.  LDS images hold bf16:
+//   m-major  [rows][BK + 8]       80-byte rows: a lane's 8 consecutive k (one MFMA operand) = one
+//                                 ds_read_b128, conflict free (rows 20 banks apart)
+//   k-major  [BK][rows + 32]      read with ds_read_b64_tr_b16 - the hardware 4x16 transpose read
+//                                 (probed: tools/_src/tr_probe.hip): the 16 lanes of a group pass the
+//                                 addresses of 4 rows x 4 four-element pieces and receive 4 consecutive
+//                                 k of ONE column each; two reads give the 8 k of an operand.  Rows
+//                                 (rows+32)*2 B apart -> the 4 rows of a read sit on disjoint banks.
+// Operand layout of the MFMA: lane l: A[i = l & 31][k = 8 (l >> 5) + 0..7], B[k = same][j = l & 31];
+// a BK = 32 chunk is two K = 16 steps.
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16_t;
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int MLDH = BK + 8;         // m-major bf16 row stride (elements)
+constexpr int KPADH = 32;            // k-major bf16 row pad (elements)
+
+template <int ROWS, bool KMAJOR> struct LdsTileH {
+  static constexpr int HALFS = KMAJOR ? BK * (ROWS + KPADH) : ROWS * MLDH;
+};
+
+// LDS bytes of one operand image
+template <bool BF, int ROWS, bool KMAJOR> struct TileBytes {
+  static constexpr int value = BF ? LdsTileH<ROWS, KMAJOR>::HALFS * 2 : LdsTile<ROWS, KMAJOR>::FLOATS * 4;
+};
+
+__device__ __forceinline__ bf16x4 to_bf16x4(const float4& v) {
+  const f32x4v f = {v.x, v.y, v.z, v.w};
+  return __builtin_convertvector(f, bf16x4);
+}
+
+// registers -> LDS, same thread mapping as store_tile, 8 bytes per float4
+template <int ROWS, bool KMAJOR>
+__device__ __forceinline__ void store_tile_h(bf16_t* lds, const float4 (&r)[ROWS / 32], int tid) {
+  constexpr int NV = ROWS / 32;
+  if (!KMAJOR) {
+    const int col4 = tid & 7, r0 = tid >> 3;
+    #pragma unroll
+    for (int i = 0; i < NV; ++i)
+      *reinterpret_cast<bf16x4*>(lds + (r0 + 32 * i) * MLDH + 4 * col4) = to_bf16x4(r[i]);
+  } else {
+    constexpr int Q = ROWS / 4;
+    const int col4 = tid % Q, k0 = tid / Q;
+    #pragma unroll
+    for (int i = 0; i < NV; ++i)
+      *reinterpret_cast<bf16x4*>(lds + (k0 + (1024 / ROWS) * i) * (ROWS + KPADH) + 4 * col4) = to_bf16x4(r[i]);
+  }
+}
+
+template <int BM, int BN> struct FragsH { bf16x8 a[BM / 64][2], b[BN / 64][2]; };
+
+// one operand (8 consecutive k of row/column `rc0 + (lane & 31)`, K step `step`) from a k-major image
+template <int ROWS>
+__device__ __forceinline__ bf16x8 read_tr(const bf16_t* img, int rc0, int step, int lane) {
+  typedef __attribute__((address_space(3))) bf16x4* LdsPtr;
+  const int p = lane & 15, g = lane >> 4;
+  const bf16_t* a = img + (16 * step + 8 * (g >> 1) + (p >> 2)) * (ROWS + KPADH) + rc0 + 16 * (g & 1) + 4 * (p & 3);
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsPtr)a);
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LdsPtr)(a + 4 * (ROWS + KPADH)));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int BM, int BN, bool AK, bool BKM>
+__device__ __forceinline__ void read_frags_h(const bf16_t* __restrict__ As, const bf16_t* __restrict__ Bs,
+                                             int wm0, int wn0, int lane, FragsH<BM, BN>& f) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  const int i = lane & 31, h = lane >> 5;
+  #pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    #pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      if (!AK) f.a[tm][st] = *reinterpret_cast<const bf16x8*>(As + (wm0 + tm * 32 + i) * MLDH + 16 * st + 8 * h);
+      else f.a[tm][st] = read_tr<BM>(As, wm0 + tm * 32, st, lane);
+    }
+    #pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      if (!BKM) f.b[tn][st] = *reinterpret_cast<const bf16x8*>(Bs + (wn0 + tn * 32 + i) * MLDH + 16 * st + 8 * h);
+      else f.b[tn][st] = read_tr<BN>(Bs, wn0 + tn * 32, st, lane);
+    }
+  }
+}
+
+template <int BM, int BN>
+__device__ __forceinline__ void mma_frags_h(const FragsH<BM, BN>& f, f32x16 (&acc)[BM / 64][BN / 64]) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  #pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    #pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      #pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[tm][st], f.b[tn][st], acc[tm][tn], 0, 0, 0);
+    }
+  }
+}
+
 // Software pipeline shared by the three kernels: the global loads of the next K-chunk are kept
 // in flight in registers while the matrix cores work on the chunk staged in LDS.
 //   load(it, set)        : global -> register set     stage(set, buf, live) : registers -> LDS buffer

@@ -168,8 +168,17 @@ def rows_src(t, gather=None):
   return SrcSpec(t, t.size(1), ld, 0, gather)
 
 
-def conv_desc(srcs, batch, in_h, in_w, kh=1, kw=1, stride=1, pad=0):
+# Arithmetic of the SPATIAL convolutions (refinement network, discriminators, mask_net): 0 = fp32
+# matrix cores, 1 = bf16 operands with fp32 accumulation (sg2im_conv_desc.compute_dtype).  Linear
+# layers (row matrices) always compute in fp32.  Set by Trainer(compute_dtype='bf16') around its step.
+CONV_COMPUTE = 0
+
+
+def conv_desc(srcs, batch, in_h, in_w, kh=1, kw=1, stride=1, pad=0, compute=None):
   d = ConvDesc()
+  if compute is None:
+    compute = CONV_COMPUTE if (kh * kw > 1 or in_h * in_w > 1) else 0
+  d.compute_dtype = int(compute)
   d.nsrc = len(srcs)
   for i, s in enumerate(srcs):
     q = d.src[i]

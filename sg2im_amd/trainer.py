@@ -53,7 +53,8 @@ def _set_requires_grad(module, flag):
 class Trainer(object):
   def __init__(self, vocab, device, generator_kwargs=None, d_obj_kwargs=None, d_img_kwargs=None,
                loss_weights=None, learning_rate=1e-4, world_size=1, seed=None, use_graphs=False,
-               gan_loss_type='gan', overlap_d=None, bucket='auto', max_graphs=32, rank=0, align_corners=False):
+               gan_loss_type='gan', overlap_d=None, bucket='auto', max_graphs=32, rank=0, align_corners=False,
+               compute_dtype='f32'):
     """use_graphs: replay one captured hipGraph per batch-shape BUCKET instead of launching ~480
     kernels from Python.  bucket = (object multiple, triple multiple): the object / triple axes of
     every batch are padded to those multiples with exactly neutral rows (sg2im_amd/bucketing.py);
@@ -61,6 +62,13 @@ class Trainer(object):
     eager launches, which then run the same kernels on the same shapes as the graph (bit-identical
     results).  Batches of any (O, T) are accepted either way."""
     self.gan_g_loss, self.gan_d_loss = L.get_gan_losses(gan_loss_type)     # train.py:467
+    # compute_dtype 'bf16' (BASELINE.json configs[2..4]): the spatial convolutions of the refinement
+    # network, the discriminators and mask_net multiply bf16-rounded operands on the bf16 matrix cores
+    # with fp32 accumulation (sg2im_conv_desc.compute_dtype); every tensor in memory - activations,
+    # gradients, master weights, BatchNorm statistics, Adam state - stays fp32
+    if compute_dtype not in ('f32', 'bf16'):
+      raise ValueError('compute_dtype must be "f32" or "bf16"')
+    self.compute_dtype = compute_dtype
     self.device = device
     self.world_size = world_size
     self.rank = rank
@@ -316,6 +324,13 @@ class Trainer(object):
     """batch: (imgs (N,3,H,W), objs, boxes, masks | None, triples, obj_to_img) on the device.
     Returns a dict of 0-dim device tensors (no host sync)."""
     self.t += 1
+    keep, ops.CONV_COMPUTE = ops.CONV_COMPUTE, (1 if self.compute_dtype == 'bf16' else 0)
+    try:
+      return self._step(batch)
+    finally:
+      ops.CONV_COMPUTE = keep
+
+  def _step(self, batch):
     if self.use_graphs:
       if self.bucketer is None:
         self.bucketer = Bucketer(32, 64)

@@ -54,6 +54,28 @@ def test_graph_triple_conv_layer():
   _run('sec_gconv')
 
 
+def test_bf16_operand_conv_kernels_match_bf16_rounded_torch():
+  """compute_dtype 1 (BASELINE.json configs[2..4]): forward / data gradient / weight gradient of every
+  conv geometry with both operands rounded to bf16 and fp32 accumulation, against torch's fp32
+  convolution on bf16-ROUNDED operands - an exact emulation, so the fp32 tolerance applies (covers the
+  m-major ds_read_b128 and the k-major ds_read_b64_tr_b16 operand paths, all four tile shapes through
+  SG2IM_FORCE_PLAN in the next test)."""
+  _run('sec_conv_bf16')
+
+
+@pytest.mark.parametrize('plan', ['0,2', '1,1', '2,3', '3,1'])
+def test_bf16_operand_conv_kernels_every_tile_shape(plan):
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, SG2IM_PLAN_TUNE='1', SG2IM_FORCE_PLAN=plan)
+  out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'gpu_check.py'), 'sec_conv_bf16'],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+  assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+  tail = [l for l in out.stdout.splitlines() if l.startswith('====')]
+  assert tail and ' 0 above' in tail[-1], out.stdout[-4000:]
+
+
 def test_layout_and_crops():
   _run('sec_layout')
 
@@ -819,3 +841,59 @@ def test_config0_figure_6_sheep_through_forward_json():
     for name, a, b in (('img', img, want[0]), ('boxes', boxes, want[1]), ('masks', masks, want[2]), ('rel', rel, want[3])):
       assert a.shape == b.shape, name
       assert max_rel_err(a.cpu(), b) <= 1e-4, (ac, name, max_rel_err(a.cpu(), b))
+
+
+BF16_LOSS_TOL = 3e-2      # losses of a bf16-operand step vs the fp32 oracle (measured: see profiles/r2_bf16_parity.log)
+
+
+@pytest.mark.parametrize('case', ['coco64_b4', 'vg64_b32', 'vg128', 'stretch256'])
+def test_bf16_training_step_within_bf16_bound_of_the_fp32_oracle(case):
+  """a full G + D training iteration with the spatial convolutions on the bf16
+  matrix cores (Trainer(compute_dtype='bf16'): bf16-rounded operands, fp32 accumulation, fp32 tensors /
+  statistics / Adam) against the FP32 oracle under a stated bf16 bound: every loss within 3e-2
+  relative, every parameter within 2 x lr of the oracle's after the Adam updates (Adam moves a
+  parameter by +-lr per step whatever the gradient's magnitude, so sign flips of rounding-size
+  gradients bound the distance) - at the COCO-64 shape, the full VG-64 batch-32 shape of configs[2],
+  the 128x128 and the 256x256 shapes."""
+  from oracle import sg2im_oracle as orc
+  from sg2im_amd.synthetic import make_vocab, synthetic_batch
+  from sg2im_amd.trainer import Trainer, GENERATOR_DEFAULTS, D_OBJ_DEFAULTS, D_IMG_DEFAULTS
+  from tests import hip_harness as hh
+  dev = hh.dev()
+  gk = {'layout_noise_dim': 0}
+  if case == 'coco64_b4':
+    vocab = make_vocab(184, 7)
+    cpu_batch = synthetic_batch(4, seed=51)
+  elif case == 'vg64_b32':
+    vocab = make_vocab(179, 46)
+    cpu_batch = synthetic_batch(32, num_objs=179, num_preds=46, style='vg', min_objs=3, max_objs=10, seed=52)
+  elif case == 'vg128':
+    vocab = make_vocab(179, 46)
+    gk.update(image_size=(128, 128))
+    cpu_batch = synthetic_batch(2, image_size=(128, 128), num_objs=179, num_preds=46, style='vg', min_objs=3, max_objs=10,
+                                seed=53)
+  else:
+    vocab = make_vocab(179, 46)
+    gk.update(image_size=(256, 256))
+    cpu_batch = synthetic_batch(1, image_size=(256, 256), num_objs=179, num_preds=46, style='vg', min_objs=10, max_objs=29,
+                                extra_rels=40, seed=54)
+  (PG, PDo, PDi), otr = _oracle_pair(vocab, gk, {}, 1e-4)
+  tr = Trainer(vocab, dev, seed=0, generator_kwargs=gk, compute_dtype='bf16')
+  hh.load_params(tr.model, PG); hh.load_params(tr.d_obj, PDo); hh.load_params(tr.d_img, PDi)
+  batch = tuple(t.to(dev) if torch.is_tensor(t) else t for t in cpu_batch)
+  got = Trainer.losses_to_host(tr.step(batch))
+  want = otr.step(tuple(cpu_batch[:6]), None)
+  worst = 0.0
+  for k, v in want.items():
+    rel = abs(got[k] - v) / max(1.0, abs(v))
+    worst = max(worst, rel)
+    assert rel <= BF16_LOSS_TOL, (case, k, got[k], v)
+  far = 0.0
+  for name, mod, P in (('G', tr.model, otr.PG), ('Do', tr.d_obj, otr.PDo), ('Di', tr.d_img, otr.PDi)):
+    sd = mod.state_dict()
+    for k, v in P.items():
+      if v.is_floating_point() and 'running_' not in k:
+        d = float((sd[k].detach().cpu() - v.detach()).abs().max())
+        far = max(far, d)
+        assert d <= 2.05e-4, (case, name, k, d)
+  print('bf16 %s: worst loss rel err %.3e, worst parameter distance %.3e' % (case, worst, far))

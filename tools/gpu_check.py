@@ -113,6 +113,75 @@ def conv_case(name, N, H, W, C0, C1, up1, Cout, k, stride, pad, bnact=False, see
     report(name + ' dgrad1', got, ref)
 
 
+def conv_case_bf16(name, N, H, W, C0, C1, up1, Cout, k, stride, pad, bnact=False, seed=0):
+  """compute_dtype 1: the kernels round both operands to bf16 and accumulate in fp32; the reference
+  does the same with torch (operands through .bfloat16().float(), fp32 convolution), so the two
+  agree to fp32 summation-order accuracy - an exact emulation, op by op."""
+  g = torch.Generator().manual_seed(seed)
+  rb = lambda t: t.bfloat16().float()
+  x0 = torch.randn(N, C0, H, W, generator=g)
+  xs = [x0]
+  if C1:
+    h1, w1 = (H // 2, W // 2) if up1 else (H, W)
+    xs.append(torch.randn(N, C1, h1, w1, generator=g))
+  Ct = C0 + C1
+  Wt = torch.randn(Cout, Ct, k, k, generator=g) / (Ct * k * k) ** 0.5
+  b = torch.randn(Cout, generator=g)
+  sc = sh = None
+  parts = [xs[0]]
+  if bnact:
+    sc = torch.rand(C0, generator=g) + 0.5
+    sh = torch.randn(C0, generator=g) * 0.3
+    parts[0] = F.leaky_relu(xs[0] * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), 0.2)
+  if C1:
+    parts.append(F.interpolate(xs[1], scale_factor=2, mode='nearest') if up1 else xs[1])
+  xcat = torch.cat(parts, 1)
+  xb = rb(xcat)
+  Wb = rb(Wt)
+  y = F.conv2d(xb, Wb, b, stride=stride, padding=pad)
+  gy = torch.randn(y.shape, generator=g)
+  gyb = rb(gy)
+  xr = xcat.clone().requires_grad_(True)
+  dx_ref = torch.autograd.grad(F.conv2d(xr, Wb, None, stride=stride, padding=pad), xr, gyb)[0]
+  Wr = Wt.clone().requires_grad_(True)
+  dw_ref = torch.autograd.grad(F.conv2d(xb, Wr, None, stride=stride, padding=pad), Wr, gyb)[0]
+  nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(D)
+  srcs = [ops.nhwc_src(nhwc(xs[0]), 0, sc.to(D) if bnact else None, sh.to(D) if bnact else None, 0.2 if bnact else 1.0)]
+  if C1:
+    srcs.append(ops.nhwc_src(nhwc(xs[1]), 1 if up1 else 0))
+  d = ops.conv_desc(srcs, N, H, W, k, k, stride, pad, compute=1)
+  Wp = Wt.permute(0, 2, 3, 1).contiguous().to(D)
+  out = torch.empty(N, d.out_h, d.out_w, Cout, device=D)
+  ops.conv2d_forward(d, Wp, Cout, b.to(D), out, Cout)
+  report(name + ' bf16 fwd', out.permute(0, 3, 1, 2), y)
+  gyd = nhwc(gy)
+  dw = torch.empty(Cout, k, k, Ct, device=D)
+  db = torch.empty(Cout, device=D)
+  ops.conv2d_backward_weight(d, gyd, Cout, Cout, dw, dbias=db)
+  report(name + ' bf16 wgrad', dw.permute(0, 3, 1, 2), dw_ref)
+  report(name + ' bf16 bias grad (fp32 sums)', db, gy.sum((0, 2, 3)))
+  if not bnact:
+    dx0 = torch.empty(N, H, W, C0, device=D)
+    ops.conv2d_backward_data(d, Wp, Cout, gyd, Cout, 0, C0, dx0, C0)
+    report(name + ' bf16 dgrad0', dx0.permute(0, 3, 1, 2), dx_ref[:, :C0])
+  if C1:
+    dx1 = torch.empty(N, H, W, C1, device=D)
+    ops.conv2d_backward_data(d, Wp, Cout, gyd, Cout, C0, C1, dx1, C1)
+    report(name + ' bf16 dgrad1', dx1.permute(0, 3, 1, 2), dx_ref[:, C0:])
+
+
+def sec_conv_bf16():
+  conv_case_bf16('conv3x3 64->64 16x16 (tile64)', 2, 16, 16, 64, 0, 0, 64, 3, 1, 1)
+  conv_case_bf16('conv3x3 160+128up->128 16x16', 4, 16, 16, 160, 128, 1, 128, 3, 1, 1)
+  conv_case_bf16('conv3x3 bnact 128->256 8x8 splitK', 4, 8, 8, 128, 0, 0, 256, 3, 1, 1, bnact=True)
+  conv_case_bf16('conv3x3 32->64 64x64 (128x64 tile)', 4, 64, 64, 32, 0, 0, 64, 3, 1, 1)
+  conv_case_bf16('conv3x3 96->192 32x32 (128x128 tile)', 8, 32, 32, 96, 0, 0, 192, 3, 1, 1)
+  conv_case_bf16('conv4x4s2 64->128 valid 31x31 (parity dgrad)', 4, 31, 31, 64, 0, 0, 128, 4, 2, 0)
+  conv_case_bf16('conv4x4s2 128->256 valid 14x14', 4, 14, 14, 128, 0, 0, 256, 4, 2, 0)
+  conv_case_bf16('conv3x3 1184->512 8x8 (m1.conv0 shape)', 4, 8, 8, 160, 1024, 1, 512, 3, 1, 1)
+  conv_case_bf16('conv3x3 36->20 pad1 9x11 (ragged tiles)', 3, 9, 11, 36, 0, 0, 20, 3, 1, 1)
+
+
 def sec_conv():
   conv_case('conv3x3 64->64 16x16 (tile64)', 2, 16, 16, 64, 0, 0, 64, 3, 1, 1)
   conv_case('conv3x3 160+128up->128 16x16', 4, 16, 16, 160, 128, 1, 128, 3, 1, 1)
@@ -464,7 +533,7 @@ def sec_golden_vg():
 if __name__ == '__main__':
   print(torch.cuda.get_device_name(0))
   only = sys.argv[1:]
-  for fn in (sec_pool, sec_linear, sec_conv, sec_gconv, sec_layout, sec_layout_align_corners, sec_losses, sec_golden_coco, sec_golden_vg, sec_golden_eval, sec_golden_nonorm, sec_golden_mlpbn, sec_golden_instnorm, sec_golden_archtokens):
+  for fn in (sec_pool, sec_linear, sec_conv, sec_conv_bf16, sec_gconv, sec_layout, sec_layout_align_corners, sec_losses, sec_golden_coco, sec_golden_vg, sec_golden_eval, sec_golden_nonorm, sec_golden_mlpbn, sec_golden_instnorm, sec_golden_archtokens):
     if not only or fn.__name__ in only:
       section(fn)
   bad = [r for r in RESULTS if not (r[1] <= 1e-4 or (r[3] <= 1e-6 and r[4] < 1e-6))]
