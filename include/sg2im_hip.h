@@ -102,9 +102,12 @@ int sg2im_column_sum(const float* x, long long rows, int cols, long long ld, flo
  * entries in [n_a, n_a+n_b) from keys_b (entry id n_a + index).  Row j lists its entry ids
  * in increasing order, i.e. all keys_a hits in index order, then all keys_b hits - the
  * accumulation order of the reference's two scatter_add calls (graph.py:98-99).
- * row_ptr: int[n_rows+1]; entries: int[n_a+n_b]; scratch: int[n_rows + n_a + n_b]. */
+ * row_ptr: int[n_rows+1]; entries: int[n_a+n_b]; scratch: int[n_rows + n_a + n_b].
+ * live_keys (device, may be NULL): only the first live_keys[0] keys of EACH key array take part - the
+ * rest is the padding of a bucketed batch (see sg2im_bn_stats); entries[] is then only filled up to
+ * row_ptr[n_rows]. */
 int sg2im_csr_build(const long long* keys_a, int n_a, const long long* keys_b, int n_b, int n_rows,
-                    int* row_ptr, int* entries, int* scratch, hipStream_t stream);
+                    int* row_ptr, int* entries, int* scratch, const int* live_keys, hipStream_t stream);
 /* out[j][0:width] = sum over row j's entries, in CSR order, starting from +0.0f, of
  *   src_a[e*ld_a + 0:width]            (e <  n_a)
  *   src_b[(e-n_a)*ld_b + 0:width]      (e >= n_a)

@@ -39,7 +39,7 @@ _SIGNATURES = {
   'sg2im_conv2d_backward_data': [_D, _P, _I, _P, _I, _I, _I, _P, _L, _I, _P, _Z, _P],
   'sg2im_conv2d_backward_weight': [_D, _P, _I, _I, _P, _P, _I, _P, _Z, _P],
   'sg2im_column_sum': [_P, _L, _I, _L, _P, _I, _P, _P],
-  'sg2im_csr_build': [_P, _I, _P, _I, _I, _P, _P, _P, _P],
+  'sg2im_csr_build': [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P],
   'sg2im_segment_sum': [_P, _L, _I, _P, _L, _P, _P, _I, _I, _I, _I, _P, _L, _P],
   'sg2im_gather_rows': [_P, _L, _P, _I, _I, _P, _P, _L, _P],
   'sg2im_copy_2d': [_P, _L, _P, _L, _L, _I, _P],

@@ -14,11 +14,20 @@
 
 namespace sg2im {
 
+// `live` (optional, device): only the first live[0] keys of EACH key array are real - the rest is the
+// padding of a bucketed batch (sg2im_amd/bucketing.py) and takes no part in the CSR, so no row grows
+// a long tail of padding entries.
+__device__ __forceinline__ bool csr_entry_live(int e, int na, const int* __restrict__ live) {
+  if (!live) return true;
+  return (e < na ? e : e - na) < live[0];
+}
+
 __global__ void csr_count_kernel(const long long* __restrict__ ka, int na, const long long* __restrict__ kb,
-                                 int nb, int* __restrict__ counts) {
+                                 int nb, int* __restrict__ counts, const int* __restrict__ live) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= na + nb || !csr_entry_live(e, na, live)) return;
   if (e < na) atomicAdd(&counts[(int)ka[e]], 1);
-  else if (e < na + nb) atomicAdd(&counts[(int)kb[e - na]], 1);
+  else atomicAdd(&counts[(int)kb[e - na]], 1);
 }
 
 // exclusive scan of counts[0..n) -> row_ptr[0..n], single workgroup, then reset counts to 0
@@ -53,9 +62,9 @@ __global__ void csr_scan_kernel(int* __restrict__ counts, int n, int* __restrict
 
 __global__ void csr_fill_kernel(const long long* __restrict__ ka, int na, const long long* __restrict__ kb,
                                 int nb, const int* __restrict__ row_ptr, int* __restrict__ cursor,
-                                int* __restrict__ tmp) {
+                                int* __restrict__ tmp, const int* __restrict__ live) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= na + nb) return;
+  if (e >= na + nb || !csr_entry_live(e, na, live)) return;
   const int key = (int)(e < na ? ka[e] : kb[e - na]);
   const int pos = atomicAdd(&cursor[key], 1);
   tmp[row_ptr[key] + pos] = e;
@@ -157,7 +166,7 @@ extern "C" {
 int sg2im_abi_version(void) { return 2; }
 
 int sg2im_csr_build(const long long* keys_a, int n_a, const long long* keys_b, int n_b, int n_rows,
-                    int* row_ptr, int* entries, int* scratch, hipStream_t stream) {
+                    int* row_ptr, int* entries, int* scratch, const int* live_keys, hipStream_t stream) {
   if (n_a < 0 || n_b < 0 || n_rows < 1 || !row_ptr || !scratch || (n_a && !keys_a) || (n_b && !keys_b))
     return SG2IM_ERR_ARG;
   const int n = n_a + n_b;
@@ -166,12 +175,12 @@ int sg2im_csr_build(const long long* keys_a, int n_a, const long long* keys_b, i
   if (hipMemsetAsync(counts, 0, sizeof(int) * n_rows, stream) != hipSuccess) return SG2IM_ERR_HIP;
   if (n > 0) {
     if (!entries) return SG2IM_ERR_ARG;
-    hipLaunchKernelGGL(csr_count_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, keys_a, n_a, keys_b, n_b, counts);
+    hipLaunchKernelGGL(csr_count_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, keys_a, n_a, keys_b, n_b, counts, live_keys);
   }
   hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, n_rows, row_ptr);
   if (n > 0) {
     hipLaunchKernelGGL(csr_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, keys_a, n_a, keys_b, n_b,
-                       row_ptr, counts, tmp);
+                       row_ptr, counts, tmp, live_keys);
     hipLaunchKernelGGL(csr_ranksort_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream, row_ptr, tmp, n_rows, entries);
   }
   return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;

@@ -223,6 +223,25 @@ __global__ void affine_act_kernel(const float* __restrict__ x, long long ld_x, l
   }
 }
 
+// float4 form (C, ld_x, ld_out multiples of 4, 16-byte aligned): the materialisation pass of the
+// refinement network's activations when the direct-to-LDS convolution loop (igemm2.h) is on
+__global__ void affine_act_v4_kernel(const float* __restrict__ x, long long ld_x, long long rows, int C,
+                                     const float* __restrict__ scale, const float* __restrict__ shift, float slope,
+                                     float* __restrict__ out, long long ld_out) {
+  const int CQ = C >> 2;
+  const long long total = rows * CQ;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / CQ; const int c = 4 * (int)(i - r * CQ);
+    const float4 v = *reinterpret_cast<const float4*>(x + r * ld_x + c);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+    float4 o;
+    o.x = leakyf(fmaf(v.x, sc.x, sh.x), slope); o.y = leakyf(fmaf(v.y, sc.y, sh.y), slope);
+    o.z = leakyf(fmaf(v.z, sc.z, sh.z), slope); o.w = leakyf(fmaf(v.w, sc.w, sh.w), slope);
+    *reinterpret_cast<float4*>(out + r * ld_out + c) = o;
+  }
+}
+
 // ---- InstanceNorm2d (affine=False, no running statistics; reference sg2im/layers.py:27-28) ----
 // One workgroup owns the (image n, 64-channel block) slice of an NHWC tensor: kInRows row lanes x
 // 64 channel lanes, partial sums combined through LDS in a fixed order (deterministic).
@@ -767,8 +786,12 @@ int sg2im_affine_act_forward(const float* x, long long ld_x, long long rows, int
                              hipStream_t stream) {
   if (!x || !scale || !shift || !out || channels < 1 || rows < 0) return SG2IM_ERR_ARG;
   if (rows == 0) return SG2IM_OK;
-  hipLaunchKernelGGL(affine_act_kernel, dim3(ew_blocks(rows * channels)), dim3(256), 0, stream, x, ld_x, rows, channels,
-                     scale, shift, slope, out, ld_out);
+  if (channels % 4 == 0 && ld_x % 4 == 0 && ld_out % 4 == 0 && al16(x) && al16(out) && al16(scale) && al16(shift))
+    hipLaunchKernelGGL(affine_act_v4_kernel, dim3(ew_blocks(rows * channels / 4)), dim3(256), 0, stream, x, ld_x, rows,
+                       channels, scale, shift, slope, out, ld_out);
+  else
+    hipLaunchKernelGGL(affine_act_kernel, dim3(ew_blocks(rows * channels)), dim3(256), 0, stream, x, ld_x, rows, channels,
+                       scale, shift, slope, out, ld_out);
   return ok_or(hipGetLastError());
 }
 

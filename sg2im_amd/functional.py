@@ -599,6 +599,16 @@ class RefinementFn(Function):
     for i in range(1, L):
       pyr.append(ops.avgpool_forward(pyr[-1], 2, _new(layout, N, H >> i, W >> i, Cl)))
     pyr = pyr[::-1]
+    # (bf16 operands: the first-generation loader rounds while it stages, keep the pending form there)
+    mat = ops.V2_MATERIALIZE and ops.CONV_COMPUTE == 0
+
+    def activated(y, st, up):
+      """the source the next convolution reads: leaky(bn(y)), materialised or pending in its loader"""
+      if not mat:
+        return nhwc_src(y, up, st.scale, st.shift, slope)
+      a = _new(layout, *y.shape)
+      ops.affine_act_forward(y.view(-1, y.size(3)), st, slope, a.view(-1, y.size(3)))
+      return nhwc_src(a, up)
     for i in range(L):
       h, w = H >> (L - 1 - i), W >> (L - 1 - i)
       lay = pyr[i]
@@ -608,14 +618,17 @@ class RefinementFn(Function):
       d0 = conv_desc([nhwc_src(lay), feat_src], N, h, w, 3, 3, 1, 1)
       y0 = ops.conv2d_forward(d0, _cl_weight(W0p), C, b0, _new(layout, N, h, w, C), C)
       st0 = ops.bn_stats(y0, N * h * w, C, C, bn0, training, BN_EPS, BN_MOMENTUM)
-      d1 = conv_desc([nhwc_src(y0, 0, st0.scale, st0.shift, slope)], N, h, w, 3, 3, 1, 1)
+      src0 = activated(y0, st0, 0)
+      d1 = conv_desc([src0], N, h, w, 3, 3, 1, 1)
       y1 = ops.conv2d_forward(d1, _cl_weight(W1p), C, b1, _new(layout, N, h, w, C), C)
       st1 = ops.bn_stats(y1, N * h * w, C, C, bn1, training, BN_EPS, BN_MOMENTUM)
-      saved.append((lay, feat_src, y0, st0, y1, st1, h, w, C))
-      feat_src = nhwc_src(y1, 1, st1.scale, st1.shift, slope)
+      saved.append((lay, feat_src, y0, st0, y1, st1, h, w, C, src0))
+      feat_src = activated(y1, st1, 1)
     last = saved[-1]
     Cf = last[8]
-    do0 = conv_desc([nhwc_src(last[4], 0, last[5].scale, last[5].shift, slope)], N, H, W, 3, 3, 1, 1)
+    # (the last module's activated output at full resolution: the same tensor `feat_src` holds, not upsampled)
+    do0 = conv_desc([ops.SrcSpec(feat_src.t, feat_src.channels, feat_src.ld, 0, None, feat_src.scale, feat_src.shift,
+                                 feat_src.slope)], N, H, W, 3, 3, 1, 1)
     z = ops.conv2d_forward(do0, _cl_weight(Wo0), Wo0.size(0), bo0, _new(layout, N, H, W, Wo0.size(0)),
                            Wo0.size(0), slope)
     do2 = conv_desc([nhwc_src(z)], N, H, W, 1, 1, 1, 0)
@@ -674,14 +687,14 @@ class RefinementFn(Function):
     for i in range(L - 1, -1, -1):
       if ops.TAIL_EVENT is not None and i == ops.TAIL_EVENT_AT:
         ops.TAIL_EVENT.record()          # Trainer: from this module on the kernels are small
-      lay, feat_src, y0, st0, y1, st1, h, w, C = saved[i]
+      lay, feat_src, y0, st0, y1, st1, h, w, C, src0 = saved[i]
       W0p, b0, W1p, b1 = convp[4 * i:4 * i + 4]
       g0, be0, g1, be1 = bnp[4 * i:4 * i + 4]
       k = 4 * L + 4 + 4 * i
       dg1, db1n, acc1, grads[k + 2], grads[k + 3] = _bn_grad_bufs(g, C, g1, be1, ni[k + 2], ni[k + 3])
       dy1 = ops.bn_act_backward(_fptr(gz), gz.size(3), pool2, N, h, w, y1, C, C, g1, st1, slope, training,
                                 _new(g, N, h, w, C), dg1, db1n, acc1)
-      d1 = conv_desc([nhwc_src(y0, 0, st0.scale, st0.shift, slope)], N, h, w, 3, 3, 1, 1)
+      d1 = conv_desc([src0], N, h, w, 3, 3, 1, 1)
       gz0 = _new(g, N, h, w, C)
       side.barrier()
       ops.conv2d_backward_data(d1, _cl_weight(W1p), C, dy1, C, 0, C, gz0, C)

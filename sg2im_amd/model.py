@@ -75,7 +75,7 @@ class Sg2ImModel(nn.Module):
     return HF.MaskNetFn.apply(obj_vecs, bns, self.training, obj_count, *params)
 
   def forward_nhwc(self, objs, triples, obj_to_img=None, boxes_gt=None, masks_gt=None, num_images=None,
-                   obj_count=None):
+                   obj_count=None, triple_count=None):
     """Same computation as ``forward`` (reference sg2im/model.py:108-171) but the image
     is returned NHWC, the internal layout of the kernels.  ``num_images`` avoids the host
     sync of reference sg2im/layout.py:143 (N = obj_to_img.max()+1).  ``obj_count``: (int32 device
@@ -88,7 +88,8 @@ class Sg2ImModel(nn.Module):
     if obj_to_img is None:
       obj_to_img = torch.zeros(O, dtype=objs.dtype, device=objs.device)
       num_images = 1
-    edges = (s, o, ops.Csr(s, o, O))
+    # (padded batch: the padding triples stay out of the pooling CSR - no long tail row on the dummy object)
+    edges = (s, o, ops.Csr(s, o, O, live=triple_count))
 
     obj_vecs = HF.Embedding.apply(self.obj_embeddings.weight, objs)
     obj_vecs_orig = obj_vecs

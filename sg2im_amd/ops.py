@@ -168,6 +168,12 @@ def rows_src(t, gather=None):
   return SrcSpec(t, t.size(1), ld, 0, gather)
 
 
+# Refinement network with SG2IM_V2=1: MATERIALISE the activated tensors (BatchNorm + LeakyReLU applied by
+# one elementwise pass) instead of folding them into the next convolution's loader, so that its stride-1
+# convolutions qualify for the direct-to-LDS loop (csrc/igemm2.h), which needs plain sources.  Off by
+# default: measured even with the first-generation loop on the whole step (see conv.hip).
+V2_MATERIALIZE = os.environ.get('SG2IM_V2', '0') == '1'
+
 # Arithmetic of the SPATIAL convolutions (refinement network, discriminators, mask_net): 0 = fp32
 # matrix cores, 1 = bf16 operands with fp32 accumulation (sg2im_conv_desc.compute_dtype).  Linear
 # layers (row matrices) always compute in fp32.  Set by Trainer(compute_dtype='bf16') around its step.
@@ -298,7 +304,9 @@ class Csr(object):
   """Stable CSR over destination rows (see sg2im_csr_build)."""
   __slots__ = ('row_ptr', 'entries', 'n_a', 'n_b', 'n_rows')
 
-  def __init__(self, keys_a, keys_b, n_rows):
+  def __init__(self, keys_a, keys_b, n_rows, live=None):
+    """live: None or (int32 device scalar, 1) - only that many leading keys of each array are real
+    (padded batches, sg2im_amd/bucketing.py)"""
     dev = keys_a.device
     self.n_a = keys_a.numel()
     self.n_b = keys_b.numel() if keys_b is not None else 0
@@ -308,7 +316,7 @@ class Csr(object):
     self.entries = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     tmp = torch.empty(self.n_rows + max(n, 1), dtype=torch.int32, device=dev)
     call('sg2im_csr_build', _i64(keys_a), self.n_a, _i64(keys_b), self.n_b, self.n_rows, _i32(self.row_ptr),
-         _i32(self.entries), _i32(tmp), _stream())
+         _i32(self.entries), _i32(tmp), _count_args(live)[0], _stream())
 
 
 def segment_sum(src_a, src_b, csr, width, average, out, accumulate=False):

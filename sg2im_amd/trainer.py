@@ -164,7 +164,8 @@ class Trainer(object):
     imgs, objs, boxes, masks, triples, obj_to_img = batch[:6]
     st['imgs_nhwc'] = HF.NchwToNhwc.apply(imgs)
     st['gen_out'] = self.model.forward_nhwc(objs, triples, obj_to_img, boxes_gt=boxes, masks_gt=masks,
-                                            num_images=imgs.size(0), obj_count=st.get('ocnt'))
+                                            num_images=imgs.size(0), obj_count=st.get('ocnt'),
+                                            triple_count=st.get('tcnt'))
     st['imgs_fake'] = st['gen_out'][0].detach()
 
   def _seg_generator_losses(self, batch, st):

@@ -843,14 +843,14 @@ def test_config0_figure_6_sheep_through_forward_json():
       assert max_rel_err(a.cpu(), b) <= 1e-4, (ac, name, max_rel_err(a.cpu(), b))
 
 
-BF16_LOSS_TOL = 3e-2      # losses of a bf16-operand step vs the fp32 oracle (measured: see profiles/r2_bf16_parity.log)
+BF16_LOSS_TOL = 5e-3      # losses of a bf16-operand step vs the fp32 oracle (measured 2.5e-4 .. 6.8e-4: profiles/r2_bf16_step_parity.log)
 
 
 @pytest.mark.parametrize('case', ['coco64_b4', 'vg64_b32', 'vg128', 'stretch256'])
 def test_bf16_training_step_within_bf16_bound_of_the_fp32_oracle(case):
   """a full G + D training iteration with the spatial convolutions on the bf16
   matrix cores (Trainer(compute_dtype='bf16'): bf16-rounded operands, fp32 accumulation, fp32 tensors /
-  statistics / Adam) against the FP32 oracle under a stated bf16 bound: every loss within 3e-2
+  statistics / Adam) against the FP32 oracle under a stated bf16 bound: every loss within 5e-3
   relative, every parameter within 2 x lr of the oracle's after the Adam updates (Adam moves a
   parameter by +-lr per step whatever the gradient's magnitude, so sign flips of rounding-size
   gradients bound the distance) - at the COCO-64 shape, the full VG-64 batch-32 shape of configs[2],
@@ -897,3 +897,20 @@ def test_bf16_training_step_within_bf16_bound_of_the_fp32_oracle(case):
         far = max(far, d)
         assert d <= 2.05e-4, (case, name, k, d)
   print('bf16 %s: worst loss rel err %.3e, worst parameter distance %.3e' % (case, worst, far))
+
+
+@pytest.mark.parametrize('v2', ['0', '1'])
+def test_conv_sections_with_and_without_the_direct_to_lds_loop(v2):
+  """csrc/igemm2.h (operands global -> LDS directly, swizzled unpadded LDS image, out-of-image rows
+  zero-filled by the buffer bounds check) takes the stride-1 convolutions on plain sources; here it is
+  forced onto every qualifying launch however small (SG2IM_V2_MIN=0), resp. switched off, and the
+  conv / linear / golden sections must pass either way."""
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, SG2IM_V2=v2, SG2IM_V2_MIN='0')
+  out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'gpu_check.py'), 'sec_conv', 'sec_linear', 'sec_golden_coco',
+                        'sec_golden_vg', 'sec_golden_eval'], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+  assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+  tail = [l for l in out.stdout.splitlines() if l.startswith('====')]
+  assert tail and ' 0 above' in tail[-1], out.stdout[-4000:]

@@ -197,6 +197,12 @@ def sec_conv():
   conv_case('conv1x1 64->3 32x32', 2, 32, 32, 64, 0, 0, 3, 1, 1, 0)
   conv_case('conv1x1 128->1 16x16', 8, 16, 16, 128, 0, 0, 1, 1, 1, 0)
   conv_case('conv3x3 1184->512 8x8 (m1.conv0 shape)', 4, 8, 8, 160, 1024, 1, 512, 3, 1, 1)
+  # shapes that take the direct-to-LDS loop (csrc/igemm2.h): plain sources, stride 1, channels % 32 == 0
+  conv_case('v2 conv3x3 160+128up->64 32x32 (256x64 tile)', 16, 32, 32, 160, 128, 1, 64, 3, 1, 1)
+  conv_case('v2 conv3x3 160+512up->256 16x16 (split-K)', 8, 16, 16, 160, 512, 1, 256, 3, 1, 1)
+  conv_case('v2 conv3x3 96->80 19x21 (ragged rows / columns)', 5, 19, 21, 96, 0, 0, 80, 3, 1, 1)
+  conv_case('v2 conv5x5 64->96 24x24 pad2', 6, 24, 24, 64, 0, 0, 96, 5, 1, 2)
+  conv_case('v2 conv1x1 128->128 32x32', 8, 32, 32, 128, 0, 0, 128, 1, 1, 0)
 
 
 def sec_linear():
