@@ -295,12 +295,14 @@ def main():
     }
     # memory-side traffic of the same family cannot be counted from inside this process: it comes from the
     # committed rocprofv3 --pmc passes over this workload (tools/pmc_step.sh -> profiles/r1_pmc_step_traffic.json)
-    pmc_path = os.path.join(ROOT, 'profiles', 'r1_pmc_step_traffic.json')
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_step_traffic.json')))
+    pmc_path = cands[-1] if cands else ''                      # the latest round's measurement
     if args.style == 'coco' and S == 64 and args.batch_size == 32 and args.dtype == 'f32' and os.path.exists(pmc_path):
       pmc = json.load(open(pmc_path))
       per_step = (pmc['fetch_mb_per_step'] + pmc['write_mb_per_step']) * 1e6
       roofline['traffic'] = round(per_step / max(roofline['launches_per_step'], 1))     # bytes per GEMM launch
-      roofline['traffic_detail'] = {'source': 'profiles/r1_pmc_step_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+      roofline['traffic_detail'] = {'source': 'profiles/' + os.path.basename(pmc_path) + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
                                               'separate passes, FETCH_SIZE x2 per the gfx950 note; counts L2 misses, '
                                               'most of which the 256 MB Infinity Cache serves)',
                                     'fetch_mb_per_step': pmc['fetch_mb_per_step'], 'write_mb_per_step': pmc['write_mb_per_step'],

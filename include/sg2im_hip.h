@@ -90,7 +90,7 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* desc, const float* dy, i
                                  float* dweight, float* dbias, int accumulate, float* workspace,
                                  size_t workspace_bytes, hipStream_t stream);
 /* out[n] = sum_m x[m][n] (+ out): bias gradients (autograd of Conv2d/Linear bias) */
-/* partial: scratch float[2 * cols * 256] */
+/* partial: scratch float[2 * cols * 1024] */
 int sg2im_column_sum(const float* x, long long rows, int cols, long long ld, float* out,
                      int accumulate, float* partial, hipStream_t stream);
 
@@ -179,7 +179,7 @@ int sg2im_crop_backward(const float* d_crops, int n_images, int height, int widt
  * with `momentum` like nn.BatchNorm2d.  training == 0: running stats are used instead.
  * unbiased_rows (0 = rows): sample count used for the unbiased running_var factor - mask_net
  * normalises a x2-upsampled tensor (model.py:98-99) whose statistics equal the source's.
- * partial: scratch float[2 * C * 256].
+ * partial: scratch float[2 * C * 1024].
  * count / count_unit (count may be NULL = every row is real): a padded row batch - only the first
  * count[0] * count_unit rows are real, the statistics run over those (sg2im_amd/bucketing.py: object /
  * triple axes padded to a bucket size so one captured hipGraph serves every batch of the bucket; the
@@ -194,7 +194,7 @@ int sg2im_bn_stats(const float* x, long long rows, int channels, long long ld, c
  *   pool2 != 0, as the 2x2 sum of g laid out [batch][2h][2w][ld_g] (nearest-upsample backward).
  *   outputs: dy [rows][C] dense, dgamma[C], dbeta[C] (+= if accumulate).
  *   training == 0 -> statistics are constants (eval-mode BN).
- *   partial: scratch float[2 * C * 256 + 3 * C].
+ *   partial: scratch float[2 * C * 1024 + 3 * C].
  *   count / count_unit: as for sg2im_bn_stats; padding rows get dy = 0. */
 int sg2im_bn_act_backward(const float* g, long long ld_g, int pool2, int batch, int h, int w,
                           const float* y, long long ld_y, int channels, const float* gamma,

@@ -9,7 +9,10 @@
 
 namespace sg2im {
 
-constexpr int RED_BLOCKS = 256;   // row blocks of the two-stage per-channel reductions
+#ifndef SG2IM_RED_BLOCKS
+#define SG2IM_RED_BLOCKS 256
+#endif
+constexpr int RED_BLOCKS = SG2IM_RED_BLOCKS;   // row blocks of the two-stage per-channel reductions (callers size `partial` for 1024)
 
 __device__ __forceinline__ float leakyf(float v, float slope) { return v > 0.f ? v : v * slope; }
 

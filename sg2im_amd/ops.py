@@ -291,7 +291,7 @@ def conv2d_backward_weight(desc, dy, ld_dy, cout, dweight, accumulate=False, dbi
 
 
 def column_sum(x_ptr, rows, cols, ld, out, accumulate=False):
-  part = scratch(out.device, 2 * cols * 256)
+  part = scratch(out.device, 2 * cols * 1024)
   call('sg2im_column_sum', x_ptr, int(rows), int(cols), int(ld), _f(out), int(accumulate), _f(part), _stream())
   return out
 
@@ -431,7 +431,7 @@ def bn_stats(x, rows, C, ld, bn, training, eps=1e-5, momentum=0.1, unbiased_rows
   """x: any float tensor viewed as [rows][ld]; bn: a module holding weight/bias/running_*."""
   st = BnState(C, x.device)
   cp, cu = _count_args(count)
-  part = scratch(x.device, 2 * C * 256)
+  part = scratch(x.device, 2 * C * 1024)
   nbt = bn.num_batches_tracked
   call('sg2im_bn_stats', _f(x), int(rows), int(C), int(ld), _f(bn.weight), _f(bn.bias), float(eps),
        float(momentum), int(training), _f(bn.running_mean), _f(bn.running_var),
@@ -442,7 +442,7 @@ def bn_stats(x, rows, C, ld, bn, training, eps=1e-5, momentum=0.1, unbiased_rows
 
 def bn_act_backward(g, ld_g, pool2, batch, h, w, y, ld_y, C, gamma, st, slope, training, dy, dgamma, dbeta,
                     accumulate=False, count=None):
-  part = scratch(y.device, 2 * C * 256 + 3 * C)
+  part = scratch(y.device, 2 * C * 1024 + 3 * C)
   cp, cu = _count_args(count)
   call('sg2im_bn_act_backward', g, int(ld_g), int(pool2), int(batch), int(h), int(w), _f(y), int(ld_y), int(C),
        _f(gamma), _f(st.mean), _f(st.invstd), _f(st.scale), _f(st.shift), float(slope), int(training), _f(dy),

@@ -364,7 +364,7 @@ def test_step_is_bit_reproducible():
       assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize('case', ['vg64', 'vg128_deeper_crn', 'stretch256', 'vg64_no_normalization'])
+@pytest.mark.parametrize('case', ['vg64', 'vg64_batch32', 'vg128_deeper_crn', 'stretch256', 'vg64_no_normalization'])
 def test_other_baseline_shapes_match_oracle(case):
   """BASELINE.json configs[2..4] as fp32 parity cases (one full iteration against the oracle):
   VG-shape graphs without GT masks (mask_net trains through the layout), the 128x128 config with
@@ -377,6 +377,8 @@ def test_other_baseline_shapes_match_oracle(case):
   vocab = make_vocab(179, 46)
   if case == 'vg64':
     S, bs, gk, bk = 64, 4, {}, dict(min_objs=3, max_objs=10)
+  elif case == 'vg64_batch32':                 # configs[2] at its per-GPU batch (global 256 = 8 x 32)
+    S, bs, gk, bk = 64, 32, {}, dict(min_objs=3, max_objs=10)
   elif case == 'vg64_no_normalization':        # --normalization none
     S, bs, gk, bk = 64, 3, dict(normalization='none'), dict(min_objs=3, max_objs=10)
   elif case == 'vg128_deeper_crn':
