@@ -6,4 +6,4 @@ reference's Python class API: ``Sg2ImModel``, ``PatchDiscriminator``,
 and state_dict keys.  There is no CPU fallback: the modules need a GPU and the built
 ``libsg2im_hip.so`` (``python -m sg2im_amd.build``)."""
 
-__version__ = '0.1.0'
+__version__ = '0.2.0'

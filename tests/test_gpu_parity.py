@@ -916,3 +916,34 @@ def test_conv_sections_with_and_without_the_direct_to_lds_loop(v2):
   assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
   tail = [l for l in out.stdout.splitlines() if l.startswith('====')]
   assert tail and ' 0 above' in tail[-1], out.stdout[-4000:]
+
+
+def test_padded_batch_without_any_triples_or_with_isolated_objects():
+  """Edge cases of the bucket padding (sg2im_amd/bucketing.py) against the oracle on the unpadded batch:
+  a batch whose images have no relationships at all (T = 0: the padded triple axis then holds ONLY
+  dummies, the pooling CSR has no live key) and a batch with objects that appear in no triple."""
+  from sg2im_amd.synthetic import make_vocab, synthetic_batch
+  from sg2im_amd.trainer import Trainer
+  from tests import hip_harness as hh
+  dev = hh.dev()
+  vocab = make_vocab(184, 7)
+  gk = {'layout_noise_dim': 0}
+  base = synthetic_batch(3, seed=61)
+  imgs, objs, boxes, masks, triples, o2i, t2i = base
+  empty = (imgs, objs, boxes, masks, triples[:0].clone(), o2i, t2i[:0].clone())
+  keep = triples[:, 1] != 0                                  # drop every __in_image__ triple: image nodes isolated
+  sparse = (imgs, objs, boxes, masks, triples[keep][::2].clone(), o2i, t2i[keep][::2].clone())
+  for name, cpu_batch in (('no triples', empty), ('isolated objects', sparse)):
+    (PG, PDo, PDi), otr = _oracle_pair(vocab, gk, {}, 1e-4)
+    tr = Trainer(vocab, dev, seed=0, generator_kwargs=gk, bucket=(16, 32))
+    hh.load_params(tr.model, PG); hh.load_params(tr.d_obj, PDo); hh.load_params(tr.d_img, PDi)
+    batch = tuple(t.to(dev) if torch.is_tensor(t) else t for t in cpu_batch)
+    got = Trainer.losses_to_host(tr.step(batch))
+    want = otr.step(tuple(cpu_batch[:6]), None)
+    for k, v in want.items():
+      assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (name, k, got[k], v)
+    sd = tr.model.state_dict()
+    for k, v in otr.PG.items():
+      if v.is_floating_point() and 'running_' not in k:
+        d = float((sd[k].detach().cpu() - v.detach()).abs().max())
+        assert d <= 2.05e-4, (name, k, d)
