@@ -399,7 +399,13 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(
     }
   };
   if constexpr (PP) k_pipeline_pp(half, it_begin, it_end, do_load, do_stage, do_mma);
-  else k_pipeline<TilePipe<BM, BN>::DEPTH>(it_begin, it_end, do_load, do_stage, do_mma);
+  else {
+    // (paired loop only: an all-zero LDS image)
+    auto do_zfill = [&](int B_) {
+      for (int q = tid; q < STAGE / 4; q += NTHREADS) reinterpret_cast<float4*>(smem + B_ * STAGE)[q] = zero4();
+    };
+    k_pipeline<TilePipe<BM, BN>::DEPTH>(it_begin, it_end, do_load, do_stage, do_mma, do_zfill);
+  }
   epilogue<BM, BN>(p.e, p.M, p.Cout, p.Cout, m0, n0, wm0, wn0, lane, split, acc);
 }
 
@@ -622,7 +628,13 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kerne
     }
   };
   if constexpr (PP) k_pipeline_pp(half, it_begin, it_end, do_load, do_stage, do_mma);
-  else k_pipeline<TilePipe<BM, BN>::DEPTH>(it_begin, it_end, do_load, do_stage, do_mma);
+  else {
+    // (paired loop only: an all-zero LDS image)
+    auto do_zfill = [&](int B_) {
+      for (int q = tid; q < STAGE / 4; q += NTHREADS) reinterpret_cast<float4*>(smem + B_ * STAGE)[q] = zero4();
+    };
+    k_pipeline<TilePipe<BM, BN>::DEPTH>(it_begin, it_end, do_load, do_stage, do_mma, do_zfill);
+  }
   if (p.parity) {
     // split-K slabs of the parity form: [split][class][p.M rows][Nc], finished (and mapped to the
     // interleaved destination rows) by splitk_finish_parity_kernel
@@ -805,7 +817,13 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_wgrad_kerne
     }
   };
   if constexpr (PP) k_pipeline_pp(half, it_begin, it_end, do_load, do_stage, do_mma);
-  else k_pipeline<TilePipe<BM, BN>::DEPTH>(it_begin, it_end, do_load, do_stage, do_mma);
+  else {
+    // (paired loop only: an all-zero LDS image)
+    auto do_zfill = [&](int B_) {
+      for (int q = tid; q < STAGE / 4; q += NTHREADS) reinterpret_cast<float4*>(smem + B_ * STAGE)[q] = zero4();
+    };
+    k_pipeline<TilePipe<BM, BN>::DEPTH>(it_begin, it_end, do_load, do_stage, do_mma, do_zfill);
+  }
   epilogue<BM, BN>(p.e, p.Cout, Ntot, Ntot, m0, n0, wm0, wn0, lane, split, acc);
   // (workgroup-uniform condition: in the ping-pong form both halves must reach the barrier below)
   if (p.dbias != nullptr && blockIdx.x == 0) {

@@ -492,18 +492,67 @@ __device__ __forceinline__ void k_pipeline_pp(int half, int it_begin, int it_end
   if (!half) __syncthreads();                       // (same barrier count as half 1)
 }
 
+// Paired variant: TWO K chunks per barrier interval (an effective K step of 64 with the BK = 32
+// loaders, LDS images and fragment reads): chunks 2i / 2i+1 sit in LDS images 0 / 1, their
+// successors in register sets 0 / 1.  Per pair: one load block, 2 x (fragment reads + MFMA block),
+// barrier, two stages, barrier - half the barriers and half the store -> barrier -> read latency
+// chains per MFMA of the depth-1 loop, for twice its LDS and staging registers.  An odd chunk
+// count is padded with an all-zero LDS image in FRONT (zfill(1) - one wasted MFMA block per
+// workgroup) so that the MFMA blocks exist only inside the loop body: a second call site makes
+// hipcc give each copy its own accumulator registers.
+template <typename Load, typename Stage, typename Mma, typename Zfill>
+__device__ __forceinline__ void k_pipeline_x2(int it_begin, int it_end, Load load, Stage stage, Mma mma, Zfill zfill) {
+  const int n = it_end - it_begin;
+  if (n <= 0) return;
+  int pos = it_begin;
+  load(pos, IC<0>());
+  stage(IC<0>(), 0, true);
+  if (n & 1) {
+    zfill(1);
+    pos += 1;
+  } else {
+    load(pos + 1, IC<1>());
+    stage(IC<1>(), 1, true);
+    pos += 2;
+  }
+  __syncthreads();
+  const int pairs = (n + 1) >> 1;
+  #pragma unroll 1
+  for (int i = 0; i < pairs; ++i, pos += 2) {
+    // (after the last pair: the final chunk is fetched and staged twice more, copies that are never
+    // read - the loaders' cursors do not advance past index it_end - 1)
+    const bool more = pos < it_end;
+    load(more ? pos : it_end - 1, IC<0>()); load(more ? pos + 1 : it_end - 1, IC<1>());
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0, 0); mma(1, 0);
+    mma(0, 1); mma(1, 1);
+    __syncthreads();
+    stage(IC<0>(), 0, more); stage(IC<1>(), 1, more);
+    __syncthreads();
+  }
+}
+
 // PD = 1: single LDS image / one register set (large tiles, occupancy bound)
 // PD = 2: double LDS image / two register sets (small tiles, latency bound)
-template <int PD, typename Load, typename Stage, typename Mma>
-__device__ __forceinline__ void k_pipeline(int it_begin, int it_end, Load load, Stage stage, Mma mma) {
-  if constexpr (PD == 2) k_pipeline_d2(it_begin, it_end, load, stage, mma);
+// PD = 3: paired chunks (k_pipeline_x2)
+template <int PD, typename Load, typename Stage, typename Mma, typename Zfill>
+__device__ __forceinline__ void k_pipeline(int it_begin, int it_end, Load load, Stage stage, Mma mma, Zfill zfill) {
+  if constexpr (PD == 3) k_pipeline_x2(it_begin, it_end, load, stage, mma, zfill);
+  else if constexpr (PD == 2) k_pipeline_d2(it_begin, it_end, load, stage, mma);
   else k_pipeline_d1(it_begin, it_end, load, stage, mma);
 }
 
+#ifndef SG2IM_X2
+#define SG2IM_X2 0         // bit 0: 128x128, bit 1: 128x64 / 64x128, bit 2: 64x64 tiles use the paired loop
+// (measured, profiles/r2_paired_chunk_ab.log: 128x128 forward +2 %, weight gradient -2 %, 128x64 tiles
+// -5 % - the lost resident workgroup costs what the saved barriers gain; step 10.29 -> 10.34 / 10.6 ms. OFF.)
+#endif
 // pipeline depth / LDS images per tile shape
 template <int BM, int BN> struct TilePipe {
-  static constexpr int DEPTH = (BM * BN <= 64 * 64) ? SG2IM_SMALL_TILE_DEPTH : 1;
-  static constexpr int LDS_IMAGES = DEPTH == 2 ? 2 : LDS_STAGES;
+  static constexpr bool X2 = (BM * BN == 128 * 128) ? (SG2IM_X2 & 1) != 0
+                           : (BM * BN == 128 * 64) ? (SG2IM_X2 & 2) != 0 : (SG2IM_X2 & 4) != 0;
+  static constexpr int DEPTH = X2 ? 3 : (BM * BN <= 64 * 64) ? SG2IM_SMALL_TILE_DEPTH : 1;
+  static constexpr int LDS_IMAGES = DEPTH >= 2 ? 2 : LDS_STAGES;
 };
 
 // wave placement inside the block tile: 2 x 2 wavefronts
