@@ -70,7 +70,14 @@ typedef struct sg2im_conv_desc {
                              *    v_mfma_f32_32x32x16_bf16, fp32 accumulate - tensors in memory stay fp32.
                              *    Taken by vectorisable, gather-free launches (channels % 4 == 0, aligned);
                              *    the rest silently computes in fp32.  BASELINE.json configs[2..4]. */
+  int launch_hints;         /* bit 0 (SG2IM_HINT_BACKGROUND), honoured by sg2im_conv2d_backward_weight: the launch
+                             * is a leaf that runs next to latency-critical small kernels of another stream
+                             * (sg2im_amd/trainer.py releases the refinement network's weight gradients under the
+                             * layout / mask / graph-convolution backward chain) - its large-tile kernels then
+                             * keep at most two workgroups resident per CU (padded LDS request) so that the other
+                             * stream's workgroups always find a free slot.  Results are unaffected. */
 } sg2im_conv_desc;
+#define SG2IM_HINT_BACKGROUND 1
 
 /* out[pix][co] = leaky_{out_slope}( conv(X, W)[pix][co] + bias[co] ) (+ out if accumulate) */
 int sg2im_conv2d_forward(const sg2im_conv_desc* desc, const float* weight, int cout,

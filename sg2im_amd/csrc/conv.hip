@@ -59,6 +59,7 @@ struct WgradParams {
   Epi e;
   float* dbias;     // optional [Cout]: column sums of dY, produced by the column-tile-0 workgroups
   float* ws_bias;   // split-K partials of dbias: [nsplit][Cout] behind the dW partials
+  int background;   // host side only: sg2im_conv_desc.launch_hints & SG2IM_HINT_BACKGROUND
 };
 
 // ---------------------------------------------------------------------------
@@ -1037,6 +1038,10 @@ __global__ void splitk_finish_parity_kernel(const float* __restrict__ ws, int ns
 static int g_num_cu = 256;
 static const bool g_plan_debug = getenv("SG2IM_PLAN_DEBUG") != nullptr;   // print the launch plans
 static const size_t g_lds_floor = getenv("SG2IM_LDS_FLOOR") ? (size_t)atol(getenv("SG2IM_LDS_FLOOR")) : 0;
+// LDS request of a "background" weight gradient (sg2im_conv_desc.launch_hints bit 0): 56 KB = at most two
+// workgroups per CU.  [measured, profiles/r2_deferred_wgrad_ab.log: 3 resident (no padding) 9.88, 2 resident
+// 9.74, 1 resident (84 KB) 10.0 ms per training step]
+static const size_t g_bg_lds = getenv("SG2IM_BG_LDS") ? (size_t)atol(getenv("SG2IM_BG_LDS")) : 56 * 1024;
 static const int g_min_iters = getenv("SG2IM_MIN_ITERS") ? atoi(getenv("SG2IM_MIN_ITERS")) : 0;   // experiments
 static const bool g_plan_tune = getenv("SG2IM_PLAN_TUNE") != nullptr;     // honour SG2IM_FORCE_PLAN
 
@@ -1238,7 +1243,8 @@ template <int BM, int BN, int VA, int VB, bool PP = false> static hipError_t pre
 }
 template <int BM, int BN, int VEC, bool GATHER, bool PP = false> static hipError_t prepare_wgrad() {
   if (g_wgrad_ready<BM, BN, VEC, GATHER, PP>) return hipSuccess;
-  const hipError_t e = ensure_lds(conv_wgrad_kernel<BM, BN, VEC, GATHER, PP>, (PP ? 2 : 1) * wgrad_lds<BM, BN>());
+  const hipError_t e = ensure_lds(conv_wgrad_kernel<BM, BN, VEC, GATHER, PP>,
+                                  std::max((PP ? 2 : 1) * wgrad_lds<BM, BN>(), g_bg_lds));
   if (e == hipSuccess) g_wgrad_ready<BM, BN, VEC, GATHER, PP> = true;
   return e;
 }
@@ -1279,7 +1285,10 @@ static hipError_t launch_wgrad_g(WgradParams& p, int ntiles_n, hipStream_t st) {
   p.ntiles_n = ntiles_n;
   p.ntiles_m = (p.Cout + BM - 1) / BM;
   dim3 grid(PP ? (p.ntiles_n + 1) / 2 : p.ntiles_n, p.ntiles_m, p.e.nsplit);
-  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, VEC, GATHER, PP>), grid, dim3(PP ? 2 * NTHREADS : NTHREADS), lds, st, p);
+  // background launch: cap the resident workgroups per CU of the large-tile kernels so that small kernels of
+  // a concurrent stream always find a free slot
+  const size_t lds_req = (p.background && BM * BN > 64 * 64) ? std::max(lds, g_bg_lds) : lds;
+  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, VEC, GATHER, PP>), grid, dim3(PP ? 2 * NTHREADS : NTHREADS), lds_req, st, p);
   return hipGetLastError();
 }
 
@@ -1311,7 +1320,8 @@ static hipError_t launch_wgrad_h(WgradParams& p, int ntiles_n, hipStream_t st) {
   p.ntiles_n = ntiles_n;
   p.ntiles_m = (p.Cout + BM - 1) / BM;
   dim3 grid(p.ntiles_n, p.ntiles_m, p.e.nsplit);
-  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, 4, false, false, true>), grid, dim3(NTHREADS), lds, st, p);
+  const size_t lds_req = (p.background && BM * BN > 64 * 64) ? std::max(lds, std::min<size_t>(g_bg_lds, 64 * 1024)) : lds;
+  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, 4, false, false, true>), grid, dim3(NTHREADS), lds_req, st, p);
   return hipGetLastError();
 }
 
@@ -1637,6 +1647,7 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
   WgradParams p;
   fill_geom(p.g, d);
   p.dY = dy; p.ldy = ld_dy; p.Cout = cout;
+  p.background = d->launch_hints & SG2IM_HINT_BACKGROUND;
   p.P = d->batch * d->out_h * d->out_w;
   const int taps = d->kh * d->kw;
   const int Ntot = taps * p.g.Ctot;

@@ -665,7 +665,12 @@ class RefinementFn(Function):
     # (otherwise their results would be allocated on that stream and handed to autograd from it)
     side = ops.SideLane(g.device)
     side.on = side.on and all(_sink(p) is not None for p in params[:4 * L + 4])
+    deferred = side.on and ops.DEFERRED is not None       # (Trainer: released at the end of the dgrad chain)
     def wgrad(desc, dy, cout, shape, need_w, need_b, Wp, bp):
+      if deferred:
+        desc.launch_hints |= ops.HINT_BACKGROUND
+        side.defer(lambda: _conv_param_grads(desc, dy, cout, shape, need_w, need_b, Wp, bp), dy, desc)
+        return None, None
       return side.run(lambda: _conv_param_grads(desc, dy, cout, shape, need_w, need_b, Wp, bp), dy, desc)
     # Order per layer: data gradient (big, alone on the GPU), then its weight gradient on the side
     # stream underneath the small kernels that lead to the next data gradient, which waits for it.
@@ -721,12 +726,16 @@ class RefinementFn(Function):
                                               ni[4 * i + 1] and not training, W0p, b0)
       if training:
         grads[4 * i + 1] = _shadowed_bias_grad(b0, ni[4 * i + 1])
+    if deferred:
+      side.flush()
+      ops.DEFERRED.append(side)                    # (joined by the Trainer before the optimiser step)
     dlayout = None
     if need_layout:
       dlayout = _new(g, N, H, W, Cl) if Cg == Cl else torch.zeros(N, H, W, Cl, dtype=torch.float32, device=g.device)
       ops.pyramid_backward([t for t, _ in dlevels], [f for _, f in dlevels], [Cg] * len(dlevels), N, H, W, Cg,
                            dlayout)
-    side.join()
+    if not deferred:
+      side.join()
     ctx.saved = None
     return (dlayout, None, None, None, None) + tuple(grads)
 

@@ -211,7 +211,14 @@ class Trainer(object):
 
   def _seg_generator_backward(self, st):
     self.opt_g.zero_grad()
-    st.pop('total').backward(ops.unit(self.device))
+    defer = ops.DEFER_WGRAD and torch.cuda.is_current_stream_capturing()
+    ops.DEFERRED = [] if defer else None
+    try:
+      st.pop('total').backward(ops.unit(self.device))
+    finally:
+      lanes, ops.DEFERRED = ops.DEFERRED, None
+    for lane in lanes or ():
+      lane.join()
 
   def _seg_d_obj(self, batch, st):
     self._seg_d_obj_forward(batch, st)
@@ -497,7 +504,7 @@ class Trainer(object):
     with torch.cuda.graph(g, stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
       main = torch.cuda.current_stream()
       side = self._side[0]
-      mode = os.environ.get('SG2IM_SCHEDULE', '2')
+      mode = os.environ.get('SG2IM_SCHEDULE', '0')
       self._seg_generator_forward(static, st)
 
       def on_side(lane, seg, wait_ev=None):
@@ -507,14 +514,15 @@ class Trainer(object):
           side.wait_stream(main)
         with torch.cuda.stream(side):
           seg(static, st)
-      # Schedule (measured; SG2IM_SCHEDULE selects the variants that were
-      # compared): right after the generator forward the side stream runs the D_img step next to the
-      # refinement network's backward; the D_obj step is held back until the generator backward
-      # reaches the layout, where it runs next to the small layout / graph-convolution backward
-      # kernels.  0: both steps at once, 10.65 ms; 1: D_obj first / D_img at the tail, 10.39;
-      # 2: this one, 10.33; 3: as 2 but the D_obj forward passes early, 10.42.  (Forking already at
-      # imgs_pred, with the side stream's BatchNorm running-statistics updates deferred to keep
-      # the reference's order, was also tried: 10.29 - not worth the machinery.)
+      # Schedule (measured; SG2IM_SCHEDULE selects the variants that were compared).
+      # The generator backward is: the refinement network's data-gradient chain (big kernels), then the
+      # layout / mask / graph-convolution backward (~150 small dependent launches) with the refinement
+      # network's eleven weight gradients released underneath them as background launches
+      # (ops.DEFER_WGRAD).  With that, mode 0 - both discriminator steps on the side stream right after
+      # the generator forward, next to the data-gradient chain - is the fastest: 9.66 ms; 2 (the D_obj
+      # step held back until the backward reaches the layout): 9.77; 1 (D_obj first, D_img at the tail):
+      # 9.81; 3 (as 2, D_obj forward passes early): not re-measured.  [Round 1, weight gradients
+      # interleaved with the data gradients: 0: 10.65, 1: 10.39, 2: 10.33, 3: 10.42.]
       if self.d_img is not None and mode != '1':
         on_side(2, self._seg_d_img)
       if self.d_obj is not None:
