@@ -145,12 +145,24 @@ __device__ __forceinline__ float load1_bf(const ConvGeom& g, const Src& S, bool 
   return ok ? r : 0.f;
 }
 
+// leaky for 0 <= slope <= 1 (check_desc enforces it for source slopes): max(v, v * slope) - two VALU
+// instead of compare + multiply + select, bit-identical (v > 0: v * slope <= v; v < 0: v * slope >= v)
+__device__ __forceinline__ float leaky01(float v, float slope) { return __builtin_fmaxf(v, v * slope); }
+
 __device__ __forceinline__ float4 apply_aff(float4 v, const Aff& a, bool ok) {
-  v.x = leaky(fmaf(v.x, a.sc.x, a.sh.x), a.slope);
-  v.y = leaky(fmaf(v.y, a.sc.y, a.sh.y), a.slope);
-  v.z = leaky(fmaf(v.z, a.sc.z, a.sh.z), a.slope);
-  v.w = leaky(fmaf(v.w, a.sc.w, a.sh.w), a.slope);
+  v.x = leaky01(fmaf(v.x, a.sc.x, a.sh.x), a.slope);
+  v.y = leaky01(fmaf(v.y, a.sc.y, a.sh.y), a.slope);
+  v.z = leaky01(fmaf(v.z, a.sc.z, a.sh.z), a.slope);
+  v.w = leaky01(fmaf(v.w, a.sc.w, a.sh.w), a.slope);
   return ok ? v : zero4();
+}
+
+// 16 bytes at a 32-bit BYTE offset from a wave-uniform base: the address is formed by the load itself
+// (global_load_dwordx4 v, v_off, s[base]) instead of a 64-bit add per lane (tensors < 4 GiB: check_desc)
+__device__ __forceinline__ float4 ld4_off(const float* base, unsigned elem_off) {
+  unsigned byte_off = elem_off << 2;
+  asm volatile("" : "+v"(byte_off));     // (keeps hipcc from turning the select on the offset into a select of two 64-bit addresses)
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + (size_t)byte_off);
 }
 
 __device__ __forceinline__ void fetch_aff(Aff& a, const Src& S, int c, bool cok) {
@@ -323,14 +335,14 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(
       #pragma unroll
       for (int i = 0; i < NVA; ++i) {
         const unsigned off = ((ma >> i & 1u) ? pix[i] * (unsigned)S.ld + (unsigned)c : 0u) & kAblMask;
-        r.a[i] = *reinterpret_cast<const float4*>(S.p + off);
+        r.a[i] = ld4_off(S.p, off);
       }
       const unsigned wcol = (unsigned)(tap * g.Ctot + cstart + c);
       const unsigned mb = cok ? bmask : 0u;
       #pragma unroll
       for (int i = 0; i < NVB; ++i) {
         const unsigned off = ((mb >> i & 1u) ? wrow[i] + wcol : 0u) & kAblMask;
-        r.b[i] = *reinterpret_cast<const float4*>(p.Wt + off);
+        r.b[i] = ld4_off(p.Wt, off);
       }
       r.ma = ma; r.mb = mb;
     } else {
@@ -373,7 +385,10 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(
     #pragma unroll
     for (int i = 0; i < NVA; ++i) ta[i] = apply_aff(r.a[i], r.aff, (r.ma >> i & 1u) != 0);
     #pragma unroll
-    for (int i = 0; i < NVB; ++i) tb[i] = (r.mb >> i & 1u) ? r.b[i] : zero4();
+    // (no select on the weight operand: where its mask is off - output channel >= Cout, channel chunk
+    // beyond the source - the load fetched W[0..3], finite, and either the A operand of the same k is
+    // zero or the accumulator column is never stored)
+    for (int i = 0; i < NVB; ++i) tb[i] = r.b[i];
     if constexpr (H) {
       store_tile_h<BM, false>(reinterpret_cast<bf16_t*>(smem + B_ * STAGE), ta, tid);
       store_tile_h<BN, false>(reinterpret_cast<bf16_t*>(smem + B_ * STAGE + AF), tb, tid);
@@ -534,7 +549,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kerne
       #pragma unroll
       for (int i = 0; i < NVA; ++i) {
         const unsigned off = (ma >> i & 1u) ? rows[i] * (unsigned)ldy + (unsigned)co : 0u;
-        r.a[i] = *reinterpret_cast<const float4*>(dY + off);
+        r.a[i] = ld4_off(dY, off);
       }
       const unsigned wcol = (unsigned)(tap * g.Ctot + p.c_begin);
       unsigned mb = 0;
@@ -546,7 +561,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kerne
         if (VB == 4) {
           const bool ok = rok && nok4;
           mb |= (ok ? 1u : 0u) << i;
-          r.b[i] = *reinterpret_cast<const float4*>(p.Wt + (ok ? base + (unsigned)nn : 0u));
+          r.b[i] = ld4_off(p.Wt, ok ? base + (unsigned)nn : 0u);
         } else {
           float bv[4];
           #pragma unroll
@@ -602,7 +617,9 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kerne
     #pragma unroll
     for (int i = 0; i < NVA; ++i) ta[i] = (r.ma >> i & 1u) ? r.a[i] : zero4();
     #pragma unroll
-    for (int i = 0; i < NVB; ++i) tb[i] = (r.mb >> i & 1u) ? r.b[i] : zero4();
+    // (no select on the weight operand, as in the forward kernel: dY is zero for k >= Cout and columns
+    // >= Nc are never stored)
+    for (int i = 0; i < NVB; ++i) tb[i] = r.b[i];
     if constexpr (H) {
       store_tile_h<BM, false>(reinterpret_cast<bf16_t*>(smem + B_ * STAGE), ta, tid);
       store_tile_h<BN, true>(reinterpret_cast<bf16_t*>(smem + B_ * STAGE + AF), tb, tid);
@@ -726,7 +743,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_wgrad_kerne
       if (VEC == 4) {
         const bool ok = aok && pix < p.P;
         ma |= (ok ? 1u : 0u) << i;
-        r.a[i] = *reinterpret_cast<const float4*>(p.dY + (ok ? (unsigned)pix * (unsigned)p.ldy + (unsigned)aco : 0u));
+        r.a[i] = ld4_off(p.dY, ok ? (unsigned)pix * (unsigned)p.ldy + (unsigned)aco : 0u);
       } else {
         float v[4];
         #pragma unroll
@@ -753,7 +770,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_wgrad_kerne
         unsigned row;
         if (GATHER) row = BS.gidx ? (unsigned)BS.gidx[ok ? n : 0] : (unsigned)(ok ? n : 0);
         else row = ok ? (unsigned)((n * Hs + (hi >> BS.up)) * Ws + (wi >> BS.up)) : 0u;
-        r.b[i] = *reinterpret_cast<const float4*>(BS.p + (ok ? row * (unsigned)BS.ld + (unsigned)bcs : 0u));
+        r.b[i] = ld4_off(BS.p, ok ? row * (unsigned)BS.ld + (unsigned)bcs : 0u);
       } else {
         float e[4];
         #pragma unroll
@@ -1089,6 +1106,11 @@ static int check_desc(const sg2im_conv_desc* d) {
   if (eh != d->out_h || ew != d->out_w) return 1;
   for (int i = 0; i < d->nsrc; ++i) {
     if (!d->src[i].data || d->src[i].channels < 1 || d->src[i].ld < d->src[i].channels) return 1;
+    // (the loaders form addresses from 32-bit byte offsets and evaluate the pending LeakyReLU as max(v, v * slope))
+    if (!(d->src[i].slope >= 0.f && d->src[i].slope <= 1.f)) return 1;
+    if (!d->src[i].gather &&
+        (double)d->batch * (d->in_h >> d->src[i].upsample_log2) * (d->in_w >> d->src[i].upsample_log2) * d->src[i].ld * 4.0 >= 4294967296.0)
+      return 1;
     if (d->src[i].upsample_log2 < 0 || d->src[i].upsample_log2 > 1) return 1;
     if (d->src[i].gather && (d->in_h != 1 || d->in_w != 1)) return 1;
     if (d->src[i].upsample_log2 && ((d->in_h & 1) || (d->in_w & 1))) return 1;
