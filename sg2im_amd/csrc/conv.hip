@@ -149,12 +149,44 @@ __device__ __forceinline__ float load1_bf(const ConvGeom& g, const Src& S, bool 
 // instead of compare + multiply + select, bit-identical (v > 0: v * slope <= v; v < 0: v * slope >= v)
 __device__ __forceinline__ float leaky01(float v, float slope) { return __builtin_fmaxf(v, v * slope); }
 
+// Pending affine + LeakyReLU + validity mask of one float4, on the packed-fp32 VALU (v_pk_fma_f32 /
+// v_pk_mul_f32: two lanes of work per instruction): 2 fma + 2 mul + 4 max + 2 mul(mask) instead of
+// 4 + 4 + 4 + 4 selects.  The mask is a multiplication by 0 / 1 (the masked-off load fetched element 0
+// of its tensor, finite).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 apply_aff(float4 v, const Aff& a, bool ok) {
-  v.x = leaky01(fmaf(v.x, a.sc.x, a.sh.x), a.slope);
-  v.y = leaky01(fmaf(v.y, a.sc.y, a.sh.y), a.slope);
-  v.z = leaky01(fmaf(v.z, a.sc.z, a.sh.z), a.slope);
-  v.w = leaky01(fmaf(v.w, a.sc.w, a.sh.w), a.slope);
-  return ok ? v : zero4();
+  const f32x2 mk = ok ? f32x2{1.f, 1.f} : f32x2{0.f, 0.f};
+  const f32x2 sl = {a.slope, a.slope};
+  f32x2 lo = f32x2{v.x, v.y} * f32x2{a.sc.x, a.sc.y} + f32x2{a.sh.x, a.sh.y};
+  f32x2 hi = f32x2{v.z, v.w} * f32x2{a.sc.z, a.sc.w} + f32x2{a.sh.z, a.sh.w};
+  const f32x2 lo2 = lo * sl, hi2 = hi * sl;
+  lo = f32x2{__builtin_fmaxf(lo.x, lo2.x), __builtin_fmaxf(lo.y, lo2.y)} * mk;
+  hi = f32x2{__builtin_fmaxf(hi.x, hi2.x), __builtin_fmaxf(hi.y, hi2.y)} * mk;
+  return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+
+// 16 bytes through a raw buffer resource: an offset at or beyond the resource's size reads zeros - rows
+// that are out of range need no select afterwards (operands without a pending affine: dY).  kOobByte is
+// out of range for every tensor below 2 GiB (the entry points check).  The descriptor is built by hand
+// and the load is the LLVM intrinsic itself: this ROCm's __builtin_amdgcn_raw_buffer_load_b128 lowers to
+// a ONE-dword load whose value is splat over the four lanes (tools/_src/bufload_probe.hip).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ f32x4 llvm_raw_buffer_load_f32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+typedef i32x4 BufRsrc;
+constexpr unsigned kOobByte = 0x80000000u;
+__device__ __forceinline__ BufRsrc rsrc_of(const float* p, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  BufRsrc r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+  r.y = __builtin_amdgcn_readfirstlane((int)(a >> 32));              // (stride 0: raw buffer)
+  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  r.w = 0x00020000;                                                  // (32-bit data format, no swizzle)
+  return r;
+}
+__device__ __forceinline__ float4 ld4_buf(BufRsrc r, unsigned byte_off) {
+  const f32x4 v = llvm_raw_buffer_load_f32x4(r, (int)byte_off, 0, 0);
+  return make_float4(v.x, v.y, v.z, v.w);
 }
 
 // 16 bytes at a 32-bit BYTE offset from a wave-uniform base: the address is formed by the load itself
@@ -277,10 +309,13 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(
 
   typedef RegSet<NVA, NVB> RS;
   RS rs0, rs1;
+  unsigned roff[NVA], rmask = 0;      // per A row: element offset of its pixel for the current (tap, source), validity
+  bool q_dirty = true;
   auto load_into = [&](int it, RS& r) {
     if (VEC == 4) {
       const int tap = q_tap, kh = q_kh, kw = q_kw, cstart = q_cstart, cb = q_cb;
       const Src S = q_S;
+      bool next_dirty;
       {
         // branch-free advance (scalar selects; the source block is re-read with scalar loads
         // every chunk) so that the loop body stays one basic block.  The last chunk is
@@ -297,6 +332,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(
         q_cb = wrap_s ? 0 : (wrap_t ? ncb : q_cb);
         q_cstart += wrap_s ? q_S.C : 0;
         q_s += wrap_s ? 1 : 0;
+        next_dirty = true;
 #else
         const int ncb = q_cb + BK;
         const bool wrap_s = adv && ncb >= q_S.C;                 // next source
@@ -308,33 +344,36 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(
         q_tap += wrap_t ? 1 : 0;
         q_kw = wrap_w ? 0 : (wrap_t ? q_kw + 1 : q_kw);
         q_kh += wrap_w ? 1 : 0;
+        next_dirty = wrap_s;                                     // (the source or the tap moves on)
 #endif
         q_S = kernarg_src(q_s);
       }
       const int c = cb + 4 * col4;
       const bool cok = c < S.C;
       fetch_aff(r.aff, S, c, cok);
-      const int Hs = g.H >> S.up, Ws = g.W >> S.up;
-      unsigned ma = 0;
-      unsigned pix[NVA];
-      #pragma unroll
-      for (int i = 0; i < NVA; ++i) {
-#if SG2IM_ABL & 8
-        // timing-only: no per-row address arithmetic (wrong addresses, same access pattern class)
-        (void)Hs; (void)Ws;
-        ma |= 1u << i;
-        pix[i] = (unsigned)((rn[i] * 7 + 4 * i + kw + kh) & 255);
-#else
-        const int hi = rhb[i] + kh, wi = rwb[i] + kw;
-        const bool ok = cok && rn[i] >= 0 && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-        ma |= (ok ? 1u : 0u) << i;
-        if (GATHER) pix[i] = S.gidx ? (unsigned)S.gidx[ok ? rn[i] : 0] : (unsigned)(ok ? rn[i] : 0);
-        else pix[i] = ok ? (unsigned)((rn[i] * Hs + (hi >> S.up)) * Ws + (wi >> S.up)) : 0u;
-#endif
+      // Row geometry (bounds test, pixel offset) depends on the tap and the source only: recomputed
+      // when either changed (wave-uniform branch - every nch-th chunk in the tap-outer order), otherwise
+      // a row's offset just moves on by the channel chunk.  This arithmetic sits in FRONT of the
+      // chunk's global loads, i.e. it is not covered by the wave's own MFMA block.
+      if (SG2IM_TAP_INNER || q_dirty) {
+        const int Hs = g.H >> S.up, Ws = g.W >> S.up;
+        rmask = 0;
+        #pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+          const int hi = rhb[i] + kh, wi = rwb[i] + kw;
+          const bool ok = rn[i] >= 0 && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+          rmask |= (ok ? 1u : 0u) << i;
+          unsigned pixel;
+          if (GATHER) pixel = S.gidx ? (unsigned)S.gidx[ok ? rn[i] : 0] : (unsigned)(ok ? rn[i] : 0);
+          else pixel = ok ? (unsigned)((rn[i] * Hs + (hi >> S.up)) * Ws + (wi >> S.up)) : 0u;
+          roff[i] = pixel * (unsigned)S.ld;
+        }
       }
+      q_dirty = next_dirty;
+      const unsigned ma = cok ? rmask : 0u;
       #pragma unroll
       for (int i = 0; i < NVA; ++i) {
-        const unsigned off = ((ma >> i & 1u) ? pix[i] * (unsigned)S.ld + (unsigned)c : 0u) & kAblMask;
+        const unsigned off = ((ma >> i & 1u) ? roff[i] + (unsigned)c : 0u) & kAblMask;
         r.a[i] = ld4_off(S.p, off);
       }
       const unsigned wcol = (unsigned)(tap * g.Ctot + cstart + c);
@@ -529,28 +568,38 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kerne
     q_cb = (it_begin - t * nch) * BK;
     q_th = t / nkw; q_tw = t - q_th * nkw;
   }
+  // (VA == 4) per A row: element offset of the output pixel the current tap hits, validity - recomputed
+  // when the tap moves on (every nch-th chunk), see the forward kernel; dY is read through a buffer
+  // resource, out-of-range rows come back as zeros
+  unsigned droff[NVA], dmask = 0;
+  bool d_dirty = true;
+  const BufRsrc rsY = rsrc_of(dY, (unsigned)(g.NB * g.Ho * g.Wo) * (unsigned)ldy * 4u);
   auto load_into = [&](int it, RS& r) {
     if (VA == 4) {
       const int cb = q_cb;
       const int kh = kh0 + kstep * q_th, kw = kw0 + kstep * q_tw;
       const int tap = kh * g.KW + kw;
+      if (d_dirty) {
+        dmask = 0;
+        #pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+          unsigned row;
+          const bool ok = out_pixel(i, kh, kw, row);
+          dmask |= (ok ? 1u : 0u) << i;
+          droff[i] = row * (unsigned)ldy;
+        }
+      }
+      d_dirty = false;
       if (it + 1 < it_end) {
         q_cb += BK;
-        if (q_cb >= Cout) { q_cb = 0; if (++q_tw == nkw) { q_tw = 0; ++q_th; } }
+        if (q_cb >= Cout) { q_cb = 0; d_dirty = true; if (++q_tw == nkw) { q_tw = 0; ++q_th; } }
       }
       const int co = cb + 4 * col4;
       const bool cok = co < Cout;
-      unsigned ma = 0, rows[NVA];
+      const unsigned ma = cok ? dmask : 0u;
       #pragma unroll
-      for (int i = 0; i < NVA; ++i) {
-        const bool ok = out_pixel(i, kh, kw, rows[i]) && cok;
-        ma |= (ok ? 1u : 0u) << i;
-      }
-      #pragma unroll
-      for (int i = 0; i < NVA; ++i) {
-        const unsigned off = (ma >> i & 1u) ? rows[i] * (unsigned)ldy + (unsigned)co : 0u;
-        r.a[i] = ld4_off(dY, off);
-      }
+      for (int i = 0; i < NVA; ++i)
+        r.a[i] = ld4_buf(rsY, (ma >> i & 1u) ? (droff[i] + (unsigned)co) << 2 : kOobByte);
       const unsigned wcol = (unsigned)(tap * g.Ctot + p.c_begin);
       unsigned mb = 0;
       #pragma unroll
@@ -615,7 +664,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kerne
     float4 ta[NVA], tb[NVB];
     launder(r);
     #pragma unroll
-    for (int i = 0; i < NVA; ++i) ta[i] = (r.ma >> i & 1u) ? r.a[i] : zero4();
+    for (int i = 0; i < NVA; ++i) ta[i] = r.a[i];      // (VA == 4: invalid rows were read as zeros; VA == 1: zeroed in the loader)
     #pragma unroll
     // (no select on the weight operand, as in the forward kernel: dY is zero for k >= Cout and columns
     // >= Nc are never stored)
@@ -735,6 +784,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_wgrad_kerne
 
   typedef RegSet<NVA, NVB> RS;
   RS rs0, rs1;
+  const BufRsrc rsY = rsrc_of(p.dY, (unsigned)p.P * (unsigned)p.ldy * 4u);
   auto load_into = [&](int it, RS& r) {
     unsigned ma = 0, mb = 0;
     #pragma unroll
@@ -743,7 +793,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_wgrad_kerne
       if (VEC == 4) {
         const bool ok = aok && pix < p.P;
         ma |= (ok ? 1u : 0u) << i;
-        r.a[i] = ld4_off(p.dY, ok ? (unsigned)pix * (unsigned)p.ldy + (unsigned)aco : 0u);
+        r.a[i] = ld4_buf(rsY, ok ? ((unsigned)pix * (unsigned)p.ldy + (unsigned)aco) << 2 : kOobByte);   // (zeros when !ok)
       } else {
         float v[4];
         #pragma unroll
@@ -797,7 +847,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_wgrad_kerne
     float4 ta[NVA], tb[NVB];
     launder(r);
     #pragma unroll
-    for (int i = 0; i < NVA; ++i) ta[i] = (r.ma >> i & 1u) ? r.a[i] : zero4();
+    for (int i = 0; i < NVA; ++i) ta[i] = r.a[i];        // (rows beyond the last pixel / channel were read as zeros)
     if (want_db && live) {
       #pragma unroll
       for (int i = 0; i < NVA; ++i) { dbs.x += ta[i].x; dbs.y += ta[i].y; dbs.z += ta[i].z; dbs.w += ta[i].w; }
@@ -1592,6 +1642,8 @@ int sg2im_conv2d_backward_data(const sg2im_conv_desc* d, const float* weight, in
   for (int i = 0; i < 4; ++i) *src_at(g, i) = Src{nullptr, nullptr, nullptr, nullptr, 1.f, 0, 0, 0};
   g.s0.p = dy; g.s0.C = cout; g.s0.ld = ld_dy;
   if (c_begin < 0 || c_begin + c_count > g.Ctot) return SG2IM_ERR_ARG;
+  // (dY is read through a buffer resource with an out-of-range offset of 2 GiB for invalid rows)
+  if ((double)d->batch * d->out_h * d->out_w * ld_dy * 4.0 >= 2147483648.0) return SG2IM_ERR_ARG;
   p.Wt = weight; p.c_begin = c_begin; p.Nc = c_count;
   const long long Mfull = (long long)d->batch * d->in_h * d->in_w;
   if (Mfull == 0) return SG2IM_OK;
@@ -1671,6 +1723,7 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
   p.dY = dy; p.ldy = ld_dy; p.Cout = cout;
   p.background = d->launch_hints & SG2IM_HINT_BACKGROUND;
   p.P = d->batch * d->out_h * d->out_w;
+  if ((double)p.P * ld_dy * 4.0 >= 2147483648.0) return SG2IM_ERR_ARG;     // (buffer-resource reads of dY, see above)
   const int taps = d->kh * d->kw;
   const int Ntot = taps * p.g.Ctot;
   if (p.P == 0) {
