@@ -346,7 +346,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(
         q_kh += wrap_w ? 1 : 0;
         next_dirty = wrap_s;                                     // (the source or the tap moves on)
 #endif
-        q_S = kernarg_src(q_s);
+        if (SG2IM_TAP_INNER || next_dirty) q_S = kernarg_src(q_s);   // (scalar loads of the source block)
       }
       const int c = cb + 4 * col4;
       const bool cok = c < S.C;
