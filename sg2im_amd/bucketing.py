@@ -79,8 +79,17 @@ class StaticBatch(object):
     self.obj_count = (self.counts[0:1], 1)
     self.triple_count = (self.counts[1:2], 1)
     dev = objs.device
-    self._far = torch.tensor([FAR_BOX], dtype=boxes.dtype, device=dev)
-    self._dummy = torch.tensor([[o_pad - 1, 0, o_pad - 1]], dtype=triples.dtype, device=dev)
+    # Constant padding rows (whole-bucket tensors: load() copies their [O:] / [T:] tails) and lookup
+    # tables for the two counts - so that a refill is three multi-tensor copies, one per dtype
+    # (torch._foreach_copy_), instead of ~15 copy / fill launches in front of every replay.  [These are
+    # torch's kernels on purpose: an eager launch of THIS library between two replays would invalidate
+    # the captured graphs, see Trainer._graph_step.]
+    self._pad_objs = torch.zeros_like(self.objs)
+    self._pad_boxes = torch.tensor(FAR_BOX, dtype=boxes.dtype, device=dev).expand(o_pad, 4).contiguous()
+    self._pad_masks = None if masks is None else torch.zeros_like(self.masks)
+    self._pad_triples = torch.tensor([o_pad - 1, 0, o_pad - 1], dtype=triples.dtype, device=dev).expand(t_pad, 3).contiguous()
+    self._pad_o2i = torch.full_like(self.obj_to_img, self.n_images - 1)
+    self._tab = torch.arange(max(o_pad, t_pad) + 1, dtype=torch.int32, device=dev)
 
   def tensors(self):
     return (self.imgs, self.objs, self.boxes, self.masks, self.triples, self.obj_to_img)
@@ -90,19 +99,18 @@ class StaticBatch(object):
     O, T = objs.numel(), triples.size(0)
     if O >= self.o_pad or T > self.t_pad or imgs.shape != self.imgs.shape or (masks is None) != (self.masks is None):
       raise ValueError('batch does not fit this bucket')
-    self.imgs.copy_(imgs, non_blocking=True)
-    self.objs[:O].copy_(objs, non_blocking=True)
-    self.objs[O:].zero_()
-    self.boxes[:O].copy_(boxes, non_blocking=True)
-    self.boxes[O:].copy_(self._far)
+    groups = {}
+    def put(dst, src):
+      if dst.numel() > 0:
+        d, s_ = groups.setdefault(dst.dtype, ([], []))
+        d.append(dst); s_.append(src)
+    put(self.imgs, imgs)
+    put(self.objs[:O], objs); put(self.objs[O:], self._pad_objs[O:])
+    put(self.boxes[:O], boxes); put(self.boxes[O:], self._pad_boxes[O:])
     if masks is not None:
-      self.masks[:O].copy_(masks, non_blocking=True)
-      self.masks[O:].zero_()
-    if T > 0:
-      self.triples[:T].copy_(triples, non_blocking=True)
-    if T < self.t_pad:
-      self.triples[T:].copy_(self._dummy)
-    self.obj_to_img[:O].copy_(o2i, non_blocking=True)
-    self.obj_to_img[O:].fill_(self.n_images - 1)
-    self.counts[0:1].fill_(O)
-    self.counts[1:2].fill_(T)
+      put(self.masks[:O], masks); put(self.masks[O:], self._pad_masks[O:])
+    put(self.triples[:T], triples.reshape(T, 3)); put(self.triples[T:], self._pad_triples[T:])
+    put(self.obj_to_img[:O], o2i); put(self.obj_to_img[O:], self._pad_o2i[O:])
+    put(self.counts[0:1], self._tab[O:O + 1]); put(self.counts[1:2], self._tab[T:T + 1])
+    for dst, src in groups.values():
+      torch._foreach_copy_(dst, src)

@@ -947,3 +947,30 @@ def test_padded_batch_without_any_triples_or_with_isolated_objects():
       if v.is_floating_point() and 'running_' not in k:
         d = float((sd[k].detach().cpu() - v.detach()).abs().max())
         assert d <= 2.05e-4, (name, k, d)
+
+
+@pytest.mark.gpu
+def test_static_batch_staging_launch_equals_pad_batch():
+  """The batch hand-over of the captured iteration (StaticBatch.load: three multi-tensor copies):
+  for batches of different object / triple counts that share a bucket - including one without triples -
+  the static buffers hold exactly what the functional ``pad_batch`` builds (bit-exact, all dtypes)."""
+  from sg2im_amd.bucketing import Bucketer, StaticBatch, pad_batch
+  from sg2im_amd.synthetic import synthetic_batch
+  from tests import hip_harness as hh
+  dev = hh.dev()
+  cpu = [synthetic_batch(4, seed=s, min_objs=lo, max_objs=hi) for s, lo, hi in ((1, 3, 4), (2, 5, 6), (3, 7, 8))]
+  b_empty = list(cpu[0][:6])
+  b_empty[4] = b_empty[4][:0]
+  cpu.append(tuple(b_empty))
+  o_pad, t_pad = 64, 128
+  gpu = [tuple(t.to(dev) if torch.is_tensor(t) else t for t in b[:6]) for b in cpu]
+  sb = StaticBatch(gpu[0], o_pad, t_pad)
+  for b in gpu[1:] + gpu[:1]:
+    sb.load(b)
+    torch.cuda.synchronize()
+    want, counts = pad_batch(b, o_pad, t_pad)
+    for got, ref in zip(sb.tensors(), want):
+      assert (got is None) == (ref is None)
+      if ref is not None:
+        assert got.dtype == ref.dtype and got.shape == ref.shape and torch.equal(got, ref)
+    assert torch.equal(sb.counts, counts)
