@@ -673,27 +673,33 @@ __global__ void avgpool_v4_kernel(const float* __restrict__ x, int B, int H, int
   }
 }
 
+// One image row (n, y) per workgroup: the per-level row bases, factors and weights are wave-uniform
+// (scalar), an item only divides its x by the level's factor - a shift when the factor is a power of
+// two.  (The grid-stride form decoded (n, y, x, c) and y / f, x / f, H / f, W / f with ~15 integer
+// divisions per float4: 99 us for the 5-level 64x64x128 batch-32 pyramid against ~20 us of traffic.)
 __global__ void pyramid_bwd_v4_kernel(PyramidArgs a, int B, int H, int W, int C, float* __restrict__ out,
                                       long long ld_out) {
   const int CQ = C >> 2;
-  const long long total = (long long)B * H * W * CQ;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int c = 4 * (int)(i % CQ); long long t = i / CQ;
-    const int x = (int)(t % W); t /= W;
-    const int y = (int)(t % H); const long long n = t / H;
+  const int n = blockIdx.x / H, y = blockIdx.x - n * H;
+  const bool cq_pow2 = (CQ & (CQ - 1)) == 0;
+  const int cq_shift = __builtin_ctz(CQ);
+  float* const orow = out + ((long long)n * H + y) * W * ld_out;
+  for (int j = threadIdx.x; j < W * CQ; j += blockDim.x) {
+    const int x = cq_pow2 ? j >> cq_shift : j / CQ;
+    const int c = 4 * (j - x * CQ);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     #pragma unroll
     for (int l = 0; l < 8; ++l) {
       if (l < a.n) {
         const int f = a.f[l];
         const int h = H / f, w = W / f;
-        const float4 v = ld4(a.lvl[l] + ((n * h + y / f) * w + x / f) * a.ld[l] + c);
+        const int xl = (f & (f - 1)) == 0 ? x >> __builtin_ctz(f) : x / f;
+        const float4 v = ld4(a.lvl[l] + (((long long)n * h + y / f) * w + xl) * a.ld[l] + c);
         const float k = 1.f / (float)(f * f);
         s.x += v.x * k; s.y += v.y * k; s.z += v.z * k; s.w += v.w * k;
       }
     }
-    *reinterpret_cast<float4*>(out + ((n * H + y) * W + x) * ld_out + c) = s;
+    *reinterpret_cast<float4*>(orow + (long long)x * ld_out + c) = s;
   }
 }
 
@@ -910,7 +916,7 @@ int sg2im_pyramid_backward(const float* const* dlevels, const int* factors, cons
   bool v4 = channels % 4 == 0 && ld_out % 4 == 0 && al16(dlayout);
   for (int l = 0; l < n_levels; ++l) v4 = v4 && lds[l] % 4 == 0 && al16(dlevels[l]);
   if (v4)
-    hipLaunchKernelGGL(pyramid_bwd_v4_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, stream, a, batch, h, w,
+    hipLaunchKernelGGL(pyramid_bwd_v4_kernel, dim3((unsigned)(batch * h)), dim3(256), 0, stream, a, batch, h, w,
                        channels, dlayout, ld_out);
   else
     hipLaunchKernelGGL(pyramid_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, a, batch, h, w, channels,
