@@ -79,6 +79,10 @@ typedef struct sg2im_conv_desc {
 } sg2im_conv_desc;
 #define SG2IM_HINT_BACKGROUND 1
 
+/* Limits (SG2IM_ERR_ARG otherwise): every source tensor below 4 GiB and dy below 2 GiB - the loaders form
+ * addresses from 32-bit byte offsets off a wave-uniform base, dy is read through a buffer resource whose
+ * out-of-range offset (2 GiB) makes invalid rows read as zeros; pending LeakyReLU slopes in [0, 1] (evaluated
+ * as max(v, v * slope)). */
 /* out[pix][co] = leaky_{out_slope}( conv(X, W)[pix][co] + bias[co] ) (+ out if accumulate) */
 int sg2im_conv2d_forward(const sg2im_conv_desc* desc, const float* weight, int cout,
                          const float* bias, float out_slope, float* out, long long ld_out,
