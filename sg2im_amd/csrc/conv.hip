@@ -772,14 +772,19 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_wgrad_kerne
   }
   // the B rows are output pixels: (n, ho, wo) of row pix = it*BK + bk0 + (1024/BN)*i is
   // advanced incrementally (BK pixels per chunk) instead of two integer divisions per row
-  int bn_[NVB], bho[NVB], bwo[NVB];
+  // (kept pre-multiplied: hb = ho * stride - pad, wb = wo * stride - pad; the wrap tests compare against the
+  // equally transformed limits, so a chunk costs no multiplication per row)
+  int bn_[NVB], bhb[NVB], bwb[NVB];
   const int dn = BK / HoWo, drem = BK - dn * HoWo, dh = drem / g.Wo, dw = drem - dh * g.Wo;
+  const int dhs = dh * g.stride, dws = dw * g.stride, WoS = g.Wo * g.stride, HoS = g.Ho * g.stride;
+  const int wlim = WoS - g.pad, hlim = HoS - g.pad;
   #pragma unroll
   for (int i = 0; i < NVB; ++i) {
     const int pix = it_begin * BK + bk0 + (1024 / BN) * i;
     bn_[i] = pix / HoWo;
     const int rem = pix - bn_[i] * HoWo;
-    bho[i] = rem / g.Wo; bwo[i] = rem - bho[i] * g.Wo;
+    const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+    bhb[i] = ho * g.stride - g.pad; bwb[i] = wo * g.stride - g.pad;
   }
 
   typedef RegSet<NVA, NVB> RS;
@@ -806,16 +811,17 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_wgrad_kerne
         ma |= 1u << i;
       }
     }
+    // (the pipelines re-issue the last chunk instead of branching around the tail: the row coordinates
+    // are not advanced past it, so pix < P keeps implying n < NB)
+    const bool adv = it + 1 < it_end;
+    const int a_dn = adv ? dn : 0, a_dhs = adv ? dhs : 0, a_dws = adv ? dws : 0;
     #pragma unroll
     for (int i = 0; i < NVB; ++i) {
       const int pix = it * BK + bk0 + (1024 / BN) * i;
-      const int n = bn_[i], ho = bho[i], wo = bwo[i];
-      const int hb = ho * g.stride - g.pad, wb = wo * g.stride - g.pad;
+      const int n = bn_[i], hb = bhb[i], wb = bwb[i];
       if (VEC == 4) {
         const int hi = hb + bkh, wi = wb + bkw;
-        // (n < NB: the depth-1 pipeline re-issues the last chunk once more, with the row
-        // coordinates already advanced past the end)
-        const bool ok = bok && pix < p.P && n < g.NB && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+        const bool ok = bok && pix < p.P && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
         mb |= (ok ? 1u : 0u) << i;
         unsigned row;
         if (GATHER) row = BS.gidx ? (unsigned)BS.gidx[ok ? n : 0] : (unsigned)(ok ? n : 0);
@@ -826,17 +832,17 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_wgrad_kerne
         #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int hi = hb + jkh[j], wi = wb + jkw[j];
-          const bool ok = pix < p.P && n < g.NB && jok[j] && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+          const bool ok = pix < p.P && jok[j] && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
           e[j] = load1_bf(g, pick_src(g, js[j]), ok, n, hi, wi, jcs[j]);
         }
         r.b[i] = make_float4(e[0], e[1], e[2], e[3]);
         mb |= 1u << i;
       }
       // advance this row by BK pixels for the next chunk
-      int w2 = wo + dw, h2 = ho + dh, n2 = n + dn;
-      if (w2 >= g.Wo) { w2 -= g.Wo; ++h2; }
-      if (h2 >= g.Ho) { h2 -= g.Ho; ++n2; }
-      bwo[i] = w2; bho[i] = h2; bn_[i] = n2;
+      int w2 = wb + a_dws, h2 = hb + a_dhs, n2 = n + a_dn;
+      if (w2 >= wlim) { w2 -= WoS; h2 += g.stride; }
+      if (h2 >= hlim) { h2 -= HoS; ++n2; }
+      bwb[i] = w2; bhb[i] = h2; bn_[i] = n2;
     }
     r.ma = ma; r.mb = mb;
   };

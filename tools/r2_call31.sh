@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 L=$PWD/sg2im_amd/lib
-timeout 300 python tools/gpu_check.py sec_conv sec_layout sec_golden_coco sec_golden_vg 2>&1 | grep -v amdgpu.ids | tail -2 | tee gpurun_out/c31_parity.log
+timeout 300 python tools/gpu_check.py sec_conv sec_linear sec_gconv sec_golden_coco sec_golden_vg 2>&1 | grep -v amdgpu.ids | tail -2 | tee gpurun_out/c31_parity.log
 for v in _v2 ""; do
   echo "== layers [$v]"; SG2IM_LIB=$L/libsg2im_hip$v.so timeout 300 python tools/bench_conv.py 2>&1 | grep -v amdgpu.ids | tail -27
 done > gpurun_out/c31_layers.log 2>&1
