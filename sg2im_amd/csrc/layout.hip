@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256) void layout_fwd_kernel(const float* __restrict
                                                          long long ld_out) {
   __shared__ float S[LO][LP + 1];
   __shared__ int objs[LO];
+  __shared__ int act[LO];      // does the object touch any of this workgroup's pixels?
   const int n = blockIdx.y, p0 = blockIdx.x * LP, HW = H * W;
   const int tid = threadIdx.x;
   const int p = tid >> 3, cl = tid & 7;
@@ -115,10 +116,15 @@ __global__ __launch_bounds__(256) void layout_fwd_kernel(const float* __restrict
           s = sample_map(mk, o, f);
         }
         S[oi][pp] = s;
+        // (an object's LP = 32 pixels are one half of a wavefront: most boxes miss most pixel tiles, and
+        // adding s = +0 products is a no-op - skip those objects, bit-identical)
+        const unsigned long long hit = __ballot(s != 0.f);
+        if ((tid & 31) == 0) act[oi] = ((tid & 32) ? (unsigned)(hit >> 32) : (unsigned)hit) != 0u;
       }
       __syncthreads();
       if (pix < HW) {
         for (int oi = 0; oi < nobj; ++oi) {
+          if (!act[oi]) continue;
           const float s = S[oi][p];
           const float* vrow = vecs + (long long)objs[oi] * ld_vecs;
           #pragma unroll
