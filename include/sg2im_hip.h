@@ -76,6 +76,15 @@ typedef struct sg2im_conv_desc {
                              * layout / mask / graph-convolution backward chain) - its large-tile kernels then
                              * keep at most two workgroups resident per CU (padded LDS request) so that the other
                              * stream's workgroups always find a free slot.  Results are unaffected. */
+  int weight_channels;      /* floats per tap of a weight row; 0 = the sum of the sources' channels.  Larger: the
+                             * weight tensor has MORE input channels per tap than the sources supply and the
+                             * convolution runs over the first sum(channels) of every tap - forward and
+                             * backward_data read weight[co][tap][0 .. sum), backward_weight writes the same
+                             * columns of dweight (row = kh * kw * weight_channels floats) and leaves the others
+                             * untouched.  Use: the refinement network's first module concatenates a constant
+                             * all-zero feature channel (crn.py:105) - 161 channels, not a multiple of 4, which
+                             * would push the layer onto the scalar loaders; the zero channel contributes nothing
+                             * forward and has an exactly zero weight gradient, so it is simply left out. */
 } sg2im_conv_desc;
 #define SG2IM_HINT_BACKGROUND 1
 

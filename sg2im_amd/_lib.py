@@ -25,7 +25,7 @@ class Src(Structure):
 class ConvDesc(Structure):
   _fields_ = [('src', Src * 4), ('nsrc', c_int), ('batch', c_int), ('in_h', c_int), ('in_w', c_int),
               ('out_h', c_int), ('out_w', c_int), ('kh', c_int), ('kw', c_int), ('stride', c_int),
-              ('pad', c_int), ('compute_dtype', c_int), ('launch_hints', c_int)]
+              ('pad', c_int), ('compute_dtype', c_int), ('launch_hints', c_int), ('weight_channels', c_int)]
 
 
 _P, _I, _L, _F, _Z = c_void_p, c_int, c_longlong, c_float, c_size_t

@@ -257,8 +257,8 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(
   const int it_begin = split * per;
   const int it_end = min(p.iters, it_begin + per);
   const int col4 = tid & 7, r0 = tid >> 3;
-  const int ldw = g.KH * g.KW * g.Ctot;
-  const int Ktot = ldw;
+  const int ldw = g.KH * g.KW * g.Wtap;
+  const int Ktot = g.KH * g.KW * g.Ctot;
 
   int rn[NVA], rhb[NVA], rwb[NVA];
   unsigned wrow[NVB], bmask = 0;
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(
         const unsigned off = ((ma >> i & 1u) ? roff[i] + (unsigned)c : 0u) & kAblMask;
         r.a[i] = ld4_off(S.p, off);
       }
-      const unsigned wcol = (unsigned)(tap * g.Ctot + cstart + c);
+      const unsigned wcol = (unsigned)(tap * g.Wtap + cstart + c);
       const unsigned mb = cok ? bmask : 0u;
       #pragma unroll
       for (int i = 0; i < NVB; ++i) {
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(
         for (int i = 0; i < NVB; ++i) {
           const int n = n0 + r0 + 32 * i;
           const bool wok = kok && n < p.Cout;
-          const float wv = p.Wt[wok ? (unsigned)n * (unsigned)ldw + (unsigned)k : 0u];
+          const float wv = p.Wt[wok ? (unsigned)n * (unsigned)ldw + (unsigned)(tap * g.Wtap + c) : 0u];
           bv[i][j] = wok ? wv : 0.f;
         }
       }
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kerne
   const int m0 = (blockIdx.y * (PP ? 2 : 1) + half) * BM, n0 = blockIdx.x * BN;
   const int col4 = tid & 7, r0 = tid >> 3;
   const int taps = g.KH * g.KW;
-  const int ldw = taps * g.Ctot;
+  const int ldw = taps * g.Wtap;
   const int Cout = g.s0.C, ldy = g.s0.ld;
   const float* dY = g.s0.p;
 
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kerne
       #pragma unroll
       for (int i = 0; i < NVA; ++i)
         r.a[i] = ld4_buf(rsY, (ma >> i & 1u) ? (droff[i] + (unsigned)co) << 2 : kOobByte);
-      const unsigned wcol = (unsigned)(tap * g.Ctot + p.c_begin);
+      const unsigned wcol = (unsigned)(tap * g.Wtap + p.c_begin);
       unsigned mb = 0;
       #pragma unroll
       for (int i = 0; i < NVB; ++i) {
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kerne
         const int k = it * BK + bk0 + (1024 / BN) * i;
         const bool kok = k < Ktot;
         const int tap = kok ? k / Cout : 0, co = kok ? k - tap * Cout : 0;
-        const unsigned base = (unsigned)co * (unsigned)ldw + (unsigned)(tap * g.Ctot + p.c_begin);
+        const unsigned base = (unsigned)co * (unsigned)ldw + (unsigned)(tap * g.Wtap + p.c_begin);
         float bv[4];
         #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -935,7 +935,8 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_wgrad_kerne
 __global__ void splitk_finish_kernel(const float* __restrict__ ws, int nsplit, long long MN, int N,
                                      float* __restrict__ C, long long ldc, const float* __restrict__ bias,
                                      float slope, int accumulate, int SL,
-                                     const float* __restrict__ ws2, float* __restrict__ C2, int N2) {
+                                     const float* __restrict__ ws2, float* __restrict__ C2, int N2,
+                                     int col_ctot, int col_wtap) {
   // second, tiny reduction riding along (weight-gradient launches: the bias gradient partials)
   __shared__ float part[256];
   if (C2 != nullptr && blockIdx.x == 0) {
@@ -973,7 +974,7 @@ __global__ void splitk_finish_kernel(const float* __restrict__ ws, int nsplit, l
       const int n = (int)(idx - m * N);
       if (bias) v += bias[n];
       v = leaky(v, slope);
-      float* dst = C + m * ldc + n;
+      float* dst = C + m * ldc + (col_wtap ? (n / col_ctot) * col_wtap + n % col_ctot : n);   // (Epi::col_*)
       if (accumulate) v += *dst;
       *dst = v;
     }
@@ -1151,12 +1152,18 @@ static void fill_geom(ConvGeom& g, const sg2im_conv_desc* d) {
   }
   g.NB = d->batch; g.H = d->in_h; g.W = d->in_w; g.Ho = d->out_h; g.Wo = d->out_w;
   g.KH = d->kh; g.KW = d->kw; g.stride = d->stride; g.pad = d->pad;
+  g.Wtap = d->weight_channels > 0 ? d->weight_channels : g.Ctot;
 }
 
 static int check_desc(const sg2im_conv_desc* d) {
   if (!d || d->nsrc < 1 || d->nsrc > 4) return 1;
   if (d->stride < 1 || d->kh < 1 || d->kw < 1) return 1;
   if (d->compute_dtype != 0 && d->compute_dtype != 1) return 1;
+  if (d->weight_channels != 0) {          // (weight rows wider than the sources: at least their channel sum)
+    int ct = 0;
+    for (int i = 0; i < d->nsrc; ++i) ct += d->src[i].channels;
+    if (d->weight_channels < ct) return 1;
+  }
   const int eh = (d->in_h + 2 * d->pad - d->kh) / d->stride + 1;
   const int ew = (d->in_w + 2 * d->pad - d->kw) / d->stride + 1;
   if (eh != d->out_h || ew != d->out_w) return 1;
@@ -1274,7 +1281,7 @@ static hipError_t finish_split(const Epi& e, long long M, int N, hipStream_t st,
   int SL = 1;
   while (SL < 16 && 2 * SL <= e.nsplit / 4 && (MN * SL + 255) / 256 < 2 * g_num_cu) SL *= 2;
   const bool v4 = SL == 1 && N % 4 == 0 && e.ldc % 4 == 0 && !((uintptr_t)e.ws & 15) && !((uintptr_t)e.C & 15) &&
-                  (!e.bias || !((uintptr_t)e.bias & 15));
+                  (!e.bias || !((uintptr_t)e.bias & 15)) && e.col_wtap == 0;
   if (v4) {
     const int blocks4 = (int)std::min<long long>((MN / 4 + 255) / 256, 4096);
     hipLaunchKernelGGL(splitk_finish_v4_kernel, dim3(blocks4), dim3(256), 0, st, e.ws, e.nsplit, MN, N, e.C, e.ldc,
@@ -1284,7 +1291,7 @@ static hipError_t finish_split(const Epi& e, long long M, int N, hipStream_t st,
   const int per = 256 / SL;
   const int blocks = (int)std::min<long long>((MN + per - 1) / per, 4096);
   hipLaunchKernelGGL(splitk_finish_kernel, dim3(blocks), dim3(256), 0, st, e.ws, e.nsplit, MN, N, e.C, e.ldc,
-                     e.bias, e.slope, e.accumulate, SL, ws2, C2, N2);
+                     e.bias, e.slope, e.accumulate, SL, ws2, C2, N2, e.col_ctot, e.col_wtap);
   return hipGetLastError();
 }
 
@@ -1487,7 +1494,7 @@ static hipError_t prepare_v2() {
 }
 
 static bool v2_geometry_ok(const sg2im_conv_desc* d) {
-  return g_v2 && d->compute_dtype == 0 && d->stride == 1 && d->out_h == d->in_h && d->out_w == d->in_w &&
+  return d->weight_channels == 0 && g_v2 && d->compute_dtype == 0 && d->stride == 1 && d->out_h == d->in_h && d->out_w == d->in_w &&
          d->kh * d->kw <= 25 && d->in_h < 32768 && d->in_w < 32768 && d->nsrc <= 2;
 }
 
@@ -1659,7 +1666,7 @@ int sg2im_conv2d_backward_data(const sg2im_conv_desc* d, const float* weight, in
     dim3 grid((unsigned)((Mfull + 255) / 256));
 #define SG2IM_FEWC(NC)                                                                                        \
     hipLaunchKernelGGL((conv_dgrad_fewc_kernel<NC>), grid, dim3(256), lds, stream, dy, ld_dy, weight, cout,   \
-                       g.Ctot, c_begin, d->batch, d->in_h, d->in_w, d->out_h, d->out_w, d->kh, d->kw,        \
+                       g.Wtap, c_begin, d->batch, d->in_h, d->in_w, d->out_h, d->out_w, d->kh, d->kw,        \
                        d->stride, d->pad, dx, ld_dx, accumulate)
     if (c_count == 1) SG2IM_FEWC(1); else if (c_count == 2) SG2IM_FEWC(2); else if (c_count == 3) SG2IM_FEWC(3);
     else SG2IM_FEWC(4);
@@ -1733,7 +1740,7 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
   const int taps = d->kh * d->kw;
   const int Ntot = taps * p.g.Ctot;
   if (p.P == 0) {
-    if (!accumulate && hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)cout * Ntot, stream) != hipSuccess)
+    if (!accumulate && hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)cout * taps * p.g.Wtap, stream) != hipSuccess)
       return SG2IM_ERR_HIP;
     if (!accumulate && dbias && hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)cout, stream) != hipSuccess)
       return SG2IM_ERR_HIP;
@@ -1749,8 +1756,8 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
                             can_split, 2, !v4, [&](int bn) { return (long long)(Ntot + bn - 1) / bn; });
   p.ntile_c = 0;
   const int ntiles_n = (Ntot + pl.bn - 1) / pl.bn;
-  (void)Ctot;
-  p.e = Epi{dweight, (long long)Ntot, nullptr, 1.f, accumulate, workspace, pl.nsplit};
+  p.e = Epi{dweight, (long long)taps * p.g.Wtap, nullptr, 1.f, accumulate, workspace, pl.nsplit};
+  if (p.g.Wtap != Ctot) { p.e.col_ctot = Ctot; p.e.col_wtap = p.g.Wtap; }     // (see Epi: per-tap destination stride)
   p.dbias = dbias;
   p.ws_bias = pl.nsplit > 1 ? workspace + (size_t)pl.nsplit * cout * Ntot : nullptr;
   hipError_t err;

@@ -44,7 +44,8 @@ struct ConvGeom {
   Src s0, s1, s2, s3;      // unused sources have C == 0 (named members: a dynamically indexed
                            // array inside a by-value kernel argument is demoted to scratch)
   int nsrc;
-  int Ctot;                // sum of src[i].C  (inner size of a weight row per tap)
+  int Ctot;                // sum of src[i].C  (channels of the virtual concat = K per tap)
+  int Wtap;                // floats per tap of a WEIGHT row (>= Ctot; sg2im_conv_desc.weight_channels)
   int NB, H, W;            // batch and *logical* input size (after upsampling)
   int Ho, Wo;              // output size
   int KH, KW, stride, pad;
@@ -58,7 +59,13 @@ struct Epi {
   int accumulate;          // 1: C += result
   float* ws;               // split-K partials [nsplit][M][N]; used when nsplit > 1
   int nsplit;
+  int col_ctot, col_wtap;  // weight gradients of a layer whose weight rows hold col_wtap > col_ctot floats per
+                           // tap: GEMM column n = tap * col_ctot + c lands in destination column
+                           // tap * col_wtap + c (0, 0: identity)
 };
+__device__ __forceinline__ int epi_col(const Epi& e, int n) {
+  return e.col_wtap ? (n / e.col_ctot) * e.col_wtap + n % e.col_ctot : n;
+}
 
 __device__ __forceinline__ int kperm(int s, int h) { return 8 * (s >> 2) + 4 * h + (s & 3); }
 
@@ -212,6 +219,7 @@ __device__ __forceinline__ void epilogue(const Epi& e, int M, int N, int nlimit,
     const int n = n0 + wn0 + tn * 32 + j;
     if (n >= nlimit) continue;
     const float bv = (e.nsplit == 1 && e.bias) ? e.bias[n] : 0.f;
+    const int ncol = epi_col(e, n);
     #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       #pragma unroll
@@ -223,7 +231,7 @@ __device__ __forceinline__ void epilogue(const Epi& e, int M, int N, int nlimit,
           e.ws[((long long)split * M + m) * N + n] = v;
         } else {
           v = leaky(v + bv, e.slope);
-          float* dst = e.C + rowmap(m) * e.ldc + n;
+          float* dst = e.C + rowmap(m) * e.ldc + ncol;
           if (e.accumulate) v += *dst;
           *dst = v;
         }

@@ -526,7 +526,8 @@ def _conv_param_grads(desc, dy, cout, w_phys_shape, need_w, need_b, W=None, b=No
       ops.conv2d_backward_weight(desc, dy, cout, cout, sk, accumulate=True, dbias=skb)
       need_b = need_b and skb is None
     else:
-      dw = _new(dy, *w_phys_shape)
+      # (weight rows wider than the sources: the columns the kernel does not write are exact zeros)
+      dw = torch.zeros(*w_phys_shape, dtype=torch.float32, device=dy.device) if desc.weight_channels else _new(dy, *w_phys_shape)
       if need_b and skb is None:
         db = _new(dy, cout)
         need_b = False
@@ -561,6 +562,14 @@ def _bn_grad_bufs(like, C, gamma, beta, need_g, need_b):
   return dg, db, False, dg, db
 
 
+def _crn_conv0_desc(lay, feat_src, N, h, w, W0p):
+  """descriptor of a refinement module's first convolution: [layout level, previous features]; the first
+  module has no previous features (the reference's all-zero channel, see RefinementFn._forward)"""
+  if feat_src is None:
+    return conv_desc([nhwc_src(lay)], N, h, w, 3, 3, 1, 1, weight_channels=W0p.size(1))
+  return conv_desc([nhwc_src(lay), feat_src], N, h, w, 3, 3, 1, 1)
+
+
 class RefinementFn(Function):
   """RefinementNetwork.forward (reference sg2im/crn.py:88-111) on an NHWC layout.
 
@@ -589,8 +598,11 @@ class RefinementFn(Function):
     if h0 == 0 or w0 == 0:
       raise AssertionError('too many refinement modules for this image size')     # crn.py:103-104
     layout = layout.contiguous()
-    feats = torch.zeros(N, h0, w0, 1, dtype=torch.float32, device=layout.device)   # crn.py:105
-    feat_src = nhwc_src(feats, up=1)
+    # crn.py:105 feeds the first module a constant all-zero 1-channel feature map: it adds nothing to the
+    # convolution and its weight-gradient column is exactly zero, so the first conv0 runs over the layout
+    # channels only, on weight rows that are one channel wider (sg2im_conv_desc.weight_channels) - with the
+    # zero channel its 161 input channels would fall off the vector loaders
+    feat_src = None
     saved = []
     # layout pyramid (crn.py:62 pools the full-resolution layout once per module): each level is
     # the 2x2 mean of the next finer one - the same value up to fp32 summation order, with the
@@ -615,7 +627,7 @@ class RefinementFn(Function):
       W0p, b0, W1p, b1 = convp[4 * i:4 * i + 4]
       C = W0p.size(0)
       bn0, bn1 = bns[i]
-      d0 = conv_desc([nhwc_src(lay), feat_src], N, h, w, 3, 3, 1, 1)
+      d0 = _crn_conv0_desc(lay, feat_src, N, h, w, W0p)
       y0 = ops.conv2d_forward(d0, _cl_weight(W0p), C, b0, _new(layout, N, h, w, C), C)
       st0 = ops.bn_stats(y0, N * h * w, C, C, bn0, training, BN_EPS, BN_MOMENTUM)
       src0 = activated(y0, st0, 0)
@@ -711,8 +723,8 @@ class RefinementFn(Function):
       # (dy1's buffer is recycled for dy0 unless a side-stream weight gradient may still be reading it)
       dy0 = ops.bn_act_backward(_fptr(gz0), C, 0, N, h, w, y0, C, C, g0, st0, slope, training,
                                 _new(g, N, h, w, C) if side.on else dy1, dg0, db0n, acc0)
-      Cprev = feat_src.channels
-      d0 = conv_desc([nhwc_src(lay), feat_src], N, h, w, 3, 3, 1, 1)
+      Cprev = feat_src.channels if feat_src is not None else W0p.size(1) - Cl
+      d0 = _crn_conv0_desc(lay, feat_src, N, h, w, W0p)
       side.barrier()
       if need_layout:
         dl = _new(g, N, h, w, Cg)

@@ -213,8 +213,9 @@ V2_MATERIALIZE = os.environ.get('SG2IM_V2', '0') == '1'
 CONV_COMPUTE = 0
 
 
-def conv_desc(srcs, batch, in_h, in_w, kh=1, kw=1, stride=1, pad=0, compute=None):
+def conv_desc(srcs, batch, in_h, in_w, kh=1, kw=1, stride=1, pad=0, compute=None, weight_channels=0):
   d = ConvDesc()
+  d.weight_channels = int(weight_channels)     # (weight rows wider than the sources: include/sg2im_hip.h)
   if compute is None:
     compute = CONV_COMPUTE if (kh * kw > 1 or in_h * in_w > 1) else 0
   d.compute_dtype = int(compute)

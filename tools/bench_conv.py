@@ -51,19 +51,21 @@ def main():
     srcs = []
     if C0:
       srcs.append(ops.nhwc_src(torch.randn(N, H, H, C0, device=D)))
-    if C1:
+    if C1 > 1:
       srcs.append(ops.nhwc_src(torch.randn(N, H // 2, H // 2, C1, device=D), 1))
-    d = ops.conv_desc(srcs, N, H, H, k, k, s, p)
+    # (C1 == 1: the first refinement module - the all-zero feature channel is left out, the weight rows keep it)
+    d = ops.conv_desc(srcs, N, H, H, k, k, s, p, weight_channels=C0 + C1 if C1 == 1 else 0)
     Ct = C0 + C1
     W = torch.randn(Cout, k, k, Ct, device=D) * 0.01
     b = torch.randn(Cout, device=D)
     y = torch.empty(N, d.out_h, d.out_w, Cout, device=D)
     gy = torch.randn_like(y)
-    dx = torch.empty(N, H, H, Ct, device=D)
+    Cx = C0 if C1 == 1 else Ct
+    dx = torch.empty(N, H, H, Cx, device=D)
     dw = torch.empty_like(W)
     gf = 2.0 * N * d.out_h * d.out_w * Cout * Ct * k * k / 1e9
     t1 = timeit(lambda: ops.conv2d_forward(d, W, Cout, b, y, Cout))
-    t2 = timeit(lambda: ops.conv2d_backward_data(d, W, Cout, gy, Cout, 0, Ct, dx, Ct))
+    t2 = timeit(lambda: ops.conv2d_backward_data(d, W, Cout, gy, Cout, 0, Cx, dx, Cx))
     t3 = timeit(lambda: ops.conv2d_backward_weight(d, gy, Cout, Cout, dw))
     print('%-10s %9.2f | %8.3f %7.1f | %8.3f %7.1f | %8.3f %7.1f' % (name, gf, t1, gf / t1, t2, gf / t2, t3, gf / t3), flush=True)
     tot['fwd'] += t1; tot['dgrad'] += t2; tot['wgrad'] += t3; totf += gf

@@ -113,6 +113,39 @@ def conv_case(name, N, H, W, C0, C1, up1, Cout, k, stride, pad, bnact=False, see
     report(name + ' dgrad1', got, ref)
 
 
+def conv_case_wide_weight(name, N, H, W, C0, Wch, Cout, k, pad, seed=0):
+  """sg2im_conv_desc.weight_channels: weight rows with Wch > C0 channels per tap, sources supplying the first
+  C0 - the reference computes with the missing channels fed zeros (crn.py:105's all-zero feature channel):
+  same forward, same input gradient, and the extra channels' weight gradient is exactly zero."""
+  g = torch.Generator().manual_seed(seed)
+  x0 = torch.randn(N, C0, H, W, generator=g)
+  Wt = torch.randn(Cout, Wch, k, k, generator=g) / (Wch * k * k) ** 0.5
+  b = torch.randn(Cout, generator=g)
+  xr = x0.clone().requires_grad_(True)
+  Wr, br = Wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+  y = F.conv2d(torch.cat([xr, torch.zeros(N, Wch - C0, H, W)], 1), Wr, br, padding=pad)
+  gy = torch.randn(y.shape, generator=g)
+  y.backward(gy)
+  nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(D)
+  d = ops.conv_desc([ops.nhwc_src(nhwc(x0))], N, H, W, k, k, 1, pad, weight_channels=Wch)
+  Wp = Wt.permute(0, 2, 3, 1).contiguous().to(D)
+  out = torch.empty(N, d.out_h, d.out_w, Cout, device=D)
+  ops.conv2d_forward(d, Wp, Cout, b.to(D), out, Cout)
+  report(name + ' fwd', out.permute(0, 3, 1, 2), y)
+  gyd = nhwc(gy)
+  dw = torch.full((Cout, k, k, Wch), 7.0, device=D)          # the kernel must leave the extra columns alone
+  db = torch.empty(Cout, device=D)
+  ops.conv2d_backward_weight(d, gyd, Cout, Cout, dw, dbias=db)
+  report(name + ' wgrad (supplied channels)', dw[..., :C0].permute(0, 3, 1, 2), Wr.grad[:, :C0])
+  report(name + ' wgrad leaves the other columns untouched', dw[..., C0:], torch.full((Cout, k, k, Wch - C0), 7.0))
+  report(name + ' bias grad', db, br.grad)
+  ops.conv2d_backward_weight(d, gyd, Cout, Cout, dw, accumulate=True, dbias=db)
+  report(name + ' wgrad accumulate', dw[..., :C0].permute(0, 3, 1, 2), 2 * Wr.grad[:, :C0])
+  dx0 = torch.empty(N, H, W, C0, device=D)
+  ops.conv2d_backward_data(d, Wp, Cout, gyd, Cout, 0, C0, dx0, C0)
+  report(name + ' dgrad', dx0.permute(0, 3, 1, 2), xr.grad)
+
+
 def conv_case_bf16(name, N, H, W, C0, C1, up1, Cout, k, stride, pad, bnact=False, seed=0):
   """compute_dtype 1: the kernels round both operands to bf16 and accumulate in fp32; the reference
   does the same with torch (operands through .bfloat16().float(), fp32 convolution), so the two
@@ -203,6 +236,11 @@ def sec_conv():
   conv_case('v2 conv3x3 96->80 19x21 (ragged rows / columns)', 5, 19, 21, 96, 0, 0, 80, 3, 1, 1)
   conv_case('v2 conv5x5 64->96 24x24 pad2', 6, 24, 24, 64, 0, 0, 96, 5, 1, 2)
   conv_case('v2 conv1x1 128->128 32x32', 8, 32, 32, 128, 0, 0, 128, 1, 1, 0)
+  # weight rows wider than the sources (sg2im_conv_desc.weight_channels): the first refinement module
+  conv_case_wide_weight('conv3x3 160 of 161 -> 1024 4x4 (m0.conv0, split-K)', 32, 4, 4, 160, 161, 1024, 3, 1)
+  conv_case_wide_weight('conv3x3 128 of 129 -> 96 8x8', 4, 8, 8, 128, 129, 96, 3, 1)
+  conv_case_wide_weight('conv3x3 6 of 9 -> 20 5x7 (scalar loaders)', 3, 5, 7, 6, 9, 20, 3, 1)
+  conv_case_wide_weight('conv1x1 64 of 72 -> 64 16x16', 4, 16, 16, 64, 72, 64, 1, 0)
 
 
 def sec_linear():
