@@ -141,6 +141,14 @@ int sg2im_segment_sum(const float* src_a, long long ld_a, int n_a, const float* 
  * divided by max(1, row_ptr[idx[i]+1]-row_ptr[idx[i]])  (backward of the 'avg' pooling). */
 int sg2im_gather_rows(const float* src, long long ld_src, const long long* idx, int n, int width,
                       const int* row_ptr, float* dst, long long ld_dst, hipStream_t stream);
+/* Backward of the GraphTripleConv pooling block (graph.py:98-114 under autograd) in one launch:
+ * d_new_t[t] = [ d_pooled[s[t]] (/ count) | g_pred[t] (zeros if NULL) | d_pooled[o[t]] (/ count) ] * leaky'_slope(new_t[t])
+ * with count = max(1, row_ptr[r+1] - row_ptr[r]) when row_ptr != NULL ('avg' pooling), new_t the ACTIVATED net1
+ * output [T][2*hidden + dout].  Equals sg2im_gather_rows x2 + sg2im_copy_2d + sg2im_act_backward, bit for bit. */
+int sg2im_gconv_pool_backward(const float* d_pooled, long long ld_dp, const long long* s_idx,
+                              const long long* o_idx, int n_triples, const int* row_ptr, const float* g_pred,
+                              long long ld_gp, const float* new_t, long long ld_nt, int hidden, int dout,
+                              float slope, float* d_new_t, long long ld_out, hipStream_t stream);
 /* dst[r][0:width] = src[r][0:width] for strided row matrices (the new_p column slice of the
  * net1 output, graph.py:88, travelling through backward) */
 int sg2im_copy_2d(const float* src, long long ld_src, float* dst, long long ld_dst, long long rows,

@@ -42,6 +42,7 @@ _SIGNATURES = {
   'sg2im_csr_build': [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P],
   'sg2im_segment_sum': [_P, _L, _I, _P, _L, _P, _P, _I, _I, _I, _I, _P, _L, _P],
   'sg2im_gather_rows': [_P, _L, _P, _I, _I, _P, _P, _L, _P],
+  'sg2im_gconv_pool_backward': [_P, _L, _P, _P, _I, _P, _P, _L, _P, _L, _I, _I, _F, _P, _L, _P],
   'sg2im_copy_2d': [_P, _L, _P, _L, _L, _I, _P],
   'sg2im_layout_forward': [_P, _L, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P],
   'sg2im_layout_backward_workspace': [_I, _I, _I, _I],

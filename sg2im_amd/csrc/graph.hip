@@ -176,6 +176,37 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, long long ld_s
   }
 }
 
+// Backward of the GraphTripleConv pooling (graph.py:98-114) in one launch: row t of d(new_t) is
+//   [ d_pooled[s[t]] / cnt(s[t]) | g_pred[t] | d_pooled[o[t]] / cnt(o[t]) ]  *  relu'(new_t[t])
+// - the two row gathers (divided by the row's entry count for 'avg' pooling), the copy of the predicate
+// gradient into the middle column block and the activation backward of net1's last layer, which were
+// four launches of the dependent chain.  Same operations per element (IEEE divide, multiply by 1 / slope).
+__global__ void gconv_pool_bwd_kernel(const float* __restrict__ dpooled, long long ld_dp,
+                                      const long long* __restrict__ s_idx, const long long* __restrict__ o_idx,
+                                      const int* __restrict__ row_ptr, const float* __restrict__ g_pred,
+                                      long long ld_gp, const float* __restrict__ new_t, long long ld_nt,
+                                      int H, int Dout, float slope, float* __restrict__ out, long long ld_out) {
+  const int t = blockIdx.x;
+  const long long s = s_idx[t], o = o_idx[t];
+  float ds = 1.f, dv = 1.f;
+  if (row_ptr) {
+    ds = (float)max(1, row_ptr[s + 1] - row_ptr[s]);
+    dv = (float)max(1, row_ptr[o + 1] - row_ptr[o]);
+  }
+  const int NT = 2 * H + Dout;
+  const float* ps = dpooled + s * ld_dp;
+  const float* po = dpooled + o * ld_dp;
+  const float* y = new_t + (long long)t * ld_nt;
+  float* d = out + (long long)t * ld_out;
+  for (int c = threadIdx.x; c < NT; c += blockDim.x) {
+    float v;
+    if (c < H) v = row_ptr ? ps[c] / ds : ps[c];
+    else if (c < H + Dout) v = g_pred ? g_pred[(long long)t * ld_gp + (c - H)] : 0.f;
+    else v = row_ptr ? po[c - H - Dout] / dv : po[c - H - Dout];
+    d[c] = v * (y[c] > 0.f ? 1.f : slope);
+  }
+}
+
 __global__ void copy_2d_kernel(const float* __restrict__ src, long long ld_src, float* __restrict__ dst,
                                long long ld_dst, long long rows, int width) {
   const long long total = rows * width;
@@ -233,6 +264,20 @@ int sg2im_copy_2d(const float* src, long long ld_src, float* dst, long long ld_d
   if (rows == 0) return SG2IM_OK;
   const int blocks = (int)std::min<long long>((rows * width + 255) / 256, 4096);
   hipLaunchKernelGGL(copy_2d_kernel, dim3(blocks), dim3(256), 0, stream, src, ld_src, dst, ld_dst, rows, width);
+  return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+}
+
+int sg2im_gconv_pool_backward(const float* d_pooled, long long ld_dp, const long long* s_idx,
+                              const long long* o_idx, int n_triples, const int* row_ptr, const float* g_pred,
+                              long long ld_gp, const float* new_t, long long ld_nt, int hidden, int dout,
+                              float slope, float* d_new_t, long long ld_out, hipStream_t stream) {
+  if (n_triples == 0) return SG2IM_OK;
+  if (n_triples < 0 || hidden < 1 || dout < 0 || !d_pooled || !s_idx || !o_idx || !new_t || !d_new_t)
+    return SG2IM_ERR_ARG;
+  const int NT = 2 * hidden + dout;
+  const int threads = std::min(256, std::max(64, (NT + 63) / 64 * 64));
+  hipLaunchKernelGGL(gconv_pool_bwd_kernel, dim3(n_triples), dim3(threads), 0, stream, d_pooled, ld_dp, s_idx, o_idx,
+                     row_ptr, g_pred, ld_gp, new_t, ld_nt, hidden, dout, slope, d_new_t, ld_out);
   return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
 }
 

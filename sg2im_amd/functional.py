@@ -389,16 +389,12 @@ class GraphTripleConvFn(Function):
     dp3 = _act_bwd_rows(dh2, h2, 0.0)
     dpooled, dW2a, db2a = _linear_bwd(conv_desc([rows_src(pooled)], O, 1, 1), W2a, dp3, True, ni[10], ni[11], H, b2a)
     # pooling backward: rows of dpooled go back to the s / o column blocks (divided by the count)
+    # (one launch: the two row gathers, the copy of g_pred into the middle block and the ReLU backward of
+    # net1's output)
     d_new_t = _new(obj_vecs, T, NT)
-    cavg = csr if avg else None
-    ops.gather_rows(dpooled, s_idx, d_new_t[:, :H], cavg)
-    ops.gather_rows(dpooled, o_idx, d_new_t[:, H + Dout:], cavg)
-    if g_pred is None:
-      d_new_t[:, H:H + Dout].zero_()
-    else:
-      ops.copy_2d(g_pred, d_new_t[:, H:H + Dout])
+    dp2 = ops.gconv_pool_backward(dpooled, s_idx, o_idx, csr if avg else None,
+                                  None if g_pred is None else g_pred.contiguous(), new_t, H, Dout, 0.0, d_new_t)
     # net1
-    dp2 = ops.act_backward(_fptr(d_new_t), NT, 0, T, 1, 1, new_t, NT, NT, 0.0, d_new_t) if T > 0 else d_new_t
     dh1, dW1b, db1b = _linear_bwd(conv_desc([rows_src(h1)], T, 1, 1), W1b, dp2, True, ni[8], ni[9], H, b1b)
     dp1 = _act_bwd_rows(dh1, h1, 0.0)
     d1 = conv_desc([rows_src(obj_vecs, s_idx), rows_src(pred_vecs), rows_src(obj_vecs, o_idx)], T, 1, 1)

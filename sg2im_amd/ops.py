@@ -374,6 +374,18 @@ def gather_rows(src, idx, out, csr_for_average=None):
   return out
 
 
+def gconv_pool_backward(dpooled, s_idx, o_idx, csr_for_average, g_pred, new_t, hidden, dout, slope, out):
+  """d(new_t) of one GraphTripleConv layer from d(pooled) and d(new_p): one launch (see the C header)"""
+  pd, ldd = rows_ld(dpooled)
+  pn, ldn = rows_ld(new_t)
+  po, ldo = rows_ld(out)
+  pg, ldg = rows_ld(g_pred) if g_pred is not None else (None, 0)
+  rp = _i32(csr_for_average.row_ptr) if csr_for_average is not None else None
+  call('sg2im_gconv_pool_backward', pd, ldd, _i64(s_idx), _i64(o_idx), s_idx.numel(), rp, pg, ldg, pn, ldn,
+       int(hidden), int(dout), float(slope), po, ldo, _stream())
+  return out
+
+
 def copy_2d(src, out):
   ps, lds = rows_ld(src)
   po, ldo = rows_ld(out)
