@@ -38,6 +38,8 @@ _SIGNATURES = {
   'sg2im_conv2d_forward': [_D, _P, _I, _P, _F, _P, _L, _I, _P, _Z, _P],
   'sg2im_conv2d_backward_data': [_D, _P, _I, _P, _I, _I, _I, _P, _L, _I, _P, _Z, _P],
   'sg2im_conv2d_backward_weight': [_D, _P, _I, _I, _P, _P, _I, _P, _Z, _P],
+  'sg2im_conv2d_backward_weight_group': [_I, POINTER(_D), POINTER(_P), POINTER(_I), POINTER(_I), POINTER(_P), POINTER(_P),
+                                         _I, _P, _Z, _P],
   'sg2im_column_sum': [_P, _L, _I, _L, _P, _I, _P, _P],
   'sg2im_csr_build': [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P],
   'sg2im_segment_sum': [_P, _L, _I, _P, _L, _P, _P, _I, _I, _I, _I, _P, _L, _P],

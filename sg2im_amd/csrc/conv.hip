@@ -717,8 +717,10 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kerne
 // weight gradient
 // ---------------------------------------------------------------------------
 // PP: the two halves own the column tiles 2*blockIdx.x + {0, 1} of the same row tile / K split
-template <int BM, int BN, int VEC, bool GATHER, bool PP = false, bool H = false>
-__global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_wgrad_kernel(const WgradParams p) {
+// (the body is a device function of (params, block coordinates) so that the grouped launch below can run it
+// for one of several problems)
+template <int BM, int BN, int VEC, bool GATHER, bool PP, bool H>
+__device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int bidx, const int bidy, const int bidz) {
   extern __shared__ __attribute__((aligned(16))) float smem_all[];
   constexpr int NVA = BM / 32, NVB = BN / 32;
   constexpr int AF = TileBytes<H, BM, true>::value / 4, BF = TileBytes<H, BN, true>::value / 4;
@@ -729,7 +731,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_wgrad_kerne
   float* const smem = smem_all + half * (TilePipe<BM, BN>::LDS_IMAGES * STAGE);
   // (an XCD-pinned 1-D grid - every column tile of a reduction slice on one XCD's L2 - was
   // measured: no gain on the large layers, so the plain 3-D grid stays)
-  const int ntile_x = blockIdx.x * (PP ? 2 : 1) + half, mtile = blockIdx.y, split = blockIdx.z;
+  const int ntile_x = bidx * (PP ? 2 : 1) + half, mtile = bidy, split = bidz;
   const int m0 = mtile * BM;
   const int per = (p.iters + p.e.nsplit - 1) / p.e.nsplit;
   const int it_begin = split * per;
@@ -900,7 +902,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_wgrad_kerne
   }
   epilogue<BM, BN>(p.e, p.Cout, Ntot, Ntot, m0, n0, wm0, wn0, lane, split, acc);
   // (workgroup-uniform condition: in the ping-pong form both halves must reach the barrier below)
-  if (p.dbias != nullptr && blockIdx.x == 0) {
+  if (p.dbias != nullptr && bidx == 0) {
     // the 256 / QA threads that share a channel quad hold sums over disjoint pixel rows:
     // combine them through LDS in thread order (fixed order -> reproducible)
     constexpr int GROUPS = NTHREADS / QA;
@@ -923,6 +925,34 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_wgrad_kerne
       }
     }
   }
+}
+
+template <int BM, int BN, int VEC, bool GATHER, bool PP = false, bool H = false>
+__global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_wgrad_kernel(const WgradParams p) {
+  conv_wgrad_body<BM, BN, VEC, GATHER, PP, H>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Grouped launch: up to four independent weight-gradient problems (the four linear layers of a
+// GraphTripleConv layer, whose weight gradients are leaves of the backward graph) as ONE grid - the
+// dependent chain of small launches they sit in gets 1 launch + 1 finish instead of 4 + 4.  Workgroup b
+// belongs to problem i with first[i] <= b < first[i + 1]; inside it the usual (column tile, row tile, split).
+// The problem is selected by a static if-chain: indexing the by-value argument dynamically would demote
+// it to scratch.  64x64 tiles, float4 loaders, row-gather capable sources.
+constexpr int kGroupMax = 4;
+struct WgradGroup { WgradParams p[kGroupMax]; int first[kGroupMax + 1]; };
+__global__ __launch_bounds__(NTHREADS) void conv_wgrad_group_kernel(const WgradGroup g) {
+  const int b = blockIdx.x;
+#define SG2IM_GROUP_CASE(i)                                                        \
+  if (b < g.first[i + 1]) {                                                        \
+    const int l = b - g.first[i];                                                  \
+    const int tiles = g.p[i].ntiles_n * g.p[i].ntiles_m;                           \
+    const int sp = l / tiles, t = l - sp * tiles;                                  \
+    const int ty = t / g.p[i].ntiles_n, tx = t - ty * g.p[i].ntiles_n;             \
+    conv_wgrad_body<64, 64, 4, true, false, false>(g.p[i], tx, ty, sp);            \
+    return;                                                                        \
+  }
+  SG2IM_GROUP_CASE(0) SG2IM_GROUP_CASE(1) SG2IM_GROUP_CASE(2) SG2IM_GROUP_CASE(3)
+#undef SG2IM_GROUP_CASE
 }
 
 // ---------------------------------------------------------------------------
@@ -983,11 +1013,16 @@ __global__ void splitk_finish_kernel(const float* __restrict__ ws, int nsplit, l
 
 // float4 form of the SL == 1 case (N, ldc multiples of 4, 16-byte aligned buffers): one thread
 // per four adjacent outputs of a row; same ascending split order per output.
-__global__ void splitk_finish_v4_kernel(const float* __restrict__ ws, int nsplit, long long MN, int N,
-                                        float* __restrict__ C, long long ldc, const float* __restrict__ bias,
-                                        float slope, int accumulate,
-                                        const float* __restrict__ ws2, float* __restrict__ C2, int N2) {
-  if (C2 != nullptr && blockIdx.x == 0) {
+struct FinishArgs {
+  const float* ws; int nsplit; long long MN; int N; float* C; long long ldc; const float* bias; float slope;
+  int accumulate; const float* ws2; float* C2; int N2;
+};
+__device__ __forceinline__ void splitk_finish_v4_body(const float* __restrict__ ws, int nsplit, long long MN, int N,
+                                                      float* __restrict__ C, long long ldc,
+                                                      const float* __restrict__ bias, float slope, int accumulate,
+                                                      const float* __restrict__ ws2, float* __restrict__ C2, int N2,
+                                                      const int blk, const int nblk) {
+  if (C2 != nullptr && blk == 0) {
     __shared__ float part[256];
     constexpr int SLB = 8, PERB = 256 / SLB;
     const int jl = threadIdx.x % PERB, sl2 = threadIdx.x / PERB;
@@ -1007,7 +1042,7 @@ __global__ void splitk_finish_v4_kernel(const float* __restrict__ ws, int nsplit
   }
   const long long Q = MN >> 2;
   const float4* __restrict__ w4 = reinterpret_cast<const float4*>(ws);
-  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += (long long)gridDim.x * blockDim.x) {
+  for (long long q = (long long)blk * blockDim.x + threadIdx.x; q < Q; q += (long long)nblk * blockDim.x) {
     float4 v = w4[q];
     for (int s = 1; s < nsplit; ++s) {
       const float4 u = w4[(long long)s * Q + q];
@@ -1025,6 +1060,28 @@ __global__ void splitk_finish_v4_kernel(const float* __restrict__ ws, int nsplit
     if (accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
     *dst = v;
   }
+}
+
+__global__ void splitk_finish_v4_kernel(const float* __restrict__ ws, int nsplit, long long MN, int N,
+                                        float* __restrict__ C, long long ldc, const float* __restrict__ bias,
+                                        float slope, int accumulate,
+                                        const float* __restrict__ ws2, float* __restrict__ C2, int N2) {
+  splitk_finish_v4_body(ws, nsplit, MN, N, C, ldc, bias, slope, accumulate, ws2, C2, N2, blockIdx.x, gridDim.x);
+}
+
+// the finishes of a grouped launch (conv_wgrad_group_kernel) in one grid
+struct FinishGroup { FinishArgs a[kGroupMax]; int first[kGroupMax + 1]; };
+__global__ void splitk_finish_v4_group_kernel(const FinishGroup g) {
+  const int b = blockIdx.x;
+#define SG2IM_GROUP_CASE(i)                                                                                  \
+  if (b < g.first[i + 1]) {                                                                                  \
+    const FinishArgs& a = g.a[i];                                                                            \
+    splitk_finish_v4_body(a.ws, a.nsplit, a.MN, a.N, a.C, a.ldc, a.bias, a.slope, a.accumulate, a.ws2, a.C2, \
+                          a.N2, b - g.first[i], g.first[i + 1] - g.first[i]);                                \
+    return;                                                                                                  \
+  }
+  SG2IM_GROUP_CASE(0) SG2IM_GROUP_CASE(1) SG2IM_GROUP_CASE(2) SG2IM_GROUP_CASE(3)
+#undef SG2IM_GROUP_CASE
 }
 
 // Data gradient w.r.t. a few (<= 4) input channels - the RGB input of the discriminators'
@@ -1582,6 +1639,7 @@ int sg2im_init(void) {
   SG2IM_PREP((prepare_wgrad<64, 64, 1, false>()));
 #undef SG2IM_PREP_TILES
 #undef SG2IM_PREP
+  if (e == hipSuccess) e = ensure_lds(conv_wgrad_group_kernel, wgrad_lds<64, 64>());
   if (e == hipSuccess) e = prepare_v2();
   if (e != hipSuccess) return SG2IM_ERR_HIP;
   hipLaunchKernelGGL(init_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)0, (int*)nullptr);
@@ -1780,6 +1838,79 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
   }
   if (err != hipSuccess) return SG2IM_ERR_HIP;
   return finish_split(p.e, cout, Ntot, stream, p.ws_bias, dbias, cout) == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+}
+
+// Up to kGroupMax weight gradients (+ their bias gradients) as one launch + one finish launch: the four
+// linear layers of a GraphTripleConv layer.  Every problem must be float4-loadable (channels, ld_dy, cout
+// multiples of 4, 16-byte aligned buffers) and small enough for 64x64 tiles to be the right shape; returns
+// SG2IM_ERR_ARG without launching anything otherwise (the caller then uses sg2im_conv2d_backward_weight).
+int sg2im_conv2d_backward_weight_group(int n, const sg2im_conv_desc* const* descs, const float* const* dys,
+                                       const int* ld_dys, const int* couts, float* const* dweights,
+                                       float* const* dbiases, int accumulate, float* workspace,
+                                       size_t workspace_bytes, hipStream_t stream) {
+  if (n < 1 || n > kGroupMax || !descs || !dys || !ld_dys || !couts || !dweights || !dbiases) return SG2IM_ERR_ARG;
+  WgradGroup wg;
+  FinishGroup fg;
+  int blocks = 0, fblocks = 0;
+  size_t ws_off = 0;                                   // floats
+  bool any_split = false;
+  wg.first[0] = fg.first[0] = 0;
+  for (int i = 0; i < kGroupMax; ++i) {
+    if (i >= n) { wg.p[i] = wg.p[0]; wg.first[i + 1] = wg.first[i]; fg.a[i] = FinishArgs{}; fg.first[i + 1] = fg.first[i]; continue; }
+    const sg2im_conv_desc* d = descs[i];
+    const int cout = couts[i], ld_dy = ld_dys[i];
+    if (check_desc(d) || !dys[i] || !dweights[i] || cout < 1 || ld_dy < cout || d->compute_dtype != 0) return SG2IM_ERR_ARG;
+    WgradParams& p = wg.p[i];
+    fill_geom(p.g, d);
+    p.dY = dys[i]; p.ldy = ld_dy; p.Cout = cout; p.background = 0;
+    p.P = d->batch * d->out_h * d->out_w;
+    if (p.P == 0 || (double)p.P * ld_dy * 4.0 >= 2147483648.0) return SG2IM_ERR_ARG;
+    const bool v4 = geom_vec4(p.g) && (cout % 4 == 0) && (ld_dy % 4 == 0) && !((uintptr_t)dys[i] & 15) &&
+                    !((uintptr_t)dweights[i] & 15);
+    if (!v4 || p.g.Wtap != p.g.Ctot) return SG2IM_ERR_ARG;
+    const int taps = d->kh * d->kw, Ntot = taps * p.g.Ctot;
+    p.iters = (p.P + BK - 1) / BK;
+    const size_t bias_room = dbiases[i] ? 512 * (size_t)cout : 0;                 // floats
+    const size_t avail = workspace && workspace_bytes / sizeof(float) > ws_off + bias_room
+                             ? workspace_bytes / sizeof(float) - ws_off - bias_room : 0;
+    const bool can_split = avail > 0;
+    const Plan pl = make_plan(PASS_WGRAD, cout, Ntot, p.iters, (long long)cout * Ntot, avail * sizeof(float), can_split, 2,
+                              true, [&](int bn) { return (long long)(Ntot + bn - 1) / bn; });
+    p.ntile_c = 0;
+    p.ntiles_n = (Ntot + 63) / 64;
+    p.ntiles_m = (cout + 63) / 64;
+    float* ws_i = workspace ? workspace + ws_off : nullptr;
+    p.e = Epi{dweights[i], (long long)Ntot, nullptr, 1.f, accumulate, ws_i, pl.nsplit};
+    p.dbias = dbiases[i];
+    p.ws_bias = pl.nsplit > 1 ? ws_i + (size_t)pl.nsplit * cout * Ntot : nullptr;
+    blocks += p.ntiles_n * p.ntiles_m * pl.nsplit;
+    wg.first[i + 1] = blocks;
+    FinishArgs& a = fg.a[i];
+    a = FinishArgs{};
+    if (pl.nsplit > 1) {
+      any_split = true;
+      const long long MN = (long long)cout * Ntot;
+      if (Ntot % 4 || ((uintptr_t)ws_i & 15)) return SG2IM_ERR_ARG;
+      a = FinishArgs{ws_i, pl.nsplit, MN, Ntot, dweights[i], (long long)Ntot, nullptr, 1.f, accumulate, p.ws_bias, dbiases[i], cout};
+      fblocks += (int)std::min<long long>((MN / 4 + 255) / 256, 1024);
+      ws_off += ((size_t)pl.nsplit * cout * Ntot + (dbiases[i] ? (size_t)pl.nsplit * cout : 0) + 3) / 4 * 4;
+    }
+    fg.first[i + 1] = fblocks;
+  }
+  { hipError_t e = prepare_wgrad<64, 64, 4, true>(); if (e != hipSuccess) return SG2IM_ERR_HIP; }
+  static bool group_ready = false;
+  const size_t glds = wgrad_lds<64, 64>();
+  if (!group_ready) {
+    if (ensure_lds(conv_wgrad_group_kernel, glds) != hipSuccess) return SG2IM_ERR_HIP;
+    group_ready = true;
+  }
+  hipLaunchKernelGGL(conv_wgrad_group_kernel, dim3(blocks), dim3(NTHREADS), glds, stream, wg);
+  if (hipGetLastError() != hipSuccess) return SG2IM_ERR_HIP;
+  if (any_split) {
+    hipLaunchKernelGGL(splitk_finish_v4_group_kernel, dim3(fblocks), dim3(256), 0, stream, fg);
+    if (hipGetLastError() != hipSuccess) return SG2IM_ERR_HIP;
+  }
+  return SG2IM_OK;
 }
 
 }  // extern "C"

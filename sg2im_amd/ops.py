@@ -5,6 +5,7 @@ stream and shapes.  Every function enqueues HIP kernels from libsg2im_hip.so on
 ``torch.cuda.current_stream()`` and returns immediately.  Inputs must live on the GPU;
 anything else raises - there is no CPU path.
 """
+import ctypes
 import os
 from ctypes import byref, c_int, c_longlong, c_void_p
 
@@ -65,6 +66,9 @@ def _i32(t):
 DEFER_WGRAD = os.environ.get('SG2IM_DEFER_WGRAD', '1') != '0'
 DEFERRED = None
 HINT_BACKGROUND = 1
+# only the first BG_COUNT released weight gradients are issued as background launches (occupancy cap): the later
+# ones run after the small-kernel tail is over and may have the whole GPU
+BG_COUNT = int(os.environ.get('SG2IM_BG_COUNT', '6'))        # [measured: all 11: 8.90-8.94, 8: 8.84, 6: 8.81, 4: 8.82, 2: 8.85 ms]
 TAIL_EVENT = None   # optional torch.cuda.Event recorded when the generator backward reaches ...
 TAIL_EVENT_AT = -1  # ... refinement module TAIL_EVENT_AT (counting down), or the layout (-1)
 def _lane(device):
@@ -80,6 +84,8 @@ def _lane(device):
 
 _wgrad_streams = {}
 WGRAD_SIDE = os.environ.get('SG2IM_WGRAD_SIDE', '1') != '0'
+# the four weight gradients of a GraphTripleConv layer as one grouped launch (sg2im_conv2d_backward_weight_group)
+GROUP_WGRAD = os.environ.get('SG2IM_GROUP_WGRAD', '1') != '0'
 
 
 class SideLane(object):
@@ -134,8 +140,9 @@ class SideLane(object):
     ev.record(self.main)
     self.side.wait_event(ev)
     with torch.cuda.stream(self.side):
-      for fn in reversed(self.queue):      # (the layers the optimiser's chain reached last first: 9.88 vs 9.96 ms)
-        fn()
+      # (the layers the data-gradient chain reached last first: 8.80 vs 8.84-8.85 ms in queue order)
+      for k, fn in enumerate(reversed(self.queue)):
+        fn(k < BG_COUNT)
     self.queue = []
     self.used = True
 
@@ -322,6 +329,35 @@ def conv2d_backward_weight(desc, dy, ld_dy, cout, dweight, accumulate=False, dbi
     'sg2im_conv2d_backward_weight', byref(desc), _f(dy), int(ld_dy), int(cout), _f(dweight),
     _f(dbias) if dbias is not None else None, int(accumulate), _f(ws), ws.numel() * 4, _stream()))
   return dweight
+
+
+def conv2d_backward_weight_group(items, accumulate=True):
+  """items: up to 4 tuples (desc, dy (M, cout) dense, cout, dweight, dbias | None) - one launch + one finish
+  launch for all of them (include/sg2im_hip.h).  Returns False (nothing launched) when a problem does not
+  qualify; the caller then uses conv2d_backward_weight per item."""
+  n = len(items)
+  if n < 1 or n > 4:
+    return False
+  ws = workspace(items[0][3].device)
+  D_, P_, I_ = ctypes.POINTER(ConvDesc), c_void_p, ctypes.c_int
+  descs = (D_ * n)(*[ctypes.pointer(it[0]) for it in items])
+  dys = (P_ * n)(*[it[1].data_ptr() for it in items])
+  lds = (I_ * n)(*[int(it[1].stride(0)) if it[1].size(0) > 1 else int(it[2]) for it in items])
+  couts = (I_ * n)(*[int(it[2]) for it in items])
+  dws = (P_ * n)(*[it[3].data_ptr() for it in items])
+  dbs = (P_ * n)(*[(it[4].data_ptr() if it[4] is not None else None) for it in items])
+  if not _lib._inited:
+    _lib.init()
+  lib = _lib.load()
+  rc = lib.sg2im_conv2d_backward_weight_group(n, descs, dys, lds, couts, dws, dbs, int(accumulate), _f(ws),
+                                              ws.numel() * 4, _stream())
+  if rc == 1:                      # SG2IM_ERR_ARG: not groupable, nothing was launched
+    return False
+  if rc != 0:
+    raise _lib.Sg2imHipError('sg2im_conv2d_backward_weight_group failed (%d)' % rc)
+  if not _lib.CAPTURING:
+    _lib.EAGER_EPOCH += 1
+  return True
 
 
 def column_sum(x_ptr, rows, cols, ld, out, accumulate=False):
