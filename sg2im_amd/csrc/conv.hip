@@ -719,7 +719,10 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kerne
 // PP: the two halves own the column tiles 2*blockIdx.x + {0, 1} of the same row tile / K split
 // (the body is a device function of (params, block coordinates) so that the grouped launch below can run it
 // for one of several problems)
-template <int BM, int BN, int VEC, bool GATHER, bool PP, bool H>
+// FR ("fast rows", VEC == 4, no gathers): stride 1 and Wo % BK == 0, so the BK output pixels of a K chunk lie
+// in ONE output row - the chunk's (n, ho) are wave-uniform and a B row is (chunk's first column + its fixed
+// k): no per-row coordinate state, ~6 instead of ~20 VALU per row and chunk.
+template <int BM, int BN, int VEC, bool GATHER, bool PP, bool H, bool FR = false>
 __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int bidx, const int bidy, const int bidz) {
   extern __shared__ __attribute__((aligned(16))) float smem_all[];
   constexpr int NVA = BM / 32, NVB = BN / 32;
@@ -780,6 +783,9 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int 
   const int dn = BK / HoWo, drem = BK - dn * HoWo, dh = drem / g.Wo, dw = drem - dh * g.Wo;
   const int dhs = dh * g.stride, dws = dw * g.stride, WoS = g.Wo * g.stride, HoS = g.Ho * g.stride;
   const int wlim = WoS - g.pad, hlim = HoS - g.pad;
+  // FR: wave-uniform cursor of the chunk's first pixel, per-row constants
+  int c_n = 0, c_ho = 0, c_wo = 0, kx[NVB];
+  const int dkh = bkh - g.pad;
   #pragma unroll
   for (int i = 0; i < NVB; ++i) {
     const int pix = it_begin * BK + bk0 + (1024 / BN) * i;
@@ -787,6 +793,13 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int 
     const int rem = pix - bn_[i] * HoWo;
     const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
     bhb[i] = ho * g.stride - g.pad; bwb[i] = wo * g.stride - g.pad;
+    kx[i] = bk0 + (1024 / BN) * i + bkw - g.pad;
+  }
+  if (FR) {
+    const int pix0 = it_begin * BK;
+    c_n = pix0 / HoWo;
+    const int rem = pix0 - c_n * HoWo;
+    c_ho = rem / g.Wo; c_wo = rem - c_ho * g.Wo;
   }
 
   typedef RegSet<NVA, NVB> RS;
@@ -817,6 +830,22 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int 
     // are not advanced past it, so pix < P keeps implying n < NB)
     const bool adv = it + 1 < it_end;
     const int a_dn = adv ? dn : 0, a_dhs = adv ? dhs : 0, a_dws = adv ? dws : 0;
+    if (FR && VEC == 4 && !GATHER) {
+      const int hv = c_ho + dkh;
+      const bool okh = bok && it * BK < p.P && (unsigned)hv < (unsigned)g.H;     // (P % BK == 0: the whole chunk)
+      const unsigned rowbase = (unsigned)((c_n * Hs + (hv >> BS.up)) * Ws);
+      #pragma unroll
+      for (int i = 0; i < NVB; ++i) {
+        const int wi = c_wo + kx[i];
+        const bool ok = okh && (unsigned)wi < (unsigned)g.W;
+        mb |= (ok ? 1u : 0u) << i;
+        r.b[i] = ld4_off(BS.p, ok ? (rowbase + (unsigned)(wi >> BS.up)) * (unsigned)BS.ld + (unsigned)bcs : 0u);
+      }
+      if (adv) {                                     // (wave-uniform: scalar unit)
+        c_wo += BK;
+        if (c_wo >= g.Wo) { c_wo = 0; if (++c_ho >= g.Ho) { c_ho = 0; ++c_n; } }
+      }
+    } else
     #pragma unroll
     for (int i = 0; i < NVB; ++i) {
       const int pix = it * BK + bk0 + (1024 / BN) * i;
@@ -927,9 +956,9 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int 
   }
 }
 
-template <int BM, int BN, int VEC, bool GATHER, bool PP = false, bool H = false>
+template <int BM, int BN, int VEC, bool GATHER, bool PP = false, bool H = false, bool FR = false>
 __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_wgrad_kernel(const WgradParams p) {
-  conv_wgrad_body<BM, BN, VEC, GATHER, PP, H>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+  conv_wgrad_body<BM, BN, VEC, GATHER, PP, H, FR>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Grouped launch: up to four independent weight-gradient problems (the four linear layers of a
@@ -1172,6 +1201,7 @@ static const size_t g_lds_floor = getenv("SG2IM_LDS_FLOOR") ? (size_t)atol(geten
 // LDS request of a "background" weight gradient (sg2im_conv_desc.launch_hints bit 0): 56 KB = at most two
 // workgroups per CU.  [measured, profiles/r2_deferred_wgrad_ab.log: 3 resident (no padding) 9.88, 2 resident
 // 9.74, 1 resident (84 KB) 10.0 ms per training step]
+static const bool g_fastrow = !(getenv("SG2IM_FASTROW") && atoi(getenv("SG2IM_FASTROW")) == 0);   // (A/B knob)
 static const size_t g_bg_lds = getenv("SG2IM_BG_LDS") ? (size_t)atol(getenv("SG2IM_BG_LDS")) : 56 * 1024;
 static const int g_min_iters = getenv("SG2IM_MIN_ITERS") ? atoi(getenv("SG2IM_MIN_ITERS")) : 0;   // experiments
 static const bool g_plan_tune = getenv("SG2IM_PLAN_TUNE") != nullptr;     // honour SG2IM_FORCE_PLAN
@@ -1420,6 +1450,15 @@ static hipError_t launch_dgrad(DgradParams& p, hipStream_t st) {
   return hipGetLastError();
 }
 
+template <int BM, int BN> bool g_wgrad_fr_ready = false;
+template <int BM, int BN> static hipError_t prepare_wgrad_fr() {
+  if (g_wgrad_fr_ready<BM, BN>) return hipSuccess;
+  const hipError_t e = ensure_lds(conv_wgrad_kernel<BM, BN, 4, false, false, false, true>,
+                                  std::max(wgrad_lds<BM, BN>(), g_bg_lds));
+  if (e == hipSuccess) g_wgrad_fr_ready<BM, BN> = true;
+  return e;
+}
+
 template <int BM, int BN, int VEC, bool GATHER, bool PP = false>
 static hipError_t launch_wgrad_g(WgradParams& p, int ntiles_n, hipStream_t st) {
   constexpr size_t lds = (PP ? 2 : 1) * wgrad_lds<BM, BN>();
@@ -1430,6 +1469,14 @@ static hipError_t launch_wgrad_g(WgradParams& p, int ntiles_n, hipStream_t st) {
   // background launch: cap the resident workgroups per CU of the large-tile kernels so that small kernels of
   // a concurrent stream always find a free slot
   const size_t lds_req = (p.background && BM * BN > 64 * 64) ? std::max(lds, g_bg_lds) : lds;
+  if constexpr (VEC == 4 && !GATHER && !PP) {
+    // "fast rows" form: the BK pixels of every K chunk lie in one output row (see conv_wgrad_body)
+    if (g_fastrow && p.g.stride == 1 && p.g.Wo % BK == 0) {
+      { hipError_t e = prepare_wgrad_fr<BM, BN>(); if (e != hipSuccess) return e; }
+      hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, 4, false, false, false, true>), grid, dim3(NTHREADS), lds_req, st, p);
+      return hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, VEC, GATHER, PP>), grid, dim3(PP ? 2 * NTHREADS : NTHREADS), lds_req, st, p);
   return hipGetLastError();
 }
@@ -1635,6 +1682,8 @@ int sg2im_init(void) {
   SG2IM_PREP((prepare_dgrad<64, 64, 4, 1>())); SG2IM_PREP((prepare_dgrad<128, 64, 4, 1>()));
   SG2IM_PREP((prepare_dgrad<64, 64, 1, 1>()));
   SG2IM_PREP_TILES(prepare_wgrad, 4, false);
+  SG2IM_PREP((prepare_wgrad_fr<128, 128>())); SG2IM_PREP((prepare_wgrad_fr<128, 64>()));
+  SG2IM_PREP((prepare_wgrad_fr<64, 64>())); SG2IM_PREP((prepare_wgrad_fr<64, 128>()));
   SG2IM_PREP_TILES(prepare_wgrad, 4, true);
   SG2IM_PREP((prepare_wgrad<64, 64, 1, false>()));
 #undef SG2IM_PREP_TILES
