@@ -288,3 +288,26 @@ def test_dp_reference_with_one_rank_is_the_oracle_step():
     for k in P:
       assert torch.allclose(P[k], Q[k], atol=1e-7), k
       assert torch.allclose(P[k], R[k], atol=2e-6) and torch.equal(R[k], S[k]), k
+
+
+def test_static_batch_refill_equals_pad_batch_on_cpu():
+  """StaticBatch.load (three multi-tensor copies, one per dtype) leaves exactly what pad_batch builds in the
+  static buffers - for batches of different object / triple counts sharing a bucket, one without triples,
+  refilled in any order (the GPU form of this test is in tests/test_gpu_parity.py)."""
+  from sg2im_amd.bucketing import StaticBatch, pad_batch
+  cpu = [tuple(synthetic_batch(4, seed=s, min_objs=lo, max_objs=hi)[:6]) for s, lo, hi in ((1, 3, 4), (2, 5, 6), (3, 7, 8))]
+  empty = list(cpu[0])
+  empty[4] = empty[4][:0]
+  cpu.append(tuple(empty))
+  o_pad, t_pad = 64, 128
+  sb = StaticBatch(cpu[0], o_pad, t_pad)
+  for b in cpu[1:] + cpu[:1] + cpu[2:3]:
+    sb.load(b)
+    want, counts = pad_batch(b, o_pad, t_pad)
+    for got, ref in zip(sb.tensors(), want):
+      assert (got is None) == (ref is None)
+      if ref is not None:
+        assert got.dtype == ref.dtype and torch.equal(got, ref)
+    assert torch.equal(sb.counts, counts)
+  with pytest.raises(ValueError):
+    sb.load(tuple(synthetic_batch(16, seed=9)[:6]))           # another image count: not this bucket
