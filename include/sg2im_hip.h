@@ -111,8 +111,9 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* desc, const float* dy, i
                                  size_t workspace_bytes, hipStream_t stream);
 /* Up to 4 weight gradients (+ bias gradients; dbiases[i] may be NULL) as ONE launch + ONE split-K finish launch:
  * the four linear layers of a GraphTripleConv layer (graph.py:60-71 under autograd) - leaves of the backward
- * graph that otherwise cost 4 + 4 launches inside a chain of small dependent kernels.  Same results as n calls of
- * sg2im_conv2d_backward_weight with compute_dtype 0.  Every problem must take the float4 loaders (channels,
+ * graph that otherwise cost 4 + 4 launches inside a chain of small dependent kernels.  Results equal those of n
+ * calls of sg2im_conv2d_backward_weight (compute_dtype 0) up to the fp32 summation order of the split-K plan
+ * (always 64x64 tiles here); deterministic.  Every problem must take the float4 loaders (channels,
  * ld_dy, cout multiples of 4; 16-byte aligned buffers; weight_channels 0) - SG2IM_ERR_ARG with nothing launched
  * otherwise, the caller then issues the single calls.  The problems share `workspace` (disjoint slices). */
 int sg2im_conv2d_backward_weight_group(int n, const sg2im_conv_desc* const* descs, const float* const* dys,
