@@ -128,9 +128,6 @@ def init():
   first launch may already sit inside a stream capture)."""
   global _inited
   if not _inited:
-    if os.environ.get('SG2IM_PROBE_NO_INIT', '0') == '1':     # tools/graph_fault_probe.py: lazy set-up as in round 1
-      _inited = True
-      return
     if load().sg2im_init() != SG2IM_OK:
       raise Sg2imHipError('sg2im_init failed')
     _inited = True

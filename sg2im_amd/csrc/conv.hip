@@ -14,18 +14,12 @@
 // are never materialised.
 #include <algorithm>
 #include "igemm.h"
-#include "igemm2.h"
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include "sg2im_hip.h"
 
 namespace sg2im {
-
-#ifndef SG2IM_TAP_INNER
-#define SG2IM_TAP_INNER 0   // (1 measured: 940 -> fewer MB fetched, but no faster - slower on the two-source layers)
-#endif
-
 
 struct FwdParams {
   ConvGeom g;
@@ -127,9 +121,6 @@ __device__ __forceinline__ void locate_chunk(const ConvGeom& g, int ch, int& s, 
 __device__ float k_ones4[4] = {1.f, 1.f, 1.f, 1.f};
 __device__ float k_zeros4[4] = {0.f, 0.f, 0.f, 0.f};
 
-// timing-only ablation (SG2IM_ABL & 4): every loader address falls into one 256-byte window
-constexpr unsigned kAblMask = (SG2IM_ABL & 4) ? 60u : ~0u;
-
 struct Aff { float4 sc, sh; float slope; };
 
 // scalar (VEC = 1) element of the virtual tensor, branch-free like the vector path
@@ -212,47 +203,18 @@ template <int NVA, int NVB> struct RegSet {
   unsigned ma, mb;          // validity bits of the A / B rows
 };
 
-// (Experiment, OFF: pins the use of a prefetched register set BEHIND the point where this is called.
-// The arithmetic of a stage - pending affine, mask selects - is pure and only depends on the loaded
-// registers, so hipcc emits it right behind the loads, interleaved with the MFMA block of the previous
-// chunk, together with an `s_waitcnt vmcnt(2)` in FRONT of that block for loads issued a few
-// instructions earlier (found in the ISA, round 2).  Forcing the consumers behind the MFMA block with
-// an opaque `asm volatile` - so that the loads get a whole MFMA block to land - measured SLOWER:
-// forward 83.1 -> 77.4 TFLOP/s over the layer table, m4.conv0 100.7 -> 93.1
-// (profiles/r2_launder_ab.log): the loader VALU that hipcc had slotted between the MFMAs is worth
-// more than the exposed load latency, which the other resident waves cover.)
-#ifndef SG2IM_LAUNDER
-#define SG2IM_LAUNDER 0
-#endif
-__device__ __forceinline__ void launder4(float4& v) {
-#if SG2IM_LAUNDER
-  asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
-#endif
-}
-template <int NVA, int NVB> __device__ __forceinline__ void launder(RegSet<NVA, NVB>& r) {
-  #pragma unroll
-  for (int i = 0; i < NVA; ++i) launder4(r.a[i]);
-  #pragma unroll
-  for (int i = 0; i < NVB; ++i) launder4(r.b[i]);
-  launder4(r.aff.sc); launder4(r.aff.sh);
-}
-
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
-// PP: ping-pong form (k_pipeline_pp): 512 threads, the two halves own M tiles 2*blockIdx.y + {0, 1}
 // H: bf16 operand path (igemm.h): operands rounded to bf16 on their way into LDS, v_mfma_f32_32x32x16_bf16
-template <int BM, int BN, int VEC, bool GATHER, bool PP = false, bool H = false>
-__global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(const FwdParams p) {
-  extern __shared__ __attribute__((aligned(16))) float smem_all[];
+template <int BM, int BN, int VEC, bool GATHER, bool H = false>
+__global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NVA = BM / 32, NVB = BN / 32;
   constexpr int AF = TileBytes<H, BM, false>::value / 4, BF = TileBytes<H, BN, false>::value / 4;   // (in floats)
-  constexpr int STAGE = AF + BF;
   const ConvGeom& g = p.g;
-  const int half = PP ? (int)(threadIdx.x >> 8) : 0;
-  const int tid = threadIdx.x & (NTHREADS - 1);
-  float* const smem = smem_all + half * (TilePipe<BM, BN>::LDS_IMAGES * STAGE);
-  const int m0 = (blockIdx.y * (PP ? 2 : 1) + half) * BM, n0 = blockIdx.x * BN, split = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, split = blockIdx.z;
   const int per = (p.iters + p.e.nsplit - 1) / p.e.nsplit;
   const int it_begin = split * per;
   const int it_end = min(p.iters, it_begin + per);
@@ -289,26 +251,17 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(
   int q_tap = 0, q_kh = 0, q_kw = 0, q_s = 0, q_cstart = 0, q_cb = 0;
   static_assert(offsetof(FwdParams, g) == 0 && offsetof(ConvGeom, s0) == 0, "kernarg_src layout");
   Src q_S = kernarg_src(0);
-  const int taps_total = g.KH * g.KW;
   if (VEC == 4 && it_begin < it_end) {
-#if SG2IM_TAP_INNER
-    // reduction order: (source, channel chunk) outer, tap INNER - the KH*KW taps re-read the same
-    // pixels of one 32-channel slab back to back, so the re-reads hit L1/L2 instead of going
-    // out to the Infinity Cache (tap-outer order: 940 MB fetched per launch of m4.conv0 for
-    // 151 MB of input, the per-XCD working set of a full tap sweep is ~20 MB against a 4 MB L2)
-    const int q = it_begin / taps_total;
-    q_tap = it_begin - q * taps_total;
-    locate_chunk(g, q, q_s, q_cstart, q_cb);
-#else
+    // (reduction order: tap outer, (source, channel chunk) inner.  Tap INNER - the taps re-reading one
+    // 32-channel slab back to back - was measured in round 2: fewer bytes fetched, not faster.)
     q_tap = it_begin / p.nch;
     locate_chunk(g, it_begin - q_tap * p.nch, q_s, q_cstart, q_cb);
-#endif
     q_S = kernarg_src(q_s);
     q_kh = q_tap / g.KW; q_kw = q_tap - q_kh * g.KW;
   }
 
   typedef RegSet<NVA, NVB> RS;
-  RS rs0, rs1;
+  RS rs0;
   unsigned roff[NVA], rmask = 0;      // per A row: element offset of its pixel for the current (tap, source), validity
   bool q_dirty = true;
   auto load_into = [&](int it, RS& r) {
@@ -321,19 +274,6 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(
         // every chunk) so that the loop body stays one basic block.  The last chunk is
         // re-issued instead of advancing past the end.
         const bool adv = it + 1 < it_end;
-#if SG2IM_TAP_INNER
-        const bool wrap_w = adv && q_kw + 1 == g.KW;             // next kernel row
-        const bool wrap_t = wrap_w && q_kh + 1 == g.KH;          // all taps done: next channel chunk
-        const int ncb = q_cb + BK;
-        const bool wrap_s = wrap_t && ncb >= q_S.C;              // next source
-        q_kw = wrap_w ? 0 : (adv ? q_kw + 1 : q_kw);
-        q_kh = wrap_t ? 0 : (wrap_w ? q_kh + 1 : q_kh);
-        q_tap = wrap_t ? 0 : (adv ? q_tap + 1 : q_tap);
-        q_cb = wrap_s ? 0 : (wrap_t ? ncb : q_cb);
-        q_cstart += wrap_s ? q_S.C : 0;
-        q_s += wrap_s ? 1 : 0;
-        next_dirty = true;
-#else
         const int ncb = q_cb + BK;
         const bool wrap_s = adv && ncb >= q_S.C;                 // next source
         const bool wrap_t = wrap_s && q_s + 1 == g.nsrc;         // next tap
@@ -345,8 +285,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(
         q_kw = wrap_w ? 0 : (wrap_t ? q_kw + 1 : q_kw);
         q_kh += wrap_w ? 1 : 0;
         next_dirty = wrap_s;                                     // (the source or the tap moves on)
-#endif
-        if (SG2IM_TAP_INNER || next_dirty) q_S = kernarg_src(q_s);   // (scalar loads of the source block)
+        if (next_dirty) q_S = kernarg_src(q_s);                  // (scalar loads of the source block)
       }
       const int c = cb + 4 * col4;
       const bool cok = c < S.C;
@@ -355,7 +294,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(
       // when either changed (wave-uniform branch - every nch-th chunk in the tap-outer order), otherwise
       // a row's offset just moves on by the channel chunk.  This arithmetic sits in FRONT of the
       // chunk's global loads, i.e. it is not covered by the wave's own MFMA block.
-      if (SG2IM_TAP_INNER || q_dirty) {
+      if (q_dirty) {
         const int Hs = g.H >> S.up, Ws = g.W >> S.up;
         rmask = 0;
         #pragma unroll
@@ -373,14 +312,14 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(
       const unsigned ma = cok ? rmask : 0u;
       #pragma unroll
       for (int i = 0; i < NVA; ++i) {
-        const unsigned off = ((ma >> i & 1u) ? roff[i] + (unsigned)c : 0u) & kAblMask;
+        const unsigned off = ((ma >> i & 1u) ? roff[i] + (unsigned)c : 0u);
         r.a[i] = ld4_off(S.p, off);
       }
       const unsigned wcol = (unsigned)(tap * g.Wtap + cstart + c);
       const unsigned mb = cok ? bmask : 0u;
       #pragma unroll
       for (int i = 0; i < NVB; ++i) {
-        const unsigned off = ((mb >> i & 1u) ? wrow[i] + wcol : 0u) & kAblMask;
+        const unsigned off = ((mb >> i & 1u) ? wrow[i] + wcol : 0u);
         r.b[i] = ld4_off(p.Wt, off);
       }
       r.ma = ma; r.mb = mb;
@@ -418,9 +357,8 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(
       r.ma = ~0u; r.mb = ~0u;
     }
   };
-  auto stage_from = [&](RS& r, int B_) {
+  auto stage_from = [&](RS& r) {
     float4 ta[NVA], tb[NVB];
-    launder(r);
     #pragma unroll
     for (int i = 0; i < NVA; ++i) ta[i] = apply_aff(r.a[i], r.aff, (r.ma >> i & 1u) != 0);
     #pragma unroll
@@ -429,11 +367,11 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(
     // zero or the accumulator column is never stored)
     for (int i = 0; i < NVB; ++i) tb[i] = r.b[i];
     if constexpr (H) {
-      store_tile_h<BM, false>(reinterpret_cast<bf16_t*>(smem + B_ * STAGE), ta, tid);
-      store_tile_h<BN, false>(reinterpret_cast<bf16_t*>(smem + B_ * STAGE + AF), tb, tid);
+      store_tile_h<BM, false>(reinterpret_cast<bf16_t*>(smem), ta, tid);
+      store_tile_h<BN, false>(reinterpret_cast<bf16_t*>(smem + AF), tb, tid);
     } else {
-      store_tile<BM, false>(smem + B_ * STAGE, ta, tid);
-      store_tile<BN, false>(smem + B_ * STAGE + AF, tb, tid);
+      store_tile<BM, false>(smem, ta, tid);
+      store_tile<BN, false>(smem + AF, tb, tid);
     }
   };
 
@@ -441,26 +379,19 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_fwd_kernel(
   int wm0, wn0, lane;
   wave_origin<BM, BN>(tid, wm0, wn0, lane);
 
-  auto do_load = [&](int it, auto set) { if constexpr (decltype(set)::value == 0) load_into(it, rs0); else load_into(it, rs1); };
-  auto do_stage = [&](auto set, int B_, bool) { if constexpr (decltype(set)::value == 0) stage_from(rs0, B_); else stage_from(rs1, B_); };
-  auto do_mma = [&](int phase, int B_) {
+  auto do_load = [&](int it) { load_into(it, rs0); };
+  auto do_stage = [&](bool) { stage_from(rs0); };
+  auto do_mma = [&](int phase) {
     if constexpr (H) {
-      if (phase == 0) read_frags_h<BM, BN, false, false>(reinterpret_cast<const bf16_t*>(smem + B_ * STAGE),
-                                                         reinterpret_cast<const bf16_t*>(smem + B_ * STAGE + AF), wm0, wn0, lane, fragsh);
+      if (phase == 0) read_frags_h<BM, BN, false, false>(reinterpret_cast<const bf16_t*>(smem),
+                                                         reinterpret_cast<const bf16_t*>(smem + AF), wm0, wn0, lane, fragsh);
       else mma_frags_h<BM, BN>(fragsh, acc);
     } else {
-      if (phase == 0) read_frags<BM, BN, false, false>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, frags);
+      if (phase == 0) read_frags<BM, BN, false, false>(smem, smem + AF, wm0, wn0, lane, frags);
       else mma_frags<BM, BN>(frags, acc);
     }
   };
-  if constexpr (PP) k_pipeline_pp(half, it_begin, it_end, do_load, do_stage, do_mma);
-  else {
-    // (paired loop only: an all-zero LDS image)
-    auto do_zfill = [&](int B_) {
-      for (int q = tid; q < STAGE / 4; q += NTHREADS) reinterpret_cast<float4*>(smem + B_ * STAGE)[q] = zero4();
-    };
-    k_pipeline<TilePipe<BM, BN>::DEPTH>(it_begin, it_end, do_load, do_stage, do_mma, do_zfill);
-  }
+  k_pipeline(it_begin, it_end, do_load, do_stage, do_mma);
   epilogue<BM, BN>(p.e, p.M, p.Cout, p.Cout, m0, n0, wm0, wn0, lane, split, acc);
 }
 
@@ -485,17 +416,14 @@ struct ParityRow {
   }
 };
 
-template <int BM, int BN, int VA, int VB, bool PP = false, bool H = false>
-__global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kernel(const DgradParams p) {
-  extern __shared__ __attribute__((aligned(16))) float smem_all[];
+template <int BM, int BN, int VA, int VB, bool H = false>
+__global__ __launch_bounds__(NTHREADS) void conv_dgrad_kernel(const DgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NVA = BM / 32, NVB = BN / 32;
   constexpr int AF = TileBytes<H, BM, false>::value / 4, BF = TileBytes<H, BN, true>::value / 4;
-  constexpr int STAGE = AF + BF;
   const ConvGeom& g = p.g;
-  const int half = PP ? (int)(threadIdx.x >> 8) : 0;
-  const int tid = threadIdx.x & (NTHREADS - 1);
-  float* const smem = smem_all + half * (TilePipe<BM, BN>::LDS_IMAGES * STAGE);
-  const int m0 = (blockIdx.y * (PP ? 2 : 1) + half) * BM, n0 = blockIdx.x * BN;
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int col4 = tid & 7, r0 = tid >> 3;
   const int taps = g.KH * g.KW;
   const int ldw = taps * g.Wtap;
@@ -517,7 +445,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kerne
     nkw = (g.KW - kw0 + 1) >> 1;
     nch = (Cout + BK - 1) / BK;
     iters = nkh * nkw * nch;
-    if (!PP && m0 >= M) return;       // (the ping-pong form is never launched in parity mode)
+    if (m0 >= M) return;
   } else {
     split = blockIdx.z;
   }
@@ -560,7 +488,7 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kerne
   };
 
   typedef RegSet<NVA, NVB> RS;
-  RS rs0, rs1;
+  RS rs0;
   // wave-uniform cursor over (live tap, output-channel chunk), advanced chunk by chunk
   int q_th = 0, q_tw = 0, q_cb = 0;
   if (VA == 4 && it_begin < it_end) {
@@ -660,9 +588,8 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kerne
       r.ma = ~0u; r.mb = ~0u;
     }
   };
-  auto stage_from = [&](RS& r, int B_) {
+  auto stage_from = [&](RS& r) {
     float4 ta[NVA], tb[NVB];
-    launder(r);
     #pragma unroll
     for (int i = 0; i < NVA; ++i) ta[i] = r.a[i];      // (VA == 4: invalid rows were read as zeros; VA == 1: zeroed in the loader)
     #pragma unroll
@@ -670,11 +597,11 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kerne
     // >= Nc are never stored)
     for (int i = 0; i < NVB; ++i) tb[i] = r.b[i];
     if constexpr (H) {
-      store_tile_h<BM, false>(reinterpret_cast<bf16_t*>(smem + B_ * STAGE), ta, tid);
-      store_tile_h<BN, true>(reinterpret_cast<bf16_t*>(smem + B_ * STAGE + AF), tb, tid);
+      store_tile_h<BM, false>(reinterpret_cast<bf16_t*>(smem), ta, tid);
+      store_tile_h<BN, true>(reinterpret_cast<bf16_t*>(smem + AF), tb, tid);
     } else {
-      store_tile<BM, false>(smem + B_ * STAGE, ta, tid);
-      store_tile<BN, true>(smem + B_ * STAGE + AF, tb, tid);
+      store_tile<BM, false>(smem, ta, tid);
+      store_tile<BN, true>(smem + AF, tb, tid);
     }
   };
 
@@ -682,26 +609,19 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kerne
   int wm0, wn0, lane;
   wave_origin<BM, BN>(tid, wm0, wn0, lane);
 
-  auto do_load = [&](int it, auto set) { if constexpr (decltype(set)::value == 0) load_into(it, rs0); else load_into(it, rs1); };
-  auto do_stage = [&](auto set, int B_, bool) { if constexpr (decltype(set)::value == 0) stage_from(rs0, B_); else stage_from(rs1, B_); };
-  auto do_mma = [&](int phase, int B_) {
+  auto do_load = [&](int it) { load_into(it, rs0); };
+  auto do_stage = [&](bool) { stage_from(rs0); };
+  auto do_mma = [&](int phase) {
     if constexpr (H) {
-      if (phase == 0) read_frags_h<BM, BN, false, true>(reinterpret_cast<const bf16_t*>(smem + B_ * STAGE),
-                                                        reinterpret_cast<const bf16_t*>(smem + B_ * STAGE + AF), wm0, wn0, lane, fragsh);
+      if (phase == 0) read_frags_h<BM, BN, false, true>(reinterpret_cast<const bf16_t*>(smem),
+                                                        reinterpret_cast<const bf16_t*>(smem + AF), wm0, wn0, lane, fragsh);
       else mma_frags_h<BM, BN>(fragsh, acc);
     } else {
-      if (phase == 0) read_frags<BM, BN, false, true>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, frags);
+      if (phase == 0) read_frags<BM, BN, false, true>(smem, smem + AF, wm0, wn0, lane, frags);
       else mma_frags<BM, BN>(frags, acc);
     }
   };
-  if constexpr (PP) k_pipeline_pp(half, it_begin, it_end, do_load, do_stage, do_mma);
-  else {
-    // (paired loop only: an all-zero LDS image)
-    auto do_zfill = [&](int B_) {
-      for (int q = tid; q < STAGE / 4; q += NTHREADS) reinterpret_cast<float4*>(smem + B_ * STAGE)[q] = zero4();
-    };
-    k_pipeline<TilePipe<BM, BN>::DEPTH>(it_begin, it_end, do_load, do_stage, do_mma, do_zfill);
-  }
+  k_pipeline(it_begin, it_end, do_load, do_stage, do_mma);
   if (p.parity) {
     // split-K slabs of the parity form: [split][class][p.M rows][Nc], finished (and mapped to the
     // interleaved destination rows) by splitk_finish_parity_kernel
@@ -716,25 +636,21 @@ __global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_dgrad_kerne
 // ---------------------------------------------------------------------------
 // weight gradient
 // ---------------------------------------------------------------------------
-// PP: the two halves own the column tiles 2*blockIdx.x + {0, 1} of the same row tile / K split
 // (the body is a device function of (params, block coordinates) so that the grouped launch below can run it
 // for one of several problems)
 // FR ("fast rows", VEC == 4, no gathers): stride 1 and Wo % BK == 0, so the BK output pixels of a K chunk lie
 // in ONE output row - the chunk's (n, ho) are wave-uniform and a B row is (chunk's first column + its fixed
 // k): no per-row coordinate state, ~6 instead of ~20 VALU per row and chunk.
-template <int BM, int BN, int VEC, bool GATHER, bool PP, bool H, bool FR = false>
+template <int BM, int BN, int VEC, bool GATHER, bool H, bool FR = false>
 __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int bidx, const int bidy, const int bidz) {
-  extern __shared__ __attribute__((aligned(16))) float smem_all[];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NVA = BM / 32, NVB = BN / 32;
   constexpr int AF = TileBytes<H, BM, true>::value / 4, BF = TileBytes<H, BN, true>::value / 4;
-  constexpr int STAGE = AF + BF;
   const ConvGeom& g = p.g;
-  const int half = PP ? (int)(threadIdx.x >> 8) : 0;
-  const int tid = threadIdx.x & (NTHREADS - 1);
-  float* const smem = smem_all + half * (TilePipe<BM, BN>::LDS_IMAGES * STAGE);
+  const int tid = threadIdx.x;
   // (an XCD-pinned 1-D grid - every column tile of a reduction slice on one XCD's L2 - was
   // measured: no gain on the large layers, so the plain 3-D grid stays)
-  const int ntile_x = bidx * (PP ? 2 : 1) + half, mtile = bidy, split = bidz;
+  const int ntile_x = bidx, mtile = bidy, split = bidz;
   const int m0 = mtile * BM;
   const int per = (p.iters + p.e.nsplit - 1) / p.e.nsplit;
   const int it_begin = split * per;
@@ -803,7 +719,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int 
   }
 
   typedef RegSet<NVA, NVB> RS;
-  RS rs0, rs1;
+  RS rs0;
   const BufRsrc rsY = rsrc_of(p.dY, (unsigned)p.P * (unsigned)p.ldy * 4u);
   auto load_into = [&](int it, RS& r) {
     unsigned ma = 0, mb = 0;
@@ -880,9 +796,8 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int 
   // bias gradient: this thread's dY values all belong to output channels aco..aco+3
   const bool want_db = p.dbias != nullptr && ntile_x == 0;
   float4 dbs = zero4();
-  auto stage_from = [&](RS& r, int B_, bool live) {
+  auto stage_from = [&](RS& r, bool live) {
     float4 ta[NVA], tb[NVB];
-    launder(r);
     #pragma unroll
     for (int i = 0; i < NVA; ++i) ta[i] = r.a[i];        // (rows beyond the last pixel / channel were read as zeros)
     if (want_db && live) {
@@ -895,11 +810,11 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int 
       else tb[i] = r.b[i];
     }
     if constexpr (H) {
-      store_tile_h<BM, true>(reinterpret_cast<bf16_t*>(smem + B_ * STAGE), ta, tid);
-      store_tile_h<BN, true>(reinterpret_cast<bf16_t*>(smem + B_ * STAGE + AF), tb, tid);
+      store_tile_h<BM, true>(reinterpret_cast<bf16_t*>(smem), ta, tid);
+      store_tile_h<BN, true>(reinterpret_cast<bf16_t*>(smem + AF), tb, tid);
     } else {
-      store_tile<BM, true>(smem + B_ * STAGE, ta, tid);
-      store_tile<BN, true>(smem + B_ * STAGE + AF, tb, tid);
+      store_tile<BM, true>(smem, ta, tid);
+      store_tile<BN, true>(smem + AF, tb, tid);
     }
   };
 
@@ -907,35 +822,26 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int 
   int wm0, wn0, lane;
   wave_origin<BM, BN>(tid, wm0, wn0, lane);
 
-  auto do_load = [&](int it, auto set) { if constexpr (decltype(set)::value == 0) load_into(it, rs0); else load_into(it, rs1); };
-  auto do_stage = [&](auto set, int B_, bool live) {
-    if constexpr (decltype(set)::value == 0) stage_from(rs0, B_, live); else stage_from(rs1, B_, live);
-  };
-  auto do_mma = [&](int phase, int B_) {
+  auto do_load = [&](int it) { load_into(it, rs0); };
+  auto do_stage = [&](bool live) { stage_from(rs0, live); };
+  auto do_mma = [&](int phase) {
     if constexpr (H) {
-      if (phase == 0) read_frags_h<BM, BN, true, true>(reinterpret_cast<const bf16_t*>(smem + B_ * STAGE),
-                                                       reinterpret_cast<const bf16_t*>(smem + B_ * STAGE + AF), wm0, wn0, lane, fragsh);
+      if (phase == 0) read_frags_h<BM, BN, true, true>(reinterpret_cast<const bf16_t*>(smem),
+                                                       reinterpret_cast<const bf16_t*>(smem + AF), wm0, wn0, lane, fragsh);
       else mma_frags_h<BM, BN>(fragsh, acc);
     } else {
-      if (phase == 0) read_frags<BM, BN, true, true>(smem + B_ * STAGE, smem + B_ * STAGE + AF, wm0, wn0, lane, frags);
+      if (phase == 0) read_frags<BM, BN, true, true>(smem, smem + AF, wm0, wn0, lane, frags);
       else mma_frags<BM, BN>(frags, acc);
     }
   };
-  if constexpr (PP) k_pipeline_pp(half, it_begin, it_end, do_load, do_stage, do_mma);
-  else {
-    // (paired loop only: an all-zero LDS image)
-    auto do_zfill = [&](int B_) {
-      for (int q = tid; q < STAGE / 4; q += NTHREADS) reinterpret_cast<float4*>(smem + B_ * STAGE)[q] = zero4();
-    };
-    k_pipeline<TilePipe<BM, BN>::DEPTH>(it_begin, it_end, do_load, do_stage, do_mma, do_zfill);
-  }
+  k_pipeline(it_begin, it_end, do_load, do_stage, do_mma);
   epilogue<BM, BN>(p.e, p.Cout, Ntot, Ntot, m0, n0, wm0, wn0, lane, split, acc);
-  // (workgroup-uniform condition: in the ping-pong form both halves must reach the barrier below)
+  // (workgroup-uniform condition: every wave must reach the barriers below)
   if (p.dbias != nullptr && bidx == 0) {
     // the 256 / QA threads that share a channel quad hold sums over disjoint pixel rows:
     // combine them through LDS in thread order (fixed order -> reproducible)
     constexpr int GROUPS = NTHREADS / QA;
-    float4* red = reinterpret_cast<float4*>(smem);            // [GROUPS][QA]  (the half's own LDS image)
+    float4* red = reinterpret_cast<float4*>(smem);            // [GROUPS][QA]  (the operand image is free now)
     __syncthreads();                                          // (every wave is done with its last chunk)
     if (want_db) red[ak0 * QA + acol4] = dbs;
     __syncthreads();
@@ -956,9 +862,9 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int 
   }
 }
 
-template <int BM, int BN, int VEC, bool GATHER, bool PP = false, bool H = false, bool FR = false>
-__global__ __launch_bounds__(PP ? 2 * NTHREADS : NTHREADS) void conv_wgrad_kernel(const WgradParams p) {
-  conv_wgrad_body<BM, BN, VEC, GATHER, PP, H, FR>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+template <int BM, int BN, int VEC, bool GATHER, bool H = false, bool FR = false>
+__global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradParams p) {
+  conv_wgrad_body<BM, BN, VEC, GATHER, H, FR>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Grouped launch: up to four independent weight-gradient problems (the four linear layers of a
@@ -977,7 +883,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_group_kernel(const WgradG
     const int tiles = g.p[i].ntiles_n * g.p[i].ntiles_m;                           \
     const int sp = l / tiles, t = l - sp * tiles;                                  \
     const int ty = t / g.p[i].ntiles_n, tx = t - ty * g.p[i].ntiles_n;             \
-    conv_wgrad_body<64, 64, 4, true, false, false>(g.p[i], tx, ty, sp);            \
+    conv_wgrad_body<64, 64, 4, true, false>(g.p[i], tx, ty, sp);                   \
     return;                                                                        \
   }
   SG2IM_GROUP_CASE(0) SG2IM_GROUP_CASE(1) SG2IM_GROUP_CASE(2) SG2IM_GROUP_CASE(3)
@@ -1197,13 +1103,10 @@ __global__ void splitk_finish_parity_kernel(const float* __restrict__ ws, int ns
 // ---------------------------------------------------------------------------
 static int g_num_cu = 256;
 static const bool g_plan_debug = getenv("SG2IM_PLAN_DEBUG") != nullptr;   // print the launch plans
-static const size_t g_lds_floor = getenv("SG2IM_LDS_FLOOR") ? (size_t)atol(getenv("SG2IM_LDS_FLOOR")) : 0;
 // LDS request of a "background" weight gradient (sg2im_conv_desc.launch_hints bit 0): 56 KB = at most two
 // workgroups per CU.  [measured, profiles/r2_deferred_wgrad_ab.log: 3 resident (no padding) 9.88, 2 resident
 // 9.74, 1 resident (84 KB) 10.0 ms per training step]
-static const bool g_fastrow = !(getenv("SG2IM_FASTROW") && atoi(getenv("SG2IM_FASTROW")) == 0);   // (A/B knob)
-static const size_t g_bg_lds = getenv("SG2IM_BG_LDS") ? (size_t)atol(getenv("SG2IM_BG_LDS")) : 56 * 1024;
-static const int g_min_iters = getenv("SG2IM_MIN_ITERS") ? atoi(getenv("SG2IM_MIN_ITERS")) : 0;   // experiments
+static const size_t g_bg_lds = 56 * 1024;
 static const bool g_plan_tune = getenv("SG2IM_PLAN_TUNE") != nullptr;     // honour SG2IM_FORCE_PLAN
 
 template <typename K>
@@ -1292,8 +1195,8 @@ static const double kEff[3][4] = {{1.0, 0.92, 0.80, 0.935}, {1.0, 0.92, 0.895, 0
 #define SG2IM_FINBW 2500.0
 #endif
 static const int kOcc[4] = {3, 4, 6, 4};                  // resident workgroups per CU (VGPR/LDS limited)
-static const double g_fin0 = getenv("SG2IM_FIN0") ? atof(getenv("SG2IM_FIN0")) : SG2IM_FIN0;       // (plan experiments)
-static const double g_finbw = getenv("SG2IM_FINBW") ? atof(getenv("SG2IM_FINBW")) : SG2IM_FINBW;
+static const double g_fin0 = SG2IM_FIN0;
+static const double g_finbw = SG2IM_FINBW;
 static double launch_cost(int pass, int t, long long tiles, int ns, int iters, long long MN) {
   const long long blocks = tiles * ns;
   const int per = (iters + ns - 1) / ns;
@@ -1309,7 +1212,6 @@ static double launch_cost(int pass, int t, long long tiles, int ns, int iters, l
 
 static int split_for(int pass, int t, long long tiles, int iters, long long MN, size_t ws_bytes, int min_iters,
                      double* cost_out = nullptr) {
-  if (g_min_iters > 0) min_iters = g_min_iters;
   long long cap = std::max(1, iters / min_iters);
   cap = std::min<long long>(cap, MN > 0 ? std::max<long long>(1, (long long)(ws_bytes / sizeof(float)) / MN) : 1);
   // (tiny outputs - the weight gradients of the RGB layers - are latency bound and may be
@@ -1349,7 +1251,7 @@ static Plan make_plan(int pass, long long M, long long N, int iters, long long M
     int t = 0, ns = 1;
     if (f && sscanf(f, "%d,%d", &t, &ns) == 2 && t >= 0 && t < 4 && !(only64 && t != 2)) {
       const long long tiles = ((M + kBM[t] - 1) / kBM[t]) * ntn(kBN[t]);
-      long long cap = can_split ? std::max(1, iters / (g_min_iters > 0 ? g_min_iters : min_iters)) : 1;
+      long long cap = can_split ? std::max(1, iters / min_iters) : 1;
       if (MN > 0) cap = std::min<long long>(cap, std::max<long long>(1, (long long)(ws_bytes / sizeof(float)) / MN));
       ns = (int)std::max<long long>(1, std::min<long long>(ns, cap));
       const int per = (iters + ns - 1) / ns;
@@ -1385,106 +1287,100 @@ static hipError_t finish_split(const Epi& e, long long M, int N, hipStream_t st,
 // Per-instantiation "attributes set" flags.  sg2im_init() sets every one of them up front, so that
 // no hipFuncSetAttribute call is left for a first launch that may happen inside a stream capture;
 // a caller that skipped sg2im_init() still gets them lazily.
-template <int BM, int BN, int VEC, bool GATHER, bool PP> bool g_fwd_ready = false;
-template <int BM, int BN, int VA, int VB, bool PP> bool g_dgrad_ready = false;
-template <int BM, int BN, int VEC, bool GATHER, bool PP> bool g_wgrad_ready = false;
+template <int BM, int BN, int VEC, bool GATHER> bool g_fwd_ready = false;
+template <int BM, int BN, int VA, int VB> bool g_dgrad_ready = false;
+template <int BM, int BN, int VEC, bool GATHER> bool g_wgrad_ready = false;
 
 template <int BM, int BN> constexpr size_t fwd_lds() {
-  return TilePipe<BM, BN>::LDS_IMAGES * (LdsTile<BM, false>::FLOATS + LdsTile<BN, false>::FLOATS) * sizeof(float);
+  return (LdsTile<BM, false>::FLOATS + LdsTile<BN, false>::FLOATS) * sizeof(float);
 }
 template <int BM, int BN> constexpr size_t dgrad_lds() {
-  return TilePipe<BM, BN>::LDS_IMAGES * (LdsTile<BM, false>::FLOATS + LdsTile<BN, true>::FLOATS) * sizeof(float);
+  return (LdsTile<BM, false>::FLOATS + LdsTile<BN, true>::FLOATS) * sizeof(float);
 }
 template <int BM, int BN> constexpr size_t wgrad_lds() {
-  return TilePipe<BM, BN>::LDS_IMAGES * (LdsTile<BM, true>::FLOATS + LdsTile<BN, true>::FLOATS) * sizeof(float);
+  return (LdsTile<BM, true>::FLOATS + LdsTile<BN, true>::FLOATS) * sizeof(float);
 }
 
-// (PP: the ping-pong form holds one LDS image per half)
-template <int BM, int BN, int VEC, bool GATHER, bool PP = false> static hipError_t prepare_fwd() {
-  if (g_fwd_ready<BM, BN, VEC, GATHER, PP>) return hipSuccess;
-  const hipError_t e = ensure_lds(conv_fwd_kernel<BM, BN, VEC, GATHER, PP>,
-                                  std::max((PP ? 2 : 1) * fwd_lds<BM, BN>(), g_lds_floor));
-  if (e == hipSuccess) g_fwd_ready<BM, BN, VEC, GATHER, PP> = true;
+template <int BM, int BN, int VEC, bool GATHER> static hipError_t prepare_fwd() {
+  if (g_fwd_ready<BM, BN, VEC, GATHER>) return hipSuccess;
+  const hipError_t e = ensure_lds(conv_fwd_kernel<BM, BN, VEC, GATHER>, fwd_lds<BM, BN>());
+  if (e == hipSuccess) g_fwd_ready<BM, BN, VEC, GATHER> = true;
   return e;
 }
-template <int BM, int BN, int VA, int VB, bool PP = false> static hipError_t prepare_dgrad() {
-  if (g_dgrad_ready<BM, BN, VA, VB, PP>) return hipSuccess;
-  const hipError_t e = ensure_lds(conv_dgrad_kernel<BM, BN, VA, VB, PP>, (PP ? 2 : 1) * dgrad_lds<BM, BN>());
-  if (e == hipSuccess) g_dgrad_ready<BM, BN, VA, VB, PP> = true;
+template <int BM, int BN, int VA, int VB> static hipError_t prepare_dgrad() {
+  if (g_dgrad_ready<BM, BN, VA, VB>) return hipSuccess;
+  const hipError_t e = ensure_lds(conv_dgrad_kernel<BM, BN, VA, VB>, dgrad_lds<BM, BN>());
+  if (e == hipSuccess) g_dgrad_ready<BM, BN, VA, VB> = true;
   return e;
 }
-template <int BM, int BN, int VEC, bool GATHER, bool PP = false> static hipError_t prepare_wgrad() {
-  if (g_wgrad_ready<BM, BN, VEC, GATHER, PP>) return hipSuccess;
-  const hipError_t e = ensure_lds(conv_wgrad_kernel<BM, BN, VEC, GATHER, PP>,
-                                  std::max((PP ? 2 : 1) * wgrad_lds<BM, BN>(), g_bg_lds));
-  if (e == hipSuccess) g_wgrad_ready<BM, BN, VEC, GATHER, PP> = true;
+template <int BM, int BN, int VEC, bool GATHER> static hipError_t prepare_wgrad() {
+  if (g_wgrad_ready<BM, BN, VEC, GATHER>) return hipSuccess;
+  const hipError_t e = ensure_lds(conv_wgrad_kernel<BM, BN, VEC, GATHER>, std::max(wgrad_lds<BM, BN>(), g_bg_lds));
+  if (e == hipSuccess) g_wgrad_ready<BM, BN, VEC, GATHER> = true;
   return e;
 }
 
-template <int BM, int BN, int VEC, bool GATHER, bool PP = false>
+template <int BM, int BN, int VEC, bool GATHER>
 static hipError_t launch_fwd_g(FwdParams& p, hipStream_t st) {
-  constexpr size_t lds = (PP ? 2 : 1) * fwd_lds<BM, BN>();
-  const size_t lds_req = std::max(lds, g_lds_floor);   // (occupancy experiments: SG2IM_LDS_FLOOR)
-  { hipError_t e = prepare_fwd<BM, BN, VEC, GATHER, PP>(); if (e != hipSuccess) return e; }
-  const int mt = (p.M + BM - 1) / BM;
-  dim3 grid((p.Cout + BN - 1) / BN, PP ? (mt + 1) / 2 : mt, p.e.nsplit);
-  hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, VEC, GATHER, PP>), grid, dim3(PP ? 2 * NTHREADS : NTHREADS), lds_req, st, p);
+  constexpr size_t lds = fwd_lds<BM, BN>();
+  { hipError_t e = prepare_fwd<BM, BN, VEC, GATHER>(); if (e != hipSuccess) return e; }
+  dim3 grid((p.Cout + BN - 1) / BN, (p.M + BM - 1) / BM, p.e.nsplit);
+  hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, VEC, GATHER>), grid, dim3(NTHREADS), lds, st, p);
   return hipGetLastError();
 }
 
 static bool any_gather(ConvGeom& g) { for (int i = 0; i < g.nsrc; ++i) if (src_at(g, i)->gidx) return true; return false; }
 
-template <int BM, int BN, int VEC, bool PP = false>
+template <int BM, int BN, int VEC>
 static hipError_t launch_fwd(FwdParams& p, hipStream_t st) {
-  if (VEC == 4 && any_gather(p.g)) return launch_fwd_g<BM, BN, VEC, true>(p, st);     // (row gathers: tiny GEMMs, never ping-pong)
-  return launch_fwd_g<BM, BN, VEC, false, PP>(p, st);
+  if (VEC == 4 && any_gather(p.g)) return launch_fwd_g<BM, BN, VEC, true>(p, st);     // (row gathers: tiny GEMMs)
+  return launch_fwd_g<BM, BN, VEC, false>(p, st);
 }
 
-template <int BM, int BN, int VA, int VB, bool PP = false>
+template <int BM, int BN, int VA, int VB>
 static hipError_t launch_dgrad(DgradParams& p, hipStream_t st) {
-  constexpr size_t lds = (PP ? 2 : 1) * dgrad_lds<BM, BN>();
-  { hipError_t e = prepare_dgrad<BM, BN, VA, VB, PP>(); if (e != hipSuccess) return e; }
-  const int mt = (p.M + BM - 1) / BM;
-  dim3 grid((p.Nc + BN - 1) / BN, PP ? (mt + 1) / 2 : mt, p.parity ? 4 * p.e.nsplit : p.e.nsplit);
-  hipLaunchKernelGGL((conv_dgrad_kernel<BM, BN, VA, VB, PP>), grid, dim3(PP ? 2 * NTHREADS : NTHREADS), lds, st, p);
+  constexpr size_t lds = dgrad_lds<BM, BN>();
+  { hipError_t e = prepare_dgrad<BM, BN, VA, VB>(); if (e != hipSuccess) return e; }
+  dim3 grid((p.Nc + BN - 1) / BN, (p.M + BM - 1) / BM, p.parity ? 4 * p.e.nsplit : p.e.nsplit);
+  hipLaunchKernelGGL((conv_dgrad_kernel<BM, BN, VA, VB>), grid, dim3(NTHREADS), lds, st, p);
   return hipGetLastError();
 }
 
 template <int BM, int BN> bool g_wgrad_fr_ready = false;
 template <int BM, int BN> static hipError_t prepare_wgrad_fr() {
   if (g_wgrad_fr_ready<BM, BN>) return hipSuccess;
-  const hipError_t e = ensure_lds(conv_wgrad_kernel<BM, BN, 4, false, false, false, true>,
+  const hipError_t e = ensure_lds(conv_wgrad_kernel<BM, BN, 4, false, false, true>,
                                   std::max(wgrad_lds<BM, BN>(), g_bg_lds));
   if (e == hipSuccess) g_wgrad_fr_ready<BM, BN> = true;
   return e;
 }
 
-template <int BM, int BN, int VEC, bool GATHER, bool PP = false>
+template <int BM, int BN, int VEC, bool GATHER>
 static hipError_t launch_wgrad_g(WgradParams& p, int ntiles_n, hipStream_t st) {
-  constexpr size_t lds = (PP ? 2 : 1) * wgrad_lds<BM, BN>();
-  { hipError_t e = prepare_wgrad<BM, BN, VEC, GATHER, PP>(); if (e != hipSuccess) return e; }
+  constexpr size_t lds = wgrad_lds<BM, BN>();
+  { hipError_t e = prepare_wgrad<BM, BN, VEC, GATHER>(); if (e != hipSuccess) return e; }
   p.ntiles_n = ntiles_n;
   p.ntiles_m = (p.Cout + BM - 1) / BM;
-  dim3 grid(PP ? (p.ntiles_n + 1) / 2 : p.ntiles_n, p.ntiles_m, p.e.nsplit);
+  dim3 grid(p.ntiles_n, p.ntiles_m, p.e.nsplit);
   // background launch: cap the resident workgroups per CU of the large-tile kernels so that small kernels of
   // a concurrent stream always find a free slot
   const size_t lds_req = (p.background && BM * BN > 64 * 64) ? std::max(lds, g_bg_lds) : lds;
-  if constexpr (VEC == 4 && !GATHER && !PP) {
+  if constexpr (VEC == 4 && !GATHER) {
     // "fast rows" form: the BK pixels of every K chunk lie in one output row (see conv_wgrad_body)
-    if (g_fastrow && p.g.stride == 1 && p.g.Wo % BK == 0) {
+    if (p.g.stride == 1 && p.g.Wo % BK == 0) {
       { hipError_t e = prepare_wgrad_fr<BM, BN>(); if (e != hipSuccess) return e; }
-      hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, 4, false, false, false, true>), grid, dim3(NTHREADS), lds_req, st, p);
+      hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, 4, false, false, true>), grid, dim3(NTHREADS), lds_req, st, p);
       return hipGetLastError();
     }
   }
-  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, VEC, GATHER, PP>), grid, dim3(PP ? 2 * NTHREADS : NTHREADS), lds_req, st, p);
+  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, VEC, GATHER>), grid, dim3(NTHREADS), lds_req, st, p);
   return hipGetLastError();
 }
 
-template <int BM, int BN, int VEC, bool PP = false>
+template <int BM, int BN, int VEC>
 static hipError_t launch_wgrad(WgradParams& p, int ntiles_n, hipStream_t st) {
   if (VEC == 4 && any_gather(p.g)) return launch_wgrad_g<BM, BN, VEC, true>(p, ntiles_n, st);
-  return launch_wgrad_g<BM, BN, VEC, false, PP>(p, ntiles_n, st);
+  return launch_wgrad_g<BM, BN, VEC, false>(p, ntiles_n, st);
 }
 
 // bf16 operand path (desc->compute_dtype == 1): vectorised, gather-free launches only (spatial convs);
@@ -1493,14 +1389,14 @@ template <int BM, int BN>
 static hipError_t launch_fwd_h(FwdParams& p, hipStream_t st) {
   constexpr size_t lds = TileBytes<true, BM, false>::value + TileBytes<true, BN, false>::value;
   dim3 grid((p.Cout + BN - 1) / BN, (p.M + BM - 1) / BM, p.e.nsplit);
-  hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, 4, false, false, true>), grid, dim3(NTHREADS), lds, st, p);
+  hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, 4, false, true>), grid, dim3(NTHREADS), lds, st, p);
   return hipGetLastError();
 }
 template <int BM, int BN>
 static hipError_t launch_dgrad_h(DgradParams& p, hipStream_t st) {
   constexpr size_t lds = TileBytes<true, BM, false>::value + TileBytes<true, BN, true>::value;
   dim3 grid((p.Nc + BN - 1) / BN, (p.M + BM - 1) / BM, p.parity ? 4 * p.e.nsplit : p.e.nsplit);
-  hipLaunchKernelGGL((conv_dgrad_kernel<BM, BN, 4, 4, false, true>), grid, dim3(NTHREADS), lds, st, p);
+  hipLaunchKernelGGL((conv_dgrad_kernel<BM, BN, 4, 4, true>), grid, dim3(NTHREADS), lds, st, p);
   return hipGetLastError();
 }
 template <int BM, int BN>
@@ -1510,142 +1406,8 @@ static hipError_t launch_wgrad_h(WgradParams& p, int ntiles_n, hipStream_t st) {
   p.ntiles_m = (p.Cout + BM - 1) / BM;
   dim3 grid(p.ntiles_n, p.ntiles_m, p.e.nsplit);
   const size_t lds_req = (p.background && BM * BN > 64 * 64) ? std::max(lds, std::min<size_t>(g_bg_lds, 64 * 1024)) : lds;
-  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, 4, false, false, true>), grid, dim3(NTHREADS), lds_req, st, p);
+  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, 4, false, true>), grid, dim3(NTHREADS), lds_req, st, p);
   return hipGetLastError();
-}
-
-// Ping-pong form (512-thread workgroups, k_pipeline_pp) for launches that fill the chip anyway:
-// at least g_pp_min 512-thread workgroups per CU after pairing.  OFF by default (SG2IM_PP=1 enables
-// it): measured SLOWER than the plain form on every layer of the table (forward 82.9 -> 71.6
-// TFLOP/s over the 25 layers, m4.conv0 100.9 -> 96.6; profiles/r2_pingpong_ab.log), i.e. the idle
-// matrix-pipe time is NOT the co-resident waves' loader phases coinciding.
-static const int g_pp = getenv("SG2IM_PP") ? atoi(getenv("SG2IM_PP")) : 0;
-static const double g_pp_min = getenv("SG2IM_PP_MIN") ? atof(getenv("SG2IM_PP_MIN")) : 1.0;
-static bool use_pp(const Plan& pl, long long pair_tiles, long long other_tiles, bool gather) {
-  if (!g_pp || gather || pl.tile == 2 || pair_tiles < 2) return false;
-  const double wgs = (double)((pair_tiles + 1) / 2) * (double)other_tiles * pl.nsplit;
-  return wgs >= g_pp_min * g_num_cu;
-}
-
-
-// ---- second-generation loop (igemm2.h): forward / data gradient of stride-1 convolutions on plain sources ----
-// OFF by default (SG2IM_V2=1 enables it): correct on every shape (tests/test_gpu_parity.py), faster on the
-// large two-source layers (m4.conv0 forward 102 -> 114, m2.conv0 94 -> 106 TFLOP/s) but slower on the small-M
-// layers and on every data gradient, and the refinement network then needs its activations materialised:
-// the training step came out even, 10.46 vs 10.39 ms (profiles/r2_v2_direct_to_lds_ab.log).  Its loop tops
-// out at ~125 TFLOP/s even with the DMA removed (tools/conv_v2.py), so it is not the missing 30 %.
-static const int g_v2 = getenv("SG2IM_V2") ? atoi(getenv("SG2IM_V2")) : 0;
-static const long long g_v2_min = getenv("SG2IM_V2_MIN") ? atoll(getenv("SG2IM_V2_MIN")) : 128LL * 64 * 32;   // rows x columns
-
-static bool v2_src_ok(const Src& s, int NB, int H, int W, Src2& o) {
-  if (s.gidx || s.scale || s.shift || s.C % BK || s.ld % 4 || ((uintptr_t)s.p & 15) || s.up > 1) return false;
-  const unsigned long long bytes = 4ull * NB * (H >> s.up) * (W >> s.up) * s.ld;
-  if (bytes >= 0x7fffff00ull) return false;
-  o.p = s.p; o.bytes = (unsigned)bytes; o.C = s.C; o.ld = s.ld; o.up = s.up;
-  return true;
-}
-
-// tile choice: 0 = 256x64 (8 waves), 1 = 128x64, 2 = 128x128 (4 waves); split-K so that ~2.5 workgroup
-// "slots" of 256 threads per CU are filled
-struct Plan2 { int tile, nsplit; };
-static Plan2 plan_v2(long long M, int N, int iters, long long MN, size_t ws_bytes, bool can_split) {
-  Plan2 pl;
-  if (N <= 64) pl.tile = (M >= 256LL * 2 * g_num_cu) ? 0 : 1;
-  else pl.tile = (N % 128 == 0 && M * N >= 128LL * 128 * 3 * g_num_cu) ? 2 : 1;
-  const int bm = pl.tile == 0 ? 256 : 128, bn = pl.tile == 2 ? 128 : 64;
-  const long long tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
-  const double slots = (double)tiles * (pl.tile == 0 ? 2.0 : 1.0);           // in units of 256-thread workgroups
-  int ns = 1;
-  if (can_split && slots < 2.5 * g_num_cu) {
-    ns = (int)std::min<double>(std::ceil(2.5 * g_num_cu / slots), std::max(1, iters / 6));
-    ns = (int)std::min<long long>(ns, MN > 0 ? std::max<long long>(1, (long long)(ws_bytes / sizeof(float)) / MN) : 1);
-    const int per = (iters + ns - 1) / ns;
-    ns = (iters + per - 1) / per;
-  }
-  pl.nsplit = std::max(1, ns);
-  return pl;
-}
-
-template <int BM, int BN, int NW, int MODE>
-static hipError_t launch_v2_t(Conv2Params& p, hipStream_t st) {
-  constexpr size_t lds = 2 * (size_t)(BM + BN) * BK * sizeof(float);
-  static bool ready = false;
-  if (!ready) {
-    const hipError_t e = ensure_lds(conv2_kernel<BM, BN, NW, MODE>, lds);
-    if (e != hipSuccess) return e;
-    ready = true;
-  }
-  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.e.nsplit);
-  hipLaunchKernelGGL((conv2_kernel<BM, BN, NW, MODE>), grid, dim3(NW * 64), lds, st, p);
-  return hipGetLastError();
-}
-
-template <int MODE>
-static hipError_t launch_v2(Conv2Params& p, int tile, hipStream_t st) {
-  return tile == 0 ? launch_v2_t<256, 64, 8, MODE>(p, st) : tile == 1 ? launch_v2_t<128, 64, 4, MODE>(p, st)
-                                                                         : launch_v2_t<128, 128, 4, MODE>(p, st);
-}
-
-// (sg2im_init: every instantiation's attribute up front)
-static hipError_t prepare_v2() {
-  hipError_t e = hipSuccess;
-#define SG2IM_V2PREP(BM, BN, NW, MODE) \
-  if (e == hipSuccess) e = ensure_lds(conv2_kernel<BM, BN, NW, MODE>, 2 * (size_t)(BM + BN) * BK * sizeof(float));
-  SG2IM_V2PREP(256, 64, 8, 0) SG2IM_V2PREP(128, 64, 4, 0) SG2IM_V2PREP(128, 128, 4, 0)
-  SG2IM_V2PREP(256, 64, 8, 1) SG2IM_V2PREP(128, 64, 4, 1) SG2IM_V2PREP(128, 128, 4, 1)
-#undef SG2IM_V2PREP
-  return e;
-}
-
-static bool v2_geometry_ok(const sg2im_conv_desc* d) {
-  return d->weight_channels == 0 && g_v2 && d->compute_dtype == 0 && d->stride == 1 && d->out_h == d->in_h && d->out_w == d->in_w &&
-         d->kh * d->kw <= 25 && d->in_h < 32768 && d->in_w < 32768 && d->nsrc <= 2;
-}
-
-// returns 1 when the launch was taken (status in *rc), 0 when the caller must use the first-generation kernels
-static int try_v2_forward(const sg2im_conv_desc* d, ConvGeom& g, const float* weight, int cout, const float* bias,
-                          float out_slope, float* out, long long ld_out, int accumulate, float* workspace,
-                          size_t workspace_bytes, hipStream_t stream, int* rc) {
-  if (!v2_geometry_ok(d) || ((uintptr_t)weight & 15) || g.Ctot % 4) return 0;
-  Conv2Params p;
-  if (!v2_src_ok(g.s0, g.NB, g.H, g.W, p.s0)) return 0;
-  p.nsrc = g.nsrc;
-  if (g.nsrc == 2) { if (!v2_src_ok(g.s1, g.NB, g.H, g.W, p.s1)) return 0; }
-  else p.s1 = p.s0;
-  const unsigned long long wb = 4ull * cout * g.KH * g.KW * g.Ctot;
-  if (wb >= 0x7fffff00ull) return 0;
-  p.Wt = weight; p.w_bytes = (unsigned)wb; p.Ctot = g.Ctot; p.ldw = g.KH * g.KW * g.Ctot;
-  p.NB = g.NB; p.H = g.H; p.W = g.W; p.KH = g.KH; p.KW = g.KW; p.pad = g.pad;
-  p.M = g.NB * g.H * g.W; p.N = cout; p.c_begin = 0; p.Kd = 0;
-  p.nch = g.Ctot / BK; p.iters = g.KH * g.KW * p.nch;
-  if (cout < 32 || (long long)p.M * cout < g_v2_min) return 0;                // tiny problems: the 64x64 tiles of igemm.h
-  const Plan2 pl = plan_v2(p.M, cout, p.iters, (long long)p.M * cout, workspace_bytes, workspace != nullptr);
-  p.e = Epi{out, ld_out, bias, out_slope, accumulate, workspace, pl.nsplit};
-  if (launch_v2<0>(p, pl.tile, stream) != hipSuccess) { *rc = SG2IM_ERR_HIP; return 1; }
-  *rc = finish_split(p.e, p.M, cout, stream) == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
-  return 1;
-}
-
-static int try_v2_dgrad(const sg2im_conv_desc* d, const ConvGeom& g, const float* weight, int cout, const float* dy,
-                        int ld_dy, int c_begin, int c_count, float* dx, long long ld_dx, int accumulate,
-                        float* workspace, size_t workspace_bytes, hipStream_t stream, int* rc) {
-  if (!v2_geometry_ok(d) || ((uintptr_t)weight & 15) || g.Ctot % 4 || c_begin % 4 || c_count % 4) return 0;
-  if (cout % BK || ld_dy % 4 || ((uintptr_t)dy & 15)) return 0;
-  Conv2Params p;
-  const unsigned long long yb = 4ull * g.NB * g.H * g.W * ld_dy, wb = 4ull * cout * g.KH * g.KW * g.Ctot;
-  if (yb >= 0x7fffff00ull || wb >= 0x7fffff00ull) return 0;
-  p.s0 = Src2{dy, (unsigned)yb, cout, ld_dy, 0};
-  p.s1 = p.s0; p.nsrc = 1;
-  p.Wt = weight; p.w_bytes = (unsigned)wb; p.Ctot = g.Ctot; p.ldw = g.KH * g.KW * g.Ctot;
-  p.NB = g.NB; p.H = g.H; p.W = g.W; p.KH = g.KH; p.KW = g.KW; p.pad = g.pad;
-  p.M = g.NB * g.H * g.W; p.N = c_count; p.c_begin = c_begin; p.Kd = cout;
-  p.nch = cout / BK; p.iters = g.KH * g.KW * p.nch;
-  if (c_count < 32 || (long long)p.M * c_count < g_v2_min) return 0;
-  const Plan2 pl = plan_v2(p.M, c_count, p.iters, (long long)p.M * c_count, workspace_bytes, workspace != nullptr);
-  p.e = Epi{dx, ld_dx, nullptr, 1.f, accumulate, workspace, pl.nsplit};
-  if (launch_v2<1>(p, pl.tile, stream) != hipSuccess) { *rc = SG2IM_ERR_HIP; return 1; }
-  *rc = finish_split(p.e, p.M, c_count, stream) == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
-  return 1;
 }
 
 __global__ void init_probe_kernel(int* flag) { if (flag) flag[0] = 1; }
@@ -1671,12 +1433,6 @@ int sg2im_init(void) {
   SG2IM_PREP((fn<64, 64, __VA_ARGS__>())); SG2IM_PREP((fn<64, 128, __VA_ARGS__>()))
   SG2IM_PREP_TILES(prepare_fwd, 4, false);
   SG2IM_PREP_TILES(prepare_fwd, 4, true);
-  SG2IM_PREP((prepare_fwd<128, 128, 4, false, true>())); SG2IM_PREP((prepare_fwd<128, 64, 4, false, true>()));
-  SG2IM_PREP((prepare_fwd<64, 128, 4, false, true>()));
-  SG2IM_PREP((prepare_dgrad<128, 128, 4, 4, true>())); SG2IM_PREP((prepare_dgrad<128, 64, 4, 4, true>()));
-  SG2IM_PREP((prepare_dgrad<64, 128, 4, 4, true>()));
-  SG2IM_PREP((prepare_wgrad<128, 128, 4, false, true>())); SG2IM_PREP((prepare_wgrad<128, 64, 4, false, true>()));
-  SG2IM_PREP((prepare_wgrad<64, 128, 4, false, true>()));
   SG2IM_PREP((prepare_fwd<64, 64, 1, false>()));
   SG2IM_PREP_TILES(prepare_dgrad, 4, 4);
   SG2IM_PREP((prepare_dgrad<64, 64, 4, 1>())); SG2IM_PREP((prepare_dgrad<128, 64, 4, 1>()));
@@ -1689,7 +1445,6 @@ int sg2im_init(void) {
 #undef SG2IM_PREP_TILES
 #undef SG2IM_PREP
   if (e == hipSuccess) e = ensure_lds(conv_wgrad_group_kernel, wgrad_lds<64, 64>());
-  if (e == hipSuccess) e = prepare_v2();
   if (e != hipSuccess) return SG2IM_ERR_HIP;
   hipLaunchKernelGGL(init_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)0, (int*)nullptr);
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize((hipStream_t)0) != hipSuccess) return SG2IM_ERR_HIP;
@@ -1706,12 +1461,6 @@ int sg2im_conv2d_forward(const sg2im_conv_desc* d, const float* weight, int cout
   p.Wt = weight; p.Cout = cout;
   p.M = d->batch * d->out_h * d->out_w;
   if (p.M == 0) return SG2IM_OK;
-  {
-    int rc2 = SG2IM_OK;
-    if (try_v2_forward(d, p.g, weight, cout, bias, out_slope, out, ld_out, accumulate, workspace, workspace_bytes,
-                       stream, &rc2))
-      return rc2;
-  }
   const bool v4 = geom_vec4(p.g) && !((uintptr_t)weight & 15);
   const int taps = d->kh * d->kw;
   if (v4) {
@@ -1729,9 +1478,6 @@ int sg2im_conv2d_forward(const sg2im_conv_desc* d, const float* weight, int cout
   if (v4 && d->compute_dtype == 1 && !any_gather(p.g)) {
     err = pl.tile == 0 ? launch_fwd_h<128, 128>(p, stream) : pl.tile == 1 ? launch_fwd_h<128, 64>(p, stream)
         : pl.tile == 2 ? launch_fwd_h<64, 64>(p, stream) : launch_fwd_h<64, 128>(p, stream);
-  } else if (v4 && use_pp(pl, (p.M + pl.bm - 1) / pl.bm, (cout + pl.bn - 1) / pl.bn, any_gather(p.g))) {
-    err = pl.tile == 0 ? launch_fwd<128, 128, 4, true>(p, stream) : pl.tile == 1 ? launch_fwd<128, 64, 4, true>(p, stream)
-                       : launch_fwd<64, 128, 4, true>(p, stream);
   } else if (v4) {
     err = pl.tile == 0 ? launch_fwd<128, 128, 4>(p, stream) : pl.tile == 1 ? launch_fwd<128, 64, 4>(p, stream)
         : pl.tile == 2 ? launch_fwd<64, 64, 4>(p, stream) : launch_fwd<64, 128, 4>(p, stream);
@@ -1752,12 +1498,6 @@ int sg2im_conv2d_backward_data(const sg2im_conv_desc* d, const float* weight, in
   // geometry (and Ctot) of the forward conv; s0 is then re-purposed to carry dY
   ConvGeom& g = p.g;
   fill_geom(g, d);
-  if (c_begin >= 0 && c_begin + c_count <= g.Ctot && (long long)d->batch * d->in_h * d->in_w > 0) {
-    int rc2 = SG2IM_OK;
-    if (try_v2_dgrad(d, g, weight, cout, dy, ld_dy, c_begin, c_count, dx, ld_dx, accumulate, workspace, workspace_bytes,
-                     stream, &rc2))
-      return rc2;
-  }
   g.nsrc = 1;
   for (int i = 0; i < 4; ++i) *src_at(g, i) = Src{nullptr, nullptr, nullptr, nullptr, 1.f, 0, 0, 0};
   g.s0.p = dy; g.s0.C = cout; g.s0.ld = ld_dy;
@@ -1811,10 +1551,6 @@ int sg2im_conv2d_backward_data(const sg2im_conv_desc* d, const float* weight, in
   if (va4 && vb4 && d->compute_dtype == 1) {
     err = pl.tile == 0 ? launch_dgrad_h<128, 128>(p, stream) : pl.tile == 1 ? launch_dgrad_h<128, 64>(p, stream)
         : pl.tile == 2 ? launch_dgrad_h<64, 64>(p, stream) : launch_dgrad_h<64, 128>(p, stream);
-  } else if (va4 && vb4 && !p.parity &&
-      use_pp(pl, (Mrows + pl.bm - 1) / pl.bm, (c_count + pl.bn - 1) / pl.bn, false)) {
-    err = pl.tile == 0 ? launch_dgrad<128, 128, 4, 4, true>(p, stream) : pl.tile == 1 ? launch_dgrad<128, 64, 4, 4, true>(p, stream)
-                       : launch_dgrad<64, 128, 4, 4, true>(p, stream);
   } else if (va4 && vb4) {
     err = pl.tile == 0 ? launch_dgrad<128, 128, 4, 4>(p, stream) : pl.tile == 1 ? launch_dgrad<128, 64, 4, 4>(p, stream)
         : pl.tile == 2 ? launch_dgrad<64, 64, 4, 4>(p, stream) : launch_dgrad<64, 128, 4, 4>(p, stream);
@@ -1873,10 +1609,6 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
         : pl.tile == 1 ? launch_wgrad_h<128, 64>(p, ntiles_n, stream)
         : pl.tile == 2 ? launch_wgrad_h<64, 64>(p, ntiles_n, stream)
                        : launch_wgrad_h<64, 128>(p, ntiles_n, stream);
-  } else if (v4 && use_pp(pl, ntiles_n, (cout + pl.bm - 1) / pl.bm, any_gather(p.g))) {
-    err = pl.tile == 0 ? launch_wgrad<128, 128, 4, true>(p, ntiles_n, stream)
-        : pl.tile == 1 ? launch_wgrad<128, 64, 4, true>(p, ntiles_n, stream)
-                       : launch_wgrad<64, 128, 4, true>(p, ntiles_n, stream);
   } else if (v4) {
     err = pl.tile == 0 ? launch_wgrad<128, 128, 4>(p, ntiles_n, stream)
         : pl.tile == 1 ? launch_wgrad<128, 64, 4>(p, ntiles_n, stream)

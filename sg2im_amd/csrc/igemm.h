@@ -344,224 +344,38 @@ __device__ __forceinline__ void mma_frags_h(const FragsH<BM, BN>& f, f32x16 (&ac
 
 // Software pipeline shared by the three kernels: the global loads of the next K-chunk are kept
 // in flight in registers while the matrix cores work on the chunk staged in LDS.
-//   load(it, set)        : global -> register set     stage(set, buf, live) : registers -> LDS buffer
-//   mma(0, buf) / (1, buf): fragments of LDS buffer `buf` -> registers / the BK chunk of MFMAs
-// (register sets / LDS buffers are selected by compile-time tags so the register arrays are
-// never dynamically indexed, which would demote them to scratch; `live` is false for the
-// re-staged copy of the last chunk, see k_pipeline_d1)
-template <int I> struct IC { static constexpr int value = I; };
-
-#ifndef SG2IM_SMALL_TILE_DEPTH
-#define SG2IM_SMALL_TILE_DEPTH 1   // (2 measured: no gain on the tiny GEMMs, fewer resident waves)
-#endif
-#ifndef SG2IM_LDS_STAGES
-#define SG2IM_LDS_STAGES 1
-#endif
-constexpr int LDS_STAGES = SG2IM_LDS_STAGES;
-
-#ifndef SG2IM_SCHED_FENCE
-#define SG2IM_SCHED_FENCE 0      // (see SG2IM_LAUNDER in conv.hip: measured slower)
-#endif
-#ifndef SG2IM_ABL
-#define SG2IM_ABL 0        // timing-only ablations (1: no loads/stores in the loop, 2: no barriers)
-#endif
-// (Measured and dropped, round 2: delaying the co-resident workgroups of a CU by 1-3k cycles at
-// kernel start - by linear block id or by the hardware wave slot - to de-phase their loader / MFMA
-// phases changed nothing, 86.9 vs 86.0-86.7 TFLOP/s forward over the layer table.)
-// Depth-1 variant: ONE register set and a branch-free loop body - the loads of chunk i+1,
-// the MFMAs of chunk i and the LDS stores of chunk i+1 are one basic block, so the compiler
-// can slot the loader's address arithmetic into the 64-cycle shadows of the MFMAs (a wave
-// issues ~8 other instructions per fp32 MFMA for free).  The last chunk is fetched and
-// staged a second time instead of guarding the tail with branches; that copy is never read.
+//   load(it)  : global -> registers          stage(live) : registers -> LDS
+//   mma(0) / mma(1): fragments of the LDS image -> registers / the BK chunk of MFMAs
+// The main loop shared by the three kernels - ONE register set, ONE LDS image per operand and a
+// branch-free loop body: the loads of chunk i+1, the MFMAs of chunk i and the LDS stores of chunk i+1
+// are one basic block, so the compiler can slot the loader's address arithmetic into the 64-cycle
+// shadows of the MFMAs (a wave issues ~8 other instructions per fp32 MFMA for free).  The last chunk
+// is fetched and staged a second time instead of guarding the tail with branches; that copy is never
+// read (`live` = false for it).  A single LDS image means two barriers per chunk (every wave must be
+// done reading chunk i before it is overwritten) but half the LDS, i.e. twice the resident workgroups.
+// [Round 2 measured and dropped: a two-image / two-register-set loop for the small tiles, a 512-thread
+// ping-pong form, two chunks per barrier interval, staggered workgroup starts and a direct-to-LDS
+// loop - none faster on the training step; see DESIGN.md section 4.1 and profiles/r2_*_ab.log.]
 template <typename Load, typename Stage, typename Mma>
-__device__ __forceinline__ void k_pipeline_d1(int it_begin, int it_end, Load load, Stage stage, Mma mma) {
+__device__ __forceinline__ void k_pipeline(int it_begin, int it_end, Load load, Stage stage, Mma mma) {
   const int n = it_end - it_begin;
   if (n <= 0) return;
-  load(it_begin, IC<0>());
-  stage(IC<0>(), 0, true);
+  load(it_begin);
+  stage(true);
   __syncthreads();
-  int cur = 0;
   #pragma unroll 1
   for (int i = 0; i < n; ++i) {
     const int nxt = i + 1 < n ? i + 1 : n - 1;
-#if !(SG2IM_ABL & 1)
-    load(it_begin + nxt, IC<0>());
-#endif
+    load(it_begin + nxt);
     // keep the global loads ahead of the MFMA block: left alone, the scheduler sinks them
     // to just before their first use (end of the block) and the wave stalls on vmcnt
     __builtin_amdgcn_sched_barrier(0);
-    if (LDS_STAGES == 2) {
-      mma(0, cur); mma(1, cur);
-      stage(IC<0>(), cur ^ 1, i + 1 < n);
-      __syncthreads();
-      cur ^= 1;
-    } else {
-      // single LDS image (half the LDS -> twice the resident workgroups): every wave must
-      // be done reading chunk i before it is overwritten, hence the second barrier
-      mma(0, 0); mma(1, 0);
-#if SG2IM_SCHED_FENCE
-      __builtin_amdgcn_sched_barrier(0);       // (experiment: keep stage(i+1) out of the MFMA block)
-#endif
-#if !(SG2IM_ABL & 2)
-      __syncthreads();
-#endif
-#if !(SG2IM_ABL & 1)
-      stage(IC<0>(), 0, i + 1 < n);
-#endif
-#if !(SG2IM_ABL & 2)
-      __syncthreads();
-#endif
-    }
-  }
-}
-// Depth-2 variant (used for the 64x64 tile): TWO register sets and TWO LDS images, one barrier
-// per chunk - two chunks of global loads stay in flight.  The small-tile launches are tiny
-// GEMMs with few workgroups per CU, where nothing else hides the load -> store -> barrier ->
-// MFMA latency chain of each chunk (measured ~1.2 us per chunk with the depth-1 loop).
-template <typename Load, typename Stage, typename Mma>
-__device__ __forceinline__ void k_pipeline_d2(int it_begin, int it_end, Load load, Stage stage, Mma mma) {
-  const int n = it_end - it_begin;
-  if (n <= 0) return;
-  load(it_begin, IC<0>());
-  if (n > 1) load(it_begin + 1, IC<1>());
-  stage(IC<0>(), 0, true);
-  __syncthreads();
-  // ONE mma call site (runtime LDS buffer index): with the MFMA block instantiated twice
-  // hipcc gives each copy its own accumulator registers and doubles the AGPR budget.
-  // The loads / stages exist twice (wave-uniform branch on the chunk parity) so that each
-  // copy addresses its register set statically.
-  #pragma unroll 1
-  for (int i = 0; i < n; ++i) {
-    const int par = i & 1;
-    // (the distinct asm markers keep hipcc from merging the two branch bodies back into
-    // one copy that selects the register set through a pointer, i.e. through scratch)
-    if (i + 2 < n) {
-      if (par == 0) {
-        asm volatile("; k_pipeline: load set 0" ::: "memory");
-        load(it_begin + i + 2, IC<0>());
-        asm volatile("; k_pipeline: load set 0 done" ::: "memory");
-      } else {
-        asm volatile("; k_pipeline: load set 1" ::: "memory");
-        load(it_begin + i + 2, IC<1>());
-        asm volatile("; k_pipeline: load set 1 done" ::: "memory");
-      }
-    }
-    mma(0, par); mma(1, par);
-    if (i + 1 < n) {
-      if (par == 0) {
-        asm volatile("; k_pipeline: stage set 1" ::: "memory");
-        stage(IC<1>(), 1, true);
-        asm volatile("; k_pipeline: stage set 1 done" ::: "memory");
-      } else {
-        asm volatile("; k_pipeline: stage set 0" ::: "memory");
-        stage(IC<0>(), 0, true);
-        asm volatile("; k_pipeline: stage set 0 done" ::: "memory");
-      }
-    }
+    mma(0); mma(1);
+    __syncthreads();
+    stage(i + 1 < n);
     __syncthreads();
   }
 }
-
-// Ping-pong variant: a 512-thread workgroup = two 256-thread HALVES, each with its own output tile,
-// LDS image and register set, running the depth-1 loop one barrier apart: while half 0 is in its
-// MFMA block, half 1 converts / stores its next chunk to LDS and issues the global loads of the one
-// after, and vice versa - the two waves that share a SIMD are, by construction, never both in their
-// loader phase (which left the matrix pipe idle: time per K chunk was N x MFMA block + one full
-// loader phase for N = 1..4 co-resident 256-thread workgroups, i.e. the loader phases of co-resident
-// waves coincided instead of hiding under each other's MFMAs).  Every s_barrier is workgroup-wide
-// (all 8 waves); the halves execute the same NUMBER of barriers, half 1 offset by one.
-//   barrier #     half 0                          half 1
-//   0             (prologue: chunk 0 staged, chunk 1 in registers - both halves)
-//   1             MFMA(0)                          -
-//   2             stage(1), load(2)                MFMA(0)
-//   3             MFMA(1)                          stage(1), load(2)
-//   ...
-// `half` must be wave-uniform and the K range identical for both halves.
-template <typename Load, typename Stage, typename Mma>
-__device__ __forceinline__ void k_pipeline_pp(int half, int it_begin, int it_end, Load load, Stage stage, Mma mma) {
-  const int n = it_end - it_begin;
-  if (n <= 0) return;
-  load(it_begin, IC<0>());
-  stage(IC<0>(), 0, true);
-  load(it_begin + (n > 1 ? 1 : 0), IC<0>());
-  __syncthreads();                                  // # 0
-  if (half) __syncthreads();                        // # 1 (half 1 sits out half 0's first MFMA block)
-  #pragma unroll 1
-  for (int i = 0; i < n; ++i) {
-    mma(0, 0); mma(1, 0);
-    __syncthreads();
-    // chunk i+1 to LDS (after the last chunk: a copy that is never read), then the loads of chunk
-    // i+2 - a whole MFMA block + loader phase ahead of their use
-    stage(IC<0>(), 0, i + 1 < n);
-    load(it_begin + (i + 2 < n ? i + 2 : n - 1), IC<0>());
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-  }
-  if (!half) __syncthreads();                       // (same barrier count as half 1)
-}
-
-// Paired variant: TWO K chunks per barrier interval (an effective K step of 64 with the BK = 32
-// loaders, LDS images and fragment reads): chunks 2i / 2i+1 sit in LDS images 0 / 1, their
-// successors in register sets 0 / 1.  Per pair: one load block, 2 x (fragment reads + MFMA block),
-// barrier, two stages, barrier - half the barriers and half the store -> barrier -> read latency
-// chains per MFMA of the depth-1 loop, for twice its LDS and staging registers.  An odd chunk
-// count is padded with an all-zero LDS image in FRONT (zfill(1) - one wasted MFMA block per
-// workgroup) so that the MFMA blocks exist only inside the loop body: a second call site makes
-// hipcc give each copy its own accumulator registers.
-template <typename Load, typename Stage, typename Mma, typename Zfill>
-__device__ __forceinline__ void k_pipeline_x2(int it_begin, int it_end, Load load, Stage stage, Mma mma, Zfill zfill) {
-  const int n = it_end - it_begin;
-  if (n <= 0) return;
-  int pos = it_begin;
-  load(pos, IC<0>());
-  stage(IC<0>(), 0, true);
-  if (n & 1) {
-    zfill(1);
-    pos += 1;
-  } else {
-    load(pos + 1, IC<1>());
-    stage(IC<1>(), 1, true);
-    pos += 2;
-  }
-  __syncthreads();
-  const int pairs = (n + 1) >> 1;
-  #pragma unroll 1
-  for (int i = 0; i < pairs; ++i, pos += 2) {
-    // (after the last pair: the final chunk is fetched and staged twice more, copies that are never
-    // read - the loaders' cursors do not advance past index it_end - 1)
-    const bool more = pos < it_end;
-    load(more ? pos : it_end - 1, IC<0>()); load(more ? pos + 1 : it_end - 1, IC<1>());
-    __builtin_amdgcn_sched_barrier(0);
-    mma(0, 0); mma(1, 0);
-    mma(0, 1); mma(1, 1);
-    __syncthreads();
-    stage(IC<0>(), 0, more); stage(IC<1>(), 1, more);
-    __syncthreads();
-  }
-}
-
-// PD = 1: single LDS image / one register set (large tiles, occupancy bound)
-// PD = 2: double LDS image / two register sets (small tiles, latency bound)
-// PD = 3: paired chunks (k_pipeline_x2)
-template <int PD, typename Load, typename Stage, typename Mma, typename Zfill>
-__device__ __forceinline__ void k_pipeline(int it_begin, int it_end, Load load, Stage stage, Mma mma, Zfill zfill) {
-  if constexpr (PD == 3) k_pipeline_x2(it_begin, it_end, load, stage, mma, zfill);
-  else if constexpr (PD == 2) k_pipeline_d2(it_begin, it_end, load, stage, mma);
-  else k_pipeline_d1(it_begin, it_end, load, stage, mma);
-}
-
-#ifndef SG2IM_X2
-#define SG2IM_X2 0         // bit 0: 128x128, bit 1: 128x64 / 64x128, bit 2: 64x64 tiles use the paired loop
-// (measured, profiles/r2_paired_chunk_ab.log: 128x128 forward +2 %, weight gradient -2 %, 128x64 tiles
-// -5 % - the lost resident workgroup costs what the saved barriers gain; step 10.29 -> 10.34 / 10.6 ms. OFF.)
-#endif
-// pipeline depth / LDS images per tile shape
-template <int BM, int BN> struct TilePipe {
-  static constexpr bool X2 = (BM * BN == 128 * 128) ? (SG2IM_X2 & 1) != 0
-                           : (BM * BN == 128 * 64) ? (SG2IM_X2 & 2) != 0 : (SG2IM_X2 & 4) != 0;
-  static constexpr int DEPTH = X2 ? 3 : (BM * BN <= 64 * 64) ? SG2IM_SMALL_TILE_DEPTH : 1;
-  static constexpr int LDS_IMAGES = DEPTH >= 2 ? 2 : LDS_STAGES;
-};
 
 // wave placement inside the block tile: 2 x 2 wavefronts
 template <int BM, int BN>

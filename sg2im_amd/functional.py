@@ -493,8 +493,6 @@ class LayoutFn(Function):
 
   @staticmethod
   def backward(ctx, g):
-    if ops.TAIL_EVENT is not None and ops.TAIL_EVENT_AT < 0:   # Trainer: the refinement network is done
-      ops.TAIL_EVENT.record()
     vecs, boxes, masks, obj_to_img = ctx.saved_tensors
     n_images, H, W, ac = ctx.geom
     ni = ctx.needs_input_grad
@@ -631,16 +629,10 @@ class RefinementFn(Function):
     for i in range(1, L):
       pyr.append(ops.avgpool_forward(pyr[-1], 2, _new(layout, N, H >> i, W >> i, Cl)))
     pyr = pyr[::-1]
-    # (bf16 operands: the first-generation loader rounds while it stages, keep the pending form there)
-    mat = ops.V2_MATERIALIZE and ops.CONV_COMPUTE == 0
 
     def activated(y, st, up):
-      """the source the next convolution reads: leaky(bn(y)), materialised or pending in its loader"""
-      if not mat:
-        return nhwc_src(y, up, st.scale, st.shift, slope)
-      a = _new(layout, *y.shape)
-      ops.affine_act_forward(y.view(-1, y.size(3)), st, slope, a.view(-1, y.size(3)))
-      return nhwc_src(a, up)
+      """the source the next convolution reads: leaky(bn(y)), pending in its loader"""
+      return nhwc_src(y, up, st.scale, st.shift, slope)
     for i in range(L):
       h, w = H >> (L - 1 - i), W >> (L - 1 - i)
       lay = pyr[i]
@@ -725,8 +717,6 @@ class RefinementFn(Function):
     Cg = Cl if grad_channels is None else min(int(grad_channels), Cl)
     dlevels = []
     for i in range(L - 1, -1, -1):
-      if ops.TAIL_EVENT is not None and i == ops.TAIL_EVENT_AT:
-        ops.TAIL_EVENT.record()          # Trainer: from this module on the kernels are small
       lay, feat_src, y0, st0, y1, st1, h, w, C, src0 = saved[i]
       W0p, b0, W1p, b1 = convp[4 * i:4 * i + 4]
       g0, be0, g1, be1 = bnp[4 * i:4 * i + 4]
@@ -1004,8 +994,8 @@ class DiscCnnFn(Function):
         src = nhwc_src(y, 0, st.scale, st.shift, slope)
       elif nonorm:
         src = nhwc_src(y)
-    if count is not None and inorm:
-      raise NotImplementedError('padded batches with instance normalisation')
+    # (padded batches under instance normalisation need nothing: the norm is per sample, the dummy crops are
+    # independent samples and the counted losses hand them a zero gradient)
     ctx.saved, ctx.misc = saved, (specs, slope, training, tuple(x.shape), nonorm, inorm, count)
     ctx.save_for_backward(*params)
     return saved[-1][2]

@@ -62,15 +62,13 @@ def _i32(t):
 # dependent kernels of the layout / mask / graph-convolution backward, which otherwise have the
 # GPU to themselves.  The Trainer sets DEFERRED to a list for the duration of the generator backward
 # and joins the lanes it finds there before the optimiser step.  [measured: 10.3 -> 9.7 ms per step,
-# profiles/r2_deferred_wgrad_ab.log; SG2IM_DEFER_WGRAD=0 restores the interleaved order]
-DEFER_WGRAD = os.environ.get('SG2IM_DEFER_WGRAD', '1') != '0'
+# profiles/r2_deferred_wgrad_ab.log]
+DEFER_WGRAD = True
 DEFERRED = None
 HINT_BACKGROUND = 1
 # only the first BG_COUNT released weight gradients are issued as background launches (occupancy cap): the later
 # ones run after the small-kernel tail is over and may have the whole GPU
-BG_COUNT = int(os.environ.get('SG2IM_BG_COUNT', '6'))        # [measured: all 11: 8.90-8.94, 8: 8.84, 6: 8.81, 4: 8.82, 2: 8.85 ms]
-TAIL_EVENT = None   # optional torch.cuda.Event recorded when the generator backward reaches ...
-TAIL_EVENT_AT = -1  # ... refinement module TAIL_EVENT_AT (counting down), or the layout (-1)
+BG_COUNT = 6        # [measured: all 11: 8.90-8.94, 8: 8.84, 6: 8.81, 4: 8.82, 2: 8.85 ms]
 def _lane(device):
   """Work buffers are per (device, stream): kernels of one in-order stream use them one after
   the other, concurrently running streams (the Trainer's side stream, autograd branches that
@@ -83,9 +81,8 @@ def _lane(device):
 
 
 _wgrad_streams = {}
-WGRAD_SIDE = os.environ.get('SG2IM_WGRAD_SIDE', '1') != '0'
 # the four weight gradients of a GraphTripleConv layer as one grouped launch (sg2im_conv2d_backward_weight_group)
-GROUP_WGRAD = os.environ.get('SG2IM_GROUP_WGRAD', '1') != '0'
+GROUP_WGRAD = True
 
 
 class SideLane(object):
@@ -99,7 +96,7 @@ class SideLane(object):
   def __init__(self, device):
     # only while a hipGraph is being captured: launched eagerly, the extra event / stream switches
     # cost more host time (the eager step is launch bound) than the overlap returns
-    self.on = WGRAD_SIDE and torch.cuda.is_current_stream_capturing()
+    self.on = torch.cuda.is_current_stream_capturing()
     self.used = False
     self.keep = []
     self.queue = []
@@ -167,11 +164,19 @@ def workspace(device):
   return w
 
 
+_scratch_retired = []
+
+
 def scratch(device, nfloats):
-  """Reduction scratch (per device and stream), grown on demand."""
+  """Reduction scratch (per device and stream), grown on demand.  A buffer that is outgrown is RETIRED, not
+  freed: hipGraphs captured earlier have its address baked in and keep writing into it on every replay - were it
+  returned to the caching allocator, a replay of an older bucket's graph would silently corrupt whatever tensor
+  owns that memory by then.  The retired buffers are small next to 288 GB of HBM."""
   key = _lane(device)
   s = _scratch.get(key)
   if s is None or s.numel() < nfloats:
+    if s is not None:
+      _scratch_retired.append(s)
     s = torch.empty(max(int(nfloats), 1 << 20), dtype=torch.float32, device=device)
     _scratch[key] = s
   return s
@@ -207,12 +212,6 @@ def rows_src(t, gather=None):
   _, ld = rows_ld(t)
   return SrcSpec(t, t.size(1), ld, 0, gather)
 
-
-# Refinement network with SG2IM_V2=1: MATERIALISE the activated tensors (BatchNorm + LeakyReLU applied by
-# one elementwise pass) instead of folding them into the next convolution's loader, so that its stride-1
-# convolutions qualify for the direct-to-LDS loop (csrc/igemm2.h), which needs plain sources.  Off by
-# default: measured even with the first-generation loop on the whole step (see conv.hip).
-V2_MATERIALIZE = os.environ.get('SG2IM_V2', '0') == '1'
 
 # Arithmetic of the SPATIAL convolutions (refinement network, discriminators, mask_net): 0 = fp32
 # matrix cores, 1 = bf16 operands with fp32 accumulation (sg2im_conv_desc.compute_dtype).  Linear
@@ -722,12 +721,9 @@ def unit(device):
   return u
 
 
-_UNIT_SHORTCUT = os.environ.get('SG2IM_UNIT_GRAD', '1') != '0'
-
-
 def is_unit(g):
   u = _units.get(g.device.index)
-  return _UNIT_SHORTCUT and u is not None and g.data_ptr() == u.data_ptr()
+  return u is not None and g.data_ptr() == u.data_ptr()
 
 
 def sum_scalars(terms, out):

@@ -122,7 +122,6 @@ class Trainer(object):
     # (they only need imgs_pred; their small kernels fill the CUs the GCN / MLP backward leaves idle)
     self.overlap_d = True if overlap_d is None else bool(overlap_d)
     self._side = None
-    self.overlap_eager = os.environ.get('SG2IM_OVERLAP_EAGER', '0') == '1'
     self._graphs = collections.OrderedDict()
     self.t = 0
 
@@ -300,34 +299,6 @@ class Trainer(object):
     self._seg_generator_backward(st)
     main.wait_stream(side)
 
-  def _run_overlapped_eager(self, batch, st):
-    """Eager form of the overlap: the generator's backward is enqueued on the current stream
-    first, then the discriminator steps on a side stream (the host runs ahead of the GPU, so
-    they execute next to the tail of the backward); gradient exchanges are started on the
-    stream that produced them."""
-    from . import ops
-    if self._side is None:
-      self._n_side = 1
-      self._side = (torch.cuda.Stream(),)
-    side, main, red = self._side[0], torch.cuda.current_stream(), self.reducer
-    self._seg_generator_forward(batch, st)
-    side.wait_stream(main)
-    self._seg_generator_backward(st)
-    red.start(self.flat_g.grad)
-    red.start(st['guard'])
-    with torch.cuda.stream(side):
-      for t in (st['imgs_fake'], st['imgs_nhwc']):
-        t.record_stream(side)
-      if self.d_obj is not None:
-        self._seg_d_obj(batch, st)
-        red.start(self.flat_do.grad)
-      if self.d_img is not None:
-        self._seg_d_img(batch, st)
-        red.start(self.flat_di.grad)
-    main.wait_stream(side)
-    red.finish()
-    self._seg_adam(st)
-
   def step(self, batch):
     """batch: (imgs (N,3,H,W), objs, boxes, masks | None, triples, obj_to_img) on the device.
     Returns a dict of 0-dim device tensors (no host sync)."""
@@ -348,10 +319,7 @@ class Trainer(object):
       o_pad, t_pad = self.bucketer.bucket(batch[1].numel(), batch[4].size(0))
       batch, counts = pad_batch(batch, o_pad, t_pad)
       st['ocnt'], st['tcnt'] = (counts[0:1], 1), (counts[1:2], 1)
-    if self.overlap_eager:
-      self._run_overlapped_eager(batch, st)
-    else:
-      self._run_segments(batch, st, lambda name, fn: fn())
+    self._run_segments(batch, st, lambda name, fn: fn())
     return st['out']
 
   # -- hipGraph replay, one graph per batch-shape bucket ---------------------------
@@ -386,15 +354,16 @@ class Trainer(object):
     steps: sg2im_init() and _prepare_lanes() did everything a first launch would do lazily.
     Collectives stay outside the graphs.
 
-    ROCm 7 caveat (measured, tools/graph_fault_probe.py): an EAGER kernel launch from this library
-    after a graph was instantiated makes the next replay of that graph fault.  Eager launches through
-    the binding bump ``_lib.EAGER_EPOCH`` (captured ones do not); a graph whose epoch is stale is
-    dropped and re-captured at its next use, so validation passes / eager use of the library between
-    training steps are safe and cost one re-capture per bucket."""
+    Safety net: round 1 reported that an EAGER launch from this library after a graph was instantiated
+    made the next replay of that graph fault; 26 probe variants in round 2 could not reproduce it
+    (profiles/r2_graph_fault_probes.log), so it is NOT a known property of the runtime.  The check stays
+    because it is free on the training path: eager launches through the binding bump ``_lib.EAGER_EPOCH``
+    (captured ones do not); a graph whose epoch is stale is dropped and re-captured at its next use, so a
+    validation pass between training steps costs one re-capture per bucket and nothing otherwise."""
     imgs, objs, masks, triples = batch[0], batch[1], batch[3], batch[4]
     o_pad, t_pad = self.bucketer.bucket(objs.numel(), triples.size(0))
     key = (o_pad, t_pad, tuple(imgs.shape), None if masks is None else (masks.dtype,) + tuple(masks.shape[1:]))
-    if self._graphs and os.environ.get('SG2IM_IGNORE_EPOCH', '0') != '1':     # (tools/graph_fault_probe.py)
+    if self._graphs:
       stale = [k for k, e in self._graphs.items() if e[3] != _lib.EAGER_EPOCH]
       for k in stale:                # the library ran eagerly since these were instantiated
         del self._graphs[k]
@@ -408,6 +377,7 @@ class Trainer(object):
         print('WARNING: hipGraph capture failed (%s: %s); falling back to eager launches' % (type(e).__name__, e))
         _lib.CAPTURING = False
         self.use_graphs = False
+        self.bucketer = None          # (later steps run eagerly on the unpadded batch)
         torch.cuda.synchronize()
         st = {'losses': {}}
         self._run_segments(batch, st, lambda name, fn: fn())
@@ -436,16 +406,7 @@ class Trainer(object):
     (static batch, graphs, state dict with the output tensors, launch epoch)."""
     imgs = sb.imgs
     # reduction scratch the crop backward wants: one image-sized plane per (padded) object
-    if os.environ.get('SG2IM_PROBE_LANES_IN_CAPTURE', '0') != '1':
-      self._prepare_lanes(max(1 << 24, sb.o_pad * imgs.size(2) * imgs.size(3) * imgs.size(1) + (1 << 20)))
-    elif self._cap_stream is None:
-      # tools/graph_fault_probe.py: the round-1 behaviour - work buffers of the capture lanes are
-      # first touched (allocated) INSIDE the capture, i.e. out of the graph's private memory pool
-      self._cap_stream, self._n_side, self._side = torch.cuda.Stream(), 1, (torch.cuda.Stream(),)
-    if os.environ.get('SG2IM_PROBE_EAGER_WARMUP', '0') == '1':      # round 1: two eager steps first
-      for _ in range(2):
-        self._run_segments(sb.tensors(), {'losses': {}, 'ocnt': sb.obj_count, 'tcnt': sb.triple_count},
-                           lambda name, fn: fn())
+    self._prepare_lanes(max(1 << 24, sb.o_pad * imgs.size(2) * imgs.size(3) * imgs.size(1) + (1 << 20)))
     st = {'losses': {}, 'ocnt': sb.obj_count, 'tcnt': sb.triple_count}
     static = sb.tensors()
     dp = self.world_size > 1 or self.reducer.force
@@ -504,49 +465,26 @@ class Trainer(object):
     with torch.cuda.graph(g, stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
       main = torch.cuda.current_stream()
       side = self._side[0]
-      mode = os.environ.get('SG2IM_SCHEDULE', '0')
       self._seg_generator_forward(static, st)
 
-      def on_side(lane, seg, wait_ev=None):
-        if wait_ev is not None:
-          side.wait_event(wait_ev)
-        else:
-          side.wait_stream(main)
+      def on_side(seg):
+        side.wait_stream(main)
         with torch.cuda.stream(side):
           seg(static, st)
-      # Schedule (measured; SG2IM_SCHEDULE selects the variants that were compared).
-      # The generator backward is: the refinement network's data-gradient chain (big kernels), then the
-      # layout / mask / graph-convolution backward (~150 small dependent launches) with the refinement
-      # network's eleven weight gradients released underneath them as background launches
-      # (ops.DEFER_WGRAD).  With that, mode 0 - both discriminator steps on the side stream right after
-      # the generator forward, next to the data-gradient chain - is the fastest: 9.66 ms; 2 (the D_obj
-      # step held back until the backward reaches the layout): 9.77; 1 (D_obj first, D_img at the tail):
-      # 9.81; 3 (as 2, D_obj forward passes early): not re-measured.  [Round 1, weight gradients
-      # interleaved with the data gradients: 0: 10.65, 1: 10.39, 2: 10.33, 3: 10.42.]
-      # The ORDER OF CAPTURE matters, not only the dependencies: a replay issues the nodes in capture
-      # order, and branches only overlap with what is issued around the same time - capturing the
-      # discriminator steps AFTER the generator backward (same dependencies) costs 10.9 ms.  Without any
-      # discriminator step the iteration takes 9.13 ms: ~0.5 of their ~1.25 ms is still exposed.
-      if self.d_img is not None and mode != '1':
-        on_side(2, self._seg_d_img)
+      # Schedule (measured in round 2).  The generator backward is: the refinement
+      # network's data-gradient chain (big kernels), then the layout / mask / graph-convolution backward
+      # (small dependent launches) with the refinement network's eleven weight gradients released underneath
+      # them as background launches (ops.DEFER_WGRAD).  Both discriminator steps go on the side stream right
+      # after the generator forward, next to the data-gradient chain: 9.66 ms against 9.77-9.81 for the
+      # variants that hold the D_obj step back until the backward reaches the layout.  The ORDER OF CAPTURE
+      # matters, not only the dependencies: a replay issues the nodes in capture order, and branches only
+      # overlap with what is issued around the same time - capturing the discriminator steps AFTER the
+      # generator backward (same dependencies) costs 10.9 ms.
+      if self.d_img is not None:
+        on_side(self._seg_d_img)
       if self.d_obj is not None:
-        if mode == '3':
-          on_side(1, self._seg_d_obj_forward)
-        elif mode == '0':
-          on_side(1, self._seg_d_obj)
-      if self.d_img is not None and mode == '1':
-        on_side(2, self._seg_d_img)
-      ops.TAIL_EVENT = torch.cuda.Event()
-      ops.TAIL_EVENT_AT = -1
-      try:
-        self._seg_generator_backward(st)
-      finally:
-        ev, ops.TAIL_EVENT = ops.TAIL_EVENT, None
-      if self.d_obj is not None:
-        if mode == '3':
-          on_side(1, self._seg_d_obj_backward, wait_ev=ev)
-        elif mode in ('1', '2'):
-          on_side(1, self._seg_d_obj, wait_ev=ev)
+        on_side(self._seg_d_obj)
+      self._seg_generator_backward(st)
       main.wait_stream(side)
       if not dp:
         self._seg_adam(st)

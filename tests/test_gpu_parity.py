@@ -777,23 +777,6 @@ def test_train_script_runs_in_graph_mode(tmp_path):
   assert ck['counters']['t'] == 8 and 'model_state' in ck and 'd_obj_state' in ck and 'optim_state' in ck
 
 
-@pytest.mark.parametrize('plan', ['0,2', '1,1', '3,3'])
-def test_ping_pong_gemm_kernels_all_geometries(plan):
-  """The 512-thread ping-pong form of the implicit-GEMM kernels (csrc/igemm.h k_pipeline_pp) only
-  takes over launches that fill the chip; here it is forced onto EVERY vectorised launch of the conv
-  / linear sections (SG2IM_PP_MIN=0) for each of its tile shapes - 128x128 with split-K 2, 128x64,
-  64x128 with split-K 3 (SG2IM_FORCE_PLAN) - including odd tile counts (a half without a tile)."""
-  import subprocess
-  import sys
-  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-  env = dict(os.environ, SG2IM_PP='1', SG2IM_PP_MIN='0', SG2IM_PLAN_TUNE='1', SG2IM_FORCE_PLAN=plan)
-  out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'gpu_check.py'), 'sec_conv', 'sec_linear', 'sec_gconv'],
-                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
-  assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
-  tail = [l for l in out.stdout.splitlines() if l.startswith('====')]
-  assert tail and ' 0 above' in tail[-1], out.stdout[-4000:]
-
-
 def test_config0_figure_6_sheep_through_forward_json():
   """BASELINE.json configs[0], exactly as the reference's scripts/run_model.py:56-69 drives it: a
   checkpoint dict {'model_kwargs', 'model_state'} with a vocabulary holding the names of
@@ -899,23 +882,6 @@ def test_bf16_training_step_within_bf16_bound_of_the_fp32_oracle(case):
         far = max(far, d)
         assert d <= 2.05e-4, (case, name, k, d)
   print('bf16 %s: worst loss rel err %.3e, worst parameter distance %.3e' % (case, worst, far))
-
-
-@pytest.mark.parametrize('v2', ['0', '1'])
-def test_conv_sections_with_and_without_the_direct_to_lds_loop(v2):
-  """csrc/igemm2.h (operands global -> LDS directly, swizzled unpadded LDS image, out-of-image rows
-  zero-filled by the buffer bounds check) takes the stride-1 convolutions on plain sources; here it is
-  forced onto every qualifying launch however small (SG2IM_V2_MIN=0), resp. switched off, and the
-  conv / linear / golden sections must pass either way."""
-  import subprocess
-  import sys
-  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-  env = dict(os.environ, SG2IM_V2=v2, SG2IM_V2_MIN='0')
-  out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'gpu_check.py'), 'sec_conv', 'sec_linear', 'sec_golden_coco',
-                        'sec_golden_vg', 'sec_golden_eval'], capture_output=True, text=True, timeout=900, env=env, cwd=root)
-  assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
-  tail = [l for l in out.stdout.splitlines() if l.startswith('====')]
-  assert tail and ' 0 above' in tail[-1], out.stdout[-4000:]
 
 
 def test_padded_batch_without_any_triples_or_with_isolated_objects():
