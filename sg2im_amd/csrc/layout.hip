@@ -117,7 +117,10 @@ __global__ __launch_bounds__(256) void layout_fwd_kernel(const float* __restrict
         }
         S[oi][pp] = s;
         // (an object's LP = 32 pixels are one half of a wavefront: most boxes miss most pixel tiles, and
-        // adding s = +0 products is a no-op - skip those objects, bit-identical)
+        // adding s = +0 products is a no-op - skip those objects.  Bit-identical for FINITE vectors; the one
+        // deviation from the reference: 0 * NaN / 0 * Inf of a skipped object's vector does not reach these
+        // pixels - a non-finite obj_vecs row still poisons the pixels its box does cover, box_net's and
+        // mask_net's outputs and hence the total loss, so the NaN guard of train.py:553-555 fires all the same)
         const unsigned long long hit = __ballot(s != 0.f);
         if ((tid & 31) == 0) act[oi] = ((tid & 32) ? (unsigned)(hit >> 32) : (unsigned)hit) != 0u;
       }

@@ -11,15 +11,49 @@ so discriminator compute hides the 112 MB exchange - in graph mode: the D_obj st
 replayed while the generator / D_img exchanges are in flight (sg2im_amd/trainer.py::_capture).
 The 1/world_size factor is folded into the fused Adam kernel (``grad_scale``), not a separate
 pass over the arena.  Replicas are brought in line by a broadcast of parameters, optimiser
-moments and BatchNorm buffers at construction and after a checkpoint restore
-(Trainer.broadcast_state); BatchNorm statistics stay per replica (the reference's batch-32
-semantics on every rank).
+moments and BatchNorm buffers at construction, after a checkpoint restore and after rank 0's
+validation pass (Trainer.broadcast_state, scripts/train.py); within a training step the BatchNorm
+batch statistics are per replica (the reference's batch-32 semantics on every rank) and the running
+statistics drift apart between two broadcasts - a checkpoint holds rank 0's.
 
 Gradient semantics (tested in tests/test_dp_gloo.py): every rank computes the reference's
 per-shard loss (means over ITS objects / pixels), so the applied gradient is the mean over
 ranks of the per-shard gradients - not the gradient of the concatenated batch.
 """
 import torch.distributed as dist
+
+
+def _host_staged(tensor, group=None):
+  """gloo has no device collectives in this build: a GPU tensor is reduced / broadcast through a host
+  copy.  Only used when the process group's backend is gloo - the single-GPU test of the data-parallel
+  schedules (two ranks sharing one MI355X, tests/test_dp_rccl.py); RCCL ("nccl") works on the arena
+  in place."""
+  return tensor.is_cuda and dist.get_backend(group) == 'gloo'
+
+
+def broadcast(tensor, src=0, group=None):
+  if _host_staged(tensor, group):
+    host = tensor.detach().cpu()
+    dist.broadcast(host, src, group=group)
+    tensor.copy_(host)
+  else:
+    dist.broadcast(tensor, src, group=group)
+
+
+class _Done(object):
+  def wait(self):
+    pass
+
+
+def all_reduce_sum_async(tensor, group=None):
+  """in-place SUM all-reduce; returns a handle with ``wait()``"""
+  if _host_staged(tensor, group):
+    host = tensor.detach().cpu()
+    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+    tensor.copy_(host)
+    return _Done()
+  return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
 
 
 class GradReducer(object):
@@ -44,7 +78,7 @@ class GradReducer(object):
   def start(self, tensor):
     """begin an all-reduce (SUM) of ``tensor`` in place; returns immediately"""
     if (self.world_size > 1 or self.force) and not self.mute:
-      self.pending.append(dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+      self.pending.append(all_reduce_sum_async(tensor, self.group))
 
   def finish(self):
     """make the current stream wait for every started reduction"""

@@ -221,14 +221,16 @@ class BnActRows(Function):
   neighbouring conv (the layer-by-layer build_cnn path)"""
 
   @staticmethod
-  def forward(ctx, y, bn, training, gamma, beta, slope=0.0):
+  def forward(ctx, y, bn, training, gamma, beta, slope=0.0, count=None):
+    """count: None or (int32 device scalar, unit) - only the first count * unit rows of a padded batch are
+    real (sg2im_amd/bucketing.py): the statistics run over those, the padding rows get a zero gradient"""
     y = y.contiguous()
     C = y.size(-1)
     rows = y.numel() // C
-    st = ops.bn_stats(y, rows, C, C, bn, training, BN_EPS, BN_MOMENTUM)
+    st = ops.bn_stats(y, rows, C, C, bn, training, BN_EPS, BN_MOMENTUM, count=count)
     z = ops.affine_act_forward(y.view(rows, C), st, slope, _new(y, rows, C)).view(y.shape)
     ctx.save_for_backward(y, gamma, beta)
-    ctx.st, ctx.training, ctx.slope = st, training, slope
+    ctx.st, ctx.training, ctx.slope, ctx.count = st, training, slope, count
     return z
 
   @staticmethod
@@ -240,8 +242,8 @@ class BnActRows(Function):
     ni = ctx.needs_input_grad
     dgam, dbet, acc, ggam, gbet = _bn_grad_bufs(g, C, gamma, beta, ni[3], ni[4])
     dy = ops.bn_act_backward(_fptr(g), C, 0, rows, 1, 1, y, C, C, gamma, ctx.st, ctx.slope, ctx.training,
-                             _new(g, *y.shape), dgam, dbet, acc)
-    return dy, None, None, ggam, gbet, None
+                             _new(g, *y.shape), dgam, dbet, acc, count=ctx.count)
+    return dy, None, None, ggam, gbet, None, None
 
 
 class TripleLinear(Function):

@@ -38,20 +38,23 @@ class GraphTripleConv(nn.Module):
     o_idx = edges[:, 1].contiguous()
     return s_idx, o_idx, ops.Csr(s_idx, o_idx, num_objs)
 
-  def forward(self, obj_vecs, pred_vecs, edges):
+  def forward(self, obj_vecs, pred_vecs, edges, counts=None):
+    """counts: None or ((int32 device scalar, 1) objects, (..., 1) triples) - the real rows of a padded
+    batch (sg2im_amd/bucketing.py); only the BatchNorm1d statistics of mlp_normalization='batch' need them"""
     if not isinstance(edges, tuple):
       edges = self.prepare_edges(edges, obj_vecs.size(0))
     s_idx, o_idx, csr = edges
+    ocnt, tcnt = counts if counts is not None else (None, None)
     a, b = self.net1.linears()
     c, d = self.net2.linears()
     if self.net1.norms():              # mlp_normalization='batch': chained from the composable pieces
       H, Dout = self.hidden_dim, self.output_dim
       t = self.net1.tail(HF.TripleLinear.apply(obj_vecs, pred_vecs, s_idx, o_idx, csr, a.weight, a.bias,
-                                                  self.training), 0)
-      new_t = self.net1.tail(HF.LinearAct.apply(t, b.weight, b.bias, 1.0, self.training), 1)
+                                                  self.training), 0, tcnt)
+      new_t = self.net1.tail(HF.LinearAct.apply(t, b.weight, b.bias, 1.0, self.training), 1, tcnt)
       pooled, new_p = HF.TriplePool.apply(new_t, s_idx, o_idx, csr, self.pooling == 'avg', H, Dout,
                                           obj_vecs.size(0))
-      return self.net2(pooled), new_p
+      return self.net2(pooled, ocnt), new_p
     return HF.GraphTripleConvFn.apply(obj_vecs, pred_vecs, s_idx, o_idx, csr, self.pooling == 'avg',
                                       a.weight, a.bias, b.weight, b.bias, c.weight, c.bias, d.weight, d.bias)
 
@@ -66,9 +69,9 @@ class GraphTripleConvNet(nn.Module):
       GraphTripleConv(input_dim=input_dim, hidden_dim=hidden_dim, pooling=pooling,
                       mlp_normalization=mlp_normalization) for _ in range(num_layers)])
 
-  def forward(self, obj_vecs, pred_vecs, edges):
+  def forward(self, obj_vecs, pred_vecs, edges, counts=None):
     if not isinstance(edges, tuple):
       edges = GraphTripleConv.prepare_edges(edges, obj_vecs.size(0))
     for gconv in self.gconvs:
-      obj_vecs, pred_vecs = gconv(obj_vecs, pred_vecs, edges)
+      obj_vecs, pred_vecs = gconv(obj_vecs, pred_vecs, edges, counts)
     return obj_vecs, pred_vecs

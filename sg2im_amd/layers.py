@@ -65,17 +65,18 @@ class Mlp(nn.Sequential):
   def norms(self):
     return [m for m in self if isinstance(m, nn.BatchNorm1d)]
 
-  def tail(self, y, i):
+  def tail(self, y, i, count=None):
     """what follows Linear i: [BatchNorm1d +] ReLU.  Only needed with batch norm - without it the
-    ReLU is fused into the GEMM epilogue by the callers."""
+    ReLU is fused into the GEMM epilogue by the callers.  count: (int32 device scalar, 1) - the real rows
+    of a padded batch (sg2im_amd/bucketing.py); the batch statistics only see those."""
     bn = self.norms()[i]
-    return HF.BnActRows.apply(y, bn, self.training, bn.weight, bn.bias)
+    return HF.BnActRows.apply(y, bn, self.training, bn.weight, bn.bias, 0.0, count)
 
-  def forward(self, x):
+  def forward(self, x, count=None):
     lin = self.linears()
     if self.norms():                   # Linear, BatchNorm1d, ReLU, ...
       for i, l in enumerate(lin):
-        x = self.tail(HF.LinearAct.apply(x, l.weight, l.bias, 1.0, self.training), i)
+        x = self.tail(HF.LinearAct.apply(x, l.weight, l.bias, 1.0, self.training), i, count)
       return x
     if len(lin) == 2:
       return HF.Mlp2.apply(x, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias)

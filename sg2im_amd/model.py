@@ -80,7 +80,8 @@ class Sg2ImModel(nn.Module):
     is returned NHWC, the internal layout of the kernels.  ``num_images`` avoids the host
     sync of reference sg2im/layout.py:143 (N = obj_to_img.max()+1).  ``obj_count``: (int32 device
     scalar, 1) when the object / triple axes are padded to a bucket size (sg2im_amd/bucketing.py):
-    the batch statistics of mask_net then only see the real objects."""
+    the batch statistics of mask_net - and of the MLPs' BatchNorm1d layers under mlp_normalization='batch' -
+    then only see the real objects / triples."""
     O = objs.size(0)
     s = triples[:, 0].contiguous()
     p = triples[:, 1].contiguous()
@@ -97,11 +98,11 @@ class Sg2ImModel(nn.Module):
     if isinstance(self.gconv, nn.Linear):
       obj_vecs = HF.LinearAct.apply(obj_vecs, self.gconv.weight, self.gconv.bias, 1.0)
     else:
-      obj_vecs, pred_vecs = self.gconv(obj_vecs, pred_vecs, edges)
+      obj_vecs, pred_vecs = self.gconv(obj_vecs, pred_vecs, edges, (obj_count, triple_count))
     if self.gconv_net is not None:
-      obj_vecs, pred_vecs = self.gconv_net(obj_vecs, pred_vecs, edges)
+      obj_vecs, pred_vecs = self.gconv_net(obj_vecs, pred_vecs, edges, (obj_count, triple_count))
 
-    boxes_pred = self.box_net(obj_vecs)
+    boxes_pred = self.box_net(obj_vecs, obj_count)
     masks_pred = None
     if self.mask_net is not None:
       masks_pred = self._run_mask_net(obj_vecs, obj_count)
@@ -109,8 +110,9 @@ class Sg2ImModel(nn.Module):
     r1, r2 = self.rel_aux_net.linears()
     if self.rel_aux_net.norms():       # mlp_normalization='batch'
       h = self.rel_aux_net.tail(HF.RelAuxLinear.apply(boxes_pred, obj_vecs_orig, s, o, edges[2], r1.weight,
-                                                      r1.bias, self.training), 0)
-      rel_scores = self.rel_aux_net.tail(HF.LinearAct.apply(h, r2.weight, r2.bias, 1.0, self.training), 1)
+                                                      r1.bias, self.training), 0, triple_count)
+      rel_scores = self.rel_aux_net.tail(HF.LinearAct.apply(h, r2.weight, r2.bias, 1.0, self.training), 1,
+                                         triple_count)
     else:
       rel_scores = HF.RelAux.apply(boxes_pred, obj_vecs_orig, s, o, edges[2], r1.weight, r1.bias, r2.weight, r2.bias)
 

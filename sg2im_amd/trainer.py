@@ -54,7 +54,7 @@ class Trainer(object):
   def __init__(self, vocab, device, generator_kwargs=None, d_obj_kwargs=None, d_img_kwargs=None,
                loss_weights=None, learning_rate=1e-4, world_size=1, seed=None, use_graphs=False,
                gan_loss_type='gan', overlap_d=None, bucket='auto', max_graphs=32, rank=0, align_corners=False,
-               compute_dtype='f32'):
+               compute_dtype='f32', dp_schedule=None):
     """use_graphs: replay one captured hipGraph per batch-shape BUCKET instead of launching ~480
     kernels from Python.  bucket = (object multiple, triple multiple): the object / triple axes of
     every batch are padded to those multiples with exactly neutral rows (sg2im_amd/bucketing.py);
@@ -111,6 +111,9 @@ class Trainer(object):
       if seed is not None:
         torch.cuda.manual_seed(seed * 1000003 + 7919 * (rank + 1))
     self.use_graphs = use_graphs
+    # data-parallel graph schedule (see _capture): 0 = one iteration graph, exchange, Adam graph;
+    # 1 = segmented, the D_obj step replayed while the generator's all-reduce is in flight
+    self.dp_schedule = int(os.environ.get('SG2IM_DP_SCHEDULE', '0')) if dp_schedule is None else int(dp_schedule)
     if bucket == 'auto':
       bucket = (32, 64) if use_graphs else None
     self.bucketer = Bucketer(*bucket) if bucket else None
@@ -130,16 +133,17 @@ class Trainer(object):
     """rank ``src``'s parameters, optimiser moments and BatchNorm buffers to every rank (after
     construction and after a checkpoint restore)"""
     import torch.distributed as dist
+    from .distributed import broadcast
     if self.world_size <= 1 or not dist.is_initialized():
       return
     for flat, opt in ((self.flat_g, self.opt_g), (self.flat_do, self.opt_do), (self.flat_di, self.opt_di)):
       if flat is not None:
         for t in (flat.flat, opt.exp_avg, opt.exp_avg_sq, opt.state):
-          dist.broadcast(t, src)
+          broadcast(t, src)
     for m in (self.model, self.d_obj, self.d_img):
       if m is not None:
         for b in m.buffers():
-          dist.broadcast(b, src)
+          broadcast(b, src)
 
   def set_generator_eval(self):
     """reference scripts/train.py:509-512: eval-mode BN for G and a fresh Adam"""
@@ -419,7 +423,7 @@ class Trainer(object):
     #    Hides the exchange behind the D_obj step, but that step then no longer runs next to the
     #    generator backward: measured 11.55 ms/step of compute against 10.4 for the one-graph form on
     #    one GPU (bench.py --force_dist), i.e. it only wins if the exchange costs > 1.1 ms.
-    segmented = dp and os.environ.get('SG2IM_DP_SCHEDULE', '0') == '1'
+    segmented = dp and self.dp_schedule == 1
     torch.cuda.synchronize()
     _lib.CAPTURING = True
     try:

@@ -61,7 +61,16 @@ def fixed_noise(noise):
     yield
     return
   real = torch.randn
-  torch.randn = lambda *a, **k: noise.clone().to(k.get('device', 'cpu'))
+  # (staged on the GPU up front: inside a stream capture a host -> device copy of a temporary would be
+  # recorded with a dangling host pointer)
+  staged = {'cpu': noise}
+  if torch.cuda.is_available():
+    staged['cuda'] = noise.to(dev())
+
+  def fake(*a, **k):
+    d = torch.device(k.get('device', 'cpu'))
+    return staged[d.type].clone()
+  torch.randn = fake
   try:
     yield
   finally:
@@ -80,3 +89,65 @@ def oracle_leafs(P):
       t.requires_grad_(True)
     out[k] = t
   return out
+
+
+# ---------------------------------------------------------------------------------------
+# Backward parity of a whole training iteration: the flat gradient arenas of the
+# HIP Trainer, sliced per parameter, against the oracle's ``.grad`` after the SAME step.  (Parameter
+# distances after an Adam update cannot serve: Adam moves every element by +-lr whatever the gradient,
+# so two runs from the same weights are never more than 2 lr apart.)
+# ---------------------------------------------------------------------------------------
+GRAD_REL, GRAD_ABS_ZERO = 1e-4, 1e-6
+
+
+def grad_parity_rows(tr, otr, scale=1.0):
+  """rows (net, name, rel-to-max error, cosine, abs error, reference max) for every parameter of
+  G / D_obj / D_img; a parameter without a reference gradient must have an all-zero arena slot
+  (reported with rel = abs = the slot's max magnitude).  ``scale``: factor applied to the arena first
+  (1 / world_size after a SUM all-reduce)."""
+  rows = []
+  for net, mod, P in (('G', tr.model, otr.PG), ('Do', tr.d_obj, otr.PDo), ('Di', tr.d_img, otr.PDi)):
+    if mod is None:
+      assert P is None, net
+      continue
+    for name, p in mod.named_parameters():
+      got = p.grad.detach().cpu().double() * scale
+      ref = P[name].grad
+      if ref is None:
+        m = float(got.abs().max())
+        rows.append((net, name, m, 1.0, m, 0.0))
+        continue
+      ref = ref.detach().double()
+      assert got.shape == ref.shape, (net, name, tuple(got.shape), tuple(ref.shape))
+      err, rmax = float((got - ref).abs().max()), float(ref.abs().max())
+      den = float(got.norm() * ref.norm())
+      cos = float((got * ref).sum()) / den if den > 0 else 1.0
+      rows.append((net, name, err / max(rmax, 1e-30), cos, err, rmax))
+  return rows
+
+
+def assert_grad_parity(tr, otr, label, rel=GRAD_REL, cos_min=None, scale=1.0):
+  """every parameter gradient within ``rel`` of its tensor's max magnitude (analytically-zero tensors -
+  the reference itself below 1e-6 everywhere, e.g. the bias of a convolution that feeds a batch-statistics
+  BatchNorm - within 1e-6 absolute); optionally a cosine bound per tensor (bf16).  Appends the measured
+  worst cases to gpurun_out/grad_parity.log and returns (worst rel, worst cosine)."""
+  import os
+  rows = grad_parity_rows(tr, otr, scale)
+  live = [r for r in rows if r[5] >= GRAD_ABS_ZERO]
+  worst = max(live, key=lambda r: r[2])
+  wcos = min(live, key=lambda r: r[3])
+  line = ('%-44s tensors %3d  worst rel-to-max %.3e (%s.%s)  worst cosine %.6f (%s.%s)' %
+          (label, len(rows), worst[2], worst[0], worst[1], wcos[3], wcos[0], wcos[1]))
+  print(line)
+  try:
+    os.makedirs('gpurun_out', exist_ok=True)
+    with open(os.path.join('gpurun_out', 'grad_parity.log'), 'a') as f:
+      f.write(line + '\n')
+  except OSError:
+    pass
+  bad = [r for r in rows if not (r[2] <= rel or (r[4] <= GRAD_ABS_ZERO and r[5] < GRAD_ABS_ZERO))]
+  if cos_min is not None:
+    bad += [r for r in live if r[3] < cos_min and r not in bad]
+  assert not bad, '%s: gradients out of tolerance:\n' % label + '\n'.join(
+    '  %s.%s rel %.3e cos %.6f abs %.3e refmax %.3e' % r for r in bad[:20])
+  return worst[2], wcos[3]
