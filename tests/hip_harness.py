@@ -96,48 +96,128 @@ def oracle_leafs(P):
 # HIP Trainer, sliced per parameter, against the oracle's ``.grad`` after the SAME step.  (Parameter
 # distances after an Adam update cannot serve: Adam moves every element by +-lr whatever the gradient,
 # so two runs from the same weights are never more than 2 lr apart.)
+#
+# What the gradients can be held to.  The step is NOT well conditioned: the L1 pixel loss is a sign
+# function of the prediction, every LeakyReLU / ReLU has a kink, and ten training-mode BatchNorms subtract
+# batch means in their backward - a 1e-7 perturbation of the forward pass flips a few of those decisions.
+# The oracle evaluated in float32 (the reference's own arithmetic) therefore deviates from the SAME oracle
+# evaluated in float64 by up to 3e-2 of a tensor's max magnitude at batch 4 and 8e-3 at batch 32 (measured:
+# profiles/r3_grad_parity_probe_*.log; pinned on the CPU by tests/test_oracle_golden.py::
+# test_fp32_gradient_of_the_step_is_only_accurate_to_1e2), although every loss agrees to 1e-7.  A bound
+# of 1e-4 against the float32 oracle is thus unattainable even for a bit-exact reimplementation with another
+# summation order.  The gradients are compared with the EXACT gradient instead - the oracle in float64 - and
+# must be as close to it as the reference's arithmetic is:
+#     e_hip64(t) <= max(1e-4, 3 e_ref(t), E_ref(net))
+# with e_hip64 / e_ref the max-abs errors of the HIP arena / of the float32 oracle against float64, relative
+# to the tensor's max magnitude, and E_ref(net) the largest e_ref over the tensors of the same network.
+# A genuinely wrong gradient (sign, missing term, missing 1/world) is off by O(1), two orders above that.
 # ---------------------------------------------------------------------------------------
 GRAD_REL, GRAD_ABS_ZERO = 1e-4, 1e-6
 
 
-def grad_parity_rows(tr, otr, scale=1.0):
-  """rows (net, name, rel-to-max error, cosine, abs error, reference max) for every parameter of
-  G / D_obj / D_img; a parameter without a reference gradient must have an all-zero arena slot
-  (reported with rel = abs = the slot's max magnitude).  ``scale``: factor applied to the arena first
-  (1 / world_size after a SUM all-reduce)."""
+def cast_batch(cpu_batch, dtype):
+  return tuple((t.to(dtype) if torch.is_tensor(t) and t.is_floating_point() else t) for t in cpu_batch[:6])
+
+
+def oracle_trainer(PG, PDo, PDi, gcfg, docfg, dicfg, dtype=torch.float32, **kw):
+  """an OracleTrainer over copies of the parameter dicts cast to ``dtype`` (float64: the exact gradient)"""
+  cv = lambda P: {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in P.items()}
+  return orc.OracleTrainer(cv(PG), cv(PDo), cv(PDi), gcfg, docfg, dicfg, **kw)
+
+
+class OracleRefs(object):
+  """The float32 oracle (losses, parameters, running statistics: what the tests always compared with) plus
+  the float64 oracle stepped on the same batches for the first ``exact_steps`` iterations (afterwards the two
+  have taken different +-lr Adam steps and the float64 run says nothing about the float32 trajectory)."""
+
+  def __init__(self, PG, PDo, PDi, gcfg, docfg, dicfg, exact_steps=1, **kw):
+    self.o32 = oracle_trainer(PG, PDo, PDi, gcfg, docfg, dicfg, torch.float32, **kw)
+    self.o64 = oracle_trainer(PG, PDo, PDi, gcfg, docfg, dicfg, torch.float64, **kw)
+    self.exact_steps, self.steps = exact_steps, 0
+
+  PG = property(lambda self: self.o32.PG)
+  PDo = property(lambda self: self.o32.PDo)
+  PDi = property(lambda self: self.o32.PDi)
+
+  @property
+  def training(self):
+    return self.o32.training
+
+  @training.setter
+  def training(self, flag):
+    self.o32.training = self.o64.training = flag
+
+  def step(self, cpu_batch, noise=None):
+    want = self.o32.step(cast_batch(cpu_batch, torch.float32), noise)
+    if self.steps < self.exact_steps:
+      self.o64.step(cast_batch(cpu_batch, torch.float64), None if noise is None else noise.double())
+    self.steps += 1
+    return want
+
+
+def grad_parity_rows3(tr, o32, o64, scale=1.0):
+  """rows (net, name, e_hip64, e_ref, e_hip32, max|g_f64|, cosine(hip, f64)): errors relative to the float64
+  gradient's max magnitude - of the HIP arena against float64, of the float32 oracle against float64, of HIP
+  against the float32 oracle.  A parameter without a reference gradient must have an all-zero arena slot."""
   rows = []
-  for net, mod, P in (('G', tr.model, otr.PG), ('Do', tr.d_obj, otr.PDo), ('Di', tr.d_img, otr.PDi)):
+  for net, mod, P32, P64 in (('G', tr.model, o32.PG, o64.PG), ('Do', tr.d_obj, o32.PDo, o64.PDo),
+                             ('Di', tr.d_img, o32.PDi, o64.PDi)):
     if mod is None:
-      assert P is None, net
+      assert P64 is None, net
       continue
     for name, p in mod.named_parameters():
       got = p.grad.detach().cpu().double() * scale
-      ref = P[name].grad
-      if ref is None:
+      g64 = P64[name].grad
+      if g64 is None:
         m = float(got.abs().max())
-        rows.append((net, name, m, 1.0, m, 0.0))
+        rows.append((net, name, m, 0.0, m, 0.0, 1.0))
         continue
-      ref = ref.detach().double()
-      assert got.shape == ref.shape, (net, name, tuple(got.shape), tuple(ref.shape))
-      err, rmax = float((got - ref).abs().max()), float(ref.abs().max())
-      den = float(got.norm() * ref.norm())
-      cos = float((got * ref).sum()) / den if den > 0 else 1.0
-      rows.append((net, name, err / max(rmax, 1e-30), cos, err, rmax))
+      g32 = P32[name].grad.detach().double()
+      g64 = g64.detach()
+      assert got.shape == g64.shape, (net, name, tuple(got.shape), tuple(g64.shape))
+      den = max(float(g64.abs().max()), 1e-30)
+      nn_ = float(got.norm() * g64.norm())
+      rows.append((net, name, float((got - g64).abs().max()) / den, float((g32 - g64).abs().max()) / den,
+                   float((got - g32).abs().max()) / den, float(g64.abs().max()),
+                   float((got * g64).sum()) / nn_ if nn_ > 0 else 1.0))
   return rows
 
 
-def assert_grad_parity(tr, otr, label, rel=GRAD_REL, cos_min=None, scale=1.0):
-  """every parameter gradient within ``rel`` of its tensor's max magnitude (analytically-zero tensors -
-  the reference itself below 1e-6 everywhere, e.g. the bias of a convolution that feeds a batch-statistics
-  BatchNorm - within 1e-6 absolute); optionally a cosine bound per tensor (bf16).  Appends the measured
-  worst cases to gpurun_out/grad_parity.log and returns (worst rel, worst cosine)."""
+def check_grad_rows(rows, rel=None, cos_min=None):
+  """-> (bad rows, summary dict).  rel None: the reference-arithmetic bound described above; a number: that
+  bound on e_hip64 for every tensor (bf16).  Analytically-zero tensors (|g_f64| < 1e-6 everywhere: the bias of
+  a convolution feeding a batch-statistics BatchNorm, parameters without a gradient) must be below 1e-6
+  absolute on the HIP side."""
+  bad, summ = [], {}
+  for net in ('G', 'Do', 'Di'):
+    sel = [r for r in rows if r[0] == net]
+    live = [r for r in sel if r[5] >= GRAD_ABS_ZERO]
+    if not sel:
+      continue
+    E_ref = max([r[3] for r in live] or [0.0])
+    for r in sel:
+      if r[5] < GRAD_ABS_ZERO:
+        if r[2] * max(r[5], 1e-30) > GRAD_ABS_ZERO and r[4] * max(r[5], 1e-30) > GRAD_ABS_ZERO:
+          bad.append(r)
+        continue
+      bound = rel if rel is not None else max(GRAD_REL, 3.0 * r[3], E_ref)
+      if r[2] > bound or (cos_min is not None and r[6] < cos_min):
+        bad.append(r)
+    if live:
+      w = max(live, key=lambda r: r[2])
+      summ[net] = (w[2], w[1], E_ref, max(r[4] for r in live), min(r[6] for r in live))
+  return bad, summ
+
+
+def assert_grad_parity(tr, refs, label, rel=None, cos_min=None, scale=1.0):
+  """every parameter gradient of G / D_obj / D_img against the float64 oracle under the bound above (``rel`` /
+  ``cos_min``: fixed bounds instead, for bf16).  Appends the measured worst cases to
+  gpurun_out/grad_parity.log and returns (worst e_hip64, worst cosine)."""
   import os
-  rows = grad_parity_rows(tr, otr, scale)
-  live = [r for r in rows if r[5] >= GRAD_ABS_ZERO]
-  worst = max(live, key=lambda r: r[2])
-  wcos = min(live, key=lambda r: r[3])
-  line = ('%-44s tensors %3d  worst rel-to-max %.3e (%s.%s)  worst cosine %.6f (%s.%s)' %
-          (label, len(rows), worst[2], worst[0], worst[1], wcos[3], wcos[0], wcos[1]))
+  rows = grad_parity_rows3(tr, refs.o32, refs.o64, scale)
+  bad, summ = check_grad_rows(rows, rel, cos_min)
+  line = '%-40s' % label + '  '.join(
+    '%s: e_hip64 %.2e (%s) E_ref %.2e e_hip32 %.2e cos %.6f' % ((n,) + summ[n]) for n in ('G', 'Do', 'Di') if n in summ)
   print(line)
   try:
     os.makedirs('gpurun_out', exist_ok=True)
@@ -145,9 +225,6 @@ def assert_grad_parity(tr, otr, label, rel=GRAD_REL, cos_min=None, scale=1.0):
       f.write(line + '\n')
   except OSError:
     pass
-  bad = [r for r in rows if not (r[2] <= rel or (r[4] <= GRAD_ABS_ZERO and r[5] < GRAD_ABS_ZERO))]
-  if cos_min is not None:
-    bad += [r for r in live if r[3] < cos_min and r not in bad]
   assert not bad, '%s: gradients out of tolerance:\n' % label + '\n'.join(
-    '  %s.%s rel %.3e cos %.6f abs %.3e refmax %.3e' % r for r in bad[:20])
-  return worst[2], wcos[3]
+    '  %s.%s e_hip64 %.3e e_ref %.3e e_hip32 %.3e max|g| %.3e cos %.6f' % r for r in bad[:20])
+  return max(v[0] for v in summ.values()), min(v[4] for v in summ.values())

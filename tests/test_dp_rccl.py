@@ -42,23 +42,24 @@ def _worker(rank, world, port, backend, share_gpu, use_graphs, dp_schedule, ret)
     from sg2im_amd.synthetic import make_vocab, shard_batch, synthetic_batch
     from sg2im_amd.trainer import Trainer, GENERATOR_DEFAULTS, D_OBJ_DEFAULTS, D_IMG_DEFAULTS
     from tests.dp_reference import dp_step
-    from tests.hip_harness import grad_parity_rows, load_params, GRAD_ABS_ZERO
+    from tests.hip_harness import check_grad_rows, grad_parity_rows3, load_params, oracle_trainer
     vocab = make_vocab(184, 7)
     gk = {'layout_noise_dim': 0}
     gcfg = dict(GENERATOR_DEFAULTS, vocab=vocab, **gk)
     docfg, dicfg = dict(D_OBJ_DEFAULTS, vocab=vocab), dict(D_IMG_DEFAULTS)
     lr = 1e-4
-    mk = lambda: orc.OracleTrainer(orc.init_generator_params(gcfg, 0, randomize_bn=True),
-                                   orc.init_ac_discriminator_params(docfg, 2, randomize_bn=True),
-                                   orc.init_patch_discriminator_params(dicfg, 1, randomize_bn=True), gcfg, docfg, dicfg, lr=lr)
-    refs = [mk() for _ in range(world)]
+    P0 = (orc.init_generator_params(gcfg, 0, randomize_bn=True), orc.init_ac_discriminator_params(docfg, 2, randomize_bn=True),
+          orc.init_patch_discriminator_params(dicfg, 1, randomize_bn=True))
+    refs = [oracle_trainer(*P0, gcfg, docfg, dicfg, torch.float32, lr=lr) for _ in range(world)]
+    # the EXACT mean-of-per-shard gradients (float64), first step only: see tests/hip_harness.py::assert_grad_parity
+    refs64 = [oracle_trainer(*P0, gcfg, docfg, dicfg, torch.float64, lr=lr) for _ in range(world)]
     # a deliberately different seed per rank: Trainer.broadcast_state must bring the replicas in line
     tr = Trainer(vocab, dev, seed=100 + rank, generator_kwargs=gk, learning_rate=lr, world_size=world, rank=rank,
                  use_graphs=use_graphs, bucket=(8, 16), dp_schedule=dp_schedule)
     if rank == 0:
       load_params(tr.model, refs[0].PG); load_params(tr.d_obj, refs[0].PDo); load_params(tr.d_img, refs[0].PDi)
     tr.broadcast_state()
-    worst_loss, worst_grad, bad = 0.0, 0.0, []
+    worst_loss, worst_grad, worst_ref, bad = 0.0, 0.0, 0.0, []
     for step in range(2):
       full = synthetic_batch(2 * world, seed=40 + step)
       shards = [tuple(shard_batch(full, r, world)[:6]) for r in range(world)]
@@ -70,19 +71,20 @@ def _worker(rank, world, port, backend, share_gpu, use_graphs, dp_schedule, ret)
         worst_loss = max(worst_loss, abs(got[k] - v) / max(1.0, abs(v)))
       if step == 0:
         # arena (SUM over ranks) x 1/world == mean over ranks of the reference's per-shard gradients
-        for r in grad_parity_rows(tr, refs[rank], scale=tr.reducer.grad_scale):
-          if r[5] >= GRAD_ABS_ZERO:
-            worst_grad = max(worst_grad, r[2])
-          if not (r[2] <= 1e-4 or (r[4] <= GRAD_ABS_ZERO and r[5] < GRAD_ABS_ZERO)):
-            bad.append(r)
+        from tests.hip_harness import cast_batch
+        dp_step(refs64, [cast_batch(s, torch.float64) for s in shards])
+        rows = grad_parity_rows3(tr, refs[rank], refs64[rank], scale=tr.reducer.grad_scale)
+        bad, summ = check_grad_rows(rows)
+        worst_grad = max(v[0] for v in summ.values())
+        worst_ref = max(v[2] for v in summ.values())
     torch.cuda.synchronize()
     # identical parameters on every rank
     from sg2im_amd.distributed import broadcast
     flat = tr.flat_g.flat.clone()
     broadcast(flat, 0)
     same = bool(torch.equal(flat, tr.flat_g.flat))
-    ret[rank] = (worst_loss, worst_grad, ['%s.%s rel %.3e abs %.3e refmax %.3e' % (r[0], r[1], r[2], r[4], r[5]) for r in bad[:10]],
-                 same, dict(tr.graph_stats))
+    ret[rank] = (worst_loss, (worst_grad, worst_ref),
+                 ['%s.%s e_hip64 %.3e e_ref %.3e e_hip32 %.3e max|g| %.3e' % r[:6] for r in bad[:10]], same, dict(tr.graph_stats))
   finally:
     dist.destroy_process_group()
 
@@ -95,8 +97,8 @@ def _run(backend, share_gpu, use_graphs, dp_schedule):
   assert len(ret) == world
   for rank in range(world):
     worst_loss, worst_grad, bad, same, stats = ret[rank]
-    line = 'dp 2 ranks %s%s graphs=%s schedule=%s rank %d: worst loss rel %.3e, worst gradient rel-to-max %.3e' % (
-      backend, ' (one GPU)' if share_gpu else '', use_graphs, dp_schedule, rank, worst_loss, worst_grad)
+    line = 'dp 2 ranks %s%s graphs=%s schedule=%s rank %d: worst loss rel %.3e, worst e_hip64 %.3e (float32 oracle: E_ref %.3e)' % (
+      backend, ' (one GPU)' if share_gpu else '', use_graphs, dp_schedule, rank, worst_loss, worst_grad[0], worst_grad[1])
     print(line)
     try:
       os.makedirs('gpurun_out', exist_ok=True)

@@ -165,3 +165,37 @@ def test_layout_known_answer_in_both_sampling_conventions(align_corners):
   want = torch.zeros(1, 1, 8, 8)
   want[0, 0, 2:6, 2:6] = 1.0
   assert torch.equal(out, want)
+
+
+def test_fp32_gradient_of_the_step_is_only_accurate_to_1e2():
+  """Conditioning of the training step (why the GPU tests compare gradients with the float64 oracle,
+  tests/hip_harness.py::assert_grad_parity): the oracle evaluated in float32 - the reference's own
+  arithmetic - and the SAME oracle in float64 agree on every loss to 1e-6, but their parameter gradients
+  differ by more than 1e-3 of a tensor's max magnitude on several tensors (L1 sign function, LeakyReLU
+  kinks and BatchNorm mean subtractions turn 1e-7 forward perturbations into flipped decisions), yet by
+  less than 0.2: a per-tensor bound of 1e-4 against a float32 reference is not attainable end to end."""
+  import torch
+  from oracle import sg2im_oracle as orc
+  from sg2im_amd.synthetic import make_vocab, synthetic_batch
+  from sg2im_amd.trainer import GENERATOR_DEFAULTS, D_OBJ_DEFAULTS, D_IMG_DEFAULTS
+  from tests import hip_harness as hh
+  vocab = make_vocab(184, 7)
+  cpu_batch = synthetic_batch(4, seed=3)
+  gcfg, docfg, dicfg = dict(GENERATOR_DEFAULTS, vocab=vocab), dict(D_OBJ_DEFAULTS, vocab=vocab), dict(D_IMG_DEFAULTS)
+  P = (orc.init_generator_params(gcfg, 0, randomize_bn=True), orc.init_ac_discriminator_params(docfg, 2, randomize_bn=True),
+       orc.init_patch_discriminator_params(dicfg, 1, randomize_bn=True))
+  noise = torch.randn(4, 32, 64, 64, generator=torch.Generator().manual_seed(5))
+  o32 = hh.oracle_trainer(*P, gcfg, docfg, dicfg, torch.float32)
+  o64 = hh.oracle_trainer(*P, gcfg, docfg, dicfg, torch.float64)
+  w32 = o32.step(hh.cast_batch(cpu_batch, torch.float32), noise)
+  w64 = o64.step(hh.cast_batch(cpu_batch, torch.float64), noise.double())
+  for k, v in w64.items():
+    assert abs(w32[k] - v) <= 1e-6 * max(1.0, abs(v)), (k, w32[k], v)
+  errs = []
+  for a, b in ((o32.PG, o64.PG), (o32.PDo, o64.PDo), (o32.PDi, o64.PDi)):
+    for k in a:
+      if b[k].grad is not None and float(b[k].grad.abs().max()) >= 1e-6:
+        errs.append(float((a[k].grad.double() - b[k].grad).abs().max() / b[k].grad.abs().max()))
+  assert len(errs) > 90
+  assert sum(1 for e in errs if e > 1e-3) >= 5, sorted(errs)[-8:]
+  assert max(errs) < 0.2, max(errs)
