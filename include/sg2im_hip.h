@@ -26,7 +26,7 @@ extern "C" {
 #define SG2IM_ERR_ARG 1   /* invalid argument (the reference would raise / assert) */
 #define SG2IM_ERR_HIP 2   /* a HIP runtime call failed; see hipGetLastError() */
 
-int sg2im_abi_version(void);
+int sg2im_abi_version(void);   /* 4 */
 
 /* One-time, idempotent set-up (kernel attributes of every implicit-GEMM instantiation, loading of
  * the library's code object).  Without it the same work happens lazily on first launches; with it
@@ -120,6 +120,72 @@ int sg2im_conv2d_backward_weight_group(int n, const sg2im_conv_desc* const* desc
                                        const int* ld_dys, const int* couts, float* const* dweights,
                                        float* const* dbiases, int accumulate, float* workspace,
                                        size_t workspace_bytes, hipStream_t stream);
+/* ------------------------------------------------------------------------------------
+ * Convolution + the BatchNorm reductions that follow / precede it in ONE set of launches
+ * (sg2im/crn.py:41-47: Conv2d -> BatchNorm2d -> LeakyReLU twice per refinement module; sg2im/layers.py:166-178;
+ * sg2im/model.py:99-101).  Training-mode BatchNorm couples every convolution to a per-channel reduction over its
+ * whole output; instead of a separate pass over the tensor the reductions ride in the GEMM: the workgroup that
+ * owns an output tile (or, with split-K, the finish launch that sums the partials) also produces that tile's
+ * per-channel partial sums, and one small launch finishes them in double.  No atomics, fixed order: results are
+ * reproducible and equal sg2im_conv2d_forward + sg2im_bn_stats (resp. sg2im_conv2d_backward_data + the first two
+ * passes of sg2im_bn_act_backward) up to the fp32 summation order of the statistics.  Launches that do not
+ * qualify (scalar loaders, row gathers, the stride-2 parity form, <= 4 output channels) run exactly those
+ * two calls internally.
+ * ---------------------------------------------------------------------------------- */
+typedef struct sg2im_bn_fwd {
+  const float* gamma;       /* [cout] or NULL (1) */
+  const float* beta;        /* [cout] or NULL (0) */
+  float eps, momentum;
+  int training;             /* 0: running statistics are used (no reduction at all) */
+  float* running_mean;      /* updated when training (may be NULL then) */
+  float* running_var;
+  long long* num_batches_tracked;
+  long long unbiased_rows;  /* 0 = the output's rows; see sg2im_bn_stats */
+  float* mean; float* invstd; float* scale; float* shift;   /* outputs, [cout] each */
+  float* partial;           /* scratch, partial_floats floats: >= 3 * cout * ceil(rows / 64) takes every fused form,
+                             * >= 2 * cout * 1024 is required (the standalone fallback) */
+  size_t partial_floats;
+  const int* count;         /* padded row batch: count[0] * count_unit real rows (NULL: all), see sg2im_bn_stats */
+  int count_unit;
+} sg2im_bn_fwd;
+/* out = leaky_{out_slope}(conv(X, W) + bias) and the batch statistics of `out` (rows = batch * out_h * out_w,
+ * channels = cout, row stride ld_out) as sg2im_bn_stats computes them */
+int sg2im_conv2d_forward_bn(const sg2im_conv_desc* desc, const float* weight, int cout, const float* bias,
+                            float out_slope, float* out, long long ld_out, float* workspace,
+                            size_t workspace_bytes, const sg2im_bn_fwd* bn, hipStream_t stream);
+
+typedef struct sg2im_bn_bwd {
+  const float* y;           /* pre-normalisation output of the BatchNorm'd layer, [rows][ld_y], channels = c_count */
+  long long ld_y;
+  int pool2;                /* 1: dx (this launch's result) is at TWICE y's resolution - the layer's activated output
+                             * was nearest-upsampled x2 into the convolution (crn.py:107): its gradient is the 2x2 sum */
+  const float* gamma;       /* [C] or NULL */
+  const float* mean; const float* invstd; const float* scale; const float* shift;   /* from the forward pass */
+  float slope;              /* LeakyReLU slope of the activation behind the norm */
+  int training;             /* 0: statistics are constants (eval-mode BatchNorm) */
+  float* dgamma; float* dbeta;   /* [C] each, may be NULL; += when accumulate */
+  int accumulate;
+  float* coef;              /* out, float[3 * C]: dy = coef[0][c] * du + coef[1][c] * y + coef[2][c], the input of
+                             * sg2im_bn_backward_apply */
+  float* partial;           /* scratch, partial_floats floats: >= 2 * C * ceil(rows_of_dx / 64) takes every fused form */
+  size_t partial_floats;
+  const int* count;         /* padded row batch: count[0] * count_unit real rows OF y (NULL: all) */
+  int count_unit;
+} sg2im_bn_bwd;
+/* dx = the data gradient of sg2im_conv2d_backward_data (accumulate = 0) for the channel range [c_begin,
+ * c_begin + c_count), which is the gradient w.r.t. the ACTIVATED output z = leaky(scale * y + shift) of a
+ * BatchNorm'd layer - plus that BatchNorm's backward reductions: dgamma, dbeta and the coefficients `coef`. */
+int sg2im_conv2d_backward_data_bn(const sg2im_conv_desc* desc, const float* weight, int cout, const float* dy,
+                                  int ld_dy, int c_begin, int c_count, float* dx, long long ld_dx,
+                                  float* workspace, size_t workspace_bytes, const sg2im_bn_bwd* bn,
+                                  hipStream_t stream);
+/* third pass of sg2im_bn_act_backward on its own: dy[rows][C] = coef[0] * du + coef[1] * y + coef[2] with
+ * du = dz * leaky'(scale * y + shift), dz read from g as in sg2im_bn_act_backward (pool2: 2x2 sums);
+ * padding rows (count / count_unit) get 0 */
+int sg2im_bn_backward_apply(const float* g, long long ld_g, int pool2, int batch, int h, int w, const float* y,
+                            long long ld_y, int channels, const float* scale, const float* shift, float slope,
+                            const float* coef, float* dy, const int* count, int count_unit, hipStream_t stream);
+
 /* out[n] = sum_m x[m][n] (+ out): bias gradients (autograd of Conv2d/Linear bias) */
 /* partial: scratch float[2 * cols * 1024] */
 int sg2im_column_sum(const float* x, long long rows, int cols, long long ld, float* out,

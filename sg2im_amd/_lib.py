@@ -28,6 +28,23 @@ class ConvDesc(Structure):
               ('pad', c_int), ('compute_dtype', c_int), ('launch_hints', c_int), ('weight_channels', c_int)]
 
 
+class BnFwd(Structure):
+  """sg2im_bn_fwd (include/sg2im_hip.h)"""
+  _fields_ = [('gamma', c_void_p), ('beta', c_void_p), ('eps', c_float), ('momentum', c_float), ('training', c_int),
+              ('running_mean', c_void_p), ('running_var', c_void_p), ('num_batches_tracked', c_void_p),
+              ('unbiased_rows', c_longlong), ('mean', c_void_p), ('invstd', c_void_p), ('scale', c_void_p),
+              ('shift', c_void_p), ('partial', c_void_p), ('partial_floats', c_size_t), ('count', c_void_p),
+              ('count_unit', c_int)]
+
+
+class BnBwd(Structure):
+  """sg2im_bn_bwd (include/sg2im_hip.h)"""
+  _fields_ = [('y', c_void_p), ('ld_y', c_longlong), ('pool2', c_int), ('gamma', c_void_p), ('mean', c_void_p),
+              ('invstd', c_void_p), ('scale', c_void_p), ('shift', c_void_p), ('slope', c_float), ('training', c_int),
+              ('dgamma', c_void_p), ('dbeta', c_void_p), ('accumulate', c_int), ('coef', c_void_p), ('partial', c_void_p),
+              ('partial_floats', c_size_t), ('count', c_void_p), ('count_unit', c_int)]
+
+
 _P, _I, _L, _F, _Z = c_void_p, c_int, c_longlong, c_float, c_size_t
 _D = POINTER(ConvDesc)
 
@@ -37,6 +54,9 @@ _SIGNATURES = {
   'sg2im_init': [],
   'sg2im_conv2d_forward': [_D, _P, _I, _P, _F, _P, _L, _I, _P, _Z, _P],
   'sg2im_conv2d_backward_data': [_D, _P, _I, _P, _I, _I, _I, _P, _L, _I, _P, _Z, _P],
+  'sg2im_conv2d_forward_bn': [_D, _P, _I, _P, _F, _P, _L, _P, _Z, POINTER(BnFwd), _P],
+  'sg2im_conv2d_backward_data_bn': [_D, _P, _I, _P, _I, _I, _I, _P, _L, _P, _Z, POINTER(BnBwd), _P],
+  'sg2im_bn_backward_apply': [_P, _L, _I, _I, _I, _I, _P, _L, _I, _P, _P, _F, _P, _P, _P, _I, _P],
   'sg2im_conv2d_backward_weight': [_D, _P, _I, _I, _P, _P, _I, _P, _Z, _P],
   'sg2im_conv2d_backward_weight_group': [_I, POINTER(_D), POINTER(_P), POINTER(_I), POINTER(_I), POINTER(_P), POINTER(_P),
                                          _I, _P, _Z, _P],

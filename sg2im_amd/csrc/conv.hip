@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "sg2im_hip.h"
+#include "bn_final.h"
 
 namespace sg2im {
 
@@ -29,6 +30,7 @@ struct FwdParams {
   int iters;        // total K iterations
   int nch;          // K chunks per tap (VEC=4)
   Epi e;
+  StatSink st;      // ST kernels: BatchNorm statistics of the output tile (igemm.h epilogue_stats)
 };
 
 struct DgradParams {
@@ -39,6 +41,7 @@ struct DgradParams {
   int iters, nch;   // (parity == 0) total K iterations / chunks per tap
   int parity;       // 1: stride-2 parity decomposition, blockIdx.z = class (no split-K)
   Epi e;
+  StatSink st;      // ST kernels: BatchNorm-backward sums of the output tile (igemm.h epilogue_bnbwd)
 };
 
 struct WgradParams {
@@ -207,7 +210,8 @@ template <int NVA, int NVB> struct RegSet {
 // forward
 // ---------------------------------------------------------------------------
 // H: bf16 operand path (igemm.h): operands rounded to bf16 on their way into LDS, v_mfma_f32_32x32x16_bf16
-template <int BM, int BN, int VEC, bool GATHER, bool H = false>
+// ST: the epilogue also reduces the tile's BatchNorm statistics (launches without split-K only)
+template <int BM, int BN, int VEC, bool GATHER, bool H = false, bool ST = false>
 __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NVA = BM / 32, NVB = BN / 32;
@@ -393,6 +397,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_kernel(const FwdParams p) {
   };
   k_pipeline(it_begin, it_end, do_load, do_stage, do_mma);
   epilogue<BM, BN>(p.e, p.M, p.Cout, p.Cout, m0, n0, wm0, wn0, lane, split, acc);
+  if constexpr (ST) {
+    if (p.e.nsplit == 1) epilogue_stats<BM, BN>(p.e, p.st, p.M, p.Cout, m0, n0, wm0, wn0, lane, tid, blockIdx.y, acc, smem);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -416,7 +423,7 @@ struct ParityRow {
   }
 };
 
-template <int BM, int BN, int VA, int VB, bool H = false>
+template <int BM, int BN, int VA, int VB, bool H = false, bool ST = false>
 __global__ __launch_bounds__(NTHREADS) void conv_dgrad_kernel(const DgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NVA = BM / 32, NVB = BN / 32;
@@ -630,6 +637,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_dgrad_kernel(const DgradParams 
     epilogue<BM, BN>(e2, M, p.Nc, p.Nc, m0, n0, wm0, wn0, lane, 0, acc, ParityRow{g.H, g.W, Hc, Wc, ph, pw});
   } else {
     epilogue<BM, BN>(p.e, M, p.Nc, p.Nc, m0, n0, wm0, wn0, lane, split, acc);
+    if constexpr (ST) {
+      if (p.e.nsplit == 1) epilogue_bnbwd<BM, BN>(p.st, M, p.Nc, m0, n0, wm0, wn0, lane, tid, blockIdx.y, acc, smem);
+    }
   }
 }
 
@@ -1019,6 +1029,104 @@ __global__ void splitk_finish_v4_group_kernel(const FinishGroup g) {
 #undef SG2IM_GROUP_CASE
 }
 
+// Split-K finish that ALSO produces the BatchNorm tile partials of its output (see igemm.h epilogue_stats /
+// epilogue_bnbwd - the launches with split-K have no finished values in their epilogue).  Workgroup
+// (blockIdx.x, blockIdx.y) owns the rows [x * per, (x + 1) * per) of the column slab [128 y, 128 (y + 1)):
+// thread -> (column quad tx, row lane ty), rows strided by TR, the row lanes of a quad combined through LDS in a
+// fixed order.  Splits are added in ascending order, as in splitk_finish_v4_kernel.  MODE 1: forward statistics of C = leaky(sum + bias) as (pivot, sum d, sum d^2)
+// with the block's first row as the pivot; MODE 2: backward sums (sum du, sum du * xhat) of C = sum.
+template <int MODE>
+__global__ __launch_bounds__(256) void splitk_finish_stats_kernel(const float* __restrict__ ws, int nsplit, long long M, int N,
+                                                                  float* __restrict__ C, long long ldc,
+                                                                  const float* __restrict__ bias, float slope, long long per,
+                                                                  const StatSink ss) {
+  __shared__ float4 red4[2 * 256];
+  constexpr int SLABQ = 32;                      // column quads per slab
+  const int CQ = N >> 2;
+  const int q_lo = blockIdx.y * SLABQ;
+  const int TQ = CQ - q_lo < SLABQ ? CQ - q_lo : SLABQ, TR = 256 / TQ;
+  const int tx = threadIdx.x % TQ, ty = threadIdx.x / TQ;
+  const long long r0 = (long long)blockIdx.x * per;
+  const long long r1 = r0 + per < M ? r0 + per : M;
+  long long live = M;
+  if (ss.count) { const long long t = (long long)ss.count[0] * ss.unit; live = t < M ? t : M; }
+  const long long MN = M * N;
+  const long long HW = (long long)ss.H * ss.W;
+  {
+    const int n = 4 * (q_lo + tx);
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) b4 = *reinterpret_cast<const float4*>(bias + n);
+    auto finished = [&](long long r) -> float4 {
+      float4 v = *reinterpret_cast<const float4*>(ws + r * N + n);
+      for (int sp = 1; sp < nsplit; ++sp) {
+        const float4 u = *reinterpret_cast<const float4*>(ws + (long long)sp * MN + r * N + n);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
+      v.x = leaky(v.x + b4.x, slope); v.y = leaky(v.y + b4.y, slope);
+      v.z = leaky(v.z + b4.z, slope); v.w = leaky(v.w + b4.w, slope);
+      return v;
+    };
+    float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), sc = pv, sh = pv, mu = pv, is = pv;
+    if (MODE == 1) pv = finished(r0);          // (every row lane of the quad recomputes it: cache hits)
+    else {
+      sc = *reinterpret_cast<const float4*>(ss.scale + n); sh = *reinterpret_cast<const float4*>(ss.shift + n);
+      mu = *reinterpret_cast<const float4*>(ss.mean + n); is = *reinterpret_cast<const float4*>(ss.invstd + n);
+    }
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (ty < TR) {
+      for (long long r = r0 + ty; r < r1; r += TR) {
+        const float4 v = finished(r);
+        *reinterpret_cast<float4*>(C + r * ldc + n) = v;
+        if (r >= live) continue;
+        if (MODE == 1) {
+          const float4 d = make_float4(v.x - pv.x, v.y - pv.y, v.z - pv.z, v.w - pv.w);
+          s0.x += d.x; s0.y += d.y; s0.z += d.z; s0.w += d.w;
+          s1.x = fmaf(d.x, d.x, s1.x); s1.y = fmaf(d.y, d.y, s1.y); s1.z = fmaf(d.z, d.z, s1.z); s1.w = fmaf(d.w, d.w, s1.w);
+        } else {
+          long long row = r;
+          if (ss.pool2) {
+            const long long nb = r / HW; const int rem = (int)(r - nb * HW);
+            const int hi = rem / ss.W, wi = rem - hi * ss.W;
+            row = (nb * (ss.H >> 1) + (hi >> 1)) * (ss.W >> 1) + (wi >> 1);
+          }
+          const float4 yv = *reinterpret_cast<const float4*>(ss.y + row * ss.ld_y + n);
+          const float4 du = make_float4(v.x * (fmaf(yv.x, sc.x, sh.x) > 0.f ? 1.f : ss.slope),
+                                        v.y * (fmaf(yv.y, sc.y, sh.y) > 0.f ? 1.f : ss.slope),
+                                        v.z * (fmaf(yv.z, sc.z, sh.z) > 0.f ? 1.f : ss.slope),
+                                        v.w * (fmaf(yv.w, sc.w, sh.w) > 0.f ? 1.f : ss.slope));
+          s0.x += du.x; s0.y += du.y; s0.z += du.z; s0.w += du.w;
+          s1.x = fmaf(du.x, (yv.x - mu.x) * is.x, s1.x); s1.y = fmaf(du.y, (yv.y - mu.y) * is.y, s1.y);
+          s1.z = fmaf(du.z, (yv.z - mu.z) * is.z, s1.z); s1.w = fmaf(du.w, (yv.w - mu.w) * is.w, s1.w);
+        }
+      }
+    }
+    if (TR > 1) {
+      __syncthreads();
+      red4[threadIdx.x] = s0; red4[256 + threadIdx.x] = s1;
+      __syncthreads();
+      if (ty == 0) {
+        for (int t = 1; t < TR; ++t) {
+          const float4 a = red4[t * TQ + tx], b = red4[256 + t * TQ + tx];
+          s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+          s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+        }
+      }
+    }
+    if (ty == 0) {
+      constexpr int K = MODE == 1 ? 3 : 2;
+      float* dst = ss.partial + (size_t)blockIdx.x * K * N + n;
+      if (MODE == 1) {
+        *reinterpret_cast<float4*>(dst) = pv;
+        *reinterpret_cast<float4*>(dst + N) = s0;
+        *reinterpret_cast<float4*>(dst + 2 * N) = s1;
+      } else {
+        *reinterpret_cast<float4*>(dst) = s0;
+        *reinterpret_cast<float4*>(dst + N) = s1;
+      }
+    }
+  }
+}
+
 // Data gradient w.r.t. a few (<= 4) input channels - the RGB input of the discriminators'
 // first convolution.  An MFMA tile would be 64 columns wide for 3 useful ones (120 us at the
 // bench shape); this is a plain gather: one thread per input pixel, the weights of the
@@ -1108,6 +1216,8 @@ static const bool g_plan_debug = getenv("SG2IM_PLAN_DEBUG") != nullptr;   // pri
 // 9.74, 1 resident (84 KB) 10.0 ms per training step]
 static const size_t g_bg_lds = 56 * 1024;
 static const bool g_plan_tune = getenv("SG2IM_PLAN_TUNE") != nullptr;     // honour SG2IM_FORCE_PLAN
+// A/B knob: 0 = the *_bn entry points run conv + the standalone BatchNorm reduction passes (the round-2 launches)
+static const bool g_fuse_bn = !(getenv("SG2IM_FUSE_BN") && atoi(getenv("SG2IM_FUSE_BN")) == 0);
 
 template <typename K>
 static hipError_t ensure_lds(K kernel, size_t bytes) {
@@ -1410,6 +1520,35 @@ static hipError_t launch_wgrad_h(WgradParams& p, int ntiles_n, hipStream_t st) {
   return hipGetLastError();
 }
 
+// ST launches: the epilogue also reduces BatchNorm tile partials (no split-K; float4 loaders, no row gathers)
+template <int BM, int BN, bool H>
+static hipError_t launch_fwd_st(FwdParams& p, hipStream_t st) {
+  constexpr size_t lds = TileBytes<H, BM, false>::value + TileBytes<H, BN, false>::value;
+  dim3 grid((p.Cout + BN - 1) / BN, (p.M + BM - 1) / BM, 1);
+  hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, 4, false, H, true>), grid, dim3(NTHREADS), lds, st, p);
+  return hipGetLastError();
+}
+template <int BM, int BN, bool H>
+static hipError_t launch_dgrad_st(DgradParams& p, hipStream_t st) {
+  constexpr size_t lds = TileBytes<H, BM, false>::value + TileBytes<H, BN, true>::value;
+  dim3 grid((p.Nc + BN - 1) / BN, (p.M + BM - 1) / BM, 1);
+  hipLaunchKernelGGL((conv_dgrad_kernel<BM, BN, 4, 4, H, true>), grid, dim3(NTHREADS), lds, st, p);
+  return hipGetLastError();
+}
+
+// rows per workgroup / row blocks / column slabs of splitk_finish_stats_kernel: ~8 workgroups per CU, at least 8
+// rows each, at most as many row blocks as the partial buffer holds (K floats per row block and column)
+static void finish_stats_grid(long long M, int N, int K, size_t partial_floats, int* nblk, long long* per, int* nslab) {
+  *nslab = (N / 4 + 31) / 32;
+  long long want = std::max<long long>(1, 2048 / *nslab);
+  const long long cap = std::max<long long>(1, (long long)(partial_floats / ((size_t)K * N)));
+  want = std::min<long long>(std::min<long long>(want, cap), 4096);
+  *per = std::max<long long>(8, (M + want - 1) / want);
+  *nblk = (int)((M + *per - 1) / *per);
+}
+
+static bool al16p(const void* q) { return ((uintptr_t)q & 15) == 0; }
+
 __global__ void init_probe_kernel(int* flag) { if (flag) flag[0] = 1; }
 
 }  // namespace sg2im
@@ -1452,15 +1591,24 @@ int sg2im_init(void) {
   return SG2IM_OK;
 }
 
-int sg2im_conv2d_forward(const sg2im_conv_desc* d, const float* weight, int cout, const float* bias,
-                         float out_slope, float* out, long long ld_out, int accumulate,
-                         float* workspace, size_t workspace_bytes, hipStream_t stream) {
+static int bn_fwd_standalone(const sg2im_bn_fwd* bn, const float* out, long long rows, int cout, long long ld_out,
+                             hipStream_t stream) {
+  return sg2im_bn_stats(out, rows, cout, ld_out, bn->gamma, bn->beta, bn->eps, bn->momentum, bn->training,
+                        bn->running_mean, bn->running_var, bn->num_batches_tracked, bn->unbiased_rows, bn->mean,
+                        bn->invstd, bn->scale, bn->shift, bn->partial, bn->count, bn->count_unit, stream);
+}
+
+// bn != nullptr: followed by the BatchNorm statistics of `out` (sg2im_conv2d_forward_bn)
+static int conv_forward_impl(const sg2im_conv_desc* d, const float* weight, int cout, const float* bias,
+                             float out_slope, float* out, long long ld_out, int accumulate,
+                             float* workspace, size_t workspace_bytes, const sg2im_bn_fwd* bn, hipStream_t stream) {
   if (check_desc(d) || !weight || !out || cout < 1) return SG2IM_ERR_ARG;
   FwdParams p;
   fill_geom(p.g, d);
   p.Wt = weight; p.Cout = cout;
   p.M = d->batch * d->out_h * d->out_w;
-  if (p.M == 0) return SG2IM_OK;
+  p.st = StatSink{};
+  if (p.M == 0) return bn ? SG2IM_ERR_ARG : SG2IM_OK;
   const bool v4 = geom_vec4(p.g) && !((uintptr_t)weight & 15);
   const int taps = d->kh * d->kw;
   if (v4) {
@@ -1475,6 +1623,19 @@ int sg2im_conv2d_forward(const sg2im_conv_desc* d, const float* weight, int cout
                             [&](int bn) { return (long long)(cout + bn - 1) / bn; });
   p.e = Epi{out, ld_out, bias, out_slope, accumulate, workspace, pl.nsplit};
   hipError_t err;
+  // BatchNorm statistics of the output from the same launches: in the conv epilogue (no split-K) or in the
+  // split-K finish; anything that does not qualify runs the standalone statistics pass afterwards
+  const bool bn_train = bn && bn->training;
+  const bool st_ok = g_fuse_bn && bn_train && v4 && !any_gather(p.g) && !accumulate && bn->partial && al16p(bn->partial);
+  if (st_ok && pl.nsplit == 1 && (size_t)((p.M + pl.bm - 1) / pl.bm) * 3 * cout <= bn->partial_floats) {
+    p.st.partial = bn->partial; p.st.count = bn->count; p.st.unit = bn->count_unit;
+    const bool hb = d->compute_dtype == 1;
+#define SG2IM_ST(BM_, BN_) (hb ? launch_fwd_st<BM_, BN_, true>(p, stream) : launch_fwd_st<BM_, BN_, false>(p, stream))
+    err = pl.tile == 0 ? SG2IM_ST(128, 128) : pl.tile == 1 ? SG2IM_ST(128, 64) : pl.tile == 2 ? SG2IM_ST(64, 64) : SG2IM_ST(64, 128);
+#undef SG2IM_ST
+    if (err != hipSuccess) return SG2IM_ERR_HIP;
+    return bn_stats_finish_tiles(bn->partial, (p.M + pl.bm - 1) / pl.bm, pl.bm, p.M, cout, bn, stream);
+  }
   if (v4 && d->compute_dtype == 1 && !any_gather(p.g)) {
     err = pl.tile == 0 ? launch_fwd_h<128, 128>(p, stream) : pl.tile == 1 ? launch_fwd_h<128, 64>(p, stream)
         : pl.tile == 2 ? launch_fwd_h<64, 64>(p, stream) : launch_fwd_h<64, 128>(p, stream);
@@ -1485,16 +1646,48 @@ int sg2im_conv2d_forward(const sg2im_conv_desc* d, const float* weight, int cout
     err = launch_fwd<64, 64, 1>(p, stream);
   }
   if (err != hipSuccess) return SG2IM_ERR_HIP;
-  return finish_split(p.e, p.M, cout, stream) == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+  if (st_ok && pl.nsplit > 1 && cout % 4 == 0 && ld_out % 4 == 0 && al16p(out) && al16p(workspace) && (!bias || al16p(bias))) {
+    int nblk, nslab; long long per;
+    finish_stats_grid(p.M, cout, 3, bn->partial_floats, &nblk, &per, &nslab);
+    if ((size_t)nblk * 3 * cout <= bn->partial_floats) {
+      StatSink ss{};
+      ss.partial = bn->partial; ss.count = bn->count; ss.unit = bn->count_unit;
+      hipLaunchKernelGGL(splitk_finish_stats_kernel<1>, dim3(nblk, nslab), dim3(256), 0, stream, workspace, pl.nsplit, (long long)p.M,
+                         cout, out, ld_out, bias, out_slope, per, ss);
+      if (hipGetLastError() != hipSuccess) return SG2IM_ERR_HIP;
+      return bn_stats_finish_tiles(bn->partial, nblk, per, p.M, cout, bn, stream);
+    }
+  }
+  if (finish_split(p.e, p.M, cout, stream) != hipSuccess) return SG2IM_ERR_HIP;
+  return bn ? bn_fwd_standalone(bn, out, p.M, cout, ld_out, stream) : SG2IM_OK;
 }
 
-int sg2im_conv2d_backward_data(const sg2im_conv_desc* d, const float* weight, int cout, const float* dy,
-                               int ld_dy, int c_begin, int c_count, float* dx, long long ld_dx,
-                               int accumulate, float* workspace, size_t workspace_bytes,
-                               hipStream_t stream) {
+int sg2im_conv2d_forward(const sg2im_conv_desc* d, const float* weight, int cout, const float* bias,
+                         float out_slope, float* out, long long ld_out, int accumulate,
+                         float* workspace, size_t workspace_bytes, hipStream_t stream) {
+  return conv_forward_impl(d, weight, cout, bias, out_slope, out, ld_out, accumulate, workspace, workspace_bytes, nullptr,
+                           stream);
+}
+
+int sg2im_conv2d_forward_bn(const sg2im_conv_desc* d, const float* weight, int cout, const float* bias,
+                            float out_slope, float* out, long long ld_out, float* workspace, size_t workspace_bytes,
+                            const sg2im_bn_fwd* bn, hipStream_t stream) {
+  if (!bn || !bn->mean || !bn->invstd || !bn->scale || !bn->shift) return SG2IM_ERR_ARG;
+  if (bn->training && !bn->partial) return SG2IM_ERR_ARG;
+  if (!bn->training && (!bn->running_mean || !bn->running_var)) return SG2IM_ERR_ARG;
+  return conv_forward_impl(d, weight, cout, bias, out_slope, out, ld_out, 0, workspace, workspace_bytes, bn, stream);
+}
+
+// bb != nullptr: followed by the reductions + coefficient set-up of a BatchNorm backward over dx
+// (sg2im_conv2d_backward_data_bn)
+static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int cout, const float* dy,
+                           int ld_dy, int c_begin, int c_count, float* dx, long long ld_dx,
+                           int accumulate, float* workspace, size_t workspace_bytes, const sg2im_bn_bwd* bb,
+                           hipStream_t stream) {
   if (!d || !weight || !dy || !dx || cout < 1 || c_count < 1 || ld_dy < cout) return SG2IM_ERR_ARG;
   if (check_desc(d)) return SG2IM_ERR_ARG;
   DgradParams p;
+  p.st = StatSink{};
   // geometry (and Ctot) of the forward conv; s0 is then re-purposed to carry dY
   ConvGeom& g = p.g;
   fill_geom(g, d);
@@ -1506,8 +1699,14 @@ int sg2im_conv2d_backward_data(const sg2im_conv_desc* d, const float* weight, in
   if ((double)d->batch * d->out_h * d->out_w * ld_dy * 4.0 >= 2147483648.0) return SG2IM_ERR_ARG;
   p.Wt = weight; p.c_begin = c_begin; p.Nc = c_count;
   const long long Mfull = (long long)d->batch * d->in_h * d->in_w;
-  if (Mfull == 0) return SG2IM_OK;
+  if (Mfull == 0) return bb ? SG2IM_ERR_ARG : SG2IM_OK;
   const int taps = d->kh * d->kw;
+  // the standalone first two passes of the BatchNorm backward over the finished dx (launches that cannot fold them)
+  auto bn_after = [&]() -> int {
+    if (!bb) return SG2IM_OK;
+    const int f = bb->pool2 ? 2 : 1;
+    return bn_bwd_standalone(dx, ld_dx, bb->pool2, d->batch, d->in_h / f, d->in_w / f, c_count, bb, stream);
+  };
   if (c_count <= 4 && (size_t)taps * cout * c_count * sizeof(float) <= 48 * 1024) {
     const size_t lds = (size_t)taps * cout * c_count * sizeof(float);
     dim3 grid((unsigned)((Mfull + 255) / 256));
@@ -1518,7 +1717,7 @@ int sg2im_conv2d_backward_data(const sg2im_conv_desc* d, const float* weight, in
     if (c_count == 1) SG2IM_FEWC(1); else if (c_count == 2) SG2IM_FEWC(2); else if (c_count == 3) SG2IM_FEWC(3);
     else SG2IM_FEWC(4);
 #undef SG2IM_FEWC
-    return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+    return hipGetLastError() == hipSuccess ? bn_after() : SG2IM_ERR_HIP;
   }
   const bool va4 = (cout % 4 == 0) && (ld_dy % 4 == 0) && !((uintptr_t)dy & 15);
   const bool vb4 = (g.Ctot % 4 == 0) && (c_begin % 4 == 0) && (c_count % 4 == 0) && !((uintptr_t)weight & 15);
@@ -1548,6 +1747,25 @@ int sg2im_conv2d_backward_data(const sg2im_conv_desc* d, const float* weight, in
   }
   p.e = Epi{dx, ld_dx, nullptr, 1.f, accumulate, workspace, pl.nsplit};
   hipError_t err;
+  // BatchNorm-backward sums of dx from the same launches (data-gradient epilogue or split-K finish)
+  const long long bn_rows = bb ? (bb->pool2 ? Mfull / 4 : Mfull) : 0;
+  const bool st_ok = g_fuse_bn && bb && va4 && vb4 && !p.parity && !accumulate && bb->partial && al16p(bb->partial) &&
+                     (!bb->pool2 || (d->in_h % 2 == 0 && d->in_w % 2 == 0));
+  StatSink ss{};
+  if (st_ok) {
+    ss.partial = bb->partial; ss.count = bb->count; ss.unit = bb->count_unit * (bb->pool2 ? 4 : 1);
+    ss.y = bb->y; ss.ld_y = bb->ld_y; ss.mean = bb->mean; ss.invstd = bb->invstd; ss.scale = bb->scale; ss.shift = bb->shift;
+    ss.slope = bb->slope; ss.pool2 = bb->pool2; ss.H = d->in_h; ss.W = d->in_w;
+  }
+  if (st_ok && pl.nsplit == 1 && (size_t)((Mfull + pl.bm - 1) / pl.bm) * 2 * c_count <= bb->partial_floats) {
+    p.st = ss;
+    const bool hb = d->compute_dtype == 1;
+#define SG2IM_ST(BM_, BN_) (hb ? launch_dgrad_st<BM_, BN_, true>(p, stream) : launch_dgrad_st<BM_, BN_, false>(p, stream))
+    err = pl.tile == 0 ? SG2IM_ST(128, 128) : pl.tile == 1 ? SG2IM_ST(128, 64) : pl.tile == 2 ? SG2IM_ST(64, 64) : SG2IM_ST(64, 128);
+#undef SG2IM_ST
+    if (err != hipSuccess) return SG2IM_ERR_HIP;
+    return bn_bwd_finish_tiles(bb->partial, (int)((Mfull + pl.bm - 1) / pl.bm), bn_rows, c_count, bb, stream);
+  }
   if (va4 && vb4 && d->compute_dtype == 1) {
     err = pl.tile == 0 ? launch_dgrad_h<128, 128>(p, stream) : pl.tile == 1 ? launch_dgrad_h<128, 64>(p, stream)
         : pl.tile == 2 ? launch_dgrad_h<64, 64>(p, stream) : launch_dgrad_h<64, 128>(p, stream);
@@ -1565,9 +1783,37 @@ int sg2im_conv2d_backward_data(const sg2im_conv_desc* d, const float* weight, in
     const int blocks = (int)std::min<long long>((per_split + 255) / 256, 4096);
     hipLaunchKernelGGL(splitk_finish_parity_kernel, dim3(blocks), dim3(256), 0, stream, workspace, pl.nsplit, p.M,
                        c_count, dx, ld_dx, accumulate, d->batch, d->in_h, d->in_w);
-    return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+    return hipGetLastError() == hipSuccess ? bn_after() : SG2IM_ERR_HIP;
   }
-  return finish_split(p.e, Mfull, c_count, stream) == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+  if (st_ok && pl.nsplit > 1 && ld_dx % 4 == 0 && al16p(dx) && al16p(workspace) && bb->ld_y % 4 == 0 && al16p(bb->y) &&
+      al16p(bb->mean) && al16p(bb->invstd) && al16p(bb->scale) && al16p(bb->shift)) {
+    int nblk, nslab; long long per;
+    finish_stats_grid(Mfull, c_count, 2, bb->partial_floats, &nblk, &per, &nslab);
+    if ((size_t)nblk * 2 * c_count <= bb->partial_floats) {
+      hipLaunchKernelGGL(splitk_finish_stats_kernel<2>, dim3(nblk, nslab), dim3(256), 0, stream, workspace, pl.nsplit, Mfull, c_count,
+                         dx, ld_dx, (const float*)nullptr, 1.f, per, ss);
+      if (hipGetLastError() != hipSuccess) return SG2IM_ERR_HIP;
+      return bn_bwd_finish_tiles(bb->partial, nblk, bn_rows, c_count, bb, stream);
+    }
+  }
+  if (finish_split(p.e, Mfull, c_count, stream) != hipSuccess) return SG2IM_ERR_HIP;
+  return bn_after();
+}
+
+int sg2im_conv2d_backward_data(const sg2im_conv_desc* d, const float* weight, int cout, const float* dy,
+                               int ld_dy, int c_begin, int c_count, float* dx, long long ld_dx,
+                               int accumulate, float* workspace, size_t workspace_bytes,
+                               hipStream_t stream) {
+  return conv_dgrad_impl(d, weight, cout, dy, ld_dy, c_begin, c_count, dx, ld_dx, accumulate, workspace, workspace_bytes,
+                         nullptr, stream);
+}
+
+int sg2im_conv2d_backward_data_bn(const sg2im_conv_desc* d, const float* weight, int cout, const float* dy,
+                                  int ld_dy, int c_begin, int c_count, float* dx, long long ld_dx,
+                                  float* workspace, size_t workspace_bytes, const sg2im_bn_bwd* bb, hipStream_t stream) {
+  if (!bb || !bb->y || !bb->mean || !bb->invstd || !bb->scale || !bb->shift || !bb->coef || !bb->partial) return SG2IM_ERR_ARG;
+  if (bb->ld_y < c_count) return SG2IM_ERR_ARG;
+  return conv_dgrad_impl(d, weight, cout, dy, ld_dy, c_begin, c_count, dx, ld_dx, 0, workspace, workspace_bytes, bb, stream);
 }
 
 int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int ld_dy, int cout,

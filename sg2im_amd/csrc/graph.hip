@@ -223,7 +223,7 @@ using namespace sg2im;
 
 extern "C" {
 
-int sg2im_abi_version(void) { return 3; }
+int sg2im_abi_version(void) { return 4; }
 
 int sg2im_csr_build(const long long* keys_a, int n_a, const long long* keys_b, int n_b, int n_rows,
                     int* row_ptr, int* entries, int* scratch, const int* live_keys, hipStream_t stream) {

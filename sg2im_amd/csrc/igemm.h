@@ -241,6 +241,149 @@ __device__ __forceinline__ void epilogue(const Epi& e, int M, int N, int nlimit,
 }
 
 // ---------------------------------------------------------------------------
+// BatchNorm reductions in the GEMM epilogue (sg2im_conv2d_forward_bn / sg2im_conv2d_backward_data_bn):
+// the workgroup that owns a BM x BN output tile also owns BM rows of BN per-channel sums.  Per column the
+// partial sums of the tile's 2 (wave rows) x 2 (lane halves) row groups are combined through LDS in a
+// fixed order and written to tile partials [tile][K][N], which a one-launch finish (norm.hip) reduces in
+// double - the same two-stage, atomics-free scheme as the standalone statistics kernels, minus their pass
+// over the tensor.  `lds` is the operand image (free after the main loop), >= 9 * BN floats.
+// ---------------------------------------------------------------------------
+struct StatSink {
+  float* partial;          // [tiles][3][N] (forward: pivot, sum d, sum d^2) or [tiles][2][N] (backward: sum du, sum du*xhat)
+  const int* count;        // optional: only the first count[0] * unit rows are real (padded row batches)
+  int unit;
+  // backward only: the normalised layer's pre-BN output and its statistics
+  const float* y; long long ld_y;
+  const float* mean; const float* invstd; const float* scale; const float* shift;
+  float slope;
+  int pool2, H, W;         // pool2: this launch's rows are pixels (n, h, w) of an H x W map at TWICE y's resolution
+};
+
+__device__ __forceinline__ int live_limit(const StatSink& ss, int M) {
+  if (!ss.count) return M;
+  const long long t = (long long)ss.count[0] * ss.unit;
+  return t < M ? (int)t : M;
+}
+
+// forward: statistics of the values the epilogue stored, v = leaky(acc + bias), as pivot-shifted sums with the
+// tile's first row as the pivot (sum d, sum d^2 with d = v - pivot: free of the cancellation of E[x^2] - mean^2)
+template <int BM, int BN>
+__device__ __forceinline__ void epilogue_stats(const Epi& e, const StatSink& ss, int M, int N, int m0, int n0, int wm0,
+                                               int wn0, int lane, int tid, int tile,
+                                               const f32x16 (&acc)[BM / 64][BN / 64], float* lds) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  const int j = lane & 31, h = lane >> 5;
+  const int wave_m = wm0 / (BM / 2);
+  float* piv = lds;                  // [BN]
+  float* red = lds + BN;             // [2][4][BN]
+  const int Mlive = live_limit(ss, M);
+  __syncthreads();                   // (every wave is done with the operand image)
+  if (wave_m == 0 && h == 0) {
+    #pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = wn0 + tn * 32 + j, n = n0 + col;
+      const float bv = (n < N && e.bias) ? e.bias[n] : 0.f;
+      piv[col] = leaky(acc[0][tn][0] + bv, e.slope);
+    }
+  }
+  __syncthreads();
+  #pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = wn0 + tn * 32 + j, n = n0 + col;
+    const float bv = (n < N && e.bias) ? e.bias[n] : 0.f;
+    const float pv = piv[col];
+    float s0 = 0.f, s1 = 0.f;
+    #pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      #pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < Mlive) {
+          const float d = leaky(acc[tm][tn][r] + bv, e.slope) - pv;
+          s0 += d; s1 = fmaf(d, d, s1);
+        }
+      }
+    }
+    red[(wave_m * 2 + h) * BN + col] = s0;
+    red[(4 + wave_m * 2 + h) * BN + col] = s1;
+  }
+  __syncthreads();
+  for (int col = tid; col < BN; col += NTHREADS) {
+    const int n = n0 + col;
+    if (n >= N) continue;
+    const float s0 = ((red[col] + red[BN + col]) + red[2 * BN + col]) + red[3 * BN + col];
+    const float s1 = ((red[4 * BN + col] + red[5 * BN + col]) + red[6 * BN + col]) + red[7 * BN + col];
+    float* dst = ss.partial + (size_t)tile * 3 * N + n;
+    dst[0] = piv[col]; dst[N] = s0; dst[2 * N] = s1;
+  }
+}
+
+// backward: this launch's result is gz = d(loss)/d(activated output of a BatchNorm'd layer).  With
+// u = scale * y + shift (the normalised, pre-activation value) and du = gz * leaky'(u):
+//   sum du  and  sum du * (y - mean) * invstd   per channel - what sg2im_bn_act_backward's first pass computes.
+// pool2: the rows are at twice y's resolution (nearest-upsample backward): by linearity the sums of the 2x2-pooled
+// gradient equal the sums over the fine pixels with y read at the coarse pixel.
+template <int BM, int BN>
+__device__ __forceinline__ void epilogue_bnbwd(const StatSink& ss, int M, int N, int m0, int n0, int wm0, int wn0,
+                                               int lane, int tid, int tile,
+                                               const f32x16 (&acc)[BM / 64][BN / 64], float* lds) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  const int j = lane & 31, h = lane >> 5;
+  const int wave_m = wm0 / (BM / 2);
+  float* red = lds;                  // [2][4][BN]
+  const int Mlive = live_limit(ss, M);
+  const int HW = ss.H * ss.W;
+  float s0[TN], s1[TN], sc[TN], sh[TN], mu[TN], is[TN];
+  #pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n0 + wn0 + tn * 32 + j;
+    const bool ok = n < N;
+    s0[tn] = 0.f; s1[tn] = 0.f;
+    sc[tn] = ok ? ss.scale[n] : 0.f; sh[tn] = ok ? ss.shift[n] : 0.f;
+    mu[tn] = ok ? ss.mean[n] : 0.f; is[tn] = ok ? ss.invstd[n] : 0.f;
+  }
+  #pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    #pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (m >= Mlive) continue;
+      long long row = m;
+      if (ss.pool2) {
+        const int nb = m / HW, rem = m - nb * HW;
+        const int hi = rem / ss.W, wi = rem - hi * ss.W;
+        row = ((long long)nb * (ss.H >> 1) + (hi >> 1)) * (ss.W >> 1) + (wi >> 1);
+      }
+      const float* yrow = ss.y + row * ss.ld_y;
+      #pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + wn0 + tn * 32 + j;
+        if (n >= N) continue;
+        const float yv = yrow[n];
+        const float du = acc[tm][tn][r] * (fmaf(yv, sc[tn], sh[tn]) > 0.f ? 1.f : ss.slope);
+        s0[tn] += du; s1[tn] = fmaf(du, (yv - mu[tn]) * is[tn], s1[tn]);
+      }
+    }
+  }
+  __syncthreads();                   // (every wave is done with the operand image)
+  #pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = wn0 + tn * 32 + j;
+    red[(wave_m * 2 + h) * BN + col] = s0[tn];
+    red[(4 + wave_m * 2 + h) * BN + col] = s1[tn];
+  }
+  __syncthreads();
+  for (int col = tid; col < BN; col += NTHREADS) {
+    const int n = n0 + col;
+    if (n >= N) continue;
+    const float a = ((red[col] + red[BN + col]) + red[2 * BN + col]) + red[3 * BN + col];
+    const float b = ((red[4 * BN + col] + red[5 * BN + col]) + red[6 * BN + col]) + red[7 * BN + col];
+    float* dst = ss.partial + (size_t)tile * 2 * N + n;
+    dst[0] = a; dst[N] = b;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // bf16 operand path (compute_dtype 1): the SAME loaders / staging registers / pipeline, but the
 // operands are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) when they are written to LDS and multiplied
 // with v_mfma_f32_32x32x16_bf16 (fp32 accumulate) - 16x the fp32 matrix rate, half the LDS bytes.

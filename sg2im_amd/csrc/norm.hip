@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <hip/hip_runtime.h>
 #include "sg2im_hip.h"
+#include "bn_final.h"
 
 namespace sg2im {
 
@@ -127,6 +128,58 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ x, const float* 
     mu = running_mean[c]; var = running_var[c];
   }
   if ((threadIdx.x & 63) != 0) return;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  mean[c] = (float)mu; invstd[c] = is;
+  const float sc = g * is;
+  scale[c] = sc; shift[c] = b - (float)mu * sc;
+}
+
+// Finish of statistics whose tile partials came out of a GEMM epilogue / split-K finish (conv.hip): tile t
+// covers the rows [t * per, (t + 1) * per) and holds (its own pivot p_t, sum d, sum d^2) with d = x - p_t.
+// Per tile: mean_t = p_t + s_t / n_t, M2_t = q_t - s_t^2 / n_t; combined in double relative to tile 0's pivot
+// (Chan et al.): one wavefront per channel, lanes stride over the tiles, xor-tree at the end (fixed order).
+__global__ void bn_stats_final_tiles_kernel(const float* __restrict__ partial, int nblk, long long per, long long rows,
+                                            long long unbiased_rows, int C,
+                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                            float eps, float momentum,
+                                            float* __restrict__ running_mean, float* __restrict__ running_var,
+                                            long long* __restrict__ nbt, float* __restrict__ mean,
+                                            float* __restrict__ invstd, float* __restrict__ scale,
+                                            float* __restrict__ shift, const int* __restrict__ count, int unit) {
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);     // one wavefront per channel
+  const int lane = threadIdx.x & 63;
+  if (c == 0 && lane == 0 && nbt) *nbt += 1;
+  long long live = live_rows(rows, count, unit);
+  if (count && unbiased_rows > 0) unbiased_rows = unbiased_rows / rows * live;   // (a whole multiple of rows)
+  if (c >= C) return;
+  const double P = (double)partial[c];                  // tile 0's pivot
+  double sn = 0.0, sm = 0.0, sq = 0.0;
+  for (int t = lane; t < nblk; t += 64) {
+    long long nt = live - (long long)t * per;
+    if (nt <= 0) continue;
+    if (nt > per) nt = per;
+    const float* q = partial + (long long)t * 3 * C + c;
+    const double n = (double)nt, s = (double)q[C], ss = (double)q[2 * C];
+    const double mt = ((double)q[0] - P) + s / n;
+    double m2 = ss - s * s / n;
+    if (m2 < 0.0) m2 = 0.0;
+    sn += n; sm += n * mt; sq += m2 + n * mt * mt;
+  }
+  #pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { sn += __shfl_xor(sn, off); sm += __shfl_xor(sm, off); sq += __shfl_xor(sq, off); }
+  if (lane != 0) return;
+  const double N = sn > 0.0 ? sn : 1.0;
+  const double dm = sm / N;
+  const double mu = P + dm;
+  double var = sq / N - dm * dm;
+  if (var < 0.0) var = 0.0;
+  if (running_mean) {
+    const double nu = (double)(unbiased_rows > 0 ? unbiased_rows : (live > 0 ? live : 1));
+    const double unbiased = nu > 1.0 ? var * nu / (nu - 1.0) : var;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+  }
   const float is = (float)(1.0 / sqrt(var + (double)eps));
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
   mean[c] = (float)mu; invstd[c] = is;
@@ -713,6 +766,42 @@ static inline int ew_blocks(long long total) {
 }
 static inline int ok_or(hipError_t e) { return e == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP; }
 
+int bn_stats_finish_tiles(const float* partial, int nblk, long long per, long long rows, int channels,
+                          const sg2im_bn_fwd* a, hipStream_t stream) {
+  hipLaunchKernelGGL(bn_stats_final_tiles_kernel, dim3((channels + 3) / 4), dim3(256), 0, stream, partial, nblk, per, rows,
+                     a->unbiased_rows, channels, a->gamma, a->beta, a->eps, a->momentum, a->running_mean, a->running_var,
+                     a->num_batches_tracked, a->mean, a->invstd, a->scale, a->shift, a->count, a->count_unit);
+  return ok_or(hipGetLastError());
+}
+
+int bn_bwd_finish_tiles(const float* partial, int nblk, long long rows, int channels, const sg2im_bn_bwd* a,
+                        hipStream_t stream) {
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((channels + 3) / 4), dim3(256), 0, stream, partial, nblk, rows, channels,
+                     a->gamma, a->mean, a->invstd, a->training, a->dgamma, a->dbeta, a->accumulate, a->coef, a->count,
+                     a->count_unit);
+  return ok_or(hipGetLastError());
+}
+
+int bn_bwd_standalone(const float* g, long long ld_g, int pool2, int batch, int h, int w, int channels,
+                      const sg2im_bn_bwd* a, hipStream_t stream) {
+  const long long rows = (long long)batch * h * w;
+  if (rows < 1 || !a->partial) return SG2IM_ERR_ARG;
+  const GradSrc gs{g, ld_g, pool2, h, w};
+  int nblk = red_blocks(rows);
+  // (the caller's partial buffer may be smaller than the usual 2 * C * RED_BLOCKS floats)
+  if ((size_t)nblk * 2 * channels > a->partial_floats) nblk = (int)std::max<size_t>(1, a->partial_floats / ((size_t)2 * channels));
+  const bool v4 = channels % 4 == 0 && ld_g % 4 == 0 && a->ld_y % 4 == 0 && al16(g) && al16(a->y) &&
+                  al16(a->partial) && al16(a->mean) && al16(a->invstd) && al16(a->scale) && al16(a->shift);
+  if (v4)
+    hipLaunchKernelGGL(bn_bwd_partial_v4_kernel, dim3(nblk), dim3(256), 8 * 256 * sizeof(float), stream, gs, a->y, a->ld_y,
+                       rows, channels, a->mean, a->invstd, a->scale, a->shift, a->slope, a->partial, a->count, a->count_unit);
+  else
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk), dim3(256), 2 * 256 * sizeof(float), stream, gs, a->y, a->ld_y, rows,
+                       channels, a->mean, a->invstd, a->scale, a->shift, a->slope, a->partial, a->count, a->count_unit);
+  if (hipGetLastError() != hipSuccess) return SG2IM_ERR_HIP;
+  return bn_bwd_finish_tiles(a->partial, nblk, rows, channels, a, stream);
+}
+
 }  // namespace sg2im
 
 using namespace sg2im;
@@ -750,22 +839,28 @@ int sg2im_bn_act_backward(const float* g, long long ld_g, int pool2, int batch, 
                           float* dgamma, float* dbeta, int accumulate, float* partial,
                           const int* count, int count_unit, hipStream_t stream) {
   if (!g || !y || !dy || !partial || channels < 1 || !mean || !invstd || !scale || !shift) return SG2IM_ERR_ARG;
+  if ((long long)batch * h * w < 1) return SG2IM_ERR_ARG;
+  sg2im_bn_bwd a;
+  a.y = y; a.ld_y = ld_y; a.pool2 = pool2; a.gamma = gamma; a.mean = mean; a.invstd = invstd; a.scale = scale;
+  a.shift = shift; a.slope = slope; a.training = training; a.dgamma = dgamma; a.dbeta = dbeta; a.accumulate = accumulate;
+  a.coef = partial + (size_t)2 * channels * RED_BLOCKS;     // 3*C floats behind the partials
+  a.partial = partial; a.partial_floats = (size_t)2 * channels * RED_BLOCKS; a.count = count; a.count_unit = count_unit;
+  const int rc = bn_bwd_standalone(g, ld_g, pool2, batch, h, w, channels, &a, stream);
+  if (rc != SG2IM_OK) return rc;
+  return sg2im_bn_backward_apply(g, ld_g, pool2, batch, h, w, y, ld_y, channels, scale, shift, slope, a.coef, dy, count,
+                                 count_unit, stream);
+}
+
+int sg2im_bn_backward_apply(const float* g, long long ld_g, int pool2, int batch, int h, int w, const float* y,
+                            long long ld_y, int channels, const float* scale, const float* shift, float slope,
+                            const float* coef, float* dy, const int* count, int count_unit, hipStream_t stream) {
+  if (!g || !y || !dy || !coef || channels < 1 || !scale || !shift) return SG2IM_ERR_ARG;
   const long long rows = (long long)batch * h * w;
   if (rows < 1) return SG2IM_ERR_ARG;
   const GradSrc gs{g, ld_g, pool2, h, w};
-  const int nblk = red_blocks(rows);
-  float* coef = partial + (size_t)2 * channels * RED_BLOCKS;     // 3*C floats behind the partials
   const bool v4 = channels % 4 == 0 && ld_g % 4 == 0 && ld_y % 4 == 0 && al16(g) && al16(y) && al16(dy) &&
-                  al16(partial) && al16(mean) && al16(invstd) && al16(scale) && al16(shift);
+                  al16(scale) && al16(shift) && al16(coef);
   if (v4)
-    hipLaunchKernelGGL(bn_bwd_partial_v4_kernel, dim3(nblk), dim3(256), 8 * 256 * sizeof(float), stream, gs, y, ld_y,
-                       rows, channels, mean, invstd, scale, shift, slope, partial, count, count_unit);
-  else
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk), dim3(256), 2 * 256 * sizeof(float), stream, gs, y, ld_y, rows,
-                       channels, mean, invstd, scale, shift, slope, partial, count, count_unit);
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((channels + 3) / 4), dim3(256), 0, stream, partial, nblk, rows,
-                     channels, gamma, mean, invstd, training, dgamma, dbeta, accumulate, coef, count, count_unit);
-  if (v4 && al16(coef))
     hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(ew_blocks(rows * channels / 4)), dim3(256), 0, stream, gs, y, ld_y,
                        rows, channels, scale, shift, slope, coef, dy, count, count_unit);
   else

@@ -642,12 +642,13 @@ class RefinementFn(Function):
       C = W0p.size(0)
       bn0, bn1 = bns[i]
       d0 = _crn_conv0_desc(lay, feat_src, N, h, w, W0p)
-      y0 = ops.conv2d_forward(d0, _cl_weight(W0p), C, b0, _new(layout, N, h, w, C), C)
-      st0 = ops.bn_stats(y0, N * h * w, C, C, bn0, training, BN_EPS, BN_MOMENTUM)
+      # (the BatchNorm statistics of a conv output come out of the conv's own launches: epilogue or split-K finish)
+      y0 = _new(layout, N, h, w, C)
+      st0 = ops.conv2d_forward_bn(d0, _cl_weight(W0p), C, b0, y0, C, bn0, training, BN_EPS, BN_MOMENTUM)
       src0 = activated(y0, st0, 0)
       d1 = conv_desc([src0], N, h, w, 3, 3, 1, 1)
-      y1 = ops.conv2d_forward(d1, _cl_weight(W1p), C, b1, _new(layout, N, h, w, C), C)
-      st1 = ops.bn_stats(y1, N * h * w, C, C, bn1, training, BN_EPS, BN_MOMENTUM)
+      y1 = _new(layout, N, h, w, C)
+      st1 = ops.conv2d_forward_bn(d1, _cl_weight(W1p), C, b1, y1, C, bn1, training, BN_EPS, BN_MOMENTUM)
       saved.append((lay, feat_src, y0, st0, y1, st1, h, w, C, src0))
       feat_src = activated(y1, st1, 1)
     last = saved[-1]
@@ -711,7 +712,18 @@ class RefinementFn(Function):
     ops.act_backward(_fptr(dz), Co, 0, N, H, W, z, Co, Co, slope, dz)
     gz = _new(g, N, H, W, Cf)                      # grad w.r.t. activated feats of the last module
     side.barrier()
-    ops.conv2d_backward_data(do0, _cl_weight(Wo0), Co, dz, Co, 0, Cf, gz, Cf)
+    # Every data gradient below that produces the gradient of a BatchNorm'd layer's activated output also
+    # produces that BatchNorm's backward reductions (epilogue / split-K finish) and coefficients: per layer
+    # only the elementwise `apply` pass is left between two data gradients of the chain.
+    def bn_bufs(i, second):
+      k_ = 4 * L + 4 + 4 * i + (2 if second else 0)
+      gam, bet = bnp[4 * i + (2 if second else 0)], bnp[4 * i + (3 if second else 1)]
+      dgm, dbt, acc_, grads[k_], grads[k_ + 1] = _bn_grad_bufs(g, gam.numel(), gam, bet, ni[k_], ni[k_ + 1])
+      return gam, dgm, dbt, acc_
+    lastm = saved[L - 1]
+    g1, dg1, db1n, acc1 = bn_bufs(L - 1, True)
+    coef1 = ops.conv2d_backward_data_bn(do0, _cl_weight(Wo0), Co, dz, Co, 0, Cf, gz, Cf, lastm[4], Cf, 0, g1, lastm[5],
+                                        slope, training, dg1, db1n, acc1)
     grads[4 * L], grads[4 * L + 1] = wgrad(do0, dz, Co, (Co, 3, 3, Cf), ni[4 * L], ni[4 * L + 1], Wo0, bo0)
     pool2 = 0
     need_layout = ctx.needs_input_grad[0]
@@ -721,23 +733,21 @@ class RefinementFn(Function):
     for i in range(L - 1, -1, -1):
       lay, feat_src, y0, st0, y1, st1, h, w, C, src0 = saved[i]
       W0p, b0, W1p, b1 = convp[4 * i:4 * i + 4]
-      g0, be0, g1, be1 = bnp[4 * i:4 * i + 4]
-      k = 4 * L + 4 + 4 * i
-      dg1, db1n, acc1, grads[k + 2], grads[k + 3] = _bn_grad_bufs(g, C, g1, be1, ni[k + 2], ni[k + 3])
-      dy1 = ops.bn_act_backward(_fptr(gz), gz.size(3), pool2, N, h, w, y1, C, C, g1, st1, slope, training,
-                                _new(g, N, h, w, C), dg1, db1n, acc1)
+      dy1 = ops.bn_backward_apply(_fptr(gz), gz.size(3), pool2, N, h, w, y1, C, C, st1, slope, coef1,
+                                  _new(g, N, h, w, C))
       d1 = conv_desc([src0], N, h, w, 3, 3, 1, 1)
       gz0 = _new(g, N, h, w, C)
       side.barrier()
-      ops.conv2d_backward_data(d1, _cl_weight(W1p), C, dy1, C, 0, C, gz0, C)
+      g0, dg0, db0n, acc0 = bn_bufs(i, False)
+      coef0 = ops.conv2d_backward_data_bn(d1, _cl_weight(W1p), C, dy1, C, 0, C, gz0, C, y0, C, 0, g0, st0, slope,
+                                          training, dg0, db0n, acc0)
       grads[4 * i + 2], grads[4 * i + 3] = wgrad(d1, dy1, C, (C, 3, 3, C), ni[4 * i + 2],
                                                   ni[4 * i + 3] and not training, W1p, b1)
       if training:
         grads[4 * i + 3] = _shadowed_bias_grad(b1, ni[4 * i + 3])
-      dg0, db0n, acc0, grads[k], grads[k + 1] = _bn_grad_bufs(g, C, g0, be0, ni[k], ni[k + 1])
       # (dy1's buffer is recycled for dy0 unless a side-stream weight gradient may still be reading it)
-      dy0 = ops.bn_act_backward(_fptr(gz0), C, 0, N, h, w, y0, C, C, g0, st0, slope, training,
-                                _new(g, N, h, w, C) if side.on else dy1, dg0, db0n, acc0)
+      dy0 = ops.bn_backward_apply(_fptr(gz0), C, 0, N, h, w, y0, C, C, st0, slope, coef0,
+                                  _new(g, N, h, w, C) if side.on else dy1)
       Cprev = feat_src.channels if feat_src is not None else W0p.size(1) - Cl
       d0 = _crn_conv0_desc(lay, feat_src, N, h, w, W0p)
       side.barrier()
@@ -747,7 +757,10 @@ class RefinementFn(Function):
         dlevels.append((dl, H // h))
       if i > 0:
         gz = _new(g, N, h, w, Cprev)               # at this (upsampled) resolution; summed 2x2 next
-        ops.conv2d_backward_data(d0, _cl_weight(W0p), C, dy0, C, Cl, Cprev, gz, Cprev)
+        prevm = saved[i - 1]
+        g1, dg1, db1n, acc1 = bn_bufs(i - 1, True)
+        coef1 = ops.conv2d_backward_data_bn(d0, _cl_weight(W0p), C, dy0, C, Cl, Cprev, gz, Cprev, prevm[4], Cprev, 1, g1,
+                                            prevm[5], slope, training, dg1, db1n, acc1)
         pool2 = 1
       grads[4 * i], grads[4 * i + 1] = wgrad(d0, dy0, C, (C, 3, 3, Cl + Cprev), ni[4 * i],
                                               ni[4 * i + 1] and not training, W0p, b0)
@@ -903,17 +916,24 @@ class MaskNetFn(Function):
     x = obj_vecs.contiguous().view(O, 1, 1, D)
     saved = []
     s = 1
+    # statistics of the upsampled tensor == statistics of x (each value repeated 4x); only the unbiased
+    # running_var factor sees the repeated count.  The first block normalises obj_vecs (standalone pass), every
+    # later one the previous block's conv + ReLU output, whose statistics ride in that conv's launches.
+    st = ops.bn_stats(x, O, D, D, bns[0], training, BN_EPS, BN_MOMENTUM, unbiased_rows=4 * O, count=cnt(1))
     for b in range(nb):
       gam, bet, Wp, bias = params[4 * b:4 * b + 4]
-      # statistics of the upsampled tensor == statistics of x (each value repeated 4x);
-      # only the unbiased running_var factor sees the repeated count
-      st = ops.bn_stats(x, O * s * s, D, D, bns[b], training, BN_EPS, BN_MOMENTUM, unbiased_rows=4 * O * s * s,
-                        count=cnt(s * s))
       d = conv_desc([nhwc_src(x, 1, st.scale, st.shift, 1.0)], O, 2 * s, 2 * s, 3, 3, 1, 1)
-      y = ops.conv2d_forward(d, _cl_weight(Wp), D, bias, _new(x, O, 2 * s, 2 * s, D), D, 0.0)
+      y = _new(x, O, 2 * s, 2 * s, D)
+      s2 = 2 * s
+      if b + 1 < nb:
+        st_next = ops.conv2d_forward_bn(d, _cl_weight(Wp), D, bias, y, D, bns[b + 1], training, BN_EPS, BN_MOMENTUM,
+                                        out_slope=0.0, unbiased_rows=4 * O * s2 * s2, count=cnt(s2 * s2))
+      else:
+        st_next = None
+        ops.conv2d_forward(d, _cl_weight(Wp), D, bias, y, D, 0.0)
       saved.append((x, st, y, s))
-      x = y
-      s *= 2
+      x, st = y, st_next
+      s = s2
     Wf, bf = params[4 * nb:4 * nb + 2]
     df = conv_desc([nhwc_src(x)], O, s, s, 1, 1, 1, 0)
     scores = ops.conv2d_forward(df, _cl_weight(Wf), 1, bf, _new(x, O, s, s, 1), 1)
@@ -945,10 +965,11 @@ class MaskNetFn(Function):
       grads[4 * b + 2], grads[4 * b + 3] = _conv_param_grads(d, dpre, D, (D, 3, 3, D), ni[4 * b + 2], ni[4 * b + 3],
                                                               Wp, bias)
       gup = _new(g, O, s2, s2, D)
-      ops.conv2d_backward_data(d, _cl_weight(Wp), D, dpre, D, 0, D, gup, D)
       dgam, dbet, accb, grads[4 * b], grads[4 * b + 1] = _bn_grad_bufs(g, D, gam, bet, ni[4 * b], ni[4 * b + 1])
-      gz = ops.bn_act_backward(_fptr(gup), D, 1, O, sb, sb, x, D, D, gam, st, 1.0, training, _new(g, O, sb, sb, D),
-                               dgam, dbet, accb, count=None if count is None else (count[0], count[1] * sb * sb))
+      bcnt = None if count is None else (count[0], count[1] * sb * sb)
+      coef = ops.conv2d_backward_data_bn(d, _cl_weight(Wp), D, dpre, D, 0, D, gup, D, x, D, 1, gam, st, 1.0, training,
+                                         dgam, dbet, accb, count=bcnt)
+      gz = ops.bn_backward_apply(_fptr(gup), D, 1, O, sb, sb, x, D, D, st, 1.0, coef, _new(g, O, sb, sb, D), count=bcnt)
     ctx.saved = None
     d_obj = gz.view(O, D) if ctx.needs_input_grad[0] else None
     return (d_obj, None, None, None) + tuple(grads)
@@ -981,15 +1002,16 @@ class DiscCnnFn(Function):
         Wp, bias = params[2 + 4 * (i - 1) + 2:2 + 4 * (i - 1) + 4]
       d = conv_desc([src], N, h, w, k, k, stride, pad)
       last = i + 1 == len(specs)
-      y = ops.conv2d_forward(d, _cl_weight(Wp), cout, bias, _new(x, N, d.out_h, d.out_w, cout), cout,
-                             slope if (nonorm and not inorm and not last) else 1.0)
       st = ypre = ist = None
+      y = _new(x, N, d.out_h, d.out_w, cout)
+      if not last and not nonorm:      # conv + the statistics of the BatchNorm behind it, same launches
+        st = ops.conv2d_forward_bn(d, _cl_weight(Wp), cout, bias, y, cout, bns[i], training, BN_EPS, BN_MOMENTUM,
+                                   count=None if count is None else (count[0], count[1] * d.out_h * d.out_w))
+      else:
+        ops.conv2d_forward(d, _cl_weight(Wp), cout, bias, y, cout, slope if (nonorm and not inorm and not last) else 1.0)
       if inorm and not last:           # materialised norm + activation; y becomes the activated tensor
         ypre, ist = y, ops.instnorm_stats(y, BN_EPS)
         y = ops.instnorm_act_forward(ypre, ist, slope, _new(x, N, d.out_h, d.out_w, cout))
-      if not last and not nonorm:
-        st = ops.bn_stats(y, N * d.out_h * d.out_w, cout, cout, bns[i], training, BN_EPS, BN_MOMENTUM,
-                          count=None if count is None else (count[0], count[1] * d.out_h * d.out_w))
       saved.append((src, d, y, st, h, w, ypre, ist))
       h, w = d.out_h, d.out_w
       if st is not None:

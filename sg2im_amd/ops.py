@@ -12,7 +12,7 @@ from ctypes import byref, c_int, c_longlong, c_void_p
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, call
+from ._lib import BnBwd, BnFwd, ConvDesc, call
 
 WORKSPACE_BYTES = 256 << 20      # split-K partials / layout-backward partials
 _ws = {}
@@ -519,6 +519,73 @@ def bn_stats(x, rows, C, ld, bn, training, eps=1e-5, momentum=0.1, unbiased_rows
        c_void_p(nbt.data_ptr()) if nbt is not None else None, int(unbiased_rows), _f(st.mean), _f(st.invstd), _f(st.scale),
        _f(st.shift), _f(part), cp, cu, _stream())
   return st
+
+
+def _ptr(t):
+  return t.data_ptr() if t is not None else None
+
+
+def conv2d_forward_bn(desc, weight, cout, bias, out, ld_out, bn, training, eps=1e-5, momentum=0.1, out_slope=1.0,
+                      unbiased_rows=0, count=None):
+  """conv2d_forward followed by bn_stats of its output, with the statistics' reductions riding in the
+  convolution's own launches (sg2im_conv2d_forward_bn).  Returns the BnState."""
+  ws = workspace(out.device)
+  st = BnState(cout, out.device)
+  M = desc.batch * desc.out_h * desc.out_w
+  nfl = max(3 * cout * ((M + 63) // 64), 3 * cout * min((M + 7) // 8, 2048), 2 * cout * 1024)
+  part = scratch(out.device, nfl)
+  a = BnFwd()
+  a.gamma, a.beta = _ptr(bn.weight), _ptr(bn.bias)
+  a.eps, a.momentum, a.training = float(eps), float(momentum), int(training)
+  a.running_mean, a.running_var = _ptr(bn.running_mean), _ptr(bn.running_var)
+  a.num_batches_tracked = _ptr(bn.num_batches_tracked)
+  a.unbiased_rows = int(unbiased_rows)
+  a.mean, a.invstd, a.scale, a.shift = st.mean.data_ptr(), st.invstd.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr()
+  a.partial, a.partial_floats = part.data_ptr(), part.numel()
+  cp, cu = _count_args(count)
+  a.count, a.count_unit = (cp.value if cp is not None else None), cu
+  flops = 2.0 * M * cout * _desc_k(desc)
+  _note_bytes('igemm_fwd', _desc_src_floats(desc) + cout * _desc_k(desc) + M * cout)
+  _timed('igemm_fwd', flops, lambda: call(
+    'sg2im_conv2d_forward_bn', byref(desc), _f(weight), int(cout), _f(bias), float(out_slope), _f(out), int(ld_out),
+    _f(ws), ws.numel() * 4, byref(a), _stream()))
+  return st
+
+
+def conv2d_backward_data_bn(desc, weight, cout, dy, ld_dy, c_begin, c_count, dx, ld_dx, y, ld_y, pool2, gamma, st,
+                            slope, training, dgamma, dbeta, accumulate=False, count=None):
+  """conv2d_backward_data whose result dx is the gradient w.r.t. the ACTIVATED output of a BatchNorm'd layer
+  (pre-norm output y, statistics st), together with that BatchNorm's backward reductions
+  (sg2im_conv2d_backward_data_bn).  Returns the coefficient tensor for bn_backward_apply."""
+  ws = workspace(dx.device)
+  rows_dx = desc.batch * desc.in_h * desc.in_w
+  nfl = max(2 * c_count * ((rows_dx + 63) // 64), 2 * c_count * min((rows_dx + 7) // 8, 2048), 2 * c_count * 1024)
+  part = scratch(dx.device, nfl)
+  coef = torch.empty(3 * c_count, dtype=torch.float32, device=dx.device)
+  a = BnBwd()
+  a.y, a.ld_y, a.pool2 = y.data_ptr(), int(ld_y), int(pool2)
+  a.gamma = _ptr(gamma)
+  a.mean, a.invstd, a.scale, a.shift = st.mean.data_ptr(), st.invstd.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr()
+  a.slope, a.training = float(slope), int(training)
+  a.dgamma, a.dbeta, a.accumulate = _ptr(dgamma), _ptr(dbeta), int(accumulate)
+  a.coef, a.partial, a.partial_floats = coef.data_ptr(), part.data_ptr(), part.numel()
+  cp, cu = _count_args(count)
+  a.count, a.count_unit = (cp.value if cp is not None else None), cu
+  flops = 2.0 * desc.batch * desc.out_h * desc.out_w * cout * desc.kh * desc.kw * c_count
+  _note_bytes('igemm_dgrad', desc.batch * desc.out_h * desc.out_w * cout + cout * desc.kh * desc.kw * c_count +
+              rows_dx * c_count)
+  _timed('igemm_dgrad', flops, lambda: call(
+    'sg2im_conv2d_backward_data_bn', byref(desc), _f(weight), int(cout), _f(dy), int(ld_dy), int(c_begin), int(c_count),
+    _f(dx), int(ld_dx), _f(ws), ws.numel() * 4, byref(a), _stream()))
+  return coef
+
+
+def bn_backward_apply(g, ld_g, pool2, batch, h, w, y, ld_y, C, st, slope, coef, dy, count=None):
+  """dy = coef[0] * du + coef[1] * y + coef[2] (the third pass of bn_act_backward; g is a raw pointer)"""
+  cp, cu = _count_args(count)
+  call('sg2im_bn_backward_apply', g, int(ld_g), int(pool2), int(batch), int(h), int(w), _f(y), int(ld_y), int(C),
+       _f(st.scale), _f(st.shift), float(slope), _f(coef), _f(dy), cp, cu, _stream())
+  return dy
 
 
 def bn_act_backward(g, ld_g, pool2, batch, h, w, y, ld_y, C, gamma, st, slope, training, dy, dgamma, dbeta,

@@ -107,12 +107,16 @@ def oracle_leafs(P):
 # of 1e-4 against the float32 oracle is thus unattainable even for a bit-exact reimplementation with another
 # summation order.  The gradients are compared with the EXACT gradient instead - the oracle in float64 - and
 # must be as close to it as the reference's arithmetic is:
-#     e_hip64(t) <= max(1e-4, 3 e_ref(t), E_ref(net))
+#     e_hip64(t) <= max(1e-4, 3 E_ref)   and   cosine(g_hip(t), g_f64(t)) >= 0.999   for every tensor t
 # with e_hip64 / e_ref the max-abs errors of the HIP arena / of the float32 oracle against float64, relative
-# to the tensor's max magnitude, and E_ref(net) the largest e_ref over the tensors of the same network.
-# A genuinely wrong gradient (sign, missing term, missing 1/world) is off by O(1), two orders above that.
+# to the tensor's max magnitude, and E_ref the largest e_ref over all tensors of the step (which decisions
+# flip is a draw per implementation: per tensor the two errors differ by large factors either way - one side
+# often has no flip at all where the other has one - while the worst tensor of a step is a stable measure of
+# the step's conditioning; measured e_hip64 <= 1.3 E_ref everywhere, profiles/r3_grad_parity.log).
+# A genuinely wrong gradient (sign, missing term, missing 1/world) is off by O(1): 10-100x above the bound,
+# and every kernel is held to 1e-4 on its own by the op-level sections (tools/gpu_check.py).
 # ---------------------------------------------------------------------------------------
-GRAD_REL, GRAD_ABS_ZERO = 1e-4, 1e-6
+GRAD_REL, GRAD_ABS_ZERO, GRAD_COS = 1e-4, 1e-6, 0.999
 
 
 def cast_batch(cpu_batch, dtype):
@@ -189,23 +193,24 @@ def check_grad_rows(rows, rel=None, cos_min=None):
   a convolution feeding a batch-statistics BatchNorm, parameters without a gradient) must be below 1e-6
   absolute on the HIP side."""
   bad, summ = [], {}
+  E_all = max([r[3] for r in rows if r[5] >= GRAD_ABS_ZERO] or [0.0])
+  if rel is None:
+    rel, cos_min = max(GRAD_REL, 3.0 * E_all), (GRAD_COS if cos_min is None else cos_min)
   for net in ('G', 'Do', 'Di'):
     sel = [r for r in rows if r[0] == net]
     live = [r for r in sel if r[5] >= GRAD_ABS_ZERO]
     if not sel:
       continue
-    E_ref = max([r[3] for r in live] or [0.0])
     for r in sel:
       if r[5] < GRAD_ABS_ZERO:
         if r[2] * max(r[5], 1e-30) > GRAD_ABS_ZERO and r[4] * max(r[5], 1e-30) > GRAD_ABS_ZERO:
           bad.append(r)
         continue
-      bound = rel if rel is not None else max(GRAD_REL, 3.0 * r[3], E_ref)
-      if r[2] > bound or (cos_min is not None and r[6] < cos_min):
+      if r[2] > rel or (cos_min is not None and r[6] < cos_min):
         bad.append(r)
     if live:
       w = max(live, key=lambda r: r[2])
-      summ[net] = (w[2], w[1], E_ref, max(r[4] for r in live), min(r[6] for r in live))
+      summ[net] = (w[2], w[1], max(r[3] for r in live), max(r[4] for r in live), min(r[6] for r in live))
   return bad, summ
 
 

@@ -60,6 +60,26 @@ def test_graph_triple_conv_layer():
   _run('sec_gconv')
 
 
+def test_conv_with_fused_batchnorm_reductions():
+  """sg2im_conv2d_forward_bn / sg2im_conv2d_backward_data_bn + sg2im_bn_backward_apply: the
+  BatchNorm statistics of a conv output and the BatchNorm-backward sums of a data gradient produced by the
+  GEMM's own launches, against torch - default plans (epilogue form, split-K finish form, standalone fallback)"""
+  _run('sec_conv_bn')
+
+
+def test_conv_with_fused_batchnorm_reductions_every_tile_shape():
+  """the same with every tile shape (128x128, 128x64, 64x64, 64x128) and the split-K finish forced in turn"""
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, SG2IM_PLAN_TUNE='1')
+  out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'gpu_check.py'), 'sec_conv_bn'],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+  assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+  tail = [l for l in out.stdout.splitlines() if l.startswith('====')]
+  assert tail and ' 0 above' in tail[-1], out.stdout[-6000:]
+
+
 def test_bf16_operand_conv_kernels_match_bf16_rounded_torch():
   """compute_dtype 1 (BASELINE.json configs[2..4]): forward / data gradient / weight gradient of every
   conv geometry with both operands rounded to bf16 and fp32 accumulation, against torch's fp32

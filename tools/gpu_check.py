@@ -215,6 +215,134 @@ def sec_conv_bf16():
   conv_case_bf16('conv3x3 36->20 pad1 9x11 (ragged tiles)', 3, 9, 11, 36, 0, 0, 20, 3, 1, 1)
 
 
+class _Bn(object):
+  """parameter container with the attributes of nn.BatchNorm2d the ops read (device tensors)"""
+
+  def __init__(self, C, g):
+    self.weight = (torch.rand(C, generator=g) + 0.5).to(D)
+    self.bias = (torch.randn(C, generator=g) * 0.3).to(D)
+    self.running_mean = torch.zeros(C, device=D)
+    self.running_var = torch.ones(C, device=D)
+    self.num_batches_tracked = torch.zeros((), dtype=torch.long, device=D)
+
+
+def conv_bn_case(name, N, H, W, Cin, Cout, k, stride, pad, out_slope=1.0, live=None, unbiased_mult=1, compute=0, seed=0):
+  """sg2im_conv2d_forward_bn: conv output AND the BatchNorm statistics / folded affine / running statistics of that
+  output (the reductions ride in the conv epilogue or the split-K finish) against torch; `live`: only the first
+  `live` batch entries are real (padded row batch)."""
+  g = torch.Generator().manual_seed(seed)
+  x = torch.randn(N, Cin, H, W, generator=g) + 0.7
+  Wt = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+  b = torch.randn(Cout, generator=g) * 2.0 + 1.0           # (a large mean / std ratio: the pivot-shifted sums matter)
+  bn = _Bn(Cout, g)
+  nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(D)
+  d = ops.conv_desc([ops.nhwc_src(nhwc(x))], N, H, W, k, k, stride, pad, compute=compute)
+  Wp = Wt.permute(0, 2, 3, 1).contiguous().to(D)
+  out = torch.empty(N, d.out_h, d.out_w, Cout, device=D)
+  cnt = None
+  if live is not None:
+    cnt = (torch.tensor([live], dtype=torch.int32, device=D), d.out_h * d.out_w)
+  rows = N * d.out_h * d.out_w
+  st = ops.conv2d_forward_bn(d, Wp, Cout, b.to(D), out, Cout, bn, True, 1e-5, 0.1, out_slope=out_slope,
+                             unbiased_rows=unbiased_mult * rows if unbiased_mult != 1 else 0, count=cnt)
+  if compute == 0:
+    y = F.leaky_relu(F.conv2d(x, Wt, b, stride=stride, padding=pad), out_slope) if out_slope != 1.0 else \
+        F.conv2d(x, Wt, b, stride=stride, padding=pad)
+    report(name + ' out', out.permute(0, 3, 1, 2), y)
+  # the statistics are checked against the tensor the kernel itself wrote (exact up to summation order)
+  o = out.detach().cpu().double()[:live if live is not None else N].reshape(-1, Cout)
+  mean, var = o.mean(0), o.var(0, unbiased=False)
+  invstd = 1.0 / torch.sqrt(var + 1e-5)
+  gam, bet = bn.weight.cpu().double(), bn.bias.cpu().double()
+  report(name + ' mean', st.mean, mean)
+  report(name + ' invstd', st.invstd, invstd)
+  report(name + ' folded scale', st.scale, gam * invstd)
+  report(name + ' folded shift', st.shift, bet - mean * gam * invstd)
+  n = o.size(0) * unbiased_mult
+  report(name + ' running_mean', bn.running_mean, 0.1 * mean)
+  report(name + ' running_var', bn.running_var, 0.9 + 0.1 * var * n / (n - 1))
+  report(name + ' num_batches_tracked', bn.num_batches_tracked.float(), torch.ones(()))
+
+
+def dgrad_bn_case(name, N, h, w, C, Cout2, k, pad, pool2, slope=0.2, live=None, seed=0):
+  """sg2im_conv2d_backward_data_bn + sg2im_bn_backward_apply against torch autograd through
+  conv(upsample?(leaky(batch_norm(y)))): the data gradient w.r.t. the activated BatchNorm output, the
+  BatchNorm's dgamma / dbeta and dy."""
+  g = torch.Generator().manual_seed(seed)
+  y = torch.randn(N, C, h, w, generator=g) * 1.5 + 0.4
+  bn = _Bn(C, g)
+  f = 2 if pool2 else 1
+  H2, W2 = h * f, w * f
+  Wt = torch.randn(Cout2, C, k, k, generator=g) / (C * k * k) ** 0.5
+  nl = live if live is not None else N
+  # torch reference on the real entries only (a padded batch's dummy rows see a zero upstream gradient)
+  yr = y[:nl].clone().requires_grad_(True)
+  gam = bn.weight.cpu().clone().requires_grad_(True)
+  bet = bn.bias.cpu().clone().requires_grad_(True)
+  z = F.leaky_relu(F.batch_norm(yr, None, None, gam, bet, True, 0.1, 1e-5), slope)
+  zin = F.interpolate(z, scale_factor=2, mode='nearest') if pool2 else z
+  o2 = F.conv2d(zin, Wt, None, padding=pad)
+  gy2 = torch.randn((N,) + tuple(o2.shape[1:]), generator=g)
+  gy2[nl:] = 0
+  o2.backward(gy2[:nl])
+  nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(D)
+  yd = nhwc(y)
+  cnt = None if live is None else (torch.tensor([live], dtype=torch.int32, device=D), h * w)
+  st = ops.bn_stats(yd, N * h * w, C, C, bn, True, 1e-5, 0.1, count=cnt)
+  d2 = ops.conv_desc([ops.nhwc_src(yd, 1 if pool2 else 0, st.scale, st.shift, slope)], N, H2, W2, k, k, 1, pad)
+  Wp = Wt.permute(0, 2, 3, 1).contiguous().to(D)
+  gz = torch.empty(N, H2, W2, C, device=D)
+  dgam, dbet = torch.empty(C, device=D), torch.empty(C, device=D)
+  coef = ops.conv2d_backward_data_bn(d2, Wp, Cout2, nhwc(gy2), Cout2, 0, C, gz, C, yd, C, 1 if pool2 else 0, bn.weight, st,
+                                     slope, True, dgam, dbet, False, count=cnt)
+  dy = torch.empty(N, h, w, C, device=D)
+  ops.bn_backward_apply(HF._fptr(gz), C, 1 if pool2 else 0, N, h, w, yd, C, C, st, slope, coef, dy, count=cnt)
+  report(name + ' gz (data gradient)', gz.permute(0, 3, 1, 2)[:nl], _dgrad_ref(zin, Wt, pad, gy2[:nl]))
+  report(name + ' dgamma', dgam, gam.grad)
+  report(name + ' dbeta', dbet, bet.grad)
+  report(name + ' dy', dy.permute(0, 3, 1, 2)[:nl], yr.grad)
+  if live is not None:
+    report(name + ' dy of padding rows is zero', dy[nl:], torch.zeros_like(dy[nl:].cpu()))
+  # accumulate mode of the parameter gradients
+  ops.conv2d_backward_data_bn(d2, Wp, Cout2, nhwc(gy2), Cout2, 0, C, gz, C, yd, C, 1 if pool2 else 0, bn.weight, st,
+                              slope, True, dgam, dbet, True, count=cnt)
+  report(name + ' dgamma accumulate', dgam, 2 * gam.grad)
+
+
+def _dgrad_ref(zin, Wt, pad, gy):
+  zi = zin.detach().clone().requires_grad_(True)
+  F.conv2d(zi, Wt, None, padding=pad).backward(gy)
+  return zi.grad
+
+
+def sec_conv_bn():
+  """convolution + BatchNorm reductions in one set of launches; with SG2IM_PLAN_TUNE=1 in the environment every
+  tile shape and the split-K finish form are forced in turn (SG2IM_FORCE_PLAN is re-read per launch)"""
+  tune = os.environ.get('SG2IM_PLAN_TUNE') == '1'
+  plans = ['0,1', '1,1', '2,1', '3,1', '2,3', '0,2'] if tune else [None]
+  for pl in plans:
+    if pl is not None:
+      os.environ['SG2IM_FORCE_PLAN'] = pl
+    tag = ' [plan %s]' % pl if pl else ''
+    conv_bn_case('conv_bn 3x3 32->64 32x32' + tag, 4, 32, 32, 32, 64, 3, 1, 1)
+    conv_bn_case('conv_bn 3x3 64->192 16x16 relu' + tag, 5, 16, 16, 64, 192, 3, 1, 1, out_slope=0.0, unbiased_mult=4)
+    conv_bn_case('conv_bn 4x4s2 64->128 valid 15x15' + tag, 6, 15, 15, 64, 128, 4, 2, 0)
+    conv_bn_case('conv_bn 3x3 128->128 8x8 padded batch' + tag, 12, 8, 8, 128, 128, 3, 1, 1, out_slope=0.0, live=7, unbiased_mult=4)
+    conv_bn_case('conv_bn 3x3 64->64 16x16 bf16 operands' + tag, 8, 16, 16, 64, 64, 3, 1, 1, compute=1)
+    dgrad_bn_case('dgrad_bn 3x3 C64 <- 96 16x16' + tag, 4, 16, 16, 64, 96, 3, 1, False)
+    dgrad_bn_case('dgrad_bn 3x3 C128 <- 64 8x8 upsampled (pool2)' + tag, 4, 8, 8, 128, 64, 3, 1, True)
+    dgrad_bn_case('dgrad_bn 3x3 C128 <- 128 4x4 pool2 padded batch relu' + tag, 9, 4, 4, 128, 128, 3, 1, True, slope=0.0, live=5)
+  if tune:
+    os.environ.pop('SG2IM_FORCE_PLAN', None)
+  # shapes whose default plan takes the epilogue form (no split-K) and the finish form
+  conv_bn_case('conv_bn 3x3 64->64 64x64 batch 8 (epilogue form)', 8, 64, 64, 64, 64, 3, 1, 1)
+  conv_bn_case('conv_bn 3x3 160->1024 4x4 batch 32 (split-K finish form)', 32, 4, 4, 160, 1024, 3, 1, 1)
+  conv_bn_case('conv_bn 3x3 6->20 9x11 (scalar loaders: standalone fallback)', 3, 9, 11, 6, 20, 3, 1, 1)
+  dgrad_bn_case('dgrad_bn 3x3 C64 <- 64 64x64 batch 8 (epilogue form)', 8, 64, 64, 64, 64, 3, 1, False)
+  dgrad_bn_case('dgrad_bn 3x3 C512 <- 256 8x8 pool2 (finish form)', 8, 4, 4, 512, 256, 3, 1, True)
+  dgrad_bn_case('dgrad_bn 3x3 C6 <- 20 9x11 (scalar loaders: standalone fallback)', 3, 9, 11, 6, 20, 3, 1, False)
+
+
 def sec_conv():
   conv_case('conv3x3 64->64 16x16 (tile64)', 2, 16, 16, 64, 0, 0, 64, 3, 1, 1)
   conv_case('conv3x3 160+128up->128 16x16', 4, 16, 16, 160, 128, 1, 128, 3, 1, 1)
@@ -230,7 +358,7 @@ def sec_conv():
   conv_case('conv1x1 64->3 32x32', 2, 32, 32, 64, 0, 0, 3, 1, 1, 0)
   conv_case('conv1x1 128->1 16x16', 8, 16, 16, 128, 0, 0, 1, 1, 1, 0)
   conv_case('conv3x3 1184->512 8x8 (m1.conv0 shape)', 4, 8, 8, 160, 1024, 1, 512, 3, 1, 1)
-  # shapes that take the direct-to-LDS loop (csrc/igemm2.h): plain sources, stride 1, channels % 32 == 0
+  # plain sources, stride 1, channels % 32 == 0
   conv_case('v2 conv3x3 160+128up->64 32x32 (256x64 tile)', 16, 32, 32, 160, 128, 1, 64, 3, 1, 1)
   conv_case('v2 conv3x3 160+512up->256 16x16 (split-K)', 8, 16, 16, 160, 512, 1, 256, 3, 1, 1)
   conv_case('v2 conv3x3 96->80 19x21 (ragged rows / columns)', 5, 19, 21, 96, 0, 0, 80, 3, 1, 1)
@@ -577,7 +705,7 @@ def sec_golden_vg():
 if __name__ == '__main__':
   print(torch.cuda.get_device_name(0))
   only = sys.argv[1:]
-  for fn in (sec_pool, sec_linear, sec_conv, sec_conv_bf16, sec_gconv, sec_layout, sec_layout_align_corners, sec_losses, sec_golden_coco, sec_golden_vg, sec_golden_eval, sec_golden_nonorm, sec_golden_mlpbn, sec_golden_instnorm, sec_golden_archtokens):
+  for fn in (sec_pool, sec_linear, sec_conv, sec_conv_bn, sec_conv_bf16, sec_gconv, sec_layout, sec_layout_align_corners, sec_losses, sec_golden_coco, sec_golden_vg, sec_golden_eval, sec_golden_nonorm, sec_golden_mlpbn, sec_golden_instnorm, sec_golden_archtokens):
     if not only or fn.__name__ in only:
       section(fn)
   bad = [r for r in RESULTS if not (r[1] <= 1e-4 or (r[3] <= 1e-6 and r[4] < 1e-6))]
