@@ -6,11 +6,11 @@
 
 namespace sg2im {
 
-// partial: [nblk][3][channels] = (pivot, sum (x - pivot), sum (x - pivot)^2) of the rows [t * per, (t + 1) * per)
+// partial: [3][channels][nblk] = (pivot, sum (x - pivot), sum (x - pivot)^2) of the rows [t * per, (t + 1) * per)
 // of an output with `rows` rows -> mean / invstd / folded scale / shift (+ running statistics)
 int bn_stats_finish_tiles(const float* partial, int nblk, long long per, long long rows, int channels,
                           const sg2im_bn_fwd* a, hipStream_t stream);
-// partial: [nblk][2][channels] = (sum du, sum du * xhat) -> dgamma / dbeta / the coefficients of
+// partial: [2][channels][nblk] = (sum du, sum du * xhat) -> dgamma / dbeta / the coefficients of
 // dy = a du + k1 y + k0;  rows: rows of the normalised tensor
 int bn_bwd_finish_tiles(const float* partial, int nblk, long long rows, int channels, const sg2im_bn_bwd* a,
                         hipStream_t stream);

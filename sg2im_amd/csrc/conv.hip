@@ -1113,15 +1113,15 @@ __global__ __launch_bounds__(256) void splitk_finish_stats_kernel(const float* _
       }
     }
     if (ty == 0) {
-      constexpr int K = MODE == 1 ? 3 : 2;
-      float* dst = ss.partial + (size_t)blockIdx.x * K * N + n;
-      if (MODE == 1) {
-        *reinterpret_cast<float4*>(dst) = pv;
-        *reinterpret_cast<float4*>(dst + N) = s0;
-        *reinterpret_cast<float4*>(dst + 2 * N) = s1;
-      } else {
-        *reinterpret_cast<float4*>(dst) = s0;
-        *reinterpret_cast<float4*>(dst + N) = s1;
+      // tile partials [K][N][tiles], see igemm.h StatSink
+      const size_t plane = (size_t)N * ss.tiles;
+      float* dst = ss.partial + (size_t)n * ss.tiles + blockIdx.x;
+      const float a0[4] = {pv.x, pv.y, pv.z, pv.w}, a1[4] = {s0.x, s0.y, s0.z, s0.w}, a2[4] = {s1.x, s1.y, s1.z, s1.w};
+      #pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float* d = dst + (size_t)j * ss.tiles;
+        if (MODE == 1) { d[0] = a0[j]; d[plane] = a1[j]; d[2 * plane] = a2[j]; }
+        else { d[0] = a1[j]; d[plane] = a2[j]; }
       }
     }
   }
@@ -1629,6 +1629,7 @@ static int conv_forward_impl(const sg2im_conv_desc* d, const float* weight, int 
   const bool st_ok = g_fuse_bn && bn_train && v4 && !any_gather(p.g) && !accumulate && bn->partial && al16p(bn->partial);
   if (st_ok && pl.nsplit == 1 && (size_t)((p.M + pl.bm - 1) / pl.bm) * 3 * cout <= bn->partial_floats) {
     p.st.partial = bn->partial; p.st.count = bn->count; p.st.unit = bn->count_unit;
+    p.st.tiles = (p.M + pl.bm - 1) / pl.bm;
     const bool hb = d->compute_dtype == 1;
 #define SG2IM_ST(BM_, BN_) (hb ? launch_fwd_st<BM_, BN_, true>(p, stream) : launch_fwd_st<BM_, BN_, false>(p, stream))
     err = pl.tile == 0 ? SG2IM_ST(128, 128) : pl.tile == 1 ? SG2IM_ST(128, 64) : pl.tile == 2 ? SG2IM_ST(64, 64) : SG2IM_ST(64, 128);
@@ -1651,7 +1652,7 @@ static int conv_forward_impl(const sg2im_conv_desc* d, const float* weight, int 
     finish_stats_grid(p.M, cout, 3, bn->partial_floats, &nblk, &per, &nslab);
     if ((size_t)nblk * 3 * cout <= bn->partial_floats) {
       StatSink ss{};
-      ss.partial = bn->partial; ss.count = bn->count; ss.unit = bn->count_unit;
+      ss.partial = bn->partial; ss.count = bn->count; ss.unit = bn->count_unit; ss.tiles = nblk;
       hipLaunchKernelGGL(splitk_finish_stats_kernel<1>, dim3(nblk, nslab), dim3(256), 0, stream, workspace, pl.nsplit, (long long)p.M,
                          cout, out, ld_out, bias, out_slope, per, ss);
       if (hipGetLastError() != hipSuccess) return SG2IM_ERR_HIP;
@@ -1759,6 +1760,7 @@ static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int co
   }
   if (st_ok && pl.nsplit == 1 && (size_t)((Mfull + pl.bm - 1) / pl.bm) * 2 * c_count <= bb->partial_floats) {
     p.st = ss;
+    p.st.tiles = (int)((Mfull + pl.bm - 1) / pl.bm);
     const bool hb = d->compute_dtype == 1;
 #define SG2IM_ST(BM_, BN_) (hb ? launch_dgrad_st<BM_, BN_, true>(p, stream) : launch_dgrad_st<BM_, BN_, false>(p, stream))
     err = pl.tile == 0 ? SG2IM_ST(128, 128) : pl.tile == 1 ? SG2IM_ST(128, 64) : pl.tile == 2 ? SG2IM_ST(64, 64) : SG2IM_ST(64, 128);
@@ -1790,6 +1792,7 @@ static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int co
     int nblk, nslab; long long per;
     finish_stats_grid(Mfull, c_count, 2, bb->partial_floats, &nblk, &per, &nslab);
     if ((size_t)nblk * 2 * c_count <= bb->partial_floats) {
+      ss.tiles = nblk;
       hipLaunchKernelGGL(splitk_finish_stats_kernel<2>, dim3(nblk, nslab), dim3(256), 0, stream, workspace, pl.nsplit, Mfull, c_count,
                          dx, ld_dx, (const float*)nullptr, 1.f, per, ss);
       if (hipGetLastError() != hipSuccess) return SG2IM_ERR_HIP;

@@ -244,12 +244,14 @@ __device__ __forceinline__ void epilogue(const Epi& e, int M, int N, int nlimit,
 // BatchNorm reductions in the GEMM epilogue (sg2im_conv2d_forward_bn / sg2im_conv2d_backward_data_bn):
 // the workgroup that owns a BM x BN output tile also owns BM rows of BN per-channel sums.  Per column the
 // partial sums of the tile's 2 (wave rows) x 2 (lane halves) row groups are combined through LDS in a
-// fixed order and written to tile partials [tile][K][N], which a one-launch finish (norm.hip) reduces in
-// double - the same two-stage, atomics-free scheme as the standalone statistics kernels, minus their pass
-// over the tensor.  `lds` is the operand image (free after the main loop), >= 9 * BN floats.
+// fixed order and written to tile partials [K][N][tiles] (the tile index fastest: the finish reads a channel's
+// partials as one contiguous run), which a one-launch finish (norm.hip) reduces in double - the same two-stage,
+// atomics-free scheme as the standalone statistics kernels, minus their pass over the tensor.  `lds` is the
+// operand image (free after the main loop), >= 9 * BN floats.
 // ---------------------------------------------------------------------------
 struct StatSink {
-  float* partial;          // [tiles][3][N] (forward: pivot, sum d, sum d^2) or [tiles][2][N] (backward: sum du, sum du*xhat)
+  float* partial;          // [3][N][tiles] (forward: pivot, sum d, sum d^2) or [2][N][tiles] (backward: sum du, sum du*xhat)
+  int tiles;               // row tiles of the launch = the stride between two channels' partials
   const int* count;        // optional: only the first count[0] * unit rows are real (padded row batches)
   int unit;
   // backward only: the normalised layer's pre-BN output and its statistics
@@ -313,8 +315,9 @@ __device__ __forceinline__ void epilogue_stats(const Epi& e, const StatSink& ss,
     if (n >= N) continue;
     const float s0 = ((red[col] + red[BN + col]) + red[2 * BN + col]) + red[3 * BN + col];
     const float s1 = ((red[4 * BN + col] + red[5 * BN + col]) + red[6 * BN + col]) + red[7 * BN + col];
-    float* dst = ss.partial + (size_t)tile * 3 * N + n;
-    dst[0] = piv[col]; dst[N] = s0; dst[2 * N] = s1;
+    float* dst = ss.partial + (size_t)n * ss.tiles + tile;
+    const size_t plane = (size_t)N * ss.tiles;
+    dst[0] = piv[col]; dst[plane] = s0; dst[2 * plane] = s1;
   }
 }
 
@@ -378,8 +381,8 @@ __device__ __forceinline__ void epilogue_bnbwd(const StatSink& ss, int M, int N,
     if (n >= N) continue;
     const float a = ((red[col] + red[BN + col]) + red[2 * BN + col]) + red[3 * BN + col];
     const float b = ((red[4 * BN + col] + red[5 * BN + col]) + red[6 * BN + col]) + red[7 * BN + col];
-    float* dst = ss.partial + (size_t)tile * 2 * N + n;
-    dst[0] = a; dst[N] = b;
+    float* dst = ss.partial + (size_t)n * ss.tiles + tile;
+    dst[0] = a; dst[(size_t)N * ss.tiles] = b;
   }
 }
 

@@ -136,7 +136,8 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ x, const float* 
 }
 
 // Finish of statistics whose tile partials came out of a GEMM epilogue / split-K finish (conv.hip): tile t
-// covers the rows [t * per, (t + 1) * per) and holds (its own pivot p_t, sum d, sum d^2) with d = x - p_t.
+// covers the rows [t * per, (t + 1) * per) and holds (its own pivot p_t, sum d, sum d^2) with d = x - p_t,
+// stored [3][C][nblk] (a channel's partials are one contiguous run: coalesced reads).
 // Per tile: mean_t = p_t + s_t / n_t, M2_t = q_t - s_t^2 / n_t; combined in double relative to tile 0's pivot
 // (Chan et al.): one wavefront per channel, lanes stride over the tiles, xor-tree at the end (fixed order).
 __global__ void bn_stats_final_tiles_kernel(const float* __restrict__ partial, int nblk, long long per, long long rows,
@@ -153,15 +154,16 @@ __global__ void bn_stats_final_tiles_kernel(const float* __restrict__ partial, i
   long long live = live_rows(rows, count, unit);
   if (count && unbiased_rows > 0) unbiased_rows = unbiased_rows / rows * live;   // (a whole multiple of rows)
   if (c >= C) return;
-  const double P = (double)partial[c];                  // tile 0's pivot
+  const size_t plane = (size_t)C * nblk;
+  const float* __restrict__ q = partial + (size_t)c * nblk;
+  const double P = (double)q[0];                        // tile 0's pivot
   double sn = 0.0, sm = 0.0, sq = 0.0;
   for (int t = lane; t < nblk; t += 64) {
     long long nt = live - (long long)t * per;
-    if (nt <= 0) continue;
+    if (nt <= 0) break;
     if (nt > per) nt = per;
-    const float* q = partial + (long long)t * 3 * C + c;
-    const double n = (double)nt, s = (double)q[C], ss = (double)q[2 * C];
-    const double mt = ((double)q[0] - P) + s / n;
+    const double n = (double)nt, s = (double)q[plane + t], ss = (double)q[2 * plane + t];
+    const double mt = ((double)q[t] - P) + s / n;
     double m2 = ss - s * s / n;
     if (m2 < 0.0) m2 = 0.0;
     sn += n; sm += n * mt; sq += m2 + n * mt * mt;
@@ -225,6 +227,36 @@ __global__ void bn_bwd_final_kernel(const float* __restrict__ partial, int nblk,
   double s, sx;
   wave_partial_sums(partial, nblk, C, c, s, sx);
   if ((threadIdx.x & 63) != 0) return;
+  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sx;
+  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
+  const double g = gamma ? gamma[c] : 1.0, is = invstd[c], mu = mean[c];
+  const double a = g * is;
+  double k1 = 0.0, k0 = 0.0;
+  if (training) {
+    const double M = (double)rows;
+    k1 = -a * sx * is / M;
+    k0 = -a * s / M - k1 * mu;
+  }
+  coef[c] = (float)a; coef[C + c] = (float)k1; coef[2 * C + c] = (float)k0;
+}
+
+// the same finish for tile partials [2][C][nblk] out of a data-gradient epilogue / split-K finish (conv.hip)
+__global__ void bn_bwd_final_tiles_kernel(const float* __restrict__ partial, int nblk, long long rows, int C,
+                                          const float* __restrict__ gamma, const float* __restrict__ mean,
+                                          const float* __restrict__ invstd, int training, float* __restrict__ dgamma,
+                                          float* __restrict__ dbeta, int accumulate, float* __restrict__ coef,
+                                          const int* __restrict__ count, int unit) {
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);     // one wavefront per channel
+  if (c >= C) return;
+  if (count) { rows = live_rows(rows, count, unit); if (rows < 1) rows = 1; }
+  const int lane = threadIdx.x & 63;
+  const float* __restrict__ q = partial + (size_t)c * nblk;
+  const size_t plane = (size_t)C * nblk;
+  double s = 0.0, sx = 0.0;
+  for (int t = lane; t < nblk; t += 64) { s += (double)q[t]; sx += (double)q[plane + t]; }
+  #pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); sx += __shfl_xor(sx, off); }
+  if (lane != 0) return;
   if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sx;
   if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
   const double g = gamma ? gamma[c] : 1.0, is = invstd[c], mu = mean[c];
@@ -776,7 +808,7 @@ int bn_stats_finish_tiles(const float* partial, int nblk, long long per, long lo
 
 int bn_bwd_finish_tiles(const float* partial, int nblk, long long rows, int channels, const sg2im_bn_bwd* a,
                         hipStream_t stream) {
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((channels + 3) / 4), dim3(256), 0, stream, partial, nblk, rows, channels,
+  hipLaunchKernelGGL(bn_bwd_final_tiles_kernel, dim3((channels + 3) / 4), dim3(256), 0, stream, partial, nblk, rows, channels,
                      a->gamma, a->mean, a->invstd, a->training, a->dgamma, a->dbeta, a->accumulate, a->coef, a->count,
                      a->count_unit);
   return ok_or(hipGetLastError());
@@ -799,7 +831,10 @@ int bn_bwd_standalone(const float* g, long long ld_g, int pool2, int batch, int 
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk), dim3(256), 2 * 256 * sizeof(float), stream, gs, a->y, a->ld_y, rows,
                        channels, a->mean, a->invstd, a->scale, a->shift, a->slope, a->partial, a->count, a->count_unit);
   if (hipGetLastError() != hipSuccess) return SG2IM_ERR_HIP;
-  return bn_bwd_finish_tiles(a->partial, nblk, rows, channels, a, stream);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((channels + 3) / 4), dim3(256), 0, stream, a->partial, nblk, rows, channels,
+                     a->gamma, a->mean, a->invstd, a->training, a->dgamma, a->dbeta, a->accumulate, a->coef, a->count,
+                     a->count_unit);
+  return ok_or(hipGetLastError());
 }
 
 }  // namespace sg2im

@@ -478,13 +478,16 @@ class LayoutFn(Function):
   returns the NHWC tensor (N, H, W, D + noise_dim) the refinement network consumes."""
 
   @staticmethod
-  def forward(ctx, vecs, boxes, masks, obj_to_img, noise, n_images, H, W, align_corners):
+  def forward(ctx, vecs, boxes, masks, obj_to_img, noise, n_images, H, W, align_corners, img_csr=None):
+    """img_csr: the per-image object lists (ops.Csr(obj_to_img, None, n_images)) when the caller built them
+    already (Sg2ImModel does, off the critical path)"""
     D = vecs.size(1)
     nd = noise.size(1) if noise is not None else 0
     if vecs.stride(1) != 1:
       vecs = vecs.contiguous()
     boxes = boxes.contiguous()
-    img_csr = ops.Csr(obj_to_img, None, n_images)
+    if img_csr is None:
+      img_csr = ops.Csr(obj_to_img, None, n_images)
     out = _new(vecs, n_images, H, W, D + nd)
     ops.layout_forward(vecs, boxes, masks, img_csr, n_images, H, W, align_corners, out)
     if nd > 0:
@@ -507,7 +510,7 @@ class LayoutFn(Function):
     if d_vecs is not None or d_masks is not None or d_boxes is not None:
       ops.layout_backward(g, vecs, boxes, masks, obj_to_img, ctx.img_csr, n_images, H, W, ac, d_vecs, d_masks,
                           d_boxes)
-    return d_vecs, d_boxes, d_masks, None, None, None, None, None, None
+    return d_vecs, d_boxes, d_masks, None, None, None, None, None, None, None
 
 
 class CropFn(Function):

@@ -75,13 +75,21 @@ class Sg2ImModel(nn.Module):
     return HF.MaskNetFn.apply(obj_vecs, bns, self.training, obj_count, *params)
 
   def forward_nhwc(self, objs, triples, obj_to_img=None, boxes_gt=None, masks_gt=None, num_images=None,
-                   obj_count=None, triple_count=None):
+                   obj_count=None, triple_count=None, aux_stream=None, detach_masks=False, detach_rel=False):
     """Same computation as ``forward`` (reference sg2im/model.py:108-171) but the image
     is returned NHWC, the internal layout of the kernels.  ``num_images`` avoids the host
     sync of reference sg2im/layout.py:143 (N = obj_to_img.max()+1).  ``obj_count``: (int32 device
     scalar, 1) when the object / triple axes are padded to a bucket size (sg2im_amd/bucketing.py):
     the batch statistics of mask_net - and of the MLPs' BatchNorm1d layers under mlp_normalization='batch' -
-    then only see the real objects / triples."""
+    then only see the real objects / triples.
+
+    ``aux_stream`` (the Trainer passes its side stream while it captures the iteration): everything that is NOT
+    on the path embeddings -> graph convolutions -> layout -> refinement network runs there, next to that path
+    instead of in front of it: the layout noise and the per-image object lists (need only the inputs), and -
+    when the caller does not back-propagate through them (``detach_masks``: ground-truth masks are laid out and
+    the mask loss is off, as in the reference's COCO configuration; ``detach_rel``: the predicate loss is off) -
+    mask_net and rel_aux_net, whose outputs are then returned detached.  [mask_net is 0.37 ms of the 0.9 ms the
+    refinement network used to wait for at the head of every step.]"""
     O = objs.size(0)
     s = triples[:, 0].contiguous()
     p = triples[:, 1].contiguous()
@@ -89,6 +97,17 @@ class Sg2ImModel(nn.Module):
     if obj_to_img is None:
       obj_to_img = torch.zeros(O, dtype=objs.dtype, device=objs.device)
       num_images = 1
+    H, W = self.image_size
+    main = torch.cuda.current_stream() if aux_stream is not None else None
+    noise = img_csr = ev_pre = None
+    if aux_stream is not None and num_images is not None:
+      aux_stream.wait_stream(main)
+      with torch.cuda.stream(aux_stream):
+        if self.layout_noise_dim > 0:                           # reference sg2im/model.py:164-168
+          noise = torch.randn((num_images, self.layout_noise_dim, H, W), dtype=torch.float32, device=objs.device)
+        img_csr = ops.Csr(obj_to_img, None, num_images)
+        ev_pre = torch.cuda.Event()
+        ev_pre.record(aux_stream)
     # (padded batch: the padding triples stay out of the pooling CSR - no long tail row on the dummy object)
     edges = (s, o, ops.Csr(s, o, O, live=triple_count))
 
@@ -102,13 +121,24 @@ class Sg2ImModel(nn.Module):
     if self.gconv_net is not None:
       obj_vecs, pred_vecs = self.gconv_net(obj_vecs, pred_vecs, edges, (obj_count, triple_count))
 
+    masks_pred = rel_scores = None
+    on_aux = aux_stream is not None and ((self.mask_net is not None and detach_masks) or detach_rel)
+    if on_aux:
+      aux_stream.wait_stream(main)
+    if on_aux and self.mask_net is not None and detach_masks:
+      with torch.cuda.stream(aux_stream), torch.no_grad():
+        masks_pred = self._run_mask_net(obj_vecs.detach(), obj_count)
     boxes_pred = self.box_net(obj_vecs, obj_count)
-    masks_pred = None
-    if self.mask_net is not None:
+    if self.mask_net is not None and masks_pred is None:
       masks_pred = self._run_mask_net(obj_vecs, obj_count)
 
     r1, r2 = self.rel_aux_net.linears()
-    if self.rel_aux_net.norms():       # mlp_normalization='batch'
+    if on_aux and detach_rel and not self.rel_aux_net.norms():
+      aux_stream.wait_stream(main)               # (boxes_pred)
+      with torch.cuda.stream(aux_stream), torch.no_grad():
+        rel_scores = HF.RelAux.apply(boxes_pred.detach(), obj_vecs_orig.detach(), s, o, edges[2], r1.weight, r1.bias,
+                                     r2.weight, r2.bias)
+    elif self.rel_aux_net.norms():       # mlp_normalization='batch'
       h = self.rel_aux_net.tail(HF.RelAuxLinear.apply(boxes_pred, obj_vecs_orig, s, o, edges[2], r1.weight,
                                                       r1.bias, self.training), 0, triple_count)
       rel_scores = self.rel_aux_net.tail(HF.LinearAct.apply(h, r2.weight, r2.bias, 1.0, self.training), 1,
@@ -116,21 +146,23 @@ class Sg2ImModel(nn.Module):
     else:
       rel_scores = HF.RelAux.apply(boxes_pred, obj_vecs_orig, s, o, edges[2], r1.weight, r1.bias, r2.weight, r2.bias)
 
-    H, W = self.image_size
     layout_boxes = boxes_pred if boxes_gt is None else boxes_gt
     layout_masks = None
     if masks_pred is not None:
       layout_masks = masks_pred if masks_gt is None else masks_gt
     if num_images is None:
       num_images = int(obj_to_img.max().item()) + 1          # reference sg2im/layout.py:143
-    noise = None
-    if self.layout_noise_dim > 0:                             # reference sg2im/model.py:164-168
+    if ev_pre is not None:
+      main.wait_event(ev_pre)                                 # (noise + per-image object lists of the aux stream)
+    elif self.layout_noise_dim > 0:                           # reference sg2im/model.py:164-168
       noise = torch.randn((num_images, self.layout_noise_dim, H, W), dtype=obj_vecs.dtype,
                           device=obj_vecs.device)
     layout = layout_nhwc(obj_vecs, layout_boxes, layout_masks, obj_to_img, H, W, noise=noise,
-                         n_images=num_images, align_corners=self.align_corners)
+                         n_images=num_images, align_corners=self.align_corners, img_csr=img_csr)
     # the appended noise channels need no gradient: only the first D layout channels do
     img = self.refinement_net.forward_nhwc(layout, layout_grad_channels=obj_vecs.size(1))
+    if aux_stream is not None:
+      main.wait_stream(aux_stream)                            # (the detached outputs; long finished by now)
     return img, boxes_pred, masks_pred, rel_scores
 
   def forward(self, objs, triples, obj_to_img=None, boxes_gt=None, masks_gt=None, num_images=None):

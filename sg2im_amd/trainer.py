@@ -166,9 +166,15 @@ class Trainer(object):
     """train.py:524-530: the generator itself; `imgs_fake` is all the discriminator steps need"""
     imgs, objs, boxes, masks, triples, obj_to_img = batch[:6]
     st['imgs_nhwc'] = HF.NchwToNhwc.apply(imgs)
+    # captured iteration: whatever is not on the path to the image leaves the critical path (Sg2ImModel.forward_nhwc)
+    aux = self._side[0] if (self._side is not None and torch.cuda.is_current_stream_capturing() and
+                            os.environ.get('SG2IM_AUX', '1') != '0') else None      # (A/B knob)
+    w = self.w
     st['gen_out'] = self.model.forward_nhwc(objs, triples, obj_to_img, boxes_gt=boxes, masks_gt=masks,
                                             num_images=imgs.size(0), obj_count=st.get('ocnt'),
-                                            triple_count=st.get('tcnt'))
+                                            triple_count=st.get('tcnt'), aux_stream=aux,
+                                            detach_masks=masks is not None and not w['mask_loss_weight'] > 0,
+                                            detach_rel=not w['predicate_pred_loss_weight'] > 0)
     st['imgs_fake'] = st['gen_out'][0].detach()
 
   def _seg_generator_losses(self, batch, st):
