@@ -1206,6 +1206,10 @@ __global__ void splitk_finish_parity_kernel(const float* __restrict__ ws, int ns
   }
 }
 
+}  // namespace sg2im
+#include "conv_halo.h"
+namespace sg2im {
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -1549,6 +1553,54 @@ static void finish_stats_grid(long long M, int N, int K, size_t partial_floats, 
 
 static bool al16p(const void* q) { return ((uintptr_t)q & 15) == 0; }
 
+// ---- halo'd-tile kernels (conv_halo.h): 3x3 / stride 1 / pad 1, float4 loaders, fp32 ----
+// A/B knob: 0 = every convolution on the first-generation per-tap kernels
+static const bool g_halo = !(getenv("SG2IM_HALO") && atoi(getenv("SG2IM_HALO")) == 0);
+struct HaloPlan { int rt, ct, bn, nsplit, patches; };
+
+static bool halo_geometry(const sg2im_conv_desc* d) {
+  return g_halo && d->compute_dtype == 0 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 &&
+         d->in_h < 32768 && d->in_w < 32768;
+}
+
+// patch shape for an H x W map, N-tile width and split-K (over whole 32-channel chunks) for `ncols` output columns
+static bool halo_plan(int NB, int H, int W, int ncols, int nchunks, size_t ws_bytes, bool can_split, HaloPlan* pl) {
+  if (W % 64 == 0 && H % 2 == 0) { pl->rt = 2; pl->ct = 64; }
+  else if (W % 32 == 0 && H % 4 == 0) { pl->rt = 4; pl->ct = 32; }
+  else if (W % 16 == 0 && H % 8 == 0) { pl->rt = 8; pl->ct = 16; }
+  else return false;
+  const long long M = (long long)NB * H * W;
+  pl->patches = (int)(M / 128);
+  if (pl->patches < 1 || ncols < 32 || nchunks < 1) return false;
+  pl->bn = (ncols > 64 && (long long)pl->patches * ((ncols + 127) / 128) >= 2 * g_num_cu) ? 128 : 64;
+  const long long blocks = (long long)pl->patches * ((ncols + pl->bn - 1) / pl->bn);
+  int ns = 1;
+  if (can_split && blocks < (3 * g_num_cu) / 2) {
+    ns = (int)std::min<long long>(nchunks, (2 * g_num_cu + blocks - 1) / blocks);
+    ns = (int)std::min<long long>(ns, std::max<long long>(1, (long long)(ws_bytes / sizeof(float)) / (M * ncols)));
+    const int per = (nchunks + ns - 1) / ns;
+    ns = (nchunks + per - 1) / per;
+  }
+  pl->nsplit = std::max(1, ns);
+  return true;
+}
+
+template <int RT, int CT, int BN, bool DG, bool ST>
+static hipError_t launch_halo_t(HaloParams& p, const HaloPlan& pl, hipStream_t st) {
+  constexpr size_t lds = halo_lds<RT, CT, BN, DG>();
+  dim3 grid((p.N + BN - 1) / BN, pl.patches, pl.nsplit);
+  hipLaunchKernelGGL((conv_halo_kernel<RT, CT, BN, DG, ST>), grid, dim3(NTHREADS), lds, st, p);
+  return hipGetLastError();
+}
+template <bool DG, bool ST>
+static hipError_t launch_halo(HaloParams& p, const HaloPlan& pl, hipStream_t st) {
+#define SG2IM_HALO_CASE(RT_, CT_) \
+  if (pl.ct == CT_) return pl.bn == 128 ? launch_halo_t<RT_, CT_, 128, DG, ST>(p, pl, st) : launch_halo_t<RT_, CT_, 64, DG, ST>(p, pl, st)
+  SG2IM_HALO_CASE(2, 64); SG2IM_HALO_CASE(4, 32); SG2IM_HALO_CASE(8, 16);
+#undef SG2IM_HALO_CASE
+  return hipErrorInvalidValue;
+}
+
 __global__ void init_probe_kernel(int* flag) { if (flag) flag[0] = 1; }
 
 }  // namespace sg2im
@@ -1619,14 +1671,33 @@ static int conv_forward_impl(const sg2im_conv_desc* d, const float* weight, int 
     p.nch = 0;
     p.iters = (taps * p.g.Ctot + BK - 1) / BK;
   }
-  const Plan pl = make_plan(PASS_FWD, p.M, cout, p.iters, (long long)p.M * cout, workspace_bytes, workspace != nullptr, 4, !v4,
-                            [&](int bn) { return (long long)(cout + bn - 1) / bn; });
-  p.e = Epi{out, ld_out, bias, out_slope, accumulate, workspace, pl.nsplit};
-  hipError_t err;
   // BatchNorm statistics of the output from the same launches: in the conv epilogue (no split-K) or in the
   // split-K finish; anything that does not qualify runs the standalone statistics pass afterwards
   const bool bn_train = bn && bn->training;
   const bool st_ok = g_fuse_bn && bn_train && v4 && !any_gather(p.g) && !accumulate && bn->partial && al16p(bn->partial);
+  hipError_t err;
+  HaloPlan hp;
+  int nsplit = 0;
+  if (v4 && !any_gather(p.g) && !accumulate && halo_geometry(d) && p.g.Wtap % 4 == 0 &&
+      halo_plan(d->batch, d->in_h, d->in_w, cout, p.nch, workspace_bytes, workspace != nullptr, &hp)) {
+    HaloParams q;
+    q.g = p.g; q.Wt = weight; q.N = cout; q.c_begin = 0; q.nchunks = p.nch;
+    q.tiles_x = d->in_w / hp.ct; q.tiles_y = d->in_h / hp.rt; q.M = p.M;
+    q.e = Epi{out, ld_out, bias, out_slope, 0, workspace, hp.nsplit};
+    q.st = StatSink{};
+    p.e = q.e;
+    nsplit = hp.nsplit;
+    if (st_ok && !bn->count && hp.nsplit == 1 && (size_t)hp.patches * 3 * cout <= bn->partial_floats) {
+      q.st.partial = bn->partial; q.st.tiles = hp.patches;
+      if (launch_halo<false, true>(q, hp, stream) != hipSuccess) return SG2IM_ERR_HIP;
+      return bn_stats_finish_tiles(bn->partial, hp.patches, 128, p.M, cout, bn, stream);
+    }
+    err = launch_halo<false, false>(q, hp, stream);
+  } else {
+  const Plan pl = make_plan(PASS_FWD, p.M, cout, p.iters, (long long)p.M * cout, workspace_bytes, workspace != nullptr, 4, !v4,
+                            [&](int bn) { return (long long)(cout + bn - 1) / bn; });
+  p.e = Epi{out, ld_out, bias, out_slope, accumulate, workspace, pl.nsplit};
+  nsplit = pl.nsplit;
   if (st_ok && pl.nsplit == 1 && (size_t)((p.M + pl.bm - 1) / pl.bm) * 3 * cout <= bn->partial_floats) {
     p.st.partial = bn->partial; p.st.count = bn->count; p.st.unit = bn->count_unit;
     p.st.tiles = (p.M + pl.bm - 1) / pl.bm;
@@ -1646,14 +1717,15 @@ static int conv_forward_impl(const sg2im_conv_desc* d, const float* weight, int 
   } else {
     err = launch_fwd<64, 64, 1>(p, stream);
   }
+  }
   if (err != hipSuccess) return SG2IM_ERR_HIP;
-  if (st_ok && pl.nsplit > 1 && cout % 4 == 0 && ld_out % 4 == 0 && al16p(out) && al16p(workspace) && (!bias || al16p(bias))) {
+  if (st_ok && nsplit > 1 && cout % 4 == 0 && ld_out % 4 == 0 && al16p(out) && al16p(workspace) && (!bias || al16p(bias))) {
     int nblk, nslab; long long per;
     finish_stats_grid(p.M, cout, 3, bn->partial_floats, &nblk, &per, &nslab);
     if ((size_t)nblk * 3 * cout <= bn->partial_floats) {
       StatSink ss{};
       ss.partial = bn->partial; ss.count = bn->count; ss.unit = bn->count_unit; ss.tiles = nblk;
-      hipLaunchKernelGGL(splitk_finish_stats_kernel<1>, dim3(nblk, nslab), dim3(256), 0, stream, workspace, pl.nsplit, (long long)p.M,
+      hipLaunchKernelGGL(splitk_finish_stats_kernel<1>, dim3(nblk, nslab), dim3(256), 0, stream, workspace, nsplit, (long long)p.M,
                          cout, out, ld_out, bias, out_slope, per, ss);
       if (hipGetLastError() != hipSuccess) return SG2IM_ERR_HIP;
       return bn_stats_finish_tiles(bn->partial, nblk, per, p.M, cout, bn, stream);
@@ -1722,6 +1794,44 @@ static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int co
   }
   const bool va4 = (cout % 4 == 0) && (ld_dy % 4 == 0) && !((uintptr_t)dy & 15);
   const bool vb4 = (g.Ctot % 4 == 0) && (c_begin % 4 == 0) && (c_count % 4 == 0) && !((uintptr_t)weight & 15);
+  // 3x3 / stride 1 / pad 1: the halo'd-tile kernel (conv_halo.h)
+  HaloPlan hp;
+  if (va4 && vb4 && !accumulate && halo_geometry(d) && g.Wtap % 4 == 0 &&
+      halo_plan(d->batch, d->in_h, d->in_w, c_count, (cout + BK - 1) / BK, workspace_bytes, workspace != nullptr, &hp)) {
+    HaloParams q;
+    q.g = g; q.Wt = weight; q.N = c_count; q.c_begin = c_begin; q.nchunks = (cout + BK - 1) / BK;
+    q.tiles_x = d->in_w / hp.ct; q.tiles_y = d->in_h / hp.rt; q.M = (int)Mfull;
+    q.e = Epi{dx, ld_dx, nullptr, 1.f, 0, workspace, hp.nsplit};
+    q.st = StatSink{};
+    const long long bn_rows_h = bb ? (bb->pool2 ? Mfull / 4 : Mfull) : 0;
+    const bool st_h = g_fuse_bn && bb && !bb->count && bb->partial && al16p(bb->partial) &&
+                      (!bb->pool2 || (d->in_h % 2 == 0 && d->in_w % 2 == 0));
+    StatSink ss{};
+    if (st_h) {
+      ss.partial = bb->partial; ss.y = bb->y; ss.ld_y = bb->ld_y; ss.mean = bb->mean; ss.invstd = bb->invstd;
+      ss.scale = bb->scale; ss.shift = bb->shift; ss.slope = bb->slope; ss.pool2 = bb->pool2; ss.H = d->in_h; ss.W = d->in_w;
+    }
+    if (st_h && hp.nsplit == 1 && (size_t)hp.patches * 2 * c_count <= bb->partial_floats) {
+      q.st = ss; q.st.tiles = hp.patches;
+      if (launch_halo<true, true>(q, hp, stream) != hipSuccess) return SG2IM_ERR_HIP;
+      return bn_bwd_finish_tiles(bb->partial, hp.patches, bn_rows_h, c_count, bb, stream);
+    }
+    if (launch_halo<true, false>(q, hp, stream) != hipSuccess) return SG2IM_ERR_HIP;
+    if (st_h && hp.nsplit > 1 && ld_dx % 4 == 0 && al16p(dx) && al16p(workspace) && bb->ld_y % 4 == 0 && al16p(bb->y) &&
+        al16p(bb->mean) && al16p(bb->invstd) && al16p(bb->scale) && al16p(bb->shift)) {
+      int nblk, nslab; long long per;
+      finish_stats_grid(Mfull, c_count, 2, bb->partial_floats, &nblk, &per, &nslab);
+      if ((size_t)nblk * 2 * c_count <= bb->partial_floats) {
+        ss.tiles = nblk;
+        hipLaunchKernelGGL(splitk_finish_stats_kernel<2>, dim3(nblk, nslab), dim3(256), 0, stream, workspace, hp.nsplit, Mfull,
+                           c_count, dx, ld_dx, (const float*)nullptr, 1.f, per, ss);
+        if (hipGetLastError() != hipSuccess) return SG2IM_ERR_HIP;
+        return bn_bwd_finish_tiles(bb->partial, nblk, bn_rows_h, c_count, bb, stream);
+      }
+    }
+    if (finish_split(q.e, Mfull, c_count, stream) != hipSuccess) return SG2IM_ERR_HIP;
+    return bn_after();
+  }
   // stride-2 parity decomposition: needs the chunked (VA=4) K enumeration; split-K partials of
   // this form are laid out per class and finished by splitk_finish_parity_kernel
   p.parity = (d->stride == 2 && va4 && d->kh >= 2 && d->kw >= 2) ? 1 : 0;

@@ -207,8 +207,9 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ As, const fl
 struct IdentityRow { __device__ __forceinline__ long long operator()(int m) const { return m; } };
 
 // `rowmap` turns a tile-local GEMM row into the destination row (identity except for the
-// stride-2 parity classes of the data gradient); split-K partials are not remapped.
-template <int BM, int BN, typename RowMap = IdentityRow>
+// stride-2 parity classes of the data gradient and the 2-D pixel patches of conv_halo.h); split-K
+// partials are only remapped with WSMAP (patches: [split][M][N] over the destination rows).
+template <int BM, int BN, typename RowMap = IdentityRow, bool WSMAP = false>
 __device__ __forceinline__ void epilogue(const Epi& e, int M, int N, int nlimit, int m0, int n0, int wm0,
                                          int wn0, int lane, int split,
                                          const f32x16 (&acc)[BM / 64][BN / 64], RowMap rowmap = RowMap()) {
@@ -228,7 +229,8 @@ __device__ __forceinline__ void epilogue(const Epi& e, int M, int N, int nlimit,
         if (m >= M) continue;
         float v = acc[tm][tn][r];
         if (e.nsplit > 1) {
-          e.ws[((long long)split * M + m) * N + n] = v;
+          const long long mw = WSMAP ? (long long)rowmap(m) : (long long)m;
+          e.ws[((long long)split * M + mw) * N + n] = v;
         } else {
           v = leaky(v + bv, e.slope);
           float* dst = e.C + rowmap(m) * e.ldc + ncol;
@@ -326,10 +328,11 @@ __device__ __forceinline__ void epilogue_stats(const Epi& e, const StatSink& ss,
 //   sum du  and  sum du * (y - mean) * invstd   per channel - what sg2im_bn_act_backward's first pass computes.
 // pool2: the rows are at twice y's resolution (nearest-upsample backward): by linearity the sums of the 2x2-pooled
 // gradient equal the sums over the fine pixels with y read at the coarse pixel.
-template <int BM, int BN>
+// rowmap: tile-local row -> row of the launch's result tensor (identity, or a conv_halo.h pixel patch)
+template <int BM, int BN, typename RowMap = IdentityRow>
 __device__ __forceinline__ void epilogue_bnbwd(const StatSink& ss, int M, int N, int m0, int n0, int wm0, int wn0,
                                                int lane, int tid, int tile,
-                                               const f32x16 (&acc)[BM / 64][BN / 64], float* lds) {
+                                               const f32x16 (&acc)[BM / 64][BN / 64], float* lds, RowMap rowmap = RowMap()) {
   constexpr int TM = BM / 64, TN = BN / 64;
   const int j = lane & 31, h = lane >> 5;
   const int wave_m = wm0 / (BM / 2);
@@ -351,9 +354,10 @@ __device__ __forceinline__ void epilogue_bnbwd(const StatSink& ss, int M, int N,
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       if (m >= Mlive) continue;
-      long long row = m;
+      long long row = rowmap(m);
       if (ss.pool2) {
-        const int nb = m / HW, rem = m - nb * HW;
+        const int mg = (int)row;
+        const int nb = mg / HW, rem = mg - nb * HW;
         const int hi = rem / ss.W, wi = rem - hi * ss.W;
         row = ((long long)nb * (ss.H >> 1) + (hi >> 1)) * (ss.W >> 1) + (wi >> 1);
       }

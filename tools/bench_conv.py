@@ -11,6 +11,7 @@ from sg2im_amd import ops
 
 D = torch.device('cuda', 0)
 NB = 32
+PLAIN = '--plain' in sys.argv
 LAYERS = [  # name, H, C0, C1(up), Cout, k, stride, pad
   ('m0.conv0', 4, 160, 1, 1024, 3, 1, 1), ('m0.conv1', 4, 1024, 0, 1024, 3, 1, 1),
   ('m1.conv0', 8, 160, 1024, 512, 3, 1, 1), ('m1.conv1', 8, 512, 0, 512, 3, 1, 1),
@@ -49,10 +50,15 @@ def main():
     name, H, C0, C1, Cout, k, s, p = L[:8]
     N = L[8] if len(L) > 8 else NB
     srcs = []
+    # as in the network: the previous layer's BatchNorm + LeakyReLU is PENDING on the feature source (applied by the
+    # operand loader); the layout levels are plain.  --plain: no pending affine anywhere
+    aff = lambda C: (None, None, 1.0) if PLAIN else (torch.rand(C, device=D) + 0.5, torch.randn(C, device=D) * 0.1, 0.2)
     if C0:
-      srcs.append(ops.nhwc_src(torch.randn(N, H, H, C0, device=D)))
+      sc, sh, sl = aff(C0) if (C1 == 0 and k == 3 and s == 1) else (None, None, 1.0)
+      srcs.append(ops.nhwc_src(torch.randn(N, H, H, C0, device=D), 0, sc, sh, sl))
     if C1 > 1:
-      srcs.append(ops.nhwc_src(torch.randn(N, H // 2, H // 2, C1, device=D), 1))
+      sc, sh, sl = aff(C1)
+      srcs.append(ops.nhwc_src(torch.randn(N, H // 2, H // 2, C1, device=D), 1, sc, sh, sl))
     # (C1 == 1: the first refinement module - the all-zero feature channel is left out, the weight rows keep it)
     d = ops.conv_desc(srcs, N, H, H, k, k, s, p, weight_channels=C0 + C1 if C1 == 1 else 0)
     Ct = C0 + C1
