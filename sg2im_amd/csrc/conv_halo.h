@@ -22,6 +22,10 @@
 #pragma once
 #include "igemm.h"
 
+#ifndef SG2IM_HALO_WAVES64
+#define SG2IM_HALO_WAVES64 4
+#endif
+
 namespace sg2im {
 
 struct HaloParams {
@@ -50,8 +54,11 @@ struct ChunkCursor {
   int s, cb, cstart;    // source index, chunk's first channel inside the source, source's first concat channel
 };
 
+// (64-wide column tiles are held to 128 registers: four resident wavefronts per SIMD, as many workgroups per CU
+// as their 35-47 KB of LDS allow)
 template <int RT, int CT, int BN, bool DG, bool ST>
-__global__ __launch_bounds__(NTHREADS) void conv_halo_kernel(const HaloParams p) {
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BN == 64 && CT <= 32) ? SG2IM_HALO_WAVES64 : 2)))
+void conv_halo_kernel(const HaloParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BM = RT * CT;
   static_assert(BM == 128, "a patch is 128 output pixels");
@@ -79,7 +86,6 @@ __global__ __launch_bounds__(NTHREADS) void conv_halo_kernel(const HaloParams p)
 
   // ---- A loader: thread -> halo float4 (pixel r0 + 32 j, channels 4 col4 .. 4 col4 + 3 of the chunk) ----
   unsigned amask = 0;                                         // bit j: the halo pixel exists and lies inside the image
-  unsigned apos[NA];                                          // (y << 16 | x) of the halo pixel (valid ones only)
   #pragma unroll
   for (int j = 0; j < NA; ++j) {
     const int hp = r0 + 32 * j;
@@ -87,14 +93,17 @@ __global__ __launch_bounds__(NTHREADS) void conv_halo_kernel(const HaloParams p)
     const int ay = y0 - 1 + hr, ax = x0 - 1 + hc;
     const bool ok = hp < HP && (unsigned)ay < (unsigned)g.H && (unsigned)ax < (unsigned)g.W;
     amask |= (ok ? 1u : 0u) << j;
-    apos[j] = ok ? ((unsigned)ay << 16 | (unsigned)ax) : 0u;
   }
   unsigned aoff[NA];                                          // element offset of the pixel in the current source
+  // (recomputed only when the source changes - a handful of times per workgroup - so the pixel coordinates are
+  // re-derived from the halo index instead of being kept in registers)
   auto pixel_offsets = [&](const Src& S) {
     const int Hs = g.H >> S.up, Ws = g.W >> S.up;
     #pragma unroll
     for (int j = 0; j < NA; ++j) {
-      const int ay = (int)(apos[j] >> 16), ax = (int)(apos[j] & 0xffffu);
+      const int hp = r0 + 32 * j;
+      const int hr = hp / HWD, hc = hp - hr * HWD;
+      const int ay = (amask >> j & 1u) ? y0 - 1 + hr : 0, ax = (amask >> j & 1u) ? x0 - 1 + hc : 0;
       aoff[j] = (unsigned)((nb * Hs + (ay >> S.up)) * Ws + (ax >> S.up)) * (unsigned)S.ld;
     }
   };

@@ -71,7 +71,13 @@ def main():
     dw = torch.empty_like(W)
     gf = 2.0 * N * d.out_h * d.out_w * Cout * Ct * k * k / 1e9
     t1 = timeit(lambda: ops.conv2d_forward(d, W, Cout, b, y, Cout))
-    t2 = timeit(lambda: ops.conv2d_backward_data(d, W, Cout, gy, Cout, 0, Cx, dx, Cx))
+    if C1 > 1:       # as the network issues it: the layout channels (128 of 160 need gradients) and the feature channels
+      dl, dz = torch.empty(N, H, H, 128, device=D), torch.empty(N, H, H, C1, device=D)
+      t2 = timeit(lambda: (ops.conv2d_backward_data(d, W, Cout, gy, Cout, 0, 128, dl, 128),
+                           ops.conv2d_backward_data(d, W, Cout, gy, Cout, C0, C1, dz, C1)))
+      t2 *= Ct / float(128 + C1)       # (per FLOP of the full layer, so that the TF/s column stays comparable)
+    else:
+      t2 = timeit(lambda: ops.conv2d_backward_data(d, W, Cout, gy, Cout, 0, Cx, dx, Cx))
     t3 = timeit(lambda: ops.conv2d_backward_weight(d, gy, Cout, Cout, dw))
     print('%-10s %9.2f | %8.3f %7.1f | %8.3f %7.1f | %8.3f %7.1f' % (name, gf, t1, gf / t1, t2, gf / t2, t3, gf / t3), flush=True)
     tot['fwd'] += t1; tot['dgrad'] += t2; tot['wgrad'] += t3; totf += gf
