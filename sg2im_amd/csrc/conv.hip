@@ -1565,9 +1565,12 @@ static bool halo_geometry(const sg2im_conv_desc* d) {
 
 // patch shape for an H x W map, N-tile width and split-K (over whole 32-channel chunks) for `ncols` output columns
 static bool halo_plan(int NB, int H, int W, int ncols, int nchunks, size_t ws_bytes, bool can_split, HaloPlan* pl) {
-  if (W % 64 == 0 && H % 2 == 0) { pl->rt = 2; pl->ct = 64; }
+  // (the squarest patch first: 8 x 16 has the smallest halo - 180 pixels for 128 outputs against 204 / 264 - and,
+  // at 35 KB of LDS with 64-wide column tiles, four resident workgroups per CU instead of three: the 64-channel
+  // 64 x 64 layers went 92 -> 114 TFLOP/s forward with it, profiles/r3_halo_layers.log)
+  if (W % 16 == 0 && H % 8 == 0) { pl->rt = 8; pl->ct = 16; }
   else if (W % 32 == 0 && H % 4 == 0) { pl->rt = 4; pl->ct = 32; }
-  else if (W % 16 == 0 && H % 8 == 0) { pl->rt = 8; pl->ct = 16; }
+  else if (W % 64 == 0 && H % 2 == 0) { pl->rt = 2; pl->ct = 64; }
   else return false;
   const long long M = (long long)NB * H * W;
   pl->patches = (int)(M / 128);

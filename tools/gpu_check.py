@@ -365,10 +365,11 @@ def sec_conv():
   conv_case('v2 conv5x5 64->96 24x24 pad2', 6, 24, 24, 64, 0, 0, 96, 5, 1, 2)
   conv_case('v2 conv1x1 128->128 32x32', 8, 32, 32, 128, 0, 0, 128, 1, 1, 0)
   # halo'd-tile kernels (csrc/conv_halo.h): ragged channel chunks, pending affine, all three patch shapes
-  conv_case('halo conv3x3 80+48up->48 16x32 (4x32 patches, ragged chunks)', 3, 16, 32, 80, 48, 1, 48, 3, 1, 1)
+  conv_case('halo conv3x3 80+48up->48 12x32 (4x32 patches, ragged chunks)', 3, 12, 32, 80, 48, 1, 48, 3, 1, 1)
   conv_case('halo conv3x3 bnact 64->96 32x32', 4, 32, 32, 64, 0, 0, 96, 3, 1, 1, bnact=True)
   conv_case('halo conv3x3 bnact 36->40 8x16 (8x16 patches)', 5, 8, 16, 36, 0, 0, 40, 3, 1, 1, bnact=True)
-  conv_case('halo conv3x3 64+64up->64 64x64 (2x64 patches)', 2, 64, 64, 64, 64, 1, 64, 3, 1, 1)
+  conv_case('halo conv3x3 64+64up->64 6x64 (2x64 patches)', 2, 6, 64, 64, 64, 1, 64, 3, 1, 1)
+  conv_case('halo conv3x3 64+64up->64 64x64 (8x16 patches)', 2, 64, 64, 64, 64, 1, 64, 3, 1, 1)
   conv_case('halo conv3x3 32->256 16x16 (128-wide tiles / split-K)', 16, 16, 16, 32, 0, 0, 256, 3, 1, 1)
   # weight rows wider than the sources (sg2im_conv_desc.weight_channels): the first refinement module
   conv_case_wide_weight('conv3x3 160 of 161 -> 1024 4x4 (m0.conv0, split-K)', 32, 4, 4, 160, 161, 1024, 3, 1)
