@@ -1208,7 +1208,6 @@ __global__ void splitk_finish_parity_kernel(const float* __restrict__ ws, int ns
 
 }  // namespace sg2im
 #include "conv_halo.h"
-#include "wgrad_halo.h"
 namespace sg2im {
 
 // ---------------------------------------------------------------------------
@@ -1557,7 +1556,6 @@ static bool al16p(const void* q) { return ((uintptr_t)q & 15) == 0; }
 // ---- halo'd-tile kernels (conv_halo.h): 3x3 / stride 1 / pad 1, float4 loaders, fp32 ----
 // A/B knob: 0 = every convolution on the first-generation per-tap kernels
 static const bool g_halo = !(getenv("SG2IM_HALO") && atoi(getenv("SG2IM_HALO")) == 0);
-static const bool g_wgrad3 = !(getenv("SG2IM_WGRAD3") && atoi(getenv("SG2IM_WGRAD3")) == 0);   // (wgrad_halo.h)
 struct HaloPlan { int rt, ct, bn, nsplit, patches; };
 
 static bool halo_geometry(const sg2im_conv_desc* d) {
@@ -1959,34 +1957,10 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
   // (room for the bias-gradient partials of up to 512 splits is kept behind the dW partials)
   const size_t bias_room = dbias ? sizeof(float) * 512 * (size_t)cout : 0;
   const bool can_split = workspace != nullptr && workspace_bytes > bias_room;
-  // 3x3 / stride 1 / pad 1 layers with <= 64 output channels and rows of 32 k pixels: the row-halo'd kernel
-  // (wgrad_halo.h) - 192-column tiles (one kernel row x three taps x 64 channels) over the staged input row
-  if (g_wgrad3 && v4 && d->compute_dtype == 0 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 &&
-      !any_gather(p.g) && cout <= 64 && d->out_w % BK == 0 && Ctot >= 32 && p.P % BK == 0) {
-    Wgrad3Params q;
-    q.g = p.g; q.dY = dy; q.ldy = ld_dy; q.Cout = cout; q.P = p.P; q.iters = p.iters;
-    q.ncb = (Ctot + W3_CB - 1) / W3_CB;
-    const int mt = (cout + W3_BM - 1) / W3_BM;
-    const long long tiles = 3LL * q.ncb * mt;
-    long long ns = 1;
-    if (can_split) {
-      ns = std::max<long long>(1, (5LL * g_num_cu / 2 + tiles / 2) / tiles);
-      ns = std::min<long long>(ns, std::max(1, p.iters / 2));
-      ns = std::min<long long>(ns, 512);
-      ns = std::min<long long>(ns, std::max<long long>(1, (long long)((workspace_bytes - bias_room) / sizeof(float)) / ((long long)cout * Ntot)));
-      const int per = (int)((p.iters + ns - 1) / ns);
-      ns = (p.iters + per - 1) / per;
-    }
-    q.e = Epi{dweight, (long long)taps * p.g.Wtap, nullptr, 1.f, accumulate, workspace, (int)ns};
-    if (p.g.Wtap != Ctot) { q.e.col_ctot = Ctot; q.e.col_wtap = p.g.Wtap; }
-    q.dbias = dbias;
-    q.ws_bias = ns > 1 ? workspace + (size_t)ns * cout * Ntot : nullptr;
-    q.background = p.background;
-    const size_t lds_req = q.background ? std::max(kWgrad3Lds, g_bg_lds) : kWgrad3Lds;
-    hipLaunchKernelGGL(conv_wgrad3_kernel, dim3(3 * q.ncb, mt, (unsigned)ns), dim3(NTHREADS), lds_req, stream, q);
-    if (hipGetLastError() != hipSuccess) return SG2IM_ERR_HIP;
-    return finish_split(q.e, cout, Ntot, stream, q.ws_bias, dbias, cout) == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
-  }
+  // [Round 3, measured and dropped (profiles/r3_wgrad3_ab.log): a row-halo'd form for the <= 64-channel layers -
+  // 192-column tiles = one kernel row x three taps x 64 channels formed from ONE staged input row - moved the
+  // 64-channel layers 76 -> 79 TFLOP/s and m4.conv0 98.6 -> 89.6: fatter column tiles need more K splits to fill
+  // the chip, and the split-K partial volume (splits x the whole dW) grows with them.]
   const Plan pl = make_plan(PASS_WGRAD, cout, Ntot, p.iters, (long long)cout * Ntot, can_split ? workspace_bytes - bias_room : 0,
                             can_split, 2, !v4, [&](int bn) { return (long long)(Ntot + bn - 1) / bn; });
   p.ntile_c = 0;

@@ -371,10 +371,10 @@ def sec_conv():
   conv_case('halo conv3x3 64+64up->64 6x64 (2x64 patches)', 2, 6, 64, 64, 64, 1, 64, 3, 1, 1)
   conv_case('halo conv3x3 64+64up->64 64x64 (8x16 patches)', 2, 64, 64, 64, 64, 1, 64, 3, 1, 1)
   conv_case('halo conv3x3 32->256 16x16 (128-wide tiles / split-K)', 16, 16, 16, 32, 0, 0, 256, 3, 1, 1)
-  # row-halo'd weight gradient (csrc/wgrad_halo.h): <= 64 output channels, rows of 32 k pixels
-  conv_case('wgrad3 conv3x3 bnact 64->64 32x32', 4, 32, 32, 64, 0, 0, 64, 3, 1, 1, bnact=True)
-  conv_case('wgrad3 conv3x3 96+40up->48 8x32 (ragged channel block, 48 outputs)', 3, 8, 32, 96, 40, 1, 48, 3, 1, 1)
-  conv_case('wgrad3 conv3x3 160+128up->64 64x64 batch 4 (m4.conv0 shape)', 4, 64, 64, 160, 128, 1, 64, 3, 1, 1)
+  # weight gradients of <= 64 output channels over rows of 32 k pixels (pending affine, ragged blocks, two sources)
+  conv_case('conv3x3 bnact 64->64 32x32', 4, 32, 32, 64, 0, 0, 64, 3, 1, 1, bnact=True)
+  conv_case('conv3x3 96+40up->48 8x32 (ragged channel block, 48 outputs)', 3, 8, 32, 96, 40, 1, 48, 3, 1, 1)
+  conv_case('conv3x3 160+128up->64 64x64 batch 4 (m4.conv0 shape)', 4, 64, 64, 160, 128, 1, 64, 3, 1, 1)
   # weight rows wider than the sources (sg2im_conv_desc.weight_channels): the first refinement module
   conv_case_wide_weight('conv3x3 160 of 161 -> 1024 4x4 (m0.conv0, split-K)', 32, 4, 4, 160, 161, 1024, 3, 1)
   conv_case_wide_weight('conv3x3 128 of 129 -> 96 8x8', 4, 8, 8, 128, 129, 96, 3, 1)
