@@ -28,6 +28,11 @@ extern "C" {
 
 int sg2im_abi_version(void);   /* 4 */
 
+/* Statistics: kernels this library has launched (or recorded into a stream capture) so far in this process;
+ * which = 0: all of them, 1: the implicit-GEMM family incl. its split-K finishes.  bench.py reads it around the
+ * capture of one training iteration to report the launches per step of the graph-mode plan. */
+unsigned long long sg2im_launch_count(int which);
+
 /* One-time, idempotent set-up (kernel attributes of every implicit-GEMM instantiation, loading of
  * the library's code object).  Without it the same work happens lazily on first launches; with it
  * the entry points below only enqueue kernels / async memsets on `stream`, so they can be issued

@@ -52,6 +52,7 @@ _D = POINTER(ConvDesc)
 _SIGNATURES = {
   'sg2im_abi_version': [],
   'sg2im_init': [],
+  'sg2im_launch_count': [_I],
   'sg2im_conv2d_forward': [_D, _P, _I, _P, _F, _P, _L, _I, _P, _Z, _P],
   'sg2im_conv2d_backward_data': [_D, _P, _I, _P, _I, _I, _I, _P, _L, _I, _P, _Z, _P],
   'sg2im_conv2d_forward_bn': [_D, _P, _I, _P, _F, _P, _L, _P, _Z, POINTER(BnFwd), _P],
@@ -107,7 +108,8 @@ _SIGNATURES = {
   'sg2im_adam_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
   'sg2im_adam_step_guarded': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P, _P],
 }
-_RESTYPE = {'sg2im_layout_backward_workspace': c_size_t, 'sg2im_crop_backward_workspace': c_size_t}
+_RESTYPE = {'sg2im_layout_backward_workspace': c_size_t, 'sg2im_crop_backward_workspace': c_size_t,
+            'sg2im_launch_count': ctypes.c_ulonglong}
 EXPORTS = tuple(sorted(_SIGNATURES))
 
 _lib = None

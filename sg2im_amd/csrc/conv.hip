@@ -13,6 +13,8 @@
 // reference (sg2im/crn.py:58-64,107; sg2im/graph.py:77-82; sg2im/layers.py:166-169)
 // are never materialised.
 #include <algorithm>
+#define SG2IM_GEMM_TU 1
+#include "launch_count.h"
 #include "igemm.h"
 #include <cstddef>
 #include <cstdio>
@@ -1387,13 +1389,13 @@ static hipError_t finish_split(const Epi& e, long long M, int N, hipStream_t st,
                   (!e.bias || !((uintptr_t)e.bias & 15)) && e.col_wtap == 0;
   if (v4) {
     const int blocks4 = (int)std::min<long long>((MN / 4 + 255) / 256, 4096);
-    hipLaunchKernelGGL(splitk_finish_v4_kernel, dim3(blocks4), dim3(256), 0, st, e.ws, e.nsplit, MN, N, e.C, e.ldc,
+    SG2IM_LAUNCH(splitk_finish_v4_kernel, dim3(blocks4), dim3(256), 0, st, e.ws, e.nsplit, MN, N, e.C, e.ldc,
                        e.bias, e.slope, e.accumulate, ws2, C2, N2);
     return hipGetLastError();
   }
   const int per = 256 / SL;
   const int blocks = (int)std::min<long long>((MN + per - 1) / per, 4096);
-  hipLaunchKernelGGL(splitk_finish_kernel, dim3(blocks), dim3(256), 0, st, e.ws, e.nsplit, MN, N, e.C, e.ldc,
+  SG2IM_LAUNCH(splitk_finish_kernel, dim3(blocks), dim3(256), 0, st, e.ws, e.nsplit, MN, N, e.C, e.ldc,
                      e.bias, e.slope, e.accumulate, SL, ws2, C2, N2, e.col_ctot, e.col_wtap);
   return hipGetLastError();
 }
@@ -1439,7 +1441,7 @@ static hipError_t launch_fwd_g(FwdParams& p, hipStream_t st) {
   constexpr size_t lds = fwd_lds<BM, BN>();
   { hipError_t e = prepare_fwd<BM, BN, VEC, GATHER>(); if (e != hipSuccess) return e; }
   dim3 grid((p.Cout + BN - 1) / BN, (p.M + BM - 1) / BM, p.e.nsplit);
-  hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, VEC, GATHER>), grid, dim3(NTHREADS), lds, st, p);
+  SG2IM_LAUNCH((conv_fwd_kernel<BM, BN, VEC, GATHER>), grid, dim3(NTHREADS), lds, st, p);
   return hipGetLastError();
 }
 
@@ -1456,7 +1458,7 @@ static hipError_t launch_dgrad(DgradParams& p, hipStream_t st) {
   constexpr size_t lds = dgrad_lds<BM, BN>();
   { hipError_t e = prepare_dgrad<BM, BN, VA, VB>(); if (e != hipSuccess) return e; }
   dim3 grid((p.Nc + BN - 1) / BN, (p.M + BM - 1) / BM, p.parity ? 4 * p.e.nsplit : p.e.nsplit);
-  hipLaunchKernelGGL((conv_dgrad_kernel<BM, BN, VA, VB>), grid, dim3(NTHREADS), lds, st, p);
+  SG2IM_LAUNCH((conv_dgrad_kernel<BM, BN, VA, VB>), grid, dim3(NTHREADS), lds, st, p);
   return hipGetLastError();
 }
 
@@ -1483,11 +1485,11 @@ static hipError_t launch_wgrad_g(WgradParams& p, int ntiles_n, hipStream_t st) {
     // "fast rows" form: the BK pixels of every K chunk lie in one output row (see conv_wgrad_body)
     if (p.g.stride == 1 && p.g.Wo % BK == 0) {
       { hipError_t e = prepare_wgrad_fr<BM, BN>(); if (e != hipSuccess) return e; }
-      hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, 4, false, false, true>), grid, dim3(NTHREADS), lds_req, st, p);
+      SG2IM_LAUNCH((conv_wgrad_kernel<BM, BN, 4, false, false, true>), grid, dim3(NTHREADS), lds_req, st, p);
       return hipGetLastError();
     }
   }
-  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, VEC, GATHER>), grid, dim3(NTHREADS), lds_req, st, p);
+  SG2IM_LAUNCH((conv_wgrad_kernel<BM, BN, VEC, GATHER>), grid, dim3(NTHREADS), lds_req, st, p);
   return hipGetLastError();
 }
 
@@ -1503,14 +1505,14 @@ template <int BM, int BN>
 static hipError_t launch_fwd_h(FwdParams& p, hipStream_t st) {
   constexpr size_t lds = TileBytes<true, BM, false>::value + TileBytes<true, BN, false>::value;
   dim3 grid((p.Cout + BN - 1) / BN, (p.M + BM - 1) / BM, p.e.nsplit);
-  hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, 4, false, true>), grid, dim3(NTHREADS), lds, st, p);
+  SG2IM_LAUNCH((conv_fwd_kernel<BM, BN, 4, false, true>), grid, dim3(NTHREADS), lds, st, p);
   return hipGetLastError();
 }
 template <int BM, int BN>
 static hipError_t launch_dgrad_h(DgradParams& p, hipStream_t st) {
   constexpr size_t lds = TileBytes<true, BM, false>::value + TileBytes<true, BN, true>::value;
   dim3 grid((p.Nc + BN - 1) / BN, (p.M + BM - 1) / BM, p.parity ? 4 * p.e.nsplit : p.e.nsplit);
-  hipLaunchKernelGGL((conv_dgrad_kernel<BM, BN, 4, 4, true>), grid, dim3(NTHREADS), lds, st, p);
+  SG2IM_LAUNCH((conv_dgrad_kernel<BM, BN, 4, 4, true>), grid, dim3(NTHREADS), lds, st, p);
   return hipGetLastError();
 }
 template <int BM, int BN>
@@ -1520,7 +1522,7 @@ static hipError_t launch_wgrad_h(WgradParams& p, int ntiles_n, hipStream_t st) {
   p.ntiles_m = (p.Cout + BM - 1) / BM;
   dim3 grid(p.ntiles_n, p.ntiles_m, p.e.nsplit);
   const size_t lds_req = (p.background && BM * BN > 64 * 64) ? std::max(lds, std::min<size_t>(g_bg_lds, 64 * 1024)) : lds;
-  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, 4, false, true>), grid, dim3(NTHREADS), lds_req, st, p);
+  SG2IM_LAUNCH((conv_wgrad_kernel<BM, BN, 4, false, true>), grid, dim3(NTHREADS), lds_req, st, p);
   return hipGetLastError();
 }
 
@@ -1529,14 +1531,14 @@ template <int BM, int BN, bool H>
 static hipError_t launch_fwd_st(FwdParams& p, hipStream_t st) {
   constexpr size_t lds = TileBytes<H, BM, false>::value + TileBytes<H, BN, false>::value;
   dim3 grid((p.Cout + BN - 1) / BN, (p.M + BM - 1) / BM, 1);
-  hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, 4, false, H, true>), grid, dim3(NTHREADS), lds, st, p);
+  SG2IM_LAUNCH((conv_fwd_kernel<BM, BN, 4, false, H, true>), grid, dim3(NTHREADS), lds, st, p);
   return hipGetLastError();
 }
 template <int BM, int BN, bool H>
 static hipError_t launch_dgrad_st(DgradParams& p, hipStream_t st) {
   constexpr size_t lds = TileBytes<H, BM, false>::value + TileBytes<H, BN, true>::value;
   dim3 grid((p.Nc + BN - 1) / BN, (p.M + BM - 1) / BM, 1);
-  hipLaunchKernelGGL((conv_dgrad_kernel<BM, BN, 4, 4, H, true>), grid, dim3(NTHREADS), lds, st, p);
+  SG2IM_LAUNCH((conv_dgrad_kernel<BM, BN, 4, 4, H, true>), grid, dim3(NTHREADS), lds, st, p);
   return hipGetLastError();
 }
 
@@ -1592,7 +1594,7 @@ template <int RT, int CT, int BN, bool DG, bool ST>
 static hipError_t launch_halo_t(HaloParams& p, const HaloPlan& pl, hipStream_t st) {
   constexpr size_t lds = halo_lds<RT, CT, BN, DG>();
   dim3 grid((p.N + BN - 1) / BN, pl.patches, pl.nsplit);
-  hipLaunchKernelGGL((conv_halo_kernel<RT, CT, BN, DG, ST>), grid, dim3(NTHREADS), lds, st, p);
+  SG2IM_LAUNCH((conv_halo_kernel<RT, CT, BN, DG, ST>), grid, dim3(NTHREADS), lds, st, p);
   return hipGetLastError();
 }
 template <bool DG, bool ST>
@@ -1640,7 +1642,7 @@ int sg2im_init(void) {
 #undef SG2IM_PREP
   if (e == hipSuccess) e = ensure_lds(conv_wgrad_group_kernel, wgrad_lds<64, 64>());
   if (e != hipSuccess) return SG2IM_ERR_HIP;
-  hipLaunchKernelGGL(init_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)0, (int*)nullptr);
+  SG2IM_LAUNCH(init_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)0, (int*)nullptr);
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize((hipStream_t)0) != hipSuccess) return SG2IM_ERR_HIP;
   done = true;
   return SG2IM_OK;
@@ -1728,7 +1730,7 @@ static int conv_forward_impl(const sg2im_conv_desc* d, const float* weight, int 
     if ((size_t)nblk * 3 * cout <= bn->partial_floats) {
       StatSink ss{};
       ss.partial = bn->partial; ss.count = bn->count; ss.unit = bn->count_unit; ss.tiles = nblk;
-      hipLaunchKernelGGL(splitk_finish_stats_kernel<1>, dim3(nblk, nslab), dim3(256), 0, stream, workspace, nsplit, (long long)p.M,
+      SG2IM_LAUNCH(splitk_finish_stats_kernel<1>, dim3(nblk, nslab), dim3(256), 0, stream, workspace, nsplit, (long long)p.M,
                          cout, out, ld_out, bias, out_slope, per, ss);
       if (hipGetLastError() != hipSuccess) return SG2IM_ERR_HIP;
       return bn_stats_finish_tiles(bn->partial, nblk, per, p.M, cout, bn, stream);
@@ -1787,7 +1789,7 @@ static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int co
     const size_t lds = (size_t)taps * cout * c_count * sizeof(float);
     dim3 grid((unsigned)((Mfull + 255) / 256));
 #define SG2IM_FEWC(NC)                                                                                        \
-    hipLaunchKernelGGL((conv_dgrad_fewc_kernel<NC>), grid, dim3(256), lds, stream, dy, ld_dy, weight, cout,   \
+    SG2IM_LAUNCH((conv_dgrad_fewc_kernel<NC>), grid, dim3(256), lds, stream, dy, ld_dy, weight, cout,   \
                        g.Wtap, c_begin, d->batch, d->in_h, d->in_w, d->out_h, d->out_w, d->kh, d->kw,        \
                        d->stride, d->pad, dx, ld_dx, accumulate)
     if (c_count == 1) SG2IM_FEWC(1); else if (c_count == 2) SG2IM_FEWC(2); else if (c_count == 3) SG2IM_FEWC(3);
@@ -1826,7 +1828,7 @@ static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int co
       finish_stats_grid(Mfull, c_count, 2, bb->partial_floats, &nblk, &per, &nslab);
       if ((size_t)nblk * 2 * c_count <= bb->partial_floats) {
         ss.tiles = nblk;
-        hipLaunchKernelGGL(splitk_finish_stats_kernel<2>, dim3(nblk, nslab), dim3(256), 0, stream, workspace, hp.nsplit, Mfull,
+        SG2IM_LAUNCH(splitk_finish_stats_kernel<2>, dim3(nblk, nslab), dim3(256), 0, stream, workspace, hp.nsplit, Mfull,
                            c_count, dx, ld_dx, (const float*)nullptr, 1.f, per, ss);
         if (hipGetLastError() != hipSuccess) return SG2IM_ERR_HIP;
         return bn_bwd_finish_tiles(bb->partial, nblk, bn_rows_h, c_count, bb, stream);
@@ -1896,7 +1898,7 @@ static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int co
   if (p.parity && pl.nsplit > 1) {
     const long long per_split = 4LL * p.M * c_count;
     const int blocks = (int)std::min<long long>((per_split + 255) / 256, 4096);
-    hipLaunchKernelGGL(splitk_finish_parity_kernel, dim3(blocks), dim3(256), 0, stream, workspace, pl.nsplit, p.M,
+    SG2IM_LAUNCH(splitk_finish_parity_kernel, dim3(blocks), dim3(256), 0, stream, workspace, pl.nsplit, p.M,
                        c_count, dx, ld_dx, accumulate, d->batch, d->in_h, d->in_w);
     return hipGetLastError() == hipSuccess ? bn_after() : SG2IM_ERR_HIP;
   }
@@ -1906,7 +1908,7 @@ static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int co
     finish_stats_grid(Mfull, c_count, 2, bb->partial_floats, &nblk, &per, &nslab);
     if ((size_t)nblk * 2 * c_count <= bb->partial_floats) {
       ss.tiles = nblk;
-      hipLaunchKernelGGL(splitk_finish_stats_kernel<2>, dim3(nblk, nslab), dim3(256), 0, stream, workspace, pl.nsplit, Mfull, c_count,
+      SG2IM_LAUNCH(splitk_finish_stats_kernel<2>, dim3(nblk, nslab), dim3(256), 0, stream, workspace, pl.nsplit, Mfull, c_count,
                          dx, ld_dx, (const float*)nullptr, 1.f, per, ss);
       if (hipGetLastError() != hipSuccess) return SG2IM_ERR_HIP;
       return bn_bwd_finish_tiles(bb->partial, nblk, bn_rows, c_count, bb, stream);
@@ -2051,10 +2053,10 @@ int sg2im_conv2d_backward_weight_group(int n, const sg2im_conv_desc* const* desc
     if (ensure_lds(conv_wgrad_group_kernel, glds) != hipSuccess) return SG2IM_ERR_HIP;
     group_ready = true;
   }
-  hipLaunchKernelGGL(conv_wgrad_group_kernel, dim3(blocks), dim3(NTHREADS), glds, stream, wg);
+  SG2IM_LAUNCH(conv_wgrad_group_kernel, dim3(blocks), dim3(NTHREADS), glds, stream, wg);
   if (hipGetLastError() != hipSuccess) return SG2IM_ERR_HIP;
   if (any_split) {
-    hipLaunchKernelGGL(splitk_finish_v4_group_kernel, dim3(fblocks), dim3(256), 0, stream, fg);
+    SG2IM_LAUNCH(splitk_finish_v4_group_kernel, dim3(fblocks), dim3(256), 0, stream, fg);
     if (hipGetLastError() != hipSuccess) return SG2IM_ERR_HIP;
   }
   return SG2IM_OK;

@@ -10,6 +10,7 @@
 // coalesced loads, one workgroup per destination row.
 #include <algorithm>
 #include <hip/hip_runtime.h>
+#include "launch_count.h"
 #include "sg2im_hip.h"
 
 namespace sg2im {
@@ -225,6 +226,8 @@ extern "C" {
 
 int sg2im_abi_version(void) { return 4; }
 
+unsigned long long sg2im_launch_count(int which) { return which == 1 ? sg2im::g_gemm_launches : sg2im::g_launches; }
+
 int sg2im_csr_build(const long long* keys_a, int n_a, const long long* keys_b, int n_b, int n_rows,
                     int* row_ptr, int* entries, int* scratch, const int* live_keys, hipStream_t stream) {
   if (n_a < 0 || n_b < 0 || n_rows < 1 || !row_ptr || !scratch || (n_a && !keys_a) || (n_b && !keys_b))
@@ -235,13 +238,13 @@ int sg2im_csr_build(const long long* keys_a, int n_a, const long long* keys_b, i
   if (hipMemsetAsync(counts, 0, sizeof(int) * n_rows, stream) != hipSuccess) return SG2IM_ERR_HIP;
   if (n > 0) {
     if (!entries) return SG2IM_ERR_ARG;
-    hipLaunchKernelGGL(csr_count_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, keys_a, n_a, keys_b, n_b, counts, live_keys);
+    SG2IM_LAUNCH(csr_count_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, keys_a, n_a, keys_b, n_b, counts, live_keys);
   }
-  hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, n_rows, row_ptr);
+  SG2IM_LAUNCH(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, n_rows, row_ptr);
   if (n > 0) {
-    hipLaunchKernelGGL(csr_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, keys_a, n_a, keys_b, n_b,
+    SG2IM_LAUNCH(csr_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, keys_a, n_a, keys_b, n_b,
                        row_ptr, counts, tmp, live_keys);
-    hipLaunchKernelGGL(csr_ranksort_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream, row_ptr, tmp, n_rows, entries);
+    SG2IM_LAUNCH(csr_ranksort_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream, row_ptr, tmp, n_rows, entries);
   }
   return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
 }
@@ -253,7 +256,7 @@ int sg2im_segment_sum(const float* src_a, long long ld_a, int n_a, const float* 
   if (n_rows == 0) return SG2IM_OK;
   if (!src_b) { src_b = src_a; ld_b = ld_a; }
   const int threads = std::min(256, std::max(64, ((width + 3) / 4 + 63) / 64 * 64));
-  hipLaunchKernelGGL(segment_sum_kernel, dim3(n_rows), dim3(threads), 0, stream, src_a, ld_a, n_a, src_b, ld_b,
+  SG2IM_LAUNCH(segment_sum_kernel, dim3(n_rows), dim3(threads), 0, stream, src_a, ld_a, n_a, src_b, ld_b,
                      row_ptr, entries, width, average, accumulate, out, ld_out);
   return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
 }
@@ -263,7 +266,7 @@ int sg2im_copy_2d(const float* src, long long ld_src, float* dst, long long ld_d
   if (!src || !dst || width < 1 || rows < 0) return SG2IM_ERR_ARG;
   if (rows == 0) return SG2IM_OK;
   const int blocks = (int)std::min<long long>((rows * width + 255) / 256, 4096);
-  hipLaunchKernelGGL(copy_2d_kernel, dim3(blocks), dim3(256), 0, stream, src, ld_src, dst, ld_dst, rows, width);
+  SG2IM_LAUNCH(copy_2d_kernel, dim3(blocks), dim3(256), 0, stream, src, ld_src, dst, ld_dst, rows, width);
   return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
 }
 
@@ -276,7 +279,7 @@ int sg2im_gconv_pool_backward(const float* d_pooled, long long ld_dp, const long
     return SG2IM_ERR_ARG;
   const int NT = 2 * hidden + dout;
   const int threads = std::min(256, std::max(64, (NT + 63) / 64 * 64));
-  hipLaunchKernelGGL(gconv_pool_bwd_kernel, dim3(n_triples), dim3(threads), 0, stream, d_pooled, ld_dp, s_idx, o_idx,
+  SG2IM_LAUNCH(gconv_pool_bwd_kernel, dim3(n_triples), dim3(threads), 0, stream, d_pooled, ld_dp, s_idx, o_idx,
                      row_ptr, g_pred, ld_gp, new_t, ld_nt, hidden, dout, slope, d_new_t, ld_out);
   return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
 }
@@ -286,7 +289,7 @@ int sg2im_gather_rows(const float* src, long long ld_src, const long long* idx, 
   if (n < 0 || width < 1 || !src || !idx || !dst) return SG2IM_ERR_ARG;
   if (n == 0) return SG2IM_OK;
   const int threads = std::min(256, std::max(64, ((width + 3) / 4 + 63) / 64 * 64));
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(n), dim3(threads), 0, stream, src, ld_src, idx, width, row_ptr, dst, ld_dst);
+  SG2IM_LAUNCH(gather_rows_kernel, dim3(n), dim3(threads), 0, stream, src, ld_src, idx, width, row_ptr, dst, ld_dst);
   return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
 }
 

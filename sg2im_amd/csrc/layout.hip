@@ -11,6 +11,7 @@
 // per-image accumulation order (objects in index order) is the reference's.
 #include <algorithm>
 #include <hip/hip_runtime.h>
+#include "launch_count.h"
 #include "sg2im_hip.h"
 
 namespace sg2im {
@@ -576,7 +577,7 @@ int sg2im_layout_forward(const float* vecs, long long ld_vecs, const float* boxe
   (void)n_objs;
   const MaskRef mk{masks, masks_i64, (masks || masks_i64) ? mask_size : 0};
   dim3 grid((height * width + LP - 1) / LP, n_images);
-  hipLaunchKernelGGL(layout_fwd_kernel, grid, dim3(256), 0, stream, vecs, ld_vecs, boxes, mk, img_row_ptr, img_entries,
+  SG2IM_LAUNCH(layout_fwd_kernel, grid, dim3(256), 0, stream, vecs, ld_vecs, boxes, mk, img_row_ptr, img_entries,
                      dim, height, width, align_corners, layout, ld_layout);
   return ok_or(hipGetLastError());
 }
@@ -607,10 +608,10 @@ int sg2im_layout_backward(const float* dlayout, long long ld_dlayout, const floa
     const int TC = dim < 256 ? dim : 256, TR = 256 / TC;
     const size_t lds = sizeof(float) * (size_t)BO * TR * TC;
     dim3 grid(n_tiles, n_images);
-    hipLaunchKernelGGL(layout_bwd_vecs_kernel, grid, dim3(256), lds, stream, dlayout, ld_dlayout, boxes, mk,
+    SG2IM_LAUNCH(layout_bwd_vecs_kernel, grid, dim3(256), lds, stream, dlayout, ld_dlayout, boxes, mk,
                        img_row_ptr, img_entries, n_objs, dim, height, width, align_corners, workspace);
     const long long tot = (long long)n_objs * dim;
-    hipLaunchKernelGGL(layout_bwd_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, workspace,
+    SG2IM_LAUNCH(layout_bwd_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, workspace,
                        n_tiles, n_objs, dim, d_vecs, ld_dvecs);
   }
   if (d_masks || d_boxes) {
@@ -619,9 +620,9 @@ int sg2im_layout_backward(const float* dlayout, long long ld_dlayout, const floa
     // if any, were consumed by layout_bwd_reduce_kernel above - same stream)
     const int HW = height * width;
     dim3 gg((HW + 255) / 256, n_objs);
-    hipLaunchKernelGGL(layout_bwd_g_kernel, gg, dim3(256), 0, stream, dlayout, ld_dlayout, vecs, ld_vecs, obj_to_img,
+    SG2IM_LAUNCH(layout_bwd_g_kernel, gg, dim3(256), 0, stream, dlayout, ld_dlayout, vecs, ld_vecs, obj_to_img,
                        dim, HW, workspace);
-    hipLaunchKernelGGL(layout_bwd_masks_kernel, dim3(n_objs), dim3(256), 0, stream, workspace, boxes, mk, height, width,
+    SG2IM_LAUNCH(layout_bwd_masks_kernel, dim3(n_objs), dim3(256), 0, stream, workspace, boxes, mk, height, width,
                        align_corners, d_masks, d_boxes);
   }
   return ok_or(hipGetLastError());
@@ -635,7 +636,7 @@ int sg2im_crop_forward(const float* imgs, long long ld_img, int n_images, int he
   const long long total = (long long)n_objs * size * size;
   if (total == 0) return SG2IM_OK;
   const int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
-  hipLaunchKernelGGL(crop_fwd_kernel, dim3(blocks), dim3(256), 0, stream, imgs, ld_img, height, width, channels, boxes,
+  SG2IM_LAUNCH(crop_fwd_kernel, dim3(blocks), dim3(256), 0, stream, imgs, ld_img, height, width, channels, boxes,
                      obj_to_img, n_objs, size, align_corners, crops);
   return ok_or(hipGetLastError());
 }
@@ -653,11 +654,11 @@ int sg2im_crop_backward(const float* d_crops, int n_images, int height, int widt
     return SG2IM_ERR_ARG;
   if (n_images < 1 || height < 1 || width < 1) return SG2IM_OK;
   if (n_objs > 0)
-    hipLaunchKernelGGL(crop_bwd_object_kernel, dim3(n_objs), dim3(256), 0, stream, d_crops, height, width, channels,
+    SG2IM_LAUNCH(crop_bwd_object_kernel, dim3(n_objs), dim3(256), 0, stream, d_crops, height, width, channels,
                        boxes, size, align_corners, workspace);
   // every pixel of d_imgs is WRITTEN (zero where no crop touches it): no pre-zeroing needed
   dim3 grid((height * width + 255) / 256, n_images);
-  hipLaunchKernelGGL(crop_bwd_sum_kernel, grid, dim3(256), 0, stream, workspace, height, width, channels, boxes,
+  SG2IM_LAUNCH(crop_bwd_sum_kernel, grid, dim3(256), 0, stream, workspace, height, width, channels, boxes,
                      obj_to_img, n_objs, size, align_corners, d_imgs, ld_dimg);
   return ok_or(hipGetLastError());
 }

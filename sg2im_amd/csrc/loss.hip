@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <hip/hip_runtime.h>
+#include "launch_count.h"
 #include "sg2im_hip.h"
 
 namespace sg2im {
@@ -206,9 +207,9 @@ static int run_elementwise(const float* x, const float* t, long long n, float ta
   constexpr bool needs_t = KIND == L_L1 || KIND == L_MSE || KIND == L_BCE_PROB;
   if (!x || !loss || !partial || n < 1 || (needs_t && !t)) return SG2IM_ERR_ARG;
   const int blocks = (int)std::min<long long>(LOSS_BLOCKS, (n + 255) / 256);
-  hipLaunchKernelGGL((elementwise_loss_kernel<KIND>), dim3(blocks), dim3(256), 0, stream, x, t, n, target,
+  SG2IM_LAUNCH((elementwise_loss_kernel<KIND>), dim3(blocks), dim3(256), 0, stream, x, t, n, target,
                      weight, grad, partial, count, unit);
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, stream, partial, blocks, (double)weight, n, count, unit, loss);
+  SG2IM_LAUNCH(loss_final_kernel, dim3(1), dim3(64), 0, stream, partial, blocks, (double)weight, n, count, unit, loss);
   return ok_or(hipGetLastError());
 }
 
@@ -250,9 +251,9 @@ int sg2im_cross_entropy_loss(const float* scores, int rows, int classes, const l
                              float weight, float* loss, float* grad, float* partial,
                              const int* count, int count_unit, hipStream_t stream) {
   if (!scores || !labels || !loss || !partial || rows < 1 || classes < 1) return SG2IM_ERR_ARG;
-  hipLaunchKernelGGL(cross_entropy_kernel, dim3(rows), dim3(64), 0, stream, scores, rows, classes, labels,
+  SG2IM_LAUNCH(cross_entropy_kernel, dim3(rows), dim3(64), 0, stream, scores, rows, classes, labels,
                      weight, grad, partial, count, count_unit);
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, stream, partial, rows, (double)weight, (long long)rows,
+  SG2IM_LAUNCH(loss_final_kernel, dim3(1), dim3(64), 0, stream, partial, rows, (double)weight, (long long)rows,
                      count, count_unit, loss);
   return ok_or(hipGetLastError());
 }
@@ -261,7 +262,7 @@ int sg2im_scale_by_scalar(const float* x, const float* a_dev, long long n, float
   if (!x || !a_dev || !y) return SG2IM_ERR_ARG;
   if (n == 0) return SG2IM_OK;
   const int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
-  hipLaunchKernelGGL(scale_by_scalar_kernel, dim3(blocks), dim3(256), 0, stream, x, a_dev, n, y);
+  SG2IM_LAUNCH(scale_by_scalar_kernel, dim3(blocks), dim3(256), 0, stream, x, a_dev, n, y);
   return ok_or(hipGetLastError());
 }
 
@@ -270,7 +271,7 @@ int sg2im_sum_scalars(const float* const* terms, int n, float* out, hipStream_t 
   ScalarPtrs t;
   for (int i = 0; i < 8; ++i) t.p[i] = i < n ? terms[i] : nullptr;
   for (int i = 0; i < n; ++i) if (!t.p[i]) return SG2IM_ERR_ARG;
-  hipLaunchKernelGGL(sum_scalars_kernel, dim3(1), dim3(64), 0, stream, t, n, out);
+  SG2IM_LAUNCH(sum_scalars_kernel, dim3(1), dim3(64), 0, stream, t, n, out);
   return ok_or(hipGetLastError());
 }
 
@@ -282,7 +283,7 @@ int sg2im_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
   const double bc1 = 1.0 - std::pow((double)beta1, step);
   const double bc2 = 1.0 - std::pow((double)beta2, step);
   const int blocks = (int)std::min<long long>((n + 255) / 256, 16384);
-  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, n,
+  SG2IM_LAUNCH(adam_kernel, dim3(blocks), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, n,
                      1.f - beta1, beta2, 1.f - beta2, (float)((double)lr / bc1), (float)(1.0 / std::sqrt(bc2)), eps,
                      grad_scale);
   return ok_or(hipGetLastError());
@@ -295,10 +296,10 @@ extern "C" int sg2im_adam_step_guarded(float* param, const float* grad, float* e
                                        float grad_scale, float* state, const float* guard,
                                        hipStream_t stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || !state) return SG2IM_ERR_ARG;
-  hipLaunchKernelGGL(sg2im::adam_prepare_kernel, dim3(1), dim3(64), 0, stream, state, guard, lr, beta1, beta2);
+  SG2IM_LAUNCH(sg2im::adam_prepare_kernel, dim3(1), dim3(64), 0, stream, state, guard, lr, beta1, beta2);
   if (n > 0) {
     const int blocks = (int)std::min<long long>((n + 255) / 256, 16384);
-    hipLaunchKernelGGL(sg2im::adam_guarded_kernel, dim3(blocks), dim3(256), 0, stream, param, grad, exp_avg,
+    SG2IM_LAUNCH(sg2im::adam_guarded_kernel, dim3(blocks), dim3(256), 0, stream, param, grad, exp_avg,
                        exp_avg_sq, n, 1.f - beta1, beta2, 1.f - beta2, state, eps, grad_scale);
   }
   return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;

@@ -5,6 +5,7 @@
 // through LDS and a per-workgroup partial that a tiny second kernel reduces in double.
 #include <algorithm>
 #include <hip/hip_runtime.h>
+#include "launch_count.h"
 #include "sg2im_hip.h"
 #include "bn_final.h"
 
@@ -800,7 +801,7 @@ static inline int ok_or(hipError_t e) { return e == hipSuccess ? SG2IM_OK : SG2I
 
 int bn_stats_finish_tiles(const float* partial, int nblk, long long per, long long rows, int channels,
                           const sg2im_bn_fwd* a, hipStream_t stream) {
-  hipLaunchKernelGGL(bn_stats_final_tiles_kernel, dim3((channels + 3) / 4), dim3(256), 0, stream, partial, nblk, per, rows,
+  SG2IM_LAUNCH(bn_stats_final_tiles_kernel, dim3((channels + 3) / 4), dim3(256), 0, stream, partial, nblk, per, rows,
                      a->unbiased_rows, channels, a->gamma, a->beta, a->eps, a->momentum, a->running_mean, a->running_var,
                      a->num_batches_tracked, a->mean, a->invstd, a->scale, a->shift, a->count, a->count_unit);
   return ok_or(hipGetLastError());
@@ -808,7 +809,7 @@ int bn_stats_finish_tiles(const float* partial, int nblk, long long per, long lo
 
 int bn_bwd_finish_tiles(const float* partial, int nblk, long long rows, int channels, const sg2im_bn_bwd* a,
                         hipStream_t stream) {
-  hipLaunchKernelGGL(bn_bwd_final_tiles_kernel, dim3((channels + 3) / 4), dim3(256), 0, stream, partial, nblk, rows, channels,
+  SG2IM_LAUNCH(bn_bwd_final_tiles_kernel, dim3((channels + 3) / 4), dim3(256), 0, stream, partial, nblk, rows, channels,
                      a->gamma, a->mean, a->invstd, a->training, a->dgamma, a->dbeta, a->accumulate, a->coef, a->count,
                      a->count_unit);
   return ok_or(hipGetLastError());
@@ -825,13 +826,13 @@ int bn_bwd_standalone(const float* g, long long ld_g, int pool2, int batch, int 
   const bool v4 = channels % 4 == 0 && ld_g % 4 == 0 && a->ld_y % 4 == 0 && al16(g) && al16(a->y) &&
                   al16(a->partial) && al16(a->mean) && al16(a->invstd) && al16(a->scale) && al16(a->shift);
   if (v4)
-    hipLaunchKernelGGL(bn_bwd_partial_v4_kernel, dim3(nblk), dim3(256), 8 * 256 * sizeof(float), stream, gs, a->y, a->ld_y,
+    SG2IM_LAUNCH(bn_bwd_partial_v4_kernel, dim3(nblk), dim3(256), 8 * 256 * sizeof(float), stream, gs, a->y, a->ld_y,
                        rows, channels, a->mean, a->invstd, a->scale, a->shift, a->slope, a->partial, a->count, a->count_unit);
   else
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk), dim3(256), 2 * 256 * sizeof(float), stream, gs, a->y, a->ld_y, rows,
+    SG2IM_LAUNCH(bn_bwd_partial_kernel, dim3(nblk), dim3(256), 2 * 256 * sizeof(float), stream, gs, a->y, a->ld_y, rows,
                        channels, a->mean, a->invstd, a->scale, a->shift, a->slope, a->partial, a->count, a->count_unit);
   if (hipGetLastError() != hipSuccess) return SG2IM_ERR_HIP;
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((channels + 3) / 4), dim3(256), 0, stream, a->partial, nblk, rows, channels,
+  SG2IM_LAUNCH(bn_bwd_final_kernel, dim3((channels + 3) / 4), dim3(256), 0, stream, a->partial, nblk, rows, channels,
                      a->gamma, a->mean, a->invstd, a->training, a->dgamma, a->dbeta, a->accumulate, a->coef, a->count,
                      a->count_unit);
   return ok_or(hipGetLastError());
@@ -855,13 +856,13 @@ int sg2im_bn_stats(const float* x, long long rows, int channels, long long ld, c
   if (training) {
     nblk = red_blocks(rows);
     if (channels % 4 == 0 && ld % 4 == 0 && al16(x) && al16(partial))
-      hipLaunchKernelGGL(bn_stats_partial_v4_kernel, dim3(nblk), dim3(256), 8 * 256 * sizeof(float), stream, x, rows,
+      SG2IM_LAUNCH(bn_stats_partial_v4_kernel, dim3(nblk), dim3(256), 8 * 256 * sizeof(float), stream, x, rows,
                          channels, ld, partial, count, count_unit);
     else
-      hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nblk), dim3(256), 2 * 256 * sizeof(float), stream, x, rows,
+      SG2IM_LAUNCH(bn_stats_partial_kernel, dim3(nblk), dim3(256), 2 * 256 * sizeof(float), stream, x, rows,
                          channels, ld, partial, count, count_unit);
   }
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((channels + 3) / 4), dim3(256), 0, stream, x, partial, nblk, rows,
+  SG2IM_LAUNCH(bn_stats_final_kernel, dim3((channels + 3) / 4), dim3(256), 0, stream, x, partial, nblk, rows,
                      unbiased_rows, channels, gamma, beta, eps, momentum, training, running_mean, running_var,
                      num_batches_tracked, mean, invstd, scale, shift, count, count_unit);
   return ok_or(hipGetLastError());
@@ -896,10 +897,10 @@ int sg2im_bn_backward_apply(const float* g, long long ld_g, int pool2, int batch
   const bool v4 = channels % 4 == 0 && ld_g % 4 == 0 && ld_y % 4 == 0 && al16(g) && al16(y) && al16(dy) &&
                   al16(scale) && al16(shift) && al16(coef);
   if (v4)
-    hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(ew_blocks(rows * channels / 4)), dim3(256), 0, stream, gs, y, ld_y,
+    SG2IM_LAUNCH(bn_bwd_apply_v4_kernel, dim3(ew_blocks(rows * channels / 4)), dim3(256), 0, stream, gs, y, ld_y,
                        rows, channels, scale, shift, slope, coef, dy, count, count_unit);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(rows * channels)), dim3(256), 0, stream, gs, y, ld_y, rows,
+    SG2IM_LAUNCH(bn_bwd_apply_kernel, dim3(ew_blocks(rows * channels)), dim3(256), 0, stream, gs, y, ld_y, rows,
                        channels, scale, shift, slope, coef, dy, count, count_unit);
   return ok_or(hipGetLastError());
 }
@@ -912,10 +913,10 @@ int sg2im_act_backward(const float* g, long long ld_g, int pool2, int batch, int
   if (rows == 0) return SG2IM_OK;
   const GradSrc gs{g, ld_g, pool2, h, w};
   if (channels % 4 == 0 && ld_g % 4 == 0 && ld_y % 4 == 0 && al16(g) && al16(y) && al16(dx))
-    hipLaunchKernelGGL(act_bwd_v4_kernel, dim3(ew_blocks(rows * channels / 4)), dim3(256), 0, stream, gs, y, ld_y, rows,
+    SG2IM_LAUNCH(act_bwd_v4_kernel, dim3(ew_blocks(rows * channels / 4)), dim3(256), 0, stream, gs, y, ld_y, rows,
                        channels, slope, dx);
   else
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(rows * channels)), dim3(256), 0, stream, gs, y, ld_y, rows,
+    SG2IM_LAUNCH(act_bwd_kernel, dim3(ew_blocks(rows * channels)), dim3(256), 0, stream, gs, y, ld_y, rows,
                        channels, slope, dx);
   return ok_or(hipGetLastError());
 }
@@ -926,10 +927,10 @@ int sg2im_affine_act_forward(const float* x, long long ld_x, long long rows, int
   if (!x || !scale || !shift || !out || channels < 1 || rows < 0) return SG2IM_ERR_ARG;
   if (rows == 0) return SG2IM_OK;
   if (channels % 4 == 0 && ld_x % 4 == 0 && ld_out % 4 == 0 && al16(x) && al16(out) && al16(scale) && al16(shift))
-    hipLaunchKernelGGL(affine_act_v4_kernel, dim3(ew_blocks(rows * channels / 4)), dim3(256), 0, stream, x, ld_x, rows,
+    SG2IM_LAUNCH(affine_act_v4_kernel, dim3(ew_blocks(rows * channels / 4)), dim3(256), 0, stream, x, ld_x, rows,
                        channels, scale, shift, slope, out, ld_out);
   else
-    hipLaunchKernelGGL(affine_act_kernel, dim3(ew_blocks(rows * channels)), dim3(256), 0, stream, x, ld_x, rows, channels,
+    SG2IM_LAUNCH(affine_act_kernel, dim3(ew_blocks(rows * channels)), dim3(256), 0, stream, x, ld_x, rows, channels,
                        scale, shift, slope, out, ld_out);
   return ok_or(hipGetLastError());
 }
@@ -938,7 +939,7 @@ int sg2im_instnorm_stats(const float* x, int batch, int hw, int channels, float 
                          hipStream_t stream) {
   if (!x || !scale || !shift || batch < 0 || hw < 1 || channels < 1) return SG2IM_ERR_ARG;
   if (batch == 0) return SG2IM_OK;
-  hipLaunchKernelGGL(instnorm_stats_kernel, dim3((channels + 63) / 64, batch), dim3(kInRows * 64), 0, stream, x, hw,
+  SG2IM_LAUNCH(instnorm_stats_kernel, dim3((channels + 63) / 64, batch), dim3(kInRows * 64), 0, stream, x, hw,
                      channels, eps, scale, shift);
   return ok_or(hipGetLastError());
 }
@@ -948,7 +949,7 @@ int sg2im_instnorm_act_forward(const float* x, int batch, int hw, int channels, 
   if (!x || !scale || !shift || !out || batch < 0 || hw < 1 || channels < 1) return SG2IM_ERR_ARG;
   const long long total = (long long)batch * hw * channels;
   if (total == 0) return SG2IM_OK;
-  hipLaunchKernelGGL(instnorm_act_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, x, total, hw, channels, scale,
+  SG2IM_LAUNCH(instnorm_act_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, x, total, hw, channels, scale,
                      shift, slope, out);
   return ok_or(hipGetLastError());
 }
@@ -957,7 +958,7 @@ int sg2im_instnorm_backward(const float* dyn, const float* x, int batch, int hw,
                             const float* shift, float* dx, hipStream_t stream) {
   if (!dyn || !x || !scale || !shift || !dx || batch < 0 || hw < 1 || channels < 1) return SG2IM_ERR_ARG;
   if (batch == 0) return SG2IM_OK;
-  hipLaunchKernelGGL(instnorm_backward_kernel, dim3((channels + 63) / 64, batch), dim3(kInRows * 64), 0, stream, dyn,
+  SG2IM_LAUNCH(instnorm_backward_kernel, dim3((channels + 63) / 64, batch), dim3(kInRows * 64), 0, stream, dyn,
                      x, hw, channels, scale, shift, dx);
   return ok_or(hipGetLastError());
 }
@@ -967,7 +968,7 @@ int sg2im_resample_nearest_up(const float* x, int batch, int h, int w, int chann
   if (!x || !out || factor < 1 || out_h < 0 || out_w < 0 || channels < 1) return SG2IM_ERR_ARG;
   const long long total = (long long)batch * out_h * out_w * channels;
   if (total == 0) return SG2IM_OK;
-  hipLaunchKernelGGL(resample_up_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, x, batch, h, w, channels, factor,
+  SG2IM_LAUNCH(resample_up_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, x, batch, h, w, channels, factor,
                      out_h, out_w, alpha, out);
   return ok_or(hipGetLastError());
 }
@@ -977,7 +978,7 @@ int sg2im_pool_sum_forward(const float* x, int batch, int h, int w, int channels
   if (!x || !out || factor < 1 || channels < 1) return SG2IM_ERR_ARG;
   const long long total = (long long)batch * (h / factor) * (w / factor) * channels;
   if (total == 0) return SG2IM_OK;
-  hipLaunchKernelGGL(pool_sum_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, x, batch, h, w, channels, factor,
+  SG2IM_LAUNCH(pool_sum_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, x, batch, h, w, channels, factor,
                      alpha, out);
   return ok_or(hipGetLastError());
 }
@@ -987,7 +988,7 @@ int sg2im_maxpool_forward(const float* x, int batch, int h, int w, int channels,
   if (!x || !out || factor < 1 || channels < 1) return SG2IM_ERR_ARG;
   const long long total = (long long)batch * (h / factor) * (w / factor) * channels;
   if (total == 0) return SG2IM_OK;
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, x, batch, h, w, channels, factor,
+  SG2IM_LAUNCH(maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, x, batch, h, w, channels, factor,
                      out);
   return ok_or(hipGetLastError());
 }
@@ -997,7 +998,7 @@ int sg2im_maxpool_backward(const float* x, const float* dy, int batch, int h, in
   if (!x || !dy || !dx || factor < 1 || channels < 1) return SG2IM_ERR_ARG;
   const long long total = (long long)batch * h * w * channels;
   if (total == 0) return SG2IM_OK;
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, x, dy, batch, h, w, channels,
+  SG2IM_LAUNCH(maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, x, dy, batch, h, w, channels,
                      factor, dx);
   return ok_or(hipGetLastError());
 }
@@ -1005,14 +1006,14 @@ int sg2im_maxpool_backward(const float* x, const float* dy, int batch, int h, in
 int sg2im_leaky_forward(const float* x, long long n, float slope, float* out, hipStream_t stream) {
   if (!x || !out || n < 0) return SG2IM_ERR_ARG;
   if (n == 0) return SG2IM_OK;
-  hipLaunchKernelGGL(leaky_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, x, n, slope, out);
+  SG2IM_LAUNCH(leaky_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, x, n, slope, out);
   return ok_or(hipGetLastError());
 }
 
 int sg2im_add_forward(const float* a, const float* b, long long n, float* out, hipStream_t stream) {
   if (!a || !b || !out || n < 0) return SG2IM_ERR_ARG;
   if (n == 0) return SG2IM_OK;
-  hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, a, b, n, out);
+  SG2IM_LAUNCH(add_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, a, b, n, out);
   return ok_or(hipGetLastError());
 }
 
@@ -1022,10 +1023,10 @@ int sg2im_avgpool_forward(const float* x, int batch, int h, int w, int channels,
   const long long total = (long long)batch * (h / factor) * (w / factor) * channels;
   if (total == 0) return SG2IM_OK;
   if (channels % 4 == 0 && al16(x) && al16(out))
-    hipLaunchKernelGGL(avgpool_v4_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, stream, x, batch, h, w, channels,
+    SG2IM_LAUNCH(avgpool_v4_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, stream, x, batch, h, w, channels,
                        factor, out);
   else
-    hipLaunchKernelGGL(avgpool_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, x, batch, h, w, channels, factor, out);
+    SG2IM_LAUNCH(avgpool_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, x, batch, h, w, channels, factor, out);
   return ok_or(hipGetLastError());
 }
 
@@ -1046,10 +1047,10 @@ int sg2im_pyramid_backward(const float* const* dlevels, const int* factors, cons
   bool v4 = channels % 4 == 0 && ld_out % 4 == 0 && al16(dlayout);
   for (int l = 0; l < n_levels; ++l) v4 = v4 && lds[l] % 4 == 0 && al16(dlevels[l]);
   if (v4)
-    hipLaunchKernelGGL(pyramid_bwd_v4_kernel, dim3((unsigned)(batch * h)), dim3(256), 0, stream, a, batch, h, w,
+    SG2IM_LAUNCH(pyramid_bwd_v4_kernel, dim3((unsigned)(batch * h)), dim3(256), 0, stream, a, batch, h, w,
                        channels, dlayout, ld_out);
   else
-    hipLaunchKernelGGL(pyramid_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, a, batch, h, w, channels,
+    SG2IM_LAUNCH(pyramid_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, a, batch, h, w, channels,
                        dlayout, ld_out);
   return ok_or(hipGetLastError());
 }
@@ -1059,7 +1060,7 @@ int sg2im_nchw_to_nhwc(const float* src, int batch, int channels, int h, int w, 
   if (!src || !dst) return SG2IM_ERR_ARG;
   const long long total = (long long)batch * channels * h * w;
   if (total == 0) return SG2IM_OK;
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, src, batch, channels, h, w,
+  SG2IM_LAUNCH(nchw_to_nhwc_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, src, batch, channels, h, w,
                      dst, ld_dst, c_offset);
   return ok_or(hipGetLastError());
 }
@@ -1069,7 +1070,7 @@ int sg2im_nhwc_to_nchw(const float* src, long long ld_src, int c_offset, int bat
   if (!src || !dst) return SG2IM_ERR_ARG;
   const long long total = (long long)batch * channels * h * w;
   if (total == 0) return SG2IM_OK;
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, src, ld_src, c_offset, batch,
+  SG2IM_LAUNCH(nhwc_to_nchw_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, src, ld_src, c_offset, batch,
                      channels, h, w, dst);
   return ok_or(hipGetLastError());
 }
@@ -1077,7 +1078,7 @@ int sg2im_nhwc_to_nchw(const float* src, long long ld_src, int c_offset, int bat
 int sg2im_gap_forward(const float* x, int batch, int hw, int channels, float* out, hipStream_t stream) {
   if (!x || !out || hw < 1) return SG2IM_ERR_ARG;
   if (batch * channels == 0) return SG2IM_OK;
-  hipLaunchKernelGGL(gap_fwd_kernel, dim3((batch * channels + 255) / 256), dim3(256), 0, stream, x, batch, hw, channels, out);
+  SG2IM_LAUNCH(gap_fwd_kernel, dim3((batch * channels + 255) / 256), dim3(256), 0, stream, x, batch, hw, channels, out);
   return ok_or(hipGetLastError());
 }
 
@@ -1085,21 +1086,21 @@ int sg2im_gap_backward(const float* dout, int batch, int hw, int channels, float
   if (!dout || !dx || hw < 1) return SG2IM_ERR_ARG;
   const long long total = (long long)batch * hw * channels;
   if (total == 0) return SG2IM_OK;
-  hipLaunchKernelGGL(gap_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, dout, batch, hw, channels, dx);
+  SG2IM_LAUNCH(gap_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, stream, dout, batch, hw, channels, dx);
   return ok_or(hipGetLastError());
 }
 
 int sg2im_sigmoid_forward(const float* x, long long n, float* y, hipStream_t stream) {
   if (!x || !y) return SG2IM_ERR_ARG;
   if (n == 0) return SG2IM_OK;
-  hipLaunchKernelGGL(sigmoid_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, x, n, y);
+  SG2IM_LAUNCH(sigmoid_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, x, n, y);
   return ok_or(hipGetLastError());
 }
 
 int sg2im_sigmoid_backward(const float* y, const float* dy, long long n, float* dx, hipStream_t stream) {
   if (!y || !dy || !dx) return SG2IM_ERR_ARG;
   if (n == 0) return SG2IM_OK;
-  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, y, dy, n, dx);
+  SG2IM_LAUNCH(sigmoid_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, y, dy, n, dx);
   return ok_or(hipGetLastError());
 }
 
@@ -1112,12 +1113,12 @@ int sg2im_column_sum(const float* x, long long rows, int cols, long long ld, flo
   }
   const int nblk = red_blocks(rows);
   if (cols % 4 == 0 && ld % 4 == 0 && al16(x) && al16(partial))
-    hipLaunchKernelGGL(colsum_partial_v4_kernel, dim3(nblk), dim3(256), 8 * 256 * sizeof(float), stream, x, rows, cols, ld,
+    SG2IM_LAUNCH(colsum_partial_v4_kernel, dim3(nblk), dim3(256), 8 * 256 * sizeof(float), stream, x, rows, cols, ld,
                        partial);
   else
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 2 * 256 * sizeof(float), stream, x, rows, cols, ld,
+    SG2IM_LAUNCH(colsum_partial_kernel, dim3(nblk), dim3(256), 2 * 256 * sizeof(float), stream, x, rows, cols, ld,
                        partial);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 3) / 4), dim3(256), 0, stream, partial, nblk, cols, out, accumulate);
+  SG2IM_LAUNCH(colsum_final_kernel, dim3((cols + 3) / 4), dim3(256), 0, stream, partial, nblk, cols, out, accumulate);
   return ok_or(hipGetLastError());
 }
 

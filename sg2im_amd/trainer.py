@@ -119,6 +119,7 @@ class Trainer(object):
     self.bucketer = Bucketer(*bucket) if bucket else None
     self.max_graphs = max_graphs
     self.graph_stats = {'captures': 0, 'replays': 0, 'invalidated': 0, 'evicted': 0}
+    self.launch_stats = {}          # kernels per captured iteration (set by the last capture)
     self._cap_stream = None
     # single-GPU graph mode: capture the whole iteration as ONE graph in which the two
     # discriminator steps run on a side stream concurrently with the generator's backward
@@ -432,6 +433,8 @@ class Trainer(object):
     segmented = dp and self.dp_schedule == 1
     torch.cuda.synchronize()
     _lib.CAPTURING = True
+    lib = _lib.load()
+    n0, g0 = lib.sg2im_launch_count(0), lib.sg2im_launch_count(1)
     try:
       if self.overlap_d and not segmented:
         graphs = self._capture_overlapped(static, st, dp)
@@ -452,6 +455,10 @@ class Trainer(object):
           self.reducer.mute = mute
     finally:
       _lib.CAPTURING = False
+    # kernels of this library in one captured iteration (torch's own - batch staging, layout noise, arena
+    # zeroing - not counted): all / implicit-GEMM family incl. split-K finishes
+    self.launch_stats = {'launches_per_step': int(lib.sg2im_launch_count(0) - n0),
+                         'gemm_launches_per_step': int(lib.sg2im_launch_count(1) - g0)}
     return (sb, graphs, st, _lib.EAGER_EPOCH)
 
   def _exchange_all(self, st):
