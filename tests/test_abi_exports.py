@@ -15,7 +15,7 @@ def declared_functions():
   src = open(HEADER).read()
   src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
   out = {}
-  for m in re.finditer(r'\b(?:int|size_t)\s+(sg2im_\w+)\s*\(([^;]*?)\)\s*;', src, flags=re.S):
+  for m in re.finditer(r'\b(?:int|size_t|unsigned long long)\s+(sg2im_\w+)\s*\(([^;]*?)\)\s*;', src, flags=re.S):
     args = m.group(2).strip()
     n = 0 if args in ('', 'void') else len([a for a in args.split(',') if a.strip()])
     out[m.group(1)] = n
