@@ -1587,6 +1587,7 @@ static bool halo_plan(int NB, int H, int W, int ncols, int nchunks, size_t ws_by
     ns = (nchunks + per - 1) / per;
   }
   pl->nsplit = std::max(1, ns);
+  if (g_plan_debug) fprintf(stderr, "[sg2im halo] M=%lld N=%d chunks=%d -> patch %dx%d bn=%d x%d\n", M, ncols, nchunks, pl->rt, pl->ct, pl->bn, pl->nsplit);
   return true;
 }
 

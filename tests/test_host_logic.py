@@ -194,14 +194,16 @@ def test_launch_planner_choices_are_valid_without_a_gpu():
   """The launch planner is host code inside libsg2im_hip.so: tools/plan_dump.py drives the three conv entry
   points with dummy pointers (the launches themselves fail without a GPU) and SG2IM_PLAN_DEBUG prints the
   chosen tile / split-K per layer.  Every plan must use one of the four tiles, a split count within the
-  reduction length, and the big CRN layers must not fall back to the 64x64 tile."""
+  reduction length, and the big CRN layers must not fall back to the 64x64 tile; the 3x3 stride-1 layers on maps
+  of 16x16 and larger take the halo'd-tile kernels (csrc/conv_halo.h) forward and in the data gradient: a 128-pixel
+  patch, 64- or 128-wide column tiles, split-K over whole 32-channel chunks."""
   import re
   import subprocess
   import sys
   tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools')
   out = subprocess.run([sys.executable, os.path.join(tools, 'plan_dump.py')], cwd=tools, capture_output=True,
                        text=True, timeout=300).stderr
-  plans = {}
+  plans, halo = {}, {}
   cur = None
   for line in out.splitlines():
     m = re.match(r'== (\S+) (\S+)', line)
@@ -210,14 +212,23 @@ def test_launch_planner_choices_are_valid_without_a_gpu():
     m = re.match(r'\[sg2im plan\] M=(\d+) N=(\d+) iters=(\d+) -> (\d+)x(\d+) x(\d+)', line)
     if m and cur:
       plans[cur] = tuple(int(v) for v in m.groups())
-  assert len(plans) >= 60, len(plans)
+    m = re.match(r'\[sg2im halo\] M=(\d+) N=(\d+) chunks=(\d+) -> patch (\d+)x(\d+) bn=(\d+) x(\d+)', line)
+    if m and cur:
+      halo[cur] = tuple(int(v) for v in m.groups())
+  assert len(plans) + len(halo) >= 60, (len(plans), len(halo))
   for (layer, what), (M, N, iters, bm, bn, ns) in plans.items():
     assert (bm, bn) in ((128, 128), (128, 64), (64, 64), (64, 128)), (layer, what, bm, bn)
     assert 1 <= ns <= max(1, iters), (layer, what, ns, iters)
+  for (layer, what), (M, N, chunks, rt, ct, bn, ns) in halo.items():
+    assert (rt, ct) in ((8, 16), (4, 32), (2, 64)) and bn in (64, 128) and 1 <= ns <= chunks and M % 128 == 0, (layer, what)
+    assert what in ('fwd', 'dgrad')
+  for layer in ('m2.conv0', 'm3.conv0', 'm4.conv0', 'm4.conv1', 'out.conv0', 'mask.c3'):
+    assert (layer, 'fwd') in halo and (layer, 'dgrad') in halo, layer
   for layer in ('m1.conv0', 'm2.conv0', 'm3.conv0', 'm4.conv0'):
     for what in ('fwd', 'dgrad', 'wgrad'):
-      bm, bn = plans[(layer, what)][3:5]
-      assert bm * bn > 64 * 64, (layer, what, bm, bn)
+      if (layer, what) not in halo:
+        bm, bn = plans[(layer, what)][3:5]
+        assert bm * bn > 64 * 64, (layer, what, bm, bn)
 
 
 def test_bucketing_pads_with_neutral_rows():
