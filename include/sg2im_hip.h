@@ -231,6 +231,43 @@ int sg2im_gconv_pool_backward(const float* d_pooled, long long ld_dp, const long
                               const long long* o_idx, int n_triples, const int* row_ptr, const float* g_pred,
                               long long ld_gp, const float* new_t, long long ld_nt, int hidden, int dout,
                               float slope, float* d_new_t, long long ld_out, hipStream_t stream);
+/* One whole GraphTripleConv layer (sg2im/graph.py:56-120) per call: the launch sequence of the entry points above -
+ *   forward : gather + concat folded into net1's first GEMM (row-gathered sources), net1 (Linear-ReLU-Linear-ReLU),
+ *             CSR pooling (sum / avg, the reference's accumulation order, bit-exact), net2;
+ *   backward: the mirror image; the pooling backward + ReLU of net1's output is one launch, the four weight
+ *             (+ bias) gradients are ONE grouped launch + one finish (sg2im_conv2d_backward_weight_group)
+ * on `stream`, with caller-owned activation / scratch buffers (nothing is allocated, no state is kept).
+ * Shapes: obj_vecs [n_objs][din], pred_vecs [n_triples][din]; w1a [hidden][3 din], w1b [2 hidden + dout][hidden],
+ * w2a [hidden][hidden], w2b [dout][hidden] (nn.Linear layout, graph.py:60-71); h1 [T][hidden],
+ * new_t [T][2 hidden + dout] (activated net1 output: columns [0, hidden) feed the subjects' pool,
+ * [hidden, hidden + dout) ARE new_pred_vecs, the rest feeds the objects' pool), pooled / h2 [O][hidden],
+ * new_obj [O][dout].  row_ptr / entries: sg2im_csr_build(s_idx, T, o_idx, T, n_objs, ...). */
+typedef struct sg2im_gconv_layer {
+  const float* obj_vecs; long long ld_obj;
+  const float* pred_vecs; long long ld_pred;
+  const long long* s_idx; const long long* o_idx;
+  const int* row_ptr; const int* entries;
+  int n_objs, n_triples, din, hidden, dout;
+  int average;                         /* 1: 'avg' pooling (graph.py:101-112), 0: 'sum' */
+  const float *w1a, *b1a, *w1b, *b1b, *w2a, *b2a, *w2b, *b2b;
+} sg2im_gconv_layer;
+typedef struct sg2im_gconv_grads {     /* parameter gradients (any may be NULL = not wanted); += when accumulate */
+  float *dw1a, *db1a, *dw1b, *db1b, *dw2a, *db2a, *dw2b, *db2b;
+  int accumulate;
+} sg2im_gconv_grads;
+int sg2im_gconv_layer_forward(const sg2im_gconv_layer* layer, float* h1, float* new_t, float* pooled, float* h2,
+                              float* new_obj, float* workspace, size_t workspace_bytes, hipStream_t stream);
+/* g_obj [O][dout] (NULL = zeros), g_pred [T][>= dout] with row stride ld_gpred (NULL = zeros): gradients w.r.t.
+ * new_obj / new_pred_vecs.  d_triple [T][3 din] (out): gradient w.r.t. the gathered net1 input - its columns
+ * [din, 2 din) are the gradient w.r.t. pred_vecs; d_obj [O][din] (out, may be NULL): gradient w.r.t. obj_vecs.
+ * scratch: sg2im_gconv_layer_backward_scratch() bytes. */
+size_t sg2im_gconv_layer_backward_scratch(int n_objs, int n_triples, int din, int hidden, int dout);
+int sg2im_gconv_layer_backward(const sg2im_gconv_layer* layer, const float* h1, const float* new_t,
+                               const float* pooled, const float* h2, const float* new_obj, const float* g_obj,
+                               const float* g_pred, long long ld_gpred, float* d_triple, float* d_obj,
+                               const sg2im_gconv_grads* grads, float* scratch, size_t scratch_bytes,
+                               float* workspace, size_t workspace_bytes, hipStream_t stream);
+
 /* dst[r][0:width] = src[r][0:width] for strided row matrices (the new_p column slice of the
  * net1 output, graph.py:88, travelling through backward) */
 int sg2im_copy_2d(const float* src, long long ld_src, float* dst, long long ld_dst, long long rows,

@@ -45,6 +45,19 @@ class BnBwd(Structure):
               ('partial_floats', c_size_t), ('count', c_void_p), ('count_unit', c_int)]
 
 
+class GconvLayer(Structure):
+  """sg2im_gconv_layer (include/sg2im_hip.h)"""
+  _fields_ = [('obj_vecs', c_void_p), ('ld_obj', c_longlong), ('pred_vecs', c_void_p), ('ld_pred', c_longlong),
+              ('s_idx', c_void_p), ('o_idx', c_void_p), ('row_ptr', c_void_p), ('entries', c_void_p),
+              ('n_objs', c_int), ('n_triples', c_int), ('din', c_int), ('hidden', c_int), ('dout', c_int),
+              ('average', c_int)] + [(k, c_void_p) for k in ('w1a', 'b1a', 'w1b', 'b1b', 'w2a', 'b2a', 'w2b', 'b2b')]
+
+
+class GconvGrads(Structure):
+  """sg2im_gconv_grads (include/sg2im_hip.h)"""
+  _fields_ = [(k, c_void_p) for k in ('dw1a', 'db1a', 'dw1b', 'db1b', 'dw2a', 'db2a', 'dw2b', 'db2b')] + [('accumulate', c_int)]
+
+
 _P, _I, _L, _F, _Z = c_void_p, c_int, c_longlong, c_float, c_size_t
 _D = POINTER(ConvDesc)
 
@@ -67,6 +80,10 @@ _SIGNATURES = {
   'sg2im_gather_rows': [_P, _L, _P, _I, _I, _P, _P, _L, _P],
   'sg2im_gconv_pool_backward': [_P, _L, _P, _P, _I, _P, _P, _L, _P, _L, _I, _I, _F, _P, _L, _P],
   'sg2im_copy_2d': [_P, _L, _P, _L, _L, _I, _P],
+  'sg2im_gconv_layer_forward': [POINTER(GconvLayer), _P, _P, _P, _P, _P, _P, _Z, _P],
+  'sg2im_gconv_layer_backward_scratch': [_I, _I, _I, _I, _I],
+  'sg2im_gconv_layer_backward': [POINTER(GconvLayer), _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, POINTER(GconvGrads), _P, _Z,
+                                 _P, _Z, _P],
   'sg2im_layout_forward': [_P, _L, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P],
   'sg2im_layout_backward_workspace': [_I, _I, _I, _I],
   'sg2im_layout_backward': [_P, _L, _P, _L, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P,
@@ -109,7 +126,7 @@ _SIGNATURES = {
   'sg2im_adam_step_guarded': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P, _P],
 }
 _RESTYPE = {'sg2im_layout_backward_workspace': c_size_t, 'sg2im_crop_backward_workspace': c_size_t,
-            'sg2im_launch_count': ctypes.c_ulonglong}
+            'sg2im_launch_count': ctypes.c_ulonglong, 'sg2im_gconv_layer_backward_scratch': c_size_t}
 EXPORTS = tuple(sorted(_SIGNATURES))
 
 _lib = None

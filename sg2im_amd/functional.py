@@ -368,7 +368,8 @@ class Embedding(Function):
 
 class GraphTripleConvFn(Function):
   """One GraphTripleConv layer (reference sg2im/graph.py:56-120): gather+concat folded into
-  the net1 GEMM, deterministic CSR pooling, net2."""
+  the net1 GEMM, deterministic CSR pooling, net2 - one call into the library per direction
+  (sg2im_gconv_layer_forward / _backward), which runs the layer's launch sequence."""
 
   @staticmethod
   def forward(ctx, obj_vecs, pred_vecs, s_idx, o_idx, csr, avg, W1a, b1a, W1b, b1b, W2a, b2a, W2b, b2b):
@@ -379,14 +380,10 @@ class GraphTripleConvFn(Function):
       obj_vecs = obj_vecs.contiguous()
     if pred_vecs.size(0) > 0 and pred_vecs.stride(1) != 1:
       pred_vecs = pred_vecs.contiguous()
-    d1 = conv_desc([rows_src(obj_vecs, s_idx), rows_src(pred_vecs), rows_src(obj_vecs, o_idx)], T, 1, 1)
-    h1 = ops.conv2d_forward(d1, W1a, H, b1a, _new(obj_vecs, T, H), H, 0.0)
-    new_t = ops.conv2d_forward(conv_desc([rows_src(h1)], T, 1, 1), W1b, NT, b1b, _new(obj_vecs, T, NT), NT, 0.0)
-    pooled = _new(obj_vecs, O, H)
-    ops.segment_sum(new_t[:, :H], new_t[:, H + Dout:], csr, H, avg, pooled)
-    h2 = ops.conv2d_forward(conv_desc([rows_src(pooled)], O, 1, 1), W2a, H, b2a, _new(obj_vecs, O, H), H, 0.0)
-    new_obj = ops.conv2d_forward(conv_desc([rows_src(h2)], O, 1, 1), W2b, Dout, b2b, _new(obj_vecs, O, Dout),
-                                 Dout, 0.0)
+    L = ops._gconv_layer_struct(obj_vecs, pred_vecs, s_idx, o_idx, csr, avg, (W1a, b1a, W1b, b1b, W2a, b2a, W2b, b2b))
+    h1, new_t = _new(obj_vecs, T, H), _new(obj_vecs, T, NT)
+    pooled, h2, new_obj = _new(obj_vecs, O, H), _new(obj_vecs, O, H), _new(obj_vecs, O, Dout)
+    ops.gconv_layer_forward(L, h1, new_t, pooled, h2, new_obj)
     ctx.save_for_backward(obj_vecs, pred_vecs, s_idx, o_idx, W1a, W1b, W2a, W2b, h1, new_t, pooled, h2, new_obj,
                           b1a, b1b, b2a, b2b)
     ctx.csr, ctx.avg = csr, avg
@@ -397,41 +394,26 @@ class GraphTripleConvFn(Function):
     (obj_vecs, pred_vecs, s_idx, o_idx, W1a, W1b, W2a, W2b, h1, new_t, pooled, h2, new_obj,
      b1a, b1b, b2a, b2b) = ctx.saved_tensors
     csr, avg = ctx.csr, ctx.avg
-    T, O = pred_vecs.size(0), obj_vecs.size(0)
-    Din, H, Dout = obj_vecs.size(1), W2a.size(0), W2b.size(0)
-    NT = W1b.size(0)
+    T, O, Din = pred_vecs.size(0), obj_vecs.size(0), obj_vecs.size(1)
     ni = ctx.needs_input_grad
-    z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=obj_vecs.device)
-    # the four weight gradients are leaves: queued, and issued as ONE grouped launch (+ one finish) at the end
-    # instead of 4 + 4 launches in between the dependent data gradients
-    grp = [] if ops.GROUP_WGRAD else None
-    # net2
-    if g_obj is None:
-      g_obj = z(O, Dout)
-    dp4 = _act_bwd_rows(g_obj, new_obj, 0.0)
-    dh2, dW2b, db2b = _linear_bwd(conv_desc([rows_src(h2)], O, 1, 1), W2b, dp4, True, ni[12], ni[13], H, b2b, grp)
-    dp3 = _act_bwd_rows(dh2, h2, 0.0)
-    dpooled, dW2a, db2a = _linear_bwd(conv_desc([rows_src(pooled)], O, 1, 1), W2a, dp3, True, ni[10], ni[11], H, b2a,
-                                      grp)
-    # pooling backward: rows of dpooled go back to the s / o column blocks (divided by the count)
-    # (one launch: the two row gathers, the copy of g_pred into the middle block and the ReLU backward of
-    # net1's output)
-    d_new_t = _new(obj_vecs, T, NT)
-    dp2 = ops.gconv_pool_backward(dpooled, s_idx, o_idx, csr if avg else None,
-                                  None if g_pred is None else g_pred.contiguous(), new_t, H, Dout, 0.0, d_new_t)
-    # net1
-    dh1, dW1b, db1b = _linear_bwd(conv_desc([rows_src(h1)], T, 1, 1), W1b, dp2, True, ni[8], ni[9], H, b1b, grp)
-    dp1 = _act_bwd_rows(dh1, h1, 0.0)
-    d1 = conv_desc([rows_src(obj_vecs, s_idx), rows_src(pred_vecs), rows_src(obj_vecs, o_idx)], T, 1, 1)
-    need_dx = ni[0] or ni[1]
-    dX, dW1a, db1a = _linear_bwd(d1, W1a, dp1, need_dx, ni[6], ni[7], 3 * Din, b1a, grp)
-    d_obj = d_pred = None
-    if ni[0]:
-      d_obj = ops.segment_sum(dX[:, :Din], dX[:, 2 * Din:], csr, Din, False, _new(obj_vecs, O, Din))
-    if ni[1]:
-      d_pred = dX[:, Din:2 * Din]
-    _flush_wgrad_group(grp)
-    return (d_obj, d_pred, None, None, None, None, dW1a, db1a, dW1b, db1b, dW2a, db2a, dW2b, db2b)
+    params = (W1a, b1a, W1b, b1b, W2a, b2a, W2b, b2b)
+    need = ni[6:14]
+    # parameter gradients: straight into the registered gradient sinks (accumulate), or into fresh tensors
+    sinks = [_sink(p) if n else None for p, n in zip(params, need)]
+    use_sinks = all((not n) or (sk is not None) for n, sk in zip(need, sinks))
+    if use_sinks:
+      bufs, ret = sinks, [None] * 8
+    else:
+      bufs = [torch.empty_like(p) if n else None for p, n in zip(params, need)]
+      ret = bufs
+    L = ops._gconv_layer_struct(obj_vecs, pred_vecs, s_idx, o_idx, csr, avg, params)
+    d_triple = _new(obj_vecs, T, 3 * Din)
+    d_obj = _new(obj_vecs, O, Din) if ni[0] else None
+    ops.gconv_layer_backward(L, h1, new_t, pooled, h2, new_obj, None if g_obj is None else g_obj.contiguous(),
+                             None if g_pred is None else (g_pred if g_pred.stride(1) == 1 else g_pred.contiguous()),
+                             d_triple, d_obj, bufs, use_sinks)
+    d_pred = d_triple[:, Din:2 * Din] if ni[1] else None
+    return (d_obj, d_pred, None, None, None, None) + tuple(ret)
 
 
 class RelAux(Function):

@@ -12,7 +12,7 @@ from ctypes import byref, c_int, c_longlong, c_void_p
 import torch
 
 from . import _lib
-from ._lib import BnBwd, BnFwd, ConvDesc, call
+from ._lib import BnBwd, BnFwd, ConvDesc, GconvGrads, GconvLayer, call
 
 WORKSPACE_BYTES = 256 << 20      # split-K partials / layout-backward partials
 _ws = {}
@@ -419,6 +419,55 @@ def gconv_pool_backward(dpooled, s_idx, o_idx, csr_for_average, g_pred, new_t, h
   call('sg2im_gconv_pool_backward', pd, ldd, _i64(s_idx), _i64(o_idx), s_idx.numel(), rp, pg, ldg, pn, ldn,
        int(hidden), int(dout), float(slope), po, ldo, _stream())
   return out
+
+
+def _gconv_layer_struct(obj_vecs, pred_vecs, s_idx, o_idx, csr, avg, weights):
+  """weights: (W1a, b1a, W1b, b1b, W2a, b2a, W2b, b2b)"""
+  L = GconvLayer()
+  po, ldo = rows_ld(obj_vecs)
+  T = pred_vecs.size(0)
+  L.obj_vecs, L.ld_obj = po.value, ldo
+  if T > 0:
+    pp, ldp = rows_ld(pred_vecs)
+    L.pred_vecs, L.ld_pred = pp.value, ldp
+    L.s_idx, L.o_idx = _i64(s_idx).value, _i64(o_idx).value
+  L.row_ptr, L.entries = csr.row_ptr.data_ptr(), csr.entries.data_ptr()
+  L.n_objs, L.n_triples, L.din = obj_vecs.size(0), T, obj_vecs.size(1)
+  L.hidden, L.dout, L.average = weights[4].size(0), weights[6].size(0), int(bool(avg))
+  for k, w in zip(('w1a', 'b1a', 'w1b', 'b1b', 'w2a', 'b2a', 'w2b', 'b2b'), weights):
+    setattr(L, k, _f(w).value if w is not None else None)
+  L._keep = (obj_vecs, pred_vecs, s_idx, o_idx, csr, weights)
+  return L
+
+
+def _gconv_flops(L):
+  T, O, H = L.n_triples, L.n_objs, L.hidden
+  return 2.0 * (T * (3 * L.din * H + H * (2 * H + L.dout)) + O * (H * H + H * L.dout))
+
+
+def gconv_layer_forward(L, h1, new_t, pooled, h2, new_obj):
+  """one GraphTripleConv layer, forward: ONE call into the library (sg2im_gconv_layer_forward)"""
+  ws = workspace(pooled.device)
+  _note_bytes('igemm_fwd', _gconv_flops(L) / 2.0 / max(L.n_triples + L.n_objs, 1))      # (weights dominate; rough)
+  _timed('igemm_fwd', _gconv_flops(L), lambda: call(
+    'sg2im_gconv_layer_forward', byref(L), _f(h1), _f(new_t), _f(pooled), _f(h2), _f(new_obj), _f(ws), ws.numel() * 4,
+    _stream()))
+
+
+def gconv_layer_backward(L, h1, new_t, pooled, h2, new_obj, g_obj, g_pred, d_triple, d_obj, grads, accumulate):
+  """grads: 8 tensors or None, in the order (dW1a, db1a, dW1b, db1b, dW2a, db2a, dW2b, db2b)"""
+  dev = pooled.device
+  ws = workspace(dev)
+  need = _lib.load().sg2im_gconv_layer_backward_scratch(L.n_objs, L.n_triples, L.din, L.hidden, L.dout)
+  sc = scratch(dev, need // 4 + 16)
+  G = GconvGrads()
+  for k, t in zip(('dw1a', 'db1a', 'dw1b', 'db1b', 'dw2a', 'db2a', 'dw2b', 'db2b'), grads):
+    setattr(G, k, _f(t).value if t is not None else None)
+  G.accumulate = int(bool(accumulate))
+  pg, ldg = rows_ld(g_pred) if g_pred is not None else (None, 0)
+  _timed('igemm_dgrad', 2.0 * _gconv_flops(L), lambda: call(
+    'sg2im_gconv_layer_backward', byref(L), _f(h1), _f(new_t), _f(pooled), _f(h2), _f(new_obj), _f(g_obj), pg, int(ldg),
+    _f(d_triple), _f(d_obj), byref(G), _f(sc), sc.numel() * 4, _f(ws), ws.numel() * 4, _stream()))
 
 
 def copy_2d(src, out):
