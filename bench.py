@@ -223,8 +223,14 @@ def main():
     exchange(0)
     ar_ms = timed(exchange, 10)
     trainer.reducer.mute = True
+    if trainer_graphs:                  # (graphs with the collectives recorded inside: re-captured without them)
+      trainer._graphs.clear()
+      for b in batches:
+        trainer.step(b)
     nocomm_ms = timed(lambda i: trainer.step(batches[i % nb]), max(8, args.steps // 2))
     trainer.reducer.mute = False
+    if trainer_graphs:
+      trainer._graphs.clear()
     step_ms = elapsed / args.steps * 1e3
     exposed = max(0.0, step_ms - nocomm_ms)
     payload = 4.0 * (trainer.flat_g.grad.numel() + (trainer.flat_di.grad.numel() if trainer.flat_di is not None else 0) +
@@ -235,7 +241,10 @@ def main():
             'overlap_frac': round(min(1.0, max(0.0, 1.0 - exposed / ar_ms)), 3) if ar_ms > 0 else None,
             'schedule': ('eager segments, exchanges started after each backward' if not trainer_graphs else
                          'graphs [G fwd+bwd | D_img] -> all-reduce(G, guard, D_img) || graph [D_obj step] -> all-reduce(D_obj) -> graph [3x Adam]'
-                         if os.environ.get('SG2IM_DP_SCHEDULE', '0') == '1' else
+                         if trainer.dp_schedule == 1 else
+                         'ONE graph with the RCCL all-reduces recorded inside: guard / D_img / D_obj right after their steps, the first two '
+                         'refinement modules (2/3 of the generator bytes) under the remaining weight gradients, the rest after the backward'
+                         if trainer.dp_schedule == 2 and trainer.reducer.capturable() else
                          'one iteration graph (D steps on a side stream) -> 4 all-reduces (exposed) -> Adam graph')}
   if use_dist:
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)

@@ -75,6 +75,17 @@ class GradReducer(object):
   def grad_scale(self):
     return 1.0 / self.world_size
 
+  def capturable(self):
+    """can the collectives be recorded into a hipGraph?  RCCL: yes (tools/rccl_capture_probe.py,
+    profiles/r3_rccl_capture_probe.log); the host-staged gloo form: no"""
+    return (self.world_size > 1 or self.force) and dist.is_initialized() and dist.get_backend(self.group) == 'nccl'
+
+  def reduce_here(self, tensor):
+    """SUM all-reduce of ``tensor`` ordered on the CURRENT stream (which waits for it; the collective itself
+    runs on the process group's own stream) - the form that is recorded into a stream capture"""
+    if (self.world_size > 1 or self.force) and not self.mute:
+      dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
+
   def start(self, tensor):
     """begin an all-reduce (SUM) of ``tensor`` in place; returns immediately"""
     if (self.world_size > 1 or self.force) and not self.mute:

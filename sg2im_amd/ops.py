@@ -65,6 +65,9 @@ def _i32(t):
 # profiles/r2_deferred_wgrad_ab.log]
 DEFER_WGRAD = True
 DEFERRED = None
+# (count, callback(stream)): called on the weight-gradient stream right after the first `count` released weight
+# gradients were issued - the data-parallel Trainer starts the all-reduce of the gradient bucket they complete
+AFTER_DEFERRED = None
 HINT_BACKGROUND = 1
 # only the first BG_COUNT released weight gradients are issued as background launches (occupancy cap): the later
 # ones run after the small-kernel tail is over and may have the whole GPU
@@ -140,6 +143,8 @@ class SideLane(object):
       # (the layers the data-gradient chain reached last first: 8.80 vs 8.84-8.85 ms in queue order)
       for k, fn in enumerate(reversed(self.queue)):
         fn(k < BG_COUNT)
+        if AFTER_DEFERRED is not None and k + 1 == AFTER_DEFERRED[0]:
+          AFTER_DEFERRED[1](self.side)       # (Trainer: the first gradient bucket is complete on this stream)
     self.queue = []
     self.used = True
 

@@ -111,9 +111,11 @@ class Trainer(object):
       if seed is not None:
         torch.cuda.manual_seed(seed * 1000003 + 7919 * (rank + 1))
     self.use_graphs = use_graphs
-    # data-parallel graph schedule (see _capture): 0 = one iteration graph, exchange, Adam graph;
-    # 1 = segmented, the D_obj step replayed while the generator's all-reduce is in flight
-    self.dp_schedule = int(os.environ.get('SG2IM_DP_SCHEDULE', '0')) if dp_schedule is None else int(dp_schedule)
+    # data-parallel graph schedule (see _capture): 2 (default with RCCL) = ONE graph with the all-reduces recorded
+    # inside it, bucketed and overlapped; 0 = one iteration graph, exchange, Adam graph; 1 = segmented, the D_obj
+    # step replayed while the generator's all-reduce is in flight
+    self.dp_schedule = int(os.environ.get('SG2IM_DP_SCHEDULE', '2')) if dp_schedule is None else int(dp_schedule)
+    self._comm = None
     if bucket == 'auto':
       bucket = (32, 64) if use_graphs else None
     self.bucketer = Bucketer(*bucket) if bucket else None
@@ -349,6 +351,8 @@ class Trainer(object):
       key = (idx, self._cap_stream.cuda_stream)
       if key not in ops._wgrad_streams:
         ops._wgrad_streams[key] = torch.cuda.Stream(device=idx)
+    if self._comm is None and (self.world_size > 1 or self.reducer.force):
+      self._comm = torch.cuda.Stream(device=idx)       # gradient exchange inside the captured iteration
     for s in (self._cap_stream, self._side[0], ops._wgrad_streams[(idx, self._cap_stream.cuda_stream)]):
       with torch.cuda.stream(s):
         ops.workspace(dev)
@@ -461,6 +465,22 @@ class Trainer(object):
                          'gemm_launches_per_step': int(lib.sg2im_launch_count(1) - g0)}
     return (sb, graphs, st, _lib.EAGER_EPOCH)
 
+  def _generator_bucket(self):
+    """(begin, end, n_weight_gradients): the slice of the generator's gradient arena that holds the first two
+    refinement modules, and how many deferred weight gradients complete it; None when the refinement network
+    has fewer than three modules or carries no BatchNorm (its backward then releases nothing early)"""
+    mods = getattr(self.model.refinement_net, 'refinement_modules', None)
+    if mods is None or len(mods) < 3 or self.model.refinement_net.normalization != 'batch':
+      return None
+    first = {id(p) for m in (mods[0], mods[1]) for p in m.parameters()}
+    offs = [(off, p.numel()) for p, off in zip(self.flat_g.params, self.flat_g.offsets) if id(p) in first]
+    a = min(o for o, _ in offs)
+    b = max(o + (n + 3) // 4 * 4 for o, n in offs)
+    inside = sum(1 for p, off in zip(self.flat_g.params, self.flat_g.offsets) if a <= off < b)
+    if inside != len(first):          # (not contiguous: keep one bucket)
+      return None
+    return a, b, 4
+
   def _exchange_all(self, st):
     red = self.reducer
     red.start(self.flat_g.grad)
@@ -478,16 +498,35 @@ class Trainer(object):
     (dp): the Adam updates are a second graph and the four all-reduces are issued between the two
     replays (the exchange is then not hidden behind compute, but the overlapped graph is 1.3 ms
     shorter than the sequential segments that could hide it)."""
+    # dp_schedule 2: the gradient exchange is part of the graph.  Collectives are issued on the comm stream in one
+    # fixed order (guard, D_img, D_obj, generator bucket A, the rest of the generator) as soon as their gradients
+    # are complete: the discriminators' right after their steps on the side stream; bucket A = the weights of the
+    # first two refinement modules (1024- and 512-channel 3x3 convolutions: ~2/3 of the generator's 112.6 MB for
+    # 1/10 of its weight-gradient time) right after their weight gradients, which are the FIRST the deferred
+    # release issues - it travels while the remaining weight gradients (~1.5 ms) run; only the rest (the graph
+    # convolution / MLP / small-conv gradients, ~1/3 of the bytes) is exchanged after the backward pass.
+    ingraph = dp and self.dp_schedule == 2 and self.reducer.capturable() and not self.reducer.mute
+    comm, red = self._comm, self.reducer
+
+    def reduce_after(stream, *tensors):
+      comm.wait_stream(stream)
+      with torch.cuda.stream(comm):
+        for t in tensors:
+          red.reduce_here(t)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
       main = torch.cuda.current_stream()
       side = self._side[0]
       self._seg_generator_forward(static, st)
+      if ingraph:
+        reduce_after(main, st['guard'])
 
-      def on_side(seg):
+      def on_side(seg, grads=None):
         side.wait_stream(main)
         with torch.cuda.stream(side):
           seg(static, st)
+        if ingraph and grads is not None:
+          reduce_after(side, grads)
       # Schedule (measured in round 2, DESIGN.md section 5.1).  The generator backward is: the refinement
       # network's data-gradient chain (big kernels), then the layout / mask / graph-convolution backward
       # (small dependent launches) with the refinement network's eleven weight gradients released underneath
@@ -498,15 +537,34 @@ class Trainer(object):
       # overlap with what is issued around the same time - capturing the discriminator steps AFTER the
       # generator backward (same dependencies) costs 10.9 ms.
       if self.d_img is not None:
-        on_side(self._seg_d_img)
+        on_side(self._seg_d_img, self.flat_di.grad)
       if self.d_obj is not None:
-        on_side(self._seg_d_obj)
-      self._seg_generator_backward(st)
+        on_side(self._seg_d_obj, self.flat_do.grad)
+      bucket = self._generator_bucket() if ingraph else None
+      sent = []
+      if bucket is not None:
+        a, b, count = bucket
+
+        def early(stream):
+          reduce_after(stream, self.flat_g.grad[a:b])
+          sent.append(True)
+        ops.AFTER_DEFERRED = (count, early)
+      try:
+        self._seg_generator_backward(st)
+      finally:
+        ops.AFTER_DEFERRED = None
+      if ingraph:
+        if sent:
+          reduce_after(main, self.flat_g.grad[:a], self.flat_g.grad[b:])
+        else:                          # (the backward released nothing early: one bucket)
+          reduce_after(main, self.flat_g.grad)
       main.wait_stream(side)
-      if not dp:
+      if ingraph:
+        main.wait_stream(comm)
+      if not dp or ingraph:
         self._seg_adam(st)
     graphs = {'all': g}
-    if dp:
+    if dp and not ingraph:
       ga = torch.cuda.CUDAGraph()
       with torch.cuda.graph(ga, pool=g.pool(), stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
         self._seg_adam(st)
