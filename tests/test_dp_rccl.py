@@ -30,6 +30,7 @@ def _worker(rank, world, port, backend, share_gpu, use_graphs, dp_schedule, ret)
   import torch.distributed as dist
   os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
   os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  torch.set_num_threads(8)       # (two workers run CPU oracles side by side: no oversubscription)
   idx = 0 if share_gpu else rank
   torch.cuda.set_device(idx)
   dev = torch.device('cuda', idx)
