@@ -175,7 +175,7 @@ def masks_to_layout(vecs, boxes, masks, obj_to_img, H, W=None, align_corners=Fal
   assert masks.size() == (O, M, M)
   W = H if W is None else W
   grid = boxes_to_grid(boxes, H, W)
-  img_in = vecs.view(O, D, 1, 1) * masks.float().view(O, 1, M, M)
+  img_in = vecs.view(O, D, 1, 1) * masks.to(vecs.dtype).view(O, 1, M, M)      # (.float() in the reference; the tests also run this oracle in float64)
   sampled = F.grid_sample(img_in, grid, mode='bilinear', padding_mode='zeros',
                           align_corners=align_corners)
   return pool_samples(sampled, obj_to_img, n_images)
@@ -526,7 +526,7 @@ def generator_losses(w, imgs, imgs_pred, boxes, boxes_pred, masks, masks_pred,
     losses['predicate_pred'] = F.cross_entropy(rel_scores, predicates) * w['predicate_pred_loss_weight']
     total = total + losses['predicate_pred']
   if w['mask_loss_weight'] > 0 and masks is not None and masks_pred is not None:
-    losses['mask_loss'] = F.binary_cross_entropy(masks_pred, masks.float()) * w['mask_loss_weight']
+    losses['mask_loss'] = F.binary_cross_entropy(masks_pred, masks.to(masks_pred.dtype)) * w['mask_loss_weight']
     total = total + losses['mask_loss']
   return total, losses
 

@@ -162,7 +162,7 @@ class OracleRefs(object):
 
 
 def grad_parity_rows3(tr, o32, o64, scale=1.0):
-  """rows (net, name, e_hip64, e_ref, e_hip32, max|g_f64|, cosine(hip, f64)): errors relative to the float64
+  """rows (net, name, e_hip64, e_ref, e_hip32, max|g_f64|, cosine(hip, f64), numel): errors relative to the float64
   gradient's max magnitude - of the HIP arena against float64, of the float32 oracle against float64, of HIP
   against the float32 oracle.  A parameter without a reference gradient must have an all-zero arena slot."""
   rows = []
@@ -176,7 +176,7 @@ def grad_parity_rows3(tr, o32, o64, scale=1.0):
       g64 = P64[name].grad
       if g64 is None:
         m = float(got.abs().max())
-        rows.append((net, name, m, 0.0, m, 0.0, 1.0))
+        rows.append((net, name, m, 0.0, m, 0.0, 1.0, got.numel()))
         continue
       g32 = P32[name].grad.detach().double()
       g64 = g64.detach()
@@ -185,7 +185,7 @@ def grad_parity_rows3(tr, o32, o64, scale=1.0):
       nn_ = float(got.norm() * g64.norm())
       rows.append((net, name, float((got - g64).abs().max()) / den, float((g32 - g64).abs().max()) / den,
                    float((got - g32).abs().max()) / den, float(g64.abs().max()),
-                   float((got * g64).sum()) / nn_ if nn_ > 0 else 1.0))
+                   float((got * g64).sum()) / nn_ if nn_ > 0 else 1.0, got.numel()))
   return rows
 
 
@@ -207,6 +207,14 @@ def check_grad_rows(rows, rel=None, cos_min=None):
     for r in sel:
       if r[5] < GRAD_ABS_ZERO:
         if r[2] * max(r[5], 1e-30) > GRAD_ABS_ZERO and r[4] * max(r[5], 1e-30) > GRAD_ABS_ZERO:
+          bad.append(r)
+        continue
+      if r[7] < 16 and not flip_ok:
+        # (fixed-bound mode, i.e. bf16: a scalar / few-element gradient - the bias of mask_net's 1-channel output
+        # conv - is one sum of cancelling terms: its relative error is unbounded and its cosine says nothing;
+        # it is held to 1 % of the largest gradient magnitude of its network instead)
+        gmax = max(q[5] for q in sel)
+        if r[2] * r[5] > 1e-2 * gmax:
           bad.append(r)
         continue
       if (r[2] > rel or (cos_min is not None and r[6] < cos_min)) and not (flip_ok and r[6] >= 0.9999 and r[2] <= 0.1):
@@ -234,5 +242,5 @@ def assert_grad_parity(tr, refs, label, rel=None, cos_min=None, scale=1.0):
   except OSError:
     pass
   assert not bad, '%s: gradients out of tolerance:\n' % label + '\n'.join(
-    '  %s.%s e_hip64 %.3e e_ref %.3e e_hip32 %.3e max|g| %.3e cos %.6f' % r for r in bad[:20])
+    '  %s.%s e_hip64 %.3e e_ref %.3e e_hip32 %.3e max|g| %.3e cos %.6f' % r[:7] for r in bad[:20])
   return max(v[0] for v in summ.values()), min(v[4] for v in summ.values())
