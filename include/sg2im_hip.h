@@ -268,6 +268,12 @@ int sg2im_gconv_layer_backward(const sg2im_gconv_layer* layer, const float* h1, 
                                const sg2im_gconv_grads* grads, float* scratch, size_t scratch_bytes,
                                float* workspace, size_t workspace_bytes, hipStream_t stream);
 
+/* Up to 16 plain device-to-device copies (sizes and addresses multiples of 4 bytes) in ONE launch: the hand-over
+ * of a collated batch (scripts/train.py:514-519 `batch = [tensor.cuda() for tensor in batch]`) into the static
+ * input buffers a captured iteration reads - images, object / triple / mask arrays and their padding, the two
+ * row counts.  dst / src / bytes are HOST arrays of n entries. */
+int sg2im_stage_batch(int n, void* const* dst, const void* const* src, const size_t* bytes, hipStream_t stream);
+
 /* dst[r][0:width] = src[r][0:width] for strided row matrices (the new_p column slice of the
  * net1 output, graph.py:88, travelling through backward) */
 int sg2im_copy_2d(const float* src, long long ld_src, float* dst, long long ld_dst, long long rows,

@@ -112,5 +112,37 @@ class StaticBatch(object):
     put(self.triples[:T], triples.reshape(T, 3)); put(self.triples[T:], self._pad_triples[T:])
     put(self.obj_to_img[:O], o2i); put(self.obj_to_img[O:], self._pad_o2i[O:])
     put(self.counts[0:1], self._tab[O:O + 1]); put(self.counts[1:2], self._tab[T:T + 1])
+    if _stage_with_library(groups):
+      return
     for dst, src in groups.values():
       torch._foreach_copy_(dst, src)
+
+
+def _stage_with_library(groups):
+  """all copies of a refill as ONE launch of the library (sg2im_stage_batch) instead of three multi-tensor
+  copies (~13 torch launches, ~70 us at the head of every replayed step).  The launch is issued straight
+  through the binding, NOT through ``_lib.call``: it is part of every training step, so it must not count as
+  "eager use" that re-captures the graphs (Trainer._graph_step)."""
+  import ctypes
+  import os
+  if os.environ.get('SG2IM_STAGE', '1') == '0':         # (A/B knob)
+    return False
+  from . import _lib
+  pairs = [(d, s) for dst, src in groups.values() for d, s in zip(dst, src)]
+  n = len(pairs)
+  if n == 0 or n > 16:
+    return n == 0
+  for d, s in pairs:
+    if not (d.is_cuda and s.is_cuda and d.is_contiguous() and s.is_contiguous() and d.dtype == s.dtype and
+            d.numel() == s.numel() and (d.numel() * d.element_size()) % 4 == 0):
+      return False
+  if not _lib._inited:
+    _lib.init()
+  P = ctypes.c_void_p * n
+  Z = ctypes.c_size_t * n
+  rc = _lib.load().sg2im_stage_batch(n, P(*[d.data_ptr() for d, _ in pairs]), P(*[s.data_ptr() for _, s in pairs]),
+                                     Z(*[d.numel() * d.element_size() for d, _ in pairs]),
+                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+  if rc != 0:
+    raise _lib.Sg2imHipError('sg2im_stage_batch failed (%d)' % rc)
+  return True

@@ -218,6 +218,16 @@ __global__ void copy_2d_kernel(const float* __restrict__ src, long long ld_src, 
   }
 }
 
+// batch hand-over of a captured iteration: up to 16 (dst, src, 4-byte words) copies in ONE launch
+struct StageJobs { unsigned* dst[16]; const unsigned* src[16]; unsigned words[16]; };
+__global__ void stage_batch_kernel(const StageJobs j) {
+  const int job = blockIdx.y;
+  unsigned* __restrict__ d = j.dst[job];
+  const unsigned* __restrict__ s = j.src[job];
+  const unsigned n = j.words[job];
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = s[i];
+}
+
 }  // namespace sg2im
 
 using namespace sg2im;
@@ -225,6 +235,26 @@ using namespace sg2im;
 extern "C" {
 
 int sg2im_abi_version(void) { return 4; }
+
+int sg2im_stage_batch(int n, void* const* dst, const void* const* src, const size_t* bytes, hipStream_t stream) {
+  if (n < 0 || n > 16 || (n && (!dst || !src || !bytes))) return SG2IM_ERR_ARG;
+  if (n == 0) return SG2IM_OK;
+  StageJobs j;
+  size_t most = 0;
+  for (int i = 0; i < 16; ++i) {
+    const bool live = i < n;
+    if (live && (bytes[i] % 4 || ((uintptr_t)dst[i] & 3) || ((uintptr_t)src[i] & 3) || bytes[i] / 4 > 0xffffffffull ||
+                 (bytes[i] && (!dst[i] || !src[i]))))
+      return SG2IM_ERR_ARG;
+    j.dst[i] = live ? (unsigned*)dst[i] : nullptr;
+    j.src[i] = live ? (const unsigned*)src[i] : nullptr;
+    j.words[i] = live ? (unsigned)(bytes[i] / 4) : 0u;
+    if (live) most = bytes[i] / 4 > most ? bytes[i] / 4 : most;
+  }
+  const int bx = (int)std::max<size_t>(1, std::min<size_t>((most + 256 * 8 - 1) / (256 * 8), 64));
+  SG2IM_LAUNCH(stage_batch_kernel, dim3(bx, n), dim3(256), 0, stream, j);
+  return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+}
 
 unsigned long long sg2im_launch_count(int which) { return which == 1 ? sg2im::g_gemm_launches : sg2im::g_launches; }
 

@@ -116,6 +116,7 @@ class Trainer(object):
     # step replayed while the generator's all-reduce is in flight
     self.dp_schedule = int(os.environ.get('SG2IM_DP_SCHEDULE', '2')) if dp_schedule is None else int(dp_schedule)
     self._comm = None
+    self._aux2 = None
     if bucket == 'auto':
       bucket = (32, 64) if use_graphs else None
     self.bucketer = Bucketer(*bucket) if bucket else None
@@ -184,6 +185,10 @@ class Trainer(object):
     imgs, objs, boxes, masks, triples, obj_to_img = batch[:6]
     w = self.w
     imgs_pred, boxes_pred, masks_pred, rel_scores = st.pop('gen_out')
+    if torch.cuda.is_current_stream_capturing():
+      ev = torch.cuda.Event()
+      ev.record()                      # (imgs_pred exists: the side stream may start on it, see below)
+      st['imgs_pred_ready'] = ev
     # padded batch (graph mode): the means over objects / triples run over the real rows only
     oc, tc = st.get('ocnt'), st.get('tcnt')
     cnt = lambda c, unit: None if c is None else (c[0], c[1] * unit)
@@ -200,6 +205,21 @@ class Trainer(object):
     if w['mask_loss_weight'] > 0 and masks is not None and masks_pred is not None:   # train.py:407-410
       losses['mask_loss'] = L.binary_cross_entropy(masks_pred, masks, w['mask_loss_weight'],
                                                    cnt(oc, masks_pred.size(1) * masks_pred.size(2)))
+    gi = None
+    par = (self.d_img is not None and self.d_obj is not None and self._aux2 is not None and
+           torch.cuda.is_current_stream_capturing() and os.environ.get('SG2IM_PAR_DIMG', '1') != '0')      # (A/B knob)
+    ev = st.pop('imgs_pred_ready', None)
+    if par:
+      # captured iteration: the image discriminator's pass over the fake images runs on a stream of its own NEXT
+      # TO the object discriminator's (both only need imgs_pred) - and so does its backward, which autograd
+      # executes on the stream of the forward: two dependent small-kernel chains between the refinement
+      # network's forward and backward instead of one twice as long.  (Issued first: a replay issues the
+      # nodes in capture order.  Not the discriminator steps' side stream: the backward of this branch would
+      # queue up behind them.)
+      main, side = torch.cuda.current_stream(), self._aux2
+      side.wait_event(ev)
+      with torch.cuda.stream(side):
+        gi = self.gan_g_loss(self.d_img.forward_nhwc(imgs_pred), weight=w['discriminator_loss_weight'] * w['d_img_weight'])
     if self.d_obj is not None:
       # (loss weights are folded into the loss kernels; the terms are summed by ONE launch and the
       # backward pass is seeded with ops.unit, so no term pays a multiply / scaling launch)
@@ -208,8 +228,11 @@ class Trainer(object):
       losses['g_gan_obj_loss'] = self.gan_g_loss(scores_fake, weight=w['discriminator_loss_weight'] * w['d_obj_weight'],
                                                  count=oc)
     if self.d_img is not None:
-      scores_fake = self.d_img.forward_nhwc(imgs_pred)
-      losses['g_gan_img_loss'] = self.gan_g_loss(scores_fake, weight=w['discriminator_loss_weight'] * w['d_img_weight'])
+      if par:
+        main.wait_stream(side)
+      else:
+        gi = self.gan_g_loss(self.d_img.forward_nhwc(imgs_pred), weight=w['discriminator_loss_weight'] * w['d_img_weight'])
+      losses['g_gan_img_loss'] = gi
     total = HF.SumScalars.apply(*losses.values())
     losses['total_loss'] = total
     st['losses'].update(losses)
@@ -353,7 +376,9 @@ class Trainer(object):
         ops._wgrad_streams[key] = torch.cuda.Stream(device=idx)
     if self._comm is None and (self.world_size > 1 or self.reducer.force):
       self._comm = torch.cuda.Stream(device=idx)       # gradient exchange inside the captured iteration
-    for s in (self._cap_stream, self._side[0], ops._wgrad_streams[(idx, self._cap_stream.cuda_stream)]):
+    if self._aux2 is None:
+      self._aux2 = torch.cuda.Stream(device=idx)       # the generator loss' pass through the image discriminator
+    for s in (self._cap_stream, self._side[0], self._aux2, ops._wgrad_streams[(idx, self._cap_stream.cuda_stream)]):
       with torch.cuda.stream(s):
         ops.workspace(dev)
         ops.scratch(dev, scratch_floats)

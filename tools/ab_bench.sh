@@ -5,7 +5,7 @@ mkdir -p $out
 for rep in 1 2; do
   for kv in "$@"; do
     tag=$(echo "$kv" | tr '= ' '__')
-    env $kv python bench.py --steps 40 --warmup 10 --cpu_baseline_steps 0 --no_roofline > $out/bench_${tag}_$rep.json 2> $out/bench_${tag}_$rep.err
+    env $kv python bench.py --steps ${STEPS:-100} --warmup 20 --cpu_baseline_steps 0 --no_roofline > $out/bench_${tag}_$rep.json 2> $out/bench_${tag}_$rep.err
     python - <<PY
 import json
 d = json.load(open('$out/bench_${tag}_$rep.json'))
