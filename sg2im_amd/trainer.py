@@ -116,7 +116,7 @@ class Trainer(object):
     # step replayed while the generator's all-reduce is in flight
     self.dp_schedule = int(os.environ.get('SG2IM_DP_SCHEDULE', '2')) if dp_schedule is None else int(dp_schedule)
     self._comm = None
-    self._aux2 = self._aux3 = None
+    self._aux2 = None
     if bucket == 'auto':
       bucket = (32, 64) if use_graphs else None
     self.bucketer = Bucketer(*bucket) if bucket else None
@@ -378,11 +378,7 @@ class Trainer(object):
       self._comm = torch.cuda.Stream(device=idx)       # gradient exchange inside the captured iteration
     if self._aux2 is None:
       self._aux2 = torch.cuda.Stream(device=idx)       # the generator loss' pass through the image discriminator
-    if self._aux3 is None and os.environ.get('SG2IM_PAR_DSTEPS', '0') == '1':
-      self._aux3 = torch.cuda.Stream(device=idx)
-    for s in (self._cap_stream, self._side[0], self._aux2, self._aux3, ops._wgrad_streams[(idx, self._cap_stream.cuda_stream)]):
-      if s is None:
-        continue
+    for s in (self._cap_stream, self._side[0], self._aux2, ops._wgrad_streams[(idx, self._cap_stream.cuda_stream)]):
       with torch.cuda.stream(s):
         ops.workspace(dev)
         ops.scratch(dev, scratch_floats)
@@ -550,15 +546,12 @@ class Trainer(object):
       if ingraph:
         reduce_after(main, st['guard'])
 
-      def on_side(seg, grads=None, stream=None):
-        stream = side if stream is None else stream
-        stream.wait_stream(main)
-        with torch.cuda.stream(stream):
+      def on_side(seg, grads=None):
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
           seg(static, st)
         if ingraph and grads is not None:
-          reduce_after(stream, grads)
-        if stream is not side:
-          side.wait_stream(stream)       # (joined through the side stream below)
+          reduce_after(side, grads)
       # Schedule (measured in round 2).  The generator backward is: the refinement
       # network's data-gradient chain (big kernels), then the layout / mask / graph-convolution backward
       # (small dependent launches) with the refinement network's eleven weight gradients released underneath
@@ -568,11 +561,10 @@ class Trainer(object):
       # matters, not only the dependencies: a replay issues the nodes in capture order, and branches only
       # overlap with what is issued around the same time - capturing the discriminator steps AFTER the
       # generator backward (same dependencies) costs 10.9 ms.
-      # (SG2IM_PAR_DSTEPS=1, A/B knob: the image discriminator's step on a stream of its own, next to the object
-      # discriminator's step instead of in front of it)
-      par_d = self._aux3 if os.environ.get('SG2IM_PAR_DSTEPS', '0') == '1' else None
+      # (the image discriminator's step on a stream of its own, next to the object discriminator's step instead
+      # of in front of it: measured, no gain - 8.31 vs 8.31 ms, round 3)
       if self.d_img is not None:
-        on_side(self._seg_d_img, self.flat_di.grad, par_d)
+        on_side(self._seg_d_img, self.flat_di.grad)
       if self.d_obj is not None:
         on_side(self._seg_d_obj, self.flat_do.grad)
       bucket = self._generator_bucket() if ingraph else None
