@@ -1577,7 +1577,9 @@ static bool halo_plan(int NB, int H, int W, int ncols, int nchunks, size_t ws_by
   const long long M = (long long)NB * H * W;
   pl->patches = (int)(M / 128);
   if (pl->patches < 1 || ncols < 32 || nchunks < 1) return false;
-  pl->bn = (ncols > 64 && (long long)pl->patches * ((ncols + 127) / 128) >= 2 * g_num_cu) ? 128 : 64;
+  // (64-wide column tiles only: the 128-wide form - 2 wavefronts per SIMD at ~200 registers - measured 90 against
+  // 113 TFLOP/s on the 128-column data gradients of the 64 x 64 layers; the template keeps the parameter)
+  pl->bn = 64;
   const long long blocks = (long long)pl->patches * ((ncols + pl->bn - 1) / pl->bn);
   int ns = 1;
   if (can_split && blocks < (3 * g_num_cu) / 2) {
@@ -1601,7 +1603,7 @@ static hipError_t launch_halo_t(HaloParams& p, const HaloPlan& pl, hipStream_t s
 template <bool DG, bool ST>
 static hipError_t launch_halo(HaloParams& p, const HaloPlan& pl, hipStream_t st) {
 #define SG2IM_HALO_CASE(RT_, CT_) \
-  if (pl.ct == CT_) return pl.bn == 128 ? launch_halo_t<RT_, CT_, 128, DG, ST>(p, pl, st) : launch_halo_t<RT_, CT_, 64, DG, ST>(p, pl, st)
+  if (pl.ct == CT_) return launch_halo_t<RT_, CT_, 64, DG, ST>(p, pl, st)
   SG2IM_HALO_CASE(2, 64); SG2IM_HALO_CASE(4, 32); SG2IM_HALO_CASE(8, 16);
 #undef SG2IM_HALO_CASE
   return hipErrorInvalidValue;

@@ -159,15 +159,27 @@ __global__ void bn_stats_final_tiles_kernel(const float* __restrict__ partial, i
   const float* __restrict__ q = partial + (size_t)c * nblk;
   const double P = (double)q[0];                        // tile 0's pivot
   double sn = 0.0, sm = 0.0, sq = 0.0;
-  for (int t = lane; t < nblk; t += 64) {
+  auto add_tile = [&](int t, float pv, float sv, float ssv) {
     long long nt = live - (long long)t * per;
-    if (nt <= 0) break;
+    if (nt <= 0) return;
     if (nt > per) nt = per;
-    const double n = (double)nt, s = (double)q[plane + t], ss = (double)q[2 * plane + t];
-    const double mt = ((double)q[t] - P) + s / n;
+    const double n = (double)nt, s = (double)sv, ss = (double)ssv;
+    const double mt = ((double)pv - P) + s / n;
     double m2 = ss - s * s / n;
     if (m2 < 0.0) m2 = 0.0;
     sn += n; sm += n * mt; sq += m2 + n * mt * mt;
+  };
+  if ((nblk & 3) == 0) {            // four tiles per lane and load (a channel's partials are contiguous, 16-byte aligned)
+    const float4* __restrict__ q4 = reinterpret_cast<const float4*>(q);
+    const float4* __restrict__ s4 = reinterpret_cast<const float4*>(q + plane);
+    const float4* __restrict__ ss4 = reinterpret_cast<const float4*>(q + 2 * plane);
+    for (int t4 = lane; t4 < (nblk >> 2); t4 += 64) {
+      const float4 a = q4[t4], b = s4[t4], c4 = ss4[t4];
+      add_tile(4 * t4 + 0, a.x, b.x, c4.x); add_tile(4 * t4 + 1, a.y, b.y, c4.y);
+      add_tile(4 * t4 + 2, a.z, b.z, c4.z); add_tile(4 * t4 + 3, a.w, b.w, c4.w);
+    }
+  } else {
+    for (int t = lane; t < nblk; t += 64) add_tile(t, q[t], q[plane + t], q[2 * plane + t]);
   }
   #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { sn += __shfl_xor(sn, off); sm += __shfl_xor(sm, off); sq += __shfl_xor(sq, off); }
@@ -254,7 +266,17 @@ __global__ void bn_bwd_final_tiles_kernel(const float* __restrict__ partial, int
   const float* __restrict__ q = partial + (size_t)c * nblk;
   const size_t plane = (size_t)C * nblk;
   double s = 0.0, sx = 0.0;
-  for (int t = lane; t < nblk; t += 64) { s += (double)q[t]; sx += (double)q[plane + t]; }
+  if ((nblk & 3) == 0) {
+    const float4* __restrict__ q4 = reinterpret_cast<const float4*>(q);
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(q + plane);
+    for (int t4 = lane; t4 < (nblk >> 2); t4 += 64) {
+      const float4 a = q4[t4], b = x4[t4];
+      s += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
+      sx += ((double)b.x + (double)b.y) + ((double)b.z + (double)b.w);
+    }
+  } else {
+    for (int t = lane; t < nblk; t += 64) { s += (double)q[t]; sx += (double)q[plane + t]; }
+  }
   #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); sx += __shfl_xor(sx, off); }
   if (lane != 0) return;
