@@ -1561,7 +1561,7 @@ static const bool g_halo = !(getenv("SG2IM_HALO") && atoi(getenv("SG2IM_HALO")) 
 struct HaloPlan { int rt, ct, bn, nsplit, patches; };
 
 static bool halo_geometry(const sg2im_conv_desc* d) {
-  return g_halo && d->compute_dtype == 0 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 &&
+  return g_halo && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 &&
          d->in_h < 32768 && d->in_w < 32768;
 }
 
@@ -1593,17 +1593,18 @@ static bool halo_plan(int NB, int H, int W, int ncols, int nchunks, size_t ws_by
   return true;
 }
 
-template <int RT, int CT, int BN, bool DG, bool ST>
+template <int RT, int CT, int BN, bool DG, bool ST, bool H>
 static hipError_t launch_halo_t(HaloParams& p, const HaloPlan& pl, hipStream_t st) {
-  constexpr size_t lds = halo_lds<RT, CT, BN, DG>();
+  constexpr size_t lds = halo_lds<RT, CT, BN, DG, H>();
   dim3 grid((p.N + BN - 1) / BN, pl.patches, pl.nsplit);
-  SG2IM_LAUNCH((conv_halo_kernel<RT, CT, BN, DG, ST>), grid, dim3(NTHREADS), lds, st, p);
+  SG2IM_LAUNCH((conv_halo_kernel<RT, CT, BN, DG, ST, H>), grid, dim3(NTHREADS), lds, st, p);
   return hipGetLastError();
 }
+// hb: bf16 operands (sg2im_conv_desc.compute_dtype 1)
 template <bool DG, bool ST>
-static hipError_t launch_halo(HaloParams& p, const HaloPlan& pl, hipStream_t st) {
+static hipError_t launch_halo(HaloParams& p, const HaloPlan& pl, hipStream_t st, bool hb = false) {
 #define SG2IM_HALO_CASE(RT_, CT_) \
-  if (pl.ct == CT_) return launch_halo_t<RT_, CT_, 64, DG, ST>(p, pl, st)
+  if (pl.ct == CT_) return hb ? launch_halo_t<RT_, CT_, 64, DG, ST, true>(p, pl, st) : launch_halo_t<RT_, CT_, 64, DG, ST, false>(p, pl, st)
   SG2IM_HALO_CASE(2, 64); SG2IM_HALO_CASE(4, 32); SG2IM_HALO_CASE(8, 16);
 #undef SG2IM_HALO_CASE
   return hipErrorInvalidValue;
@@ -1697,10 +1698,10 @@ static int conv_forward_impl(const sg2im_conv_desc* d, const float* weight, int 
     nsplit = hp.nsplit;
     if (st_ok && !bn->count && hp.nsplit == 1 && (size_t)hp.patches * 3 * cout <= bn->partial_floats) {
       q.st.partial = bn->partial; q.st.tiles = hp.patches;
-      if (launch_halo<false, true>(q, hp, stream) != hipSuccess) return SG2IM_ERR_HIP;
+      if (launch_halo<false, true>(q, hp, stream, d->compute_dtype == 1) != hipSuccess) return SG2IM_ERR_HIP;
       return bn_stats_finish_tiles(bn->partial, hp.patches, 128, p.M, cout, bn, stream);
     }
-    err = launch_halo<false, false>(q, hp, stream);
+    err = launch_halo<false, false>(q, hp, stream, d->compute_dtype == 1);
   } else {
   const Plan pl = make_plan(PASS_FWD, p.M, cout, p.iters, (long long)p.M * cout, workspace_bytes, workspace != nullptr, 4, !v4,
                             [&](int bn) { return (long long)(cout + bn - 1) / bn; });
@@ -1821,10 +1822,10 @@ static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int co
     }
     if (st_h && hp.nsplit == 1 && (size_t)hp.patches * 2 * c_count <= bb->partial_floats) {
       q.st = ss; q.st.tiles = hp.patches;
-      if (launch_halo<true, true>(q, hp, stream) != hipSuccess) return SG2IM_ERR_HIP;
+      if (launch_halo<true, true>(q, hp, stream, d->compute_dtype == 1) != hipSuccess) return SG2IM_ERR_HIP;
       return bn_bwd_finish_tiles(bb->partial, hp.patches, bn_rows_h, c_count, bb, stream);
     }
-    if (launch_halo<true, false>(q, hp, stream) != hipSuccess) return SG2IM_ERR_HIP;
+    if (launch_halo<true, false>(q, hp, stream, d->compute_dtype == 1) != hipSuccess) return SG2IM_ERR_HIP;
     if (st_h && hp.nsplit > 1 && ld_dx % 4 == 0 && al16p(dx) && al16p(workspace) && bb->ld_y % 4 == 0 && al16p(bb->y) &&
         al16p(bb->mean) && al16p(bb->invstd) && al16p(bb->scale) && al16p(bb->shift)) {
       int nblk, nslab; long long per;

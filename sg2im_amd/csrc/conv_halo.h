@@ -56,7 +56,9 @@ struct ChunkCursor {
 
 // (64-wide column tiles are held to 128 registers: four resident wavefronts per SIMD, as many workgroups per CU
 // as their 35-47 KB of LDS allow)
-template <int RT, int CT, int BN, bool DG, bool ST>
+// H: bf16 operand path (igemm.h): both LDS images hold bf16 (halo [pixel][32 + 8], weights [BN][32 + 8] resp.
+// k-major [32][BN + 32] read with the transposing ds_read_b64_tr_b16), v_mfma_f32_32x32x16_bf16, fp32 accumulate
+template <int RT, int CT, int BN, bool DG, bool ST, bool H = false>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BN == 64 && CT <= 32) ? SG2IM_HALO_WAVES64 : 2)))
 void conv_halo_kernel(const HaloParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -66,9 +68,11 @@ void conv_halo_kernel(const HaloParams p) {
   constexpr int NA = (HP * 8 + NTHREADS - 1) / NTHREADS;      // float4 of the halo image per thread
   constexpr int NVB = BN / 32;
   constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int AF = HP * MLD;
+  constexpr int AF = H ? HP * MLDH / 2 : HP * MLD;            // (floats)
   float* const As = smem;
   float* const Bs = smem + AF;
+  bf16_t* const Ash = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* const Bsh = reinterpret_cast<bf16_t*>(smem + AF);
   const ConvGeom& g = p.g;
   const int tid = threadIdx.x;
   const int n0 = blockIdx.x * BN, split = blockIdx.z;
@@ -158,7 +162,10 @@ void conv_halo_kernel(const HaloParams p) {
       const int hp = r0 + 32 * j;
       float4 v = ra[j];
       if (!DG) v = apply_aff(v, aaff, (ramask >> j & 1u) != 0);
-      if (NA * 32 <= HP || hp < HP) *reinterpret_cast<float4*>(As + hp * MLD + 4 * col4) = v;
+      if (NA * 32 <= HP || hp < HP) {
+        if constexpr (H) *reinterpret_cast<bf16x4*>(Ash + hp * MLDH + 4 * col4) = to_bf16x4(v);
+        else *reinterpret_cast<float4*>(As + hp * MLD + 4 * col4) = v;
+      }
     }
   };
 
@@ -197,8 +204,13 @@ void conv_halo_kernel(const HaloParams p) {
     }
   };
   auto stage_B = [&]() {
-    if (!DG) store_tile<BN, false>(Bs, rb, tid);
-    else store_tile<BN, true>(Bs, rb, tid);
+    if constexpr (H) {
+      if (!DG) store_tile_h<BN, false>(Bsh, rb, tid);
+      else store_tile_h<BN, true>(Bsh, rb, tid);
+    } else {
+      if (!DG) store_tile<BN, false>(Bs, rb, tid);
+      else store_tile<BN, true>(Bs, rb, tid);
+    }
   };
 
   // ---- fragments ----
@@ -212,6 +224,7 @@ void conv_halo_kernel(const HaloParams p) {
     apix[tm] = (q / CT) * HWD + q % CT;
   }
   Frags<BM, BN> f;
+  FragsH<BM, BN> fh;
   f32x16 acc[TM][TN];
   #pragma unroll
   for (int a_ = 0; a_ < TM; ++a_)
@@ -219,6 +232,21 @@ void conv_halo_kernel(const HaloParams p) {
     for (int b_ = 0; b_ < TN; ++b_) zero_acc(acc[a_][b_]);
 
   auto mma_tap = [&](int tapoff) {
+    if constexpr (H) {
+      #pragma unroll
+      for (int stp = 0; stp < 2; ++stp) {
+        #pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          fh.a[tm][stp] = *reinterpret_cast<const bf16x8*>(Ash + (apix[tm] + tapoff) * MLDH + 16 * stp + 8 * lh);
+        #pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          if (!DG) fh.b[tn][stp] = *reinterpret_cast<const bf16x8*>(Bsh + (wn0 + tn * 32 + li) * MLDH + 16 * stp + 8 * lh);
+          else fh.b[tn][stp] = read_tr<BN>(Bsh, wn0 + tn * 32, stp, lane);
+        }
+      }
+      mma_frags_h<BM, BN>(fh, acc);
+      return;
+    }
     #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const float* row = As + (apix[tm] + tapoff) * MLD + 4 * lh;
@@ -286,8 +314,9 @@ void conv_halo_kernel(const HaloParams p) {
   }
 }
 
-template <int RT, int CT, int BN, bool DG> constexpr size_t halo_lds() {
-  return ((size_t)(RT + 2) * (CT + 2) * MLD + (DG ? (size_t)BK * (BN + KPAD) : (size_t)BN * MLD)) * sizeof(float);
+template <int RT, int CT, int BN, bool DG, bool H = false> constexpr size_t halo_lds() {
+  return H ? ((size_t)(RT + 2) * (CT + 2) * MLDH + (DG ? (size_t)BK * (BN + KPADH) : (size_t)BN * MLDH)) * 2
+           : ((size_t)(RT + 2) * (CT + 2) * MLD + (DG ? (size_t)BK * (BN + KPAD) : (size_t)BN * MLD)) * sizeof(float);
 }
 
 }  // namespace sg2im

@@ -213,6 +213,11 @@ def sec_conv_bf16():
   conv_case_bf16('conv4x4s2 128->256 valid 14x14', 4, 14, 14, 128, 0, 0, 256, 4, 2, 0)
   conv_case_bf16('conv3x3 1184->512 8x8 (m1.conv0 shape)', 4, 8, 8, 160, 1024, 1, 512, 3, 1, 1)
   conv_case_bf16('conv3x3 36->20 pad1 9x11 (ragged tiles)', 3, 9, 11, 36, 0, 0, 20, 3, 1, 1)
+  # halo'd-tile kernels with bf16 operands: every patch form, pending affine, ragged chunks, split-K
+  conv_case_bf16('halo conv3x3 bnact 64->96 32x32', 4, 32, 32, 64, 0, 0, 96, 3, 1, 1, bnact=True)
+  conv_case_bf16('halo conv3x3 80+48up->48 12x32 (4x32 patches)', 3, 12, 32, 80, 48, 1, 48, 3, 1, 1)
+  conv_case_bf16('halo conv3x3 64+64up->64 6x64 (2x64 patches)', 2, 6, 64, 64, 64, 1, 64, 3, 1, 1)
+  conv_case_bf16('halo conv3x3 32->256 16x16 (split-K)', 16, 16, 16, 32, 0, 0, 256, 3, 1, 1)
 
 
 class _Bn(object):
