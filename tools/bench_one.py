@@ -16,8 +16,9 @@ x0 = torch.randn(N, H, H, C0, device=D)
 sc = torch.rand(C0, device=D) + 0.5 if bn else None
 sh = torch.randn(C0, device=D) if bn else None
 srcs = [ops.nhwc_src(x0, 0, sc, sh, 0.2 if bn else 1.0)]
-if C1:
-  srcs.append(ops.nhwc_src(torch.randn(N, H // 2, H // 2, C1, device=D), 1))
+if C1:      # (as in the network: the previous module's BatchNorm + LeakyReLU pending on the upsampled feature source)
+  srcs.append(ops.nhwc_src(torch.randn(N, H // 2, H // 2, C1, device=D), 1, torch.rand(C1, device=D) + 0.5,
+                           torch.randn(C1, device=D) * 0.1, 0.2))
 d = ops.conv_desc(srcs, N, H, H, k, k, s, p)
 Ct = C0 + C1
 W = torch.randn(Cout, k, k, Ct, device=D) * 0.01
