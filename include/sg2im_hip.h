@@ -292,6 +292,19 @@ int sg2im_layout_forward(const float* vecs, long long ld_vecs, const float* boxe
                          const int* img_row_ptr, const int* img_entries, int n_images, int n_objs,
                          int dim, int height, int width, int align_corners, float* layout,
                          long long ld_layout, hipStream_t stream);
+/* The same layout, the layout-noise channels (model.py:164-169: torch.cat([layout, noise], dim=1); `noise` is
+ * the NCHW tensor [n_images][noise_dim][H][W], may be NULL with noise_dim 0) and the average-pool pyramid the
+ * refinement network builds from it (crn.py:58-62: F.avg_pool2d(layout, factor) per module) in ONE pass:
+ * levels[0] = NHWC [n_images][H][W][ld_levels] with channels [0, dim) = layout, [dim, dim + noise_dim) = noise;
+ * levels[l] (1 <= l <= n_levels <= 4) = [n_images][H >> l][W >> l][ld_levels], the 2 x 2 mean of levels[l - 1]
+ * (== sg2im_avgpool_forward(levels[l - 1], 2), bit for bit).  `levels` is a HOST array of n_levels + 1 device
+ * pointers.  Requires dim % 32 == 0, noise_dim % 32 == 0, H % 16 == 0, W % 16 == 0 (SG2IM_ERR_ARG otherwise:
+ * use sg2im_layout_forward + sg2im_nchw_to_nhwc + sg2im_avgpool_forward). */
+int sg2im_layout_pyramid_forward(const float* vecs, long long ld_vecs, const float* boxes, const float* masks,
+                                 const long long* masks_i64, int mask_size, const int* img_row_ptr,
+                                 const int* img_entries, int n_images, int dim, const float* noise, int noise_dim,
+                                 int height, int width, int align_corners, int n_levels, float* const* levels,
+                                 long long ld_levels, hipStream_t stream);
 /* d_vecs[o][d] = sum_{y,x} dlayout[n_o][y][x][d] * S_o(y,x)  (deterministic two-stage sum;
  * workspace: sg2im_layout_backward_workspace() bytes);  optional d_masks [O][M][M] for float
  * (predicted) masks: d_masks[o][i][j] = sum_{y,x} <dlayout[n_o][y][x], vecs[o]> * dS_o/dm_ij;

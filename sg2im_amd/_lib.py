@@ -86,6 +86,7 @@ _SIGNATURES = {
   'sg2im_gconv_layer_backward': [POINTER(GconvLayer), _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, POINTER(GconvGrads), _P, _Z,
                                  _P, _Z, _P],
   'sg2im_layout_forward': [_P, _L, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P],
+  'sg2im_layout_pyramid_forward': [_P, _L, _P, _P, _P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, POINTER(c_void_p), _L, _P],
   'sg2im_layout_backward_workspace': [_I, _I, _I, _I],
   'sg2im_layout_backward': [_P, _L, _P, _L, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P,
                             _P, _P, _P],

@@ -61,6 +61,56 @@ __global__ void csr_scan_kernel(int* __restrict__ counts, int n, int* __restrict
   if (tid == 0) row_ptr[n] = carry;
 }
 
+// The whole build in ONE launch for the sizes of a training batch (a few hundred rows, a few hundred to a few
+// thousand keys): one workgroup stages the live keys in LDS, every thread owns rows r = tid, tid + 1024, ... and
+// walks the keys twice - count, then (after a block scan of the counts) append in entry order, which is the
+// stable order by construction.  Replaces memset + count + scan + fill + sort (five dependent launches at the very
+// head of the training step).
+constexpr int kCsrSmallKeys = 8192;
+__global__ __launch_bounds__(1024) void csr_build_small_kernel(const long long* __restrict__ ka, int na,
+                                                               const long long* __restrict__ kb, int nb, int n_rows,
+                                                               int* __restrict__ row_ptr, int* __restrict__ entries,
+                                                               const int* __restrict__ live) {
+  __shared__ int keys[kCsrSmallKeys];        // -1: padding entry (not live)
+  __shared__ int warp_sums[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = na + nb;
+  for (int e = tid; e < n; e += blockDim.x)
+    keys[e] = csr_entry_live(e, na, live) ? (int)(e < na ? ka[e] : kb[e - na]) : -1;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n_rows; base += blockDim.x) {
+    const int r = base + tid;
+    int v = 0;
+    if (r < n_rows)
+      for (int e = 0; e < n; ++e) v += keys[e] == r ? 1 : 0;
+    int x = v;
+    #pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int y = __shfl_up(x, off);
+      if (lane >= off) x += y;
+    }
+    if (lane == 63) warp_sums[wave] = x;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += warp_sums[w];
+    const int c = carry;
+    const int begin = c + woff + x - v;
+    if (r < n_rows) {
+      row_ptr[r] = begin;
+      int pos = begin;
+      if (v > 0)
+        for (int e = 0; e < n; ++e)
+          if (keys[e] == r) entries[pos++] = e;
+    }
+    __syncthreads();
+    if (tid == blockDim.x - 1) carry = c + woff + x;
+    __syncthreads();
+  }
+  if (tid == 0) row_ptr[n_rows] = carry;
+}
+
 __global__ void csr_fill_kernel(const long long* __restrict__ ka, int na, const long long* __restrict__ kb,
                                 int nb, const int* __restrict__ row_ptr, int* __restrict__ cursor,
                                 int* __restrict__ tmp, const int* __restrict__ live) {
@@ -263,6 +313,11 @@ int sg2im_csr_build(const long long* keys_a, int n_a, const long long* keys_b, i
   if (n_a < 0 || n_b < 0 || n_rows < 1 || !row_ptr || !scratch || (n_a && !keys_a) || (n_b && !keys_b))
     return SG2IM_ERR_ARG;
   const int n = n_a + n_b;
+  if (n <= kCsrSmallKeys && (long long)n * ((n_rows + 1023) / 1024) <= 65536 && (n == 0 || entries)) {
+    SG2IM_LAUNCH(csr_build_small_kernel, dim3(1), dim3(1024), 0, stream, keys_a, n_a, keys_b, n_b, n_rows, row_ptr, entries,
+                 live_keys);
+    return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+  }
   int* counts = scratch;            // [n_rows]
   int* tmp = scratch + n_rows;      // [n]
   if (hipMemsetAsync(counts, 0, sizeof(int) * n_rows, stream) != hipSuccess) return SG2IM_ERR_HIP;

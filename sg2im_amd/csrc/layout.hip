@@ -159,6 +159,119 @@ __global__ __launch_bounds__(256) void layout_fwd_kernel(const float* __restrict
   }
 }
 
+// ---- layout + noise channels + the refinement network's average-pool pyramid in ONE pass -------------------
+// (crn.py:58-62 pools the full-resolution layout once per module; model.py:164-169 appends the noise channels.)
+// A workgroup owns a 16 x 16 pixel tile of one image and a slab of 32 channels - layout channels, computed as in
+// layout_fwd_kernel (objects in index order, one thread per pixel), or noise channels, read from the NCHW noise
+// tensor - writes the full-resolution NHWC tile and reduces it through LDS to up to four coarser levels, each the
+// 2 x 2 mean of the next finer one in avgpool_v4_kernel's summation order (bit-identical to the chain of
+// sg2im_avgpool_forward launches it replaces, which re-read the 84 MB tensor).
+constexpr int PT = 16;                 // tile edge
+constexpr int PS = 32;                 // channels per slab
+struct PyrLevels { float* p[5]; };     // [0] = full resolution; [l] = (H >> l) x (W >> l)
+__global__ __launch_bounds__(256) void layout_pyramid_kernel(const float* __restrict__ vecs, long long ld_vecs,
+                                                             const float* __restrict__ boxes, MaskRef mk,
+                                                             const int* __restrict__ img_row_ptr,
+                                                             const int* __restrict__ img_entries, int D,
+                                                             const float* __restrict__ noise, int ND, int H, int W,
+                                                             int align_corners, int n_levels, PyrLevels out, int ldc) {
+  __shared__ float T[PT * PT][PS + 1];
+  __shared__ float L1[64][PS + 1];
+  __shared__ float vs[LO][PS];
+  __shared__ int objs[LO];
+  const int tiles_x = W / PT;
+  const int ty0 = (blockIdx.x / tiles_x) * PT, tx0 = (blockIdx.x % tiles_x) * PT;
+  const int n = blockIdx.y, slab = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int y = ty0 + tid / PT, x = tx0 + tid % PT;
+  const int nl = D / PS;                         // layout slabs; the rest are noise slabs
+  const int cbase = slab * PS;                   // first destination channel
+  float acc[PS];
+  #pragma unroll
+  for (int k = 0; k < PS; ++k) acc[k] = 0.f;
+  if (slab < nl) {
+    const int ob = img_row_ptr[n], oe = img_row_ptr[n + 1];
+    const int Min = mk.M == 0 ? 8 : mk.M;
+    for (int cb = ob; cb < oe; cb += LO) {
+      const int nobj = min(LO, oe - cb);
+      __syncthreads();
+      if (tid < nobj) objs[tid] = img_entries[cb + tid];
+      __syncthreads();
+      for (int e = tid; e < nobj * PS; e += 256) {
+        const int oi = e / PS, k = e - oi * PS;
+        vs[oi][k] = vecs[(long long)objs[oi] * ld_vecs + cbase + k];
+      }
+      __syncthreads();
+      for (int oi = 0; oi < nobj; ++oi) {
+        const int o = objs[oi];
+        const Foot f = footprint(boxes + 4LL * o, y, x, H, W, Min, align_corners);
+        const float sv = sample_map(mk, o, f);
+        if (sv != 0.f) {                          // (a zero sample adds exactly +0: skipped, as in layout_fwd_kernel)
+          #pragma unroll
+          for (int k = 0; k < PS; ++k) acc[k] += vs[oi][k] * sv;
+        }
+      }
+    }
+  } else {
+    const int c0 = cbase - D;
+    #pragma unroll
+    for (int k = 0; k < PS; ++k) acc[k] = noise[(((long long)n * ND + c0 + k) * H + y) * W + x];
+  }
+  // full resolution
+  {
+    float* dst = out.p[0] + (((long long)n * H + y) * W + x) * ldc + cbase;
+    #pragma unroll
+    for (int k = 0; k < PS; k += 4) *reinterpret_cast<float4*>(dst + k) = make_float4(acc[k], acc[k + 1], acc[k + 2], acc[k + 3]);
+  }
+  if (n_levels < 1) return;
+  #pragma unroll
+  for (int k = 0; k < PS; ++k) T[tid][k] = acc[k];
+  __syncthreads();
+  // level 1: 8 x 8 pixels of the tile
+  for (int v = tid; v < 64 * PS; v += 256) {
+    const int px = v / PS, ch = v - px * PS;
+    const int y1 = px / 8, x1 = px - y1 * 8;
+    const int b = (2 * y1) * PT + 2 * x1;
+    float sm = T[b][ch];
+    sm += T[b + 1][ch]; sm += T[b + PT][ch]; sm += T[b + PT + 1][ch];
+    const float r = sm * 0.25f;
+    L1[px][ch] = r;
+    out.p[1][(((long long)n * (H >> 1) + (ty0 >> 1) + y1) * (W >> 1) + (tx0 >> 1) + x1) * ldc + cbase + ch] = r;
+  }
+  if (n_levels < 2) return;
+  __syncthreads();
+  // level 2: 4 x 4 (into T rows 0..15, free now), level 3: 2 x 2 (T rows 16..19), level 4: 1 (from level 3)
+  for (int v = tid; v < 16 * PS; v += 256) {
+    const int px = v / PS, ch = v - px * PS;
+    const int y2 = px / 4, x2 = px - y2 * 4;
+    const int b = (2 * y2) * 8 + 2 * x2;
+    float sm = L1[b][ch];
+    sm += L1[b + 1][ch]; sm += L1[b + 8][ch]; sm += L1[b + 9][ch];
+    const float r = sm * 0.25f;
+    T[px][ch] = r;
+    out.p[2][(((long long)n * (H >> 2) + (ty0 >> 2) + y2) * (W >> 2) + (tx0 >> 2) + x2) * ldc + cbase + ch] = r;
+  }
+  if (n_levels < 3) return;
+  __syncthreads();
+  if (tid < 4 * PS) {
+    const int px = tid / PS, ch = tid - px * PS;
+    const int y3 = px / 2, x3 = px - y3 * 2;
+    const int b = (2 * y3) * 4 + 2 * x3;
+    float sm = T[b][ch];
+    sm += T[b + 1][ch]; sm += T[b + 4][ch]; sm += T[b + 5][ch];
+    const float r = sm * 0.25f;
+    T[16 + px][ch] = r;
+    out.p[3][(((long long)n * (H >> 3) + (ty0 >> 3) + y3) * (W >> 3) + (tx0 >> 3) + x3) * ldc + cbase + ch] = r;
+  }
+  if (n_levels < 4) return;
+  __syncthreads();
+  if (tid < PS) {
+    float sm = T[16][tid];
+    sm += T[17][tid]; sm += T[18][tid]; sm += T[19][tid];
+    out.p[4][(((long long)n * (H >> 4) + (ty0 >> 4)) * (W >> 4) + (tx0 >> 4)) * ldc + cbase + tid] = sm * 0.25f;
+  }
+}
+
 // ---- backward w.r.t. vecs: partial[tile][o_local][d] then reduce --------------------
 constexpr int BP = 64;      // pixels per workgroup
 constexpr int BO = 8;       // objects per register pass
@@ -579,6 +692,30 @@ int sg2im_layout_forward(const float* vecs, long long ld_vecs, const float* boxe
   dim3 grid((height * width + LP - 1) / LP, n_images);
   SG2IM_LAUNCH(layout_fwd_kernel, grid, dim3(256), 0, stream, vecs, ld_vecs, boxes, mk, img_row_ptr, img_entries,
                      dim, height, width, align_corners, layout, ld_layout);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_layout_pyramid_forward(const float* vecs, long long ld_vecs, const float* boxes, const float* masks,
+                                 const long long* masks_i64, int mask_size, const int* img_row_ptr,
+                                 const int* img_entries, int n_images, int dim, const float* noise, int noise_dim,
+                                 int height, int width, int align_corners, int n_levels, float* const* levels,
+                                 long long ld_levels, hipStream_t stream) {
+  if (!vecs || !boxes || !img_row_ptr || !levels || dim < 1 || height < 1 || width < 1 || n_images < 0 || noise_dim < 0)
+    return SG2IM_ERR_ARG;
+  if ((masks || masks_i64) && mask_size < 1) return SG2IM_ERR_ARG;
+  if (dim % PS || noise_dim % PS || (noise_dim > 0 && !noise) || height % PT || width % PT || n_levels < 0 || n_levels > 4 ||
+      ld_levels < dim + noise_dim || ld_levels % 4)
+    return SG2IM_ERR_ARG;
+  PyrLevels out;
+  for (int l = 0; l < 5; ++l) {
+    out.p[l] = l <= n_levels ? levels[l] : nullptr;
+    if (l <= n_levels && (!levels[l] || ((uintptr_t)levels[l] & 15))) return SG2IM_ERR_ARG;
+  }
+  if (n_images == 0) return SG2IM_OK;
+  const MaskRef mk{masks, masks_i64, (masks || masks_i64) ? mask_size : 0};
+  dim3 grid((height / PT) * (width / PT), n_images, (dim + noise_dim) / PS);
+  SG2IM_LAUNCH(layout_pyramid_kernel, grid, dim3(256), 0, stream, vecs, ld_vecs, boxes, mk, img_row_ptr, img_entries, dim,
+               noise, noise_dim, height, width, align_corners, n_levels, out, (int)ld_levels);
   return ok_or(hipGetLastError());
 }
 

@@ -460,9 +460,12 @@ class LayoutFn(Function):
   returns the NHWC tensor (N, H, W, D + noise_dim) the refinement network consumes."""
 
   @staticmethod
-  def forward(ctx, vecs, boxes, masks, obj_to_img, noise, n_images, H, W, align_corners, img_csr=None):
+  def forward(ctx, vecs, boxes, masks, obj_to_img, noise, n_images, H, W, align_corners, img_csr=None,
+              pyramid_levels=0):
     """img_csr: the per-image object lists (ops.Csr(obj_to_img, None, n_images)) when the caller built them
-    already (Sg2ImModel does, off the critical path)"""
+    already (Sg2ImModel does, off the critical path).  pyramid_levels > 0: the caller feeds the result to a
+    refinement network of pyramid_levels + 1 modules, whose 2 x 2 average-pool pyramid (crn.py:58-62) is then
+    produced by the same kernel and handed over through LAYOUT_PYRAMIDS."""
     D = vecs.size(1)
     nd = noise.size(1) if noise is not None else 0
     if vecs.stride(1) != 1:
@@ -471,9 +474,18 @@ class LayoutFn(Function):
     if img_csr is None:
       img_csr = ops.Csr(obj_to_img, None, n_images)
     out = _new(vecs, n_images, H, W, D + nd)
-    ops.layout_forward(vecs, boxes, masks, img_csr, n_images, H, W, align_corners, out)
-    if nd > 0:
-      ops.nchw_to_nhwc(noise.contiguous(), out, D)
+    nlev = min(int(pyramid_levels), 4)
+    if ops.LAYOUT_PYRAMID and D % 32 == 0 and nd % 32 == 0 and H % 16 == 0 and W % 16 == 0 and n_images > 0:
+      levels = [out] + [_new(vecs, n_images, H >> l, W >> l, D + nd) for l in range(1, nlev + 1)]
+      ops.layout_pyramid_forward(vecs, boxes, masks, img_csr, n_images, H, W, align_corners,
+                                 noise.contiguous() if nd > 0 else None, levels)
+      if nlev > 0:
+        LAYOUT_PYRAMIDS.clear()                       # (one pending hand-over at a time)
+        LAYOUT_PYRAMIDS[out.data_ptr()] = levels
+    else:
+      ops.layout_forward(vecs, boxes, masks, img_csr, n_images, H, W, align_corners, out)
+      if nd > 0:
+        ops.nchw_to_nhwc(noise.contiguous(), out, D)
     ctx.save_for_backward(vecs, boxes, masks, obj_to_img)
     ctx.img_csr, ctx.geom = img_csr, (n_images, H, W, align_corners)
     return out
@@ -492,7 +504,22 @@ class LayoutFn(Function):
     if d_vecs is not None or d_masks is not None or d_boxes is not None:
       ops.layout_backward(g, vecs, boxes, masks, obj_to_img, ctx.img_csr, n_images, H, W, ac, d_vecs, d_masks,
                           d_boxes)
-    return d_vecs, d_boxes, d_masks, None, None, None, None, None, None, None
+    return d_vecs, d_boxes, d_masks, None, None, None, None, None, None, None, None
+
+
+LAYOUT_PYRAMIDS = {}      # data_ptr of a full-resolution layout -> [level 0, level 1, ...] from LayoutFn
+
+
+def _layout_pyramid(layout, L):
+  """[coarsest, ..., full resolution]: the L levels a refinement network of L modules reads (crn.py:58-62 pools
+  the full-resolution layout once per module; each level here is the 2 x 2 mean of the next finer one - the same
+  value up to fp32 summation order).  Levels LayoutFn already produced are taken over, the rest pooled."""
+  N, H, W, Cl = layout.shape
+  pyr = LAYOUT_PYRAMIDS.pop(layout.data_ptr(), None) or [layout]
+  pyr = pyr[:L]
+  for i in range(len(pyr), L):
+    pyr.append(ops.avgpool_forward(pyr[-1], 2, _new(layout, N, H >> i, W >> i, Cl)))
+  return pyr[::-1]
 
 
 class CropFn(Function):
@@ -609,13 +636,7 @@ class RefinementFn(Function):
     # zero channel its 161 input channels would fall off the vector loaders
     feat_src = None
     saved = []
-    # layout pyramid (crn.py:62 pools the full-resolution layout once per module): each level is
-    # the 2x2 mean of the next finer one - the same value up to fp32 summation order, with the
-    # 84 MB full-resolution layout read once instead of L - 1 times
-    pyr = [layout]
-    for i in range(1, L):
-      pyr.append(ops.avgpool_forward(pyr[-1], 2, _new(layout, N, H >> i, W >> i, Cl)))
-    pyr = pyr[::-1]
+    pyr = _layout_pyramid(layout, L)
 
     def activated(y, st, up):
       """the source the next convolution reads: leaky(bn(y)), pending in its loader"""
@@ -782,10 +803,7 @@ class RefinementNoNormFn(Function):
       layout = layout.contiguous()
       feats = torch.zeros(N, h0, w0, 1, dtype=torch.float32, device=layout.device)   # crn.py:105
       feat_src = nhwc_src(feats, up=1)
-      pyr = [layout]
-      for i in range(1, L):
-        pyr.append(ops.avgpool_forward(pyr[-1], 2, _new(layout, N, H >> i, W >> i, Cl)))
-      pyr = pyr[::-1]
+      pyr = _layout_pyramid(layout, L)
       saved = []
       for i in range(L):
         h, w = H >> (L - 1 - i), W >> (L - 1 - i)

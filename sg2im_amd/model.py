@@ -158,7 +158,8 @@ class Sg2ImModel(nn.Module):
       noise = torch.randn((num_images, self.layout_noise_dim, H, W), dtype=obj_vecs.dtype,
                           device=obj_vecs.device)
     layout = layout_nhwc(obj_vecs, layout_boxes, layout_masks, obj_to_img, H, W, noise=noise,
-                         n_images=num_images, align_corners=self.align_corners, img_csr=img_csr)
+                         n_images=num_images, align_corners=self.align_corners, img_csr=img_csr,
+                         pyramid_levels=len(self.refinement_net.refinement_modules) - 1)
     # the appended noise channels need no gradient: only the first D layout channels do
     img = self.refinement_net.forward_nhwc(layout, layout_grad_channels=obj_vecs.size(1))
     if aux_stream is not None:

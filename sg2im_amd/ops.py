@@ -507,6 +507,25 @@ def layout_forward(vecs, boxes, masks, img_csr, n_images, H, W, align_corners, o
   return out
 
 
+LAYOUT_PYRAMID = os.environ.get('SG2IM_LAYOUT_PYRAMID', '1') != '0'   # A/B knob: fused layout + noise + pyramid
+
+
+def layout_pyramid_forward(vecs, boxes, masks, img_csr, n_images, H, W, align_corners, noise, levels):
+  """levels[0]: NHWC (N,H,W,D+nd) full resolution; levels[l]: (N, H>>l, W>>l, D+nd) - all written."""
+  pv, ldv = rows_ld(vecs)
+  mf, mi, M = _mask_args(masks)
+  O, D = vecs.size(0), vecs.size(1)
+  nd = noise.size(1) if noise is not None else 0
+  ptrs = (c_void_p * len(levels))(*[t.data_ptr() for t in levels])
+  px = sum(t.size(1) * t.size(2) for t in levels)
+  nbytes = 4.0 * (n_images * px * (D + nd) + n_images * H * W * nd + O * (D + 4 + M * M))
+  _timed('hbm_layout_fwd', nbytes, lambda: call(
+    'sg2im_layout_pyramid_forward', pv, ldv, _f(boxes), mf, mi, M, _i32(img_csr.row_ptr), _i32(img_csr.entries),
+    int(n_images), D, _f(noise) if noise is not None else None, nd, int(H), int(W), int(align_corners),
+    len(levels) - 1, ptrs, levels[0].size(3), _stream()))
+  return levels
+
+
 def layout_backward(dlayout, vecs, boxes, masks, obj_to_img, img_csr, n_images, H, W, align_corners,
                     d_vecs, d_masks, d_boxes=None):
   pv, ldv = rows_ld(vecs)

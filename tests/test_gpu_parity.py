@@ -112,6 +112,45 @@ def test_layout_and_crops_align_corners_true():
   _run('sec_layout_align_corners')
 
 
+@pytest.mark.parametrize('H,L,nd,masks', [(64, 5, 32, 'float'), (64, 3, 0, 'float'), (32, 2, 32, 'int'),
+                                          (128, 5, 32, None), (16, 5, 32, 'float')])
+def test_layout_noise_pyramid_in_one_launch_is_bit_exact(H, L, nd, masks):
+  """sg2im_layout_pyramid_forward (layout + noise channels + the refinement network's
+  average-pool pyramid in one pass) against the launches it replaces: sg2im_layout_forward, sg2im_nchw_to_nhwc
+  and the chain of sg2im_avgpool_forward - every level bit for bit; ragged images, one image without objects"""
+  from sg2im_amd import ops
+  D = torch.device('cuda', 0)
+  g = torch.Generator().manual_seed(H + L)
+  N, Dv, M = 5, 128, 16
+  o2i = torch.tensor([0] * 7 + [1] * 1 + [3] * 40 + [4] * 3, dtype=torch.long)       # image 2 is empty; 40 > 32 objects
+  O = o2i.numel()
+  vecs = torch.randn(O, Dv, generator=g).to(D)
+  xy = torch.rand(O, 2, generator=g) * 0.6
+  wh = torch.rand(O, 2, generator=g) * 0.4 + 0.02
+  boxes = torch.cat([xy, xy + wh], 1).to(D)
+  mk = None
+  if masks == 'float':
+    mk = torch.rand(O, M, M, generator=g).to(D)
+  elif masks == 'int':
+    mk = (torch.rand(O, M, M, generator=g) > 0.4).long().to(D)
+  noise = torch.randn(N, nd, H, H, generator=g).to(D) if nd else None
+  csr = ops.Csr(o2i.to(D), None, N)
+  want0 = torch.empty(N, H, H, Dv + nd, device=D)
+  ops.layout_forward(vecs, boxes, mk, csr, N, H, H, 0, want0)
+  if nd:
+    ops.nchw_to_nhwc(noise, want0, Dv)
+  nlev = min(L - 1, 4, max(0, H.bit_length() - 1))
+  want = [want0]
+  for l in range(1, nlev + 1):
+    want.append(ops.avgpool_forward(want[-1], 2, torch.empty(N, H >> l, H >> l, Dv + nd, device=D)))
+  got = [torch.full_like(t, float('nan')) for t in want]
+  ops.layout_pyramid_forward(vecs, boxes, mk, csr, N, H, H, 0, noise, got)
+  torch.cuda.synchronize()
+  for l, (a, b) in enumerate(zip(got, want)):
+    assert torch.equal(a, b), (l, float((a - b).abs().max()))
+  assert float(got[0][2, :, :, :Dv].abs().max()) == 0.0
+
+
 def test_losses_and_adam():
   _run('sec_losses')
 
