@@ -185,12 +185,25 @@ def main():
     trainer.step(batches[i % nb])
   sync()
   stats0 = dict(trainer.graph_stats)
+  host0 = dict(trainer.host_seconds)
   t0 = time.perf_counter()
+  host_trace = [] if os.environ.get('SG2IM_HOST_TRACE') == '1' else None      # diagnostics: host time of every step() call
   for i in range(args.steps):
+    t1 = time.perf_counter()
     losses = trainer.step(batches[(args.warmup + i) % nb])
+    if host_trace is not None:
+      bt = batches[(args.warmup + i) % nb]
+      host_trace.append((time.perf_counter() - t1, trainer.bucketer.bucket(bt[1].numel(), bt[4].size(0)) if trainer.bucketer else None))
+  host_issue = time.perf_counter() - t0          # (the host's share: how long issuing the K steps took)
+  if host_trace is not None:
+    print('[host] ' + ' '.join('%s:%.2f' % (b[0] if b else '-', dt * 1e3) for dt, b in host_trace), file=sys.stderr)
   sync()
   elapsed = time.perf_counter() - t0
   stats1 = dict(trainer.graph_stats)
+  if os.environ.get('SG2IM_MARKS') == '1':       # diagnostics: where the lanes of the last replayed iteration were in time
+    from sg2im_amd import ops as _ops
+    for name, us in _ops.marks_report():
+      print('[mark] %-18s %9.1f us' % (name, us), file=sys.stderr)
   launch_stats = dict(trainer.launch_stats)
   n_graphs = len(trainer._graphs)
 
@@ -342,7 +355,9 @@ def main():
     out = {
       'metric': 'training images/sec (G+D step)', 'value': round(imgs / elapsed, 2), 'unit': 'images/sec',
       'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-      'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+      'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+      'host_issue_ms_per_step': round(host_issue / args.steps * 1e3, 3),
+      'host_issue_detail_ms': {k: round((trainer.host_seconds[k] - host0[k]) / args.steps * 1e3, 3) for k in host0}, 'higher_is_better': True, 'scaling': 'weak',
       'vs_baseline': None,
       'dtype': 'f32' if args.dtype == 'f32' else 'bf16 (matrix-core operands of the spatial convolutions; fp32 accumulation, tensors, statistics and Adam)',
       'data': 'synthetic',

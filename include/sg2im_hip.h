@@ -273,6 +273,9 @@ int sg2im_gconv_layer_backward(const sg2im_gconv_layer* layer, const float* h1, 
  * input buffers a captured iteration reads - images, object / triple / mask arrays and their padding, the two
  * row counts.  dst / src / bytes are HOST arrays of n entries. */
 int sg2im_stage_batch(int n, void* const* dst, const void* const* src, const size_t* bytes, hipStream_t stream);
+/* Diagnostics: one single-thread launch that stores the device's constant-rate clock (wall_clock64(), 100 MHz) in
+ * *slot when the stream reaches it - schedule marks inside a captured iteration (Trainer, SG2IM_MARKS=1). */
+int sg2im_timestamp(unsigned long long* slot, hipStream_t stream);
 
 /* dst[r][0:width] = src[r][0:width] for strided row matrices (the new_p column slice of the
  * net1 output, graph.py:88, travelling through backward) */

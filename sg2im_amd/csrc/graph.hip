@@ -23,6 +23,11 @@ __device__ __forceinline__ bool csr_entry_live(int e, int na, const int* __restr
   return (e < na ? e : e - na) < live[0];
 }
 
+// The constant 100 MHz device clock into *slot: the Trainer's schedule marks (SG2IM_MARKS=1) - where the lanes of a
+// replayed iteration really are in time, without a profiler serialising the host side of the replay.
+__global__ void timestamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+
+
 __global__ void csr_count_kernel(const long long* __restrict__ ka, int na, const long long* __restrict__ kb,
                                  int nb, int* __restrict__ counts, const int* __restrict__ live) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -303,6 +308,12 @@ int sg2im_stage_batch(int n, void* const* dst, const void* const* src, const siz
   }
   const int bx = (int)std::max<size_t>(1, std::min<size_t>((most + 256 * 8 - 1) / (256 * 8), 64));
   SG2IM_LAUNCH(stage_batch_kernel, dim3(bx, n), dim3(256), 0, stream, j);
+  return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+}
+
+int sg2im_timestamp(unsigned long long* slot, hipStream_t stream) {
+  if (!slot) return SG2IM_ERR_ARG;
+  SG2IM_LAUNCH(sg2im::timestamp_kernel, dim3(1), dim3(1), 0, stream, slot);
   return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
 }
 

@@ -614,6 +614,7 @@ class RefinementFn(Function):
   @staticmethod
   def forward(ctx, layout, bns, slope, training, grad_channels, *params):
     ops.TIMER_TAG = 'crn'
+    ops.mark('crn_fwd_start')
     try:
       return RefinementFn._forward(ctx, layout, bns, slope, training, grad_channels, *params)
     finally:
@@ -675,9 +676,12 @@ class RefinementFn(Function):
 
   @staticmethod
   def backward(ctx, g):
+    ops.mark('crn_bwd_start')
     ops.TIMER_TAG = 'crn'
     try:
-      return RefinementFn._backward(ctx, g)
+      out = RefinementFn._backward(ctx, g)
+      ops.mark('crn_bwd_done')
+      return out
     finally:
       ops.TIMER_TAG = None
 

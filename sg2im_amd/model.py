@@ -111,6 +111,7 @@ class Sg2ImModel(nn.Module):
     # (padded batch: the padding triples stay out of the pooling CSR - no long tail row on the dummy object)
     edges = (s, o, ops.Csr(s, o, O, live=triple_count))
 
+    ops.mark('csr_done')
     obj_vecs = HF.Embedding.apply(self.obj_embeddings.weight, objs)
     obj_vecs_orig = obj_vecs
     pred_vecs = HF.Embedding.apply(self.pred_embeddings.weight, p)
@@ -121,6 +122,7 @@ class Sg2ImModel(nn.Module):
     if self.gconv_net is not None:
       obj_vecs, pred_vecs = self.gconv_net(obj_vecs, pred_vecs, edges, (obj_count, triple_count))
 
+    ops.mark('gcn_layers_done')
     masks_pred = rel_scores = None
     on_aux = aux_stream is not None and ((self.mask_net is not None and detach_masks) or detach_rel)
     if on_aux:
@@ -157,6 +159,7 @@ class Sg2ImModel(nn.Module):
     elif self.layout_noise_dim > 0:                           # reference sg2im/model.py:164-168
       noise = torch.randn((num_images, self.layout_noise_dim, H, W), dtype=obj_vecs.dtype,
                           device=obj_vecs.device)
+    ops.mark('gcn_done')
     layout = layout_nhwc(obj_vecs, layout_boxes, layout_masks, obj_to_img, H, W, noise=noise,
                          n_images=num_images, align_corners=self.align_corners, img_csr=img_csr,
                          pyramid_levels=len(self.refinement_net.refinement_modules) - 1)

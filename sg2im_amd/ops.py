@@ -64,6 +64,9 @@ def _i32(t):
 # and joins the lanes it finds there before the optimiser step.  [measured: 10.3 -> 9.7 ms per step,
 # profiles/r2_deferred_wgrad_ab.log]
 DEFER_WGRAD = True
+# probe knob: capture the whole iteration on ONE stream (a hipGraph without parallel branches replays on clr's
+# single-stream fast path, tools/graph_order_probe.py)
+SINGLE_STREAM = os.environ.get('SG2IM_SINGLE_STREAM', '0') == '1'
 DEFERRED = None
 # (count, callback(stream)): called on the weight-gradient stream right after the first `count` released weight
 # gradients were issued - the data-parallel Trainer starts the all-reduce of the gradient bucket they complete
@@ -88,6 +91,33 @@ _wgrad_streams = {}
 GROUP_WGRAD = True
 
 
+# Schedule marks (diagnostics, SG2IM_MARKS=1): mark(name) stores the device clock when the current stream reaches
+# that point of a (captured) iteration; marks_report() reads the last replay's values back.
+MARKS = os.environ.get('SG2IM_MARKS', '0') == '1'
+_marks = {'buf': None, 'names': {}}
+
+
+def marks_init(device):
+  if MARKS and _marks['buf'] is None:
+    _marks['buf'] = torch.zeros(256, dtype=torch.int64, device=device)
+
+
+def mark(name):
+  if not MARKS or _marks['buf'] is None:
+    return
+  idx = _marks['names'].setdefault(name, len(_marks['names']))
+  call('sg2im_timestamp', _marks['buf'].data_ptr() + 8 * idx, _stream())
+
+
+def marks_report():
+  """[(name, microseconds since the 'start' mark)] of the last replay, in time order"""
+  if _marks['buf'] is None:
+    return []
+  v = _marks['buf'].cpu().tolist()
+  t0 = v[_marks['names'].get('start', 0)]
+  return sorted(((n, (v[i] - t0) / 100.0) for n, i in _marks['names'].items()), key=lambda r: r[1])
+
+
 class SideLane(object):
   """Runs the weight-gradient launches of a backward pass on a second stream.  They are leaves of
   the backward graph (nothing downstream reads dW before the optimiser), so the small kernels of
@@ -99,7 +129,7 @@ class SideLane(object):
   def __init__(self, device):
     # only while a hipGraph is being captured: launched eagerly, the extra event / stream switches
     # cost more host time (the eager step is launch bound) than the overlap returns
-    self.on = torch.cuda.is_current_stream_capturing()
+    self.on = torch.cuda.is_current_stream_capturing() and not SINGLE_STREAM
     self.used = False
     self.keep = []
     self.queue = []
@@ -140,11 +170,13 @@ class SideLane(object):
     ev.record(self.main)
     self.side.wait_event(ev)
     with torch.cuda.stream(self.side):
+      mark('wgrad_lane_start')
       # (the layers the data-gradient chain reached last first: 8.80 vs 8.84-8.85 ms in queue order)
       for k, fn in enumerate(reversed(self.queue)):
         fn(k < BG_COUNT)
         if AFTER_DEFERRED is not None and k + 1 == AFTER_DEFERRED[0]:
           AFTER_DEFERRED[1](self.side)       # (Trainer: the first gradient bucket is complete on this stream)
+      mark('wgrad_lane_done')
     self.queue = []
     self.used = True
 

@@ -14,6 +14,7 @@ Differences from the reference that do not change the mathematics:
 import collections
 import math
 import os
+import time
 
 import torch
 
@@ -128,6 +129,7 @@ class Trainer(object):
     # discriminator steps run on a side stream concurrently with the generator's backward
     # (they only need imgs_pred; their small kernels fill the CUs the GCN / MLP backward leaves idle)
     self.overlap_d = True if overlap_d is None else bool(overlap_d)
+    self.host_seconds = {'stage_batch': 0.0, 'graph_launch': 0.0}     # host time spent issuing replays (bench.py)
     self._side = None
     self._graphs = collections.OrderedDict()
     self.t = 0
@@ -169,10 +171,11 @@ class Trainer(object):
   def _seg_generator_model(self, batch, st):
     """train.py:524-530: the generator itself; `imgs_fake` is all the discriminator steps need"""
     imgs, objs, boxes, masks, triples, obj_to_img = batch[:6]
+    ops.mark('start')
     st['imgs_nhwc'] = HF.NchwToNhwc.apply(imgs)
     # captured iteration: whatever is not on the path to the image leaves the critical path (Sg2ImModel.forward_nhwc)
     aux = self._side[0] if (self._side is not None and torch.cuda.is_current_stream_capturing() and
-                            os.environ.get('SG2IM_AUX', '1') != '0') else None      # (A/B knob)
+                            os.environ.get('SG2IM_AUX', '1') != '0' and not ops.SINGLE_STREAM) else None      # (A/B knob)
     w = self.w
     st['gen_out'] = self.model.forward_nhwc(objs, triples, obj_to_img, boxes_gt=boxes, masks_gt=masks,
                                             num_images=imgs.size(0), obj_count=st.get('ocnt'),
@@ -180,6 +183,7 @@ class Trainer(object):
                                             detach_masks=masks is not None and not w['mask_loss_weight'] > 0,
                                             detach_rel=not w['predicate_pred_loss_weight'] > 0)
     st['imgs_fake'] = st['gen_out'][0].detach()
+    ops.mark('g_fwd_done')
 
   def _seg_generator_losses(self, batch, st):
     imgs, objs, boxes, masks, triples, obj_to_img = batch[:6]
@@ -207,7 +211,8 @@ class Trainer(object):
                                                    cnt(oc, masks_pred.size(1) * masks_pred.size(2)))
     gi = None
     par = (self.d_img is not None and self.d_obj is not None and self._aux2 is not None and
-           torch.cuda.is_current_stream_capturing() and os.environ.get('SG2IM_PAR_DIMG', '1') != '0')      # (A/B knob)
+           torch.cuda.is_current_stream_capturing() and os.environ.get('SG2IM_PAR_DIMG', '1') != '0' and
+           not ops.SINGLE_STREAM)      # (A/B knob)
     ev = st.pop('imgs_pred_ready', None)
     if par:
       # captured iteration: the image discriminator's pass over the fake images runs on a stream of its own NEXT
@@ -240,24 +245,29 @@ class Trainer(object):
     # NaN guard of train.py:553-555 without a host sync: every optimiser of this iteration
     # skips its update when the generator loss is not finite (on any rank).
     st['guard'] = total.detach().reshape(1).clone()
+    ops.mark('g_losses_done')
     for d in (self.d_obj, self.d_img):
       if d is not None:
         _set_requires_grad(d, True)
 
   def _seg_generator_backward(self, st):
     self.opt_g.zero_grad()
-    defer = ops.DEFER_WGRAD and torch.cuda.is_current_stream_capturing()
+    ops.mark('g_bwd_start')
+    defer = ops.DEFER_WGRAD and torch.cuda.is_current_stream_capturing() and not ops.SINGLE_STREAM
     ops.DEFERRED = [] if defer else None
     try:
       st.pop('total').backward(ops.unit(self.device))
     finally:
       lanes, ops.DEFERRED = ops.DEFERRED, None
+    ops.mark('g_bwd_done')
     for lane in lanes or ():
       lane.join()
 
   def _seg_d_obj(self, batch, st):
+    ops.mark('d_obj_start')
     self._seg_d_obj_forward(batch, st)
     self._seg_d_obj_backward(batch, st)
+    ops.mark('d_obj_done')
 
   def _seg_d_obj_forward(self, batch, st):
     imgs, objs, boxes, masks, triples, obj_to_img = batch[:6]
@@ -277,12 +287,14 @@ class Trainer(object):
 
   def _seg_d_img(self, batch, st):
     losses = st['losses']
+    ops.mark('d_img_start')
     # train.py:581-592
     sf = self.d_img.forward_nhwc(st['imgs_fake'])
     sr = self.d_img.forward_nhwc(st['imgs_nhwc'])
     losses['d_img_gan_loss'] = self.gan_d_loss(sr, sf)
     self.opt_di.zero_grad()
     losses['d_img_gan_loss'].backward(ops.unit(self.device))
+    ops.mark('d_img_done')
 
   def _seg_adam(self, st):
     # all three updates at the end: same values as the reference's in-order updates because
@@ -294,6 +306,7 @@ class Trainer(object):
     if self.opt_di is not None:
       self.opt_di.step_guarded(guard, gs)
     st['out'] = {k: v.detach() for k, v in st['losses'].items()}
+    ops.mark('adam_done')
 
   def _run_segments(self, batch, st, run):
     """run(name, fn) executes (or replays) one segment; exchanges are started in between.
@@ -383,6 +396,7 @@ class Trainer(object):
         ops.workspace(dev)
         ops.scratch(dev, scratch_floats)
     ops.unit(dev)                    # (cached process-wide: must not be born inside a capture)
+    ops.marks_init(dev)
 
   def _graph_step(self, batch):
     """The eager step costs ~12 ms of Python/ctypes launch time for ~480 kernels - more than the
@@ -429,11 +443,15 @@ class Trainer(object):
         self.graph_stats['evicted'] += 1
     else:
       self._graphs.move_to_end(key)
+      t0 = time.perf_counter()
       ent[0].load(batch)
+      self.host_seconds['stage_batch'] += time.perf_counter() - t0
     sb, graphs, st, _ = ent
     self.graph_stats['replays'] += 1
     if 'all' in graphs:
+      t0 = time.perf_counter()
       graphs['all'].replay()
+      self.host_seconds['graph_launch'] += time.perf_counter() - t0
       if 'adam' in graphs:          # data parallel: gradient exchange between the two graphs
         self._exchange_all(st)
         graphs['adam'].replay()
@@ -547,6 +565,9 @@ class Trainer(object):
         reduce_after(main, st['guard'])
 
       def on_side(seg, grads=None):
+        if ops.SINGLE_STREAM:
+          seg(static, st)
+          return
         side.wait_stream(main)
         with torch.cuda.stream(side):
           seg(static, st)
