@@ -76,20 +76,25 @@ __global__ __launch_bounds__(1024) void csr_build_small_kernel(const long long* 
                                                                const long long* __restrict__ kb, int nb, int n_rows,
                                                                int* __restrict__ row_ptr, int* __restrict__ entries,
                                                                const int* __restrict__ live) {
-  __shared__ int keys[kCsrSmallKeys];        // -1: padding entry (not live)
+  __shared__ __attribute__((aligned(16))) int keys[kCsrSmallKeys];        // -1: padding entry (not live)
   __shared__ int warp_sums[16];
   __shared__ int carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = na + nb;
-  for (int e = tid; e < n; e += blockDim.x)
-    keys[e] = csr_entry_live(e, na, live) ? (int)(e < na ? ka[e] : kb[e - na]) : -1;
+  const int n4 = (n + 3) >> 2;               // (walked four keys per LDS read; the tail is padding)
+  for (int e = tid; e < 4 * n4; e += blockDim.x)
+    keys[e] = e < n && csr_entry_live(e, na, live) ? (int)(e < na ? ka[e] : kb[e - na]) : -1;
   if (tid == 0) carry = 0;
   __syncthreads();
+  const int4* keys4 = reinterpret_cast<const int4*>(keys);
   for (int base = 0; base < n_rows; base += blockDim.x) {
     const int r = base + tid;
     int v = 0;
     if (r < n_rows)
-      for (int e = 0; e < n; ++e) v += keys[e] == r ? 1 : 0;
+      for (int q = 0; q < n4; ++q) {
+        const int4 k = keys4[q];
+        v += (k.x == r ? 1 : 0) + (k.y == r ? 1 : 0) + (k.z == r ? 1 : 0) + (k.w == r ? 1 : 0);
+      }
     int x = v;
     #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -105,9 +110,14 @@ __global__ __launch_bounds__(1024) void csr_build_small_kernel(const long long* 
     if (r < n_rows) {
       row_ptr[r] = begin;
       int pos = begin;
-      if (v > 0)
-        for (int e = 0; e < n; ++e)
-          if (keys[e] == r) entries[pos++] = e;
+      const int end = begin + v;
+      for (int q = 0; q < n4 && pos < end; ++q) {
+        const int4 k = keys4[q];
+        if (k.x == r) entries[pos++] = 4 * q;
+        if (k.y == r) entries[pos++] = 4 * q + 1;
+        if (k.z == r) entries[pos++] = 4 * q + 2;
+        if (k.w == r) entries[pos++] = 4 * q + 3;
+      }
     }
     __syncthreads();
     if (tid == blockDim.x - 1) carry = c + woff + x;
