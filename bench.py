@@ -300,7 +300,7 @@ def main():
     launches = sum(v['launches'] for v in summ.values())
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     roofline = {
-      'bound': 'mfma', 'kernel': 'implicit-GEMM family conv_fwd/dgrad/wgrad_kernel (%s) incl. split-K finish' % (
+      'bound': 'mfma', 'kernel': 'implicit-GEMM family conv_fwd/dgrad/wgrad_kernel + conv_halo_kernel (3x3 stride-1 forward / data gradient) (%s) incl. split-K finish' % (
         'bf16 operands v_mfma_f32_32x32x16_bf16 for the spatial convolutions, fp32 v_mfma_f32_32x32x2_f32 for the linear layers; '
         'priced against the bf16 peak' if args.dtype == 'bf16' else 'fp32 v_mfma_f32_32x32x2_f32'),
       'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',

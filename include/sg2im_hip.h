@@ -273,6 +273,10 @@ int sg2im_gconv_layer_backward(const sg2im_gconv_layer* layer, const float* h1, 
  * input buffers a captured iteration reads - images, object / triple / mask arrays and their padding, the two
  * row counts.  dst / src / bytes are HOST arrays of n entries. */
 int sg2im_stage_batch(int n, void* const* dst, const void* const* src, const size_t* bytes, hipStream_t stream);
+/* Diagnostics (bench.py's instrumented pass): while `event` is set (per host thread; NULL clears it), the *_bn
+ * entry points record it on their stream between their GEMM launches (incl. a split-K finish) and their BatchNorm
+ * finish launch and set *recorded = 1 - a timer bracketing the call can then attribute the two parts separately. */
+int sg2im_debug_mark_gemm_end(hipEvent_t event, int* recorded);
 /* Diagnostics: one single-thread launch that stores the device's constant-rate clock (wall_clock64(), 100 MHz) in
  * *slot when the stream reaches it - schedule marks inside a captured iteration (Trainer, SG2IM_MARKS=1). */
 int sg2im_timestamp(unsigned long long* slot, hipStream_t stream);

@@ -81,6 +81,7 @@ _SIGNATURES = {
   'sg2im_gconv_pool_backward': [_P, _L, _P, _P, _I, _P, _P, _L, _P, _L, _I, _I, _F, _P, _L, _P],
   'sg2im_copy_2d': [_P, _L, _P, _L, _L, _I, _P],
   'sg2im_timestamp': [_P, _P],
+  'sg2im_debug_mark_gemm_end': [_P, POINTER(c_int)],
   'sg2im_stage_batch': [_I, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_size_t), _P],
   'sg2im_gconv_layer_forward': [POINTER(GconvLayer), _P, _P, _P, _P, _P, _P, _Z, _P],
   'sg2im_gconv_layer_backward_scratch': [_I, _I, _I, _I, _I],

@@ -821,8 +821,18 @@ static inline int ew_blocks(long long total) {
 }
 static inline int ok_or(hipError_t e) { return e == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP; }
 
+// sg2im_debug_mark_gemm_end: a caller-supplied event recorded between the GEMM launches of a *_bn entry point and
+// its BatchNorm finish launch (per host thread), so that a timer can attribute the two parts separately
+static thread_local hipEvent_t t_gemm_end_event = nullptr;
+static thread_local int* t_gemm_end_flag = nullptr;
+static void mark_gemm_end(hipStream_t stream) {
+  if (!t_gemm_end_event) return;
+  if (hipEventRecord(t_gemm_end_event, stream) == hipSuccess && t_gemm_end_flag) *t_gemm_end_flag = 1;
+}
+
 int bn_stats_finish_tiles(const float* partial, int nblk, long long per, long long rows, int channels,
                           const sg2im_bn_fwd* a, hipStream_t stream) {
+  mark_gemm_end(stream);
   SG2IM_LAUNCH(bn_stats_final_tiles_kernel, dim3((channels + 3) / 4), dim3(256), 0, stream, partial, nblk, per, rows,
                      a->unbiased_rows, channels, a->gamma, a->beta, a->eps, a->momentum, a->running_mean, a->running_var,
                      a->num_batches_tracked, a->mean, a->invstd, a->scale, a->shift, a->count, a->count_unit);
@@ -831,6 +841,7 @@ int bn_stats_finish_tiles(const float* partial, int nblk, long long per, long lo
 
 int bn_bwd_finish_tiles(const float* partial, int nblk, long long rows, int channels, const sg2im_bn_bwd* a,
                         hipStream_t stream) {
+  mark_gemm_end(stream);
   SG2IM_LAUNCH(bn_bwd_final_tiles_kernel, dim3((channels + 3) / 4), dim3(256), 0, stream, partial, nblk, rows, channels,
                      a->gamma, a->mean, a->invstd, a->training, a->dgamma, a->dbeta, a->accumulate, a->coef, a->count,
                      a->count_unit);
@@ -907,6 +918,12 @@ int sg2im_bn_act_backward(const float* g, long long ld_g, int pool2, int batch, 
   if (rc != SG2IM_OK) return rc;
   return sg2im_bn_backward_apply(g, ld_g, pool2, batch, h, w, y, ld_y, channels, scale, shift, slope, a.coef, dy, count,
                                  count_unit, stream);
+}
+
+int sg2im_debug_mark_gemm_end(hipEvent_t event, int* recorded) {
+  sg2im::t_gemm_end_event = event;
+  sg2im::t_gemm_end_flag = event ? recorded : nullptr;
+  return SG2IM_OK;
 }
 
 int sg2im_bn_backward_apply(const float* g, long long ld_g, int pool2, int batch, int h, int w, const float* y,

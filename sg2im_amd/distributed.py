@@ -4,11 +4,12 @@
 The reference has no distributed code at all.  The exchange here is deliberately minimal:
 each network keeps all parameter gradients in ONE flat fp32 arena (sg2im_amd.optim), so a
 step needs exactly one SUM all-reduce per network (generator 112.6 MB, D_obj 4.4 MB, D_img
-2.6 MB) plus a 1-element reduce of the NaN guard.  The generator's all-reduce is launched
-asynchronously right after its backward pass and only waited for after BOTH discriminator
-passes: those never read the generator's parameters (they consume ``imgs_pred.detach()``),
-so discriminator compute hides the 112 MB exchange - in graph mode: the D_obj step's graph is
-replayed while the generator / D_img exchanges are in flight (sg2im_amd/trainer.py::_capture).
+2.6 MB) plus a 1-element reduce of the NaN guard.  Default (Trainer dp_schedule 2): the collectives are
+RECORDED INSIDE the captured iteration on a comm stream, each as soon as its gradients are complete - the
+discriminators' right after their steps, the generator's in two buckets (the first two refinement modules'
+weight gradients, ~2/3 of the bytes, travel under the remaining weight gradients; the rest after the backward
+pass) - and the Adam updates wait for the comm stream (sg2im_amd/trainer.py::_capture_overlapped).  Eager mode
+and schedules 0 / 1 start the all-reduces asynchronously between (segments of) the step and wait before Adam.
 The 1/world_size factor is folded into the fused Adam kernel (``grad_scale``), not a separate
 pass over the arena.  Replicas are brought in line by a broadcast of parameters, optimiser
 moments and BatchNorm buffers at construction, after a checkpoint restore and after rank 0's

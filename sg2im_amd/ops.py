@@ -307,14 +307,28 @@ TIMER = None     # set to a KernelTimer to time every conv / linear launch
 TIMER_TAG = None # set by a network around its launches (e.g. 'crn') to attribute them
 
 
-def _timed(kind, flops, fn):
+def _timed(kind, flops, fn, bn_finish=False):
+  """bn_finish: fn is a *_bn entry point - its BatchNorm finish launch (not a GEMM) is timed as 'hbm_bn_finish'"""
   if TIMER is None:
     return fn()
   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  em, hit = None, c_int(0)
+  if bn_finish:
+    em = torch.cuda.Event(enable_timing=True)
+    em.record()                     # (creates the underlying hipEvent_t; the library records it again)
+    _lib.load().sg2im_debug_mark_gemm_end(c_void_p(em.cuda_event), byref(hit))
   e0.record()
-  fn()
+  try:
+    fn()
+  finally:
+    if bn_finish:
+      _lib.load().sg2im_debug_mark_gemm_end(None, None)
   e1.record()
-  TIMER.records.append((kind, flops, e0, e1, TIMER_TAG))
+  if hit.value:
+    TIMER.records.append((kind, flops, e0, em, TIMER_TAG))
+    TIMER.records.append(('hbm_bn_finish', 0.0, em, e1, TIMER_TAG))
+  else:
+    TIMER.records.append((kind, flops, e0, e1, TIMER_TAG))
 
 
 def _desc_k(desc):
@@ -653,7 +667,7 @@ def conv2d_forward_bn(desc, weight, cout, bias, out, ld_out, bn, training, eps=1
   _note_bytes('igemm_fwd', _desc_src_floats(desc) + cout * _desc_k(desc) + M * cout)
   _timed('igemm_fwd', flops, lambda: call(
     'sg2im_conv2d_forward_bn', byref(desc), _f(weight), int(cout), _f(bias), float(out_slope), _f(out), int(ld_out),
-    _f(ws), ws.numel() * 4, byref(a), _stream()))
+    _f(ws), ws.numel() * 4, byref(a), _stream()), bn_finish=True)
   return st
 
 
@@ -681,7 +695,7 @@ def conv2d_backward_data_bn(desc, weight, cout, dy, ld_dy, c_begin, c_count, dx,
               rows_dx * c_count)
   _timed('igemm_dgrad', flops, lambda: call(
     'sg2im_conv2d_backward_data_bn', byref(desc), _f(weight), int(cout), _f(dy), int(ld_dy), int(c_begin), int(c_count),
-    _f(dx), int(ld_dx), _f(ws), ws.numel() * 4, byref(a), _stream()))
+    _f(dx), int(ld_dx), _f(ws), ws.numel() * 4, byref(a), _stream()), bn_finish=True)
   return coef
 
 

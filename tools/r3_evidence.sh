@@ -10,6 +10,7 @@ cd $R
 timeout 900 python bench.py > $O/bench_n1.out 2> $O/bench_n1.err; grep '^{"metric' $O/bench_n1.out > $O/bench_n1.json; head -c 600 $O/bench_n1.json; echo
 timeout 300 python tools/bench_conv.py 2>&1 | grep -v amdgpu.ids > $O/conv_layers.log; tail -2 $O/conv_layers.log
 tools/trace_step.sh gpurun_out/ev/step
+SG2IM_MARKS=1 python bench.py --steps 60 --warmup 20 --cpu_baseline_steps 0 --no_roofline 2>&1 >/dev/null | grep '\[mark\]' > $O/schedule_marks.txt; cat $O/schedule_marks.txt
 bash tools/pmc_step.sh > $O/pmc_step.log 2>&1; tail -2 $O/pmc_step.log; cp $R/gpurun_out/pmc_step.json $O/pmc_step_traffic.json 2>/dev/null
 bash tools/pmc_traffic.sh m4.conv0 > $O/pmc_traffic_m4conv0.txt 2>&1; tail -8 $O/pmc_traffic_m4conv0.txt
 bash tools/pmc_one.sh m4.conv0 > $O/pmc_m4conv0.txt 2>&1; head -40 $O/pmc_m4conv0.txt
