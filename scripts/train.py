@@ -3,12 +3,15 @@
 driving sg2im_amd.trainer.Trainer on MI355X; one process per GPU under
 ``python -m torch.distributed.run --nproc-per-node N scripts/train.py ...``.
 
-Datasets are outside the hot-path scope (COCO/VG loaders need
-torchvision/h5py/pycocotools and the data); batches come from the seeded synthetic generator
-that reproduces the collate layout (``--dataset coco|vg`` selects the graph style).  Every
-reference flag is accepted; flags whose feature is not on the HIP path yet fail loudly.
+Data: when the dataset files the flags name exist, the reference's loaders are used (sg2im_amd/data: COCO /
+COCO-Stuff annotations + images; Visual Genome arrays as the reference's .h5 when h5py is importable, or an .npz
+with the same keys) - ``build_loaders`` below, reference train.py:230-306.  When they do not exist (this build
+container: no datasets), batches come from the seeded synthetic generator that reproduces the collate layout
+(``--dataset coco|vg`` selects the graph style), and the script says so loudly.  Every reference flag is
+accepted; flags whose feature is not on the HIP path yet fail loudly.
 """
 import argparse
+import json
 import os
 import sys
 import time
@@ -116,14 +119,80 @@ _DATASET_FLAGS = ('vg_image_dir', 'train_h5', 'val_h5', 'vocab_json', 'coco_trai
                   'coco_val_stuff_json', 'num_train_samples', 'instance_whitelist', 'stuff_whitelist')
 
 
-def warn_synthetic_data(args):
-  """The COCO / VG loaders are outside this build (no torchvision / h5py / pycocotools / data here):
-  batches are seeded synthetic scene graphs.  Say so loudly - above all when the caller pointed the
-  dataset flags somewhere, which would otherwise be ignored silently."""
+def dataset_files(args):
+  """the files / directories the selected dataset needs, and which of them are missing"""
+  if args.dataset == 'coco':
+    need = [args.coco_train_image_dir, args.coco_train_instances_json, args.coco_val_image_dir, args.coco_val_instances_json]
+    need += [p for p in (args.coco_train_stuff_json, args.coco_val_stuff_json) if p]
+  else:
+    need = [args.vg_image_dir, args.train_h5, args.val_h5, args.vocab_json]
+  return need, [p for p in need if not os.path.exists(p)]
+
+
+def build_coco_dsets(args):
+  """reference train.py:230-262"""
+  from sg2im_amd.data import CocoSceneGraphDataset
+  kw = dict(image_dir=args.coco_train_image_dir, instances_json=args.coco_train_instances_json,
+            stuff_json=args.coco_train_stuff_json, stuff_only=args.coco_stuff_only, image_size=args.image_size,
+            mask_size=args.mask_size, max_samples=args.num_train_samples, min_object_size=args.min_object_size,
+            min_objects_per_image=args.min_objects_per_image, instance_whitelist=args.instance_whitelist,
+            stuff_whitelist=args.stuff_whitelist, include_other=args.coco_include_other,
+            include_relationships=args.include_relationships)
+  train = CocoSceneGraphDataset(**kw)
+  print('Training dataset has %d images and %d objects' % (len(train), train.total_objects()))
+  print('(%.2f objects per image)' % (float(train.total_objects()) / max(len(train), 1)))
+  kw.update(image_dir=args.coco_val_image_dir, instances_json=args.coco_val_instances_json,
+            stuff_json=args.coco_val_stuff_json, max_samples=args.num_val_samples)
+  val = CocoSceneGraphDataset(**kw)
+  assert train.vocab == val.vocab
+  return json.loads(json.dumps(train.vocab)), train, val
+
+
+def build_vg_dsets(args):
+  """reference train.py:265-285"""
+  from sg2im_amd.data import VgSceneGraphDataset
+  with open(args.vocab_json, 'r') as f:
+    vocab = json.load(f)
+  kw = dict(vocab=vocab, h5_path=args.train_h5, image_dir=args.vg_image_dir, image_size=args.image_size,
+            max_samples=args.num_train_samples, max_objects=args.max_objects_per_image,
+            use_orphaned_objects=args.vg_use_orphaned_objects, include_relationships=args.include_relationships)
+  train = VgSceneGraphDataset(**kw)
+  print('There are %d iterations per epoch' % (len(train) // args.batch_size))
+  kw.update(h5_path=args.val_h5)
+  del kw['max_samples']
+  return vocab, train, VgSceneGraphDataset(**kw)
+
+
+def build_loaders(args, rank=0):
+  """reference train.py:288-306 -> (vocab, train_loader, val_loader).  Data parallel: every rank draws its own
+  shuffle of the whole training set (generator seeded with seed + rank)."""
+  from torch.utils.data import DataLoader
+  from sg2im_amd.data import coco_collate_fn, vg_collate_fn
+  if args.dataset == 'vg':
+    (vocab, train, val), collate = build_vg_dsets(args), vg_collate_fn
+  else:
+    (vocab, train, val), collate = build_coco_dsets(args), coco_collate_fn
+  kw = dict(batch_size=args.batch_size, num_workers=args.loader_num_workers, collate_fn=collate)
+  gen = torch.Generator().manual_seed(args.seed + rank)
+  return vocab, DataLoader(train, shuffle=True, generator=gen, **kw), DataLoader(val, shuffle=args.shuffle_val, **kw)
+
+
+def as_step_batch(batch, device):
+  """a collated batch -> the 7-tuple (imgs, objs, boxes, masks | None, triples, obj_to_img, triple_to_img) on the
+  device (reference train.py:514-519: the VG collate has no masks)"""
+  if len(batch) == 6:
+    imgs, objs, boxes, triples, obj_to_img, triple_to_img = batch
+    batch = (imgs, objs, boxes, None, triples, obj_to_img, triple_to_img)
+  return tuple(x.to(device, non_blocking=True) if torch.is_tensor(x) else x for x in batch)
+
+
+def warn_synthetic_data(args, missing=()):
+  """No dataset files here: batches are seeded synthetic scene graphs.  Say so loudly - above all when the caller
+  pointed the dataset flags somewhere, which would otherwise be ignored silently."""
   given = [f for f in _DATASET_FLAGS if getattr(args, f) != parser.get_default(f)]
   print('=' * 100)
   print('WARNING: training on SYNTHETIC scene graphs (--dataset %s shape) with a fabricated vocabulary;' % args.dataset)
-  print('         the reference data loaders (sg2im/data/coco.py, vg.py) are not part of this build.')
+  print('         dataset files not found: ' + ', '.join(missing))
   if given:
     print('         IGNORED dataset flags: ' + ', '.join('--' + f for f in given))
   print('=' * 100)
@@ -200,11 +269,17 @@ def main(args):
   device = torch.device('cuda', local_rank)
   if world > 1:
     dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+  need, missing = dataset_files(args)
+  real_data = not missing
   if rank == 0:
     print(args)
-    warn_synthetic_data(args)
+    if not real_data:
+      warn_synthetic_data(args, missing)
   num_objs, num_preds = (184, 7) if args.dataset == 'coco' else (179, 46)
-  vocab = make_vocab(num_objs, num_preds)
+  if real_data:
+    vocab, train_dl, val_dl = build_loaders(args, rank)
+  else:
+    vocab, train_dl, val_dl = make_vocab(num_objs, num_preds), None, None
   gk = dict(image_size=args.image_size, embedding_dim=args.embedding_dim, gconv_dim=args.gconv_dim,
             gconv_hidden_dim=args.gconv_hidden_dim, gconv_num_layers=args.gconv_num_layers,
             mlp_normalization=args.mlp_normalization, refinement_dims=args.refinement_network_dims,
@@ -227,8 +302,18 @@ def main(args):
     trainer.model.load_state_dict(sd)
     trainer.broadcast_state()
 
-  def batches(split, start):
-    """endless seeded synthetic stand-in for the train / val DataLoader"""
+  epoch_box = [0]
+
+  def batches(split, start, training=False):
+    """the train / val DataLoader, cycled over epochs (reference train.py:506-514; ``training``: the iterator that
+    feeds the optimisation loop counts the epochs) - or its endless seeded synthetic stand-in"""
+    while real_data:
+      if training:
+        epoch_box[0] += 1
+        if rank == 0:
+          print('Starting epoch %d' % epoch_box[0])
+      for cpu_batch in (train_dl if split == 'train' else val_dl):
+        yield as_step_batch(cpu_batch, device)
     i = start
     while True:
       i += 1
@@ -256,10 +341,10 @@ def main(args):
       trainer.model.eval()
     else:
       trainer.model.train()
-    epoch = checkpoint['counters']['epoch']
+    epoch_box[0] = checkpoint['counters']['epoch'] or 0
     trainer.broadcast_state()
   else:
-    t, epoch = 0, 0
+    t = 0
     checkpoint = {'args': args.__dict__, 'vocab': vocab, 'model_kwargs': trainer.model_kwargs,
                   'd_obj_kwargs': trainer.d_obj_kwargs, 'd_img_kwargs': trainer.d_img_kwargs, 'losses_ts': [],
                   'losses': defaultdict(list), 'd_losses': defaultdict(list), 'checkpoint_ts': [],
@@ -270,7 +355,7 @@ def main(args):
                   'd_obj_state': None, 'd_obj_best_state': None, 'd_obj_optim_state': None,
                   'd_img_state': None, 'd_img_best_state': None, 'd_img_optim_state': None, 'best_t': []}
   t0 = time.time()
-  train_loader = batches('train', t)
+  train_loader = batches('train', t, training=True)
   while t < args.num_iterations:
     if t == args.eval_mode_after:                                   # reference train.py:509-512
       if rank == 0:
@@ -315,7 +400,7 @@ def main(args):
                         d_img_state=sd_of(trainer.d_img), optim_state=trainer.opt_g.state_dict(),
                         d_obj_optim_state=sd_of(trainer.opt_do), d_img_optim_state=sd_of(trainer.opt_di))
       checkpoint['counters']['t'] = t
-      checkpoint['counters']['epoch'] = epoch
+      checkpoint['counters']['epoch'] = epoch_box[0]
       path = os.path.join(args.output_dir, '%s_with_model.pt' % args.checkpoint_name)
       print('Saving checkpoint to ', path)
       torch.save(checkpoint, path)
