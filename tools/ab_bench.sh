@@ -4,7 +4,7 @@ out=$1; shift
 mkdir -p $out
 for rep in 1 2; do
   for kv in "$@"; do
-    tag=$(echo "$kv" | tr '= ' '__')
+    tag=$(echo "$kv" | tr '= /' '___')
     env $kv python bench.py --steps ${STEPS:-100} --warmup 20 --cpu_baseline_steps 0 --no_roofline > $out/bench_${tag}_$rep.json 2> $out/bench_${tag}_$rep.err
     python - <<PY
 import json
