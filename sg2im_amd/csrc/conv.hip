@@ -1210,6 +1210,7 @@ __global__ void splitk_finish_parity_kernel(const float* __restrict__ ws, int ns
 
 }  // namespace sg2im
 #include "conv_halo.h"
+#include "wgrad_halo.h"
 namespace sg2im {
 
 // ---------------------------------------------------------------------------
@@ -1384,7 +1385,9 @@ static hipError_t finish_split(const Epi& e, long long M, int N, hipStream_t st,
   if (e.nsplit <= 1) return hipSuccess;
   const long long MN = M * N;
   int SL = 1;
-  while (SL < 16 && 2 * SL <= e.nsplit / 4 && (MN * SL + 255) / 256 < 2 * g_num_cu) SL *= 2;
+  // (up to 8 workgroups per CU: the loop over the splits is a chain of load latencies, not bandwidth - 256 splits of a
+  // 64 x 576 weight gradient took 19 us with 2 split lanes)
+  while (SL < 16 && 2 * SL <= e.nsplit / 4 && (MN * SL + 255) / 256 < 8 * g_num_cu) SL *= 2;
   const bool v4 = SL == 1 && N % 4 == 0 && e.ldc % 4 == 0 && !((uintptr_t)e.ws & 15) && !((uintptr_t)e.C & 15) &&
                   (!e.bias || !((uintptr_t)e.bias & 15)) && e.col_wtap == 0;
   if (v4) {
@@ -1460,6 +1463,16 @@ static hipError_t launch_dgrad(DgradParams& p, hipStream_t st) {
   dim3 grid((p.Nc + BN - 1) / BN, (p.M + BM - 1) / BM, p.parity ? 4 * p.e.nsplit : p.e.nsplit);
   SG2IM_LAUNCH((conv_dgrad_kernel<BM, BN, VA, VB>), grid, dim3(NTHREADS), lds, st, p);
   return hipGetLastError();
+}
+
+// (two LDS images of the halo'd weight-gradient kernel: 84-88 KB, above the 64 KB a launch may ask for unprepared)
+static bool g_wgrad_halo_ready = false;
+static hipError_t prepare_wgrad_halo() {
+  if (g_wgrad_halo_ready) return hipSuccess;
+  hipError_t e = ensure_lds(conv_wgrad_halo_kernel<4, 16>, wgrad_halo_lds<4, 16>());
+  if (e == hipSuccess) e = ensure_lds(conv_wgrad_halo_kernel<8, 8>, wgrad_halo_lds<8, 8>());
+  if (e == hipSuccess) g_wgrad_halo_ready = true;
+  return e;
 }
 
 template <int BM, int BN> bool g_wgrad_fr_ready = false;
@@ -1558,6 +1571,9 @@ static bool al16p(const void* q) { return ((uintptr_t)q & 15) == 0; }
 // ---- halo'd-tile kernels (conv_halo.h): 3x3 / stride 1 / pad 1, float4 loaders, fp32 ----
 // A/B knob: 0 = every convolution on the first-generation per-tap kernels
 static const bool g_halo = !(getenv("SG2IM_HALO") && atoi(getenv("SG2IM_HALO")) == 0);
+// A/B knob: 0 = weight gradients of the 3x3 convolutions on the per-tap kernel, 1 (default) = the halo'd-tile kernel
+// where it measured faster, 2 = wherever its geometry allows (the parity tests run every eligible shape through it)
+static const int g_wgrad_halo = getenv("SG2IM_WGRAD_HALO") ? atoi(getenv("SG2IM_WGRAD_HALO")) : 1;
 struct HaloPlan { int rt, ct, bn, nsplit, patches; };
 
 static bool halo_geometry(const sg2im_conv_desc* d) {
@@ -1645,6 +1661,7 @@ int sg2im_init(void) {
 #undef SG2IM_PREP_TILES
 #undef SG2IM_PREP
   if (e == hipSuccess) e = ensure_lds(conv_wgrad_group_kernel, wgrad_lds<64, 64>());
+  if (e == hipSuccess) e = prepare_wgrad_halo();
   if (e != hipSuccess) return SG2IM_ERR_HIP;
   SG2IM_LAUNCH(init_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)0, (int*)nullptr);
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize((hipStream_t)0) != hipSuccess) return SG2IM_ERR_HIP;
@@ -1963,10 +1980,52 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
   // (room for the bias-gradient partials of up to 512 splits is kept behind the dW partials)
   const size_t bias_room = dbias ? sizeof(float) * 512 * (size_t)cout : 0;
   const bool can_split = workspace != nullptr && workspace_bytes > bias_room;
-  // [Round 3, measured and dropped (profiles/r3_wgrad3_ab.log): a row-halo'd form for the <= 64-channel layers -
-  // 192-column tiles = one kernel row x three taps x 64 channels formed from ONE staged input row - moved the
-  // 64-channel layers 76 -> 79 TFLOP/s and m4.conv0 98.6 -> 89.6: fatter column tiles need more K splits to fill
-  // the chip, and the split-K partial volume (splits x the whole dW) grows with them.]
+  // 3x3 / stride 1 / pad 1 over maps that 64-pixel patches tile: the halo'd-tile kernel (wgrad_halo.h)
+  if (g_wgrad_halo && v4 && d->compute_dtype == 0 && !any_gather(p.g) && halo_geometry(d) &&
+      ((d->in_w % 16 == 0 && d->in_h % 4 == 0) || (d->in_w % 8 == 0 && d->in_h % 8 == 0))) {
+    const bool wide = d->in_w % 16 == 0;
+    WgHaloParams q;
+    q.g = p.g; q.dY = dy; q.ldy = ld_dy; q.Cout = cout;
+    q.tiles_x = d->in_w / (wide ? 16 : 8); q.tiles_y = d->in_h / (wide ? 4 : 8);
+    q.npatch = d->batch * q.tiles_x * q.tiles_y;
+    const int ncb = (Ctot + 63) / 64, nkb = (cout + 63) / 64;
+    // K split over whole patches.  One workgroup per CU is resident (324 registers per lane), so the launch runs in
+    // ceil(blocks / #CU) rounds of `per` patches each (+ ~1 patch worth of prologue / epilogue, + the finish launch
+    // growing with the split count): take the split count that minimises that
+    const long long tiles = (long long)ncb * nkb;
+    long long cap = can_split ? std::max<long long>(1, (long long)((workspace_bytes - bias_room) / sizeof(float)) / ((long long)cout * Ntot)) : 1;
+    cap = std::min<long long>(std::min<long long>(cap, 512), q.npatch);
+    long long ns = 1;
+    double best = -1.0;
+    for (long long t = 1; t <= cap; ++t) {
+      const long long per = (q.npatch + t - 1) / t;
+      if ((q.npatch + per - 1) / per != t) continue;            // every split non-empty
+      const long long rounds = (tiles * t + g_num_cu - 1) / g_num_cu;
+      const double cost = (double)rounds * ((double)per + 1.0) + 0.02 * (double)t;
+      if (best < 0 || cost < best) { best = cost; ns = t; }
+    }
+    q.per = (int)((q.npatch + ns - 1) / ns);
+    // [measured, profiles/r3_wgrad_halo.log] it wins where a workgroup gets enough patches to amortise its prologue and
+    // its 147 KB of partial sums, and loses on the widest concats (dY is re-read once per 64-channel block):
+    // m4.conv0 97 -> 106, the 64-channel 64x64 layers 76 -> 89, m2.conv1 84 -> 94, m1.conv1 80 -> 92 TFLOP/s;
+    // m2.conv0 (672 channels) 97 -> 93, m1.conv0 (1184) 87 -> 86, mask_net's 8x8 layer (4 patches each) 67 -> 61
+    const bool halo_pays = Ctot <= 512 && q.per >= 6;
+    const int nsplit = (q.npatch + q.per - 1) / q.per;
+    q.e = Epi{dweight, (long long)taps * p.g.Wtap, nullptr, 1.f, accumulate, workspace, nsplit};
+    if (p.g.Wtap != Ctot) { q.e.col_ctot = Ctot; q.e.col_wtap = p.g.Wtap; }
+    q.dbias = dbias;
+    q.ws_bias = nsplit > 1 ? workspace + (size_t)nsplit * cout * Ntot : nullptr;
+    if (halo_pays || g_wgrad_halo >= 2) {
+      if (g_plan_debug) fprintf(stderr, "[sg2im wgrad halo] Cout=%d Ctot=%d patches=%d -> %s blocks %dx%d x%d\n", cout, Ctot, q.npatch,
+                                wide ? "4x16" : "8x8", ncb, nkb, nsplit);
+      dim3 grid(ncb, nkb, nsplit);
+      if (prepare_wgrad_halo() != hipSuccess) return SG2IM_ERR_HIP;
+      if (wide) SG2IM_LAUNCH((conv_wgrad_halo_kernel<4, 16>), grid, dim3(NTHREADS), (wgrad_halo_lds<4, 16>()), stream, q);
+      else SG2IM_LAUNCH((conv_wgrad_halo_kernel<8, 8>), grid, dim3(NTHREADS), (wgrad_halo_lds<8, 8>()), stream, q);
+      if (hipGetLastError() != hipSuccess) return SG2IM_ERR_HIP;
+      return finish_split(q.e, cout, Ntot, stream, q.ws_bias, dbias, cout) == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+    }
+  }
   const Plan pl = make_plan(PASS_WGRAD, cout, Ntot, p.iters, (long long)cout * Ntot, can_split ? workspace_bytes - bias_room : 0,
                             can_split, 2, !v4, [&](int bn) { return (long long)(Ntot + bn - 1) / bn; });
   p.ntile_c = 0;

@@ -56,6 +56,22 @@ def test_conv_forward_dgrad_wgrad_all_geometries():
   _run('sec_conv')
 
 
+def test_weight_gradient_halo_kernel_on_every_eligible_shape():
+  """csrc/wgrad_halo.h forced onto every 3x3 / stride-1 shape whose map 64-pixel patches tile (SG2IM_WGRAD_HALO=2;
+  by default it only takes the shapes where it measured faster): two sources incl. the upsampled one, pending
+  BatchNorm affine, ragged channel blocks, weight rows wider than the sources, 4x16 and 8x8 patches, accumulate,
+  the fused bias gradient - all of sec_conv against torch"""
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, SG2IM_WGRAD_HALO='2', SG2IM_PLAN_DEBUG='1')
+  out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'gpu_check.py'), 'sec_conv'],
+                       capture_output=True, text=True, timeout=600, env=env)
+  assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+  used = [l for l in out.stderr.splitlines() if l.startswith('[sg2im wgrad halo]')]
+  assert len(used) >= 20 and any('8x8' in l for l in used) and any('4x16' in l for l in used), len(used)
+
+
 def test_graph_triple_conv_layer():
   _run('sec_gconv')
 

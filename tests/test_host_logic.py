@@ -196,14 +196,16 @@ def test_launch_planner_choices_are_valid_without_a_gpu():
   chosen tile / split-K per layer.  Every plan must use one of the four tiles, a split count within the
   reduction length, and the big CRN layers must not fall back to the 64x64 tile; the 3x3 stride-1 layers on maps
   of 16x16 and larger take the halo'd-tile kernels (csrc/conv_halo.h) forward and in the data gradient: a 128-pixel
-  patch, 64- or 128-wide column tiles, split-K over whole 32-channel chunks."""
+  patch, 64- or 128-wide column tiles, split-K over whole 32-channel chunks; their weight gradients take the halo'd
+  weight-gradient kernel (csrc/wgrad_halo.h: 64-pixel patches, 64 x 64-channel blocks, K split over whole patches)
+  except on the widest concats."""
   import re
   import subprocess
   import sys
   tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools')
   out = subprocess.run([sys.executable, os.path.join(tools, 'plan_dump.py')], cwd=tools, capture_output=True,
                        text=True, timeout=300).stderr
-  plans, halo = {}, {}
+  plans, halo, whalo = {}, {}, {}
   cur = None
   for line in out.splitlines():
     m = re.match(r'== (\S+) (\S+)', line)
@@ -215,7 +217,10 @@ def test_launch_planner_choices_are_valid_without_a_gpu():
     m = re.match(r'\[sg2im halo\] M=(\d+) N=(\d+) chunks=(\d+) -> patch (\d+)x(\d+) bn=(\d+) x(\d+)', line)
     if m and cur:
       halo[cur] = tuple(int(v) for v in m.groups())
-  assert len(plans) + len(halo) >= 60, (len(plans), len(halo))
+    m = re.match(r'\[sg2im wgrad halo\] Cout=(\d+) Ctot=(\d+) patches=(\d+) -> (\S+) blocks (\d+)x(\d+) x(\d+)', line)
+    if m and cur:
+      whalo[cur] = m.groups()
+  assert len(plans) + len(halo) + len(whalo) >= 60, (len(plans), len(halo), len(whalo))
   for (layer, what), (M, N, iters, bm, bn, ns) in plans.items():
     assert (bm, bn) in ((128, 128), (128, 64), (64, 64), (64, 128)), (layer, what, bm, bn)
     assert 1 <= ns <= max(1, iters), (layer, what, ns, iters)
@@ -224,9 +229,14 @@ def test_launch_planner_choices_are_valid_without_a_gpu():
     assert what in ('fwd', 'dgrad')
   for layer in ('m2.conv0', 'm3.conv0', 'm4.conv0', 'm4.conv1', 'out.conv0', 'mask.c3'):
     assert (layer, 'fwd') in halo and (layer, 'dgrad') in halo, layer
+  for (layer, what), (cout, ctot, patches, patch, ncb, nkb, ns) in whalo.items():
+    assert what == 'wgrad' and patch in ('4x16', '8x8') and int(ctot) <= 512, (layer, what, patch, ctot)
+    assert int(ncb) == (int(ctot) + 63) // 64 and int(nkb) == (int(cout) + 63) // 64 and 1 <= int(ns) <= int(patches) // 6
+  for layer in ('m1.conv1', 'm2.conv1', 'm3.conv0', 'm3.conv1', 'm4.conv0', 'm4.conv1', 'out.conv0', 'mask.c3'):
+    assert (layer, 'wgrad') in whalo, layer
   for layer in ('m1.conv0', 'm2.conv0', 'm3.conv0', 'm4.conv0'):
     for what in ('fwd', 'dgrad', 'wgrad'):
-      if (layer, what) not in halo:
+      if (layer, what) not in halo and (layer, what) not in whalo:
         bm, bn = plans[(layer, what)][3:5]
         assert bm * bn > 64 * 64, (layer, what, bm, bn)
 

@@ -12,6 +12,8 @@ from sg2im_amd import ops
 D = torch.device('cuda', 0)
 NB = 32
 PLAIN = '--plain' in sys.argv
+WGRAD_ONLY = '--wgrad' in sys.argv          # time the weight gradients only
+ONLY = [a[7:].split(',') for a in sys.argv if a.startswith('--only=')]      # --only=m3,m4,out: layer name prefixes
 LAYERS = [  # name, H, C0, C1(up), Cout, k, stride, pad
   ('m0.conv0', 4, 160, 1, 1024, 3, 1, 1), ('m0.conv1', 4, 1024, 0, 1024, 3, 1, 1),
   ('m1.conv0', 8, 160, 1024, 512, 3, 1, 1), ('m1.conv1', 8, 512, 0, 512, 3, 1, 1),
@@ -48,6 +50,8 @@ def main():
   print('%-10s %9s | %8s %7s | %8s %7s | %8s %7s' % ('layer', 'GFLOP', 'fwd ms', 'TF/s', 'dgrad ms', 'TF/s', 'wgrad ms', 'TF/s'))
   for L in LAYERS:
     name, H, C0, C1, Cout, k, s, p = L[:8]
+    if ONLY and not any(name.startswith(pre) for pre in ONLY[0]):
+      continue
     N = L[8] if len(L) > 8 else NB
     srcs = []
     # as in the network: the previous layer's BatchNorm + LeakyReLU is PENDING on the feature source (applied by the
@@ -70,8 +74,10 @@ def main():
     dx = torch.empty(N, H, H, Cx, device=D)
     dw = torch.empty_like(W)
     gf = 2.0 * N * d.out_h * d.out_w * Cout * Ct * k * k / 1e9
-    t1 = timeit(lambda: ops.conv2d_forward(d, W, Cout, b, y, Cout))
-    if C1 > 1:       # as the network issues it: the layout channels (128 of 160 need gradients) and the feature channels
+    t1 = 1e-9 if WGRAD_ONLY else timeit(lambda: ops.conv2d_forward(d, W, Cout, b, y, Cout))
+    if WGRAD_ONLY:
+      t2 = 1e-9
+    elif C1 > 1:       # as the network issues it: the layout channels (128 of 160 need gradients) and the feature channels
       dl, dz = torch.empty(N, H, H, 128, device=D), torch.empty(N, H, H, C1, device=D)
       t2 = timeit(lambda: (ops.conv2d_backward_data(d, W, Cout, gy, Cout, 0, 128, dl, 128),
                            ops.conv2d_backward_data(d, W, Cout, gy, Cout, C0, C1, dz, C1)))
