@@ -938,8 +938,11 @@ __global__ void splitk_finish_kernel(const float* __restrict__ ws, int nsplit, l
   for (long long base = (long long)blockIdx.x * per; base < MN; base += (long long)gridDim.x * per) {
     const long long idx = base + ol;
     float v = 0.f;
-    if (idx < MN)
+    if (idx < MN) {
+      // (eight loads in flight per thread: the loop is a chain of load latencies; the additions keep their order)
+      #pragma unroll 8
       for (int s = sl; s < nsplit; s += SL) v += ws[(long long)s * MN + idx];
+    }
     if (SL > 1) {
       __syncthreads();
       part[threadIdx.x] = v;
