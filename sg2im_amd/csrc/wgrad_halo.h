@@ -6,7 +6,8 @@
 // The first-generation kernel (conv_wgrad_kernel) tiles the FLAT (tap, channel) axis: a 64 x 64 or 64 x 128 tile
 // re-loads and re-activates the (shifted) input pixels once per tap and gets 16-32 MFMAs out of every staged
 // 32-pixel chunk - too few to cover the latency of the next chunk's loads on the 64-channel layers (76 TFLOP/s),
-// and m4.conv0 fetched 1.09 GB per launch for 0.18 GB of operands (profiles/r3_pmc_hbm_traffic_m4conv0.txt).
+// and m4.conv0 fetched 1.1 GB per launch for 0.18 GB of operands (profiles/r2_pmc_hbm_traffic_m4conv0.txt; this kernel:
+// 0.30 GB, profiles/r3_pmc_hbm_traffic_m4conv0.txt).
 // Here a workgroup owns 64 output channels x 64 input channels x ALL NINE TAPS and walks a range of RT x CT = 64
 // pixel patches: per patch it stages the 64 x 64 dY tile and the (RT + 2) x (CT + 2) halo of the input ONCE
 // (loaded once, activated once) and issues 9 x 32 MFMAs per wave from them - a tap is an immediate offset of the
