@@ -278,6 +278,8 @@ def main(args):
   num_objs, num_preds = (184, 7) if args.dataset == 'coco' else (179, 46)
   if real_data:
     vocab, train_dl, val_dl = build_loaders(args, rank)
+    if len(train_dl) == 0 or len(val_dl) == 0:
+      raise ValueError('the %s dataset is empty after filtering (train: %d batches, val: %d)' % (args.dataset, len(train_dl), len(val_dl)))
   else:
     vocab, train_dl, val_dl = make_vocab(num_objs, num_preds), None, None
   gk = dict(image_size=args.image_size, embedding_dim=args.embedding_dim, gconv_dim=args.gconv_dim,

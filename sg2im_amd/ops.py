@@ -106,6 +106,8 @@ def mark(name):
   if not MARKS or _marks['buf'] is None:
     return
   idx = _marks['names'].setdefault(name, len(_marks['names']))
+  if idx >= _marks['buf'].numel():
+    raise RuntimeError('too many distinct schedule marks (%d slots)' % _marks['buf'].numel())
   call('sg2im_timestamp', _marks['buf'].data_ptr() + 8 * idx, _stream())
 
 
