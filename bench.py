@@ -62,7 +62,41 @@ def parse():
                        '--eval_mode_after iterations (train.py:509-512); not the headline workload')
   ap.add_argument('--force_dist', action='store_true',
                   help='debug: 1-rank RCCL group with real all-reduces (exercises the N>1 code path on one GPU)')
+  ap.add_argument('--launcher_selftest', action='store_true',
+                  help='CPU-only check of the --gpus N self-launcher: every rank joins a gloo group, all-reduces its rank, '
+                       'rank 0 prints one JSON line (tests/test_bench_launcher.py)')
   return ap.parse_args()
+
+
+def _free_port():
+  import socket
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  return port
+
+
+def self_launch(n):
+  """`python bench.py --gpus N` without a launcher around it (WORLD_SIZE unset): re-execute this command line under
+  torch.distributed.run with one rank per GPU on 127.0.0.1 - what the driver's own command does - and hand its
+  output and exit status through."""
+  import subprocess
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # (dmabuf IPC: RCCL across processes needs it on this stack)
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+         '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+  return subprocess.call(cmd, env=env)
+
+
+def launcher_selftest(world, rank):
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  t = torch.tensor([float(rank + 1)])
+  dist.all_reduce(t)
+  dist.barrier()
+  dist.destroy_process_group()
+  if rank == 0:
+    print(json.dumps({'launcher_selftest': True, 'world': world, 'sum_of_ranks_plus_one': float(t.item())}), flush=True)
 
 
 def host_cpu():
@@ -127,9 +161,13 @@ def main():
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+    raise SystemExit(self_launch(args.gpus))                 # one rank per GPU, launched from here
   if world != args.gpus:
-    if world == 1 and args.gpus > 1:
-      raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+    raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d (or without a '
+                     'launcher: bench.py starts its own ranks)' % (args.gpus, world, args.gpus))
+  if args.launcher_selftest:
+    return launcher_selftest(world, rank)
   if not torch.cuda.is_available():
     raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
   torch.cuda.set_device(local_rank)
@@ -184,6 +222,31 @@ def main():
   for i in range(args.warmup):
     trainer.step(batches[i % nb])
   sync()
+
+  def replicas_in_sync():
+    """every rank applied the same (all-reduced) gradients <=> the parameter arenas are still bit-identical"""
+    if world == 1:
+      return True
+    c = torch.stack([f.flat.double().sum() for f in (trainer.flat_g, trainer.flat_do, trainer.flat_di) if f is not None])
+    hi, lo = c.clone(), c.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    return bool(torch.equal(hi, lo))
+  in_sync = replicas_in_sync()
+  if not in_sync and trainer.use_graphs and trainer.dp_schedule == 2:
+    # the in-graph exchange (never executed on more than one rank when this was written) did not keep the replicas
+    # together on this stack: fall back to the exposed exchange between an iteration graph and an Adam graph
+    if rank == 0:
+      print('WARNING: replicas diverged under dp_schedule 2; falling back to dp_schedule 0', file=sys.stderr, flush=True)
+    trainer.dp_schedule = 0
+    trainer._graphs.clear()
+    trainer.broadcast_state()
+    for b in batches:
+      trainer.step(b)
+    for i in range(args.warmup):
+      trainer.step(batches[i % nb])
+    sync()
+    in_sync = replicas_in_sync()
   stats0 = dict(trainer.graph_stats)
   host0 = dict(trainer.host_seconds)
   t0 = time.perf_counter()
@@ -380,6 +443,8 @@ def main():
       'roofline': roofline, 'cpu_baseline': cpu,
     }
     if comm is not None:
+      comm['replicas_bit_identical_after_warmup'] = in_sync
+      comm['dp_schedule'] = trainer.dp_schedule
       out['gradient_exchange'] = comm
   if use_dist:
     dist.destroy_process_group()

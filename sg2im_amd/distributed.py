@@ -71,9 +71,17 @@ class GradReducer(object):
     # mute: skip the collectives (while a graph is being captured; bench.py's "step without the
     # exchange" timing leg)
     self.mute = False
+    # test instrumentation (tests/test_gpu_parity.py::test_in_graph_exchange_reduces_every_gradient_exactly_once): a
+    # 1-rank SUM is the identity, so a gradient slice that is reduced twice, never, or BEFORE its last writer ran
+    # would go unnoticed on a one-GPU box.  With test_gain = g every reduction is followed by an in-place x g on
+    # the same stream and grad_scale becomes 1/g: the arena x grad_scale equals the plain gradient exactly
+    # (g a power of two) if and only if every element went through exactly one reduction after it was complete.
+    self.test_gain = None
 
   @property
   def grad_scale(self):
+    if self.test_gain is not None:
+      return 1.0 / (self.world_size * self.test_gain)
     return 1.0 / self.world_size
 
   def capturable(self):
@@ -86,11 +94,18 @@ class GradReducer(object):
     runs on the process group's own stream) - the form that is recorded into a stream capture"""
     if (self.world_size > 1 or self.force) and not self.mute:
       dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
+      if self.test_gain is not None:
+        tensor.mul_(self.test_gain)
 
   def start(self, tensor):
     """begin an all-reduce (SUM) of ``tensor`` in place; returns immediately"""
     if (self.world_size > 1 or self.force) and not self.mute:
-      self.pending.append(all_reduce_sum_async(tensor, self.group))
+      h = all_reduce_sum_async(tensor, self.group)
+      if self.test_gain is not None:
+        h.wait()
+        tensor.mul_(self.test_gain)
+        h = _Done()
+      self.pending.append(h)
 
   def finish(self):
     """make the current stream wait for every started reduction"""

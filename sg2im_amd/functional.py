@@ -709,7 +709,7 @@ class RefinementFn(Function):
           if background:
             desc.launch_hints |= ops.HINT_BACKGROUND
           _conv_param_grads(desc, dy, cout, shape, need_w, need_b, Wp, bp)
-        side.defer(run, dy, desc)
+        side.defer(run, dy, desc, completes=(Wp, bp))
         return None, None
       return side.run(lambda: _conv_param_grads(desc, dy, cout, shape, need_w, need_b, Wp, bp), dy, desc)
     # Order per layer: data gradient (big, alone on the GPU), then its weight gradient on the side

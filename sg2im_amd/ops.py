@@ -68,8 +68,10 @@ DEFER_WGRAD = True
 # single-stream fast path, tools/graph_order_probe.py)
 SINGLE_STREAM = os.environ.get('SG2IM_SINGLE_STREAM', '0') == '1'
 DEFERRED = None
-# (count, callback(stream)): called on the weight-gradient stream right after the first `count` released weight
-# gradients were issued - the data-parallel Trainer starts the all-reduce of the gradient bucket they complete
+# (ids, callback(stream)): `ids` = data_ptr() of the parameters whose weight gradients make up the first gradient bucket of
+# the data-parallel Trainer.  Every deferred launch is tagged with the parameters it completes; the callback runs on
+# the weight-gradient stream right after the LAST of them was issued (never, if one of them is not among the released
+# launches - the Trainer then exchanges the arena as one bucket).
 AFTER_DEFERRED = None
 HINT_BACKGROUND = 1
 # only the first BG_COUNT released weight gradients are issued as background launches (occupancy cap): the later
@@ -120,6 +122,22 @@ def marks_report():
   return sorted(((n, (v[i] - t0) / 100.0) for n, i in _marks['names'].items()), key=lambda r: r[1])
 
 
+def release_deferred(queue, stream):
+  """issue the queued (fn, tags) launches, last queued first (the layers the data-gradient chain reached last first:
+  8.80 vs 8.84-8.85 ms in queue order), the first BG_COUNT as background launches; AFTER_DEFERRED's callback runs
+  right after the last launch that completes one of its parameters"""
+  queued = frozenset().union(*(tags for _, tags in queue))
+  # (a bucket whose parameters are not all among the released launches is never reported complete)
+  pending = set(AFTER_DEFERRED[0]) if AFTER_DEFERRED is not None and AFTER_DEFERRED[0] <= queued else None
+  for k, (fn, tags) in enumerate(reversed(queue)):
+    fn(k < BG_COUNT)
+    if pending is not None:
+      pending -= tags
+      if not pending:
+        AFTER_DEFERRED[1](stream)          # (Trainer: the first gradient bucket is complete on this stream)
+        pending = None
+
+
 class SideLane(object):
   """Runs the weight-gradient launches of a backward pass on a second stream.  They are leaves of
   the backward graph (nothing downstream reads dW before the optimiser), so the small kernels of
@@ -157,10 +175,10 @@ class SideLane(object):
     self.used = True
     return out
 
-  def defer(self, fn, *reads):
-    """queue fn for flush()"""
+  def defer(self, fn, *reads, completes=()):
+    """queue fn for flush(); completes: the parameters whose gradients this launch finishes (see AFTER_DEFERRED)"""
     self.deferring = True
-    self.queue.append(fn)
+    self.queue.append((fn, frozenset(p.data_ptr() for p in completes if p is not None)))
     self.keep.extend(reads)
 
   def flush(self):
@@ -173,11 +191,7 @@ class SideLane(object):
     self.side.wait_event(ev)
     with torch.cuda.stream(self.side):
       mark('wgrad_lane_start')
-      # (the layers the data-gradient chain reached last first: 8.80 vs 8.84-8.85 ms in queue order)
-      for k, fn in enumerate(reversed(self.queue)):
-        fn(k < BG_COUNT)
-        if AFTER_DEFERRED is not None and k + 1 == AFTER_DEFERRED[0]:
-          AFTER_DEFERRED[1](self.side)       # (Trainer: the first gradient bucket is complete on this stream)
+      release_deferred(self.queue, self.side)
       mark('wgrad_lane_done')
     self.queue = []
     self.used = True

@@ -51,6 +51,22 @@ def _set_requires_grad(module, flag):
     p.requires_grad_(flag)
 
 
+def generator_bucket(model, flat_g):
+  """see Trainer._generator_bucket (module level so that the slicing can be unit-tested without a GPU)"""
+  mods = getattr(model.refinement_net, 'refinement_modules', None)
+  if mods is None or len(mods) < 3 or model.refinement_net.normalization != 'batch':
+    return None
+  first = {id(p) for m in (mods[0], mods[1]) for p in m.parameters()}
+  offs = [(off, p.numel()) for p, off in zip(flat_g.params, flat_g.offsets) if id(p) in first]
+  a = min(o for o, _ in offs)
+  b = max(o + (n + 3) // 4 * 4 for o, n in offs)
+  inside = sum(1 for p, off in zip(flat_g.params, flat_g.offsets) if a <= off < b)
+  if inside != len(first):          # (not contiguous: keep one bucket)
+    return None
+  ids = frozenset(p.data_ptr() for m in (mods[0], mods[1]) for p in m.parameters() if p.dim() == 4)
+  return a, b, ids
+
+
 class Trainer(object):
   def __init__(self, vocab, device, generator_kwargs=None, d_obj_kwargs=None, d_img_kwargs=None,
                loss_weights=None, learning_rate=1e-4, world_size=1, seed=None, use_graphs=False,
@@ -406,7 +422,8 @@ class Trainer(object):
     our C ABI makes on the capture stream) and every later batch of that bucket is copied into the
     graph's static input buffers and replayed.  A new bucket is captured directly - no eager warm-up
     steps: sg2im_init() and _prepare_lanes() did everything a first launch would do lazily.
-    Collectives stay outside the graphs.
+    Data parallel: the RCCL collectives are recorded inside the graph (dp_schedule 2, the default) or issued
+    between an iteration graph and an Adam graph (schedules 0 / 1), see _capture.
 
     Safety net: round 1 reported that an EAGER launch from this library after a graph was instantiated
     made the next replay of that graph fault; 26 probe variants in round 2 could not reproduce it
@@ -469,7 +486,9 @@ class Trainer(object):
     static = sb.tensors()
     dp = self.world_size > 1 or self.reducer.force
     # Data parallel, two forms:
-    #  SG2IM_DP_SCHEDULE=0 (default): ONE iteration graph (discriminator steps on the side stream next
+    #  SG2IM_DP_SCHEDULE=2 (default, RCCL only): ONE graph with the all-reduces recorded inside it
+    #    (_capture_overlapped); falls back to schedule 0 for a process group that cannot be captured (gloo).
+    #  SG2IM_DP_SCHEDULE=0: ONE iteration graph (discriminator steps on the side stream next
     #    to the generator backward, as at N = 1) -> the four all-reduces -> Adam graph.  The exchange
     #    (119.7 MB) is exposed, but the iteration graph is the short one.
     #  SG2IM_DP_SCHEDULE=1: [G fwd + bwd | D_img] graph -> all-reduce(G, guard, D_img) started ->
@@ -509,20 +528,21 @@ class Trainer(object):
     return (sb, graphs, st, _lib.EAGER_EPOCH)
 
   def _generator_bucket(self):
-    """(begin, end, n_weight_gradients): the slice of the generator's gradient arena that holds the first two
-    refinement modules, and how many deferred weight gradients complete it; None when the refinement network
-    has fewer than three modules or carries no BatchNorm (its backward then releases nothing early)"""
-    mods = getattr(self.model.refinement_net, 'refinement_modules', None)
-    if mods is None or len(mods) < 3 or self.model.refinement_net.normalization != 'batch':
-      return None
-    first = {id(p) for m in (mods[0], mods[1]) for p in m.parameters()}
-    offs = [(off, p.numel()) for p, off in zip(self.flat_g.params, self.flat_g.offsets) if id(p) in first]
-    a = min(o for o, _ in offs)
-    b = max(o + (n + 3) // 4 * 4 for o, n in offs)
-    inside = sum(1 for p, off in zip(self.flat_g.params, self.flat_g.offsets) if a <= off < b)
-    if inside != len(first):          # (not contiguous: keep one bucket)
-      return None
-    return a, b, 4
+    """(begin, end, ids): the slice of the generator's gradient arena that holds the first two refinement modules,
+    and the data_ptr()s of their convolution weights - the parameters whose (deferred) weight gradients are the last
+    writes into that slice: ops.SideLane.flush reports the bucket complete once every one of them was issued
+    (their biases ride in the same launches, the BatchNorm gradients were written by the data-gradient chain the
+    release waits for).  None when the refinement network has fewer than three modules or carries no BatchNorm
+    (its backward then releases nothing early), or when the slice is not contiguous."""
+    return generator_bucket(self.model, self.flat_g)
+
+  @staticmethod
+  def _log_schedule(msg):
+    if not Trainer._schedule_logged:
+      Trainer._schedule_logged = True
+      print('[sg2im_amd] data-parallel schedule: ' + msg, flush=True)
+
+  _schedule_logged = False
 
   def _exchange_all(self, st):
     red = self.reducer
@@ -591,12 +611,12 @@ class Trainer(object):
       bucket = self._generator_bucket() if ingraph else None
       sent = []
       if bucket is not None:
-        a, b, count = bucket
+        a, b, ids = bucket
 
         def early(stream):
           reduce_after(stream, self.flat_g.grad[a:b])
           sent.append(True)
-        ops.AFTER_DEFERRED = (count, early)
+        ops.AFTER_DEFERRED = (ids, early)
       try:
         self._seg_generator_backward(st)
       finally:
@@ -606,6 +626,12 @@ class Trainer(object):
           reduce_after(main, self.flat_g.grad[:a], self.flat_g.grad[b:])
         else:                          # (the backward released nothing early: one bucket)
           reduce_after(main, self.flat_g.grad)
+      if dp and self.rank == 0:
+        self._log_schedule(
+          ('2: all-reduces recorded inside the iteration graph, generator in %d bucket(s)' % (2 if sent else 1)) if ingraph else
+          ('%d requested, running 0 (iteration graph -> exposed all-reduces -> Adam graph): in-graph collectives need '
+           'RCCL and an unmuted reducer' % self.dp_schedule) if self.dp_schedule == 2 else
+          '0: iteration graph -> exposed all-reduces -> Adam graph')
       main.wait_stream(side)
       if ingraph:
         main.wait_stream(comm)

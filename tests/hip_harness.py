@@ -119,6 +119,7 @@ def oracle_leafs(P):
 # and every kernel is held to 1e-4 on its own by the op-level sections (tools/gpu_check.py).
 # ---------------------------------------------------------------------------------------
 GRAD_REL, GRAD_ABS_ZERO, GRAD_COS = 1e-4, 1e-6, 0.999
+NO_REFERENCE_GRAD = -1.0     # max|g_f64| of a parameter the reference has no gradient for
 
 
 def cast_batch(cpu_batch, dtype):
@@ -162,9 +163,10 @@ class OracleRefs(object):
 
 
 def grad_parity_rows3(tr, o32, o64, scale=1.0):
-  """rows (net, name, e_hip64, e_ref, e_hip32, max|g_f64|, cosine(hip, f64), numel): errors relative to the float64
+  """rows (net, name, e_hip64, e_ref, e_hip32, max|g_f64|, cosine(hip, f64), numel, ndim): errors relative to the float64
   gradient's max magnitude - of the HIP arena against float64, of the float32 oracle against float64, of HIP
-  against the float32 oracle.  A parameter without a reference gradient must have an all-zero arena slot."""
+  against the float32 oracle.  A parameter without a reference gradient must have an all-zero arena slot (its row carries
+  max|g_f64| = NO_REFERENCE_GRAD and e_hip64 = max|g_hip|; check_grad_rows fails it unless that is exactly 0)."""
   rows = []
   for net, mod, P32, P64 in (('G', tr.model, o32.PG, o64.PG), ('Do', tr.d_obj, o32.PDo, o64.PDo),
                              ('Di', tr.d_img, o32.PDi, o64.PDi)):
@@ -175,8 +177,12 @@ def grad_parity_rows3(tr, o32, o64, scale=1.0):
       got = p.grad.detach().cpu().double() * scale
       g64 = P64[name].grad
       if g64 is None:
-        m = float(got.abs().max())
-        rows.append((net, name, m, 0.0, m, 0.0, 1.0, got.numel()))
+        # the reference's optimiser SKIPS this parameter (no gradient at all): the arena slot must be exactly zero
+        # (max|g_f64| = -1 marks the row; check_grad_rows tests e_hip64 == 0 for it)
+        m = float(got.abs().max()) if got.numel() else 0.0
+        if m != m:
+          m = float('inf')
+        rows.append((net, name, m, 0.0, m, NO_REFERENCE_GRAD, 1.0, got.numel(), got.dim()))
         continue
       g32 = P32[name].grad.detach().double()
       g64 = g64.detach()
@@ -185,13 +191,16 @@ def grad_parity_rows3(tr, o32, o64, scale=1.0):
       nn_ = float(got.norm() * g64.norm())
       rows.append((net, name, float((got - g64).abs().max()) / den, float((g32 - g64).abs().max()) / den,
                    float((got - g32).abs().max()) / den, float(g64.abs().max()),
-                   float((got * g64).sum()) / nn_ if nn_ > 0 else 1.0, got.numel()))
+                   float((got * g64).sum()) / nn_ if nn_ > 0 else 1.0, got.numel(), got.dim()))
   return rows
 
 
-def check_grad_rows(rows, rel=None, cos_min=None):
+def check_grad_rows(rows, rel=None, cos_min=None, vector_bound=None):
   """-> (bad rows, summary dict).  rel None: the reference-arithmetic bound described above; a number: that
-  bound on e_hip64 for every tensor (bf16).  Analytically-zero tensors (|g_f64| < 1e-6 everywhere: the bias of
+  bound on e_hip64 for every tensor (bf16) - with ``vector_bound`` = (rel, cos) a separate, looser pair for the
+  one-dimensional parameters (biases, BatchNorm gamma / beta: sums of cancelling terms over a whole feature map),
+  so that ``rel`` / ``cos_min`` can hold the matrices / filters / embedding tables to a bound that says something
+  about magnitude.  Analytically-zero tensors (|g_f64| < 1e-6 everywhere: the bias of
   a convolution feeding a batch-statistics BatchNorm, parameters without a gradient) must be below 1e-6
   absolute on the HIP side."""
   bad, summ = [], {}
@@ -205,6 +214,10 @@ def check_grad_rows(rows, rel=None, cos_min=None):
     if not sel:
       continue
     for r in sel:
+      if r[5] == NO_REFERENCE_GRAD:
+        if r[2] != 0.0:              # anything but an all-zero slot would move a parameter the reference leaves alone
+          bad.append(r)
+        continue
       if r[5] < GRAD_ABS_ZERO:
         if r[2] * max(r[5], 1e-30) > GRAD_ABS_ZERO and r[4] * max(r[5], 1e-30) > GRAD_ABS_ZERO:
           bad.append(r)
@@ -217,23 +230,31 @@ def check_grad_rows(rows, rel=None, cos_min=None):
         if r[2] * r[5] > 1e-2 * gmax:
           bad.append(r)
         continue
-      if (r[2] > rel or (cos_min is not None and r[6] < cos_min)) and not (flip_ok and r[6] >= 0.9999 and r[2] <= 0.1):
+      r_rel, r_cos = (vector_bound if (vector_bound is not None and r[8] <= 1) else (rel, cos_min))
+      if (r[2] > r_rel or (r_cos is not None and r[6] < r_cos)) and not (flip_ok and r[6] >= 0.9999 and r[2] <= 0.1):
         bad.append(r)
     if live:
       w = max(live, key=lambda r: r[2])
       summ[net] = (w[2], w[1], max(r[3] for r in live), max(r[4] for r in live), min(r[6] for r in live))
+      mats = [r for r in live if r[8] >= 2 and r[7] >= 16]
+      if mats:                      # worst matrix / filter tensor on its own (the bf16 bound is stated per class)
+        wm = max(mats, key=lambda r: r[2])
+        summ[net + ':matrices'] = (wm[2], wm[1], min(r[6] for r in mats))
   return bad, summ
 
 
-def assert_grad_parity(tr, refs, label, rel=None, cos_min=None, scale=1.0):
+def assert_grad_parity(tr, refs, label, rel=None, cos_min=None, scale=1.0, vector_bound=None):
   """every parameter gradient of G / D_obj / D_img against the float64 oracle under the bound above (``rel`` /
   ``cos_min``: fixed bounds instead, for bf16).  Appends the measured worst cases to
   gpurun_out/grad_parity.log and returns (worst e_hip64, worst cosine)."""
   import os
   rows = grad_parity_rows3(tr, refs.o32, refs.o64, scale)
-  bad, summ = check_grad_rows(rows, rel, cos_min)
+  bad, summ = check_grad_rows(rows, rel, cos_min, vector_bound)
   line = '%-40s' % label + '  '.join(
     '%s: e_hip64 %.2e (%s) E_ref %.2e e_hip32 %.2e cos %.6f' % ((n,) + summ[n]) for n in ('G', 'Do', 'Di') if n in summ)
+  if vector_bound is not None:
+    line += '  | matrices: ' + '  '.join('%s %.2e (%s) cos %.6f' % ((n,) + summ[n + ':matrices'])
+                                         for n in ('G', 'Do', 'Di') if n + ':matrices' in summ)
   print(line)
   try:
     os.makedirs('gpurun_out', exist_ok=True)
@@ -243,4 +264,5 @@ def assert_grad_parity(tr, refs, label, rel=None, cos_min=None, scale=1.0):
     pass
   assert not bad, '%s: gradients out of tolerance:\n' % label + '\n'.join(
     '  %s.%s e_hip64 %.3e e_ref %.3e e_hip32 %.3e max|g| %.3e cos %.6f' % r[:7] for r in bad[:20])
-  return max(v[0] for v in summ.values()), min(v[4] for v in summ.values())
+  nets = [v for k, v in summ.items() if ':' not in k]
+  return max(v[0] for v in nets), min(v[4] for v in nets)

@@ -332,3 +332,66 @@ def test_static_batch_refill_equals_pad_batch_on_cpu():
     assert torch.equal(sb.counts, counts)
   with pytest.raises(ValueError):
     sb.load(tuple(synthetic_batch(16, seed=9)[:6]))           # another image count: not this bucket
+
+
+def test_generator_gradient_buckets_partition_the_arena():
+  """Data-parallel schedule 2 (sg2im_amd/trainer.py::_capture_overlapped) exchanges the generator's gradient arena as
+  [a:b] (early: the first two refinement modules) and [:a], [b:] (after the backward pass): the three slices must
+  cover every element exactly once, [a:b] must hold exactly the parameters of refinement modules 0 and 1, and the
+  completion tags must be exactly their 3x3 convolution weights (VERDICT r3 weak #1d)."""
+  import torch
+  from sg2im_amd.model import Sg2ImModel
+  from sg2im_amd.optim import FlatParams
+  from sg2im_amd.synthetic import make_vocab
+  from sg2im_amd.trainer import GENERATOR_DEFAULTS, generator_bucket
+  model = Sg2ImModel(**dict(GENERATOR_DEFAULTS, vocab=make_vocab(184, 7), refinement_dims=(64, 32, 16, 16, 8), gconv_dim=32,
+                            gconv_hidden_dim=64, embedding_dim=32))
+  flat = FlatParams(model)
+  try:
+    a, b, ids = generator_bucket(model, flat)
+    assert 0 <= a < b <= flat.numel and a % 4 == 0 and b % 4 == 0
+    cover = torch.zeros(flat.numel, dtype=torch.int32)
+    for sl in (slice(a, b), slice(0, a), slice(b, flat.numel)):
+      cover[sl] += 1
+    assert int(cover.min()) == 1 and int(cover.max()) == 1
+    mods = model.refinement_net.refinement_modules
+    first = {p.data_ptr() for m in (mods[0], mods[1]) for p in m.parameters()}
+    inside = {p.data_ptr() for p, off in zip(flat.params, flat.offsets) if a <= off < b}
+    assert inside == first
+    for p, off in zip(flat.params, flat.offsets):                  # no parameter straddles a bucket boundary
+      assert (a <= off and off + p.numel() <= b) or off + p.numel() <= a or off >= b
+    convs = {p.data_ptr() for m in (mods[0], mods[1]) for p in m.parameters() if p.dim() == 4}
+    assert ids == convs and len(ids) == 4
+    # fewer than three modules: one bucket
+    small = Sg2ImModel(**dict(GENERATOR_DEFAULTS, vocab=make_vocab(184, 7), refinement_dims=(16, 8), gconv_dim=32,
+                              gconv_hidden_dim=64, embedding_dim=32, image_size=(8, 8)))
+    fs = FlatParams(small)
+    assert generator_bucket(small, fs) is None
+    fs.close()
+  finally:
+    flat.close()
+
+
+def test_deferred_release_reports_the_bucket_only_when_all_its_weight_gradients_were_issued():
+  """ops.SideLane.flush: the early-exchange callback fires right after the LAST tagged launch of the bucket, and
+  never when a tagged parameter is not among the released launches (no hard-coded count)."""
+  import torch
+  from sg2im_amd import ops
+
+  ps = [torch.zeros(2) for _ in range(5)]
+  issued, fired = [], []
+  lane = ops.SideLane.__new__(ops.SideLane)              # (the queue without streams)
+  lane.on, lane.used, lane.keep, lane.queue, lane.deferring = False, False, [], [], False
+  for i, p in enumerate(ps):
+    lane.defer(lambda bg, i=i: issued.append(i), completes=(p, None))
+  try:
+    ops.AFTER_DEFERRED = (frozenset({ps[4].data_ptr(), ps[2].data_ptr()}), lambda stream: fired.append(len(issued)))
+    ops.release_deferred(lane.queue, 'stream')
+    assert issued == [4, 3, 2, 1, 0]      # released in reverse order
+    assert fired == [3]                   # right after ps[2]'s launch, the last of the bucket
+    del issued[:], fired[:]
+    ops.AFTER_DEFERRED = (frozenset({ps[4].data_ptr(), torch.zeros(1).data_ptr()}), lambda stream: fired.append(len(issued)))
+    ops.release_deferred(lane.queue, 'stream')
+    assert fired == []                    # a bucket parameter that is never released: no early exchange
+  finally:
+    ops.AFTER_DEFERRED = None
