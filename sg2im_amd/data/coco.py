@@ -39,7 +39,7 @@ class CocoSceneGraphDataset(Dataset):
       print('Falling back to stuff_only=False.')
     self.image_dir, self.mask_size, self.max_samples = image_dir, int(mask_size), max_samples
     self.normalize_images, self.include_relationships = normalize_images, include_relationships
-    self.rng = random if seed is None else random.Random(seed)     # (the reference draws from the global module)
+    self._rng = None if seed is None else random.Random(seed)     # (the reference draws from the global module)
     self.set_image_size(image_size)
 
     instances = _read_json(instances_json)
@@ -98,6 +98,11 @@ class CocoSceneGraphDataset(Dataset):
   def set_image_size(self, image_size):
     self.transform = ImageTransform(image_size, self.normalize_images)
     self.image_size = image_size
+
+  def rng(self):
+    """the global `random` module when no seed was given (what the reference draws from) - resolved at use, so that the
+    dataset object stays picklable for DataLoader workers under the spawn / forkserver start methods"""
+    return self._rng if self._rng is not None else random
 
   def __len__(self):
     n = len(self.image_ids)
@@ -174,8 +179,8 @@ class CocoSceneGraphDataset(Dataset):
       centers = self._centers(boxes, masks)
       pred_idx = self.vocab['pred_name_to_idx']
       for cur in range(n):
-        other = self.rng.choice([j for j in range(n) if j != cur])
-        s, o = (cur, other) if self.rng.random() > 0.5 else (other, cur)
+        other = self.rng().choice([j for j in range(n) if j != cur])
+        s, o = (cur, other) if self.rng().random() > 0.5 else (other, cur)
         triples.append((s, pred_idx[self._predicate(boxes[s], boxes[o], centers[s] - centers[o])], o))
     triples += [(i, 0, n) for i in range(n)]                     # __in_image__
     return (image, torch.from_numpy(objs), torch.from_numpy(boxes), torch.from_numpy(masks),

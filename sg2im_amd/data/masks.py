@@ -9,8 +9,8 @@ Deviations from the reference's third-party code (documented, not pinned - see d
    the boundary: masks can differ in a one-pixel ring along the boundary.  The loader thresholds a 16 x 16 resize
    of the cropped mask, where a ring of boundary pixels rarely flips a cell.
  * `resize_mask` is first-order (bilinear) sampling at output pixel centres with zeros outside the image - what
-   skimage.transform.resize(order=1, mode='constant') computes WITHOUT anti-aliasing (skimage 0.13, the version of
-   the reference's requirements.txt; newer releases blur before down-sampling)."""
+   skimage.transform.resize(order=1, mode='constant') computes WITHOUT anti-aliasing (scikit-image 0.14.0 is what
+   the reference's requirements.txt pins: no anti-aliasing by default; releases from 0.15 on blur before down-sampling)."""
 import numpy as np
 import PIL.Image
 import PIL.ImageDraw

@@ -36,12 +36,17 @@ class VgSceneGraphDataset(Dataset):
     self.num_objects = len(vocab['object_idx_to_name'])
     self.use_orphaned_objects, self.max_objects = use_orphaned_objects, max_objects
     self.max_samples, self.include_relationships = max_samples, include_relationships
-    self.rng = random if seed is None else random.Random(seed)
+    self._rng = None if seed is None else random.Random(seed)
     self.transform = ImageTransform(image_size, normalize_images)
     arrays = _load_arrays(h5_path)
     paths = arrays.pop('image_paths')
     self.image_paths = [p.decode('utf-8') if isinstance(p, bytes) else str(p) for p in paths]
     self.data = {k: np.asarray(v).astype(np.int64) for k, v in arrays.items()}
+
+  def rng(self):
+    """the global `random` module when no seed was given (what the reference draws from) - resolved at use, so that the
+    dataset object stays picklable for DataLoader workers under the spawn / forkserver start methods"""
+    return self._rng if self._rng is not None else random
 
   def __len__(self):
     n = self.data['object_names'].shape[0]
@@ -60,9 +65,9 @@ class VgSceneGraphDataset(Dataset):
     # reference vg.py:95-100: more related objects than fit -> a random max_objects of them (one more than the
     # max_objects - 1 it otherwise aims for; kept as is); fewer -> filled up with objects outside any relationship
     if len(chosen) > self.max_objects - 1:
-      chosen = self.rng.sample(chosen, self.max_objects)
+      chosen = self.rng().sample(chosen, self.max_objects)
     if len(chosen) < self.max_objects - 1 and self.use_orphaned_objects:
-      chosen += self.rng.sample(orphans, min(self.max_objects - 1 - len(chosen), len(orphans)))
+      chosen += self.rng().sample(orphans, min(self.max_objects - 1 - len(chosen), len(orphans)))
     n = len(chosen)
     objs = np.empty(n + 1, dtype=np.int64)
     boxes = np.empty((n + 1, 4), dtype=np.float32)
