@@ -267,6 +267,17 @@ def main():
     from sg2im_amd import ops as _ops
     for name, us in _ops.marks_report():
       print('[mark] %-18s %9.1f us' % (name, us), file=sys.stderr)
+    # the persistent GraphTripleConv launches of the last replay: workgroup 0's (before, after)-barrier stamps
+    import ctypes as _ct
+    from sg2im_amd import _lib as _l
+    for key, area in _ops._sync_areas.items():
+      host = area.cpu().contiguous()
+      buf = (_ct.c_ulonglong * 256)()
+      n = _l.load().sg2im_gconv_stack_stamps(_ct.c_void_p(host.data_ptr()), _ct.cast(buf, _ct.c_void_p), 256)
+      if n > 2:
+        st = [(buf[i] - buf[0]) / 100.0 for i in range(n)]
+        print('[gcn-stamps] lane %s: total %.1f us; compute/barrier per stage: %s' % (
+          key, st[-1], ' '.join('%.1f/%.1f' % (st[i] - st[i - 1], st[i + 1] - st[i]) for i in range(1, n - 1, 2))), file=sys.stderr)
   launch_stats = dict(trainer.launch_stats)
   n_graphs = len(trainer._graphs)
 

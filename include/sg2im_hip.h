@@ -26,7 +26,7 @@ extern "C" {
 #define SG2IM_ERR_ARG 1   /* invalid argument (the reference would raise / assert) */
 #define SG2IM_ERR_HIP 2   /* a HIP runtime call failed; see hipGetLastError() */
 
-int sg2im_abi_version(void);   /* 4 */
+int sg2im_abi_version(void);   /* 5 */
 
 /* Statistics: kernels this library has launched (or recorded into a stream capture) so far in this process;
  * which = 0: all of them, 1: the implicit-GEMM family incl. its split-K finishes.  bench.py reads it around the
@@ -267,6 +267,57 @@ int sg2im_gconv_layer_backward(const sg2im_gconv_layer* layer, const float* h1, 
                                const float* g_pred, long long ld_gpred, float* d_triple, float* d_obj,
                                const sg2im_gconv_grads* grads, float* scratch, size_t scratch_bytes,
                                float* workspace, size_t workspace_bytes, hipStream_t stream);
+
+/* The whole GraphTripleConv STACK - sg2im/model.py:136-140: `gconv` followed by `gconv_net`'s layers, each layer
+ * sg2im/graph.py:56-120 - as ONE persistent launch per direction (csrc/gcn_persist.hip): <= one workgroup per CU
+ * stays resident and walks the stages of all layers, separated by XCD-hierarchical grid barriers; gather + concat
+ * and the CSR pool (bit-exact, the reference's accumulation order) run inside the GEMM operand loaders.
+ * Layer l reads layer l-1's new_obj / new_t[:, hidden:hidden+dout] (layer 0: obj_vecs / pred_vecs) and writes its
+ * activations h1 [T][hidden], new_t [T][2 hidden + dout], pooled [O][hidden], h2 [O][hidden], new_obj [O][dout]
+ * (dense, caller-owned; what backward reads).  Requirements (else SG2IM_ERR_ARG - use the per-layer entry points):
+ * din, hidden, dout multiples of 32 (sg2im_gconv_stack_supported), 16-byte aligned pointers, mlp_normalization
+ * 'none'.  sync: >= sg2im_gconv_stack_sync_bytes() of device memory private to the call (zeroed by the launcher on
+ * `stream`); after completion word 64 is non-zero iff a grid barrier timed out (never on a healthy device: every
+ * spin is bounded instead of hanging the queue) - sg2im_gconv_stack_status() of a host copy. */
+#define SG2IM_GCONV_MAX_LAYERS 8
+typedef struct sg2im_gconv_stack_layer {
+  const float *w1a, *b1a, *w1b, *b1b, *w2a, *b2a, *w2b, *b2b;   /* nn.Linear layout, see sg2im_gconv_layer */
+  float *h1, *new_t, *pooled, *h2, *new_obj;
+  int din, hidden, dout, reserved;
+} sg2im_gconv_stack_layer;
+typedef struct sg2im_gconv_stack {
+  const float* obj_vecs; long long ld_obj;
+  const float* pred_vecs; long long ld_pred;
+  const long long* s_idx; const long long* o_idx;
+  const int* row_ptr; const int* entries;        /* sg2im_csr_build(s_idx, T, o_idx, T, n_objs, ...) */
+  int n_objs, n_triples, n_layers;
+  int average;                                   /* 1: 'avg' pooling, 0: 'sum' */
+  sg2im_gconv_stack_layer layer[SG2IM_GCONV_MAX_LAYERS];
+} sg2im_gconv_stack;
+size_t sg2im_gconv_stack_sync_bytes(void);
+int sg2im_gconv_stack_supported(int din, int hidden, int dout);
+int sg2im_gconv_stack_forward(const sg2im_gconv_stack* stack, void* sync, size_t sync_bytes, hipStream_t stream);
+/* Backward of the stack, ONE persistent launch: last layer first; per layer the data gradients of net2 / the pool +
+ * concat (rebuilt in the operand loader) / net1, and the eight parameter gradients as extra tiles of the stage that
+ * has their operands (+= when layer[l].accumulate; a NULL pointer skips that gradient).
+ * g_obj [O][dout_last] dense (NULL = zeros), g_pred [T][>= dout_last] with row stride ld_gpred (NULL = zeros): gradients
+ * w.r.t. the stack's outputs (new_obj of the last layer, its new_t[:, hidden:hidden+dout]).  d_triple [T][3 din_0]
+ * (out, required): gradient w.r.t. layer 0's gathered net1 input - columns [din_0, 2 din_0) are the gradient w.r.t.
+ * pred_vecs; d_obj [O][din_0] (out, may be NULL): gradient w.r.t. obj_vecs.  scratch:
+ * sg2im_gconv_stack_backward_scratch() bytes.  Requires n_triples >= 1 (else SG2IM_ERR_ARG: use the per-layer calls). */
+typedef struct sg2im_gconv_stack_grads {
+  const float* g_obj; const float* g_pred; long long ld_gpred;
+  float* d_triple; float* d_obj;
+  float* scratch; size_t scratch_bytes;
+  sg2im_gconv_grads layer[SG2IM_GCONV_MAX_LAYERS];
+} sg2im_gconv_stack_grads;
+size_t sg2im_gconv_stack_backward_scratch(const sg2im_gconv_stack* stack);
+int sg2im_gconv_stack_backward(const sg2im_gconv_stack* stack, const sg2im_gconv_stack_grads* grads, void* sync,
+                               size_t sync_bytes, hipStream_t stream);
+int sg2im_gconv_stack_status(const void* sync_host_copy);
+/* diagnostics: the 100 MHz device-clock stamps workgroup 0 left in the sync area (host copy): kernel start, then
+ * (before, after) every grid barrier, then the end; returns the number copied into out[0..max_out) */
+int sg2im_gconv_stack_stamps(const void* sync_host_copy, unsigned long long* out, int max_out);
 
 /* Up to 16 plain device-to-device copies (sizes and addresses multiples of 4 bytes) in ONE launch: the hand-over
  * of a collated batch (scripts/train.py:514-519 `batch = [tensor.cuda() for tensor in batch]`) into the static

@@ -53,9 +53,32 @@ class GconvLayer(Structure):
               ('average', c_int)] + [(k, c_void_p) for k in ('w1a', 'b1a', 'w1b', 'b1b', 'w2a', 'b2a', 'w2b', 'b2b')]
 
 
+SG2IM_GCONV_MAX_LAYERS = 8
+
+
+class GconvStackLayer(Structure):
+  """sg2im_gconv_stack_layer (include/sg2im_hip.h)"""
+  _fields_ = [(k, c_void_p) for k in ('w1a', 'b1a', 'w1b', 'b1b', 'w2a', 'b2a', 'w2b', 'b2b', 'h1', 'new_t', 'pooled', 'h2',
+                                      'new_obj')] + [('din', c_int), ('hidden', c_int), ('dout', c_int), ('reserved', c_int)]
+
+
+class GconvStack(Structure):
+  """sg2im_gconv_stack (include/sg2im_hip.h)"""
+  _fields_ = [('obj_vecs', c_void_p), ('ld_obj', c_longlong), ('pred_vecs', c_void_p), ('ld_pred', c_longlong),
+              ('s_idx', c_void_p), ('o_idx', c_void_p), ('row_ptr', c_void_p), ('entries', c_void_p),
+              ('n_objs', c_int), ('n_triples', c_int), ('n_layers', c_int), ('average', c_int),
+              ('layer', GconvStackLayer * SG2IM_GCONV_MAX_LAYERS)]
+
+
 class GconvGrads(Structure):
   """sg2im_gconv_grads (include/sg2im_hip.h)"""
   _fields_ = [(k, c_void_p) for k in ('dw1a', 'db1a', 'dw1b', 'db1b', 'dw2a', 'db2a', 'dw2b', 'db2b')] + [('accumulate', c_int)]
+
+
+class GconvStackGrads(Structure):
+  """sg2im_gconv_stack_grads (include/sg2im_hip.h)"""
+  _fields_ = [('g_obj', c_void_p), ('g_pred', c_void_p), ('ld_gpred', c_longlong), ('d_triple', c_void_p), ('d_obj', c_void_p),
+              ('scratch', c_void_p), ('scratch_bytes', c_size_t), ('layer', GconvGrads * SG2IM_GCONV_MAX_LAYERS)]
 
 
 _P, _I, _L, _F, _Z = c_void_p, c_int, c_longlong, c_float, c_size_t
@@ -87,6 +110,13 @@ _SIGNATURES = {
   'sg2im_gconv_layer_backward_scratch': [_I, _I, _I, _I, _I],
   'sg2im_gconv_layer_backward': [POINTER(GconvLayer), _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, POINTER(GconvGrads), _P, _Z,
                                  _P, _Z, _P],
+  'sg2im_gconv_stack_sync_bytes': [],
+  'sg2im_gconv_stack_supported': [_I, _I, _I],
+  'sg2im_gconv_stack_forward': [POINTER(GconvStack), _P, _Z, _P],
+  'sg2im_gconv_stack_backward_scratch': [POINTER(GconvStack)],
+  'sg2im_gconv_stack_backward': [POINTER(GconvStack), POINTER(GconvStackGrads), _P, _Z, _P],
+  'sg2im_gconv_stack_status': [_P],
+  'sg2im_gconv_stack_stamps': [_P, _P, _I],
   'sg2im_layout_forward': [_P, _L, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P],
   'sg2im_layout_pyramid_forward': [_P, _L, _P, _P, _P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, POINTER(c_void_p), _L, _P],
   'sg2im_layout_backward_workspace': [_I, _I, _I, _I],
@@ -130,7 +160,8 @@ _SIGNATURES = {
   'sg2im_adam_step_guarded': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P, _P],
 }
 _RESTYPE = {'sg2im_layout_backward_workspace': c_size_t, 'sg2im_crop_backward_workspace': c_size_t,
-            'sg2im_launch_count': ctypes.c_ulonglong, 'sg2im_gconv_layer_backward_scratch': c_size_t}
+            'sg2im_launch_count': ctypes.c_ulonglong, 'sg2im_gconv_layer_backward_scratch': c_size_t,
+            'sg2im_gconv_stack_sync_bytes': c_size_t, 'sg2im_gconv_stack_backward_scratch': c_size_t}
 EXPORTS = tuple(sorted(_SIGNATURES))
 
 _lib = None

@@ -15,6 +15,7 @@
 #include <algorithm>
 #define SG2IM_GEMM_TU 1
 #include "launch_count.h"
+#include "gcn_persist.h"
 #include "igemm.h"
 #include <cstddef>
 #include <cstdio>
@@ -1665,6 +1666,7 @@ int sg2im_init(void) {
 #undef SG2IM_PREP
   if (e == hipSuccess) e = ensure_lds(conv_wgrad_group_kernel, wgrad_lds<64, 64>());
   if (e == hipSuccess) e = prepare_wgrad_halo();
+  if (e == hipSuccess) e = gcn::prepare();          // the persistent GraphTripleConv-stack kernels (gcn_persist.hip)
   if (e != hipSuccess) return SG2IM_ERR_HIP;
   SG2IM_LAUNCH(init_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)0, (int*)nullptr);
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize((hipStream_t)0) != hipSuccess) return SG2IM_ERR_HIP;

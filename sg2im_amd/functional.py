@@ -416,6 +416,85 @@ class GraphTripleConvFn(Function):
     return (d_obj, d_pred, None, None, None, None) + tuple(ret)
 
 
+class GraphTripleConvStackFn(Function):
+  """ALL GraphTripleConv layers of the model (reference sg2im/model.py:136-140: `gconv` then `gconv_net`, each layer
+  sg2im/graph.py:56-120) as one persistent launch per direction (csrc/gcn_persist.hip): the stages of the layers
+  are separated by grid barriers inside the kernel instead of by ~9 dependent launches per layer."""
+
+  @staticmethod
+  def forward(ctx, obj_vecs, pred_vecs, s_idx, o_idx, csr, avg, *params):
+    nl = len(params) // 8
+    T, O = pred_vecs.size(0), obj_vecs.size(0)
+    if obj_vecs.stride(1) != 1:
+      obj_vecs = obj_vecs.contiguous()
+    if T > 0 and pred_vecs.stride(1) != 1:
+      pred_vecs = pred_vecs.contiguous()
+    weights = [tuple(params[8 * l:8 * l + 8]) for l in range(nl)]
+    acts = []
+    for w in weights:
+      H, Dout, NT = w[4].size(0), w[6].size(0), w[2].size(0)
+      acts.append((_new(obj_vecs, T, H), _new(obj_vecs, T, NT), _new(obj_vecs, O, H), _new(obj_vecs, O, H),
+                   _new(obj_vecs, O, Dout)))
+    S = ops.gconv_stack_struct(obj_vecs, pred_vecs, s_idx, o_idx, csr, avg, weights, acts)
+    ops.gconv_stack_forward(S, obj_vecs.device)
+    ctx.save_for_backward(obj_vecs, pred_vecs, s_idx, o_idx, *params, *[t for a in acts for t in a])
+    ctx.csr, ctx.avg, ctx.nl = csr, avg, nl
+    H, Dout = weights[-1][4].size(0), weights[-1][6].size(0)
+    return acts[-1][4], acts[-1][1][:, H:H + Dout]
+
+  @staticmethod
+  def backward(ctx, g_obj, g_pred):
+    nl = ctx.nl
+    sv = ctx.saved_tensors
+    obj_vecs, pred_vecs, s_idx, o_idx = sv[:4]
+    params, flat_acts = sv[4:4 + 8 * nl], sv[4 + 8 * nl:]
+    csr, avg = ctx.csr, ctx.avg
+    T, O = pred_vecs.size(0), obj_vecs.size(0)
+    need = ctx.needs_input_grad[6:]
+    sinks = [_sink(p) if n else None for p, n in zip(params, need)]
+    use_sinks = all((not n) or (sk is not None) for n, sk in zip(need, sinks))
+    if use_sinks:
+      bufs, ret = sinks, [None] * (8 * nl)
+    else:
+      bufs = [torch.empty_like(p) if n else None for p, n in zip(params, need)]
+      ret = bufs
+    g_obj = None if g_obj is None else g_obj.contiguous()
+    if g_pred is not None and g_pred.stride(1) != 1:
+      g_pred = g_pred.contiguous()
+    if T > 0 and ops.GCN_PERSISTENT_BACKWARD:
+      # ONE persistent launch for all layers (sg2im_gconv_stack_backward)
+      weights = [tuple(params[8 * l:8 * l + 8]) for l in range(nl)]
+      acts = [tuple(flat_acts[5 * l:5 * l + 5]) for l in range(nl)]
+      S = ops.gconv_stack_struct(obj_vecs, pred_vecs, s_idx, o_idx, csr, avg, weights, acts)
+      Din0 = obj_vecs.size(1)
+      d_triple = _new(obj_vecs, T, 3 * Din0)
+      d_obj = _new(obj_vecs, O, Din0) if ctx.needs_input_grad[0] else None
+      ops.gconv_stack_backward(S, g_obj, g_pred, d_triple, d_obj, [bufs[8 * l:8 * l + 8] for l in range(nl)], use_sinks,
+                               obj_vecs.device)
+      return (d_obj, d_triple[:, Din0:2 * Din0] if ctx.needs_input_grad[1] else None, None, None, None, None) + tuple(ret)
+    d_obj = d_pred = None
+    # layer by layer, last first (each: sg2im_gconv_layer_backward)
+    for l in range(nl - 1, -1, -1):
+      w = params[8 * l:8 * l + 8]
+      h1, new_t, pooled, h2, new_obj = flat_acts[5 * l:5 * l + 5]
+      if l == 0:
+        xin, pin = obj_vecs, pred_vecs
+      else:
+        pa = flat_acts[5 * (l - 1):5 * (l - 1) + 5]
+        Hp, Dp = params[8 * (l - 1) + 4].size(0), params[8 * (l - 1) + 6].size(0)
+        xin, pin = pa[4], pa[1][:, Hp:Hp + Dp]
+      Din = xin.size(1)
+      L = ops._gconv_layer_struct(xin, pin, s_idx, o_idx, csr, avg, w)
+      d_triple = _new(obj_vecs, T, 3 * Din)
+      want_obj = l > 0 or ctx.needs_input_grad[0]
+      d_obj = _new(obj_vecs, O, Din) if want_obj else None
+      ops.gconv_layer_backward(L, h1, new_t, pooled, h2, new_obj, g_obj, g_pred, d_triple, d_obj, bufs[8 * l:8 * l + 8], use_sinks)
+      g_obj, g_pred = d_obj, d_triple[:, Din:2 * Din]
+      d_pred = g_pred
+    return (d_obj if ctx.needs_input_grad[0] else None, d_pred if ctx.needs_input_grad[1] else None,
+            None, None, None, None) + tuple(ret)
+
+
 class RelAux(Function):
   """rel_aux_net on cat[boxes[s], boxes[o], vecs[s], vecs[o]] (reference sg2im/model.py:149-152)"""
 

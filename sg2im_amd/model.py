@@ -115,12 +115,19 @@ class Sg2ImModel(nn.Module):
     obj_vecs = HF.Embedding.apply(self.obj_embeddings.weight, objs)
     obj_vecs_orig = obj_vecs
     pred_vecs = HF.Embedding.apply(self.pred_embeddings.weight, p)
-    if isinstance(self.gconv, nn.Linear):
-      obj_vecs = HF.LinearAct.apply(obj_vecs, self.gconv.weight, self.gconv.bias, 1.0)
+    stack = self._gconv_stack()
+    if stack is not None:
+      # every GraphTripleConv layer in ONE persistent launch (csrc/gcn_persist.hip)
+      params = [t for g in stack for lin in (g.net1.linears() + g.net2.linears()) for t in (lin.weight, lin.bias)]
+      obj_vecs, pred_vecs = HF.GraphTripleConvStackFn.apply(obj_vecs, pred_vecs, edges[0], edges[1], edges[2],
+                                                           stack[0].pooling == 'avg', *params)
     else:
-      obj_vecs, pred_vecs = self.gconv(obj_vecs, pred_vecs, edges, (obj_count, triple_count))
-    if self.gconv_net is not None:
-      obj_vecs, pred_vecs = self.gconv_net(obj_vecs, pred_vecs, edges, (obj_count, triple_count))
+      if isinstance(self.gconv, nn.Linear):
+        obj_vecs = HF.LinearAct.apply(obj_vecs, self.gconv.weight, self.gconv.bias, 1.0)
+      else:
+        obj_vecs, pred_vecs = self.gconv(obj_vecs, pred_vecs, edges, (obj_count, triple_count))
+      if self.gconv_net is not None:
+        obj_vecs, pred_vecs = self.gconv_net(obj_vecs, pred_vecs, edges, (obj_count, triple_count))
 
     ops.mark('gcn_layers_done')
     masks_pred = rel_scores = None
@@ -168,6 +175,19 @@ class Sg2ImModel(nn.Module):
     if aux_stream is not None:
       main.wait_stream(aux_stream)                            # (the detached outputs; long finished by now)
     return img, boxes_pred, masks_pred, rel_scores
+
+  def _gconv_stack(self):
+    """the GraphTripleConv layers as a list when the persistent stack kernels can run them (no MLP normalisation,
+    one pooling mode, feature sizes that are multiples of 32), else None (layer-by-layer launches)"""
+    from .graph import GraphTripleConv
+    if not isinstance(self.gconv, GraphTripleConv):
+      return None
+    layers = [self.gconv] + (list(self.gconv_net.gconvs) if self.gconv_net is not None else [])
+    if any(g.net1.norms() or g.net2.norms() or g.pooling != layers[0].pooling for g in layers):
+      return None
+    if not ops.gconv_stack_supported([(g.input_dim, g.hidden_dim, g.output_dim) for g in layers]):
+      return None
+    return layers
 
   def forward(self, objs, triples, obj_to_img=None, boxes_gt=None, masks_gt=None, num_images=None):
     """Required: objs (O,) int64 categories, triples (T,3) int64 [s,p,o].  Optional:

@@ -12,7 +12,7 @@ from ctypes import byref, c_int, c_longlong, c_void_p
 import torch
 
 from . import _lib
-from ._lib import BnBwd, BnFwd, ConvDesc, GconvGrads, GconvLayer, call
+from ._lib import BnBwd, BnFwd, ConvDesc, GconvGrads, GconvLayer, GconvStack, GconvStackGrads, call
 
 WORKSPACE_BYTES = 256 << 20      # split-K partials / layout-backward partials
 _ws = {}
@@ -232,6 +232,20 @@ def scratch(device, nfloats):
       _scratch_retired.append(s)
     s = torch.empty(max(int(nfloats), 1 << 20), dtype=torch.float32, device=device)
     _scratch[key] = s
+  return s
+
+
+_sync_areas = {}
+
+
+def sync_area(device):
+  """grid-barrier state of the persistent kernels (per device and stream; zeroed by every launch on its stream).
+  Like the other lane buffers it must exist before a capture starts (Trainer._prepare_lanes)."""
+  key = _lane(device)
+  s = _sync_areas.get(key)
+  if s is None:
+    s = torch.zeros(int(_lib.load().sg2im_gconv_stack_sync_bytes()) // 4, dtype=torch.int32, device=device)
+    _sync_areas[key] = s
   return s
 
 
@@ -535,6 +549,91 @@ def gconv_layer_backward(L, h1, new_t, pooled, h2, new_obj, g_obj, g_pred, d_tri
   _timed('igemm_dgrad', 2.0 * _gconv_flops(L), lambda: call(
     'sg2im_gconv_layer_backward', byref(L), _f(h1), _f(new_t), _f(pooled), _f(h2), _f(new_obj), _f(g_obj), pg, int(ldg),
     _f(d_triple), _f(d_obj), byref(G), _f(sc), sc.numel() * 4, _f(ws), ws.numel() * 4, _stream()))
+
+
+GCN_PERSISTENT = os.environ.get('SG2IM_GCN_PERSIST', '1') != '0'      # (A/B knob: 0 = one call per layer)
+GCN_PERSISTENT_BACKWARD = os.environ.get('SG2IM_GCN_PERSIST_BWD', '1') != '0'   # (0: persistent forward, per-layer backward)
+
+
+def gconv_stack_supported(dims):
+  """dims: [(din, hidden, dout)] per layer - can the persistent stack kernels run them?"""
+  lib = _lib.load()
+  return (GCN_PERSISTENT and 1 <= len(dims) <= _lib.SG2IM_GCONV_MAX_LAYERS and
+          all(lib.sg2im_gconv_stack_supported(int(a), int(b), int(c)) for a, b, c in dims))
+
+
+def gconv_stack_struct(obj_vecs, pred_vecs, s_idx, o_idx, csr, avg, weights, acts):
+  """weights: per layer (W1a, b1a, W1b, b1b, W2a, b2a, W2b, b2b); acts: per layer (h1, new_t, pooled, h2, new_obj)"""
+  S = GconvStack()
+  po, ldo = rows_ld(obj_vecs)
+  T = pred_vecs.size(0)
+  S.obj_vecs, S.ld_obj = po.value, ldo
+  if T > 0:
+    pp, ldp = rows_ld(pred_vecs)
+    S.pred_vecs, S.ld_pred = pp.value, ldp
+    S.s_idx, S.o_idx = _i64(s_idx).value, _i64(o_idx).value
+  S.row_ptr, S.entries = csr.row_ptr.data_ptr(), csr.entries.data_ptr()
+  S.n_objs, S.n_triples, S.n_layers, S.average = obj_vecs.size(0), T, len(weights), int(bool(avg))
+  flops = 0.0
+  for l, (w, a) in enumerate(zip(weights, acts)):
+    L = S.layer[l]
+    for k, t in zip(('w1a', 'b1a', 'w1b', 'b1b', 'w2a', 'b2a', 'w2b', 'b2b'), w):
+      setattr(L, k, _f(t).value if t is not None else None)
+    for k, t in zip(('h1', 'new_t', 'pooled', 'h2', 'new_obj'), a):
+      setattr(L, k, _f(t).value if (t is not None and t.numel() > 0) else None)
+    L.din, L.hidden, L.dout = w[0].size(1) // 3, w[4].size(0), w[6].size(0)
+    flops += 2.0 * (T * (3 * L.din * L.hidden + L.hidden * (2 * L.hidden + L.dout)) + S.n_objs * (L.hidden * L.hidden + L.hidden * L.dout))
+  S._keep = (obj_vecs, pred_vecs, s_idx, o_idx, csr, weights, acts)
+  S._flops = flops
+  return S
+
+
+def gconv_stack_forward(S, device):
+  """the whole GraphTripleConv stack, forward: ONE persistent launch (sg2im_gconv_stack_forward)"""
+  sy = sync_area(device)
+  _note_bytes('igemm_fwd', S._flops / 2.0 / max(S.n_triples + S.n_objs, 1))
+  _timed('igemm_fwd', S._flops, lambda: call('sg2im_gconv_stack_forward', byref(S), c_void_p(sy.data_ptr()), sy.numel() * 4,
+                                             _stream()))
+
+
+def gconv_stack_backward(S, g_obj, g_pred, d_triple, d_obj, grads, accumulate, device):
+  """the whole stack, backward: ONE persistent launch (sg2im_gconv_stack_backward).  grads: per layer 8 tensors or
+  None in the order (dW1a, db1a, dW1b, db1b, dW2a, db2a, dW2b, db2b)"""
+  G = GconvStackGrads()
+  G.g_obj = _f(g_obj).value if g_obj is not None else None
+  if g_pred is not None:
+    pg, ldg = rows_ld(g_pred)
+    G.g_pred, G.ld_gpred = pg.value, ldg
+  G.d_triple = _f(d_triple).value
+  G.d_obj = _f(d_obj).value if d_obj is not None else None
+  need = int(_lib.load().sg2im_gconv_stack_backward_scratch(byref(S)))
+  sc = scratch(device, need // 4 + 16)
+  G.scratch, G.scratch_bytes = sc.data_ptr(), sc.numel() * 4
+  for l, gl in enumerate(grads):
+    for k, t in zip(('dw1a', 'db1a', 'dw1b', 'db1b', 'dw2a', 'db2a', 'dw2b', 'db2b'), gl):
+      setattr(G.layer[l], k, _f(t).value if t is not None else None)
+    G.layer[l].accumulate = int(bool(accumulate))
+  sy = sync_area(device)
+  _timed('igemm_dgrad', 2.0 * S._flops, lambda: call('sg2im_gconv_stack_backward', byref(S), byref(G), c_void_p(sy.data_ptr()),
+                                                     sy.numel() * 4, _stream()))
+
+
+def gconv_stack_check(device):
+  """(debugging / tests; synchronises) raise if a grid barrier of the last persistent launch on this lane timed out"""
+  sy = sync_area(device)
+  host = sy.cpu().contiguous()
+  if _lib.load().sg2im_gconv_stack_status(c_void_p(host.data_ptr())) != 0:
+    raise _lib.Sg2imHipError('a grid barrier of the persistent GraphTripleConv kernel timed out (grid not resident?)')
+
+
+def gconv_stack_stamps(device):
+  """(diagnostics; synchronises) microseconds since kernel start of workgroup 0's stamps of the last persistent launch on
+  this lane: [start = 0, before barrier 1, after barrier 1, ..., end]"""
+  import ctypes
+  host = sync_area(device).cpu().contiguous()
+  out = (ctypes.c_ulonglong * 256)()
+  n = _lib.load().sg2im_gconv_stack_stamps(c_void_p(host.data_ptr()), ctypes.cast(out, c_void_p), 256)
+  return [(out[i] - out[0]) / 100.0 for i in range(n)]
 
 
 def copy_2d(src, out):

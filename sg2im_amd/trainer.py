@@ -411,6 +411,7 @@ class Trainer(object):
       with torch.cuda.stream(s):
         ops.workspace(dev)
         ops.scratch(dev, scratch_floats)
+        ops.sync_area(dev)           # (grid-barrier state of the persistent GraphTripleConv kernels)
     ops.unit(dev)                    # (cached process-wide: must not be born inside a capture)
     ops.marks_init(dev)
 

@@ -76,6 +76,14 @@ def test_graph_triple_conv_layer():
   _run('sec_gconv')
 
 
+def test_graph_triple_conv_stack_persistent_kernel():
+  """csrc/gcn_persist.hip: all GraphTripleConv layers in one persistent launch (grid barriers between the stages,
+  gather / concat / CSR pool in the operand loaders) against the oracle's layer-by-layer composition; the pooled
+  vectors bit-exact against sg2im_segment_sum over the kernel's own net1 output; ragged sizes, 'sum' pooling, long
+  CSR rows, isolated objects, T = 0, more tiles than resident workgroups."""
+  _run('sec_gconv_stack')
+
+
 def test_conv_with_fused_batchnorm_reductions():
   """sg2im_conv2d_forward_bn / sg2im_conv2d_backward_data_bn + sg2im_bn_backward_apply: the
   BatchNorm statistics of a conv output and the BatchNorm-backward sums of a data gradient produced by the

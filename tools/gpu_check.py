@@ -457,6 +457,121 @@ def sec_gconv():
     report('gconv d ' + k, p.grad, Pl['g.' + k].grad)
 
 
+def _masked_stack_reference(Wcpu, dims, ov, pv, s, o, pooling, acts):
+  """float64 CPU restatement of the layer stack (sg2im/graph.py:56-120 per layer) in which every ReLU is a
+  multiplication by the 0/1 mask of the HIP kernel's OWN activation: the gradient of exactly the piecewise-linear
+  branch the kernel took.  (Against the plain oracle a pre-activation within rounding distance of the kink takes the
+  other branch on one side and moves a whole row's worth of gradient: measured 1e-2 of a tensor's max with the 3.9 M
+  activations of the training shape.)"""
+  x, pr = ov.double().requires_grad_(True), pv.double().requires_grad_(True)
+  Wd = [w.detach().cpu().double().requires_grad_(True) for w in Wcpu]
+  O, T = x.size(0), pr.size(0)
+  cnt = torch.bincount(torch.cat([s, o]), minlength=O).clamp(min=1).double().view(O, 1)
+  xin, pin = x, pr
+  for l, (din, H, dout) in enumerate(dims):
+    W1a, b1a, W1b, b1b, W2a, b2a, W2b, b2b = Wd[8 * l:8 * l + 8]
+    h1m, ntm, h2m, nom = [(acts[5 * l + i].detach().cpu() > 0).double() for i in (0, 1, 3, 4)]
+    tin = torch.cat([xin[s], pin, xin[o]], 1)
+    h1 = (tin @ W1a.t() + b1a) * h1m
+    nt = (h1 @ W1b.t() + b1b) * ntm
+    pooled = torch.zeros(O, H, dtype=torch.float64).index_add(0, s, nt[:, :H]).index_add(0, o, nt[:, H + dout:])
+    if pooling == 'avg':
+      pooled = pooled / cnt
+    h2 = (pooled @ W2a.t() + b2a) * h2m
+    xin = (h2 @ W2b.t() + b2b) * nom
+    pin = nt[:, H:H + dout]
+  return xin, pin, x, pr, Wd
+
+
+def _gconv_stack_case(tag, O, T, dims, pooling, g, s=None, o=None):
+  """dims: [(din, H, dout)] per layer.  The persistent stack kernels (HF.GraphTripleConvStackFn): outputs against the
+  oracle's layer-by-layer composition; the saved `pooled` against sg2im_segment_sum over its OWN new_t (bit-exact: the
+  loader-side pool follows the reference's accumulation order); every gradient against the float64 reference of the
+  same piecewise-linear branch (_masked_stack_reference); the barrier status word."""
+  P = {}
+  for l, (din, H, dout) in enumerate(dims):
+    orc._lin(P, 'g%d.net1.0' % l, H, 3 * din, g, True); orc._lin(P, 'g%d.net1.2' % l, 2 * H + dout, H, g, True)
+    orc._lin(P, 'g%d.net2.0' % l, H, H, g, True); orc._lin(P, 'g%d.net2.2' % l, dout, H, g, True)
+  din0, dl = dims[0][0], dims[-1][2]
+  ov, pv = torch.randn(O, din0, generator=g), torch.randn(T, din0, generator=g)
+  if s is None:
+    s = torch.randint(0, O, (T,), generator=g)
+    o = torch.randint(0, O, (T,), generator=g)
+  edges = torch.stack([s, o], 1)
+  with torch.no_grad():
+    x, pr = ov, pv
+    for l, (din, H, dout) in enumerate(dims):
+      x, pr = orc.graph_triple_conv(P, 'g%d' % l, x, pr, edges, H, dout, pooling)
+  go, gp = torch.randn(O, dl, generator=g), torch.randn(T, dl, generator=g)
+  W, names = [], []
+  for l in range(len(dims)):
+    for k in ('net1.0', 'net1.2', 'net2.0', 'net2.2'):
+      W += [P['g%d.%s.weight' % (l, k)].to(D).requires_grad_(True), P['g%d.%s.bias' % (l, k)].to(D).requires_grad_(True)]
+      names += ['g%d.%s.weight' % (l, k), 'g%d.%s.bias' % (l, k)]
+  sd, od = s.to(D), o.to(D)
+  csr = ops.Csr(sd, od, O)
+  ovd, pvd = ov.to(D).requires_grad_(True), pv.to(D).requires_grad_(True)
+  assert ops.gconv_stack_supported(dims), dims
+  xd, prd = HF.GraphTripleConvStackFn.apply(ovd, pvd, sd, od, csr, pooling == 'avg', *W)
+  ops.gconv_stack_check(D)
+  report(tag + ' obj out', xd, x); report(tag + ' pred out', prd, pr)
+  # the saved activations of every layer: pooled == segment_sum(new_t) bit for bit
+  saved = xd.grad_fn.saved_tensors
+  acts = saved[4 + 8 * len(dims):]
+  for l, (din, H, dout) in enumerate(dims):
+    new_t, pooled = acts[5 * l + 1], acts[5 * l + 2]
+    want = torch.empty(O, H, device=D)
+    if T > 0:
+      ops.segment_sum(new_t[:, :H], new_t[:, H + dout:], csr, H, pooling == 'avg', want)
+    else:
+      want.zero_()
+    report(tag + ' layer %d pooled == segment_sum(new_t)' % l, pooled, want, exact=True)
+  xr, prr, ovr, pvr, Wr = _masked_stack_reference(W, dims, ov, pv, s, o, pooling, acts)
+  report(tag + ' obj out (float64, same branches)', xd, xr); report(tag + ' pred out (float64, same branches)', prd, prr)
+  (xr * go.double()).sum().add((prr * gp.double()).sum()).backward()
+  (xd * go.to(D)).sum().add((prd * gp.to(D)).sum()).backward()
+  report(tag + ' d obj', ovd.grad, ovr.grad)
+  if T > 0:
+    report(tag + ' d pred', pvd.grad, pvr.grad)
+  for i, n in enumerate(names):
+    if T > 0 or '.net2.' in n:
+      report('%s d %s' % (tag, n), W[i].grad, Wr[i].grad)
+  ops.gconv_stack_check(D)
+  if T > 0 and ops.GCN_PERSISTENT_BACKWARD:
+    # the ONE-launch backward against the layer-by-layer launches (sg2im_gconv_layer_backward) on identical activations
+    W2 = [w.detach().clone().requires_grad_(True) for w in W]
+    ov2, pv2 = ov.to(D).requires_grad_(True), pv.to(D).requires_grad_(True)
+    ops.GCN_PERSISTENT_BACKWARD = False
+    try:
+      x2, pr2 = HF.GraphTripleConvStackFn.apply(ov2, pv2, sd, od, csr, pooling == 'avg', *W2)
+      (x2 * go.to(D)).sum().add((pr2 * gp.to(D)).sum()).backward()
+    finally:
+      ops.GCN_PERSISTENT_BACKWARD = True
+    report(tag + ' one-launch vs per-layer backward: d obj', ovd.grad, ov2.grad)
+    report(tag + ' one-launch vs per-layer backward: d pred', pvd.grad, pv2.grad)
+    worst = max(((err(W[i].grad, W2[i].grad)[0], names[i]) for i in range(len(W))), key=lambda r: r[0])
+    j = names.index(worst[1])
+    report('%s one-launch vs per-layer backward: worst parameter gradient (%s)' % (tag, worst[1]), W[j].grad, W2[j].grad)
+
+
+def sec_gconv_stack():
+  g = torch.Generator().manual_seed(7)
+  batch = synthetic_batch(32, seed=3)
+  objs, triples = batch[1], batch[4]
+  # the training shape: 5 layers 128 -> 512 -> 128 on a COCO-style batch of 32 images
+  _gconv_stack_case('stack coco b32', objs.numel(), triples.size(0), [(128, 512, 128)] * 5, 'avg', g,
+                    triples[:, 0].contiguous(), triples[:, 2].contiguous())
+  # ragged sizes (rows not multiples of 32), a narrower first layer, 'sum' pooling, rows with many entries
+  _gconv_stack_case('stack ragged sum', 45, 333, [(64, 128, 96), (96, 128, 96)], 'sum', g)
+  # one object collects most entries (a long CSR row), several isolated objects
+  s = torch.randint(0, 3, (150,), generator=g); o = torch.randint(0, 3, (150,), generator=g)
+  _gconv_stack_case('stack long rows', 40, 150, [(32, 64, 32)] * 3, 'avg', g, s, o)
+  # no triples at all: every object pools to zero (net2(0))
+  _gconv_stack_case('stack no triples', 37, 0, [(32, 64, 32)] * 2, 'avg', g)
+  # one layer, more than 256 tiles per stage (several rounds over the resident grid)
+  _gconv_stack_case('stack large', 700, 2100, [(128, 512, 128)], 'avg', g)
+
+
 def sec_layout():
   sec_layout_mode(False)
 
