@@ -461,7 +461,7 @@ class GraphTripleConvStackFn(Function):
     g_obj = None if g_obj is None else g_obj.contiguous()
     if g_pred is not None and g_pred.stride(1) != 1:
       g_pred = g_pred.contiguous()
-    if T > 0 and ops.GCN_PERSISTENT_BACKWARD:
+    if T > 0 and ops.gconv_stack_backward_in_one_launch():
       # ONE persistent launch for all layers (sg2im_gconv_stack_backward)
       weights = [tuple(params[8 * l:8 * l + 8]) for l in range(nl)]
       acts = [tuple(flat_acts[5 * l:5 * l + 5]) for l in range(nl)]

@@ -552,7 +552,19 @@ def gconv_layer_backward(L, h1, new_t, pooled, h2, new_obj, g_obj, g_pred, d_tri
 
 
 GCN_PERSISTENT = os.environ.get('SG2IM_GCN_PERSIST', '1') != '0'      # (A/B knob: 0 = one call per layer)
-GCN_PERSISTENT_BACKWARD = os.environ.get('SG2IM_GCN_PERSIST_BWD', '1') != '0'   # (0: persistent forward, per-layer backward)
+# The one-launch backward needs every one of its workgroups resident at once (grid barriers).  Inside the captured
+# training iteration it would start underneath the refinement network's released weight gradients, which occupy every
+# CU: its first barrier then waits ~0.5 ms for residency and the step gets slower (8.32 vs 7.99 ms,
+# profiles/r4_gcn_persistent_backward_ab.txt).  'auto' (default): one launch when launched eagerly, layer by layer
+# inside a stream capture; '1' / '0' force it.
+_GCN_BWD = os.environ.get('SG2IM_GCN_PERSIST_BWD', 'auto')
+GCN_PERSISTENT_BACKWARD = True
+
+
+def gconv_stack_backward_in_one_launch():
+  if not GCN_PERSISTENT_BACKWARD or _GCN_BWD == '0':
+    return False
+  return _GCN_BWD == '1' or not torch.cuda.is_current_stream_capturing()
 
 
 def gconv_stack_supported(dims):
