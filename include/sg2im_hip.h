@@ -377,6 +377,16 @@ int sg2im_layout_backward(const float* dlayout, long long ld_dlayout, const floa
                           float* d_vecs, long long ld_dvecs, float* d_masks, float* d_boxes,
                           float* workspace, hipStream_t stream);
 
+/* d_vecs of the layout (the d_vecs part of sg2im_layout_backward) straight from the refinement network's PER-LEVEL
+ * layout gradients: dlevels[l] [n_images][height / factors[l]][width / factors[l]][>= dim] with row stride lds[l] is the
+ * gradient w.r.t. the layout average-pooled by factors[l] (crn.py:58-62; factors powers of two, <= 5 levels), so
+ * d layout = sum_l upsample(dlevels[l]) / factors[l]^2 - what sg2im_pyramid_backward would write - is summed on the fly
+ * and never materialised.  workspace: sg2im_layout_backward_workspace() bytes.  dim a multiple of 4. */
+int sg2im_layout_backward_vecs_levels(const float* const* dlevels, const int* factors, const long long* lds, int n_levels,
+                                      const float* boxes, const float* masks, const long long* masks_i64, int mask_size,
+                                      const int* img_row_ptr, const int* img_entries, int n_images, int n_objs, int dim,
+                                      int height, int width, int align_corners, float* d_vecs, long long ld_dvecs,
+                                      float* workspace, hipStream_t stream);
 /* Object crops for the object discriminator (sg2im/bilinear.py:28-132, 'cudnn' path):
  * crops[o] = bilinear sample of image obj_to_img[o] on linspace(2*x0-1, 2*x1-1, size).
  * imgs are NHWC [N][H][W][C] (row stride ld_img); crops NHWC [O][size][size][C]. */

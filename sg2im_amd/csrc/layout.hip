@@ -346,6 +346,100 @@ __global__ __launch_bounds__(256) void layout_bwd_vecs_kernel(const float* __res
   }
 }
 
+// The same partial sums straight from the refinement network's PER-LEVEL layout gradients (crn.py:58-62: module i
+// reads the layout average-pooled by 2^(L-1-i), so d layout = sum over levels of the level's gradient spread over
+// its f x f pixels with weight 1 / f^2).  The full-resolution d layout (67 MB at the bench shape) is never written
+// or re-read: sg2im_pyramid_backward + layout_bwd_vecs_kernel moved 89 + 67 + 67 MB, this pass reads the 89 MB of
+// level gradients once (coarse levels are re-read by the 4^k fine pixels that share them: cache hits).  float4
+// lanes along the channels, several pixels in flight per thread.
+struct GradLevels { const float* p[5]; int ld[5]; int shift[5]; float k[5]; int n; };
+
+__global__ __launch_bounds__(256) void layout_bwd_vecs_levels_kernel(GradLevels lv, const float* __restrict__ boxes, MaskRef mk,
+                                                                     const int* __restrict__ img_row_ptr,
+                                                                     const int* __restrict__ img_entries, int O, int D,
+                                                                     int H, int W, int align_corners,
+                                                                     float* __restrict__ part) {
+  __shared__ float S[BO][BP + 1];
+  __shared__ int objs[BO];
+  extern __shared__ __attribute__((aligned(16))) float red[];          // [BO][TR][TC] float4 reduction scratch
+  const int n = blockIdx.y, p0 = blockIdx.x * BP, HW = H * W;
+  const int tid = threadIdx.x;
+  const int ob = img_row_ptr[n], oe = img_row_ptr[n + 1];
+  const int Min = mk.M == 0 ? 8 : mk.M;
+  const int D4 = D >> 2;
+  const int TC = D4 < 256 ? D4 : 256, TR = 256 / TC;          // float4 lanes along channels x pixel groups
+  const int tx = tid % TC, pg = tid / TC;
+  for (int cb = ob; cb < oe; cb += BO) {
+    const int nobj = min(BO, oe - cb);
+    __syncthreads();
+    if (tid < nobj) objs[tid] = img_entries[cb + tid];
+    __syncthreads();
+    for (int e = tid; e < BO * BP; e += 256) {
+      const int oi = e / BP, pp = e - oi * BP;
+      const int px = p0 + pp;
+      float s = 0.f;
+      if (oi < nobj && px < HW) {
+        const int o = objs[oi];
+        const Foot f = footprint(boxes + 4LL * o, px / W, px % W, H, W, Min, align_corners);
+        s = sample_map(mk, o, f);
+      }
+      S[oi][pp] = s;
+    }
+    __syncthreads();
+    for (int c4 = tx; c4 < D4; c4 += TC) {
+      float4 acc[BO];
+      #pragma unroll
+      for (int k = 0; k < BO; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pg < TR) {
+        for (int pp = pg; pp < BP; pp += TR) {
+          const int px = p0 + pp;
+          if (px >= HW) break;
+          const int y = px / W, x = px - y * W;
+          float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+          #pragma unroll
+          for (int l = 0; l < 5; ++l) {
+            if (l < lv.n) {
+              const int sh = lv.shift[l];
+              const float4 v = *reinterpret_cast<const float4*>(
+                lv.p[l] + ((long long)(n * (H >> sh) + (y >> sh)) * (W >> sh) + (x >> sh)) * lv.ld[l] + 4 * c4);
+              const float kk = lv.k[l];
+              g.x += v.x * kk; g.y += v.y * kk; g.z += v.z * kk; g.w += v.w * kk;      // (pyramid_bwd_v4_kernel's sum)
+            }
+          }
+          #pragma unroll
+          for (int k = 0; k < BO; ++k) {
+            const float sv = S[k][pp];
+            acc[k].x = fmaf(g.x, sv, acc[k].x); acc[k].y = fmaf(g.y, sv, acc[k].y);
+            acc[k].z = fmaf(g.z, sv, acc[k].z); acc[k].w = fmaf(g.w, sv, acc[k].w);
+          }
+        }
+      }
+      if (TR > 1) {
+        __syncthreads();
+        #pragma unroll
+        for (int k = 0; k < BO; ++k) *reinterpret_cast<float4*>(red + 4 * ((k * TR + pg) * TC + tx)) = acc[k];
+        __syncthreads();
+        if (pg == 0) {
+          #pragma unroll
+          for (int k = 0; k < BO; ++k) {
+            float4 s = acc[k];
+            for (int t = 1; t < TR; ++t) {
+              const float4 v = *reinterpret_cast<const float4*>(red + 4 * ((k * TR + t) * TC + tx));
+              s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            acc[k] = s;
+          }
+        }
+      }
+      if (pg == 0) {
+        #pragma unroll
+        for (int k = 0; k < BO; ++k)
+          if (k < nobj) *reinterpret_cast<float4*>(part + ((long long)blockIdx.x * O + objs[k]) * D + 4 * c4) = acc[k];
+      }
+    }
+  }
+}
+
 __global__ void layout_bwd_reduce_kernel(const float* __restrict__ part, int n_tiles, int O, int D,
                                          float* __restrict__ dvecs, long long ld_dvecs) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -764,6 +858,41 @@ int sg2im_layout_backward(const float* dlayout, long long ld_dlayout, const floa
     SG2IM_LAUNCH(layout_bwd_masks_kernel, dim3(n_objs), dim3(256), 0, stream, workspace, boxes, mk, height, width,
                        align_corners, d_masks, d_boxes);
   }
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_layout_backward_vecs_levels(const float* const* dlevels, const int* factors, const long long* lds, int n_levels,
+                                      const float* boxes, const float* masks, const long long* masks_i64, int mask_size,
+                                      const int* img_row_ptr, const int* img_entries, int n_images, int n_objs, int dim,
+                                      int height, int width, int align_corners, float* d_vecs, long long ld_dvecs,
+                                      float* workspace, hipStream_t stream) {
+  if (!dlevels || !factors || !lds || n_levels < 1 || n_levels > 5 || !boxes || !img_row_ptr || !d_vecs || !workspace ||
+      dim < 4 || (dim & 3) || height < 1 || width < 1)
+    return SG2IM_ERR_ARG;
+  if (n_objs == 0) return SG2IM_OK;
+  GradLevels lv;
+  lv.n = n_levels;
+  for (int l = 0; l < 5; ++l) {
+    lv.p[l] = nullptr; lv.ld[l] = 0; lv.shift[l] = 0; lv.k[l] = 0.f;
+    if (l >= n_levels) continue;
+    const int f = factors[l];
+    if (f < 1 || (f & (f - 1)) || height % f || width % f || !dlevels[l] || (lds[l] & 3) || lds[l] < dim ||
+        ((uintptr_t)dlevels[l] & 15))
+      return SG2IM_ERR_ARG;
+    lv.p[l] = dlevels[l]; lv.ld[l] = (int)lds[l]; lv.shift[l] = __builtin_ctz((unsigned)f); lv.k[l] = 1.f / (float)(f * f);
+  }
+  const MaskRef mk{masks, masks_i64, (masks || masks_i64) ? mask_size : 0};
+  const int n_tiles = (height * width + BP - 1) / BP;
+  const size_t vec_part = sizeof(float) * (size_t)n_tiles * (size_t)n_objs * (size_t)dim;
+  if (hipMemsetAsync(workspace, 0, vec_part, stream) != hipSuccess) return SG2IM_ERR_HIP;
+  const int D4 = dim / 4, TC = D4 < 256 ? D4 : 256, TR = 256 / TC;
+  const size_t lds_bytes = sizeof(float) * 4 * (size_t)BO * TR * TC;
+  dim3 grid(n_tiles, n_images);
+  SG2IM_LAUNCH(layout_bwd_vecs_levels_kernel, grid, dim3(256), lds_bytes, stream, lv, boxes, mk, img_row_ptr, img_entries,
+                     n_objs, dim, height, width, align_corners, workspace);
+  const long long tot = (long long)n_objs * dim;
+  SG2IM_LAUNCH(layout_bwd_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, workspace, n_tiles,
+                     n_objs, dim, d_vecs, ld_dvecs);
   return ok_or(hipGetLastError());
 }
 

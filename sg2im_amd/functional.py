@@ -580,6 +580,19 @@ class LayoutFn(Function):
     d_masks = None
     if ni[2] and masks is not None and masks.is_floating_point():
       d_masks = _new(vecs, *masks.shape)
+    lazy = LAYOUT_GRAD_LEVELS.pop(g.data_ptr(), None)        # (g itself was never written: see LAYOUT_GRAD_LEVELS)
+    if lazy is not None:
+      levels, factors, Cg = lazy
+      D = vecs.size(1)
+      only_vecs = d_masks is None and d_boxes is None
+      if (only_vecs and d_vecs is not None and D % 4 == 0 and D <= Cg and
+          (g.size(1), g.size(2)) == (H, W) and all(t.size(3) % 4 == 0 for t in levels)):
+        ops.layout_backward_vecs_levels(levels, factors, vecs, boxes, masks, ctx.img_csr, n_images, H, W, ac, d_vecs)
+        return d_vecs, d_boxes, d_masks, None, None, None, None, None, None, None, None
+      if d_vecs is not None or not only_vecs:             # the summed gradient is needed as a tensor after all
+        if Cg < g.size(3):
+          g[..., Cg:].zero_()
+        ops.pyramid_backward(levels, factors, [Cg] * len(levels), g.size(0), H, W, Cg, g)
     if d_vecs is not None or d_masks is not None or d_boxes is not None:
       ops.layout_backward(g, vecs, boxes, masks, obj_to_img, ctx.img_csr, n_images, H, W, ac, d_vecs, d_masks,
                           d_boxes)
@@ -587,18 +600,39 @@ class LayoutFn(Function):
 
 
 LAYOUT_PYRAMIDS = {}      # data_ptr of a full-resolution layout -> [level 0, level 1, ...] from LayoutFn
+# Backward hand-over in the other direction: a refinement network whose layout came from LayoutFn (with its pyramid)
+# does not sum its per-level layout gradients into a full-resolution tensor - it returns an UNWRITTEN tensor of that
+# shape and leaves the levels here, keyed by its data_ptr, for LayoutFn.backward (the only consumer), which computes
+# d_vecs from the levels directly (ops.layout_backward_vecs_levels) or, when mask / box gradients are wanted too,
+# materialises the sum first.  [-(67 MB written + 67 MB re-read) per step]
+LAYOUT_GRAD_LEVELS = {}
+LAZY_LAYOUT_GRAD = True     # (A/B knob)
+
+
+def _hand_over_layout_grad(like, dlevels, N, H, W, Cg, Cl):
+  """the full-resolution d layout as LayoutFn.backward's input: lazily (see above) or summed now"""
+  lazy = LAZY_LAYOUT_GRAD and len(dlevels) <= 5 and all(f & (f - 1) == 0 for _, f in dlevels)
+  if lazy:
+    dlayout = _new(like, N, H, W, Cl)                  # never read as a tensor: LayoutFn.backward takes the levels
+    LAYOUT_GRAD_LEVELS.clear()
+    LAYOUT_GRAD_LEVELS[dlayout.data_ptr()] = ([t for t, _ in dlevels], [f for _, f in dlevels], Cg)
+    return dlayout
+  dlayout = _new(like, N, H, W, Cl) if Cg == Cl else torch.zeros(N, H, W, Cl, dtype=torch.float32, device=like.device)
+  ops.pyramid_backward([t for t, _ in dlevels], [f for _, f in dlevels], [Cg] * len(dlevels), N, H, W, Cg, dlayout)
+  return dlayout
 
 
 def _layout_pyramid(layout, L):
   """[coarsest, ..., full resolution]: the L levels a refinement network of L modules reads (crn.py:58-62 pools
   the full-resolution layout once per module; each level here is the 2 x 2 mean of the next finer one - the same
-  value up to fp32 summation order).  Levels LayoutFn already produced are taken over, the rest pooled."""
+  value up to fp32 summation order).  Levels LayoutFn already produced are taken over, the rest pooled.
+  Second result: the layout came from LayoutFn (its backward then accepts the per-level gradients, LAYOUT_GRAD_LEVELS)."""
   N, H, W, Cl = layout.shape
-  pyr = LAYOUT_PYRAMIDS.pop(layout.data_ptr(), None) or [layout]
-  pyr = pyr[:L]
+  handed = LAYOUT_PYRAMIDS.pop(layout.data_ptr(), None)
+  pyr = (handed or [layout])[:L]
   for i in range(len(pyr), L):
     pyr.append(ops.avgpool_forward(pyr[-1], 2, _new(layout, N, H >> i, W >> i, Cl)))
-  return pyr[::-1]
+  return pyr[::-1], handed is not None
 
 
 class CropFn(Function):
@@ -716,7 +750,7 @@ class RefinementFn(Function):
     # zero channel its 161 input channels would fall off the vector loaders
     feat_src = None
     saved = []
-    pyr = _layout_pyramid(layout, L)
+    pyr, ctx.layout_from_fn = _layout_pyramid(layout, L)
 
     def activated(y, st, up):
       """the source the next convolution reads: leaky(bn(y)), pending in its loader"""
@@ -860,9 +894,11 @@ class RefinementFn(Function):
       ops.DEFERRED.append(side)                    # (joined by the Trainer before the optimiser step)
     dlayout = None
     if need_layout:
-      dlayout = _new(g, N, H, W, Cl) if Cg == Cl else torch.zeros(N, H, W, Cl, dtype=torch.float32, device=g.device)
-      ops.pyramid_backward([t for t, _ in dlevels], [f for _, f in dlevels], [Cg] * len(dlevels), N, H, W, Cg,
-                           dlayout)
+      if getattr(ctx, 'layout_from_fn', False):
+        dlayout = _hand_over_layout_grad(g, dlevels, N, H, W, Cg, Cl)
+      else:
+        dlayout = _new(g, N, H, W, Cl) if Cg == Cl else torch.zeros(N, H, W, Cl, dtype=torch.float32, device=g.device)
+        ops.pyramid_backward([t for t, _ in dlevels], [f for _, f in dlevels], [Cg] * len(dlevels), N, H, W, Cg, dlayout)
     if not deferred:
       side.join()
     ctx.saved = None
@@ -886,7 +922,7 @@ class RefinementNoNormFn(Function):
       layout = layout.contiguous()
       feats = torch.zeros(N, h0, w0, 1, dtype=torch.float32, device=layout.device)   # crn.py:105
       feat_src = nhwc_src(feats, up=1)
-      pyr = _layout_pyramid(layout, L)
+      pyr, ctx.layout_from_fn = _layout_pyramid(layout, L)
       saved = []
       for i in range(L):
         h, w = H >> (L - 1 - i), W >> (L - 1 - i)
@@ -980,9 +1016,11 @@ class RefinementNoNormFn(Function):
           pool2 = 1
       dlayout = None
       if need_layout:
-        dlayout = _new(g, N, H, W, Cl) if Cg == Cl else torch.zeros(N, H, W, Cl, dtype=torch.float32, device=g.device)
-        ops.pyramid_backward([t for t, _ in dlevels], [f for _, f in dlevels], [Cg] * len(dlevels), N, H, W, Cg,
-                             dlayout)
+        if getattr(ctx, 'layout_from_fn', False):
+          dlayout = _hand_over_layout_grad(g, dlevels, N, H, W, Cg, Cl)
+        else:
+          dlayout = _new(g, N, H, W, Cl) if Cg == Cl else torch.zeros(N, H, W, Cl, dtype=torch.float32, device=g.device)
+          ops.pyramid_backward([t for t, _ in dlevels], [f for _, f in dlevels], [Cg] * len(dlevels), N, H, W, Cg, dlayout)
       ctx.saved = None
       return (dlayout, None, None, None, None) + tuple(grads)
     finally:

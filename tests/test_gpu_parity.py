@@ -175,6 +175,39 @@ def test_layout_noise_pyramid_in_one_launch_is_bit_exact(H, L, nd, masks):
   assert float(got[0][2, :, :, :Dv].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('H,L,masks', [(64, 5, 'int'), (32, 3, 'float'), (16, 1, None)])
+def test_layout_vector_gradient_straight_from_the_level_gradients(H, L, masks):
+  """sg2im_layout_backward_vecs_levels (d_vecs from the refinement network's per-level layout gradients, the summed
+  full-resolution gradient never materialised) against sg2im_pyramid_backward + sg2im_layout_backward."""
+  from sg2im_amd import ops
+  D = torch.device('cuda', 0)
+  g = torch.Generator().manual_seed(11)
+  N, Dv, Cl = 5, 128, 160
+  counts = [3, 9, 1, 0, 6]                                # an image without objects, one with more than a register pass
+  o2i = torch.cat([torch.full((c,), i, dtype=torch.long) for i, c in enumerate(counts)])
+  O = int(o2i.numel())
+  x0 = torch.rand(O, 2, generator=g) * 0.6
+  boxes = torch.cat([x0, x0 + 0.05 + torch.rand(O, 2, generator=g) * 0.35], 1).clamp(max=1.0).to(D)
+  vecs = torch.randn(O, Dv, generator=g).to(D)
+  mk = None
+  if masks == 'int':
+    mk = (torch.rand(O, 16, 16, generator=g) > 0.5).long().to(D)
+  elif masks == 'float':
+    mk = torch.rand(O, 16, 16, generator=g).to(D)
+  levels = [torch.randn(N, H >> i, H >> i, Dv, generator=g).to(D) for i in range(L)]     # (as the refinement network's: Dv channels)
+  factors = [1 << i for i in range(L)]
+  img_csr = ops.Csr(o2i.to(D), None, N)
+  summed = torch.zeros(N, H, H, Cl, device=D)
+  ops.pyramid_backward(levels, factors, [Dv] * L, N, H, H, Dv, summed)
+  want = torch.empty(O, Dv, device=D)
+  ops.layout_backward(summed, vecs, boxes, mk, o2i.to(D), img_csr, N, H, H, False, want, None, None)
+  got = torch.full((O, Dv), 7.0, device=D)
+  ops.layout_backward_vecs_levels(levels, factors, vecs, boxes, mk, img_csr, N, H, H, False, got)
+  torch.cuda.synchronize()
+  err = float((got - want).abs().max()) / max(float(want.abs().max()), 1e-30)
+  assert err <= 1e-5, err
+
+
 def test_losses_and_adam():
   _run('sec_losses')
 
