@@ -21,6 +21,7 @@ Gradient semantics (tested in tests/test_dp_gloo.py): every rank computes the re
 per-shard loss (means over ITS objects / pixels), so the applied gradient is the mean over
 ranks of the per-shard gradients - not the gradient of the concatenated batch.
 """
+import torch
 import torch.distributed as dist
 
 
@@ -60,7 +61,7 @@ def all_reduce_sum_async(tensor, group=None):
 class GradReducer(object):
   """Sum-reduces flat gradient arenas across ranks, asynchronously."""
 
-  def __init__(self, world_size=None, group=None, force=False):
+  def __init__(self, world_size=None, group=None, force=False, payload='f32'):
     if world_size is None:
       world_size = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     self.world_size = world_size
@@ -71,6 +72,14 @@ class GradReducer(object):
     # mute: skip the collectives (while a graph is being captured; bench.py's "step without the
     # exchange" timing leg)
     self.mute = False
+    # payload 'bf16' (the Trainer's choice for compute_dtype 'bf16', BASELINE configs[2..4]): the arena travels as
+    # bfloat16 - rounded (RNE) into a staging buffer, summed by RCCL in bfloat16, widened back into the fp32 arena -
+    # i.e. half the xGMI bytes (59.9 instead of 119.7 MB per step) for two extra elementwise passes over the arena;
+    # Adam's moments and the parameters stay fp32.  'f32': the arena itself is reduced in place.
+    if payload not in ('f32', 'bf16'):
+      raise ValueError('payload must be "f32" or "bf16"')
+    self.payload = payload
+    self._staging = {}               # arena data_ptr -> bfloat16 buffer of the arena's size (allocated once)
     # test instrumentation (tests/test_gpu_parity.py::test_in_graph_exchange_reduces_every_gradient_exactly_once): a
     # 1-rank SUM is the identity, so a gradient slice that is reduced twice, never, or BEFORE its last writer ran
     # would go unnoticed on a one-GPU box.  With test_gain = g every reduction is followed by an in-place x g on
@@ -93,14 +102,39 @@ class GradReducer(object):
     """SUM all-reduce of ``tensor`` ordered on the CURRENT stream (which waits for it; the collective itself
     runs on the process group's own stream) - the form that is recorded into a stream capture"""
     if (self.world_size > 1 or self.force) and not self.mute:
-      dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
+      if self.payload == 'bf16' and tensor.numel() > 1:
+        buf = self.staging(tensor)
+        buf.copy_(tensor)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        tensor.copy_(buf)
+      else:
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
       if self.test_gain is not None:
         tensor.mul_(self.test_gain)
+
+  def staging(self, tensor):
+    """the bfloat16 staging buffer of an arena (slice): one per distinct (address, size), allocated at first use -
+    for a captured iteration that is inside the capture, i.e. in the graph's private pool, like every other tensor
+    the graph creates"""
+    key = (tensor.data_ptr(), tensor.numel())
+    buf = self._staging.get(key)
+    if buf is None:
+      buf = torch.empty(tensor.numel(), dtype=torch.bfloat16, device=tensor.device)
+      self._staging[key] = buf
+    return buf
 
   def start(self, tensor):
     """begin an all-reduce (SUM) of ``tensor`` in place; returns immediately"""
     if (self.world_size > 1 or self.force) and not self.mute:
-      h = all_reduce_sum_async(tensor, self.group)
+      if self.payload == 'bf16' and tensor.numel() > 1:
+        buf = self.staging(tensor)
+        buf.copy_(tensor)
+        h = all_reduce_sum_async(buf, self.group)
+        h.wait()
+        tensor.copy_(buf)
+        h = _Done()
+      else:
+        h = all_reduce_sum_async(tensor, self.group)
       if self.test_gain is not None:
         h.wait()
         tensor.mul_(self.test_gain)

@@ -120,7 +120,8 @@ class Trainer(object):
     self.opt_g = FlatAdam(self.flat_g, lr=learning_rate)
     self.opt_do = FlatAdam(self.flat_do, lr=learning_rate) if self.d_obj is not None else None
     self.opt_di = FlatAdam(self.flat_di, lr=learning_rate) if self.d_img is not None else None
-    self.reducer = GradReducer(world_size)
+    # (bf16 mode: the gradient arenas travel as bfloat16, sg2im_amd/distributed.py; SG2IM_GRAD_PAYLOAD overrides)
+    self.reducer = GradReducer(world_size, payload=os.environ.get('SG2IM_GRAD_PAYLOAD', 'bf16' if compute_dtype == 'bf16' else 'f32'))
     if world_size > 1:
       # replicas must start from identical weights / buffers whatever the seeds were, and draw
       # different layout noise (model.py:164-168) per rank
@@ -412,6 +413,17 @@ class Trainer(object):
         ops.workspace(dev)
         ops.scratch(dev, scratch_floats)
         ops.sync_area(dev)           # (grid-barrier state of the persistent GraphTripleConv kernels)
+    if self.reducer.payload == 'bf16' and (self.world_size > 1 or self.reducer.force):
+      # the bfloat16 staging buffers of the gradient exchange: born here, not inside a capture (a buffer from one
+      # graph's private pool must not be used by the graph of another shape bucket)
+      for flat in (self.flat_g, self.flat_do, self.flat_di):
+        if flat is not None:
+          self.reducer.staging(flat.grad)
+      bucket = self._generator_bucket()
+      if bucket is not None:
+        a, b, _ = bucket
+        for sl in (self.flat_g.grad[a:b], self.flat_g.grad[:a], self.flat_g.grad[b:]):
+          self.reducer.staging(sl)
     ops.unit(dev)                    # (cached process-wide: must not be born inside a capture)
     ops.marks_init(dev)
 

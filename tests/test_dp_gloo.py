@@ -68,6 +68,22 @@ def _worker(rank, world, port, ret):
       if k in mine:
         mean = sum(w[k] for w in want) / world
         worst = max(worst, float((p.grad * red.grad_scale - mean).abs().max()))
+    # the same exchange with the bfloat16 payload (GradReducer(payload='bf16'): what the bf16 training mode sends):
+    # every element within bfloat16 rounding of the exact mean - of each rank's value (2^-9 relative) and of the sum
+    for k, p in module.named_parameters():
+      if k in mine:
+        p.grad.copy_(mine[k])
+    redh = GradReducer(payload='bf16')
+    redh.start(flat.grad)
+    redh.start(guard.clone())             # (a one-element tensor - the NaN guard - travels as it is)
+    redh.finish()
+    worst_h = 0.0
+    for k, p in module.named_parameters():
+      if k in mine:
+        mean = sum(w[k] for w in want) / world
+        bound = sum(w[k].abs() for w in want) / world * 2.0 ** -7 + 1e-12
+        worst_h = max(worst_h, float(((p.grad * redh.grad_scale - mean).abs() / bound).max()))
+    assert flat.grad.dtype == torch.float32 and worst_h <= 1.0, worst_h
     ret[rank] = (worst, bool(torch.isfinite(guard).all()))
     # shard_batch on the 4-image synthetic batch gives each rank 2 whole images
     from sg2im_amd.synthetic import synthetic_batch

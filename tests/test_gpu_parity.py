@@ -527,6 +527,20 @@ def test_in_graph_exchange_reduces_every_gradient_exactly_once():
             schedule, name, int((scaled != want).sum()), want.numel(), sorted(set(ratio.round(decimals=3).tolist()))[:6]))
       hh.assert_grad_parity(tr, otr, 'dp schedule %d, 1 rank RCCL, test gain 2' % schedule, scale=tr.reducer.grad_scale)
       assert torch.equal(tr.flat_g.flat, plain.flat_g.flat)      # (and the Adam update saw the same gradient)
+    # the bfloat16 payload of the bf16 training mode (GradReducer(payload='bf16')) through the in-graph exchange:
+    # every element is the plain gradient rounded to bfloat16 once (RNE), nothing else
+    os.environ['SG2IM_GRAD_PAYLOAD'] = 'bf16'
+    try:
+      tr = make(world_size=1, use_graphs=True, dp_schedule=2)
+    finally:
+      del os.environ['SG2IM_GRAD_PAYLOAD']
+    assert tr.reducer.payload == 'bf16'
+    tr.reducer.force, tr.reducer.test_gain = True, 2.0
+    tr.step(batch)
+    torch.cuda.synchronize()
+    for name, got, want in (('G', tr.flat_g.grad, plain.flat_g.grad), ('Do', tr.flat_do.grad, plain.flat_do.grad),
+                            ('Di', tr.flat_di.grad, plain.flat_di.grad)):
+      assert torch.equal(got * tr.reducer.grad_scale, want.bfloat16().float()), name
   finally:
     dist.destroy_process_group()
 
