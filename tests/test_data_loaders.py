@@ -232,3 +232,25 @@ def test_train_script_on_real_coco_loaders(tmp_path):
   ck = torch.load(os.path.join(out, 'checkpoint_with_model.pt'), map_location='cpu', weights_only=False)
   assert ck['vocab']['object_name_to_idx']['sky'] == 92 and ck['counters']['t'] == 6 and ck['counters']['epoch'] >= 2
   assert len(ck['val_losses']['bbox_pred']) == 1 and ck['model_state'] is not None
+  # scripts/sample_images.py (reference scripts/sample_images.py) on that checkpoint and the same files: predicted
+  # boxes / masks, then ground-truth boxes + masks with the GT images saved
+  samples = str(tmp_path / 'samples')
+  base = [sys.executable, os.path.join(root, 'scripts', 'sample_images.py'), '--checkpoint', os.path.join(out, 'checkpoint_with_model.pt'),
+          '--dataset', 'coco', '--batch_size', '4', '--num_samples', '6', '--loader_num_workers', '0',
+          '--coco_image_dir', p['image_dir'], '--instances_json', p['instances_json'], '--stuff_json', p['stuff_json']]
+  for extra, sub in (([], 'pred'), (['--use_gt_boxes', '1', '--use_gt_masks', '1', '--save_gt_imgs', '1'], 'gt')):
+    r = subprocess.run(base + ['--output_dir', os.path.join(samples, sub)] + extra, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    data = torch.load(os.path.join(samples, sub, 'data.pt'), map_location='cpu', weights_only=False)
+    n = len(data['filenames'])
+    assert n == 6 and data['filenames'][0] == '0000.png' and data['vocab']['object_name_to_idx']['sky'] == 92
+    assert all(len(data[k]) == n for k in ('objs', 'boxes_pred', 'boxes_gt', 'masks_pred', 'masks_gt'))
+    for i in range(n):
+      k = data['objs'][i].numel()
+      assert data['boxes_pred'][i].shape == (k, 4) and data['boxes_gt'][i].shape == (k, 4)
+      assert data['masks_pred'][i].shape == (k, 16, 16) and data['masks_gt'][i].shape == (k, 16, 16)
+      assert int(data['objs'][i][-1]) == 0                  # (the __image__ object closes every image)
+      assert os.path.isfile(os.path.join(samples, sub, 'images', data['filenames'][i]))
+    assert os.path.isdir(os.path.join(samples, sub, 'images_gt')) == (sub == 'gt')
+    import PIL.Image
+    assert PIL.Image.open(os.path.join(samples, sub, 'images', '0003.png')).size == (64, 64)
