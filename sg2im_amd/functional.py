@@ -606,7 +606,8 @@ LAYOUT_PYRAMIDS = {}      # data_ptr of a full-resolution layout -> [level 0, le
 # d_vecs from the levels directly (ops.layout_backward_vecs_levels) or, when mask / box gradients are wanted too,
 # materialises the sum first.  [-(67 MB written + 67 MB re-read) per step]
 LAYOUT_GRAD_LEVELS = {}
-LAZY_LAYOUT_GRAD = True     # (A/B knob)
+import os as _os
+LAZY_LAYOUT_GRAD = _os.environ.get('SG2IM_LAZY_LAYOUT_GRAD', '1') != '0'     # (A/B knob)
 
 
 def _hand_over_layout_grad(like, dlevels, N, H, W, Cg, Cl):

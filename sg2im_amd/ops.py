@@ -555,16 +555,14 @@ GCN_PERSISTENT = os.environ.get('SG2IM_GCN_PERSIST', '1') != '0'      # (A/B kno
 # The one-launch backward needs every one of its workgroups resident at once (grid barriers).  Inside the captured
 # training iteration it would start underneath the refinement network's released weight gradients, which occupy every
 # CU: its first barrier then waits ~0.5 ms for residency and the step gets slower (8.32 vs 7.99 ms,
-# profiles/r4_gcn_persistent_backward_ab.txt).  'auto' (default): one launch when launched eagerly, layer by layer
-# inside a stream capture; '1' / '0' force it.
-_GCN_BWD = os.environ.get('SG2IM_GCN_PERSIST_BWD', 'auto')
-GCN_PERSISTENT_BACKWARD = True
+# profiles/r4_gcn_persistent_backward_ab.txt).  Default therefore: layer by layer (sg2im_gconv_layer_backward) -
+# in eager mode too, so that eager and replayed iterations stay bit-identical; SG2IM_GCN_PERSIST_BWD=1 selects the
+# one-launch form (standalone 419 us for the five layers, tested against the layer-by-layer form in sec_gconv_stack).
+GCN_PERSISTENT_BACKWARD = os.environ.get('SG2IM_GCN_PERSIST_BWD', '0') == '1'
 
 
 def gconv_stack_backward_in_one_launch():
-  if not GCN_PERSISTENT_BACKWARD or _GCN_BWD == '0':
-    return False
-  return _GCN_BWD == '1' or not torch.cuda.is_current_stream_capturing()
+  return GCN_PERSISTENT_BACKWARD
 
 
 def gconv_stack_supported(dims):

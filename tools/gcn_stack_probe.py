@@ -85,7 +85,7 @@ us_on = bwd_bench(True)
 ops.gconv_stack_check(D)
 stb = ops.gconv_stack_stamps(D)
 us_off = bwd_bench(False)
-ops.GCN_PERSISTENT_BACKWARD = True
+ops.GCN_PERSISTENT_BACKWARD = False
 print('forward + backward, one launch each: %.1f us; forward one launch + backward layer by layer: %.1f us (eager, incl. host)' % (us_on, us_off))
 names = []
 for l in range(nl - 1, -1, -1):

@@ -512,6 +512,7 @@ def _gconv_stack_case(tag, O, T, dims, pooling, g, s=None, o=None):
   csr = ops.Csr(sd, od, O)
   ovd, pvd = ov.to(D).requires_grad_(True), pv.to(D).requires_grad_(True)
   assert ops.gconv_stack_supported(dims), dims
+  keep_bwd, ops.GCN_PERSISTENT_BACKWARD = ops.GCN_PERSISTENT_BACKWARD, True      # (the one-launch backward is what is checked)
   xd, prd = HF.GraphTripleConvStackFn.apply(ovd, pvd, sd, od, csr, pooling == 'avg', *W)
   ops.gconv_stack_check(D)
   report(tag + ' obj out', xd, x); report(tag + ' pred out', prd, pr)
@@ -537,8 +538,8 @@ def _gconv_stack_case(tag, O, T, dims, pooling, g, s=None, o=None):
     if T > 0 or '.net2.' in n:
       report('%s d %s' % (tag, n), W[i].grad, Wr[i].grad)
   ops.gconv_stack_check(D)
-  if T > 0 and ops.GCN_PERSISTENT_BACKWARD:
-    # the ONE-launch backward against the layer-by-layer launches (sg2im_gconv_layer_backward) on identical activations
+  if T > 0:
+    # the layer-by-layer launches (sg2im_gconv_layer_backward) on identical activations against the one-launch form
     W2 = [w.detach().clone().requires_grad_(True) for w in W]
     ov2, pv2 = ov.to(D).requires_grad_(True), pv.to(D).requires_grad_(True)
     ops.GCN_PERSISTENT_BACKWARD = False
@@ -546,12 +547,13 @@ def _gconv_stack_case(tag, O, T, dims, pooling, g, s=None, o=None):
       x2, pr2 = HF.GraphTripleConvStackFn.apply(ov2, pv2, sd, od, csr, pooling == 'avg', *W2)
       (x2 * go.to(D)).sum().add((pr2 * gp.to(D)).sum()).backward()
     finally:
-      ops.GCN_PERSISTENT_BACKWARD = True
+      ops.GCN_PERSISTENT_BACKWARD = keep_bwd
     report(tag + ' one-launch vs per-layer backward: d obj', ovd.grad, ov2.grad)
     report(tag + ' one-launch vs per-layer backward: d pred', pvd.grad, pv2.grad)
     worst = max(((err(W[i].grad, W2[i].grad)[0], names[i]) for i in range(len(W))), key=lambda r: r[0])
     j = names.index(worst[1])
     report('%s one-launch vs per-layer backward: worst parameter gradient (%s)' % (tag, worst[1]), W[j].grad, W2[j].grad)
+  ops.GCN_PERSISTENT_BACKWARD = keep_bwd
 
 
 def sec_gconv_stack():
