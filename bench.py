@@ -280,6 +280,27 @@ def main():
           key, st[-1], ' '.join('%.1f/%.1f' % (st[i] - st[i - 1], st[i + 1] - st[i]) for i in range(1, n - 1, 2))), file=sys.stderr)
   launch_stats = dict(trainer.launch_stats)
   n_graphs = len(trainer._graphs)
+  # the persistent GraphTripleConv forward of the LAST replayed iteration: workgroup 0's device-clock stamps
+  # (kernel start, before / after every grid barrier, end) - latency-bound, reported in us
+  gcn_stack = None
+  try:
+    from sg2im_amd import ops as _ops2
+    for key in list(_ops2._sync_areas):
+      if key[0] != (device.index or 0):
+        continue
+      with torch.cuda.device(device):
+        host = _ops2._sync_areas[key].cpu().contiguous()
+      import ctypes as _ct
+      from sg2im_amd import _lib as _l2
+      buf = (_ct.c_ulonglong * 256)()
+      n = _l2.load().sg2im_gconv_stack_stamps(_ct.c_void_p(host.data_ptr()), _ct.cast(buf, _ct.c_void_p), 256)
+      if n > 2:
+        st_ = [(buf[i] - buf[0]) / 100.0 for i in range(n)]
+        gcn_stack = {'kernel': 'gcn_stack_fwd_kernel (one persistent launch for all GraphTripleConv layers)',
+                     'us': round(st_[-1], 1), 'stages': (n - 2) // 2 + 1, 'grid_barriers': (n - 2) // 2,
+                     'barrier_wait_us_workgroup0': round(sum(st_[i + 1] - st_[i] for i in range(1, n - 1, 2)), 1)}
+  except Exception:
+    gcn_stack = None
 
   comm = None
   if use_dist:
@@ -397,6 +418,7 @@ def main():
                         'gb_per_s': round(v['flops'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] > 0 else 0.0,
                         'frac_of_8TBps': round(v['flops'] / (v['ms'] * 1e-3) / 8e12, 4) if v['ms'] > 0 else 0.0}
                     for k, v in hbm.items()},
+      'latency_bound': {'gcn_stack_forward': gcn_stack},
       'by_kind': {k: {'launches_per_step': v['launches'] // n_prof, 'gflop_per_step': round(v['flops'] / n_prof / 1e9, 1),
                       'ms_per_step': round(v['ms'] / n_prof, 3),
                       'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else 0.0}

@@ -548,6 +548,14 @@ int sg2im_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
 int sg2im_adam_step_guarded(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                             long long n, float lr, float beta1, float beta2, float eps,
                             float grad_scale, float* state, const float* guard, hipStream_t stream);
+/* The same in two calls: prepare (once per optimiser step: advances state[0], sets the bias corrections and the
+ * "applied" flag - or marks the step skipped when guard[0] is not finite) and apply (the update of ANY slice
+ * [param, param + n) of the arena, in any order, on any stream ordered after the prepare) - so that a part of the arena
+ * whose gradients are complete early can be updated while the rest of the backward pass is still running. */
+int sg2im_adam_prepare_guarded(float lr, float beta1, float beta2, float* state, const float* guard, hipStream_t stream);
+int sg2im_adam_apply_guarded(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
+                             float beta1, float beta2, float eps, float grad_scale, const float* state,
+                             hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -160,6 +160,8 @@ _SIGNATURES = {
   'sg2im_sum_scalars': [_P, _I, _P, _P],
   'sg2im_adam_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
   'sg2im_adam_step_guarded': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P, _P],
+  'sg2im_adam_prepare_guarded': [_F, _F, _F, _P, _P, _P],
+  'sg2im_adam_apply_guarded': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P],
 }
 _RESTYPE = {'sg2im_layout_backward_workspace': c_size_t, 'sg2im_crop_backward_workspace': c_size_t,
             'sg2im_launch_count': ctypes.c_ulonglong, 'sg2im_gconv_layer_backward_scratch': c_size_t,

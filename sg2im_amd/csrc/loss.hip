@@ -304,3 +304,25 @@ extern "C" int sg2im_adam_step_guarded(float* param, const float* grad, float* e
   }
   return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
 }
+
+// The two halves of sg2im_adam_step_guarded as separate calls: sg2im_adam_prepare_guarded advances the step counter /
+// bias corrections in `state` once per optimiser step (or marks the step as skipped), sg2im_adam_apply_guarded applies
+// the update to ANY slice of the arena - a part of the arena whose gradients are complete early can then be updated
+// while the rest of the backward pass is still running.
+extern "C" int sg2im_adam_prepare_guarded(float lr, float beta1, float beta2, float* state, const float* guard,
+                                          hipStream_t stream) {
+  if (!state) return SG2IM_ERR_ARG;
+  SG2IM_LAUNCH(sg2im::adam_prepare_kernel, dim3(1), dim3(64), 0, stream, state, guard, lr, beta1, beta2);
+  return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+}
+
+extern "C" int sg2im_adam_apply_guarded(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
+                                        float beta1, float beta2, float eps, float grad_scale, const float* state,
+                                        hipStream_t stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !state || n < 0) return SG2IM_ERR_ARG;
+  if (n == 0) return SG2IM_OK;
+  const int blocks = (int)std::min<long long>((n + 255) / 256, 16384);
+  SG2IM_LAUNCH(sg2im::adam_guarded_kernel, dim3(blocks), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, n,
+                     1.f - beta1, beta2, 1.f - beta2, state, eps, grad_scale);
+  return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+}

@@ -73,6 +73,8 @@ DEFERRED = None
 # the weight-gradient stream right after the LAST of them was issued (never, if one of them is not among the released
 # launches - the Trainer then exchanges the arena as one bucket).
 AFTER_DEFERRED = None
+# callback(stream): called on the weight-gradient stream after the LAST released weight gradient was issued
+AFTER_ALL_DEFERRED = None
 HINT_BACKGROUND = 1
 # only the first BG_COUNT released weight gradients are issued as background launches (occupancy cap): the later
 # ones run after the small-kernel tail is over and may have the whole GPU
@@ -193,6 +195,8 @@ class SideLane(object):
       mark('wgrad_lane_start')
       release_deferred(self.queue, self.side)
       mark('wgrad_lane_done')
+      if AFTER_ALL_DEFERRED is not None:
+        AFTER_ALL_DEFERRED(self.side)
     self.queue = []
     self.used = True
 
@@ -1072,6 +1076,17 @@ def scale_by_scalar(x, a_dev, out):
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale=1.0):
   call('sg2im_adam_step', _f(param), _f(grad), _f(exp_avg), _f(exp_avg_sq), param.numel(), float(lr),
        float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _stream())
+
+
+def adam_prepare_guarded(lr, beta1, beta2, state, guard):
+  call('sg2im_adam_prepare_guarded', float(lr), float(beta1), float(beta2), _f(state), _f(guard), _stream())
+
+
+def adam_apply_guarded(param, grad, exp_avg, exp_avg_sq, beta1, beta2, eps, state, grad_scale=1.0):
+  """the update of a slice of the arena (after adam_prepare_guarded of the same step)"""
+  _timed('hbm_adam', 28.0 * param.numel(), lambda: call(
+    'sg2im_adam_apply_guarded', _f(param), _f(grad), _f(exp_avg), _f(exp_avg_sq), param.numel(), float(beta1), float(beta2),
+    float(eps), float(grad_scale), _f(state), _stream()))
 
 
 def adam_step_guarded(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, state, guard, grad_scale=1.0):

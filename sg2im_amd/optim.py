@@ -111,6 +111,17 @@ class FlatAdam(object):
     ops.adam_step_guarded(self.flat.flat, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0],
                           self.betas[1], self.eps, self.state, guard, grad_scale)
 
+  def prepare_guarded(self, guard):
+    """first half of step_guarded: the step counter / bias corrections (or the skip flag) of THIS step"""
+    ops.adam_prepare_guarded(self.lr, self.betas[0], self.betas[1], self.state, guard)
+
+  def apply_guarded(self, lo, hi, grad_scale=1.0):
+    """second half, for the arena slice [lo, hi): may be called for disjoint slices at different times / on
+    different streams, each ordered after prepare_guarded and after the slice's gradients are complete"""
+    if hi > lo:
+      ops.adam_apply_guarded(self.flat.flat[lo:hi], self.flat.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
+                             self.betas[0], self.betas[1], self.eps, self.state, grad_scale)
+
   def _steps_taken(self):
     # the guarded path counts on the device (a skipped non-finite step does not count)
     return max(int(self.t), int(round(float(self.state[0].item()))))

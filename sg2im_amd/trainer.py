@@ -67,6 +67,19 @@ def generator_bucket(model, flat_g):
   return a, b, ids
 
 
+def refinement_slice(model, flat_g):
+  """(begin, end) of the refinement network's parameters in the generator's arena, None when they are not one
+  contiguous run"""
+  ps = {id(p) for p in model.refinement_net.parameters()}
+  offs = [(off, p.numel()) for p, off in zip(flat_g.params, flat_g.offsets) if id(p) in ps]
+  if not offs:
+    return None
+  a = min(o for o, _ in offs)
+  b = max(o + (n + 3) // 4 * 4 for o, n in offs)
+  inside = sum(1 for p, off in zip(flat_g.params, flat_g.offsets) if a <= off < b)
+  return (a, min(b, flat_g.numel)) if inside == len(ps) else None
+
+
 class Trainer(object):
   def __init__(self, vocab, device, generator_kwargs=None, d_obj_kwargs=None, d_img_kwargs=None,
                loss_weights=None, learning_rate=1e-4, world_size=1, seed=None, use_graphs=False,
@@ -317,7 +330,15 @@ class Trainer(object):
     # all three updates at the end: same values as the reference's in-order updates because
     # no forward/backward above reads another network's *updated* parameters
     gs, guard = self.reducer.grad_scale, st['guard']
-    self.opt_g.step_guarded(guard, gs)
+    early = st.get('g_adam_early')
+    if early is not None:            # (captured iteration: [a, b) was updated under the weight gradients already)
+      self.opt_g.apply_guarded(0, early[0], gs)
+      self.opt_g.apply_guarded(early[1], self.flat_g.numel, gs)
+    else:
+      if st.get('g_adam_prepared'):
+        self.opt_g.apply_guarded(0, self.flat_g.numel, gs)
+      else:
+        self.opt_g.step_guarded(guard, gs)
     if self.opt_do is not None:
       self.opt_do.step_guarded(guard, gs)
     if self.opt_di is not None:
@@ -630,10 +651,29 @@ class Trainer(object):
           reduce_after(stream, self.flat_g.grad[a:b])
           sent.append(True)
         ops.AFTER_DEFERRED = (ids, early)
+      # One GPU: the Adam update of the refinement network's parameters (3/4 of the generator) at the END OF THE
+      # WEIGHT-GRADIENT LANE, right behind its last weight gradient - every gradient of that slice is complete there
+      # (convolutions: the lane itself; BatchNorm: the data-gradient chain the release waited for) - while the main
+      # lane finishes the graph-convolution / embedding backward; only the rest is left for the final update.  No new
+      # stream or fork / join edge (an update on a stream of its own, under the remaining weight gradients, re-mapped
+      # the branches onto the hardware queues and cost 0.7 ms: profiles/r4_early_adam_ab.txt).  Same values: the
+      # update is element-wise (optim.FlatAdam.apply_guarded).
+      early_adam = not dp and not ops.SINGLE_STREAM and ops.DEFER_WGRAD and os.environ.get('SG2IM_EARLY_ADAM', '1') != '0'
+      crn = refinement_slice(self.model, self.flat_g) if early_adam else None
+      if crn is not None:
+        a, b = crn
+        self.opt_g.prepare_guarded(st['guard'])        # (main stream: the release fork orders it before the lane)
+        st['g_adam_prepared'] = True
+
+        def early_update(stream):
+          self.opt_g.apply_guarded(a, b, self.reducer.grad_scale)     # (current stream = the weight-gradient lane)
+          st['g_adam_early'] = (a, b)
+        ops.AFTER_ALL_DEFERRED = early_update
       try:
         self._seg_generator_backward(st)
       finally:
         ops.AFTER_DEFERRED = None
+        ops.AFTER_ALL_DEFERRED = None
       if ingraph:
         if sent:
           reduce_after(main, self.flat_g.grad[:a], self.flat_g.grad[b:])

@@ -1,0 +1,10 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+for e in 0 1 0 1; do
+  SG2IM_EARLY_ADAM=$e SG2IM_MARKS=1 timeout 600 python bench.py --steps 40 --warmup 10 --cpu_baseline_steps 0 --no_roofline 2> gpurun_out/r4_call15_ea$e.err | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('early adam=$e', d['ms_per_step'], d['value'])"
+  grep -h "crn_bwd_done\|wgrad_lane_done\|g_bwd_done\|adam_done" gpurun_out/r4_call15_ea$e.err | tr '\n' ' '; echo
+done
+timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -k "trainer_two_steps or graph_replay_matches or bit_reproducible or padded_batch_step or eval_mode_step" 2>&1 | tail -3
