@@ -41,6 +41,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#define SG2IM_GEMM_TU            // (a launch of this file counts as an implicit-GEMM-family launch)
 #include "launch_count.h"
 #include "gcn_persist.h"
 #include "sg2im_hip.h"

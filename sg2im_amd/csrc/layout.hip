@@ -354,86 +354,111 @@ __global__ __launch_bounds__(256) void layout_bwd_vecs_kernel(const float* __res
 // lanes along the channels, several pixels in flight per thread.
 struct GradLevels { const float* p[5]; int ld[5]; int shift[5]; float k[5]; int n; };
 
+constexpr int BOL = 16;     // objects per register pass of the level-gradient form (an image rarely has more)
+constexpr int BPL = 256;    // pixels per workgroup of the level-gradient form (128 KB of level-0 gradient at 128 channels)
+
 __global__ __launch_bounds__(256) void layout_bwd_vecs_levels_kernel(GradLevels lv, const float* __restrict__ boxes, MaskRef mk,
                                                                      const int* __restrict__ img_row_ptr,
                                                                      const int* __restrict__ img_entries, int O, int D,
                                                                      int H, int W, int align_corners,
                                                                      float* __restrict__ part) {
-  __shared__ float S[BO][BP + 1];
-  __shared__ int objs[BO];
-  extern __shared__ __attribute__((aligned(16))) float red[];          // [BO][TR][TC] float4 reduction scratch
-  const int n = blockIdx.y, p0 = blockIdx.x * BP, HW = H * W;
+  __shared__ float S[BOL][BPL + 1];
+  __shared__ int objs[BOL];
+  extern __shared__ __attribute__((aligned(16))) float red[];          // [8][TR][TC] float4 reduction scratch
+  const int n = blockIdx.y, p0 = blockIdx.x * BPL, HW = H * W;
   const int tid = threadIdx.x;
   const int ob = img_row_ptr[n], oe = img_row_ptr[n + 1];
   const int Min = mk.M == 0 ? 8 : mk.M;
   const int D4 = D >> 2;
   const int TC = D4 < 256 ? D4 : 256, TR = 256 / TC;          // float4 lanes along channels x pixel groups
   const int tx = tid % TC, pg = tid / TC;
-  for (int cb = ob; cb < oe; cb += BO) {
-    const int nobj = min(BO, oe - cb);
+  for (int cb = ob; cb < oe; cb += BOL) {
+    const int nobj = min(BOL, oe - cb);
     __syncthreads();
     if (tid < nobj) objs[tid] = img_entries[cb + tid];
     __syncthreads();
-    for (int e = tid; e < BO * BP; e += 256) {
-      const int oi = e / BP, pp = e - oi * BP;
+    for (int e = tid; e < nobj * BPL; e += 256) {
+      const int oi = e / BPL, pp = e - oi * BPL;
       const int px = p0 + pp;
       float s = 0.f;
-      if (oi < nobj && px < HW) {
+      if (px < HW) {
         const int o = objs[oi];
         const Foot f = footprint(boxes + 4LL * o, px / W, px % W, H, W, Min, align_corners);
         s = sample_map(mk, o, f);
       }
       S[oi][pp] = s;
     }
+    for (int e = nobj * BPL + tid; e < BOL * BPL; e += 256) S[e / BPL][e % BPL] = 0.f;       // (unused object slots)
     __syncthreads();
     for (int c4 = tx; c4 < D4; c4 += TC) {
-      float4 acc[BO];
+      float4 acc[BOL];
       #pragma unroll
-      for (int k = 0; k < BO; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < BOL; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (pg < TR) {
-        for (int pp = pg; pp < BP; pp += TR) {
-          const int px = p0 + pp;
-          if (px >= HW) break;
-          const int y = px / W, x = px - y * W;
-          float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        // this thread's pixels pg, pg + TR, ... in groups of 8: per group, level by level, the 8 loads of a level are
+        // issued back to back (a pixel-by-pixel loop would wait for every pixel's loads in turn)
+        for (int pb = pg; pb < BPL; pb += 8 * TR) {
+          float4 g[8];
+          #pragma unroll
+          for (int i = 0; i < 8; ++i) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
           #pragma unroll
           for (int l = 0; l < 5; ++l) {
             if (l < lv.n) {
               const int sh = lv.shift[l];
-              const float4 v = *reinterpret_cast<const float4*>(
-                lv.p[l] + ((long long)(n * (H >> sh) + (y >> sh)) * (W >> sh) + (x >> sh)) * lv.ld[l] + 4 * c4);
               const float kk = lv.k[l];
-              g.x += v.x * kk; g.y += v.y * kk; g.z += v.z * kk; g.w += v.w * kk;      // (pyramid_bwd_v4_kernel's sum)
+              const float* const base = lv.p[l] + 4 * c4;
+              const int hl = H >> sh, wl = W >> sh, ldl = lv.ld[l];
+              float4 v[8];
+              #pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                const int px = min(p0 + pb + i * TR, HW - 1);
+                const int y = px / W, x = px - y * W;
+                v[i] = *reinterpret_cast<const float4*>(base + ((long long)(n * hl + (y >> sh)) * wl + (x >> sh)) * ldl);
+              }
+              #pragma unroll
+              for (int i = 0; i < 8; ++i) {          // (pyramid_bwd_v4_kernel's sum: level 0 first)
+                g[i].x += v[i].x * kk; g[i].y += v[i].y * kk; g[i].z += v[i].z * kk; g[i].w += v[i].w * kk;
+              }
             }
           }
           #pragma unroll
-          for (int k = 0; k < BO; ++k) {
-            const float sv = S[k][pp];
-            acc[k].x = fmaf(g.x, sv, acc[k].x); acc[k].y = fmaf(g.y, sv, acc[k].y);
-            acc[k].z = fmaf(g.z, sv, acc[k].z); acc[k].w = fmaf(g.w, sv, acc[k].w);
+          for (int i = 0; i < 8; ++i) {
+            const int pp = pb + i * TR;
+            if (pp < BPL && p0 + pp < HW) {
+              #pragma unroll
+              for (int k = 0; k < BOL; ++k) {
+                const float sv = S[k][pp];
+                acc[k].x = fmaf(g[i].x, sv, acc[k].x); acc[k].y = fmaf(g[i].y, sv, acc[k].y);
+                acc[k].z = fmaf(g[i].z, sv, acc[k].z); acc[k].w = fmaf(g[i].w, sv, acc[k].w);
+              }
+            }
           }
         }
       }
       if (TR > 1) {
-        __syncthreads();
+        // the TR pixel groups' partials through LDS, eight objects at a time (32 KB), added in group order
         #pragma unroll
-        for (int k = 0; k < BO; ++k) *reinterpret_cast<float4*>(red + 4 * ((k * TR + pg) * TC + tx)) = acc[k];
-        __syncthreads();
-        if (pg == 0) {
+        for (int kh = 0; kh < BOL; kh += 8) {
+          if (kh >= nobj) break;                       // (workgroup-uniform)
+          __syncthreads();
           #pragma unroll
-          for (int k = 0; k < BO; ++k) {
-            float4 s = acc[k];
-            for (int t = 1; t < TR; ++t) {
-              const float4 v = *reinterpret_cast<const float4*>(red + 4 * ((k * TR + t) * TC + tx));
-              s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+          for (int k = 0; k < 8; ++k) *reinterpret_cast<float4*>(red + 4 * ((k * TR + pg) * TC + tx)) = acc[kh + k];
+          __syncthreads();
+          for (int e = tid; e < 8 * TC; e += 256) {
+            const int k = e / TC, t4 = e - k * TC;
+            if (kh + k < nobj && t4 + (c4 - tx) < D4) {
+              float4 sum = *reinterpret_cast<const float4*>(red + 4 * ((k * TR) * TC + t4));
+              for (int t = 1; t < TR; ++t) {
+                const float4 v = *reinterpret_cast<const float4*>(red + 4 * ((k * TR + t) * TC + t4));
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+              }
+              *reinterpret_cast<float4*>(part + ((long long)blockIdx.x * O + objs[kh + k]) * D + 4 * (t4 + (c4 - tx))) = sum;
             }
-            acc[k] = s;
           }
         }
-      }
-      if (pg == 0) {
+      } else {
         #pragma unroll
-        for (int k = 0; k < BO; ++k)
+        for (int k = 0; k < BOL; ++k)
           if (k < nobj) *reinterpret_cast<float4*>(part + ((long long)blockIdx.x * O + objs[k]) * D + 4 * c4) = acc[k];
       }
     }
@@ -882,11 +907,11 @@ int sg2im_layout_backward_vecs_levels(const float* const* dlevels, const int* fa
     lv.p[l] = dlevels[l]; lv.ld[l] = (int)lds[l]; lv.shift[l] = __builtin_ctz((unsigned)f); lv.k[l] = 1.f / (float)(f * f);
   }
   const MaskRef mk{masks, masks_i64, (masks || masks_i64) ? mask_size : 0};
-  const int n_tiles = (height * width + BP - 1) / BP;
+  const int n_tiles = (height * width + BPL - 1) / BPL;
   const size_t vec_part = sizeof(float) * (size_t)n_tiles * (size_t)n_objs * (size_t)dim;
   if (hipMemsetAsync(workspace, 0, vec_part, stream) != hipSuccess) return SG2IM_ERR_HIP;
   const int D4 = dim / 4, TC = D4 < 256 ? D4 : 256, TR = 256 / TC;
-  const size_t lds_bytes = sizeof(float) * 4 * (size_t)BO * TR * TC;
+  const size_t lds_bytes = sizeof(float) * 4 * (size_t)8 * TR * TC;
   dim3 grid(n_tiles, n_images);
   SG2IM_LAUNCH(layout_bwd_vecs_levels_kernel, grid, dim3(256), lds_bytes, stream, lv, boxes, mk, img_row_ptr, img_entries,
                      n_objs, dim, height, width, align_corners, workspace);
