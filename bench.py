@@ -341,9 +341,10 @@ def main():
       trainer._graphs.clear()
     step_ms = elapsed / args.steps * 1e3
     exposed = max(0.0, step_ms - nocomm_ms)
-    payload = 4.0 * (trainer.flat_g.grad.numel() + (trainer.flat_di.grad.numel() if trainer.flat_di is not None else 0) +
-                     (trainer.flat_do.grad.numel() if trainer.flat_do is not None else 0))
-    comm = {'allreduce_ms': round(ar_ms, 3), 'payload_mb': round(payload / 1e6, 1),
+    payload = (2.0 if trainer.reducer.payload == 'bf16' else 4.0) * (
+      trainer.flat_g.grad.numel() + (trainer.flat_di.grad.numel() if trainer.flat_di is not None else 0) +
+      (trainer.flat_do.grad.numel() if trainer.flat_do is not None else 0))
+    comm = {'allreduce_ms': round(ar_ms, 3), 'payload_mb': round(payload / 1e6, 1), 'payload_dtype': trainer.reducer.payload,
             'allreduce_bus_gb_per_s': round(payload * 2 * (world - 1) / max(world, 1) / (ar_ms * 1e-3) / 1e9, 1) if world > 1 else None,
             'step_ms_without_exchange': round(nocomm_ms, 3), 'exposed_ms': round(exposed, 3),
             'overlap_frac': round(min(1.0, max(0.0, 1.0 - exposed / ar_ms)), 3) if ar_ms > 0 else None,

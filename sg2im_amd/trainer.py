@@ -605,11 +605,22 @@ class Trainer(object):
     ingraph = dp and self.dp_schedule == 2 and self.reducer.capturable() and not self.reducer.mute
     comm, red = self._comm, self.reducer
 
+    packed = []
+
     def reduce_after(stream, *tensors):
+      live = (self.world_size > 1 or red.force) and not red.mute
+      for t in tensors:
+        if live and red.packs(t):            # (bf16 payload: rounded on the producer's stream, see GradReducer.pack)
+          with torch.cuda.stream(stream):
+            red.pack(t)
       comm.wait_stream(stream)
       with torch.cuda.stream(comm):
         for t in tensors:
-          red.reduce_here(t)
+          if live and red.packs(t):
+            red.reduce_packed(t)
+            packed.append(t)
+          else:
+            red.reduce_here(t)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
       main = torch.cuda.current_stream()
@@ -688,6 +699,8 @@ class Trainer(object):
       main.wait_stream(side)
       if ingraph:
         main.wait_stream(comm)
+        for t in packed:                     # (bf16 payload: back into the fp32 arenas Adam reads)
+          red.unpack(t)
       if not dp or ingraph:
         self._seg_adam(st)
     graphs = {'all': g}
