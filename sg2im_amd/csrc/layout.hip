@@ -169,6 +169,10 @@ __global__ __launch_bounds__(256) void layout_fwd_kernel(const float* __restrict
 constexpr int PT = 16;                 // tile edge
 constexpr int PS = 32;                 // channels per slab
 struct PyrLevels { float* p[5]; };     // [0] = full resolution; [l] = (H >> l) x (W >> l)
+// grid.z = 2: z = 0 walks ALL layout slabs of its tile, z = 1 the noise slabs.  The per-pixel, per-object mask sample
+// does not depend on the channel: the z = 0 workgroup evaluates it once (first slab) and keeps it in LDS for the
+// other slabs (round 3: one workgroup per slab, i.e. the sampling - ~3x the arithmetic of a slab's multiply-adds - was
+// repeated D / 32 times).  Same operations per element in the same order: bit-identical.
 __global__ __launch_bounds__(256) void layout_pyramid_kernel(const float* __restrict__ vecs, long long ld_vecs,
                                                              const float* __restrict__ boxes, MaskRef mk,
                                                              const int* __restrict__ img_row_ptr,
@@ -178,97 +182,123 @@ __global__ __launch_bounds__(256) void layout_pyramid_kernel(const float* __rest
   __shared__ float T[PT * PT][PS + 1];
   __shared__ float L1[64][PS + 1];
   __shared__ float vs[LO][PS];
+  __shared__ float SV[LO][PT * PT];              // the samples of the (single) object pass, [object][pixel]
   __shared__ int objs[LO];
   const int tiles_x = W / PT;
   const int ty0 = (blockIdx.x / tiles_x) * PT, tx0 = (blockIdx.x % tiles_x) * PT;
-  const int n = blockIdx.y, slab = blockIdx.z;
+  const int n = blockIdx.y;
+  const bool noise_group = blockIdx.z == 1;
   const int tid = threadIdx.x;
   const int y = ty0 + tid / PT, x = tx0 + tid % PT;
   const int nl = D / PS;                         // layout slabs; the rest are noise slabs
-  const int cbase = slab * PS;                   // first destination channel
-  float acc[PS];
-  #pragma unroll
-  for (int k = 0; k < PS; ++k) acc[k] = 0.f;
-  if (slab < nl) {
-    const int ob = img_row_ptr[n], oe = img_row_ptr[n + 1];
-    const int Min = mk.M == 0 ? 8 : mk.M;
-    for (int cb = ob; cb < oe; cb += LO) {
-      const int nobj = min(LO, oe - cb);
-      __syncthreads();
-      if (tid < nobj) objs[tid] = img_entries[cb + tid];
-      __syncthreads();
-      for (int e = tid; e < nobj * PS; e += 256) {
-        const int oi = e / PS, k = e - oi * PS;
-        vs[oi][k] = vecs[(long long)objs[oi] * ld_vecs + cbase + k];
-      }
-      __syncthreads();
-      for (int oi = 0; oi < nobj; ++oi) {
-        const int o = objs[oi];
-        const Foot f = footprint(boxes + 4LL * o, y, x, H, W, Min, align_corners);
-        const float sv = sample_map(mk, o, f);
-        if (sv != 0.f) {                          // (a zero sample adds exactly +0: skipped, as in layout_fwd_kernel)
-          #pragma unroll
-          for (int k = 0; k < PS; ++k) acc[k] += vs[oi][k] * sv;
+  const int slab_lo = noise_group ? nl : 0, slab_hi = noise_group ? nl + ND / PS : nl;
+  const int ob = img_row_ptr[n], oe = img_row_ptr[n + 1];
+  const int Min = mk.M == 0 ? 8 : mk.M;
+  const bool one_pass = oe - ob <= LO;
+  for (int slab = slab_lo; slab < slab_hi; ++slab) {
+    const int cbase = slab * PS;                 // first destination channel
+    float acc[PS];
+    #pragma unroll
+    for (int k = 0; k < PS; ++k) acc[k] = 0.f;
+    if (!noise_group) {
+      const bool sampled = one_pass && slab > slab_lo;      // (workgroup-uniform) SV holds this tile's samples
+      for (int cb = ob; cb < oe; cb += LO) {
+        const int nobj = min(LO, oe - cb);
+        __syncthreads();
+        if (tid < nobj) objs[tid] = img_entries[cb + tid];
+        __syncthreads();
+        for (int e = tid; e < nobj * PS; e += 256) {
+          const int oi = e / PS, k = e - oi * PS;
+          vs[oi][k] = vecs[(long long)objs[oi] * ld_vecs + cbase + k];
+        }
+        __syncthreads();
+        for (int oi = 0; oi < nobj; ++oi) {
+          float sv;
+          if (sampled) {
+            sv = SV[oi][tid];
+          } else {
+            const int o = objs[oi];
+            const Foot f = footprint(boxes + 4LL * o, y, x, H, W, Min, align_corners);
+            sv = sample_map(mk, o, f);
+            if (one_pass) SV[oi][tid] = sv;         // (read back by this thread only)
+          }
+          if (sv != 0.f) {                          // (a zero sample adds exactly +0: skipped, as in layout_fwd_kernel)
+            #pragma unroll
+            for (int k = 0; k < PS; ++k) acc[k] += vs[oi][k] * sv;
+          }
         }
       }
+    } else {
+      const int c0 = cbase - D;
+      #pragma unroll
+      for (int k = 0; k < PS; ++k) acc[k] = noise[(((long long)n * ND + c0 + k) * H + y) * W + x];
     }
-  } else {
-    const int c0 = cbase - D;
-    #pragma unroll
-    for (int k = 0; k < PS; ++k) acc[k] = noise[(((long long)n * ND + c0 + k) * H + y) * W + x];
-  }
-  // full resolution
-  {
-    float* dst = out.p[0] + (((long long)n * H + y) * W + x) * ldc + cbase;
-    #pragma unroll
-    for (int k = 0; k < PS; k += 4) *reinterpret_cast<float4*>(dst + k) = make_float4(acc[k], acc[k + 1], acc[k + 2], acc[k + 3]);
-  }
-  if (n_levels < 1) return;
-  #pragma unroll
-  for (int k = 0; k < PS; ++k) T[tid][k] = acc[k];
-  __syncthreads();
-  // level 1: 8 x 8 pixels of the tile
-  for (int v = tid; v < 64 * PS; v += 256) {
-    const int px = v / PS, ch = v - px * PS;
-    const int y1 = px / 8, x1 = px - y1 * 8;
-    const int b = (2 * y1) * PT + 2 * x1;
-    float sm = T[b][ch];
-    sm += T[b + 1][ch]; sm += T[b + PT][ch]; sm += T[b + PT + 1][ch];
-    const float r = sm * 0.25f;
-    L1[px][ch] = r;
-    out.p[1][(((long long)n * (H >> 1) + (ty0 >> 1) + y1) * (W >> 1) + (tx0 >> 1) + x1) * ldc + cbase + ch] = r;
-  }
-  if (n_levels < 2) return;
-  __syncthreads();
-  // level 2: 4 x 4 (into T rows 0..15, free now), level 3: 2 x 2 (T rows 16..19), level 4: 1 (from level 3)
-  for (int v = tid; v < 16 * PS; v += 256) {
-    const int px = v / PS, ch = v - px * PS;
-    const int y2 = px / 4, x2 = px - y2 * 4;
-    const int b = (2 * y2) * 8 + 2 * x2;
-    float sm = L1[b][ch];
-    sm += L1[b + 1][ch]; sm += L1[b + 8][ch]; sm += L1[b + 9][ch];
-    const float r = sm * 0.25f;
-    T[px][ch] = r;
-    out.p[2][(((long long)n * (H >> 2) + (ty0 >> 2) + y2) * (W >> 2) + (tx0 >> 2) + x2) * ldc + cbase + ch] = r;
-  }
-  if (n_levels < 3) return;
-  __syncthreads();
-  if (tid < 4 * PS) {
-    const int px = tid / PS, ch = tid - px * PS;
-    const int y3 = px / 2, x3 = px - y3 * 2;
-    const int b = (2 * y3) * 4 + 2 * x3;
-    float sm = T[b][ch];
-    sm += T[b + 1][ch]; sm += T[b + 4][ch]; sm += T[b + 5][ch];
-    const float r = sm * 0.25f;
-    T[16 + px][ch] = r;
-    out.p[3][(((long long)n * (H >> 3) + (ty0 >> 3) + y3) * (W >> 3) + (tx0 >> 3) + x3) * ldc + cbase + ch] = r;
-  }
-  if (n_levels < 4) return;
-  __syncthreads();
-  if (tid < PS) {
-    float sm = T[16][tid];
-    sm += T[17][tid]; sm += T[18][tid]; sm += T[19][tid];
-    out.p[4][(((long long)n * (H >> 4) + (ty0 >> 4)) * (W >> 4) + (tx0 >> 4)) * ldc + cbase + tid] = sm * 0.25f;
+    // full resolution
+    if (n_levels < 1) {
+      float* dst = out.p[0] + (((long long)n * H + y) * W + x) * ldc + cbase;
+      #pragma unroll
+      for (int k = 0; k < PS; k += 4) *reinterpret_cast<float4*>(dst + k) = make_float4(acc[k], acc[k + 1], acc[k + 2], acc[k + 3]);
+    }
+    if (n_levels >= 1) {
+      __syncthreads();                             // (the previous slab's reads of T are over)
+      #pragma unroll
+      for (int k = 0; k < PS; ++k) T[tid][k] = acc[k];
+      __syncthreads();
+      // full resolution, written from the LDS tile: 8 consecutive lanes cover a pixel's 128-byte slab (a thread
+      // writing its own pixel's 32 channels touches 64 lines per store instruction)
+      for (int v = tid; v < PT * PT * (PS / 4); v += 256) {
+        const int px = v >> 3, q = v & 7;
+        const float* t = &T[px][4 * q];
+        *reinterpret_cast<float4*>(out.p[0] + (((long long)n * H + ty0 + px / PT) * W + tx0 + px % PT) * ldc + cbase + 4 * q) =
+          make_float4(t[0], t[1], t[2], t[3]);
+      }
+      // level 1: 8 x 8 pixels of the tile
+      for (int v = tid; v < 64 * PS; v += 256) {
+        const int px = v / PS, ch = v - px * PS;
+        const int y1 = px / 8, x1 = px - y1 * 8;
+        const int b = (2 * y1) * PT + 2 * x1;
+        float sm = T[b][ch];
+        sm += T[b + 1][ch]; sm += T[b + PT][ch]; sm += T[b + PT + 1][ch];
+        const float r = sm * 0.25f;
+        L1[px][ch] = r;
+        out.p[1][(((long long)n * (H >> 1) + (ty0 >> 1) + y1) * (W >> 1) + (tx0 >> 1) + x1) * ldc + cbase + ch] = r;
+      }
+    }
+    if (n_levels >= 2) {
+      __syncthreads();
+      // level 2: 4 x 4 (into T rows 0..15, free now), level 3: 2 x 2 (T rows 16..19), level 4: 1 (from level 3)
+      for (int v = tid; v < 16 * PS; v += 256) {
+        const int px = v / PS, ch = v - px * PS;
+        const int y2 = px / 4, x2 = px - y2 * 4;
+        const int b = (2 * y2) * 8 + 2 * x2;
+        float sm = L1[b][ch];
+        sm += L1[b + 1][ch]; sm += L1[b + 8][ch]; sm += L1[b + 9][ch];
+        const float r = sm * 0.25f;
+        T[px][ch] = r;
+        out.p[2][(((long long)n * (H >> 2) + (ty0 >> 2) + y2) * (W >> 2) + (tx0 >> 2) + x2) * ldc + cbase + ch] = r;
+      }
+    }
+    if (n_levels >= 3) {
+      __syncthreads();
+      if (tid < 4 * PS) {
+        const int px = tid / PS, ch = tid - px * PS;
+        const int y3 = px / 2, x3 = px - y3 * 2;
+        const int b = (2 * y3) * 4 + 2 * x3;
+        float sm = T[b][ch];
+        sm += T[b + 1][ch]; sm += T[b + 4][ch]; sm += T[b + 5][ch];
+        const float r = sm * 0.25f;
+        T[16 + px][ch] = r;
+        out.p[3][(((long long)n * (H >> 3) + (ty0 >> 3) + y3) * (W >> 3) + (tx0 >> 3) + x3) * ldc + cbase + ch] = r;
+      }
+    }
+    if (n_levels >= 4) {
+      __syncthreads();
+      if (tid < PS) {
+        float sm = T[16][tid];
+        sm += T[17][tid]; sm += T[18][tid]; sm += T[19][tid];
+        out.p[4][(((long long)n * (H >> 4) + (ty0 >> 4)) * (W >> 4) + (tx0 >> 4)) * ldc + cbase + tid] = sm * 0.25f;
+      }
+    }
   }
 }
 
@@ -834,7 +864,7 @@ int sg2im_layout_pyramid_forward(const float* vecs, long long ld_vecs, const flo
   }
   if (n_images == 0) return SG2IM_OK;
   const MaskRef mk{masks, masks_i64, (masks || masks_i64) ? mask_size : 0};
-  dim3 grid((height / PT) * (width / PT), n_images, (dim + noise_dim) / PS);
+  dim3 grid((height / PT) * (width / PT), n_images, noise_dim > 0 ? 2 : 1);      // (z: layout slabs | noise slabs)
   SG2IM_LAUNCH(layout_pyramid_kernel, grid, dim3(256), 0, stream, vecs, ld_vecs, boxes, mk, img_row_ptr, img_entries, dim,
                noise, noise_dim, height, width, align_corners, n_levels, out, (int)ld_levels);
   return ok_or(hipGetLastError());
