@@ -21,3 +21,5 @@ done
 timeout 300 python bench.py --steps 50 --warmup 10 --cpu_baseline_steps 0 --style vg 2>/dev/null | grep '^{"metric' > $O/bench_f32_vg.json
 python -c "import json; d=json.load(open('$O/bench_f32_vg.json')); print('f32 vg', d['ms_per_step'], d['value'])"
 timeout 300 python tools/gcn_stack_probe.py 2>&1 | grep -v amdgpu.ids > $O/gcn_stack_probe.log; head -3 $O/gcn_stack_probe.log
+cd $R && timeout 600 python __graft_entry__.py smoke > $O/smoke.log 2>&1; tail -3 $O/smoke.log
+timeout 300 python tools/bench_layout.py 2>&1 | grep -v amdgpu.ids > $O/layout_kernels.log; cat $O/layout_kernels.log
