@@ -141,7 +141,8 @@ typedef struct sg2im_bn_fwd {
   const float* gamma;       /* [cout] or NULL (1) */
   const float* beta;        /* [cout] or NULL (0) */
   float eps, momentum;
-  int training;             /* 0: running statistics are used (no reduction at all) */
+  int training;             /* 0: running statistics are used (no reduction at all); n >= 1: batch statistics, the
+                               running statistics move as after n passes over this batch (see sg2im_bn_stats) */
   float* running_mean;      /* updated when training (may be NULL then) */
   float* running_var;
   long long* num_batches_tracked;
@@ -411,6 +412,9 @@ int sg2im_crop_backward(const float* d_crops, int n_images, int height, int widt
  * affine scale = gamma*invstd, shift = beta - mean*scale that the conv loader applies.
  * training != 0: batch stats; running_mean/var/num_batches_tracked (may be NULL) are updated
  * with `momentum` like nn.BatchNorm2d.  training == 0: running stats are used instead.
+ * training = n > 1: the running statistics (and the batch counter) move exactly as after n forward passes over
+ * this same batch - the discriminators see the generated images twice per iteration with unchanged weights
+ * (scripts/train.py:544-548 and :566-568 / :581-583), the second pass is not computed again.
  * unbiased_rows (0 = rows): sample count used for the unbiased running_var factor - mask_net
  * normalises a x2-upsampled tensor (model.py:98-99) whose statistics equal the source's.
  * partial: scratch float[2 * C * 1024].

@@ -1189,6 +1189,85 @@ __global__ void conv_dgrad_fewc_kernel(const float* __restrict__ dY, int ldy, co
   for (int c = 0; c < NC; ++c) dst[c] = accumulate ? dst[c] + acc[c] : acc[c];
 }
 
+// The same gather with FOUR LANES PER PIXEL for the geometries whose pixels see at most 2 x 2 taps (kernel 4 /
+// stride 2, kernel 3 / stride 2, kernel 2 / stride 1 ...).  One thread per pixel is a chain of 64 dependent
+// 16-byte loads on 3 waves per SIMD (55 us for the crops of the object discriminator, profiles/r4_conv_layers.log);
+// here lane q of a pixel's quad owns the output channels {16 i + 4 q + j}: a quad's load is one contiguous 64-byte
+// piece of the dY row, the (up to) 16 loads of the four taps are issued before the first multiply (branch-free:
+// a tap outside the output reads row 0 and its values are replaced by zeros), four times the waves.  The quad's partial sums
+// are combined by two xor shuffles (fixed order).
+template <int NC>
+__global__ __launch_bounds__(256) void conv_dgrad_fewc_quad_kernel(
+    const float* __restrict__ dY, int ldy, const float* __restrict__ Wt, int Cout, int Ctot, int c_begin, int NB,
+    int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad, float* __restrict__ dx, long long ld_dx,
+    int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) float wsh[];
+  const int taps = KH * KW;
+  for (int idx = threadIdx.x; idx < taps * Cout * NC; idx += blockDim.x) {
+    const int c = idx % NC, co = (idx / NC) % Cout, tap = idx / (NC * Cout);
+    wsh[idx] = Wt[((long long)co * taps + tap) * Ctot + c_begin + c];
+  }
+  __syncthreads();
+  const long long total = (long long)NB * H * W;
+  const long long pix_raw = (long long)blockIdx.x * 64 + (threadIdx.x >> 2);
+  const bool live = pix_raw < total;
+  const long long pix = live ? pix_raw : total - 1;
+  const int q = threadIdx.x & 3;
+  const int w = (int)(pix % W), h = (int)((pix / W) % H), n = (int)(pix / ((long long)W * H));
+  // the taps that reach this pixel: kh = (h + pad) mod stride + stride a, a = 0, 1 (same for kw)
+  const int kh0 = (h + pad) % stride, kw0 = (w + pad) % stride;
+  const float* rowp[4];
+  const float* wtp[4];
+  bool tv[4];
+  #pragma unroll
+  for (int a = 0; a < 2; ++a)
+    #pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int kh = kh0 + stride * a, kw = kw0 + stride * b;
+      const int ho = (h + pad - kh) / stride, wo = (w + pad - kw) / stride;       // (exact when the tap is live)
+      const bool ok = kh < KH && kw < KW && h + pad - kh >= 0 && w + pad - kw >= 0 && ho < Ho && wo < Wo;
+      tv[2 * a + b] = ok;
+      rowp[2 * a + b] = dY + (ok ? (((long long)n * Ho + ho) * Wo + wo) * ldy : 0);
+      wtp[2 * a + b] = wsh + (ok ? (kh * KW + kw) : 0) * Cout * NC;
+    }
+  float acc[NC];
+  #pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+  for (int co0 = 0; co0 < Cout; co0 += 64) {
+    float4 g[4][4];
+    #pragma unroll
+    for (int t = 0; t < 4; ++t)
+      #pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int co = co0 + 16 * i + 4 * q;
+        g[t][i] = *reinterpret_cast<const float4*>(rowp[t] + (co < Cout ? co : 0));
+      }
+    #pragma unroll
+    for (int t = 0; t < 4; ++t)
+      #pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int co = co0 + 16 * i + 4 * q;
+        const bool on = tv[t] && co < Cout;
+        const float gv[4] = {on ? g[t][i].x : 0.f, on ? g[t][i].y : 0.f, on ? g[t][i].z : 0.f, on ? g[t][i].w : 0.f};
+        const float* wt = wtp[t] + (co < Cout ? co : 0) * NC;
+        #pragma unroll
+        for (int j = 0; j < 4; ++j)
+          #pragma unroll
+          for (int c = 0; c < NC; ++c) acc[c] = fmaf(gv[j], wt[j * NC + c], acc[c]);
+      }
+  }
+  #pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    acc[c] += __shfl_xor(acc[c], 1);
+    acc[c] += __shfl_xor(acc[c], 2);
+  }
+  if (live && q == 0) {
+    float* dst = dx + pix * ld_dx;
+    #pragma unroll
+    for (int c = 0; c < NC; ++c) dst[c] = accumulate ? dst[c] + acc[c] : acc[c];
+  }
+}
+
 // finish of the stride-2 parity data gradient: slabs [split][class][Mmax][N]; class (ph, pw) row m
 // is destination pixel (n, 2 hp + ph, 2 wp + pw)
 __global__ void splitk_finish_parity_kernel(const float* __restrict__ ws, int nsplit, int Mmax, int N,
@@ -1221,6 +1300,7 @@ namespace sg2im {
 // host side
 // ---------------------------------------------------------------------------
 static int g_num_cu = 256;
+static const bool g_fewc_scalar = getenv("SG2IM_FEWC_SCALAR") != nullptr;   // (A/B knob: one thread per pixel)
 static const bool g_plan_debug = getenv("SG2IM_PLAN_DEBUG") != nullptr;   // print the launch plans
 // LDS request of a "background" weight gradient (sg2im_conv_desc.launch_hints bit 0): 56 KB = at most two
 // workgroups per CU.  [measured, profiles/r2_deferred_wgrad_ab.log: 3 resident (no padding) 9.88, 2 resident
@@ -1813,6 +1893,20 @@ static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int co
   };
   if (c_count <= 4 && (size_t)taps * cout * c_count * sizeof(float) <= 48 * 1024) {
     const size_t lds = (size_t)taps * cout * c_count * sizeof(float);
+    // at most 2 x 2 taps per pixel, 16-byte dY loads
+    const bool quad = (d->kh + d->stride - 1) / d->stride <= 2 && (d->kw + d->stride - 1) / d->stride <= 2 &&
+                      cout % 4 == 0 && ld_dy % 4 == 0 && !((uintptr_t)dy & 15) && !g_fewc_scalar;
+    if (quad) {
+      dim3 qgrid((unsigned)((Mfull + 63) / 64));
+#define SG2IM_FEWQ(NC)                                                                                        \
+      SG2IM_LAUNCH((conv_dgrad_fewc_quad_kernel<NC>), qgrid, dim3(256), lds, stream, dy, ld_dy, weight, cout, \
+                         g.Wtap, c_begin, d->batch, d->in_h, d->in_w, d->out_h, d->out_w, d->kh, d->kw,      \
+                         d->stride, d->pad, dx, ld_dx, accumulate)
+      if (c_count == 1) SG2IM_FEWQ(1); else if (c_count == 2) SG2IM_FEWQ(2); else if (c_count == 3) SG2IM_FEWQ(3);
+      else SG2IM_FEWQ(4);
+#undef SG2IM_FEWQ
+      return hipGetLastError() == hipSuccess ? bn_after() : SG2IM_ERR_HIP;
+    }
     dim3 grid((unsigned)((Mfull + 255) / 256));
 #define SG2IM_FEWC(NC)                                                                                        \
     SG2IM_LAUNCH((conv_dgrad_fewc_kernel<NC>), grid, dim3(256), lds, stream, dy, ld_dy, weight, cout,   \

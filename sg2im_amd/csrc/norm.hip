@@ -104,7 +104,7 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ x, const float* 
                                       float* __restrict__ invstd, float* __restrict__ scale,
                                       float* __restrict__ shift, const int* __restrict__ count, int unit) {
   const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);     // one wavefront per channel
-  if (c == 0 && (threadIdx.x & 63) == 0 && training && nbt) *nbt += 1;
+  if (c == 0 && (threadIdx.x & 63) == 0 && training && nbt) *nbt += training;      // (training = n: the pass counts n times)
   if (count) {
     const long long live = live_rows(rows, count, unit);
     if (unbiased_rows > 0) unbiased_rows = unbiased_rows / rows * live;   // (a whole multiple of rows)
@@ -122,8 +122,12 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ x, const float* 
     if (running_mean && (threadIdx.x & 63) == 0) {
       const double nu = (double)(unbiased_rows > 0 ? unbiased_rows : rows);
       const double unbiased = nu > 1.0 ? var * nu / (nu - 1.0) : var;
-      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
-      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+      float rm = running_mean[c], rv = running_var[c];
+      for (int u = 0; u < training; ++u) {              // the same rounding as n passes over the same batch
+        rm = (float)((1.0 - momentum) * rm + momentum * mu);
+        rv = (float)((1.0 - momentum) * rv + momentum * unbiased);
+      }
+      running_mean[c] = rm; running_var[c] = rv;
     }
   } else {
     mu = running_mean[c]; var = running_var[c];
@@ -144,14 +148,14 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ x, const float* 
 __global__ void bn_stats_final_tiles_kernel(const float* __restrict__ partial, int nblk, long long per, long long rows,
                                             long long unbiased_rows, int C,
                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                            float eps, float momentum,
+                                            float eps, float momentum, int updates,
                                             float* __restrict__ running_mean, float* __restrict__ running_var,
                                             long long* __restrict__ nbt, float* __restrict__ mean,
                                             float* __restrict__ invstd, float* __restrict__ scale,
                                             float* __restrict__ shift, const int* __restrict__ count, int unit) {
   const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);     // one wavefront per channel
   const int lane = threadIdx.x & 63;
-  if (c == 0 && lane == 0 && nbt) *nbt += 1;
+  if (c == 0 && lane == 0 && nbt) *nbt += updates;
   long long live = live_rows(rows, count, unit);
   if (count && unbiased_rows > 0) unbiased_rows = unbiased_rows / rows * live;   // (a whole multiple of rows)
   if (c >= C) return;
@@ -192,8 +196,12 @@ __global__ void bn_stats_final_tiles_kernel(const float* __restrict__ partial, i
   if (running_mean) {
     const double nu = (double)(unbiased_rows > 0 ? unbiased_rows : (live > 0 ? live : 1));
     const double unbiased = nu > 1.0 ? var * nu / (nu - 1.0) : var;
-    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
-    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    float rm = running_mean[c], rv = running_var[c];
+    for (int u = 0; u < updates; ++u) {                 // (sg2im_bn_fwd.training = n: see bn_stats_final_kernel)
+      rm = (float)((1.0 - momentum) * rm + momentum * mu);
+      rv = (float)((1.0 - momentum) * rv + momentum * unbiased);
+    }
+    running_mean[c] = rm; running_var[c] = rv;
   }
   const float is = (float)(1.0 / sqrt(var + (double)eps));
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -834,8 +842,8 @@ int bn_stats_finish_tiles(const float* partial, int nblk, long long per, long lo
                           const sg2im_bn_fwd* a, hipStream_t stream) {
   mark_gemm_end(stream);
   SG2IM_LAUNCH(bn_stats_final_tiles_kernel, dim3((channels + 3) / 4), dim3(256), 0, stream, partial, nblk, per, rows,
-                     a->unbiased_rows, channels, a->gamma, a->beta, a->eps, a->momentum, a->running_mean, a->running_var,
-                     a->num_batches_tracked, a->mean, a->invstd, a->scale, a->shift, a->count, a->count_unit);
+                     a->unbiased_rows, channels, a->gamma, a->beta, a->eps, a->momentum, a->training > 1 ? a->training : 1,
+                     a->running_mean, a->running_var, a->num_batches_tracked, a->mean, a->invstd, a->scale, a->shift, a->count, a->count_unit);
   return ok_or(hipGetLastError());
 }
 

@@ -4,7 +4,7 @@ import torch.nn as nn
 
 from . import functional as HF
 from .bilinear import crop_bbox_batch_nhwc
-from .layers import GlobalAvgPool, build_cnn
+from .layers import DiscCnn, GlobalAvgPool, build_cnn
 from .layout import ALIGN_CORNERS
 
 
@@ -18,7 +18,10 @@ class PatchDiscriminator(nn.Module):
     # present in the state_dict but never applied (reference sg2im/discriminators.py:40-45)
     self.classifier = nn.Conv2d(output_dim, 1, kernel_size=1, stride=1)
 
-  def forward_nhwc(self, x_nhwc):
+  def forward_nhwc(self, x_nhwc, share=None):
+    """share: None or a functional.SharedPass (only the 'C'-token architectures can share a pass)"""
+    if share is not None and isinstance(self.cnn, DiscCnn):
+      return self.cnn(None if share.recorded else x_nhwc, share=share)
     return self.cnn(x_nhwc)
 
   def forward(self, x, layout=None):
@@ -38,8 +41,11 @@ class AcDiscriminator(nn.Module):
     self.real_classifier = nn.Linear(1024, 1)
     self.obj_classifier = nn.Linear(1024, num_objects)
 
-  def scores_nhwc(self, x_nhwc, count=None):
-    feats = self.cnn[0](x_nhwc, count) if count is not None else self.cnn[0](x_nhwc)
+  def scores_nhwc(self, x_nhwc, count=None, share=None):
+    if share is not None and isinstance(self.cnn[0], DiscCnn):
+      feats = self.cnn[0](x_nhwc, count, share)
+    else:
+      feats = self.cnn[0](x_nhwc, count) if count is not None else self.cnn[0](x_nhwc)
     vecs = self.cnn[1](feats)
     fc = self.cnn[2]
     vecs = HF.LinearAct.apply(vecs, fc.weight, fc.bias, 1.0)
@@ -47,8 +53,8 @@ class AcDiscriminator(nn.Module):
     cls = HF.LinearAct.apply(vecs, self.obj_classifier.weight, self.obj_classifier.bias, 1.0)
     return real, cls
 
-  def forward_nhwc(self, x_nhwc, y, ac_weight=1.0, count=None):
-    real, cls = self.scores_nhwc(x_nhwc, count)
+  def forward_nhwc(self, x_nhwc, y, ac_weight=1.0, count=None, share=None):
+    real, cls = self.scores_nhwc(x_nhwc, count, share)
     return real, HF.CrossEntropyLoss.apply(cls, y, float(ac_weight), count)   # reference sg2im/discriminators.py:74
 
   def forward(self, x, y):
@@ -68,12 +74,19 @@ class AcCropDiscriminator(nn.Module):
     self.object_size = object_size
     self.align_corners = bool(align_corners)
 
-  def forward_nhwc(self, imgs_nhwc, objs, boxes, obj_to_img, ac_weight=1.0, obj_count=None):
+  def forward_nhwc(self, imgs_nhwc, objs, boxes, obj_to_img, ac_weight=1.0, obj_count=None, share=None):
     """ac_weight: loss weight folded into the classification loss (the Trainer's ac_loss_weight);
-    obj_count: (int32 device scalar, 1) when the object axis is padded (sg2im_amd/bucketing.py)"""
-    crops = crop_bbox_batch_nhwc(imgs_nhwc, boxes, obj_to_img, self.object_size,
-                                 align_corners=self.align_corners)
-    return self.discriminator.forward_nhwc(crops, objs, ac_weight, obj_count)
+    obj_count: (int32 device scalar, 1) when the object axis is padded (sg2im_amd/bucketing.py);
+    share: None or a functional.SharedPass - the crops and the CNN over them are computed by the first call that
+    gets it and adopted by the second (same images, boxes and weights: scripts/train.py:544 and :566-568)"""
+    if share is not None and not isinstance(self.discriminator.cnn[0], DiscCnn):
+      share = None                     # (architectures with R / U / P / FC tokens run layer by layer)
+    if share is not None and share.recorded:
+      crops = None
+    else:
+      crops = crop_bbox_batch_nhwc(imgs_nhwc, boxes, obj_to_img, self.object_size,
+                                   align_corners=self.align_corners)
+    return self.discriminator.forward_nhwc(crops, objs, ac_weight, obj_count, share)
 
   def forward(self, imgs, objs, boxes, obj_to_img):
     """imgs (N,3,H,W) -> (real_scores (O,1), ac_loss scalar)  (reference :87-90)"""

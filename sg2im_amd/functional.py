@@ -343,23 +343,27 @@ class Embedding(Function):
   Backward is a deterministic CSR segment-sum instead of atomics."""
 
   @staticmethod
-  def forward(ctx, weight, idx):
+  def forward(ctx, weight, idx, csr=None):
+    """csr: None or ops.Csr(idx, None, weight.size(0)) built ahead of time (Sg2ImModel.forward_nhwc builds it on its
+    aux stream at the head of the step instead of at the very end of the backward pass)"""
     out = ops.gather_rows(weight, idx, _new(weight, idx.numel(), weight.size(1)))
     ctx.save_for_backward(idx, weight)
-    ctx.rows = weight.size(0)
+    ctx.rows, ctx.csr = weight.size(0), csr
     return out
 
   @staticmethod
   def backward(ctx, g):
     idx, weight = ctx.saved_tensors
     g = g.contiguous()
-    csr = ops.Csr(idx, None, ctx.rows)
+    csr, ctx.csr = ctx.csr, None
+    if csr is None:
+      csr = ops.Csr(idx, None, ctx.rows)
     sk = _sink(weight)
     if sk is not None:
       ops.segment_sum(g, None, csr, g.size(1), False, sk, accumulate=True)
-      return None, None
+      return None, None, None
     dw = ops.segment_sum(g, None, csr, g.size(1), False, _new(g, ctx.rows, g.size(1)))
-    return dw, None
+    return dw, None, None
 
 
 # ----------------------------------------------------------------------------
@@ -1100,17 +1104,46 @@ class MaskNetFn(Function):
     return (d_obj, None, None, None) + tuple(grads)
 
 
+class SharedPass(object):
+  """One forward pass of a discriminator CNN that two autograd graphs use.
+
+  scripts/train.py runs every discriminator over the generated images TWICE per iteration - :544-548 inside the
+  generator loss and :566-568 / :581-583 (on ``imgs_pred.detach()``) inside the discriminator's own step - with
+  the same weights, the same inputs and (training-mode BatchNorm) the same batch statistics: the discriminator's
+  optimiser only steps afterwards.  The Trainer computes the pass once: the first call records the activations
+  here and lets every BatchNorm move its running statistics twice (sg2im_bn_fwd.training = 2, bit-identical to a
+  second pass); the second call builds its autograd node - on the stream of the discriminator step - around the
+  recorded activations without launching anything."""
+
+  def __init__(self):
+    self.saved = self.misc = self.input = None
+
+  @property
+  def recorded(self):
+    return self.saved is not None
+
+
 class DiscCnnFn(Function):
   """build_cnn with 'CK-X-S' tokens, batch norm, valid/same padding (reference
   sg2im/layers.py:129-213): conv, then [BN, LeakyReLU, conv] ... on an NHWC input.
   specs: list of (k, cout, stride, pad); params: [W0, b0], then per later conv
   [gamma, beta, W, b] - or, with normalization='none' (bns is None), just [W, b] per conv:
-  the LeakyReLU in front of conv i+1 is then fused into conv i's epilogue."""
+  the LeakyReLU in front of conv i+1 is then fused into conv i's epilogue.
+  share: None or a SharedPass (x may be None once it is recorded)."""
 
   @staticmethod
-  def forward(ctx, x, bns, specs, slope, training, count, *params):
+  def forward(ctx, x, bns, specs, slope, training, count, share, *params):
     """count: None or (int32 device scalar, 1) - the number of real batch entries (objects) of a
     padded batch: BatchNorm statistics and their backward only see those"""
+    if share is not None and share.recorded:
+      # the second pass over the same input with the same weights: nothing to compute (SharedPass)
+      if (specs, slope, bool(training)) != (share.misc[0], share.misc[1], bool(share.misc[2])):
+        raise RuntimeError('SharedPass: recorded by a different network / mode')
+      ctx.saved, ctx.misc = share.saved, share.misc
+      ctx.save_for_backward(*params)
+      return share.saved[-1][2].detach()
+    if share is not None and training:
+      training = 2                     # (this pass stands for two: the running statistics move twice)
     x = x.contiguous()
     N, H, W, Cin = x.shape
     saved = []
@@ -1146,6 +1179,8 @@ class DiscCnnFn(Function):
     # (padded batches under instance normalisation need nothing: the norm is per sample, the dummy crops are
     # independent samples and the counted losses hand them a zero gradient)
     ctx.saved, ctx.misc = saved, (specs, slope, training, tuple(x.shape), nonorm, inorm, count)
+    if share is not None:
+      share.saved, share.misc = saved, ctx.misc
     ctx.save_for_backward(*params)
     return saved[-1][2]
 
@@ -1155,7 +1190,7 @@ class DiscCnnFn(Function):
     specs, slope, training, xshape, nonorm, inorm, count = ctx.misc
     saved = ctx.saved
     N = xshape[0]
-    ni = ctx.needs_input_grad[6:]
+    ni = ctx.needs_input_grad[7:]
     grads = [None] * len(params)
     dy = g.contiguous()
     for i in range(len(specs) - 1, -1, -1):
@@ -1182,7 +1217,7 @@ class DiscCnnFn(Function):
           dx = _new(g, *xshape)
           ops.conv2d_backward_data(d, _cl_weight(Wp), cout, dy, cout, 0, cin, dx, cin)
         ctx.saved = None
-        return (dx, None, None, None, None, None) + tuple(grads)
+        return (dx, None, None, None, None, None, None) + tuple(grads)
       gz = _new(g, N, h, w, cin)
       ops.conv2d_backward_data(d, _cl_weight(Wp), cout, dy, cout, 0, cin, gz, cin)
       yp, stp = saved[i - 1][2], saved[i - 1][3]

@@ -116,8 +116,10 @@ class DiscCnn(nn.Sequential):
     self.specs, self.slope = specs, slope
     return self
 
-  def forward(self, x_nhwc, count=None):
-    """count: None or (int32 device scalar, 1) - real entries of a padded batch (sg2im_amd/bucketing.py)"""
+  def forward(self, x_nhwc, count=None, share=None):
+    """count: None or (int32 device scalar, 1) - real entries of a padded batch (sg2im_amd/bucketing.py);
+    share: None or a functional.SharedPass - this pass is needed by two autograd graphs (x_nhwc may be None once
+    the pass is recorded)"""
     convs = [m for m in self if isinstance(m, nn.Conv2d)]
     bns = [m for m in self if isinstance(m, nn.BatchNorm2d)]
     if not bns:                       # 'none': conv, act, conv, ...; 'instance': conv, IN, act, conv, ...
@@ -126,13 +128,13 @@ class DiscCnn(nn.Sequential):
       for cv in convs:
         params += [cv.weight, cv.bias]
       return HF.DiscCnnFn.apply(x_nhwc, 'instance' if inorm else None, self.specs, self.slope, self.training, count,
-                                *params)
+                                share, *params)
     if len(bns) != len(convs) - 1:
       raise NotImplementedError('discriminator CNN with a partial set of normalization layers')
     params = [convs[0].weight, convs[0].bias]
     for bn, cv in zip(bns, convs[1:]):
       params += [bn.weight, bn.bias, cv.weight, cv.bias]
-    return HF.DiscCnnFn.apply(x_nhwc, bns, self.specs, self.slope, self.training, count, *params)
+    return HF.DiscCnnFn.apply(x_nhwc, bns, self.specs, self.slope, self.training, count, share, *params)
 
 
 def _init_conv(layer, method):

@@ -10,6 +10,9 @@ from .graph import GraphTripleConv, GraphTripleConvNet
 from .layers import build_mlp, to_channels_last
 from .layout import ALIGN_CORNERS, layout_nhwc
 
+import os as _os
+EMB_CSR_AHEAD = _os.environ.get('SG2IM_EMB_CSR_AHEAD', '1') != '0'      # (A/B knob)
+
 
 class Sg2ImModel(nn.Module):
   def __init__(self, vocab, image_size=(64, 64), embedding_dim=64, gconv_dim=128, gconv_hidden_dim=512,
@@ -100,6 +103,7 @@ class Sg2ImModel(nn.Module):
     H, W = self.image_size
     main = torch.cuda.current_stream() if aux_stream is not None else None
     noise = img_csr = ev_pre = None
+    emb_csr = (None, None)            # the CSRs the embeddings' backward sums over, built ahead of time
     if aux_stream is not None and num_images is not None:
       aux_stream.wait_stream(main)
       with torch.cuda.stream(aux_stream):
@@ -108,13 +112,17 @@ class Sg2ImModel(nn.Module):
         img_csr = ops.Csr(obj_to_img, None, num_images)
         ev_pre = torch.cuda.Event()
         ev_pre.record(aux_stream)
+        # (not waited for by the layout: joined with everything else of this stream at the end of the forward pass)
+        if torch.is_grad_enabled() and self.obj_embeddings.weight.requires_grad and EMB_CSR_AHEAD:
+          emb_csr = (ops.Csr(objs, None, self.obj_embeddings.weight.size(0)),
+                     ops.Csr(p, None, self.pred_embeddings.weight.size(0)))
     # (padded batch: the padding triples stay out of the pooling CSR - no long tail row on the dummy object)
     edges = (s, o, ops.Csr(s, o, O, live=triple_count))
 
     ops.mark('csr_done')
-    obj_vecs = HF.Embedding.apply(self.obj_embeddings.weight, objs)
+    obj_vecs = HF.Embedding.apply(self.obj_embeddings.weight, objs, emb_csr[0])
     obj_vecs_orig = obj_vecs
-    pred_vecs = HF.Embedding.apply(self.pred_embeddings.weight, p)
+    pred_vecs = HF.Embedding.apply(self.pred_embeddings.weight, p, emb_csr[1])
     stack = self._gconv_stack()
     if stack is not None:
       # every GraphTripleConv layer in ONE persistent launch (csrc/gcn_persist.hip)

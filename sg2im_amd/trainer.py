@@ -6,6 +6,9 @@ Differences from the reference that do not change the mathematics:
   * the discriminators are frozen while the generator's loss is back-propagated - the
     reference deposits gradients in the D parameters there (train.py:559) and throws them
     away with the next zero_grad (train.py:577,590);
+  * each discriminator's pass over the generated images is computed once per iteration and used by both the
+    generator loss (train.py:544-548) and the discriminator's own step (train.py:566-568, 581-583: same images,
+    same weights, same batch statistics; the BatchNorm running statistics still move twice) - functional.SharedPass;
   * losses stay on the device: no ``.item()`` per loss (train.py:145,552; utils.py:88);
   * ``num_images`` is passed down, removing the host sync of layout.py:143;
   * under data parallelism the gradient of every network is summed with one all-reduce
@@ -40,6 +43,8 @@ LOSS_WEIGHTS = dict(l1_pixel_loss_weight=1.0, bbox_pred_loss_weight=10.0, predic
                     mask_loss_weight=0.0, discriminator_loss_weight=0.01, d_obj_weight=1.0, d_img_weight=1.0,
                     ac_loss_weight=0.1)                          # train.py:108-131
 
+
+SHARE_FAKE_PASS = os.environ.get('SG2IM_SHARE_FAKE_PASS', '1') != '0'      # (A/B knob)
 
 # 'thread_local': other threads (the RCCL watchdog polls events) may call into HIP while this
 # thread captures; the default 'global' mode treats that as a capture error
@@ -155,6 +160,8 @@ class Trainer(object):
     self.graph_stats = {'captures': 0, 'replays': 0, 'invalidated': 0, 'evicted': 0}
     self.launch_stats = {}          # kernels per captured iteration (set by the last capture)
     self._cap_stream = None
+    self._wgrad_stream = None
+    self._lane_handles = set()
     # single-GPU graph mode: capture the whole iteration as ONE graph in which the two
     # discriminator steps run on a side stream concurrently with the generator's backward
     # (they only need imgs_pred; their small kernels fill the CUs the GCN / MLP backward leaves idle)
@@ -240,6 +247,9 @@ class Trainer(object):
       losses['mask_loss'] = L.binary_cross_entropy(masks_pred, masks, w['mask_loss_weight'],
                                                    cnt(oc, masks_pred.size(1) * masks_pred.size(2)))
     gi = None
+    # the discriminators' passes over the generated images are needed twice (here and in their own steps, with
+    # unchanged weights): computed once, functional.SharedPass
+    share = st['shared_fake'] = {'obj': HF.SharedPass(), 'img': HF.SharedPass()} if SHARE_FAKE_PASS else {}
     par = (self.d_img is not None and self.d_obj is not None and self._aux2 is not None and
            torch.cuda.is_current_stream_capturing() and os.environ.get('SG2IM_PAR_DIMG', '1') != '0' and
            not ops.SINGLE_STREAM)      # (A/B knob)
@@ -254,11 +264,13 @@ class Trainer(object):
       main, side = torch.cuda.current_stream(), self._aux2
       side.wait_event(ev)
       with torch.cuda.stream(side):
-        gi = self.gan_g_loss(self.d_img.forward_nhwc(imgs_pred), weight=w['discriminator_loss_weight'] * w['d_img_weight'])
+        gi = self.gan_g_loss(self.d_img.forward_nhwc(imgs_pred, share.get('img')),
+                             weight=w['discriminator_loss_weight'] * w['d_img_weight'])
     if self.d_obj is not None:
       # (loss weights are folded into the loss kernels; the terms are summed by ONE launch and the
       # backward pass is seeded with ops.unit, so no term pays a multiply / scaling launch)
-      scores_fake, ac_loss = self.d_obj.forward_nhwc(imgs_pred, objs, boxes, obj_to_img, w['ac_loss_weight'], oc)
+      scores_fake, ac_loss = self.d_obj.forward_nhwc(imgs_pred, objs, boxes, obj_to_img, w['ac_loss_weight'], oc,
+                                                     share.get('obj'))
       losses['ac_loss'] = ac_loss
       losses['g_gan_obj_loss'] = self.gan_g_loss(scores_fake, weight=w['discriminator_loss_weight'] * w['d_obj_weight'],
                                                  count=oc)
@@ -266,7 +278,8 @@ class Trainer(object):
       if par:
         main.wait_stream(side)
       else:
-        gi = self.gan_g_loss(self.d_img.forward_nhwc(imgs_pred), weight=w['discriminator_loss_weight'] * w['d_img_weight'])
+        gi = self.gan_g_loss(self.d_img.forward_nhwc(imgs_pred, share.get('img')),
+                             weight=w['discriminator_loss_weight'] * w['d_img_weight'])
       losses['g_gan_img_loss'] = gi
     total = HF.SumScalars.apply(*losses.values())
     losses['total_loss'] = total
@@ -304,7 +317,8 @@ class Trainer(object):
     losses = st['losses']
     # train.py:566-579
     oc = st.get('ocnt')
-    sf, ac_fake = self.d_obj.forward_nhwc(st['imgs_fake'], objs, boxes, obj_to_img, obj_count=oc)
+    sf, ac_fake = self.d_obj.forward_nhwc(st['imgs_fake'], objs, boxes, obj_to_img, obj_count=oc,
+                                          share=st.get('shared_fake', {}).get('obj'))
     sr, ac_real = self.d_obj.forward_nhwc(st['imgs_nhwc'], objs, boxes, obj_to_img, obj_count=oc)
     gan_terms = self.gan_d_loss.terms(sr, sf, oc)
     losses['d_obj_gan_loss'] = HF.SumScalars.apply(*gan_terms).detach()      # (reported value only)
@@ -319,7 +333,7 @@ class Trainer(object):
     losses = st['losses']
     ops.mark('d_img_start')
     # train.py:581-592
-    sf = self.d_img.forward_nhwc(st['imgs_fake'])
+    sf = self.d_img.forward_nhwc(st['imgs_fake'], st.get('shared_fake', {}).get('img'))
     sr = self.d_img.forward_nhwc(st['imgs_nhwc'])
     losses['d_img_gan_loss'] = self.gan_d_loss(sr, sf)
     self.opt_di.zero_grad()
@@ -417,19 +431,35 @@ class Trainer(object):
     weight gradients run on (ops.SideLane)."""
     dev = self.device
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    # torch.cuda.Stream() hands out a pool of 32 streams per device round-robin: in a process that builds many
+    # Trainers a new stream object may BE a stream this Trainer already holds (or the weight-gradient stream an
+    # earlier Trainer cached under the same capture-stream handle) - two lanes of the captured iteration would
+    # then be one stream.  Every lane of this Trainer gets a handle none of its other lanes has.
+    taken = self._lane_handles
+
+    def fresh():
+      for _ in range(64):
+        s = torch.cuda.Stream(device=idx)
+        if s.cuda_stream not in taken:
+          taken.add(s.cuda_stream)
+          return s
+      raise RuntimeError('no unused stream left for a lane of the captured iteration')
     if self._cap_stream is None:
       _lib.init()
-      self._cap_stream = torch.cuda.Stream(device=idx)
+      self._cap_stream = fresh()
       self._n_side = 1               # (a second side stream for D_img measured slower: 11.1 vs 10.65 ms)
-      self._side = (torch.cuda.Stream(device=idx),)
-      key = (idx, self._cap_stream.cuda_stream)
-      if key not in ops._wgrad_streams:
-        ops._wgrad_streams[key] = torch.cuda.Stream(device=idx)
+      self._side = (fresh(),)
+      self._wgrad_stream = fresh()
     if self._comm is None and (self.world_size > 1 or self.reducer.force):
-      self._comm = torch.cuda.Stream(device=idx)       # gradient exchange inside the captured iteration
+      self._comm = fresh()           # gradient exchange inside the captured iteration
     if self._aux2 is None:
-      self._aux2 = torch.cuda.Stream(device=idx)       # the generator loss' pass through the image discriminator
-    for s in (self._cap_stream, self._side[0], self._aux2, ops._wgrad_streams[(idx, self._cap_stream.cuda_stream)]):
+      self._aux2 = fresh()           # the generator loss' pass through the image discriminator
+    # (ops.SideLane looks the weight-gradient stream up by the capture stream's handle: this Trainer's, whatever
+    # another Trainer with the same pooled handle left there)
+    ops._wgrad_streams[(idx, self._cap_stream.cuda_stream)] = self._wgrad_stream
+    lanes = [self._cap_stream, self._side[0], self._aux2, self._wgrad_stream] + ([self._comm] if self._comm is not None else [])
+    assert len(set(s.cuda_stream for s in lanes)) == len(lanes), 'two lanes of the captured iteration share a stream'
+    for s in (self._cap_stream, self._side[0], self._aux2, self._wgrad_stream):
       with torch.cuda.stream(s):
         ops.workspace(dev)
         ops.scratch(dev, scratch_floats)

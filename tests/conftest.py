@@ -21,3 +21,19 @@ def pytest_collection_modifyitems(config, items):
   for it in items:
     if 'gpu' in it.keywords:
       it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _release_graphs_between_tests(request):
+  """GPU tests build Trainers whose hipGraphs (some with recorded RCCL kernels of a process group the test has
+  already destroyed) would otherwise be torn down by the cyclic garbage collector at an arbitrary allocation inside a
+  LATER test - possibly between that test's capture and its replays.  Collect them at the test boundary, with the
+  device idle."""
+  yield
+  if 'gpu' in request.keywords:
+    import gc
+    import torch
+    if torch.cuda.is_available():
+      torch.cuda.synchronize()
+      gc.collect()
+      torch.cuda.synchronize()

@@ -446,6 +446,51 @@ def test_graph_replay_matches_eager_steps():
   assert b.graph_stats['captures'] == 2
 
 
+@pytest.mark.parametrize('use_graphs', [False, True])
+def test_shared_pass_over_the_generated_images_is_bit_identical_to_two_passes(use_graphs):
+  """scripts/train.py:544-548 and :566-568 / :581-583 run each discriminator over the generated images twice with
+  the same weights; the Trainer computes that pass once (functional.SharedPass).  Against the trainer that runs it
+  twice: every loss, every parameter of the three networks after three Adam steps and every BatchNorm buffer
+  (running_mean / running_var moved twice per iteration by that pass, num_batches_tracked + 3 per iteration)
+  must be bit-identical - and fewer launches must have been recorded."""
+  import sg2im_amd.trainer as T
+  from sg2im_amd.synthetic import make_vocab, synthetic_batch
+  from tests import hip_harness as hh
+  dev = hh.dev()
+  vocab = make_vocab(184, 7)
+  batch = tuple(t.to(dev) if torch.is_tensor(t) else t for t in synthetic_batch(4, seed=21))
+  kw = dict(generator_kwargs={'layout_noise_dim': 0}, seed=9, bucket=(32, 64), use_graphs=use_graphs)
+  import gc
+  runs = {}
+  keep = T.SHARE_FAKE_PASS
+  try:
+    for share in (False, True):
+      T.SHARE_FAKE_PASS = share
+      tr = T.Trainer(vocab, dev, **kw)
+      losses = [T.Trainer.losses_to_host(tr.step(batch)) for _ in range(3)]
+      torch.cuda.synchronize()
+      bufs = {}
+      for name, m in (('d_obj', tr.d_obj), ('d_img', tr.d_img)):
+        for k, v in m.named_buffers():
+          bufs[name + '.' + k] = v.clone()
+      runs[share] = (losses, [f.flat.clone() for f in (tr.flat_g, tr.flat_do, tr.flat_di)], bufs, dict(tr.launch_stats))
+      del tr                           # (one trainer - and its hipGraph - at a time)
+      gc.collect()
+  finally:
+    T.SHARE_FAKE_PASS = keep
+  (la, fa, ba, sa), (lb, fb, bb, sb) = runs[False], runs[True]
+  assert la == lb, (la, lb)
+  for x, y in zip(fa, fb):
+    assert torch.equal(x, y)
+  assert ba.keys() == bb.keys() and len(ba) >= 12
+  for k in ba:
+    assert torch.equal(ba[k], bb[k]), k
+    if k.endswith('num_batches_tracked'):
+      assert int(ba[k]) == 9, (k, int(ba[k]))       # fake, fake again, real - three iterations
+  if use_graphs:
+    assert sb['launches_per_step'] <= sa['launches_per_step'] - 14, (sa, sb)
+
+
 def test_rccl_path_single_rank():
   """The N > 1 code path on one GPU: a 1-rank RCCL group with the gradient all-reduces really
   issued (GradReducer.force), in the eager form (async launch after each backward, wait before Adam)

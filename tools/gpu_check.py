@@ -360,6 +360,9 @@ def sec_conv():
   conv_case('conv3x3 160+1up->96 4x4 (VEC1 concat)', 4, 4, 4, 160, 1, 1, 96, 3, 1, 1)
   conv_case('conv3x3 3->20 pad1 9x11 (few-channel dgrad)', 3, 9, 11, 3, 0, 0, 20, 3, 1, 1)
   conv_case('conv4x4s2 2->8 pad1 10x10 (few-channel dgrad)', 2, 10, 10, 2, 0, 0, 8, 4, 2, 1)
+  conv_case('conv4x4s2 3->64 valid 32x32 batch 37 (four lanes per pixel, ragged last workgroup)', 37, 32, 32, 3, 0, 0, 64, 4, 2, 0)
+  conv_case('conv3x3s2 4->80 pad1 13x9 (four lanes per pixel, two channel rounds)', 3, 13, 9, 4, 0, 0, 80, 3, 2, 1)
+  conv_case('conv2x2 1->12 valid 7x7 (four lanes per pixel, stride 1)', 2, 7, 7, 1, 0, 0, 12, 2, 1, 0)
   conv_case('conv1x1 64->3 32x32', 2, 32, 32, 64, 0, 0, 3, 1, 1, 0)
   conv_case('conv1x1 128->1 16x16', 8, 16, 16, 128, 0, 0, 1, 1, 1, 0)
   conv_case('conv3x3 1184->512 8x8 (m1.conv0 shape)', 4, 8, 8, 160, 1024, 1, 512, 3, 1, 1)
