@@ -491,6 +491,36 @@ def test_shared_pass_over_the_generated_images_is_bit_identical_to_two_passes(us
     assert sb['launches_per_step'] <= sa['launches_per_step'] - 14, (sa, sb)
 
 
+def test_lanes_of_a_trainer_never_share_a_pooled_stream():
+  """torch.cuda.Stream() hands out 32 pooled streams per device round-robin.  In a process that had built ~9
+  graph-mode Trainers a new Trainer's aux / comm stream object WAS the weight-gradient stream ops.SideLane had
+  cached for the same capture-stream handle: two lanes of the captured iteration on one stream, and the first
+  replay of that graph died inside hipGraphLaunch (hip::Graph::UpdateStreams,
+  profiles/r4_graph_replay_crash_backtrace.txt).  Every lane of a Trainer must be its own stream, and
+  ops.SideLane must find THIS Trainer's weight-gradient stream, however far the pool has wrapped."""
+  from sg2im_amd import ops
+  from sg2im_amd.synthetic import make_vocab
+  from sg2im_amd.trainer import Trainer
+  from tests import hip_harness as hh
+  dev = hh.dev()
+  vocab = make_vocab(184, 7)
+  small = dict(generator_kwargs={'refinement_dims': (64, 32), 'gconv_num_layers': 2, 'gconv_hidden_dim': 64,
+                                 'gconv_dim': 32, 'embedding_dim': 32, 'layout_noise_dim': 0})
+  seen = set()
+  for k in range(24):                 # (> 32 / 4 trainers: the pool wraps several times)
+    tr = Trainer(vocab, dev, use_graphs=True, seed=k, **small)
+    if k % 3 == 0:
+      tr.reducer.force = True         # (a comm lane as well)
+    tr._prepare_lanes(1 << 20)
+    lanes = [tr._cap_stream, tr._side[0], tr._aux2, tr._wgrad_stream] + ([tr._comm] if tr._comm is not None else [])
+    handles = [s.cuda_stream for s in lanes]
+    assert len(set(handles)) == len(handles), (k, handles)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    assert ops._wgrad_streams[(idx, tr._cap_stream.cuda_stream)] is tr._wgrad_stream
+    seen.update(handles)
+  assert len(seen) <= 32              # (the pool did wrap: the situation the test is about)
+
+
 def test_rccl_path_single_rank():
   """The N > 1 code path on one GPU: a 1-rank RCCL group with the gradient all-reduces really
   issued (GradReducer.force), in the eager form (async launch after each backward, wait before Adam)
