@@ -26,7 +26,7 @@ extern "C" {
 #define SG2IM_ERR_ARG 1   /* invalid argument (the reference would raise / assert) */
 #define SG2IM_ERR_HIP 2   /* a HIP runtime call failed; see hipGetLastError() */
 
-int sg2im_abi_version(void);   /* 5 */
+int sg2im_abi_version(void);   /* 6 */
 
 /* Statistics: kernels this library has launched (or recorded into a stream capture) so far in this process;
  * which = 0: all of them, 1: the implicit-GEMM family incl. its split-K finishes.  bench.py reads it around the
@@ -319,6 +319,23 @@ int sg2im_gconv_stack_status(const void* sync_host_copy);
 /* diagnostics: the 100 MHz device-clock stamps workgroup 0 left in the sync area (host copy): kernel start, then
  * (before, after) every grid barrier, then the end; returns the number copied into out[0..max_out) */
 int sg2im_gconv_stack_stamps(const void* sync_host_copy, unsigned long long* out, int max_out);
+
+/* ------------------------------------------------------------------------------------
+ * Two nn.Linear heads over the same row matrix (sg2im/discriminators.py:66-75: AcDiscriminator's real_classifier and
+ * obj_classifier both read the pooled 1024-vector) in one launch per direction:
+ *   forward        y1 [rows][n1] = x w1^T + b1,  y2 [rows][n2] = x w2^T + b2        (b1 / b2 may be NULL)
+ *   backward_data  dx [rows][k]  = g1 w1 + g2 w2     (what autograd sums from the two heads' input gradients)
+ * w1 [n1][k], w2 [n2][k]: nn.Linear layout, 16-byte aligned; k % 4 == 0, k <= 1536, n1 + n2 <= 2048 (sg2im_two_heads_supported);
+ * ldx / lddx multiples of 4.  Fixed summation order.  Weight / bias gradients: sg2im_conv2d_backward_weight[_group]
+ * on the 1x1 geometry, as for every other nn.Linear.
+ * ---------------------------------------------------------------------------------- */
+int sg2im_two_heads_supported(int k, int n1, int n2);
+int sg2im_two_heads_forward(const float* x, long long ldx, int rows, int k, const float* w1, const float* b1, int n1,
+                            const float* w2, const float* b2, int n2, float* y1, long long ld1, float* y2,
+                            long long ld2, hipStream_t stream);
+int sg2im_two_heads_backward_data(const float* g1, long long ldg1, const float* g2, long long ldg2, int rows, int k,
+                                  const float* w1, int n1, const float* w2, int n2, float* dx, long long lddx,
+                                  hipStream_t stream);
 
 /* Up to 16 plain device-to-device copies (sizes and addresses multiples of 4 bytes) in ONE launch: the hand-over
  * of a collated batch (scripts/train.py:514-519 `batch = [tensor.cuda() for tensor in batch]`) into the static

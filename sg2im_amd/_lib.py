@@ -162,6 +162,9 @@ _SIGNATURES = {
   'sg2im_adam_step_guarded': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P, _P],
   'sg2im_adam_prepare_guarded': [_F, _F, _F, _P, _P, _P],
   'sg2im_adam_apply_guarded': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P],
+  'sg2im_two_heads_supported': [_I, _I, _I],
+  'sg2im_two_heads_forward': [_P, _L, _I, _I, _P, _P, _I, _P, _P, _I, _P, _L, _P, _L, _P],
+  'sg2im_two_heads_backward_data': [_P, _L, _P, _L, _I, _I, _P, _I, _P, _I, _P, _L, _P],
 }
 _RESTYPE = {'sg2im_layout_backward_workspace': c_size_t, 'sg2im_crop_backward_workspace': c_size_t,
             'sg2im_launch_count': ctypes.c_ulonglong, 'sg2im_gconv_layer_backward_scratch': c_size_t,

@@ -1,11 +1,16 @@
 """Image / object PatchGAN discriminators (reference sg2im/discriminators.py) on HIP."""
+import os
+
 import torch
 import torch.nn as nn
 
 from . import functional as HF
+from . import ops
 from .bilinear import crop_bbox_batch_nhwc
 from .layers import DiscCnn, GlobalAvgPool, build_cnn
 from .layout import ALIGN_CORNERS
+
+TWO_HEADS = os.environ.get('SG2IM_TWO_HEADS', '1') != '0'      # (A/B knob)
 
 
 class PatchDiscriminator(nn.Module):
@@ -49,8 +54,11 @@ class AcDiscriminator(nn.Module):
     vecs = self.cnn[1](feats)
     fc = self.cnn[2]
     vecs = HF.LinearAct.apply(vecs, fc.weight, fc.bias, 1.0)
-    real = HF.LinearAct.apply(vecs, self.real_classifier.weight, self.real_classifier.bias, 1.0)
-    cls = HF.LinearAct.apply(vecs, self.obj_classifier.weight, self.obj_classifier.bias, 1.0)
+    rc, oc = self.real_classifier, self.obj_classifier
+    if TWO_HEADS and ops.two_heads_supported(vecs.size(1), rc.weight.size(0), oc.weight.size(0)):
+      return HF.TwoHeads.apply(vecs, rc.weight, rc.bias, oc.weight, oc.bias)     # (both heads, one launch)
+    real = HF.LinearAct.apply(vecs, rc.weight, rc.bias, 1.0)
+    cls = HF.LinearAct.apply(vecs, oc.weight, oc.bias, 1.0)
     return real, cls
 
   def forward_nhwc(self, x_nhwc, y, ac_weight=1.0, count=None, share=None):

@@ -183,6 +183,36 @@ class LinearAct(Function):
     return dx, dw, db, None, None
 
 
+class TwoHeads(Function):
+  """(x W1^T + b1, x W2^T + b2): two nn.Linear layers on the same input - AcDiscriminator's real_classifier and
+  obj_classifier (reference sg2im/discriminators.py:66-75) - one launch forward, one for the summed input gradient
+  (csrc/heads.hip); their weight / bias gradients as one grouped launch of the implicit-GEMM family."""
+
+  @staticmethod
+  def forward(ctx, x, W1, b1, W2, b2):
+    if not (x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0):    # (column views are fine)
+      x = x.contiguous()
+    M = x.size(0)
+    y1, y2 = ops.two_heads_forward(x, W1, b1, W2, b2, _new(x, M, W1.size(0)), _new(x, M, W2.size(0)))
+    ctx.save_for_backward(x, W1, b1, W2, b2)
+    return y1, y2
+
+  @staticmethod
+  def backward(ctx, g1, g2):
+    x, W1, b1, W2, b2 = ctx.saved_tensors
+    ni = ctx.needs_input_grad
+    M, K = x.shape
+    g1 = torch.zeros(M, W1.size(0), dtype=x.dtype, device=x.device) if g1 is None else g1.contiguous()
+    g2 = torch.zeros(M, W2.size(0), dtype=x.dtype, device=x.device) if g2 is None else g2.contiguous()
+    dx = ops.two_heads_backward_data(g1, g2, W1, W2, _new(x, M, K)) if ni[0] else None
+    desc = conv_desc([rows_src(x)], M, 1, 1)
+    group = []
+    _, dw1, db1 = _linear_bwd(desc, W1, g1, False, ni[1], ni[2], K, b1, group)
+    _, dw2, db2 = _linear_bwd(desc, W2, g2, False, ni[3], ni[4], K, b2, group)
+    _flush_wgrad_group(group)
+    return dx, dw1, db1, dw2, db2
+
+
 class Mlp2(Function):
   """ReLU(W2 ReLU(W1 x + b1) + b2): build_mlp([D, H, out]) (reference sg2im/model.py:76-78)"""
 

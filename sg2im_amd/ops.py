@@ -486,6 +486,34 @@ def segment_sum(src_a, src_b, csr, width, average, out, accumulate=False):
   return out
 
 
+def two_heads_supported(k, n1, n2):
+  return bool(_lib.load().sg2im_two_heads_supported(int(k), int(n1), int(n2)))
+
+
+def two_heads_forward(x, W1, b1, W2, b2, y1, y2):
+  """y1 = x W1^T + b1, y2 = x W2^T + b2 in one launch (sg2im_two_heads_forward)"""
+  px, ldx = rows_ld(x)
+  p1, ld1 = rows_ld(y1)
+  p2, ld2 = rows_ld(y2)
+  M, K = x.shape
+  n1, n2 = W1.size(0), W2.size(0)
+  _timed('igemm_fwd', 2.0 * M * K * (n1 + n2), lambda: call(
+    'sg2im_two_heads_forward', px, ldx, M, K, _f(W1), _f(b1), n1, _f(W2), _f(b2), n2, p1, ld1, p2, ld2, _stream()))
+  return y1, y2
+
+
+def two_heads_backward_data(g1, g2, W1, W2, dx):
+  """dx = g1 W1 + g2 W2 in one launch (sg2im_two_heads_backward_data)"""
+  p1, ld1 = rows_ld(g1)
+  p2, ld2 = rows_ld(g2)
+  pd, ldd = rows_ld(dx)
+  M, K = dx.shape
+  n1, n2 = W1.size(0), W2.size(0)
+  _timed('igemm_dgrad', 2.0 * M * K * (n1 + n2), lambda: call(
+    'sg2im_two_heads_backward_data', p1, ld1, p2, ld2, M, K, _f(W1), n1, _f(W2), n2, pd, ldd, _stream()))
+  return dx
+
+
 def gather_rows(src, idx, out, csr_for_average=None):
   ps, lds = rows_ld(src)
   po, ldo = rows_ld(out)

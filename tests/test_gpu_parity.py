@@ -52,6 +52,10 @@ def test_linear_layers():
   _run('sec_linear')
 
 
+def test_two_linear_heads_in_one_launch():
+  _run('sec_two_heads')
+
+
 def test_conv_forward_dgrad_wgrad_all_geometries():
   _run('sec_conv')
 

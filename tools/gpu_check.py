@@ -410,6 +410,33 @@ def sec_linear():
     report(tag + ' db', bd.grad, br.grad)
 
 
+def sec_two_heads():
+  """two nn.Linear heads on one input (AcDiscriminator's real / class heads, discriminators.py:66-75) in one launch
+  per direction vs torch; ragged row counts (the last workgroup of 4 rows), a column view with a row stride as x"""
+  g = torch.Generator().manual_seed(12)
+  for (M, K, n1, n2, wide) in ((203, 1024, 1, 184, False), (7, 20, 3, 5, False), (224, 256, 1, 10, True), (1, 1536, 2, 1, False)):
+    xw = torch.randn(M, K + (12 if wide else 0), generator=g)
+    x = xw[:, :K]
+    W1 = torch.randn(n1, K, generator=g) / K ** 0.5
+    W2 = torch.randn(n2, K, generator=g) / K ** 0.5
+    b1, b2 = torch.randn(n1, generator=g), torch.randn(n2, generator=g)
+    ref = [t.clone().requires_grad_(True) for t in (x, W1, b1, W2, b2)]
+    y1, y2 = F.linear(ref[0], ref[1], ref[2]), F.linear(ref[0], ref[3], ref[4])
+    g1, g2 = torch.randn(M, n1, generator=g), torch.randn(M, n2, generator=g)
+    torch.autograd.backward([y1, y2], [g1, g2])
+    assert ops.two_heads_supported(K, n1, n2)
+    xd = xw.to(D)[:, :K].detach().requires_grad_(True) if wide else x.clone().to(D).requires_grad_(True)
+    dev = [xd] + [t.clone().to(D).requires_grad_(True) for t in (W1, b1, W2, b2)]
+    z1, z2 = HF.TwoHeads.apply(*dev)
+    torch.autograd.backward([z1, z2], [g1.to(D), g2.to(D)])
+    tag = 'two heads %dx%d -> %d + %d%s' % (M, K, n1, n2, ' (strided x)' if wide else '')
+    report(tag + ' y1', z1, y1)
+    report(tag + ' y2', z2, y2)
+    for name, a, b in zip(('dx', 'dW1', 'db1', 'dW2', 'db2'), dev, ref):
+      report(tag + ' ' + name, a.grad, b.grad)
+  assert not ops.two_heads_supported(1022, 1, 4) and not ops.two_heads_supported(2048, 1, 4)
+
+
 def sec_pool():
   g = torch.Generator().manual_seed(3)
   for (T, O, H, Dd) in ((700, 9, 24, 8), (342, 203, 512, 128), (5, 4, 6, 3)):
