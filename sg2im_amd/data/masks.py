@@ -4,7 +4,7 @@
 same way through pycocotools.mask): a list of polygons, an uncompressed RLE ({'counts': [..], 'size': [h, w]}) and a
 compressed RLE ({'counts': '<string>', 'size': [h, w]}).
 
-Deviations from the reference's third-party code (documented, not pinned - see data/__init__.py):
+Deviations from the reference's third-party code (third-party behaviour, checked against independent re-derivations - see data/__init__.py):
  * polygons are rasterised with PIL.ImageDraw (pixel-centre rule + outline); pycocotools up-samples by 5 and walks
    the boundary: masks can differ in a one-pixel ring along the boundary.  The loader thresholds a 16 x 16 resize
    of the cropped mask, where a ring of boundary pixels rarely flips a cell.

@@ -1,6 +1,6 @@
 """The data front end (sg2im_amd/data, reference sg2im/data/*.py) against its documented contract on tiny on-disk
-datasets (tests/data_fixtures.py).  The reference loaders themselves cannot run here (torchvision / pycocotools /
-skimage / h5py absent), so these are contract tests and independent re-derivations, not reference goldens."""
+datasets (tests/data_fixtures.py).  These are contract tests and independent re-derivations; the comparison with the
+LIVE reference loaders (over stand-ins for the four absent third-party packages) is tests/test_loaders_vs_reference.py."""
 import json
 import math
 import os
