@@ -78,7 +78,7 @@ AFTER_ALL_DEFERRED = None
 HINT_BACKGROUND = 1
 # only the first BG_COUNT released weight gradients are issued as background launches (occupancy cap): the later
 # ones run after the small-kernel tail is over and may have the whole GPU
-BG_COUNT = 6        # [measured: all 11: 8.90-8.94, 8: 8.84, 6: 8.81, 4: 8.82, 2: 8.85 ms]
+BG_COUNT = int(os.environ.get('SG2IM_BG_COUNT', '6'))        # [measured, round 2: all 11: 8.90-8.94, 8: 8.84, 6: 8.81, 4: 8.82, 2: 8.85 ms]
 def _lane(device):
   """Work buffers are per (device, stream): kernels of one in-order stream use them one after
   the other, concurrently running streams (the Trainer's side stream, autograd branches that
