@@ -1,0 +1,15 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+L=gpurun_out/r4_call35.log
+: > $L
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "real_image_passes or shared_pass or graph_replay or trainer_two_steps" 2>&1 | grep -v "^  File" | tail -6 >> $L
+b() { python bench.py --steps 40 --warmup 10 --cpu_baseline_steps 0 --no_roofline 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['ms_per_step'], d['value'])" >> $L; }
+SG2IM_EARLY_REAL_PASS=0 b "real passes in the D steps"
+SG2IM_EARLY_REAL_PASS=1 b "real passes at the head   "
+SG2IM_EARLY_REAL_PASS=0 b "real passes in the D steps"
+SG2IM_EARLY_REAL_PASS=1 b "real passes at the head   "
+SG2IM_MARKS=1 python bench.py --steps 40 --warmup 10 --cpu_baseline_steps 0 --no_roofline 2>&1 >/dev/null | grep '\[mark\]' >> $L
+cat $L
