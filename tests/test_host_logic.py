@@ -395,3 +395,28 @@ def test_deferred_release_reports_the_bucket_only_when_all_its_weight_gradients_
     assert fired == []                    # a bucket parameter that is never released: no early exchange
   finally:
     ops.AFTER_DEFERRED = None
+
+
+def test_shared_pass_adoption_needs_no_kernel_and_rejects_a_foreign_recording():
+  """functional.SharedPass: the second user of a recorded discriminator pass (the discriminator step, over the
+  generated images the generator loss already ran through the same weights) builds its autograd node around the
+  recorded activations without launching anything - so this runs on the CPU - and a recording made by another
+  network / mode is refused."""
+  from sg2im_amd import functional as HF
+  specs = [(4, 8, 2, 0), (4, 16, 2, 0)]
+  y0, y1 = torch.randn(2, 7, 7, 8), torch.randn(2, 2, 2, 16)
+  sp = HF.SharedPass()
+  assert not sp.recorded
+  sp.saved = [(None, None, y0, None, 16, 16, None, None), (None, None, y1, None, 7, 7, None, None)]
+  sp.misc = (specs, 0.2, 2, (2, 16, 16, 3), True, False, None)       # (training = 2: recorded as a pass that counts twice)
+  assert sp.recorded
+  params = [torch.randn(8, 4, 4, 3, requires_grad=True), torch.randn(8, requires_grad=True),
+            torch.randn(16, 4, 4, 8, requires_grad=True), torch.randn(16, requires_grad=True)]
+  out = HF.DiscCnnFn.apply(None, None, specs, 0.2, True, None, sp, *params)
+  assert out.data_ptr() == y1.data_ptr() and out.requires_grad and out.grad_fn is not None
+  with pytest.raises(RuntimeError):
+    HF.DiscCnnFn.apply(None, None, specs, 0.1, True, None, sp, *params)          # another activation slope
+  with pytest.raises(RuntimeError):
+    HF.DiscCnnFn.apply(None, None, specs[:1], 0.2, True, None, sp, *params[:2])  # another architecture
+  with pytest.raises(RuntimeError):
+    HF.DiscCnnFn.apply(None, None, specs, 0.2, False, None, sp, *params)         # eval mode
