@@ -537,6 +537,7 @@ struct TileWalk {
   }
 };
 
+#ifndef SG2IM_PERSIST_HELPERS_ONLY      // (disc_persist.hip includes this file for everything above: barrier, loaders, tile_gemm)
 // ---- forward tiles -------------------------------------------------------------------------------------------
 // out[M][N] = relu(A W^T + bias), W [N][K] (nn.Linear layout).  KIND 0: A dense [M][K]; 1: the gathered triple input.
 struct FwdStage {
@@ -1055,3 +1056,4 @@ int sg2im_gconv_stack_status(const void* sync_host_copy) {
 }
 
 }  // extern "C"
+#endif  // SG2IM_PERSIST_HELPERS_ONLY

@@ -1181,7 +1181,22 @@ class DiscCnnFn(Function):
     h, w = H, W
     inorm = isinstance(bns, str) and bns == 'instance'    # InstanceNorm2d: no parameters either
     nonorm = bns is None or inorm
-    for i, (k, cout, stride, pad) in enumerate(specs):
+    if ops.DISC_PERSISTENT and not nonorm and training and len(specs) > 1 and ops.disc_stack_supported(specs, Cin):
+      # the whole chain in ONE persistent launch (csrc/disc_persist.hip); what is saved for the backward pass is
+      # what the launch path saves
+      convs = [(params[0], params[1])] + [(params[2 + 4 * (i - 1) + 2], params[2 + 4 * (i - 1) + 3]) for i in range(1, len(specs))]
+      ys, sts = ops.disc_stack_forward(x, specs, [(_cl_weight(Wp), b) for Wp, b in convs], bns, slope, int(training), BN_EPS,
+                                       BN_MOMENTUM, count=count)
+      for i, (k, cout, stride, pad) in enumerate(specs):
+        d = conv_desc([src], N, h, w, k, k, stride, pad)
+        saved.append((src, d, ys[i], sts[i], h, w, None, None))
+        h, w = d.out_h, d.out_w
+        if sts[i] is not None:
+          src = nhwc_src(ys[i], 0, sts[i].scale, sts[i].shift, slope)
+      specs_done = True
+    else:
+      specs_done = False
+    for i, (k, cout, stride, pad) in enumerate(() if specs_done else specs):
       if nonorm:
         Wp, bias = params[2 * i:2 * i + 2]
       elif i == 0:

@@ -12,7 +12,7 @@ from ctypes import byref, c_int, c_longlong, c_void_p
 import torch
 
 from . import _lib
-from ._lib import BnBwd, BnFwd, ConvDesc, GconvGrads, GconvLayer, GconvStack, GconvStackGrads, call
+from ._lib import BnBwd, BnFwd, ConvDesc, DiscStack, GconvGrads, GconvLayer, GconvStack, GconvStackGrads, call
 
 WORKSPACE_BYTES = 256 << 20      # split-K partials / layout-backward partials
 _ws = {}
@@ -636,6 +636,62 @@ def gconv_stack_forward(S, device):
   _note_bytes('igemm_fwd', S._flops / 2.0 / max(S.n_triples + S.n_objs, 1))
   _timed('igemm_fwd', S._flops, lambda: call('sg2im_gconv_stack_forward', byref(S), c_void_p(sy.data_ptr()), sy.numel() * 4,
                                              _stream()))
+
+
+# The discriminator CNNs' forward pass as one persistent launch (csrc/disc_persist.hip).  Off by default: parity-checked
+# on its own (tests: sec_disc_stack), not yet enabled inside the training step.
+DISC_PERSISTENT = os.environ.get('SG2IM_DISC_PERSIST', '0') == '1'
+
+
+def disc_stack_supported(specs, cin0):
+  """specs: [(k, cout, stride, pad), ...] of a DiscCnn, cin0: its input channels"""
+  n = len(specs)
+  if n < 1 or n > _lib.SG2IM_DISC_MAX_LAYERS:
+    return False
+  arr = c_int * n
+  cins = [cin0] + [sp[1] for sp in specs[:-1]]
+  return bool(_lib.load().sg2im_disc_stack_supported(n, arr(*cins), arr(*[sp[1] for sp in specs]), arr(*[sp[0] for sp in specs])))
+
+
+def disc_stack_forward(x, specs, params, bns, slope, training, eps=1e-5, momentum=0.1, count=None):
+  """conv, [BatchNorm, LeakyReLU, conv] ... over the NHWC tensor x in ONE launch (sg2im_disc_stack_forward).
+  params: [(W channels-last, bias)] per convolution; bns: the BatchNorm2d modules between them; training: 1 or n
+  (the running statistics move n times).  Returns ([y_i], [BnState_i])."""
+  N, H, W, C = x.shape
+  S = DiscStack()
+  S.x, S.batch, S.n_layers = x.data_ptr(), N, len(specs)
+  S.eps, S.momentum, S.slope, S.training = float(eps), float(momentum), float(slope), int(training)
+  cp, cu = _count_args(count)
+  S.count, S.count_unit = (cp.value if cp is not None else None), cu
+  ys, sts, keep = [], [], []
+  h, w, c = H, W, C
+  flops = 0.0
+  for i, ((k, cout, stride, pad), (Wp, bias)) in enumerate(zip(specs, params)):
+    L = S.layer[i]
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    y = torch.empty(N, ho, wo, cout, dtype=torch.float32, device=x.device)
+    L.weight, L.bias, L.out = Wp.data_ptr(), _ptr(bias), y.data_ptr()
+    L.cin, L.cout, L.kh, L.kw, L.stride, L.pad = c, cout, k, k, stride, pad
+    L.in_h, L.in_w, L.out_h, L.out_w = h, w, ho, wo
+    if i + 1 < len(specs):
+      bn = bns[i]
+      st = BnState(cout, x.device)
+      nfl = int(_lib.load().sg2im_disc_stack_partial_floats(N, ho, wo, cout))
+      part = torch.empty(nfl, dtype=torch.float32, device=x.device)
+      keep.append(part)
+      L.gamma, L.beta = _ptr(bn.weight), _ptr(bn.bias)
+      L.running_mean, L.running_var, L.num_batches_tracked = _ptr(bn.running_mean), _ptr(bn.running_var), _ptr(bn.num_batches_tracked)
+      L.mean, L.invstd, L.scale, L.shift = st.mean.data_ptr(), st.invstd.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr()
+      L.partial = part.data_ptr()
+      sts.append(st)
+    else:
+      sts.append(None)
+    ys.append(y)
+    flops += 2.0 * N * ho * wo * cout * k * k * c
+    h, w, c = ho, wo, cout
+  sy = sync_area(x.device)
+  _timed('igemm_fwd', flops, lambda: call('sg2im_disc_stack_forward', byref(S), c_void_p(sy.data_ptr()), sy.numel() * 4, _stream()))
+  return ys, sts
 
 
 def gconv_stack_backward(S, g_obj, g_pred, d_triple, d_obj, grads, accumulate, device):

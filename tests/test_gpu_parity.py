@@ -52,6 +52,10 @@ def test_linear_layers():
   _run('sec_linear')
 
 
+def test_discriminator_cnn_forward_in_one_persistent_launch():
+  _run('sec_disc_stack')
+
+
 def test_two_linear_heads_in_one_launch():
   _run('sec_two_heads')
 
