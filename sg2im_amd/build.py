@@ -10,6 +10,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libsg2im_hip.so')
 SOURCES = ['conv.hip', 'graph.hip', 'gconv.hip', 'gcn_persist.hip', 'disc_persist.hip', 'heads.hip', 'norm.hip', 'layout.hip', 'loss.hip']
+INCLUDES = {'disc_persist.hip': ['gcn_persist.hip']}      # (.hip files another translation unit includes)
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
 
 
@@ -33,7 +34,7 @@ def build(force=False, verbose=True, cflags=(), tag=''):
     sp = os.path.join(CSRC, src)
     op = os.path.join(LIBDIR, src.replace('.hip', tag + '.o'))
     objs.append(op)
-    if force or _stale(op, [sp] + headers):
+    if force or _stale(op, [sp] + headers + [os.path.join(CSRC, f) for f in INCLUDES.get(src, ())]):
       cmd = [hipcc] + FLAGS + list(cflags) + ['-c', sp, '-o', op]
       if verbose:
         print(' '.join(cmd), flush=True)
