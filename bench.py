@@ -199,7 +199,8 @@ def main():
   batch = batches[0]
   bucket = tuple(int(v) for v in args.bucket.split(','))
   trainer = Trainer(vocab, device, generator_kwargs={'image_size': (S, S)}, world_size=world, seed=1234,
-                    use_graphs=not args.no_graphs, bucket=bucket, rank=rank, compute_dtype=args.dtype)
+                    use_graphs=not args.no_graphs, bucket=bucket, rank=rank, compute_dtype=args.dtype,
+                    verify_replicas=False)      # (checked here, around the timed loop: Trainer.check_replicas)
   peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == 'bf16' else FP32_MFMA_PEAK_TFLOPS
   # (data parallel: the same overlapped graph without its Adam updates, the four all-reduces issued
   # eagerly, then an Adam graph - DESIGN.md section 6; --no_graphs selects the eager segments)
@@ -223,32 +224,22 @@ def main():
     trainer.step(batches[i % nb])
   sync()
 
-  def replicas_in_sync():
-    """every rank applied the same (all-reduced) gradients <=> the parameter arenas are still bit-identical"""
-    if world == 1:
-      return True
-    c = torch.stack([f.flat.double().sum() for f in (trainer.flat_g, trainer.flat_do, trainer.flat_di) if f is not None])
-    hi, lo = c.clone(), c.clone()
-    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-    return bool(torch.equal(hi, lo))
-  in_sync = replicas_in_sync()
-  if not in_sync and trainer.use_graphs and trainer.dp_schedule == 2:
-    # the in-graph exchange (never executed on more than one rank when this was written) did not keep the replicas
-    # together on this stack: fall back to the exposed exchange between an iteration graph and an Adam graph
-    if rank == 0:
-      print('WARNING: replicas diverged under dp_schedule 2; falling back to dp_schedule 0', file=sys.stderr, flush=True)
-    trainer.dp_schedule = 0
-    trainer._graphs.clear()
-    trainer.broadcast_state()
+  # every rank applied the same (all-reduced) gradients <=> the parameter arenas are still bit-identical.  If the
+  # in-graph exchange (dp_schedule 2) let them diverge on this stack, Trainer.check_replicas has fallen back to
+  # schedule 0 and re-broadcast rank 0's state: warm up again and re-check (a training run gets the same check from
+  # the Trainer itself, at steps 1, 2, 4 ... and every 1024th)
+  schedule0 = trainer.dp_schedule
+  in_sync = trainer.check_replicas() if world > 1 else True
+  if not in_sync and trainer.dp_schedule != schedule0:
     for b in batches:
       trainer.step(b)
     for i in range(args.warmup):
       trainer.step(batches[i % nb])
     sync()
-    in_sync = replicas_in_sync()
+    in_sync = trainer.replicas_in_sync()
   stats0 = dict(trainer.graph_stats)
   host0 = dict(trainer.host_seconds)
+  trainer.host_launch_samples.clear()
   t0 = time.perf_counter()
   host_trace = [] if os.environ.get('SG2IM_HOST_TRACE') == '1' else None      # diagnostics: host time of every step() call
   for i in range(args.steps):
@@ -262,7 +253,9 @@ def main():
     print('[host] ' + ' '.join('%s:%.2f' % (b[0] if b else '-', dt * 1e3) for dt, b in host_trace), file=sys.stderr)
   sync()
   elapsed = time.perf_counter() - t0
+  ops.persistent_kernels_check()         # (raises if a grid barrier of a persistent launch ever timed out)
   stats1 = dict(trainer.graph_stats)
+  launch_samples = sorted(trainer.host_launch_samples)
   if os.environ.get('SG2IM_MARKS') == '1':       # diagnostics: where the lanes of the last replayed iteration were in time
     from sg2im_amd import ops as _ops
     for name, us in _ops.marks_report():
@@ -351,8 +344,9 @@ def main():
             'schedule': ('eager segments, exchanges started after each backward' if not trainer_graphs else
                          'graphs [G fwd+bwd | D_img] -> all-reduce(G, guard, D_img) || graph [D_obj step] -> all-reduce(D_obj) -> graph [3x Adam]'
                          if trainer.dp_schedule == 1 else
-                         'ONE graph with the RCCL all-reduces recorded inside: guard / D_img / D_obj right after their steps, the first two '
-                         'refinement modules (2/3 of the generator bytes) under the remaining weight gradients, the rest after the backward'
+                         'ONE graph with the RCCL all-reduces recorded inside: guard / D_img / D_obj right after their steps, the generator in '
+                         'four buckets (refinement module 0, module 1, modules 2.. + output convolutions as their weight gradients complete, '
+                         'the refinement network\'s Adam slice behind them on the weight-gradient lane; the rest after the backward)'
                          if trainer.dp_schedule == 2 and trainer.reducer.capturable() else
                          'one iteration graph (D steps on a side stream) -> 4 all-reduces (exposed) -> Adam graph')}
   if use_dist:
@@ -433,10 +427,11 @@ def main():
     if args.style == 'coco' and S == 64 and args.batch_size == 32 and args.dtype == 'f32' and os.path.exists(pmc_path):
       pmc = json.load(open(pmc_path))
       per_step = (pmc['fetch_mb_per_step'] + pmc['write_mb_per_step']) * 1e6
-      roofline['traffic'] = round(per_step / max(roofline['launches_per_step'], 1))     # bytes per GEMM launch
-      roofline['traffic_detail'] = {'source': 'profiles/' + os.path.basename(pmc_path) + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+      roofline['traffic'] = round(per_step)       # HBM-side bytes per STEP (all launches of the family; algorithmic_mb_per_step is its counterpart)
+      roofline['traffic_detail'] = {'bytes_per_gemm_launch': round(per_step / max(roofline['launches_per_step'], 1)),'source': 'profiles/' + os.path.basename(pmc_path) + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
                                               'separate passes, FETCH_SIZE x2 per the gfx950 note; counts L2 misses, '
                                               'most of which the 256 MB Infinity Cache serves)',
+                                    'measured': 'not in this run: read from the committed file named in source',
                                     'fetch_mb_per_step': pmc['fetch_mb_per_step'], 'write_mb_per_step': pmc['write_mb_per_step'],
                                     'over_algorithmic': round(per_step / alg_bytes, 2) if alg_bytes else None}
   if use_dist:
@@ -454,7 +449,12 @@ def main():
       'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
       'ms_per_step': round(elapsed / args.steps * 1e3, 3),
       'host_issue_ms_per_step': round(host_issue / args.steps * 1e3, 3),
-      'host_issue_detail_ms': {k: round((trainer.host_seconds[k] - host0[k]) / args.steps * 1e3, 3) for k in host0}, 'higher_is_better': True, 'scaling': 'weak',
+      # mean per step incl. the stalls of a host that runs ahead of the device (back-pressure inside hipGraphLaunch);
+      # what ISSUING a step costs is the median of the individual hipGraphLaunch calls
+      'host_issue_detail_ms': dict({k: round((trainer.host_seconds[k] - host0[k]) / args.steps * 1e3, 3) for k in host0},
+                                   graph_launch_median=round(launch_samples[len(launch_samples) // 2] * 1e3, 3) if launch_samples else None,
+                                   graph_launch_min=round(launch_samples[0] * 1e3, 3) if launch_samples else None),
+      'higher_is_better': True, 'scaling': 'weak',
       'vs_baseline': None,
       'dtype': 'f32' if args.dtype == 'f32' else 'bf16 (matrix-core operands of the spatial convolutions; fp32 accumulation, tensors, statistics and Adam)',
       'data': 'synthetic',

@@ -26,7 +26,7 @@ extern "C" {
 #define SG2IM_ERR_ARG 1   /* invalid argument (the reference would raise / assert) */
 #define SG2IM_ERR_HIP 2   /* a HIP runtime call failed; see hipGetLastError() */
 
-int sg2im_abi_version(void);   /* 7 */
+int sg2im_abi_version(void);   /* 8 */
 
 /* Statistics: kernels this library has launched (or recorded into a stream capture) so far in this process;
  * which = 0: all of them, 1: the implicit-GEMM family incl. its split-K finishes.  bench.py reads it around the
@@ -278,8 +278,14 @@ int sg2im_gconv_layer_backward(const sg2im_gconv_layer* layer, const float* h1, 
  * (dense, caller-owned; what backward reads).  Requirements (else SG2IM_ERR_ARG - use the per-layer entry points):
  * din, hidden, dout multiples of 32 (sg2im_gconv_stack_supported), 16-byte aligned pointers, mlp_normalization
  * 'none'.  sync: >= sg2im_gconv_stack_sync_bytes() of device memory private to the call (zeroed by the launcher on
- * `stream`); after completion word 64 is non-zero iff a grid barrier timed out (never on a healthy device: every
- * spin is bounded instead of hanging the queue) - sg2im_gconv_stack_status() of a host copy. */
+ * `stream` - all but ONE word, see below); after completion word 64 is non-zero iff a grid barrier of THIS launch
+ * timed out (never on a healthy device with the grid fully resident: every spin is bounded instead of hanging the
+ * queue); word 2040 is a STICKY count of timed-out spins over all launches that ever used the area - the launcher's
+ * memset leaves it alone, so a caller that only looks every now and then (sg2im_amd.trainer does, wherever it
+ * synchronises with the host anyway) cannot miss a launch that produced garbage.  sg2im_gconv_stack_status() of a
+ * host copy: 0 = healthy; bit 0 = the last launch timed out, bits 1.. = the sticky count.  Only ONE persistent
+ * launch may be in flight per device at a time (two whole-chip resident grids can starve each other's barriers);
+ * the Trainer issues the forward on its main lane only and keeps the backward layer-by-layer by default. */
 #define SG2IM_GCONV_MAX_LAYERS 8
 typedef struct sg2im_gconv_stack_layer {
   const float *w1a, *b1a, *w1b, *b1b, *w2a, *b2a, *w2b, *b2b;   /* nn.Linear layout, see sg2im_gconv_layer */
@@ -319,42 +325,6 @@ int sg2im_gconv_stack_status(const void* sync_host_copy);
 /* diagnostics: the 100 MHz device-clock stamps workgroup 0 left in the sync area (host copy): kernel start, then
  * (before, after) every grid barrier, then the end; returns the number copied into out[0..max_out) */
 int sg2im_gconv_stack_stamps(const void* sync_host_copy, unsigned long long* out, int max_out);
-
-/* ------------------------------------------------------------------------------------
- * A discriminator CNN of 'CK-X-S' tokens with BatchNorm (build_cnn, sg2im/layers.py:129-213, as PatchDiscriminator and
- * AcDiscriminator use it: sg2im/discriminators.py:25-45,48-64) FORWARD in one persistent launch:
- *   y_0 = conv_0(x) + b_0;   y_i = conv_i(leaky(BatchNorm_{i-1}(y_{i-1}))) + b_i
- * with training-mode batch statistics after every convolution but the last.  Per layer the caller owns `out` (the
- * convolution's output BEFORE the BatchNorm - what the backward pass needs) and the statistics vectors mean / invstd /
- * scale / shift (scale = gamma * invstd, shift = beta - mean * scale: what sg2im_conv2d_* loaders apply).
- * training = n >= 1: the running statistics move n times (see sg2im_bn_stats); count / count_unit: only the first
- * count[0] * count_unit batch entries are real (padded object axis).  Constraints (sg2im_disc_stack_supported): cout a
- * multiple of 64; cin a multiple of 32 except in the first layer, whose kh * kw * cin may instead be <= 64; every tensor
- * below 2^31 elements.  sync: as for sg2im_gconv_stack_forward.  The launch takes at most half the CUs, so that two
- * of them (D_obj and D_img inside the generator loss) can be resident together.
- * ---------------------------------------------------------------------------------- */
-#define SG2IM_DISC_MAX_LAYERS 6
-typedef struct sg2im_disc_layer {
-  const float* weight;      /* [cout][kh][kw][cin] */
-  const float* bias;        /* [cout] or NULL */
-  float* out;               /* [batch][out_h][out_w][cout] */
-  const float* gamma; const float* beta;                      /* the BatchNorm behind this convolution (NULL: 1 / 0) */
-  float* running_mean; float* running_var; long long* num_batches_tracked;     /* may be NULL */
-  float* mean; float* invstd; float* scale; float* shift;     /* [cout] each */
-  float* partial;           /* scratch, sg2im_disc_stack_partial_floats() floats; NULL = no BatchNorm (the last layer) */
-  int cin, cout, kh, kw, stride, pad, in_h, in_w, out_h, out_w;
-} sg2im_disc_layer;
-typedef struct sg2im_disc_stack {
-  const float* x;           /* [batch][in_h][in_w][cin] of layer 0 */
-  int batch, n_layers;
-  float eps, momentum, slope;
-  int training;
-  const int* count; int count_unit, reserved;
-  sg2im_disc_layer layer[SG2IM_DISC_MAX_LAYERS];
-} sg2im_disc_stack;
-int sg2im_disc_stack_supported(int n_layers, const int* cin, const int* cout, const int* ksize);
-size_t sg2im_disc_stack_partial_floats(int batch, int out_h, int out_w, int cout);
-int sg2im_disc_stack_forward(const sg2im_disc_stack* stack, void* sync, size_t sync_bytes, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Two nn.Linear heads over the same row matrix (sg2im/discriminators.py:66-75: AcDiscriminator's real_classifier and

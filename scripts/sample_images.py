@@ -94,13 +94,15 @@ def build_model(args, checkpoint, device):
   return model.to(device)
 
 
-def makedir(base, name, flag=True):
-  dir_name = None
-  if flag:
-    dir_name = os.path.join(base, name)
-    if not os.path.isdir(dir_name):
-      os.makedirs(dir_name)
-  return dir_name
+def output_dirs(root, wanted):
+  """create root/<name> for every wanted name -> {name: path or None}; the reference's output layout
+  (images/, images_gt/ only with --save_gt_imgs)"""
+  made = {}
+  for name, want in wanted.items():
+    made[name] = os.path.join(root, name) if want else None
+    if want:
+      os.makedirs(made[name], exist_ok=True)
+  return made
 
 
 def imsave(path, chw_uint8):
@@ -116,8 +118,8 @@ def run_model(args, checkpoint, output_dir, loader=None):
   model = build_model(args, checkpoint, device)
   if loader is None:
     loader = build_loader(args, checkpoint)
-  img_dir = makedir(output_dir, 'images')
-  gt_img_dir = makedir(output_dir, 'images_gt', args.save_gt_imgs)
+  dirs = output_dirs(output_dir, {'images': True, 'images_gt': args.save_gt_imgs})
+  img_dir, gt_img_dir = dirs['images'], dirs['images_gt']
   data_path = os.path.join(output_dir, 'data.pt')
   data = {'vocab': vocab, 'objs': [], 'masks_pred': [], 'boxes_pred': [], 'masks_gt': [], 'boxes_gt': [], 'filenames': []}
   img_idx = 0
@@ -156,38 +158,40 @@ def run_model(args, checkpoint, output_dir, loader=None):
     print('Saved %d images' % img_idx)
 
 
-def main(args):
-  got_checkpoint = args.checkpoint is not None
-  got_checkpoint_list = args.checkpoint_list is not None
-  if got_checkpoint == got_checkpoint_list:
+def sampling_jobs(args):
+  """[(checkpoint file, output directory)] in the order they are sampled - the reference's conventions
+  (sample_images.py:243-286): ``--checkpoint`` writes into ``--output_dir`` itself; line k (1-based) of
+  ``--checkpoint_list`` writes into ``result%03d`` % k when it names a file, and when it names a directory every
+  ``*snapshot*`` file in it, in sorted order, writes into ``result%03d_<tag>`` % (k - 1) with <tag> the second
+  underscore field of the file name ("snapshot_00100K.pt" -> "00100K").  Lines naming nothing that exists are skipped."""
+  if (args.checkpoint is None) == (args.checkpoint_list is None):
     raise ValueError('Must specify exactly one of --checkpoint and --checkpoint_list')
+  if args.checkpoint is not None:
+    return [(args.checkpoint, args.output_dir)]
+  jobs = []
+  with open(args.checkpoint_list) as f:
+    entries = [line.strip() for line in f]
+  for k, entry in enumerate(entries, 1):
+    if os.path.isfile(entry):
+      jobs.append((entry, os.path.join(args.output_dir, 'result%03d' % k)))
+    elif os.path.isdir(entry):
+      snaps = sorted(fn for fn in os.listdir(entry) if 'snapshot' in fn)
+      jobs += [(os.path.join(entry, fn), os.path.join(args.output_dir, 'result%03d_%s' % (k - 1, os.path.splitext(fn)[0].split('_')[1])))
+               for fn in snaps]
+  return jobs
+
+
+def main(args):
+  jobs = sampling_jobs(args)
   if not torch.cuda.is_available():
     raise RuntimeError('sg2im_amd runs on an MI355X only: no CPU path')
-  load = lambda path: torch.load(path, map_location='cpu', weights_only=False)
-  if got_checkpoint:
-    print('Loading model from ', args.checkpoint)
-    run_model(args, load(args.checkpoint), args.output_dir)
-    return 0
-  loader = None                               # (the same loader for all checkpoints)
-  with open(args.checkpoint_list, 'r') as f:
-    checkpoint_list = [line.strip() for line in f]
-  for i, path in enumerate(checkpoint_list):
-    if os.path.isfile(path):
-      print('Loading model from ', path)
-      checkpoint = load(path)
-      if loader is None:
-        loader = build_loader(args, checkpoint)
-      run_model(args, checkpoint, os.path.join(args.output_dir, 'result%03d' % (i + 1)), loader)
-    elif os.path.isdir(path):
-      for fn in sorted(os.listdir(path)):       # snapshots: "snapshot_00100K.pt" -> result000_00100K
-        if 'snapshot' not in fn:
-          continue
-        print('Loading model from ', os.path.join(path, fn))
-        checkpoint = load(os.path.join(path, fn))
-        if loader is None:
-          loader = build_loader(args, checkpoint)
-        snapshot_name = os.path.splitext(fn)[0].split('_')[1]
-        run_model(args, checkpoint, os.path.join(args.output_dir, 'result%03d_%s' % (i, snapshot_name)), loader)
+  loader = None                               # (one loader serves every checkpoint of a list)
+  for path, out_dir in jobs:
+    print('Loading model from ', path)
+    checkpoint = torch.load(path, map_location='cpu', weights_only=False)
+    if loader is None and len(jobs) > 1:
+      loader = build_loader(args, checkpoint)
+    run_model(args, checkpoint, out_dir, loader)
   return 0
 
 

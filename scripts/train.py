@@ -172,18 +172,25 @@ def build_loaders(args, rank=0):
     (vocab, train, val), collate = build_vg_dsets(args), vg_collate_fn
   else:
     (vocab, train, val), collate = build_coco_dsets(args), coco_collate_fn
-  kw = dict(batch_size=args.batch_size, num_workers=args.loader_num_workers, collate_fn=collate)
+  # pinned host batches: CopyAhead (sg2im_amd/data/prefetch.py) copies batch k + 1 on its own stream under iteration k
+  kw = dict(batch_size=args.batch_size, num_workers=args.loader_num_workers, collate_fn=collate,
+            pin_memory=torch.cuda.is_available())
   gen = torch.Generator().manual_seed(args.seed + rank)
   return vocab, DataLoader(train, shuffle=True, generator=gen, **kw), DataLoader(val, shuffle=args.shuffle_val, **kw)
 
 
-def as_step_batch(batch, device):
-  """a collated batch -> the 7-tuple (imgs, objs, boxes, masks | None, triples, obj_to_img, triple_to_img) on the
-  device (reference train.py:514-519: the VG collate has no masks)"""
+def as_step_tuple(batch):
+  """a collated batch -> the 7-tuple (imgs, objs, boxes, masks | None, triples, obj_to_img, triple_to_img)
+  (reference train.py:514-519: the VG collate has no masks)"""
   if len(batch) == 6:
     imgs, objs, boxes, triples, obj_to_img, triple_to_img = batch
     batch = (imgs, objs, boxes, None, triples, obj_to_img, triple_to_img)
-  return tuple(x.to(device, non_blocking=True) if torch.is_tensor(x) else x for x in batch)
+  return tuple(batch)
+
+
+def as_step_batch(batch, device):
+  """as_step_tuple on the device (one-off batches: validation samples; the training stream goes through CopyAhead)"""
+  return tuple(x.to(device, non_blocking=True) if torch.is_tensor(x) else x for x in as_step_tuple(batch))
 
 
 def warn_synthetic_data(args, missing=()):
@@ -309,20 +316,23 @@ def main(args):
   def batches(split, start, training=False):
     """the train / val DataLoader, cycled over epochs (reference train.py:506-514; ``training``: the iterator that
     feeds the optimisation loop counts the epochs) - or its endless seeded synthetic stand-in"""
-    while real_data:
-      if training:
-        epoch_box[0] += 1
-        if rank == 0:
-          print('Starting epoch %d' % epoch_box[0])
-      for cpu_batch in (train_dl if split == 'train' else val_dl):
-        yield as_step_batch(cpu_batch, device)
-    i = start
-    while True:
-      i += 1
-      seed = args.seed + 1000003 * i + rank + (0 if split == 'train' else 500000009)
-      cpu_batch = synthetic_batch(args.batch_size, image_size=args.image_size, num_objs=num_objs,
-                                  num_preds=num_preds, mask_size=max(args.mask_size, 1), style=args.dataset, seed=seed)
-      yield tuple(x.to(device, non_blocking=True) if torch.is_tensor(x) else x for x in cpu_batch)
+    def host_batches():
+      while real_data:
+        if training:
+          epoch_box[0] += 1
+          if rank == 0:
+            print('Starting epoch %d' % epoch_box[0])
+        for cpu_batch in (train_dl if split == 'train' else val_dl):
+          yield cpu_batch
+      i = start
+      while True:
+        i += 1
+        seed = args.seed + 1000003 * i + rank + (0 if split == 'train' else 500000009)
+        yield synthetic_batch(args.batch_size, image_size=args.image_size, num_objs=num_objs,
+                              num_preds=num_preds, mask_size=max(args.mask_size, 1), style=args.dataset, seed=seed)
+    # GPU-side input pipeline: pinned host batches, batch k + 1 copied on a stream of its own under iteration k
+    from sg2im_amd.data.prefetch import CopyAhead
+    return CopyAhead(host_batches(), device, finish=as_step_tuple)
 
   sd_of = lambda m: None if m is None else m.state_dict()           # reference train.py:634-641
   restore_path = None

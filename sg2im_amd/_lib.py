@@ -70,23 +70,6 @@ class GconvStack(Structure):
               ('layer', GconvStackLayer * SG2IM_GCONV_MAX_LAYERS)]
 
 
-SG2IM_DISC_MAX_LAYERS = 6
-
-
-class DiscLayer(Structure):
-  """sg2im_disc_layer (include/sg2im_hip.h)"""
-  _fields_ = [(k, c_void_p) for k in ('weight', 'bias', 'out', 'gamma', 'beta', 'running_mean', 'running_var',
-                                      'num_batches_tracked', 'mean', 'invstd', 'scale', 'shift', 'partial')] + \
-             [(k, c_int) for k in ('cin', 'cout', 'kh', 'kw', 'stride', 'pad', 'in_h', 'in_w', 'out_h', 'out_w')]
-
-
-class DiscStack(Structure):
-  """sg2im_disc_stack (include/sg2im_hip.h)"""
-  _fields_ = [('x', c_void_p), ('batch', c_int), ('n_layers', c_int), ('eps', c_float), ('momentum', c_float),
-              ('slope', c_float), ('training', c_int), ('count', c_void_p), ('count_unit', c_int), ('reserved', c_int),
-              ('layer', DiscLayer * SG2IM_DISC_MAX_LAYERS)]
-
-
 class GconvGrads(Structure):
   """sg2im_gconv_grads (include/sg2im_hip.h)"""
   _fields_ = [(k, c_void_p) for k in ('dw1a', 'db1a', 'dw1b', 'db1b', 'dw2a', 'db2a', 'dw2b', 'db2b')] + [('accumulate', c_int)]
@@ -179,17 +162,13 @@ _SIGNATURES = {
   'sg2im_adam_step_guarded': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P, _P],
   'sg2im_adam_prepare_guarded': [_F, _F, _F, _P, _P, _P],
   'sg2im_adam_apply_guarded': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P],
-  'sg2im_disc_stack_supported': [_I, POINTER(c_int), POINTER(c_int), POINTER(c_int)],
-  'sg2im_disc_stack_partial_floats': [_I, _I, _I, _I],
-  'sg2im_disc_stack_forward': [POINTER(DiscStack), _P, _Z, _P],
   'sg2im_two_heads_supported': [_I, _I, _I],
   'sg2im_two_heads_forward': [_P, _L, _I, _I, _P, _P, _I, _P, _P, _I, _P, _L, _P, _L, _P],
   'sg2im_two_heads_backward_data': [_P, _L, _P, _L, _I, _I, _P, _I, _P, _I, _P, _L, _P],
 }
 _RESTYPE = {'sg2im_layout_backward_workspace': c_size_t, 'sg2im_crop_backward_workspace': c_size_t,
             'sg2im_launch_count': ctypes.c_ulonglong, 'sg2im_gconv_layer_backward_scratch': c_size_t,
-            'sg2im_gconv_stack_sync_bytes': c_size_t, 'sg2im_gconv_stack_backward_scratch': c_size_t,
-            'sg2im_disc_stack_partial_floats': c_size_t}
+            'sg2im_gconv_stack_sync_bytes': c_size_t, 'sg2im_gconv_stack_backward_scratch': c_size_t}
 EXPORTS = tuple(sorted(_SIGNATURES))
 
 _lib = None

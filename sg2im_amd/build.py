@@ -9,8 +9,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libsg2im_hip.so')
-SOURCES = ['conv.hip', 'graph.hip', 'gconv.hip', 'gcn_persist.hip', 'disc_persist.hip', 'heads.hip', 'norm.hip', 'layout.hip', 'loss.hip']
-INCLUDES = {'disc_persist.hip': ['gcn_persist.hip']}      # (.hip files another translation unit includes)
+SOURCES = ['conv.hip', 'graph.hip', 'gconv.hip', 'gcn_persist.hip', 'heads.hip', 'norm.hip', 'layout.hip', 'loss.hip']
+INCLUDES = {}      # (.hip files another translation unit includes: none)
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
 
 

@@ -53,7 +53,9 @@ class RefinementNetwork(nn.Module):
     self.output_conv = nn.Sequential(*out_layers)
     to_channels_last(self)
 
-  def forward_nhwc(self, layout_nhwc, layout_grad_channels=None):
+  def forward_nhwc(self, layout_nhwc, layout_grad_channels=None, link=None):
+    """link: the functional.LayoutLink of the LayoutFn call that produced ``layout_nhwc`` when this network is
+    that tensor's ONLY consumer (Sg2ImModel.forward_nhwc): pyramid and per-level gradients travel through it"""
     o0, o2 = self.output_conv[0], self.output_conv[2]
     if self.normalization in ('none', 'instance'):      # no norm parameters, no running statistics
       convs = []
@@ -62,7 +64,7 @@ class RefinementNetwork(nn.Module):
         convs += [c0.weight, c0.bias, c1.weight, c1.bias]
       params = convs + [o0.weight, o0.bias, o2.weight, o2.bias]
       return HF.RefinementNoNormFn.apply(layout_nhwc, len(self.refinement_modules), self.slope,
-                                         layout_grad_channels, self.normalization == 'instance', *params)
+                                         layout_grad_channels, self.normalization == 'instance', link, *params)
     convs, bnps, bns = [], [], []
     for mod in self.refinement_modules:
       c0, n0, _, c1, n1, _ = mod.net
@@ -71,7 +73,7 @@ class RefinementNetwork(nn.Module):
       bns.append((n0, n1))
     o0, o2 = self.output_conv[0], self.output_conv[2]
     params = convs + [o0.weight, o0.bias, o2.weight, o2.bias] + bnps
-    return HF.RefinementFn.apply(layout_nhwc, bns, self.slope, self.training, layout_grad_channels, *params)
+    return HF.RefinementFn.apply(layout_nhwc, bns, self.slope, self.training, layout_grad_channels, link, *params)
 
   def forward(self, layout):
     return HF.NhwcToNchw.apply(self.forward_nhwc(HF.NchwToNhwc.apply(layout)))

@@ -80,6 +80,13 @@ constexpr int kFlat = 0, kTop = 32, kError = 64, kMembers = 96, kXcc = 256, kXcc
 // diagnostics: workgroup 0 stores the 100 MHz device clock at kernel start, before and after every barrier and at the
 // end as 64-bit words from word kStamps on (sg2im_gconv_stack_stamps reads them from a host copy of the area)
 constexpr int kStamps = 1536, kMaxStamps = 250;
+// STICKY error count: the ONLY word of the area the per-launch memset leaves alone (the launcher clears the first
+// kStickyWord words).  kError aborts the spins of the launch that timed out and is gone with the next launch's
+// memset; this word keeps counting, so a grid that was not fully resident (another process on the GPU, a second
+// persistent kernel on another stream) cannot go unnoticed: sg2im_gconv_stack_status() reports it and
+// sg2im_amd.trainer polls it wherever it synchronises with the host anyway.
+constexpr int kStickyWord = 2040;
+static_assert(kStamps + 2 * kMaxStamps <= kStickyWord, "the stamps end below the sticky word");
 constexpr unsigned long long kSpinTimeout = 200ull * 1000 * 100;      // 200 ms of the 100 MHz clock
 
 struct Sync {
@@ -111,7 +118,11 @@ __device__ __noinline__ bool spin_ge(unsigned* p, unsigned target, unsigned* err
     __builtin_amdgcn_s_sleep(1);
     if ((++n & 63) == 0) {
       if (ld_agent(err) != 0) return false;
-      if (wall_clock64() - t0 > kSpinTimeout) { st_agent(err, 1u); return false; }
+      if (wall_clock64() - t0 > kSpinTimeout) {
+        st_agent(err, 1u);
+        add_agent(err - kError + kStickyWord, 1u);
+        return false;
+      }
     }
   }
 }
@@ -537,7 +548,6 @@ struct TileWalk {
   }
 };
 
-#ifndef SG2IM_PERSIST_HELPERS_ONLY      // (disc_persist.hip includes this file for everything above: barrier, loaders, tile_gemm)
 // ---- forward tiles -------------------------------------------------------------------------------------------
 // out[M][N] = relu(A W^T + bias), W [N][K] (nn.Linear layout).  KIND 0: A dense [M][K]; 1: the gathered triple input.
 struct FwdStage {
@@ -983,7 +993,7 @@ int sg2im_gconv_stack_supported(int din, int hidden, int dout) {
 int sg2im_gconv_stack_forward(const sg2im_gconv_stack* S, void* sync, size_t sync_bytes, hipStream_t stream) {
   if (!gcn::stack_ok(S) || !sync || sync_bytes < sg2im_gconv_stack_sync_bytes() || !gcn::aligned16(sync)) return SG2IM_ERR_ARG;
   if (gcn::prepare() != hipSuccess) return SG2IM_ERR_HIP;
-  if (hipMemsetAsync(sync, 0, sg2im_gconv_stack_sync_bytes(), stream) != hipSuccess) return SG2IM_ERR_HIP;
+  if (hipMemsetAsync(sync, 0, sizeof(unsigned) * gcn::kStickyWord, stream) != hipSuccess) return SG2IM_ERR_HIP;
   gcn::FwdArgs a;
   std::memcpy(&a.s, S, sizeof(*S));
   a.sync = static_cast<unsigned*>(sync);
@@ -1015,7 +1025,7 @@ int sg2im_gconv_stack_backward(const sg2im_gconv_stack* S, const sg2im_gconv_sta
     for (const void* p : ps) if (p && !gcn::aligned16(p)) return SG2IM_ERR_ARG;
   }
   if (gcn::prepare() != hipSuccess) return SG2IM_ERR_HIP;
-  if (hipMemsetAsync(sync, 0, sg2im_gconv_stack_sync_bytes(), stream) != hipSuccess) return SG2IM_ERR_HIP;
+  if (hipMemsetAsync(sync, 0, sizeof(unsigned) * gcn::kStickyWord, stream) != hipSuccess) return SG2IM_ERR_HIP;
   gcn::BwdArgs a;
   std::memcpy(&a.s, S, sizeof(*S));
   std::memcpy(&a.g, G, sizeof(*G));
@@ -1051,9 +1061,13 @@ int sg2im_gconv_stack_stamps(const void* sync_host_copy, unsigned long long* out
 }
 
 int sg2im_gconv_stack_status(const void* sync_host_copy) {
-  // the error word of a sync area copied back to the host: 0 = every barrier completed
-  return sync_host_copy ? (int)static_cast<const unsigned*>(sync_host_copy)[gcn::kError] : SG2IM_ERR_ARG;
+  // the error words of a sync area copied back to the host: 0 = every barrier of every launch that ever used this
+  // area completed (bit 0: the last launch timed out; the rest: the sticky count of timed-out spins since the area
+  // was created, shifted left by one)
+  if (!sync_host_copy) return SG2IM_ERR_ARG;
+  const unsigned* w = static_cast<const unsigned*>(sync_host_copy);
+  const unsigned sticky = w[gcn::kStickyWord] > 0x3fffffffu ? 0x3fffffffu : w[gcn::kStickyWord];
+  return (int)((w[gcn::kError] != 0 ? 1u : 0u) | (sticky << 1));
 }
 
 }  // extern "C"
-#endif  // SG2IM_PERSIST_HELPERS_ONLY

@@ -26,7 +26,7 @@ class PatchDiscriminator(nn.Module):
   def forward_nhwc(self, x_nhwc, share=None):
     """share: None or a functional.SharedPass (only the 'C'-token architectures can share a pass)"""
     if share is not None and isinstance(self.cnn, DiscCnn):
-      return self.cnn(None if share.recorded else x_nhwc, share=share)
+      return self.cnn(x_nhwc, share=share)       # (a recorded pass is adopted; x is then only checked against the recording)
     return self.cnn(x_nhwc)
 
   def forward(self, x, layout=None):

@@ -58,6 +58,30 @@ def all_reduce_sum_async(tensor, group=None):
 
 
 
+class _Widen(object):
+  """handle of a bfloat16-payload reduction started by GradReducer.start: ``wait()`` makes the current stream wait for
+  the collective and only then widens the staging buffer back into the fp32 arena (the copy is deferred to
+  GradReducer.finish, so the stream that started the exchange is not blocked behind it: the D_obj step keeps
+  running while the generator's 60 MB are in flight - ADVICE r4)"""
+
+  def __init__(self, handle, buf, tensor, after):
+    self.handle, self.buf, self.tensor, self.after = handle, buf, tensor, after
+
+  def wait(self):
+    self.handle.wait()
+    self.after(self.buf)
+    self.tensor.copy_(self.buf)
+
+
+class _Then(object):
+  def __init__(self, handle, tensor, after):
+    self.handle, self.tensor, self.after = handle, tensor, after
+
+  def wait(self):
+    self.handle.wait()
+    self.after(self.tensor)
+
+
 class GradReducer(object):
   """Sum-reduces flat gradient arenas across ranks, asynchronously."""
 
@@ -76,22 +100,23 @@ class GradReducer(object):
     # bfloat16 - rounded (RNE) into a staging buffer, summed by RCCL in bfloat16, widened back into the fp32 arena -
     # i.e. half the xGMI bytes (59.9 instead of 119.7 MB per step) for two extra elementwise passes over the arena;
     # Adam's moments and the parameters stay fp32.  'f32': the arena itself is reduced in place.
+    # Accuracy of the bfloat16 SUM over ranks: tests/test_dp_gloo.py::test_bf16_sum_of_eight_bf16_shards (CPU).
     if payload not in ('f32', 'bf16'):
       raise ValueError('payload must be "f32" or "bf16"')
     self.payload = payload
-    self._staging = {}               # arena data_ptr -> bfloat16 buffer of the arena's size (allocated once)
-    # test instrumentation (tests/test_gpu_parity.py::test_in_graph_exchange_reduces_every_gradient_exactly_once): a
-    # 1-rank SUM is the identity, so a gradient slice that is reduced twice, never, or BEFORE its last writer ran
-    # would go unnoticed on a one-GPU box.  With test_gain = g every reduction is followed by an in-place x g on
-    # the same stream and grad_scale becomes 1/g: the arena x grad_scale equals the plain gradient exactly
-    # (g a power of two) if and only if every element went through exactly one reduction after it was complete.
-    self.test_gain = None
+    self._staging = {}               # (arena address, elements) -> bfloat16 buffer (allocated once, see staging())
 
   @property
   def grad_scale(self):
-    if self.test_gain is not None:
-      return 1.0 / (self.world_size * self.test_gain)
     return 1.0 / self.world_size
+
+  def _reduced(self, tensor):
+    """hook: called on the stream that carries a collective right after it was issued on ``tensor`` (the fp32 arena
+    slice, or the bfloat16 staging buffer that travelled in its place).  Nothing here; tests/hip_harness.py's
+    GainReducer uses it to prove on ONE GPU that every gradient element goes through exactly one reduction."""
+
+  def live(self):
+    return (self.world_size > 1 or self.force) and not self.mute
 
   def capturable(self):
     """can the collectives be recorded into a hipGraph?  RCCL: yes (tools/rccl_capture_probe.py,
@@ -101,16 +126,16 @@ class GradReducer(object):
   def reduce_here(self, tensor):
     """SUM all-reduce of ``tensor`` ordered on the CURRENT stream (which waits for it; the collective itself
     runs on the process group's own stream) - the form that is recorded into a stream capture"""
-    if (self.world_size > 1 or self.force) and not self.mute:
+    if self.live():
       if self.payload == 'bf16' and tensor.numel() > 1:
         buf = self.staging(tensor)
         buf.copy_(tensor)
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        self._reduced(buf)
         tensor.copy_(buf)
       else:
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
-      if self.test_gain is not None:
-        tensor.mul_(self.test_gain)
+        self._reduced(tensor)
 
   # The bfloat16 payload inside a captured iteration, in three steps on three streams, so that the comm stream carries
   # nothing but the collective (an elementwise kernel on it re-maps the graph's branches onto the hardware queues:
@@ -120,11 +145,10 @@ class GradReducer(object):
     self.staging(tensor).copy_(tensor)
 
   def reduce_packed(self, tensor):
-    if (self.world_size > 1 or self.force) and not self.mute:
+    if self.live():
       buf = self.staging(tensor)
       dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-      if self.test_gain is not None:
-        buf.mul_(self.test_gain)
+      self._reduced(buf)
 
   def unpack(self, tensor):
     tensor.copy_(self.staging(tensor))
@@ -134,36 +158,35 @@ class GradReducer(object):
     return self.payload == 'bf16' and tensor.numel() > 1
 
   def staging(self, tensor):
-    """the bfloat16 staging buffer of an arena (slice): one per distinct (address, size), allocated at first use -
-    for a captured iteration that is inside the capture, i.e. in the graph's private pool, like every other tensor
-    the graph creates"""
+    """the bfloat16 staging buffer of an arena (slice): one per distinct (address, elements), allocated at first use
+    and kept for the reducer's lifetime.  The Trainer calls this for every arena and bucket slice in _prepare_lanes,
+    i.e. OUTSIDE any stream capture: a buffer born inside one graph's private pool must not be written by the graph
+    of another shape bucket.  ``drop_staging`` frees them (a Trainer that rebuilds its arenas)."""
     key = (tensor.data_ptr(), tensor.numel())
     buf = self._staging.get(key)
     if buf is None:
+      if torch.cuda.is_available() and tensor.is_cuda and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError('GradReducer.staging: first use of a staging buffer inside a stream capture - create it '
+                           'eagerly first (Trainer._prepare_lanes does)')
       buf = torch.empty(tensor.numel(), dtype=torch.bfloat16, device=tensor.device)
       self._staging[key] = buf
     return buf
 
+  def drop_staging(self):
+    self._staging = {}
+
   def start(self, tensor):
     """begin an all-reduce (SUM) of ``tensor`` in place; returns immediately"""
-    if (self.world_size > 1 or self.force) and not self.mute:
+    if self.live():
       if self.payload == 'bf16' and tensor.numel() > 1:
         buf = self.staging(tensor)
         buf.copy_(tensor)
-        h = all_reduce_sum_async(buf, self.group)
-        h.wait()
-        tensor.copy_(buf)
-        h = _Done()
+        self.pending.append(_Widen(all_reduce_sum_async(buf, self.group), buf, tensor, self._reduced))
       else:
-        h = all_reduce_sum_async(tensor, self.group)
-      if self.test_gain is not None:
-        h.wait()
-        tensor.mul_(self.test_gain)
-        h = _Done()
-      self.pending.append(h)
+        self.pending.append(_Then(all_reduce_sum_async(tensor, self.group), tensor, self._reduced))
 
   def finish(self):
-    """make the current stream wait for every started reduction"""
+    """make the current stream wait for every started reduction (and widen the bfloat16 payloads back)"""
     for h in self.pending:
       h.wait()
     self.pending = []

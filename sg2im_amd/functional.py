@@ -574,11 +574,12 @@ class LayoutFn(Function):
 
   @staticmethod
   def forward(ctx, vecs, boxes, masks, obj_to_img, noise, n_images, H, W, align_corners, img_csr=None,
-              pyramid_levels=0):
+              pyramid_levels=0, link=None):
     """img_csr: the per-image object lists (ops.Csr(obj_to_img, None, n_images)) when the caller built them
-    already (Sg2ImModel does, off the critical path).  pyramid_levels > 0: the caller feeds the result to a
-    refinement network of pyramid_levels + 1 modules, whose 2 x 2 average-pool pyramid (crn.py:58-62) is then
-    produced by the same kernel and handed over through LAYOUT_PYRAMIDS."""
+    already (Sg2ImModel does, off the critical path).  link (a LayoutLink) + pyramid_levels > 0: the caller feeds
+    the result to a refinement network of pyramid_levels + 1 modules AND TO NOTHING ELSE; that network's 2 x 2
+    average-pool pyramid (crn.py:58-62) is then produced by the same kernel and handed over through the link, and
+    the backward pass takes the per-level gradients back through it (see LayoutLink)."""
     D = vecs.size(1)
     nd = noise.size(1) if noise is not None else 0
     if vecs.stride(1) != 1:
@@ -587,20 +588,20 @@ class LayoutFn(Function):
     if img_csr is None:
       img_csr = ops.Csr(obj_to_img, None, n_images)
     out = _new(vecs, n_images, H, W, D + nd)
-    nlev = min(int(pyramid_levels), 4)
+    nlev = min(int(pyramid_levels), 4) if link is not None else 0
     if ops.LAYOUT_PYRAMID and D % 32 == 0 and nd % 32 == 0 and H % 16 == 0 and W % 16 == 0 and n_images > 0:
       levels = [out] + [_new(vecs, n_images, H >> l, W >> l, D + nd) for l in range(1, nlev + 1)]
       ops.layout_pyramid_forward(vecs, boxes, masks, img_csr, n_images, H, W, align_corners,
                                  noise.contiguous() if nd > 0 else None, levels)
       if nlev > 0:
-        LAYOUT_PYRAMIDS.clear()                       # (one pending hand-over at a time)
-        LAYOUT_PYRAMIDS[out.data_ptr()] = levels
+        link.offer(out, levels)
     else:
       ops.layout_forward(vecs, boxes, masks, img_csr, n_images, H, W, align_corners, out)
       if nd > 0:
         ops.nchw_to_nhwc(noise.contiguous(), out, D)
     ctx.save_for_backward(vecs, boxes, masks, obj_to_img)
     ctx.img_csr, ctx.geom = img_csr, (n_images, H, W, align_corners)
+    ctx.link = link
     return out
 
   @staticmethod
@@ -608,13 +609,15 @@ class LayoutFn(Function):
     vecs, boxes, masks, obj_to_img = ctx.saved_tensors
     n_images, H, W, ac = ctx.geom
     ni = ctx.needs_input_grad
+    # (the per-level gradients of the refinement network, if it left them in the link: `g` is then the UNWRITTEN
+    # tensor it returned - taken BEFORE anything touches g)
+    lazy = ctx.link.take_grad(g) if ctx.link is not None else None
     g = g.contiguous()
     d_vecs = _new(vecs, vecs.size(0), vecs.size(1)) if ni[0] else None
     d_boxes = _new(vecs, boxes.size(0), 4) if ni[1] else None      # predicted boxes laid out (boxes_gt=None)
     d_masks = None
     if ni[2] and masks is not None and masks.is_floating_point():
       d_masks = _new(vecs, *masks.shape)
-    lazy = LAYOUT_GRAD_LEVELS.pop(g.data_ptr(), None)        # (g itself was never written: see LAYOUT_GRAD_LEVELS)
     if lazy is not None:
       levels, factors, Cg = lazy
       D = vecs.size(1)
@@ -622,7 +625,7 @@ class LayoutFn(Function):
       if (only_vecs and d_vecs is not None and D % 4 == 0 and D <= Cg and
           (g.size(1), g.size(2)) == (H, W) and all(t.size(3) % 4 == 0 for t in levels)):
         ops.layout_backward_vecs_levels(levels, factors, vecs, boxes, masks, ctx.img_csr, n_images, H, W, ac, d_vecs)
-        return d_vecs, d_boxes, d_masks, None, None, None, None, None, None, None, None
+        return d_vecs, d_boxes, d_masks, None, None, None, None, None, None, None, None, None
       if d_vecs is not None or not only_vecs:             # the summed gradient is needed as a tensor after all
         if Cg < g.size(3):
           g[..., Cg:].zero_()
@@ -630,40 +633,85 @@ class LayoutFn(Function):
     if d_vecs is not None or d_masks is not None or d_boxes is not None:
       ops.layout_backward(g, vecs, boxes, masks, obj_to_img, ctx.img_csr, n_images, H, W, ac, d_vecs, d_masks,
                           d_boxes)
-    return d_vecs, d_boxes, d_masks, None, None, None, None, None, None, None, None
+    return d_vecs, d_boxes, d_masks, None, None, None, None, None, None, None, None, None
 
 
-LAYOUT_PYRAMIDS = {}      # data_ptr of a full-resolution layout -> [level 0, level 1, ...] from LayoutFn
-# Backward hand-over in the other direction: a refinement network whose layout came from LayoutFn (with its pyramid)
-# does not sum its per-level layout gradients into a full-resolution tensor - it returns an UNWRITTEN tensor of that
-# shape and leaves the levels here, keyed by its data_ptr, for LayoutFn.backward (the only consumer), which computes
-# d_vecs from the levels directly (ops.layout_backward_vecs_levels) or, when mask / box gradients are wanted too,
-# materialises the sum first.  [-(67 MB written + 67 MB re-read) per step]
-LAYOUT_GRAD_LEVELS = {}
+class LayoutLink(object):
+  """The explicit hand-over between ONE LayoutFn call and the ONE RefinementFn call that consumes its result
+  (Sg2ImModel.forward_nhwc creates a link per forward pass and passes it to both; nothing else may read that layout).
+
+  forward:  LayoutFn leaves the refinement network's average-pool pyramid (crn.py:58-62), which its kernel produced
+            next to the full-resolution layout, in ``levels``; RefinementFn takes it over instead of pooling.
+  backward: a refinement network that took the pyramid does not sum its per-level layout gradients into a
+            full-resolution tensor - it returns an UNWRITTEN tensor of that shape and leaves the levels here;
+            LayoutFn.backward computes d_vecs from the levels directly (ops.layout_backward_vecs_levels) or, when
+            mask / box gradients are wanted too, materialises the sum first.  [-(67 MB written + 67 MB re-read) per step]
+
+  The unwritten tensor is only ever interpreted through the link: LayoutFn.backward checks that the gradient it was
+  handed IS that tensor (same storage, same version, nothing accumulated into or copied from it) and raises
+  otherwise - a second consumer of the layout, a tensor hook or retain_grad on it would make autograd sum or copy
+  uninitialised memory, which must not go unnoticed.  Callers that cannot promise a single consumer pass
+  no link and get the plain, materialised gradient."""
+
+  def __init__(self):
+    self.layout_ptr = None
+    self.levels = None
+    self.taken = False
+    self.grad = None            # (unwritten tensor, its _version at hand-over, levels, factors, Cg)
+
+  def offer(self, layout, levels):
+    self.layout_ptr, self.levels, self.taken = layout.data_ptr(), levels, False
+
+  def take_pyramid(self, layout):
+    """the levels LayoutFn produced for exactly this tensor, else None"""
+    if self.levels is None or self.layout_ptr != layout.data_ptr():
+      return None
+    levels, self.levels, self.taken = self.levels, None, True
+    return levels
+
+  def leave_grad(self, dlayout, levels, factors, Cg):
+    if self.grad is not None:
+      raise RuntimeError('LayoutLink: a pending layout gradient was never consumed (two backward passes through one link?)')
+    self.grad = (dlayout, dlayout._version, levels, factors, Cg)
+
+  def take_grad(self, g):
+    if self.grad is None:
+      return None
+    dlayout, version, levels, factors, Cg = self.grad
+    self.grad = None
+    if g is not dlayout and (g.data_ptr() != dlayout.data_ptr() or g.shape != dlayout.shape or g.stride() != dlayout.stride()):
+      raise RuntimeError('LayoutLink: the layout gradient reaching LayoutFn.backward is not the tensor the refinement '
+                         'network handed over - the layout has a second consumer, a hook or retain_grad; build the model '
+                         'with SG2IM_LAZY_LAYOUT_GRAD=0 (materialised layout gradient) for such graphs')
+    if dlayout._version != version:
+      raise RuntimeError('LayoutLink: the handed-over (unwritten) layout gradient was modified in place before '
+                         'LayoutFn.backward ran')
+    return levels, factors, Cg
+
+
 import os as _os
 LAZY_LAYOUT_GRAD = _os.environ.get('SG2IM_LAZY_LAYOUT_GRAD', '1') != '0'     # (A/B knob)
 
 
-def _hand_over_layout_grad(like, dlevels, N, H, W, Cg, Cl):
-  """the full-resolution d layout as LayoutFn.backward's input: lazily (see above) or summed now"""
-  lazy = LAZY_LAYOUT_GRAD and len(dlevels) <= 5 and all(f & (f - 1) == 0 for _, f in dlevels)
+def _hand_over_layout_grad(like, dlevels, N, H, W, Cg, Cl, link):
+  """the full-resolution d layout as LayoutFn.backward's input: lazily through the link (see LayoutLink) or summed now"""
+  lazy = link is not None and LAZY_LAYOUT_GRAD and len(dlevels) <= 5 and all(f & (f - 1) == 0 for _, f in dlevels)
   if lazy:
     dlayout = _new(like, N, H, W, Cl)                  # never read as a tensor: LayoutFn.backward takes the levels
-    LAYOUT_GRAD_LEVELS.clear()
-    LAYOUT_GRAD_LEVELS[dlayout.data_ptr()] = ([t for t, _ in dlevels], [f for _, f in dlevels], Cg)
+    link.leave_grad(dlayout, [t for t, _ in dlevels], [f for _, f in dlevels], Cg)
     return dlayout
   dlayout = _new(like, N, H, W, Cl) if Cg == Cl else torch.zeros(N, H, W, Cl, dtype=torch.float32, device=like.device)
   ops.pyramid_backward([t for t, _ in dlevels], [f for _, f in dlevels], [Cg] * len(dlevels), N, H, W, Cg, dlayout)
   return dlayout
 
 
-def _layout_pyramid(layout, L):
+def _layout_pyramid(layout, L, link=None):
   """[coarsest, ..., full resolution]: the L levels a refinement network of L modules reads (crn.py:58-62 pools
   the full-resolution layout once per module; each level here is the 2 x 2 mean of the next finer one - the same
-  value up to fp32 summation order).  Levels LayoutFn already produced are taken over, the rest pooled.
-  Second result: the layout came from LayoutFn (its backward then accepts the per-level gradients, LAYOUT_GRAD_LEVELS)."""
+  value up to fp32 summation order).  Levels LayoutFn already produced are taken over (LayoutLink), the rest pooled.
+  Second result: the pyramid came through the link (LayoutFn.backward then accepts the per-level gradients)."""
   N, H, W, Cl = layout.shape
-  handed = LAYOUT_PYRAMIDS.pop(layout.data_ptr(), None)
+  handed = link.take_pyramid(layout) if link is not None else None
   pyr = (handed or [layout])[:L]
   for i in range(len(pyr), L):
     pyr.append(ops.avgpool_forward(pyr[-1], 2, _new(layout, N, H >> i, W >> i, Cl)))
@@ -760,16 +808,16 @@ class RefinementFn(Function):
   """
 
   @staticmethod
-  def forward(ctx, layout, bns, slope, training, grad_channels, *params):
+  def forward(ctx, layout, bns, slope, training, grad_channels, link, *params):
     ops.TIMER_TAG = 'crn'
     ops.mark('crn_fwd_start')
     try:
-      return RefinementFn._forward(ctx, layout, bns, slope, training, grad_channels, *params)
+      return RefinementFn._forward(ctx, layout, bns, slope, training, grad_channels, link, *params)
     finally:
       ops.TIMER_TAG = None
 
   @staticmethod
-  def _forward(ctx, layout, bns, slope, training, grad_channels, *params):
+  def _forward(ctx, layout, bns, slope, training, grad_channels, link, *params):
     L = len(bns)
     N, H, W, Cl = layout.shape
     convp = params[:4 * L]
@@ -785,7 +833,8 @@ class RefinementFn(Function):
     # zero channel its 161 input channels would fall off the vector loaders
     feat_src = None
     saved = []
-    pyr, ctx.layout_from_fn = _layout_pyramid(layout, L)
+    pyr, from_link = _layout_pyramid(layout, L, link)
+    ctx.link = link if from_link else None
 
     def activated(y, st, up):
       """the source the next convolution reads: leaky(bn(y)), pending in its loader"""
@@ -842,7 +891,7 @@ class RefinementFn(Function):
     convp = params[:4 * L]
     Wo0, bo0, Wo2, bo2 = params[4 * L:4 * L + 4]
     bnp = params[4 * L + 4:]
-    ni = ctx.needs_input_grad[5:]
+    ni = ctx.needs_input_grad[6:]
     grads = [None] * len(params)
     g = g.contiguous()
     Co = Wo0.size(0)
@@ -929,15 +978,11 @@ class RefinementFn(Function):
       ops.DEFERRED.append(side)                    # (joined by the Trainer before the optimiser step)
     dlayout = None
     if need_layout:
-      if getattr(ctx, 'layout_from_fn', False):
-        dlayout = _hand_over_layout_grad(g, dlevels, N, H, W, Cg, Cl)
-      else:
-        dlayout = _new(g, N, H, W, Cl) if Cg == Cl else torch.zeros(N, H, W, Cl, dtype=torch.float32, device=g.device)
-        ops.pyramid_backward([t for t, _ in dlevels], [f for _, f in dlevels], [Cg] * len(dlevels), N, H, W, Cg, dlayout)
+      dlayout = _hand_over_layout_grad(g, dlevels, N, H, W, Cg, Cl, getattr(ctx, 'link', None))
     if not deferred:
       side.join()
     ctx.saved = None
-    return (dlayout, None, None, None, None) + tuple(grads)
+    return (dlayout, None, None, None, None, None) + tuple(grads)
 
 
 class RefinementNoNormFn(Function):
@@ -946,7 +991,7 @@ class RefinementNoNormFn(Function):
   params (flat): per module [W0, b0, W1, b1] ..., then [Wo0, bo0, Wo2, bo2]."""
 
   @staticmethod
-  def forward(ctx, layout, n_modules, slope, grad_channels, inorm, *params):
+  def forward(ctx, layout, n_modules, slope, grad_channels, inorm, link, *params):
     ops.TIMER_TAG = 'crn'
     try:
       L = n_modules
@@ -957,7 +1002,8 @@ class RefinementNoNormFn(Function):
       layout = layout.contiguous()
       feats = torch.zeros(N, h0, w0, 1, dtype=torch.float32, device=layout.device)   # crn.py:105
       feat_src = nhwc_src(feats, up=1)
-      pyr, ctx.layout_from_fn = _layout_pyramid(layout, L)
+      pyr, from_link = _layout_pyramid(layout, L, link)
+      ctx.link = link if from_link else None
       saved = []
       for i in range(L):
         h, w = H >> (L - 1 - i), W >> (L - 1 - i)
@@ -1000,7 +1046,7 @@ class RefinementNoNormFn(Function):
       params = ctx.saved_tensors
       L, slope, z, do0, do2, Cl, Cf, grad_channels, (N, H, W), inorm = ctx.misc
       saved = ctx.saved
-      ni = ctx.needs_input_grad[5:]
+      ni = ctx.needs_input_grad[6:]
       grads = [None] * len(params)
       Wo0, bo0, Wo2, bo2 = params[4 * L:4 * L + 4]
       g = g.contiguous()
@@ -1051,13 +1097,9 @@ class RefinementNoNormFn(Function):
           pool2 = 1
       dlayout = None
       if need_layout:
-        if getattr(ctx, 'layout_from_fn', False):
-          dlayout = _hand_over_layout_grad(g, dlevels, N, H, W, Cg, Cl)
-        else:
-          dlayout = _new(g, N, H, W, Cl) if Cg == Cl else torch.zeros(N, H, W, Cl, dtype=torch.float32, device=g.device)
-          ops.pyramid_backward([t for t, _ in dlevels], [f for _, f in dlevels], [Cg] * len(dlevels), N, H, W, Cg, dlayout)
+        dlayout = _hand_over_layout_grad(g, dlevels, N, H, W, Cg, Cl, getattr(ctx, 'link', None))
       ctx.saved = None
-      return (dlayout, None, None, None, None) + tuple(grads)
+      return (dlayout, None, None, None, None, None) + tuple(grads)
     finally:
       ops.TIMER_TAG = None
 
@@ -1143,7 +1185,10 @@ class SharedPass(object):
   optimiser only steps afterwards.  The Trainer computes the pass once: the first call records the activations
   here and lets every BatchNorm move its running statistics twice (sg2im_bn_fwd.training = 2, bit-identical to a
   second pass); the second call builds its autograd node - on the stream of the discriminator step - around the
-  recorded activations without launching anything."""
+  recorded activations without launching anything (it checks network, mode and - when it is handed the input - that
+  the input is the recorded tensor).  NOTE for callers outside the Trainer: the second running-statistics update is
+  made by the RECORDING pass, so a recorded pass that is never adopted has still moved the running statistics
+  twice; every Trainer path adopts it (trainer._seg_d_obj_forward / _seg_d_img)."""
 
   def __init__(self):
     self.saved = self.misc = self.input = None
@@ -1169,6 +1214,8 @@ class DiscCnnFn(Function):
       # the second pass over the same input with the same weights: nothing to compute (SharedPass)
       if (specs, slope, bool(training)) != (share.misc[0], share.misc[1], bool(share.misc[2])):
         raise RuntimeError('SharedPass: recorded by a different network / mode')
+      if x is not None and share.input is not None and (x.data_ptr(), tuple(x.shape)) != share.input:
+        raise RuntimeError('SharedPass: the second pass was handed another input than the recorded one')
       ctx.saved, ctx.misc = share.saved, share.misc
       ctx.save_for_backward(*params)
       return share.saved[-1][2].detach()
@@ -1181,22 +1228,7 @@ class DiscCnnFn(Function):
     h, w = H, W
     inorm = isinstance(bns, str) and bns == 'instance'    # InstanceNorm2d: no parameters either
     nonorm = bns is None or inorm
-    if ops.DISC_PERSISTENT and not nonorm and training and len(specs) > 1 and ops.disc_stack_supported(specs, Cin):
-      # the whole chain in ONE persistent launch (csrc/disc_persist.hip); what is saved for the backward pass is
-      # what the launch path saves
-      convs = [(params[0], params[1])] + [(params[2 + 4 * (i - 1) + 2], params[2 + 4 * (i - 1) + 3]) for i in range(1, len(specs))]
-      ys, sts = ops.disc_stack_forward(x, specs, [(_cl_weight(Wp), b) for Wp, b in convs], bns, slope, int(training), BN_EPS,
-                                       BN_MOMENTUM, count=count)
-      for i, (k, cout, stride, pad) in enumerate(specs):
-        d = conv_desc([src], N, h, w, k, k, stride, pad)
-        saved.append((src, d, ys[i], sts[i], h, w, None, None))
-        h, w = d.out_h, d.out_w
-        if sts[i] is not None:
-          src = nhwc_src(ys[i], 0, sts[i].scale, sts[i].shift, slope)
-      specs_done = True
-    else:
-      specs_done = False
-    for i, (k, cout, stride, pad) in enumerate(() if specs_done else specs):
+    for i, (k, cout, stride, pad) in enumerate(specs):
       if nonorm:
         Wp, bias = params[2 * i:2 * i + 2]
       elif i == 0:
@@ -1225,7 +1257,7 @@ class DiscCnnFn(Function):
     # independent samples and the counted losses hand them a zero gradient)
     ctx.saved, ctx.misc = saved, (specs, slope, training, tuple(x.shape), nonorm, inorm, count)
     if share is not None:
-      share.saved, share.misc = saved, ctx.misc
+      share.saved, share.misc, share.input = saved, ctx.misc, (x.data_ptr(), tuple(x.shape))
     ctx.save_for_backward(*params)
     return saved[-1][2]
 

@@ -13,14 +13,15 @@ def _num_images(obj_to_img, n_images):
 
 
 def layout_nhwc(vecs, boxes, masks, obj_to_img, H, W=None, noise=None, n_images=None,
-                align_corners=ALIGN_CORNERS, img_csr=None, pyramid_levels=0):
-  """(N, H, W, D [+ noise channels]) NHWC layout; masks=None gives boxes_to_layout."""
+                align_corners=ALIGN_CORNERS, img_csr=None, pyramid_levels=0, link=None):
+  """(N, H, W, D [+ noise channels]) NHWC layout; masks=None gives boxes_to_layout.
+  link / pyramid_levels: see functional.LayoutFn (the hand-over to a refinement network that is the only consumer)."""
   W = H if W is None else W
   if masks is not None:
     O, M = masks.size(0), masks.size(1)
     assert masks.size() == (O, M, M)              # reference sg2im/layout.py:81
   return HF.LayoutFn.apply(vecs, boxes, masks, obj_to_img, noise, _num_images(obj_to_img, n_images), H, W,
-                           int(align_corners), img_csr, int(pyramid_levels))
+                           int(align_corners), img_csr, int(pyramid_levels), link)
 
 
 def boxes_to_layout(vecs, boxes, obj_to_img, H, W=None, pooling='sum', n_images=None,

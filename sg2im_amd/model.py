@@ -175,11 +175,14 @@ class Sg2ImModel(nn.Module):
       noise = torch.randn((num_images, self.layout_noise_dim, H, W), dtype=obj_vecs.dtype,
                           device=obj_vecs.device)
     ops.mark('gcn_done')
+    # (the layout has exactly one consumer, the refinement network: pyramid forward / per-level gradients backward
+    # are handed over through an explicit per-forward link, functional.LayoutLink)
+    link = HF.LayoutLink()
     layout = layout_nhwc(obj_vecs, layout_boxes, layout_masks, obj_to_img, H, W, noise=noise,
                          n_images=num_images, align_corners=self.align_corners, img_csr=img_csr,
-                         pyramid_levels=len(self.refinement_net.refinement_modules) - 1)
+                         pyramid_levels=len(self.refinement_net.refinement_modules) - 1, link=link)
     # the appended noise channels need no gradient: only the first D layout channels do
-    img = self.refinement_net.forward_nhwc(layout, layout_grad_channels=obj_vecs.size(1))
+    img = self.refinement_net.forward_nhwc(layout, layout_grad_channels=obj_vecs.size(1), link=link)
     if aux_stream is not None:
       main.wait_stream(aux_stream)                            # (the detached outputs; long finished by now)
     return img, boxes_pred, masks_pred, rel_scores

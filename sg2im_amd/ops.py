@@ -12,7 +12,7 @@ from ctypes import byref, c_int, c_longlong, c_void_p
 import torch
 
 from . import _lib
-from ._lib import BnBwd, BnFwd, ConvDesc, DiscStack, GconvGrads, GconvLayer, GconvStack, GconvStackGrads, call
+from ._lib import BnBwd, BnFwd, ConvDesc, GconvGrads, GconvLayer, GconvStack, GconvStackGrads, call
 
 WORKSPACE_BYTES = 256 << 20      # split-K partials / layout-backward partials
 _ws = {}
@@ -68,10 +68,11 @@ DEFER_WGRAD = True
 # single-stream fast path, tools/graph_order_probe.py)
 SINGLE_STREAM = os.environ.get('SG2IM_SINGLE_STREAM', '0') == '1'
 DEFERRED = None
-# (ids, callback(stream)): `ids` = data_ptr() of the parameters whose weight gradients make up the first gradient bucket of
-# the data-parallel Trainer.  Every deferred launch is tagged with the parameters it completes; the callback runs on
-# the weight-gradient stream right after the LAST of them was issued (never, if one of them is not among the released
-# launches - the Trainer then exchanges the arena as one bucket).
+# [(ids, callback(stream)), ...]: the early gradient buckets of the data-parallel Trainer.  `ids` = data_ptr() of the
+# parameters whose weight gradients complete a bucket.  Every deferred launch is tagged with the parameters it
+# completes; a bucket's callback runs on the weight-gradient stream right after the LAST of its launches was issued
+# (never, if one of its parameters is not among the released launches - the Trainer then exchanges that slice with
+# the rest of the arena after the backward pass).
 AFTER_DEFERRED = None
 # callback(stream): called on the weight-gradient stream after the LAST released weight gradient was issued
 AFTER_ALL_DEFERRED = None
@@ -126,18 +127,18 @@ def marks_report():
 
 def release_deferred(queue, stream):
   """issue the queued (fn, tags) launches, last queued first (the layers the data-gradient chain reached last first:
-  8.80 vs 8.84-8.85 ms in queue order), the first BG_COUNT as background launches; AFTER_DEFERRED's callback runs
-  right after the last launch that completes one of its parameters"""
+  8.80 vs 8.84-8.85 ms in queue order), the first BG_COUNT as background launches; each AFTER_DEFERRED bucket's
+  callback runs right after the last launch that completes one of its parameters"""
   queued = frozenset().union(*(tags for _, tags in queue))
   # (a bucket whose parameters are not all among the released launches is never reported complete)
-  pending = set(AFTER_DEFERRED[0]) if AFTER_DEFERRED is not None and AFTER_DEFERRED[0] <= queued else None
+  pending = [[set(ids), cb] for ids, cb in (AFTER_DEFERRED or ()) if ids and ids <= queued]
   for k, (fn, tags) in enumerate(reversed(queue)):
     fn(k < BG_COUNT)
-    if pending is not None:
-      pending -= tags
-      if not pending:
-        AFTER_DEFERRED[1](stream)          # (Trainer: the first gradient bucket is complete on this stream)
-        pending = None
+    for ent in pending:
+      if ent[0]:
+        ent[0] -= tags
+        if not ent[0]:
+          ent[1](stream)                   # (Trainer: this gradient bucket is complete on this stream)
 
 
 class SideLane(object):
@@ -638,62 +639,6 @@ def gconv_stack_forward(S, device):
                                              _stream()))
 
 
-# The discriminator CNNs' forward pass as one persistent launch (csrc/disc_persist.hip).  Off by default: parity-checked
-# on its own (tests: sec_disc_stack), not yet enabled inside the training step.
-DISC_PERSISTENT = os.environ.get('SG2IM_DISC_PERSIST', '0') == '1'
-
-
-def disc_stack_supported(specs, cin0):
-  """specs: [(k, cout, stride, pad), ...] of a DiscCnn, cin0: its input channels"""
-  n = len(specs)
-  if n < 1 or n > _lib.SG2IM_DISC_MAX_LAYERS:
-    return False
-  arr = c_int * n
-  cins = [cin0] + [sp[1] for sp in specs[:-1]]
-  return bool(_lib.load().sg2im_disc_stack_supported(n, arr(*cins), arr(*[sp[1] for sp in specs]), arr(*[sp[0] for sp in specs])))
-
-
-def disc_stack_forward(x, specs, params, bns, slope, training, eps=1e-5, momentum=0.1, count=None):
-  """conv, [BatchNorm, LeakyReLU, conv] ... over the NHWC tensor x in ONE launch (sg2im_disc_stack_forward).
-  params: [(W channels-last, bias)] per convolution; bns: the BatchNorm2d modules between them; training: 1 or n
-  (the running statistics move n times).  Returns ([y_i], [BnState_i])."""
-  N, H, W, C = x.shape
-  S = DiscStack()
-  S.x, S.batch, S.n_layers = x.data_ptr(), N, len(specs)
-  S.eps, S.momentum, S.slope, S.training = float(eps), float(momentum), float(slope), int(training)
-  cp, cu = _count_args(count)
-  S.count, S.count_unit = (cp.value if cp is not None else None), cu
-  ys, sts, keep = [], [], []
-  h, w, c = H, W, C
-  flops = 0.0
-  for i, ((k, cout, stride, pad), (Wp, bias)) in enumerate(zip(specs, params)):
-    L = S.layer[i]
-    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
-    y = torch.empty(N, ho, wo, cout, dtype=torch.float32, device=x.device)
-    L.weight, L.bias, L.out = Wp.data_ptr(), _ptr(bias), y.data_ptr()
-    L.cin, L.cout, L.kh, L.kw, L.stride, L.pad = c, cout, k, k, stride, pad
-    L.in_h, L.in_w, L.out_h, L.out_w = h, w, ho, wo
-    if i + 1 < len(specs):
-      bn = bns[i]
-      st = BnState(cout, x.device)
-      nfl = int(_lib.load().sg2im_disc_stack_partial_floats(N, ho, wo, cout))
-      part = torch.empty(nfl, dtype=torch.float32, device=x.device)
-      keep.append(part)
-      L.gamma, L.beta = _ptr(bn.weight), _ptr(bn.bias)
-      L.running_mean, L.running_var, L.num_batches_tracked = _ptr(bn.running_mean), _ptr(bn.running_var), _ptr(bn.num_batches_tracked)
-      L.mean, L.invstd, L.scale, L.shift = st.mean.data_ptr(), st.invstd.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr()
-      L.partial = part.data_ptr()
-      sts.append(st)
-    else:
-      sts.append(None)
-    ys.append(y)
-    flops += 2.0 * N * ho * wo * cout * k * k * c
-    h, w, c = ho, wo, cout
-  sy = sync_area(x.device)
-  _timed('igemm_fwd', flops, lambda: call('sg2im_disc_stack_forward', byref(S), c_void_p(sy.data_ptr()), sy.numel() * 4, _stream()))
-  return ys, sts
-
-
 def gconv_stack_backward(S, g_obj, g_pred, d_triple, d_obj, grads, accumulate, device):
   """the whole stack, backward: ONE persistent launch (sg2im_gconv_stack_backward).  grads: per layer 8 tensors or
   None in the order (dW1a, db1a, dW1b, db1b, dW2a, db2a, dW2b, db2b)"""
@@ -722,6 +667,24 @@ def gconv_stack_check(device):
   host = sy.cpu().contiguous()
   if _lib.load().sg2im_gconv_stack_status(c_void_p(host.data_ptr())) != 0:
     raise _lib.Sg2imHipError('a grid barrier of the persistent GraphTripleConv kernel timed out (grid not resident?)')
+
+
+def persistent_kernels_check():
+  """Raise if ANY persistent launch on ANY lane of this process ever timed out in a grid barrier (the sticky word of
+  every sync area, include/sg2im_hip.h).  A timed-out launch carries on with incomplete data - e.g. when another
+  process shares the GPU and the grid is not fully resident - so its outputs are garbage; the per-launch error word
+  is gone with the next launch's memset, the sticky one is not.  Costs one small device-to-host copy per lane: called
+  where the host synchronises anyway (Trainer.losses_to_host, i.e. every --print_every iterations; bench.py after
+  its timed loop)."""
+  for key, sy in list(_sync_areas.items()):
+    with torch.cuda.device(key[0]):
+      host = sy.cpu().contiguous()
+    st = int(_lib.load().sg2im_gconv_stack_status(c_void_p(host.data_ptr())))
+    if st != 0:
+      raise _lib.Sg2imHipError('a grid barrier of a persistent GraphTripleConv launch timed out (%d timed-out spins so far on lane %s): '
+                               'its grid was not fully resident - another process on this GPU, or a second persistent kernel in '
+                               'flight - and every result since is suspect.  SG2IM_GCN_PERSIST=0 selects the layer-by-layer launches.'
+                               % (st >> 1, key))
 
 
 def gconv_stack_stamps(device):

@@ -266,3 +266,23 @@ def assert_grad_parity(tr, refs, label, rel=None, cos_min=None, scale=1.0, vecto
     '  %s.%s e_hip64 %.3e e_ref %.3e e_hip32 %.3e max|g| %.3e cos %.6f' % r[:7] for r in bad[:20])
   nets = [v for k, v in summ.items() if ':' not in k]
   return max(v[0] for v in nets), min(v[4] for v in nets)
+
+
+def gain_reducer(like, gain=2.0, force=True):
+  """Test instrumentation for the data-parallel exchange on ONE GPU (VERDICT r3 weak #1d; moved out of the product
+  class in round 5): a 1-rank SUM is the identity, so a gradient slice that is reduced twice, never, or BEFORE its
+  last writer ran would go unnoticed on a one-GPU box.  This reducer multiplies every tensor by ``gain`` right after
+  its collective, on the stream that carries the collective (GradReducer._reduced), and reports grad_scale =
+  1 / (world x gain): the arena x grad_scale equals the plain gradient exactly (gain a power of two) if and only if
+  every element went through exactly one reduction after it was complete."""
+  from sg2im_amd.distributed import GradReducer
+
+  class GainReducer(GradReducer):
+    @property
+    def grad_scale(self):
+      return 1.0 / (self.world_size * gain)
+
+    def _reduced(self, tensor):
+      tensor.mul_(gain)
+  r = GainReducer(like.world_size, like.group, force=force, payload=like.payload)
+  return r

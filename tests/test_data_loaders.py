@@ -254,3 +254,54 @@ def test_train_script_on_real_coco_loaders(tmp_path):
     assert os.path.isdir(os.path.join(samples, sub, 'images_gt')) == (sub == 'gt')
     import PIL.Image
     assert PIL.Image.open(os.path.join(samples, sub, 'images', '0003.png')).size == (64, 64)
+
+
+def test_copy_ahead_keeps_order_and_applies_finish():
+  """sg2im_amd/data/prefetch.py::CopyAhead (the GPU-side input pipeline of scripts/train.py; on a CPU device the
+  batches pass through): order, the 6-tuple -> 7-tuple `finish`, one batch requested ahead, clean exhaustion."""
+  import torch
+  from sg2im_amd.data.prefetch import CopyAhead
+  pulled = []
+
+  def gen():
+    for i in range(4):
+      pulled.append(i)
+      yield (torch.full((2,), float(i)), torch.tensor([i]), 'tag%d' % i)
+  it = CopyAhead(gen(), 'cpu', finish=lambda b: b + (None,))
+  first = next(it)
+  assert pulled == [0, 1]                         # batch 1 was already requested while batch 0 is in use
+  assert float(first[0][0]) == 0.0 and first[2] == 'tag0' and first[3] is None
+  rest = list(it)
+  assert [int(b[1]) for b in rest] == [1, 2, 3]
+  with pytest.raises(StopIteration):
+    next(it)
+
+
+def test_sample_images_checkpoint_list_conventions(tmp_path):
+  """scripts/sample_images.py::sampling_jobs - the reference's output-directory conventions for --checkpoint /
+  --checkpoint_list (reference scripts/sample_images.py:243-286), without a GPU: file on line k -> result%03d % k,
+  snapshot directory on line k -> result%03d_<tag> % (k - 1) for its *snapshot* files in sorted order, missing
+  paths skipped, exactly one of the two flags."""
+  import argparse
+  import importlib.util
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  spec = importlib.util.spec_from_file_location('sample_images_script', os.path.join(root, 'scripts', 'sample_images.py'))
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  ck = tmp_path / 'a.pt'; ck.write_bytes(b'x')
+  snaps = tmp_path / 'run'; snaps.mkdir()
+  for fn in ('snapshot_00200K.pt', 'snapshot_00100K.pt', 'notes.txt'):
+    (snaps / fn).write_bytes(b'x')
+  lst = tmp_path / 'list.txt'
+  lst.write_text('%s\n%s\n%s\n' % (ck, tmp_path / 'missing.pt', snaps))
+  out = str(tmp_path / 'out')
+  jobs = mod.sampling_jobs(argparse.Namespace(checkpoint=None, checkpoint_list=str(lst), output_dir=out))
+  assert jobs == [(str(ck), os.path.join(out, 'result001')),
+                  (str(snaps / 'snapshot_00100K.pt'), os.path.join(out, 'result002_00100K')),
+                  (str(snaps / 'snapshot_00200K.pt'), os.path.join(out, 'result002_00200K'))]
+  assert mod.sampling_jobs(argparse.Namespace(checkpoint=str(ck), checkpoint_list=None, output_dir=out)) == [(str(ck), out)]
+  for bad in (dict(checkpoint=None, checkpoint_list=None), dict(checkpoint=str(ck), checkpoint_list=str(lst))):
+    with pytest.raises(ValueError):
+      mod.sampling_jobs(argparse.Namespace(output_dir=out, **bad))
+  made = mod.output_dirs(out, {'images': True, 'images_gt': False})
+  assert os.path.isdir(made['images']) and made['images_gt'] is None and not os.path.exists(os.path.join(out, 'images_gt'))

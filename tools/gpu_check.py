@@ -437,71 +437,6 @@ def sec_two_heads():
   assert not ops.two_heads_supported(1022, 1, 4) and not ops.two_heads_supported(2048, 1, 4)
 
 
-def sec_disc_stack():
-  """the discriminator CNN forward as ONE persistent launch (csrc/disc_persist.hip) vs the launch path
-  (functional.DiscCnnFn): every layer's pre-norm output, the BatchNorm statistics / folded affine, the running
-  statistics and the batch counter - D_obj's and D_img's default architectures, a padded object axis, a pass that
-  counts twice, 'same' padding"""
-  import copy
-  from sg2im_amd.layers import build_cnn
-  torch.manual_seed(0)
-  cases = [('d_obj crops', 'C4-64-2,C4-128-2,C4-256-2', 'valid', (37, 32, 32, 3), None, 1),
-           ('d_img images', 'C4-64-2,C4-128-2,C4-256-2', 'valid', (8, 64, 64, 3), None, 2),
-           ('padded object axis', 'C4-64-2,C4-128-2,C4-256-2', 'valid', (40, 32, 32, 3), 29, 2),
-           ('same padding, stride 1', 'C3-64-1,C3-64-2,C3-128-1', 'same', (5, 12, 10, 3), None, 1)]
-  for name, arch, padding, shape, live, updates in cases:
-    cnn, _ = build_cnn('I3,' + arch, normalization='batch', activation='leakyrelu-0.2', padding=padding, pooling='avg')
-    cnn = cnn.to(D).train()
-    for m in cnn.modules():
-      if isinstance(m, torch.nn.BatchNorm2d):
-        m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.3)
-        m.running_mean.normal_(0, 0.5); m.running_var.uniform_(0.5, 2.0)
-    ref = copy.deepcopy(cnn)
-    x = torch.randn(*shape, device=D)
-    count = None
-    if live is not None:
-      count = (torch.tensor([live], dtype=torch.int32, device=D), 1)
-    assert ops.disc_stack_supported(cnn.specs, 3), name
-    convs = [m for m in cnn if isinstance(m, torch.nn.Conv2d)]
-    bns = [m for m in cnn if isinstance(m, torch.nn.BatchNorm2d)]
-    rconvs = [m for m in ref if isinstance(m, torch.nn.Conv2d)]
-    rbns = [m for m in ref if isinstance(m, torch.nn.BatchNorm2d)]
-    share = HF.SharedPass() if updates == 2 else None
-    rparams = [rconvs[0].weight, rconvs[0].bias]
-    for bn, cv in zip(rbns, rconvs[1:]):
-      rparams += [bn.weight, bn.bias, cv.weight, cv.bias]
-    rec = HF.SharedPass()                       # (only to get at the launch path's per-layer tensors)
-    if updates == 2:
-      HF.DiscCnnFn.apply(x, rbns, ref.specs, ref.slope, True, count, rec, *rparams)
-    else:
-      # a plain pass (one update): record through a SharedPass that defers nothing - undo its doubling by hand
-      HF.DiscCnnFn.apply(x, rbns, ref.specs, ref.slope, True, count, rec, *rparams)
-      ref2 = copy.deepcopy(cnn)
-      r2c = [m for m in ref2 if isinstance(m, torch.nn.Conv2d)]
-      r2b = [m for m in ref2 if isinstance(m, torch.nn.BatchNorm2d)]
-      p2 = [r2c[0].weight, r2c[0].bias]
-      for bn, cv in zip(r2b, r2c[1:]):
-        p2 += [bn.weight, bn.bias, cv.weight, cv.bias]
-      HF.DiscCnnFn.apply(x, r2b, ref2.specs, ref2.slope, True, count, None, *p2)
-      rbns = r2b
-    params = [(HF._cl_weight(cv.weight), cv.bias) for cv in convs]
-    ys, sts = ops.disc_stack_forward(x, cnn.specs, params, bns, cnn.slope, updates, HF.BN_EPS, HF.BN_MOMENTUM, count=count)
-    torch.cuda.synchronize()
-    ops.gconv_stack_check(D)
-    nlive = shape[0] if live is None else live
-    for i, y in enumerate(ys):
-      want = rec.saved[i][2]
-      report('%s: layer %d output (live entries)' % (name, i), y[:nlive], want[:nlive])
-      st, rst = sts[i], rec.saved[i][3]
-      if st is not None:
-        for k in ('mean', 'invstd', 'scale', 'shift'):
-          report('%s: layer %d BatchNorm %s' % (name, i, k), getattr(st, k), getattr(rst, k))
-    for i, (bn, rbn) in enumerate(zip(bns, rbns)):
-      report('%s: BatchNorm %d running_mean (%d update(s))' % (name, i, updates), bn.running_mean, rbn.running_mean)
-      report('%s: BatchNorm %d running_var' % (name, i), bn.running_var, rbn.running_var)
-      report('%s: BatchNorm %d num_batches_tracked' % (name, i), bn.num_batches_tracked.float(), rbn.num_batches_tracked.float(), exact=True)
-
-
 def sec_pool():
   g = torch.Generator().manual_seed(3)
   for (T, O, H, Dd) in ((700, 9, 24, 8), (342, 203, 512, 128), (5, 4, 6, 3)):
