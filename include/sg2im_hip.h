@@ -108,6 +108,17 @@ int sg2im_conv2d_backward_data(const sg2im_conv_desc* desc, const float* weight,
                                const float* dy, int ld_dy, int c_begin, int c_count, float* dx,
                                long long ld_dx, int accumulate, float* workspace,
                                size_t workspace_bytes, hipStream_t stream);
+/* dX of sg2im_conv2d_backward_data (accumulate = 0) multiplied by leaky'_slope of the layer it flows into:
+ *   dx[r][c] *= (act[r * ld_act + c] > 0 ? 1 : slope),   act = that layer's ACTIVATED output, rows / columns as dx
+ * - autograd of  conv(leaky(y))  w.r.t. the pre-activation y (nn.ReLU / nn.LeakyReLU between two layers without a
+ * norm: sg2im/layers.py:216-232 build_mlp, sg2im/graph.py:47-54 net1 / net2, sg2im/crn.py:79-86 output_conv) in the
+ * launches of the data gradient: its epilogue or, with split-K, its finish applies the mask (the arithmetic of
+ * sg2im_act_backward on the finished sum, bit for bit); launches that cannot (<= 4 input channels, the stride-2
+ * parity form) run sg2im_act_backward over dx internally, which then must be dense (ld_dx == c_count). */
+int sg2im_conv2d_backward_data_act(const sg2im_conv_desc* desc, const float* weight, int cout, const float* dy,
+                                   int ld_dy, int c_begin, int c_count, float* dx, long long ld_dx, const float* act,
+                                   long long ld_act, float slope, float* workspace, size_t workspace_bytes,
+                                   hipStream_t stream);
 /* dW[co][kh][kw][c] = sum_pix dY[pix][co] * X[pix (+) tap][c]  (+ dW if accumulate)
  * dbias (optional, may be NULL): dB[co] = sum_pix dY[pix][co]  (+ dB if accumulate) - the
  * bias gradient of the same layer, produced in the same pass over dY. */

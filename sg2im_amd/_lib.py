@@ -91,6 +91,7 @@ _SIGNATURES = {
   'sg2im_launch_count': [_I],
   'sg2im_conv2d_forward': [_D, _P, _I, _P, _F, _P, _L, _I, _P, _Z, _P],
   'sg2im_conv2d_backward_data': [_D, _P, _I, _P, _I, _I, _I, _P, _L, _I, _P, _Z, _P],
+  'sg2im_conv2d_backward_data_act': [_D, _P, _I, _P, _I, _I, _I, _P, _L, _P, _L, _F, _P, _Z, _P],
   'sg2im_conv2d_forward_bn': [_D, _P, _I, _P, _F, _P, _L, _P, _Z, POINTER(BnFwd), _P],
   'sg2im_conv2d_backward_data_bn': [_D, _P, _I, _P, _I, _I, _I, _P, _L, _P, _Z, POINTER(BnBwd), _P],
   'sg2im_bn_backward_apply': [_P, _L, _I, _I, _I, _I, _P, _L, _I, _P, _P, _F, _P, _P, _P, _I, _P],

@@ -639,7 +639,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_dgrad_kernel(const DgradParams 
     if (e2.nsplit > 1) e2.ws += ((size_t)split * 4 + cls) * (size_t)p.M * p.Nc;
     epilogue<BM, BN>(e2, M, p.Nc, p.Nc, m0, n0, wm0, wn0, lane, 0, acc, ParityRow{g.H, g.W, Hc, Wc, ph, pw});
   } else {
-    epilogue<BM, BN>(p.e, M, p.Nc, p.Nc, m0, n0, wm0, wn0, lane, split, acc);
+    if (!ST && p.e.mask != nullptr && p.e.nsplit == 1)      // (workgroup-uniform: sg2im_conv2d_backward_data_act)
+      epilogue<BM, BN, IdentityRow, false, true>(p.e, M, p.Nc, p.Nc, m0, n0, wm0, wn0, lane, split, acc);
+    else
+      epilogue<BM, BN>(p.e, M, p.Nc, p.Nc, m0, n0, wm0, wn0, lane, split, acc);
     if constexpr (ST) {
       if (p.e.nsplit == 1) epilogue_bnbwd<BM, BN>(p.st, M, p.Nc, m0, n0, wm0, wn0, lane, tid, blockIdx.y, acc, smem);
     }
@@ -914,7 +917,8 @@ __global__ void splitk_finish_kernel(const float* __restrict__ ws, int nsplit, l
                                      float* __restrict__ C, long long ldc, const float* __restrict__ bias,
                                      float slope, int accumulate, int SL,
                                      const float* __restrict__ ws2, float* __restrict__ C2, int N2,
-                                     int col_ctot, int col_wtap) {
+                                     int col_ctot, int col_wtap, const float* __restrict__ mask, long long ld_mask,
+                                     float mask_slope) {
   // second, tiny reduction riding along (weight-gradient launches: the bias gradient partials)
   __shared__ float part[256];
   if (C2 != nullptr && blockIdx.x == 0) {
@@ -955,6 +959,7 @@ __global__ void splitk_finish_kernel(const float* __restrict__ ws, int nsplit, l
       const int n = (int)(idx - m * N);
       if (bias) v += bias[n];
       v = leaky(v, slope);
+      if (mask) v *= mask[m * ld_mask + n] > 0.f ? 1.f : mask_slope;                          // (Epi::mask)
       float* dst = C + m * ldc + (col_wtap ? (n / col_ctot) * col_wtap + n % col_ctot : n);   // (Epi::col_*)
       if (accumulate) v += *dst;
       *dst = v;
@@ -968,11 +973,12 @@ struct FinishArgs {
   const float* ws; int nsplit; long long MN; int N; float* C; long long ldc; const float* bias; float slope;
   int accumulate; const float* ws2; float* C2; int N2;
 };
+struct FinishMask { const float* act; long long ld; float slope; };        // Epi::mask for the finish kernels (act: may be null)
 __device__ __forceinline__ void splitk_finish_v4_body(const float* __restrict__ ws, int nsplit, long long MN, int N,
                                                       float* __restrict__ C, long long ldc,
                                                       const float* __restrict__ bias, float slope, int accumulate,
                                                       const float* __restrict__ ws2, float* __restrict__ C2, int N2,
-                                                      const int blk, const int nblk) {
+                                                      const int blk, const int nblk, const FinishMask fm = FinishMask{nullptr, 0, 1.f}) {
   if (C2 != nullptr && blk == 0) {
     __shared__ float part[256];
     constexpr int SLB = 8, PERB = 256 / SLB;
@@ -1007,6 +1013,11 @@ __device__ __forceinline__ void splitk_finish_v4_body(const float* __restrict__ 
       v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
     }
     v.x = leaky(v.x, slope); v.y = leaky(v.y, slope); v.z = leaky(v.z, slope); v.w = leaky(v.w, slope);
+    if (fm.act) {
+      const float4 a = *reinterpret_cast<const float4*>(fm.act + m * fm.ld + n);
+      v.x *= a.x > 0.f ? 1.f : fm.slope; v.y *= a.y > 0.f ? 1.f : fm.slope;
+      v.z *= a.z > 0.f ? 1.f : fm.slope; v.w *= a.w > 0.f ? 1.f : fm.slope;
+    }
     float4* dst = reinterpret_cast<float4*>(C + m * ldc + n);
     if (accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
     *dst = v;
@@ -1016,8 +1027,8 @@ __device__ __forceinline__ void splitk_finish_v4_body(const float* __restrict__ 
 __global__ void splitk_finish_v4_kernel(const float* __restrict__ ws, int nsplit, long long MN, int N,
                                         float* __restrict__ C, long long ldc, const float* __restrict__ bias,
                                         float slope, int accumulate,
-                                        const float* __restrict__ ws2, float* __restrict__ C2, int N2) {
-  splitk_finish_v4_body(ws, nsplit, MN, N, C, ldc, bias, slope, accumulate, ws2, C2, N2, blockIdx.x, gridDim.x);
+                                        const float* __restrict__ ws2, float* __restrict__ C2, int N2, const FinishMask fm) {
+  splitk_finish_v4_body(ws, nsplit, MN, N, C, ldc, bias, slope, accumulate, ws2, C2, N2, blockIdx.x, gridDim.x, fm);
 }
 
 // the finishes of a grouped launch (conv_wgrad_group_kernel) in one grid
@@ -1473,17 +1484,18 @@ static hipError_t finish_split(const Epi& e, long long M, int N, hipStream_t st,
   // 64 x 576 weight gradient took 19 us with 2 split lanes)
   while (SL < 16 && 2 * SL <= e.nsplit / 4 && (MN * SL + 255) / 256 < 8 * g_num_cu) SL *= 2;
   const bool v4 = SL == 1 && N % 4 == 0 && e.ldc % 4 == 0 && !((uintptr_t)e.ws & 15) && !((uintptr_t)e.C & 15) &&
-                  (!e.bias || !((uintptr_t)e.bias & 15)) && e.col_wtap == 0;
+                  (!e.bias || !((uintptr_t)e.bias & 15)) && e.col_wtap == 0 &&
+                  (!e.mask || (e.ld_mask % 4 == 0 && !((uintptr_t)e.mask & 15)));
   if (v4) {
     const int blocks4 = (int)std::min<long long>((MN / 4 + 255) / 256, 4096);
     SG2IM_LAUNCH(splitk_finish_v4_kernel, dim3(blocks4), dim3(256), 0, st, e.ws, e.nsplit, MN, N, e.C, e.ldc,
-                       e.bias, e.slope, e.accumulate, ws2, C2, N2);
+                       e.bias, e.slope, e.accumulate, ws2, C2, N2, (FinishMask{e.mask, e.ld_mask, e.mask_slope}));
     return hipGetLastError();
   }
   const int per = 256 / SL;
   const int blocks = (int)std::min<long long>((MN + per - 1) / per, 4096);
   SG2IM_LAUNCH(splitk_finish_kernel, dim3(blocks), dim3(256), 0, st, e.ws, e.nsplit, MN, N, e.C, e.ldc,
-                     e.bias, e.slope, e.accumulate, SL, ws2, C2, N2, e.col_ctot, e.col_wtap);
+                     e.bias, e.slope, e.accumulate, SL, ws2, C2, N2, e.col_ctot, e.col_wtap, e.mask, e.ld_mask, e.mask_slope);
   return hipGetLastError();
 }
 
@@ -1864,11 +1876,14 @@ int sg2im_conv2d_forward_bn(const sg2im_conv_desc* d, const float* weight, int c
 
 // bb != nullptr: followed by the reductions + coefficient set-up of a BatchNorm backward over dx
 // (sg2im_conv2d_backward_data_bn)
+// am: optional activation mask of the result (sg2im_conv2d_backward_data_act; never together with bb)
+struct ActMask { const float* act; long long ld; float slope; };
 static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int cout, const float* dy,
                            int ld_dy, int c_begin, int c_count, float* dx, long long ld_dx,
                            int accumulate, float* workspace, size_t workspace_bytes, const sg2im_bn_bwd* bb,
-                           hipStream_t stream) {
+                           hipStream_t stream, const ActMask* am = nullptr) {
   if (!d || !weight || !dy || !dx || cout < 1 || c_count < 1 || ld_dy < cout) return SG2IM_ERR_ARG;
+  if (am && (bb || accumulate || !am->act || am->ld < c_count)) return SG2IM_ERR_ARG;
   if (check_desc(d)) return SG2IM_ERR_ARG;
   DgradParams p;
   p.st = StatSink{};
@@ -1891,6 +1906,13 @@ static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int co
     const int f = bb->pool2 ? 2 : 1;
     return bn_bwd_standalone(dx, ld_dx, bb->pool2, d->batch, d->in_h / f, d->in_w / f, c_count, bb, stream);
   };
+  // launches that cannot apply the activation mask themselves (few-channel gathers, the stride-2 parity form): the
+  // elementwise pass over the finished dx (in place; needs a dense dx)
+  auto mask_after = [&]() -> int {
+    if (!am) return SG2IM_OK;
+    if (ld_dx != c_count) return SG2IM_ERR_ARG;
+    return sg2im_act_backward(dx, ld_dx, 0, d->batch, d->in_h, d->in_w, am->act, am->ld, c_count, am->slope, dx, stream);
+  };
   if (c_count <= 4 && (size_t)taps * cout * c_count * sizeof(float) <= 48 * 1024) {
     const size_t lds = (size_t)taps * cout * c_count * sizeof(float);
     // at most 2 x 2 taps per pixel, 16-byte dY loads
@@ -1905,6 +1927,7 @@ static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int co
       if (c_count == 1) SG2IM_FEWQ(1); else if (c_count == 2) SG2IM_FEWQ(2); else if (c_count == 3) SG2IM_FEWQ(3);
       else SG2IM_FEWQ(4);
 #undef SG2IM_FEWQ
+      if (am) return hipGetLastError() == hipSuccess ? mask_after() : SG2IM_ERR_HIP;
       return hipGetLastError() == hipSuccess ? bn_after() : SG2IM_ERR_HIP;
     }
     dim3 grid((unsigned)((Mfull + 255) / 256));
@@ -1915,6 +1938,7 @@ static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int co
     if (c_count == 1) SG2IM_FEWC(1); else if (c_count == 2) SG2IM_FEWC(2); else if (c_count == 3) SG2IM_FEWC(3);
     else SG2IM_FEWC(4);
 #undef SG2IM_FEWC
+    if (am) return hipGetLastError() == hipSuccess ? mask_after() : SG2IM_ERR_HIP;
     return hipGetLastError() == hipSuccess ? bn_after() : SG2IM_ERR_HIP;
   }
   const bool va4 = (cout % 4 == 0) && (ld_dy % 4 == 0) && !((uintptr_t)dy & 15);
@@ -1927,6 +1951,7 @@ static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int co
     q.g = g; q.Wt = weight; q.N = c_count; q.c_begin = c_begin; q.nchunks = (cout + BK - 1) / BK;
     q.tiles_x = d->in_w / hp.ct; q.tiles_y = d->in_h / hp.rt; q.M = (int)Mfull;
     q.e = Epi{dx, ld_dx, nullptr, 1.f, 0, workspace, hp.nsplit};
+    if (am) { q.e.mask = am->act; q.e.ld_mask = am->ld; q.e.mask_slope = am->slope; }     // (epilogue, or the split-K finish)
     q.st = StatSink{};
     const long long bn_rows_h = bb ? (bb->pool2 ? Mfull / 4 : Mfull) : 0;
     const bool st_h = g_fuse_bn && bb && !bb->count && bb->partial && al16p(bb->partial) &&
@@ -1982,6 +2007,7 @@ static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int co
                             iters_eff, MNslab, workspace_bytes, 4);
   }
   p.e = Epi{dx, ld_dx, nullptr, 1.f, accumulate, workspace, pl.nsplit};
+  if (am && !p.parity) { p.e.mask = am->act; p.e.ld_mask = am->ld; p.e.mask_slope = am->slope; }
   hipError_t err;
   // BatchNorm-backward sums of dx from the same launches (data-gradient epilogue or split-K finish)
   const long long bn_rows = bb ? (bb->pool2 ? Mfull / 4 : Mfull) : 0;
@@ -2020,8 +2046,10 @@ static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int co
     const int blocks = (int)std::min<long long>((per_split + 255) / 256, 4096);
     SG2IM_LAUNCH(splitk_finish_parity_kernel, dim3(blocks), dim3(256), 0, stream, workspace, pl.nsplit, p.M,
                        c_count, dx, ld_dx, accumulate, d->batch, d->in_h, d->in_w);
+    if (am) return hipGetLastError() == hipSuccess ? mask_after() : SG2IM_ERR_HIP;
     return hipGetLastError() == hipSuccess ? bn_after() : SG2IM_ERR_HIP;
   }
+  if (p.parity && am) return mask_after();                  // (parity form without split-K: its epilogue has no mask)
   if (st_ok && pl.nsplit > 1 && ld_dx % 4 == 0 && al16p(dx) && al16p(workspace) && bb->ld_y % 4 == 0 && al16p(bb->y) &&
       al16p(bb->mean) && al16p(bb->invstd) && al16p(bb->scale) && al16p(bb->shift)) {
     int nblk, nslab; long long per;
@@ -2052,6 +2080,15 @@ int sg2im_conv2d_backward_data_bn(const sg2im_conv_desc* d, const float* weight,
   if (!bb || !bb->y || !bb->mean || !bb->invstd || !bb->scale || !bb->shift || !bb->coef || !bb->partial) return SG2IM_ERR_ARG;
   if (bb->ld_y < c_count) return SG2IM_ERR_ARG;
   return conv_dgrad_impl(d, weight, cout, dy, ld_dy, c_begin, c_count, dx, ld_dx, 0, workspace, workspace_bytes, bb, stream);
+}
+
+int sg2im_conv2d_backward_data_act(const sg2im_conv_desc* d, const float* weight, int cout, const float* dy,
+                                   int ld_dy, int c_begin, int c_count, float* dx, long long ld_dx, const float* act,
+                                   long long ld_act, float slope, float* workspace, size_t workspace_bytes,
+                                   hipStream_t stream) {
+  const ActMask am{act, ld_act, slope};
+  return conv_dgrad_impl(d, weight, cout, dy, ld_dy, c_begin, c_count, dx, ld_dx, 0, workspace, workspace_bytes, nullptr,
+                         stream, &am);
 }
 
 int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int ld_dy, int cout,

@@ -59,7 +59,9 @@ struct ChunkCursor {
 // H: bf16 operand path (igemm.h): both LDS images hold bf16 (halo [pixel][32 + 8], weights [BN][32 + 8] resp.
 // k-major [32][BN + 32] read with the transposing ds_read_b64_tr_b16), v_mfma_f32_32x32x16_bf16, fp32 accumulate
 template <int RT, int CT, int BN, bool DG, bool ST, bool H = false>
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BN == 64 && CT <= 32) ? SG2IM_HALO_WAVES64 : 2)))
+// (the fp32 4 x 32 data-gradient form - 7 halo float4 per thread, maps that 8 x 16 patches do not tile - needs 130
+// registers: three waves per SIMD instead of a spilled offset that is reloaded every chunk)
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BN == 64 && CT <= 32) ? ((RT == 4 && DG && !H) ? 3 : SG2IM_HALO_WAVES64) : 2)))
 void conv_halo_kernel(const HaloParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BM = RT * CT;
@@ -75,6 +77,7 @@ void conv_halo_kernel(const HaloParams p) {
   bf16_t* const Bsh = reinterpret_cast<bf16_t*>(smem + AF);
   const ConvGeom& g = p.g;
   const int tid = threadIdx.x;
+  const int s_wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: a scalar register)
   const int n0 = blockIdx.x * BN, split = blockIdx.z;
   int tile = blockIdx.y;
   const int tx = tile % p.tiles_x; tile /= p.tiles_x;
@@ -105,7 +108,9 @@ void conv_halo_kernel(const HaloParams p) {
     const int Hs = g.H >> S.up, Ws = g.W >> S.up;
     #pragma unroll
     for (int j = 0; j < NA; ++j) {
-      const int hp = r0 + 32 * j;
+      int hp = r0 + 32 * j;
+      asm volatile("" : "+v"(hp));    // (opaque: keeps the compiler from holding the prologue's hr / hc of every j live
+                                      // across the main loop for this rarely executed block - spilled registers otherwise)
       const int hr = hp / HWD, hc = hp - hr * HWD;
       const int ay = (amask >> j & 1u) ? y0 - 1 + hr : 0, ax = (amask >> j & 1u) ? x0 - 1 + hc : 0;
       aoff[j] = (unsigned)((nb * Hs + (ay >> S.up)) * Ws + (ax >> S.up)) * (unsigned)S.ld;
@@ -304,12 +309,21 @@ void conv_halo_kernel(const HaloParams p) {
     }
   }
 
+  // The epilogue's thread coordinates are RE-DERIVED here (lane from mbcnt, the wave's tile origin from a scalar)
+  // instead of being kept alive across the main loop: at the 128-register budget of the 64-column forms that cost
+  // two or three spilled registers (scratch stores in the prologue, reloads here).
+  const int e_lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int e_wm0 = (s_wave >> 1) * (BM / 2), e_wn0 = (s_wave & 1) * (BN / 2);
+  const int e_tid = s_wave * 64 + e_lane;
   const PatchRow<CT> rowmap{nb, g.H, g.W, y0, x0};
-  epilogue<BM, BN, PatchRow<CT>, true>(p.e, p.M, p.N, p.N, 0, n0, wm0, wn0, lane, split, acc, rowmap);
+  if (DG && p.e.mask != nullptr && p.e.nsplit == 1)       // (workgroup-uniform; the activation mask of sg2im_conv2d_backward_data_act)
+    epilogue<BM, BN, PatchRow<CT>, true, true>(p.e, p.M, p.N, p.N, 0, n0, e_wm0, e_wn0, e_lane, split, acc, rowmap);
+  else
+    epilogue<BM, BN, PatchRow<CT>, true>(p.e, p.M, p.N, p.N, 0, n0, e_wm0, e_wn0, e_lane, split, acc, rowmap);
   if constexpr (ST) {
     if (p.e.nsplit == 1) {
-      if (!DG) epilogue_stats<BM, BN>(p.e, p.st, BM, p.N, 0, n0, wm0, wn0, lane, tid, blockIdx.y, acc, smem);
-      else epilogue_bnbwd<BM, BN, PatchRow<CT>>(p.st, BM, p.N, 0, n0, wm0, wn0, lane, tid, blockIdx.y, acc, smem, rowmap);
+      if (!DG) epilogue_stats<BM, BN>(p.e, p.st, BM, p.N, 0, n0, e_wm0, e_wn0, e_lane, e_tid, blockIdx.y, acc, smem);
+      else epilogue_bnbwd<BM, BN, PatchRow<CT>>(p.st, BM, p.N, 0, n0, e_wm0, e_wn0, e_lane, e_tid, blockIdx.y, acc, smem, rowmap);
     }
   }
 }

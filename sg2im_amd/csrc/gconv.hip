@@ -5,10 +5,14 @@
 // stream, with caller-provided activation / scratch buffers (no allocation, no state).  A host that is not
 // Python binds two functions per layer instead of re-creating the sequence.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstring>
 #include "sg2im_hip.h"
 
 namespace {
+
+// A/B knob (SG2IM_FUSE_ACT_BWD=0): the ReLU backward behind a data gradient as a launch of its own (rounds 1-4)
+const bool g_fuse_act = !(getenv("SG2IM_FUSE_ACT_BWD") && atoi(getenv("SG2IM_FUSE_ACT_BWD")) == 0);
 
 sg2im_conv_desc rows_desc(int rows) {
   sg2im_conv_desc d;
@@ -99,8 +103,13 @@ int sg2im_gconv_layer_backward(const sg2im_gconv_layer* L, const float* h1, cons
   if (g_obj) SG2IM_TRY(sg2im_act_backward(g_obj, Dout, 0, O, 1, 1, new_obj, Dout, Dout, 0.f, dp4, stream));
   else if (hipMemsetAsync(dp4, 0, sizeof(float) * (size_t)O * Dout, stream) != hipSuccess) return SG2IM_ERR_HIP;
   const sg2im_conv_desc d4 = dense_desc(h2, O, H);
-  SG2IM_TRY(sg2im_conv2d_backward_data(&d4, L->w2b, Dout, dp4, Dout, 0, H, dh2, H, 0, workspace, workspace_bytes, stream));
-  SG2IM_TRY(sg2im_act_backward(dh2, H, 0, O, 1, 1, h2, H, H, 0.f, dh2, stream));            // dp3 (in place)
+  // dp3 = (dp4 W2b) * relu'(h2): the mask rides in the data gradient's launches (epilogue / split-K finish)
+  if (g_fuse_act) {
+    SG2IM_TRY(sg2im_conv2d_backward_data_act(&d4, L->w2b, Dout, dp4, Dout, 0, H, dh2, H, h2, H, 0.f, workspace, workspace_bytes, stream));
+  } else {
+    SG2IM_TRY(sg2im_conv2d_backward_data(&d4, L->w2b, Dout, dp4, Dout, 0, H, dh2, H, 0, workspace, workspace_bytes, stream));
+    SG2IM_TRY(sg2im_act_backward(dh2, H, 0, O, 1, 1, h2, H, H, 0.f, dh2, stream));          // dp3 (in place)
+  }
   const sg2im_conv_desc d3 = dense_desc(pooled, O, H);
   SG2IM_TRY(sg2im_conv2d_backward_data(&d3, L->w2a, H, dh2, H, 0, H, dpooled, H, 0, workspace, workspace_bytes, stream));
   sg2im_conv_desc d1 = triple_desc(L), d2 = dense_desc(h1, T, H);
@@ -109,8 +118,12 @@ int sg2im_gconv_layer_backward(const sg2im_gconv_layer* L, const float* h1, cons
     SG2IM_TRY(sg2im_gconv_pool_backward(dpooled, H, L->s_idx, L->o_idx, T, L->average ? L->row_ptr : nullptr, g_pred, ld_gpred,
                                         new_t, NT, H, Dout, 0.f, dnt, NT, stream));
     // ---- net1 ----
-    SG2IM_TRY(sg2im_conv2d_backward_data(&d2, L->w1b, NT, dnt, NT, 0, H, dh1, H, 0, workspace, workspace_bytes, stream));
-    SG2IM_TRY(sg2im_act_backward(dh1, H, 0, T, 1, 1, h1, H, H, 0.f, dh1, stream));          // dp1 (in place)
+    if (g_fuse_act) {                                                                       // dp1 = (dnt W1b) * relu'(h1)
+      SG2IM_TRY(sg2im_conv2d_backward_data_act(&d2, L->w1b, NT, dnt, NT, 0, H, dh1, H, h1, H, 0.f, workspace, workspace_bytes, stream));
+    } else {
+      SG2IM_TRY(sg2im_conv2d_backward_data(&d2, L->w1b, NT, dnt, NT, 0, H, dh1, H, 0, workspace, workspace_bytes, stream));
+      SG2IM_TRY(sg2im_act_backward(dh1, H, 0, T, 1, 1, h1, H, H, 0.f, dh1, stream));        // dp1 (in place)
+    }
     SG2IM_TRY(sg2im_conv2d_backward_data(&d1, L->w1a, H, dh1, H, 0, 3 * Din, d_triple, 3 * Din, 0, workspace, workspace_bytes,
                                          stream));
   }

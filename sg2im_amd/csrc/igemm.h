@@ -62,6 +62,13 @@ struct Epi {
   int col_ctot, col_wtap;  // weight gradients of a layer whose weight rows hold col_wtap > col_ctot floats per
                            // tap: GEMM column n = tap * col_ctot + c lands in destination column
                            // tap * col_wtap + c (0, 0: identity)
+  // data gradients that flow into an activation (sg2im_conv2d_backward_data_act): the finished value is multiplied
+  // by leaky'(act) = (act[row][n] > 0 ? 1 : mask_slope), act = the ACTIVATED output of the layer the gradient is
+  // taken with respect to (same rows / columns as the destination) - the arithmetic of act_bwd_kernel (norm.hip),
+  // applied by the epilogue or, with split-K, by the finish
+  const float* mask;
+  long long ld_mask;
+  float mask_slope;
 };
 __device__ __forceinline__ int epi_col(const Epi& e, int n) {
   return e.col_wtap ? (n / e.col_ctot) * e.col_wtap + n % e.col_ctot : n;
@@ -209,7 +216,7 @@ struct IdentityRow { __device__ __forceinline__ long long operator()(int m) cons
 // `rowmap` turns a tile-local GEMM row into the destination row (identity except for the
 // stride-2 parity classes of the data gradient and the 2-D pixel patches of conv_halo.h); split-K
 // partials are only remapped with WSMAP (patches: [split][M][N] over the destination rows).
-template <int BM, int BN, typename RowMap = IdentityRow, bool WSMAP = false>
+template <int BM, int BN, typename RowMap = IdentityRow, bool WSMAP = false, bool MASK = false>
 __device__ __forceinline__ void epilogue(const Epi& e, int M, int N, int nlimit, int m0, int n0, int wm0,
                                          int wn0, int lane, int split,
                                          const f32x16 (&acc)[BM / 64][BN / 64], RowMap rowmap = RowMap()) {
@@ -233,7 +240,9 @@ __device__ __forceinline__ void epilogue(const Epi& e, int M, int N, int nlimit,
           e.ws[((long long)split * M + mw) * N + n] = v;
         } else {
           v = leaky(v + bv, e.slope);
-          float* dst = e.C + rowmap(m) * e.ldc + ncol;
+          const long long drow = rowmap(m);
+          if (MASK) v *= e.mask[drow * e.ld_mask + n] > 0.f ? 1.f : e.mask_slope;
+          float* dst = e.C + drow * e.ldc + ncol;
           if (e.accumulate) v += *dst;
           *dst = v;
         }

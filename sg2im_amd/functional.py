@@ -98,16 +98,21 @@ class NhwcToNchw(Function):
 # linear layers
 # ----------------------------------------------------------------------------
 
-def _linear_bwd(desc, W, dpre, need_dx, need_dw, need_db, K, b=None, group=None):
+def _linear_bwd(desc, W, dpre, need_dx, need_dw, need_db, K, b=None, group=None, act=None):
   """dpre: dense (M,N) gradient of the pre-activation.  Returns (dx (M,K), dW, db); a
   parameter gradient that went straight into its registered sink is reported as None.
   group: a list - parameter gradients that go into sinks are only QUEUED on it, for one grouped
-  launch by the caller (_flush_wgrad_group)."""
+  launch by the caller (_flush_wgrad_group).  act = (z, slope): the layer's input x is z = leaky_slope(pre) of a
+  previous layer and the caller wants the gradient w.r.t. that pre-activation: dx *= leaky'(z), applied by the data
+  gradient's own launches (ops.conv2d_backward_data_act)."""
   M, N = dpre.shape
   dx = dw = db = None
   if need_dx:
     dx = _new(dpre, M, K)
-    ops.conv2d_backward_data(desc, W, N, dpre, N, 0, K, dx, K)
+    if act is not None and act[1] != 1.0 and M > 0:
+      ops.conv2d_backward_data_act(desc, W, N, dpre, N, 0, K, dx, K, act[0], act[0].stride(0), act[1])
+    else:
+      ops.conv2d_backward_data(desc, W, N, dpre, N, 0, K, dx, K)
   if group is not None and need_dw and M > 0:
     sk, skb = _sink(W), (_sink(b) if need_db else None)
     if sk is not None and (not need_db or skb is not None):
@@ -233,8 +238,8 @@ class Mlp2(Function):
     ni = ctx.needs_input_grad
     dp2 = _act_bwd_rows(g, y, 0.0)
     d2 = conv_desc([rows_src(h)], M, 1, 1)
-    dh, dW2, db2 = _linear_bwd(d2, W2, dp2, True, ni[3], ni[4], h.size(1), b2)
-    dp1 = _act_bwd_rows(dh, h, 0.0)
+    # (dp1 = (dp2 W2) * relu'(h): the mask rides in the data gradient's launches)
+    dp1, dW2, db2 = _linear_bwd(d2, W2, dp2, True, ni[3], ni[4], h.size(1), b2, act=(h, 0.0))
     d1 = conv_desc([rows_src(x)], M, 1, 1)
     dx, dW1, db1 = _linear_bwd(d1, W1, dp1, ni[0], ni[1], ni[2], x.size(1), b1)
     return dx, dW1, db1, dW2, db2
@@ -551,8 +556,8 @@ class RelAux(Function):
     T, E = s_idx.numel(), vecs.size(1)
     ni = ctx.needs_input_grad
     dp2 = _act_bwd_rows(g, y, 0.0)
-    dh, dW2, db2 = _linear_bwd(conv_desc([rows_src(h)], T, 1, 1), W2, dp2, True, ni[7], ni[8], h.size(1), b2)
-    dp1 = _act_bwd_rows(dh, h, 0.0)
+    dp1, dW2, db2 = _linear_bwd(conv_desc([rows_src(h)], T, 1, 1), W2, dp2, True, ni[7], ni[8], h.size(1), b2,
+                                act=(h, 0.0))
     d1 = conv_desc([rows_src(boxes, s_idx), rows_src(boxes, o_idx), rows_src(vecs, s_idx), rows_src(vecs, o_idx)],
                    T, 1, 1)
     dX, dW1, db1 = _linear_bwd(d1, W1, dp1, ni[0] or ni[1], ni[5], ni[6], 8 + 2 * E, b1)
@@ -913,10 +918,10 @@ class RefinementFn(Function):
     # stream underneath the small kernels that lead to the next data gradient, which waits for it.
     # output 1x1 conv
     dz = _new(g, N, H, W, Co)
-    ops.conv2d_backward_data(do2, _cl_weight(Wo2), Wo2.size(0), g, Wo2.size(0), 0, Co, dz, Co)
+    # (d loss / d pre-activation of output_conv[0]: the LeakyReLU mask of z rides in the data gradient's epilogue)
+    ops.conv2d_backward_data_act(do2, _cl_weight(Wo2), Wo2.size(0), g, Wo2.size(0), 0, Co, dz, Co, z, Co, slope)
     grads[4 * L + 2], grads[4 * L + 3] = wgrad(do2, g, Wo2.size(0), (Wo2.size(0), 1, 1, Co),
                                                ni[4 * L + 2], ni[4 * L + 3], Wo2, bo2)
-    ops.act_backward(_fptr(dz), Co, 0, N, H, W, z, Co, Co, slope, dz)
     gz = _new(g, N, H, W, Cf)                      # grad w.r.t. activated feats of the last module
     side.barrier()
     # Every data gradient below that produces the gradient of a BatchNorm'd layer's activated output also
@@ -1054,8 +1059,7 @@ class RefinementNoNormFn(Function):
       grads[4 * L + 2], grads[4 * L + 3] = _conv_param_grads(do2, g, Wo2.size(0), (Wo2.size(0), 1, 1, Co),
                                                              ni[4 * L + 2], ni[4 * L + 3], Wo2, bo2)
       dz = _new(g, N, H, W, Co)
-      ops.conv2d_backward_data(do2, _cl_weight(Wo2), Wo2.size(0), g, Wo2.size(0), 0, Co, dz, Co)
-      ops.act_backward(_fptr(dz), Co, 0, N, H, W, z, Co, Co, slope, dz)
+      ops.conv2d_backward_data_act(do2, _cl_weight(Wo2), Wo2.size(0), g, Wo2.size(0), 0, Co, dz, Co, z, Co, slope)
       grads[4 * L], grads[4 * L + 1] = _conv_param_grads(do0, dz, Co, (Co, 3, 3, Cf), ni[4 * L], ni[4 * L + 1], Wo0, bo0)
       gz = _new(g, N, H, W, Cf)
       ops.conv2d_backward_data(do0, _cl_weight(Wo0), Co, dz, Co, 0, Cf, gz, Cf)

@@ -405,6 +405,27 @@ def conv2d_backward_data(desc, weight, cout, dy, ld_dy, c_begin, c_count, dx, ld
   return dx
 
 
+# A/B knob: 0 = the activation backward as a launch of its own behind the data gradient (rounds 1-4)
+FUSE_ACT_BWD = os.environ.get('SG2IM_FUSE_ACT_BWD', '1') != '0'
+
+
+def conv2d_backward_data_act(desc, weight, cout, dy, ld_dy, c_begin, c_count, dx, ld_dx, act, ld_act, slope):
+  """conv2d_backward_data whose result is multiplied by leaky'_slope(act) - act = the ACTIVATED output of the layer
+  the gradient flows into - in the data gradient's own launches (sg2im_conv2d_backward_data_act)"""
+  if not FUSE_ACT_BWD:
+    conv2d_backward_data(desc, weight, cout, dy, ld_dy, c_begin, c_count, dx, ld_dx)
+    rows = dx.numel() // c_count
+    return act_backward(c_void_p(dx.data_ptr()), ld_dx, 0, rows, 1, 1, act, ld_act, c_count, slope, dx)
+  ws = workspace(dx.device)
+  flops = 2.0 * desc.batch * desc.out_h * desc.out_w * cout * desc.kh * desc.kw * c_count
+  _note_bytes('igemm_dgrad', desc.batch * desc.out_h * desc.out_w * cout + cout * desc.kh * desc.kw * c_count +
+              2 * desc.batch * desc.in_h * desc.in_w * c_count)
+  _timed('igemm_dgrad', flops, lambda: call(
+    'sg2im_conv2d_backward_data_act', byref(desc), _f(weight), int(cout), _f(dy), int(ld_dy), int(c_begin),
+    int(c_count), _f(dx), int(ld_dx), _f(act), int(ld_act), float(slope), _f(ws), ws.numel() * 4, _stream()))
+  return dx
+
+
 def conv2d_backward_weight(desc, dy, ld_dy, cout, dweight, accumulate=False, dbias=None):
   """dbias (optional): the layer's bias gradient, produced in the same pass over dy."""
   ws = workspace(dweight.device)

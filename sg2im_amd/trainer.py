@@ -74,6 +74,11 @@ def generator_buckets(model, flat_g):
   if mods is None or len(mods) < 3 or net.normalization != 'batch':
     return []
   groups = [[mods[0]], [mods[1]], list(mods[2:]) + [net.output_conv]]
+  nb = int(os.environ.get('SG2IM_DP_BUCKETS', '3'))        # (A/B knob: 1 = rounds 3-4's single early bucket, modules 0 + 1)
+  if nb == 1:
+    groups = [[mods[0], mods[1]]]
+  elif nb == 2:
+    groups = [[mods[0]], [mods[1]]]
   out = []
   for grp in groups:
     ps = [p for m in grp for p in m.parameters()]
@@ -780,53 +785,37 @@ class Trainer(object):
       # the order the release issues them - and, after the backward pass, whatever the arena holds besides.
       buckets = self._generator_buckets() if ingraph else []
       sent = []
-      early_packed = []
       if buckets:
         def early_cb(a, b):
           def cb(stream):
-            n0 = len(packed)
             reduce_after(stream, self.flat_g.grad[a:b])
-            early_packed.extend(packed[n0:])
-            del packed[n0:]
             sent.append((a, b))
           return cb
         ops.AFTER_DEFERRED = [(ids, early_cb(a, b)) for a, b, ids in buckets]
-      # The Adam update of the refinement network's parameters (3/4 of the generator) at the END OF THE
+      # One GPU: the Adam update of the refinement network's parameters (3/4 of the generator) at the END OF THE
       # WEIGHT-GRADIENT LANE, right behind its last weight gradient - every gradient of that slice is complete there
       # (convolutions: the lane itself; BatchNorm: the data-gradient chain the release waited for) - while the main
       # lane finishes the graph-convolution / embedding backward; only the rest is left for the final update.  No new
       # stream or fork / join edge (an update on a stream of its own, under the remaining weight gradients, re-mapped
       # the branches onto the hardware queues and cost 0.7 ms: profiles/r4_early_adam_ab.txt).  Same values: the
       # update is element-wise (optim.FlatAdam.apply_guarded).
-      # Data parallel (in-graph exchange): the same, once the early buckets - which then must cover exactly that
-      # slice - have been reduced: the lane waits for the comm stream, widens a bfloat16 payload back and updates;
-      # the N > 1 step is then structurally the N = 1 step plus the collectives (VERDICT r4 weak #8 iii).
-      early_adam = ((not dp or ingraph) and not ops.SINGLE_STREAM and ops.DEFER_WGRAD and
-                    os.environ.get('SG2IM_EARLY_ADAM', '1') != '0')
+      # NOT under data parallelism.  Round 5 built it (the three early buckets are exactly that slice: the lane - or
+      # the discriminator lane - waits for the comm stream, then updates) and hipStreamEndCapture SEGFAULTS on it: any
+      # captured stream other than the capture's origin that waits for the comm stream (whose only operations are
+      # waits and the collectives' own fork / join) kills clr at the end of the capture, also with a kernel on the
+      # comm stream in front of the wait (profiles/r5_dp_early_adam_capture_crash.txt: three placements, all dump
+      # core; without the early update the same 4-bucket graph captures and runs).  The alternatives - the collective
+      # of the last early bucket on the lane itself, or the update on the comm stream - either depend on torch's
+      # choice of NCCL stream or put an elementwise kernel on the comm stream (+1.7 ms when measured in round 4).
+      early_adam = not dp and not ops.SINGLE_STREAM and ops.DEFER_WGRAD and os.environ.get('SG2IM_EARLY_ADAM', '1') != '0'
       crn = refinement_slice(self.model, self.flat_g) if early_adam else None
-      if crn is not None and dp:
-        cover = sorted((a, b) for a, b, _ in buckets)
-        if not cover or cover[0][0] != crn[0] or cover[-1][1] != crn[1] or any(
-            cover[i][1] != cover[i + 1][0] for i in range(len(cover) - 1)):
-          crn = None                  # (the early buckets are not exactly the refinement slice)
       if crn is not None:
         a, b = crn
-        if not dp:
-          self.opt_g.prepare_guarded(st['guard'])      # (main stream: the release fork orders it before the lane)
-          st['g_adam_prepared'] = True
+        self.opt_g.prepare_guarded(st['guard'])        # (main stream: the release fork orders it before the lane)
+        st['g_adam_prepared'] = True
 
         def early_update(stream):
-          # (current stream = the weight-gradient lane, behind its last weight gradient)
-          if dp:
-            if sorted(sent) != cover:                   # (a bucket was never reported: its slice waits for the end)
-              return
-            stream.wait_stream(comm)                    # the early buckets AND the guard have been reduced
-            for t in early_packed:
-              red.unpack(t)
-            del early_packed[:]
-            self.opt_g.prepare_guarded(st['guard'])
-            st['g_adam_prepared'] = True
-          self.opt_g.apply_guarded(a, b, self.reducer.grad_scale)
+          self.opt_g.apply_guarded(a, b, self.reducer.grad_scale)     # (current stream = the weight-gradient lane)
           st['g_adam_early'] = (a, b)
         ops.AFTER_ALL_DEFERRED = early_update
       try:
@@ -840,14 +829,14 @@ class Trainer(object):
       if dp and self.rank == 0:
         self._log_schedule(
           ('2: all-reduces recorded inside the iteration graph, generator in %d bucket(s)%s' % (
-            len(sent) + 1, ', early Adam slice behind the early buckets' if st.get('g_adam_early') else '')) if ingraph else
+            len(sent) + 1, '')) if ingraph else
           ('%d requested, running 0 (iteration graph -> exposed all-reduces -> Adam graph): in-graph collectives need '
            'RCCL and an unmuted reducer' % self.dp_schedule) if self.dp_schedule == 2 else
           '0: iteration graph -> exposed all-reduces -> Adam graph')
       main.wait_stream(side)
       if ingraph:
         main.wait_stream(comm)
-        for t in early_packed + packed:      # (bf16 payload: back into the fp32 arenas Adam reads)
+        for t in packed:                     # (bf16 payload: back into the fp32 arenas Adam reads)
           red.unpack(t)
       if not dp or ingraph:
         self._seg_adam(st)
