@@ -346,7 +346,7 @@ def main():
                          if trainer.dp_schedule == 1 else
                          'ONE graph with the RCCL all-reduces recorded inside: guard / D_img / D_obj right after their steps, the generator in '
                          'four buckets (refinement module 0, module 1, modules 2.. + output convolutions as their weight gradients complete, '
-                         'the refinement network\'s Adam slice behind them on the weight-gradient lane; the rest after the backward)'
+                         'the rest after the backward)'
                          if trainer.dp_schedule == 2 and trainer.reducer.capturable() else
                          'one iteration graph (D steps on a side stream) -> 4 all-reduces (exposed) -> Adam graph')}
   if use_dist:

@@ -328,6 +328,13 @@ typedef struct sg2im_gconv_stack_grads {
   float* d_triple; float* d_obj;
   float* scratch; size_t scratch_bytes;
   sg2im_gconv_grads layer[SG2IM_GCONV_MAX_LAYERS];
+  int low_footprint;        /* 0: the kernel that wants WHOLE CUs (one workgroup per CU, ~390 registers, 98 KB of LDS: fastest
+                             * on an otherwise idle GPU, 419 us at the bench shape); 1: <= 168 registers / 41 KB of LDS, 32 x 32
+                             * tiles - its workgroups fit NEXT TO resident workgroups of other kernels, so the launch can
+                             * run inside a busy multi-stream graph (sg2im_amd/trainer.py: under the refinement network's
+                             * weight gradients) without waiting for whole CUs to drain.  Same results up to the fp32
+                             * summation order of the weight gradients' tiles. */
+  int reserved;
 } sg2im_gconv_stack_grads;
 size_t sg2im_gconv_stack_backward_scratch(const sg2im_gconv_stack* stack);
 int sg2im_gconv_stack_backward(const sg2im_gconv_stack* stack, const sg2im_gconv_stack_grads* grads, void* sync,

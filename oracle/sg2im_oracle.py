@@ -20,6 +20,61 @@ import torch.nn.functional as F
 BN_EPS = 1e-5        # torch.nn.BatchNorm2d default (sg2im/layers.py:26)
 BN_MOMENTUM = 0.1
 
+# ----------------------------------------------------------------------------
+# Emulation of the HIP library's bf16 OPERAND mode (sg2im_conv_desc.compute_dtype = 1, BASELINE configs[2..4]) -
+# not reference behaviour (the reference is fp32 only, scripts/train.py:418,423): with OPERAND_ROUND = 'bf16' every
+# SPATIAL convolution multiplies operands rounded to bfloat16 (round-to-nearest-even) and accumulates exactly as
+# before, in all three passes - forward conv(round(x), round(W)), data gradient conv_T(round(dy), round(W)), weight
+# gradient corr(round(x), round(dy)); bias and everything else untouched.  Which passes round follows the library's
+# dispatch (csrc/conv.hip: only the float4 loaders have a bf16 form): forward iff the input channels are a multiple
+# of 4; data / weight gradient iff, in addition, the output channels are (and, for the data gradient, there are more
+# than 4 input channels - fewer take the few-channel gather kernel).  Linear layers never round.  The float64 run of
+# this emulation is the exact result of the arithmetic the bf16 mode is SPECIFIED to perform, which is what its
+# parity tests compare against (tests/test_gpu_parity.py::test_bf16_*).
+# ----------------------------------------------------------------------------
+OPERAND_ROUND = None
+
+
+def _round_bf16(t):
+  return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _RoundedConv2d(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x, w, b, stride, padding, rf, rd, rw):
+    ctx.save_for_backward(x, w)
+    ctx.cfg = (stride, padding, rd, rw, b is not None)
+    return F.conv2d(_round_bf16(x) if rf else x, _round_bf16(w) if rf else w, b, stride=stride, padding=padding)
+
+  @staticmethod
+  def backward(ctx, g):
+    x, w = ctx.saved_tensors
+    stride, padding, rd, rw, has_b = ctx.cfg
+    dx = dw = db = None
+    if ctx.needs_input_grad[0]:
+      dx = torch.nn.grad.conv2d_input(x.shape, _round_bf16(w) if rd else w, _round_bf16(g) if rd else g, stride=stride,
+                                      padding=padding)
+    if ctx.needs_input_grad[1]:
+      dw = torch.nn.grad.conv2d_weight(_round_bf16(x) if rw else x, w.shape, _round_bf16(g) if rw else g, stride=stride,
+                                       padding=padding)
+    if has_b and ctx.needs_input_grad[2]:
+      db = g.sum((0, 2, 3))
+    return dx, dw, db, None, None, None, None, None
+
+
+def conv2d(x, w, b=None, stride=1, padding=0, cin_eff=None):
+  """F.conv2d, or its bf16-operand emulation (OPERAND_ROUND).  cin_eff: the input channels the HIP path actually
+  runs over when it drops a constant all-zero channel (the first refinement module, crn.py:105)"""
+  if OPERAND_ROUND is None:
+    return F.conv2d(x, w, b, stride=stride, padding=padding)
+  if OPERAND_ROUND != 'bf16':
+    raise ValueError('OPERAND_ROUND must be None or "bf16"')
+  cout, cin = w.size(0), (w.size(1) if cin_eff is None else cin_eff)
+  rf = cin % 4 == 0
+  rd = rf and cout % 4 == 0 and cin > 4
+  rw = rf and cout % 4 == 0
+  return _RoundedConv2d.apply(x, w, b, stride, padding, rf, rd, rw)
+
 
 # ----------------------------------------------------------------------------
 # small helpers
@@ -239,22 +294,23 @@ def refinement_network(P, prefix, layout, n_modules, slope, training, normalizat
       lay = F.avg_pool2d(layout, kernel_size=factor, stride=factor)
     x = torch.cat([lay, feats], dim=1)
     p = '%s.refinement_modules.%d.net' % (prefix, i)
-    x = F.conv2d(x, P[p + '.0.weight'], P[p + '.0.bias'], padding=1)
+    x = conv2d(x, P[p + '.0.weight'], P[p + '.0.bias'], padding=1,
+               cin_eff=x.size(1) - 1 if (i == 0 and normalization == 'batch') else None)
     if normalization == 'none':
       x = F.leaky_relu(x, slope)
-      feats = F.leaky_relu(F.conv2d(x, P[p + '.2.weight'], P[p + '.2.bias'], padding=1), slope)
+      feats = F.leaky_relu(conv2d(x, P[p + '.2.weight'], P[p + '.2.bias'], padding=1), slope)
       continue
     if normalization == 'instance':     # nn.InstanceNorm2d(C): no affine, no running stats (layers.py:27-28)
       x = F.leaky_relu(F.instance_norm(x, eps=BN_EPS), slope)
-      x = F.conv2d(x, P[p + '.3.weight'], P[p + '.3.bias'], padding=1)
+      x = conv2d(x, P[p + '.3.weight'], P[p + '.3.bias'], padding=1)
       feats = F.leaky_relu(F.instance_norm(x, eps=BN_EPS), slope)
       continue
     x = F.leaky_relu(batch_norm(P, p + '.1', x, training), slope)
-    x = F.conv2d(x, P[p + '.3.weight'], P[p + '.3.bias'], padding=1)
+    x = conv2d(x, P[p + '.3.weight'], P[p + '.3.bias'], padding=1)
     feats = F.leaky_relu(batch_norm(P, p + '.4', x, training), slope)
   o = prefix + '.output_conv'
-  x = F.leaky_relu(F.conv2d(feats, P[o + '.0.weight'], P[o + '.0.bias'], padding=1), slope)
-  return F.conv2d(x, P[o + '.2.weight'], P[o + '.2.bias'])
+  x = F.leaky_relu(conv2d(feats, P[o + '.0.weight'], P[o + '.0.bias'], padding=1), slope)
+  return conv2d(x, P[o + '.2.weight'], P[o + '.2.bias'])
 
 
 def mask_net(P, prefix, obj_vecs, mask_size, training):
@@ -266,14 +322,14 @@ def mask_net(P, prefix, obj_vecs, mask_size, training):
   while size < mask_size:
     x = F.interpolate(x, scale_factor=2, mode='nearest')
     x = batch_norm(P, '%s.%d' % (prefix, 4 * b + 1), x, training)
-    x = F.relu(F.conv2d(x, P['%s.%d.weight' % (prefix, 4 * b + 2)],
-                        P['%s.%d.bias' % (prefix, 4 * b + 2)], padding=1))
+    x = F.relu(conv2d(x, P['%s.%d.weight' % (prefix, 4 * b + 2)],
+                      P['%s.%d.bias' % (prefix, 4 * b + 2)], padding=1))
     size *= 2
     b += 1
   if size != mask_size:
     raise ValueError('Mask size must be a power of 2')   # model.py:104
   k = 4 * b
-  scores = F.conv2d(x, P['%s.%d.weight' % (prefix, k)], P['%s.%d.bias' % (prefix, k)])
+  scores = conv2d(x, P['%s.%d.weight' % (prefix, k)], P['%s.%d.bias' % (prefix, k)])
   return scores.squeeze(1).sigmoid()
 
 
@@ -405,7 +461,7 @@ def residual_block(P, prefix, x, C, normalization, slope, padding, training):
         j += 1
       t = F.leaky_relu(t, slope)
       j += 1
-      t = F.conv2d(t, P['%s.net.%d.weight' % (prefix, j)], P['%s.net.%d.bias' % (prefix, j)], padding=pad)
+      t = conv2d(t, P['%s.net.%d.weight' % (prefix, j)], P['%s.net.%d.bias' % (prefix, j)], padding=pad)
       j += 1
     return t
   shortcut = x
@@ -430,7 +486,7 @@ def disc_cnn(P, prefix, x, arch, slope, padding, training, normalization='batch'
     elif kind == 'conv':
       _cin, _cout, k, stride = lay[2:]
       pad = 0 if padding == 'valid' else (k - 1) // 2
-      x = F.conv2d(x, P[name + '.weight'], P[name + '.bias'], stride=stride, padding=pad)
+      x = conv2d(x, P[name + '.weight'], P[name + '.bias'], stride=stride, padding=pad)
     elif kind == 'res':
       x = residual_block(P, name, x, lay[2], lay[3], slope, padding, training)
     elif kind == 'up':

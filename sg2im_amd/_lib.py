@@ -78,7 +78,8 @@ class GconvGrads(Structure):
 class GconvStackGrads(Structure):
   """sg2im_gconv_stack_grads (include/sg2im_hip.h)"""
   _fields_ = [('g_obj', c_void_p), ('g_pred', c_void_p), ('ld_gpred', c_longlong), ('d_triple', c_void_p), ('d_obj', c_void_p),
-              ('scratch', c_void_p), ('scratch_bytes', c_size_t), ('layer', GconvGrads * SG2IM_GCONV_MAX_LAYERS)]
+              ('scratch', c_void_p), ('scratch_bytes', c_size_t), ('layer', GconvGrads * SG2IM_GCONV_MAX_LAYERS),
+              ('low_footprint', c_int), ('reserved', c_int)]
 
 
 _P, _I, _L, _F, _Z = c_void_p, c_int, c_longlong, c_float, c_size_t

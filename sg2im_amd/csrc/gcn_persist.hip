@@ -40,6 +40,7 @@
 #include <algorithm>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #define SG2IM_GEMM_TU            // (a launch of this file counts as an implicit-GEMM-family launch)
 #include "launch_count.h"
@@ -270,22 +271,21 @@ struct RowsTriple {
 // out != nullptr: the tile also writes the rows it builds (the weight gradient of net1's second layer reads them).
 struct RowsDnt {
   const float* dp; const float* gp; const float* nt; float* out;
-  int os[4], og[4], oo[4], on[4];
+  // per-row state kept small (this loader sets the register high-water mark of the backward kernels): the triple's
+  // subject / object rows and its own (clamped) row; the element offsets are re-formed per chunk (one mad each)
+  int rs[4], ro[4], rm[4];
   float ds[4], dv[4];
+  int H, ld_gp, ld_nt, c4x4, M, m0r;
   int cH, cHD;                     // chunk boundaries: [0, cH) subject block, [cH, cHD) predicate block, then object block
-  bool valid[4];
-  __device__ __forceinline__ void init(const float* dpooled, int H, const float* g_pred, int ld_gp, const float* new_t, int ld_nt,
-                                       int Dout, const int* row_ptr, bool average, float* out_, int m0, int M, const TripleIdx& ix,
+  __device__ __forceinline__ void init(const float* dpooled, int H_, const float* g_pred, int ld_gp_, const float* new_t, int ld_nt_,
+                                       int Dout, const int* row_ptr, bool average, float* out_, int m0, int M_, const TripleIdx& ix,
                                        const Lane& L) {
-    dp = dpooled; gp = g_pred; nt = new_t; out = out_; cH = H >> 5; cHD = (H + Dout) >> 5;
+    dp = dpooled; gp = g_pred; nt = new_t; out = out_; cH = H_ >> 5; cHD = (H_ + Dout) >> 5;
+    H = H_; ld_gp = ld_gp_; ld_nt = ld_nt_; c4x4 = 4 * L.c4; M = M_; m0r = m0 + L.r8;
     #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int m = m0 + L.r8 + 8 * j, mc = min(m, M - 1);
-      valid[j] = m < M;
-      os[j] = ix.s[j] * H + 4 * L.c4;
-      oo[j] = ix.o[j] * H + 4 * L.c4;
-      og[j] = mc * ld_gp + 4 * L.c4;
-      on[j] = mc * ld_nt + 4 * L.c4;
+      rs[j] = ix.s[j]; ro[j] = ix.o[j];
+      rm[j] = min(m0r + 8 * j, M - 1);
       ds[j] = 1.f; dv[j] = 1.f;
       if (average) {
         ds[j] = (float)max(1, row_ptr[ix.s[j] + 1] - row_ptr[ix.s[j]]);
@@ -294,27 +294,27 @@ struct RowsDnt {
     }
   }
   __device__ __forceinline__ void chunk(int c, v4f (&d)[4]) const {
-    v4f x[4], y[4];
+    v4f y[4];
     #pragma unroll
-    for (int j = 0; j < 4; ++j) y[j] = ld4(nt + on[j] + 32 * c);
+    for (int j = 0; j < 4; ++j) y[j] = ld4(nt + rm[j] * ld_nt + c4x4 + 32 * c);
     if (c < cH) {
       #pragma unroll
-      for (int j = 0; j < 4; ++j) x[j] = ld4(dp + os[j] + 32 * c);
+      for (int j = 0; j < 4; ++j) d[j] = ld4(dp + rs[j] * H + c4x4 + 32 * c);
       #pragma unroll
-      for (int j = 0; j < 4; ++j) { x[j].x = x[j].x / ds[j]; x[j].y = x[j].y / ds[j]; x[j].z = x[j].z / ds[j]; x[j].w = x[j].w / ds[j]; }
+      for (int j = 0; j < 4; ++j) { d[j].x = d[j].x / ds[j]; d[j].y = d[j].y / ds[j]; d[j].z = d[j].z / ds[j]; d[j].w = d[j].w / ds[j]; }
     } else if (c < cHD) {
       #pragma unroll
-      for (int j = 0; j < 4; ++j) x[j] = gp ? ld4(gp + og[j] + 32 * (c - cH)) : zero4();
+      for (int j = 0; j < 4; ++j) d[j] = gp ? ld4(gp + rm[j] * ld_gp + c4x4 + 32 * (c - cH)) : zero4();
     } else {
       #pragma unroll
-      for (int j = 0; j < 4; ++j) x[j] = ld4(dp + oo[j] + 32 * (c - cHD));
+      for (int j = 0; j < 4; ++j) d[j] = ld4(dp + ro[j] * H + c4x4 + 32 * (c - cHD));
       #pragma unroll
-      for (int j = 0; j < 4; ++j) { x[j].x = x[j].x / dv[j]; x[j].y = x[j].y / dv[j]; x[j].z = x[j].z / dv[j]; x[j].w = x[j].w / dv[j]; }
+      for (int j = 0; j < 4; ++j) { d[j].x = d[j].x / dv[j]; d[j].y = d[j].y / dv[j]; d[j].z = d[j].z / dv[j]; d[j].w = d[j].w / dv[j]; }
     }
     #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      d[j] = mask4(x[j], y[j]);
-      if (out && valid[j]) st4(out + on[j] + 32 * c, d[j]);      // (dnt has new_t's shape and row stride)
+      d[j] = mask4(d[j], y[j]);
+      if (out && m0r + 8 * j < M) st4(out + rm[j] * ld_nt + c4x4 + 32 * c, d[j]);      // (dnt has new_t's shape and row stride)
     }
   }
 };
@@ -443,6 +443,24 @@ __device__ __forceinline__ void mma_chunk(const ChunkRegs<NB>& g, float* img, co
     for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[nb][s], acc[nb], 0, 0, 0);
 }
 
+// Footprint of a kernel's tile machinery.  Full: up to four K chunks of a wave in flight (4 x 48 staging registers at
+// NB = 2), 32 x 64 tiles, a reduction scratch next to the wave images - 98 KB of LDS, ~390-500 registers: one
+// workgroup per CU, which needs WHOLE CUs.  Low (round 5): two chunks in flight, 32 x 32 tiles
+// only, the reduction scratch ALIASES the wave images (one more workgroup barrier per tile) - 41 KB of LDS, <= 168
+// registers: its workgroups co-reside with the refinement network's weight gradients, so the one-launch backward
+// can run inside the captured iteration's tail instead of waiting for the weight-gradient lane to drain.
+struct FullFootprint { static constexpr int MAXNB = 2, MAXCH = 4; static constexpr bool ALIAS = false; };
+struct LowFootprint { static constexpr int MAXNB = 1, MAXCH = 2; static constexpr bool ALIAS = true; };
+template <typename CFG> struct LdsPlan {
+  static constexpr int kWaveFloats = (1 + CFG::MAXNB) * kImgFloats;
+  static constexpr int kStage = 4 * kWaveFloats;
+  static constexpr int kRedLd_ = 32 * CFG::MAXNB + 8;               // 4 * ld = 32 (mod 64): the two lane halves on disjoint banks
+  static constexpr int kRed = 4 * 32 * kRedLd_;
+  static constexpr int kRedOff = CFG::ALIAS ? 0 : kStage;
+  static constexpr size_t kBytes = sizeof(float) * (CFG::ALIAS ? (kStage > kRed ? kStage : kRed) : kStage + kRed);
+};
+static_assert(LdsPlan<FullFootprint>::kBytes == kLdsBytes, "the full plan is the original layout");
+
 // NCH chunks (cbase, cbase + 4, ...) of one wave: all their global loads are issued first.  The register sets are
 // separate named objects (an array indexed by the chunk-in-batch number is not reliably promoted to registers), and
 // the body is instantiated per chunk count: with the loads under run-time conditions the compiler's s_waitcnt
@@ -463,30 +481,34 @@ __device__ __forceinline__ void batch(const RA& ra, const RB (&rb)[NB], int cbas
 // One 32 x (32 NB) tile: acc = sum over nchunks K chunks of A-chunk x B-chunk (waves split the chunks), the four
 // partials added in wave order through LDS, then epi(row, col, v4f) for every 4-column piece of the tile
 // (row in [0, 32), col in [0, 32 NB) a multiple of 4).
-template <int NB, bool AK, bool BK, typename RA, typename RB, typename Epi>
+template <int NB, bool AK, bool BK, typename CFG = FullFootprint, typename RA, typename RB, typename Epi>
 __device__ __forceinline__ void tile_gemm(const RA& ra, const RB (&rb)[NB], int nchunks, float* smem, const Lane& L, const Epi& epi) {
-  float* const img = smem + L.wave * (1 + kMaxNB) * kImgFloats;
-  float* const red = smem + kStageFloats;
+  static_assert(NB <= CFG::MAXNB, "tile wider than the footprint's wave images");
+  typedef LdsPlan<CFG> LP;
+  constexpr int RLD = LP::kRedLd_;
+  float* const img = smem + L.wave * LP::kWaveFloats;
+  float* const red = smem + LP::kRedOff;
   f32x16 acc[NB];
   #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
     #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-  for (int cbase = L.wave; cbase < nchunks; cbase += 16) {
+  for (int cbase = L.wave; cbase < nchunks; cbase += 4 * CFG::MAXCH) {
     const int n = (nchunks - cbase + 3) >> 2;              // this wave's chunks from cbase on (wave-uniform)
-    if (n >= 4) batch<NB, 4, AK, BK>(ra, rb, cbase, img, L, acc);
-    else if (n == 3) batch<NB, 3, AK, BK>(ra, rb, cbase, img, L, acc);
-    else if (n == 2) batch<NB, 2, AK, BK>(ra, rb, cbase, img, L, acc);
+    if (CFG::MAXCH >= 4 && n >= 4) batch<NB, 4, AK, BK>(ra, rb, cbase, img, L, acc);
+    else if (CFG::MAXCH >= 4 && n == 3) batch<NB, 3, AK, BK>(ra, rb, cbase, img, L, acc);
+    else if (n >= 2) batch<NB, 2, AK, BK>(ra, rb, cbase, img, L, acc);
     else batch<NB, 1, AK, BK>(ra, rb, cbase, img, L, acc);
   }
-  __syncthreads();                                   // (every thread is done with the previous tile's `red`)
+  __syncthreads();                                   // (every thread is done with the previous tile's `red`; ALIAS: and every
+                                                     //  wave with its images, which `red` overwrites)
   {
     const int jc = L.lane & 31, h = L.lane >> 5;
-    float* const mine = red + L.wave * 32 * kRedLd;
+    float* const mine = red + L.wave * 32 * RLD;
     #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
       #pragma unroll
-      for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * h) * kRedLd + 32 * nb + jc] = acc[nb][r];
+      for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * h) * RLD + 32 * nb + jc] = acc[nb][r];
   }
   __syncthreads();
   {
@@ -494,11 +516,12 @@ __device__ __forceinline__ void tile_gemm(const RA& ra, const RB (&rb)[NB], int 
     #pragma unroll
     for (int q = 0; q < NB; ++q) {
       const int col = col0 + 4 * q;
-      const float* p = red + row * kRedLd + col;
-      const v4f v = ((ld4(p) + ld4(p + 32 * kRedLd)) + ld4(p + 64 * kRedLd)) + ld4(p + 96 * kRedLd);
+      const float* p = red + row * RLD + col;
+      const v4f v = ((ld4(p) + ld4(p + 32 * RLD)) + ld4(p + 64 * RLD)) + ld4(p + 96 * RLD);
       epi(row, col, v);
     }
   }
+  if (CFG::ALIAS) __syncthreads();                   // (the next tile's wave images overwrite `red`)
 }
 
 // epilogues: (row, col) are tile-local
@@ -729,7 +752,7 @@ struct DgradStage {
   const long long* s_idx; const long long* o_idx;
 };
 
-template <int AKIND>
+template <int AKIND, typename CFG>
 __device__ __forceinline__ void dgrad_tile(const DgradStage& st, int tile, int nrb, float* smem, TripleIdx& ix, const Lane& L) {
   const int cb = tile / nrb, rb = tile - cb * nrb;
   const int m0 = rb << 5, n0 = cb << 5;
@@ -739,16 +762,16 @@ __device__ __forceinline__ void dgrad_tile(const DgradStage& st, int tile, int n
   epi.out = st.out; epi.act = st.act; epi.ldo = st.N; epi.m0 = m0; epi.n0 = n0; epi.M = st.M; epi.N = st.N;
   if (AKIND == 0) {
     RowsM a; a.init(st.a, st.K, m0, st.M, L);
-    tile_gemm<1, false, true>(a, w, st.K >> 5, smem, L, epi);
+    tile_gemm<1, false, true, CFG>(a, w, st.K >> 5, smem, L, epi);
   } else if (AKIND == 1) {
     RowsMMasked a; a.init(st.a, st.y, st.K, m0, st.M, L);
-    tile_gemm<1, false, true>(a, w, st.K >> 5, smem, L, epi);
+    tile_gemm<1, false, true, CFG>(a, w, st.K >> 5, smem, L, epi);
   } else {
     fetch_triple_idx(ix, st.s_idx, st.o_idx, m0, st.M, L);
     RowsDnt a;
     a.init(st.dpooled, st.H, st.g_pred, st.ld_gp, st.new_t, st.K, st.Dout, st.row_ptr, st.average != 0, cb == 0 ? st.dnt : nullptr, m0,
            st.M, ix, L);
-    tile_gemm<1, false, true>(a, w, st.K >> 5, smem, L, epi);
+    tile_gemm<1, false, true, CFG>(a, w, st.K >> 5, smem, L, epi);
   }
 }
 
@@ -762,34 +785,41 @@ struct WgradStage {
   // gathered X
   const float* obj; int ld_obj; const float* pred; int ld_pred; const long long* s_idx; const long long* o_idx; int din;
 };
-__device__ __forceinline__ int wgrad_tiles(const WgradStage& st) { return st.dw ? ((st.NI + 31) >> 5) * ((st.NJ + 63) >> 6) : 0; }
+template <typename CFG>
+__device__ __forceinline__ int wgrad_tiles(const WgradStage& st) {
+  return st.dw ? ((st.NI + 31) >> 5) * ((st.NJ + 32 * CFG::MAXNB - 1) / (32 * CFG::MAXNB)) : 0;
+}
 
-template <int AKIND, int BKIND>
+// (32 x 64 tiles with the full footprint, 32 x 32 with the low one: WNB = CFG::MAXNB column blocks)
+template <int AKIND, int BKIND, typename CFG>
 __device__ __forceinline__ void wgrad_tile(const WgradStage& st, int tile, float* smem, const Lane& L) {
+  constexpr int WNB = CFG::MAXNB;
   const int nib = (st.NI + 31) >> 5;
   const int jb = tile / nib, ib = tile - jb * nib;
-  const int i0 = ib << 5, j0 = jb << 6;
+  const int i0 = ib << 5, j0 = jb * 32 * WNB;
   const int nchunks = (st.R + 31) >> 5;
   EpiAccum epi;
   epi.dw = st.dw; epi.ld = st.NJ; epi.i0 = i0; epi.j0 = j0; epi.NI = st.NI; epi.NJ = st.NJ; epi.accumulate = st.accumulate;
   if (BKIND == 0) {
-    RowsK x[2];
-    x[0].init(st.x, st.NJ, j0, st.R, L); x[1].init(st.x, st.NJ, min(j0 + 32, st.NJ - 32), st.R, L);
-    if (AKIND == 0) { RowsK a; a.init(st.dy, st.NI, i0, st.R, L); tile_gemm<2, true, true>(a, x, nchunks, smem, L, epi); }
-    else { RowsKMasked a; a.init(st.dy, st.y, st.NI, i0, st.R, L); tile_gemm<2, true, true>(a, x, nchunks, smem, L, epi); }
+    RowsK x[WNB];
+    #pragma unroll
+    for (int q = 0; q < WNB; ++q) x[q].init(st.x, st.NJ, min(j0 + 32 * q, st.NJ - 32), st.R, L);
+    if (AKIND == 0) { RowsK a; a.init(st.dy, st.NI, i0, st.R, L); tile_gemm<WNB, true, true, CFG>(a, x, nchunks, smem, L, epi); }
+    else { RowsKMasked a; a.init(st.dy, st.y, st.NI, i0, st.R, L); tile_gemm<WNB, true, true, CFG>(a, x, nchunks, smem, L, epi); }
   } else {
-    RowsKTriple x[2];
-    x[0].init(st.obj, st.ld_obj, st.pred, st.ld_pred, st.s_idx, st.o_idx, st.din, j0, st.R, L);
-    x[1].init(st.obj, st.ld_obj, st.pred, st.ld_pred, st.s_idx, st.o_idx, st.din, min(j0 + 32, st.NJ - 32), st.R, L);
+    RowsKTriple x[WNB];
+    #pragma unroll
+    for (int q = 0; q < WNB; ++q)
+      x[q].init(st.obj, st.ld_obj, st.pred, st.ld_pred, st.s_idx, st.o_idx, st.din, min(j0 + 32 * q, st.NJ - 32), st.R, L);
     RowsK a; a.init(st.dy, st.NI, i0, st.R, L);
-    tile_gemm<2, true, true>(a, x, nchunks, smem, L, epi);
+    tile_gemm<WNB, true, true, CFG>(a, x, nchunks, smem, L, epi);
   }
 }
 
 // bias-gradient work item: db[n0 .. n0 + 32) (+)= column sums of dY [R][N] (MASK: of G * relu'(Y)) - fixed order:
 // thread (g = tid >> 3, piece = tid & 7) sums rows g, g + 32, ... of its 4 columns, the 32 partial rows are then added in
 // order
-template <bool MASK>
+template <bool MASK, typename CFG>
 __device__ __forceinline__ void colsum_tile(const float* dy, const float* y, int R, int N, int n0, float* db, int accumulate,
                                             float* smem) {
   const int g = threadIdx.x >> 3, piece = threadIdx.x & 7;
@@ -800,7 +830,7 @@ __device__ __forceinline__ void colsum_tile(const float* dy, const float* y, int
       const v4f v = ld4(dy + r * N + col);
       s = s + (MASK ? mask4(v, ld4(y + r * N + col)) : v);
     }
-  float* const red = smem + kStageFloats;
+  float* const red = smem + LdsPlan<CFG>::kRedOff;
   __syncthreads();
   st4(red + g * 32 + 4 * piece, s);
   __syncthreads();
@@ -811,9 +841,11 @@ __device__ __forceinline__ void colsum_tile(const float* dy, const float* y, int
     float* p = db + n0 + threadIdx.x;
     *p = accumulate ? *p + t : t;
   }
+  if (CFG::ALIAS) __syncthreads();                   // (the next tile's wave images overwrite `red`)
 }
 
-__global__ __launch_bounds__(kThreads) void gcn_stack_bwd_kernel(const BwdArgs a) {
+template <typename CFG>
+__device__ __forceinline__ void gcn_stack_bwd_body(const BwdArgs& a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   Sync sy = {};
   if (threadIdx.x == 0) sync_begin(sy, a.sync);
@@ -848,12 +880,12 @@ __global__ __launch_bounds__(kThreads) void gcn_stack_bwd_kernel(const BwdArgs a
       st.a = g_obj; st.y = L.new_obj; st.M = O; st.N = H; st.K = Dout; st.W = L.w2b; st.out = dp3; st.act = L.h2;
       WgradStage wg = {};
       wg.dy = g_obj; wg.y = L.new_obj; wg.NI = Dout; wg.x = L.h2; wg.NJ = H; wg.R = O; wg.dw = G.dw2b; wg.accumulate = G.accumulate;
-      const int nrb = (O + 31) >> 5, nd = nrb * (H >> 5), nw = wgrad_tiles(wg), nc = G.db2b ? Dout >> 5 : 0;
+      const int nrb = (O + 31) >> 5, nd = nrb * (H >> 5), nw = wgrad_tiles<CFG>(wg), nc = G.db2b ? Dout >> 5 : 0;
       const TileWalk tw(nd + nw + nc);
       for (int t = tw.first; t < tw.end; t += tw.step) {
-        if (t < nd) dgrad_tile<1>(st, t, nrb, smem, ix, LN);
-        else if (t < nd + nw) wgrad_tile<1, 0>(wg, t - nd, smem, LN);
-        else colsum_tile<true>(g_obj, L.new_obj, O, Dout, (t - nd - nw) << 5, G.db2b, G.accumulate, smem);
+        if (t < nd) dgrad_tile<1, CFG>(st, t, nrb, smem, ix, LN);
+        else if (t < nd + nw) wgrad_tile<1, 0, CFG>(wg, t - nd, smem, LN);
+        else colsum_tile<true, CFG>(g_obj, L.new_obj, O, Dout, (t - nd - nw) << 5, G.db2b, G.accumulate, smem);
       }
     }
     grid_barrier(sy);
@@ -863,12 +895,12 @@ __global__ __launch_bounds__(kThreads) void gcn_stack_bwd_kernel(const BwdArgs a
       st.a = dp3; st.M = O; st.N = H; st.K = H; st.W = L.w2a; st.out = dpooled; st.act = nullptr;
       WgradStage wg = {};
       wg.dy = dp3; wg.NI = H; wg.x = L.pooled; wg.NJ = H; wg.R = O; wg.dw = G.dw2a; wg.accumulate = G.accumulate;
-      const int nrb = (O + 31) >> 5, nd = T > 0 ? nrb * (H >> 5) : 0, nw = wgrad_tiles(wg), nc = G.db2a ? H >> 5 : 0;
+      const int nrb = (O + 31) >> 5, nd = T > 0 ? nrb * (H >> 5) : 0, nw = wgrad_tiles<CFG>(wg), nc = G.db2a ? H >> 5 : 0;
       const TileWalk tw(nd + nw + nc);
       for (int t = tw.first; t < tw.end; t += tw.step) {
-        if (t < nd) dgrad_tile<0>(st, t, nrb, smem, ix, LN);
-        else if (t < nd + nw) wgrad_tile<0, 0>(wg, t - nd, smem, LN);
-        else colsum_tile<false>(dp3, nullptr, O, H, (t - nd - nw) << 5, G.db2a, G.accumulate, smem);
+        if (t < nd) dgrad_tile<0, CFG>(st, t, nrb, smem, ix, LN);
+        else if (t < nd + nw) wgrad_tile<0, 0, CFG>(wg, t - nd, smem, LN);
+        else colsum_tile<false, CFG>(dp3, nullptr, O, H, (t - nd - nw) << 5, G.db2a, G.accumulate, smem);
       }
     }
     if (T > 0) {
@@ -881,7 +913,7 @@ __global__ __launch_bounds__(kThreads) void gcn_stack_bwd_kernel(const BwdArgs a
         st.row_ptr = a.s.row_ptr; st.average = a.s.average; st.dnt = dnt; st.s_idx = a.s.s_idx; st.o_idx = a.s.o_idx;
         const int nrb = (T + 31) >> 5;
         const TileWalk tw(nrb * (H >> 5));
-        for (int t = tw.first; t < tw.end; t += tw.step) dgrad_tile<2>(st, t, nrb, smem, ix, LN);
+        for (int t = tw.first; t < tw.end; t += tw.step) dgrad_tile<2, CFG>(st, t, nrb, smem, ix, LN);
       }
       grid_barrier(sy);
       // ---- P4: d_triple = dp1 W1a;  dW1a, db1a, db1b
@@ -891,14 +923,14 @@ __global__ __launch_bounds__(kThreads) void gcn_stack_bwd_kernel(const BwdArgs a
         WgradStage wg = {};
         wg.dy = dp1; wg.NI = H; wg.NJ = 3 * Din; wg.R = T; wg.dw = G.dw1a; wg.accumulate = G.accumulate;
         wg.obj = xin; wg.ld_obj = ld_x; wg.pred = pin; wg.ld_pred = ld_p; wg.s_idx = a.s.s_idx; wg.o_idx = a.s.o_idx; wg.din = Din;
-        const int nrb = (T + 31) >> 5, nd = nrb * ((3 * Din) >> 5), nw = wgrad_tiles(wg);
+        const int nrb = (T + 31) >> 5, nd = nrb * ((3 * Din) >> 5), nw = wgrad_tiles<CFG>(wg);
         const int nc1 = G.db1a ? H >> 5 : 0, nc2 = G.db1b ? NTc >> 5 : 0;
         const TileWalk tw(nd + nw + nc1 + nc2);
         for (int t = tw.first; t < tw.end; t += tw.step) {
-          if (t < nd) dgrad_tile<0>(st, t, nrb, smem, ix, LN);
-          else if (t < nd + nw) wgrad_tile<0, 1>(wg, t - nd, smem, LN);
-          else if (t < nd + nw + nc1) colsum_tile<false>(dp1, nullptr, T, H, (t - nd - nw) << 5, G.db1a, G.accumulate, smem);
-          else colsum_tile<false>(dnt, nullptr, T, NTc, (t - nd - nw - nc1) << 5, G.db1b, G.accumulate, smem);
+          if (t < nd) dgrad_tile<0, CFG>(st, t, nrb, smem, ix, LN);
+          else if (t < nd + nw) wgrad_tile<0, 1, CFG>(wg, t - nd, smem, LN);
+          else if (t < nd + nw + nc1) colsum_tile<false, CFG>(dp1, nullptr, T, H, (t - nd - nw) << 5, G.db1a, G.accumulate, smem);
+          else colsum_tile<false, CFG>(dnt, nullptr, T, NTc, (t - nd - nw - nc1) << 5, G.db1b, G.accumulate, smem);
         }
       }
       grid_barrier(sy);
@@ -906,9 +938,9 @@ __global__ __launch_bounds__(kThreads) void gcn_stack_bwd_kernel(const BwdArgs a
       {
         WgradStage wg = {};
         wg.dy = dnt; wg.NI = NTc; wg.x = L.h1; wg.NJ = H; wg.R = T; wg.dw = G.dw1b; wg.accumulate = G.accumulate;
-        const int nw = wgrad_tiles(wg);
+        const int nw = wgrad_tiles<CFG>(wg);
         const TileWalk tw(nw);
-        for (int t = tw.first; t < tw.end; t += tw.step) wgrad_tile<0, 0>(wg, t, smem, LN);
+        for (int t = tw.first; t < tw.end; t += tw.step) wgrad_tile<0, 0, CFG>(wg, t, smem, LN);
         if (d_obj) pool_stage(d_triple, 3 * Din, 2 * Din, a.s.row_ptr, a.s.entries, T, Din, false, O, d_obj, LN);
       }
     }
@@ -917,6 +949,15 @@ __global__ __launch_bounds__(kThreads) void gcn_stack_bwd_kernel(const BwdArgs a
   }
   if (threadIdx.x == 0) stamp(sy);
 }
+
+__global__ __launch_bounds__(kThreads) void gcn_stack_bwd_kernel(const BwdArgs a) { gcn_stack_bwd_body<FullFootprint>(a); }
+// <= 168 registers (three wavefronts per SIMD): a wavefront of this kernel fits next to a resident wavefront of the
+// halo'd weight-gradient kernel (wgrad_halo.h: 324 of the SIMD's 512 registers per lane, 88 of the CU's 160 KB of
+// LDS) or next to two of the per-tap kernel's (2 x 152).  The cap costs ~70 spilled registers - values that live
+// ACROSS stages (layer pointers, lane geometry), saved / reloaded around the grid barriers and per tile, never
+// inside a K loop (checked in the ISA with -gline-tables-only): the price of co-residency, 25 times per launch.
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3)))
+void gcn_stack_bwd_low_kernel(const BwdArgs a) { gcn_stack_bwd_body<LowFootprint>(a); }
 
 static int g_cus = 0;
 
@@ -931,6 +972,9 @@ hipError_t prepare() {
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(gcn_stack_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kLdsBytes);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gcn_stack_bwd_low_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LdsPlan<LowFootprint>::kBytes);
   if (e == hipSuccess) g_cus = cus > 0 ? cus : 1;
   return e;
 }
@@ -973,6 +1017,10 @@ static int grid_for(const sg2im_gconv_stack* S, bool backward) {
     if (backward) most = std::max({most, (NTc / 32) * ((L.hidden + 63) / 64), rt * (3 * L.din / 32) + (L.hidden / 32) * ((3 * L.din + 63) / 64)});
   }
   int grid = (int)std::min<long long>(g_cus, most);
+  // (probe knob: fewer resident workgroups for the BACKWARD launch - it then takes longer but leaves more of every CU
+  // to the weight gradients it runs next to)
+  static const int cap = getenv("SG2IM_GCN_BWD_GRID") ? atoi(getenv("SG2IM_GCN_BWD_GRID")) : 0;
+  if (backward && cap > 0) grid = std::min(grid, cap);
   if (grid >= 8) grid &= ~7;
   return grid;
 }
@@ -1046,7 +1094,11 @@ int sg2im_gconv_stack_backward(const sg2im_gconv_stack* S, const sg2im_gconv_sta
   a.off_dobj0 = (long long)off; off += up4(O * D);
   a.off_dobj1 = (long long)off; off += up4(O * D);
   a.sync = static_cast<unsigned*>(sync);
-  SG2IM_LAUNCH(gcn::gcn_stack_bwd_kernel, dim3(gcn::grid_for(S, true)), dim3(gcn::kThreads), gcn::kLdsBytes, stream, a);
+  if (G->low_footprint)
+    SG2IM_LAUNCH(gcn::gcn_stack_bwd_low_kernel, dim3(gcn::grid_for(S, true)), dim3(gcn::kThreads),
+                 gcn::LdsPlan<gcn::LowFootprint>::kBytes, stream, a);
+  else
+    SG2IM_LAUNCH(gcn::gcn_stack_bwd_kernel, dim3(gcn::grid_for(S, true)), dim3(gcn::kThreads), gcn::kLdsBytes, stream, a);
   return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
 }
 

@@ -384,112 +384,112 @@ __global__ __launch_bounds__(256) void layout_bwd_vecs_kernel(const float* __res
 // lanes along the channels, several pixels in flight per thread.
 struct GradLevels { const float* p[5]; int ld[5]; int shift[5]; float k[5]; int n; };
 
-constexpr int BOL = 16;     // objects per register pass of the level-gradient form (an image rarely has more)
-constexpr int BPL = 256;    // pixels per workgroup of the level-gradient form (128 KB of level-0 gradient at 128 channels)
+// Round 5 form (the round-4 kernel - 256-pixel tiles, 16 float4 accumulators + 2 x 8 staged loads
+// per thread = 196 registers, 512 workgroups - ran at 0.23 of 8 TB/s isolated and 172 us under the weight-gradient
+// lane): many light workgroups.  A workgroup owns an 8 x 8 PIXEL TILE of one image and a slab of <= 128 channels:
+//   1. g[pixel][channel] = sum over levels of level[l][pixel >> l] / 4^l (pyramid_bwd_v4_kernel's order, level 0
+//      first) is formed ONCE - every level's loads of a half tile issued back to back - and parked in LDS (32 KB);
+//   2. S[object][pixel], the bilinear mask samples of the image's objects at the tile's pixels (<= 16 objects per pass);
+//   3. the contraction d_vecs[o][c] += sum_pixel S[o][pixel] g[pixel][c] runs out of LDS: a thread owns one float4
+//      of channels for one or two objects and walks the 64 pixels in order (fixed order: reproducible);
+//   4. one partial per (tile, object) - summed over the tiles by layout_bwd_reduce_kernel.
+// ~70 registers, 36 KB of LDS: four workgroups per CU, 2 048 workgroups at the bench shape.
+constexpr int BOL = 16;     // objects per pass (an image rarely has more)
+constexpr int TPX = 64;     // pixels per tile (8 x 8)
+constexpr int TCH = 128;    // channels per slab
 
 __global__ __launch_bounds__(256) void layout_bwd_vecs_levels_kernel(GradLevels lv, const float* __restrict__ boxes, MaskRef mk,
                                                                      const int* __restrict__ img_row_ptr,
                                                                      const int* __restrict__ img_entries, int O, int D,
-                                                                     int H, int W, int align_corners,
+                                                                     int H, int W, int tiles_x, int align_corners,
                                                                      float* __restrict__ part) {
-  __shared__ float S[BOL][BPL + 1];
+  __shared__ __attribute__((aligned(16))) float G[TPX][TCH];
+  __shared__ float S[BOL][TPX + 1];
   __shared__ int objs[BOL];
-  extern __shared__ __attribute__((aligned(16))) float red[];          // [8][TR][TC] float4 reduction scratch
-  const int n = blockIdx.y, p0 = blockIdx.x * BPL, HW = H * W;
-  const int tid = threadIdx.x;
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const int ty0 = (blockIdx.x / tiles_x) * 8, tx0 = (blockIdx.x % tiles_x) * 8;
   const int ob = img_row_ptr[n], oe = img_row_ptr[n + 1];
+  if (ob == oe) return;                               // (workgroup-uniform: an image without objects)
   const int Min = mk.M == 0 ? 8 : mk.M;
-  const int D4 = D >> 2;
-  const int TC = D4 < 256 ? D4 : 256, TR = 256 / TC;          // float4 lanes along channels x pixel groups
-  const int tx = tid % TC, pg = tid / TC;
-  for (int cb = ob; cb < oe; cb += BOL) {
-    const int nobj = min(BOL, oe - cb);
-    __syncthreads();
-    if (tid < nobj) objs[tid] = img_entries[cb + tid];
-    __syncthreads();
-    for (int e = tid; e < nobj * BPL; e += 256) {
-      const int oi = e / BPL, pp = e - oi * BPL;
-      const int px = p0 + pp;
-      float s = 0.f;
-      if (px < HW) {
-        const int o = objs[oi];
-        const Foot f = footprint(boxes + 4LL * o, px / W, px % W, H, W, Min, align_corners);
-        s = sample_map(mk, o, f);
-      }
-      S[oi][pp] = s;
-    }
-    for (int e = nobj * BPL + tid; e < BOL * BPL; e += 256) S[e / BPL][e % BPL] = 0.f;       // (unused object slots)
-    __syncthreads();
-    for (int c4 = tx; c4 < D4; c4 += TC) {
-      float4 acc[BOL];
-      #pragma unroll
-      for (int k = 0; k < BOL; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pg < TR) {
-        // this thread's pixels pg, pg + TR, ... in groups of 8: per group, level by level, the 8 loads of a level are
-        // issued back to back (a pixel-by-pixel loop would wait for every pixel's loads in turn)
-        for (int pb = pg; pb < BPL; pb += 8 * TR) {
-          float4 g[8];
+  for (int c0 = 0; c0 < D; c0 += TCH) {
+    const int DS = min(TCH, D - c0), D4 = DS >> 2;   // this slab's channels / float4 lanes (D % 4 == 0)
+    // ---- 1. the summed level gradient of the tile -> LDS ----
+    __syncthreads();                                  // (the previous slab's contraction is done with G)
+    {
+      const int c4 = tid % D4, prow = tid / D4, PR = 256 / D4;     // PR pixel rows of the thread grid
+      if (prow < PR) {
+        #pragma unroll 1
+        for (int pb = prow; pb < TPX; pb += 4 * PR) {
+          float4 g[4];
           #pragma unroll
-          for (int i = 0; i < 8; ++i) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int i = 0; i < 4; ++i) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
           #pragma unroll
           for (int l = 0; l < 5; ++l) {
             if (l < lv.n) {
               const int sh = lv.shift[l];
               const float kk = lv.k[l];
-              const float* const base = lv.p[l] + 4 * c4;
+              const float* const base = lv.p[l] + c0 + 4 * c4;
               const int hl = H >> sh, wl = W >> sh, ldl = lv.ld[l];
-              float4 v[8];
+              float4 v[4];
               #pragma unroll
-              for (int i = 0; i < 8; ++i) {
-                const int px = min(p0 + pb + i * TR, HW - 1);
-                const int y = px / W, x = px - y * W;
+              for (int i = 0; i < 4; ++i) {
+                const int pp = min(pb + i * PR, TPX - 1);
+                const int y = min(ty0 + (pp >> 3), H - 1), x = min(tx0 + (pp & 7), W - 1);
                 v[i] = *reinterpret_cast<const float4*>(base + ((long long)(n * hl + (y >> sh)) * wl + (x >> sh)) * ldl);
               }
               #pragma unroll
-              for (int i = 0; i < 8; ++i) {          // (pyramid_bwd_v4_kernel's sum: level 0 first)
+              for (int i = 0; i < 4; ++i) {            // (pyramid_bwd_v4_kernel's sum: level 0 first)
                 g[i].x += v[i].x * kk; g[i].y += v[i].y * kk; g[i].z += v[i].z * kk; g[i].w += v[i].w * kk;
               }
             }
           }
           #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int pp = pb + i * TR;
-            if (pp < BPL && p0 + pp < HW) {
-              #pragma unroll
-              for (int k = 0; k < BOL; ++k) {
-                const float sv = S[k][pp];
-                acc[k].x = fmaf(g[i].x, sv, acc[k].x); acc[k].y = fmaf(g[i].y, sv, acc[k].y);
-                acc[k].z = fmaf(g[i].z, sv, acc[k].z); acc[k].w = fmaf(g[i].w, sv, acc[k].w);
-              }
-            }
+          for (int i = 0; i < 4; ++i) {
+            const int pp = pb + i * PR;
+            if (pp < TPX) *reinterpret_cast<float4*>(&G[pp][4 * c4]) = g[i];     // (pixels outside the image: S is 0 there)
           }
         }
       }
-      if (TR > 1) {
-        // the TR pixel groups' partials through LDS, eight objects at a time (32 KB), added in group order
-        #pragma unroll
-        for (int kh = 0; kh < BOL; kh += 8) {
-          if (kh >= nobj) break;                       // (workgroup-uniform)
-          __syncthreads();
-          #pragma unroll
-          for (int k = 0; k < 8; ++k) *reinterpret_cast<float4*>(red + 4 * ((k * TR + pg) * TC + tx)) = acc[kh + k];
-          __syncthreads();
-          for (int e = tid; e < 8 * TC; e += 256) {
-            const int k = e / TC, t4 = e - k * TC;
-            if (kh + k < nobj && t4 + (c4 - tx) < D4) {
-              float4 sum = *reinterpret_cast<const float4*>(red + 4 * ((k * TR) * TC + t4));
-              for (int t = 1; t < TR; ++t) {
-                const float4 v = *reinterpret_cast<const float4*>(red + 4 * ((k * TR + t) * TC + t4));
-                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-              }
-              *reinterpret_cast<float4*>(part + ((long long)blockIdx.x * O + objs[kh + k]) * D + 4 * (t4 + (c4 - tx))) = sum;
+    }
+    for (int cb = ob; cb < oe; cb += BOL) {
+      const int nobj = min(BOL, oe - cb);
+      __syncthreads();                                // (G complete; the previous pass is done with S / objs)
+      if (tid < nobj) objs[tid] = img_entries[cb + tid];
+      __syncthreads();
+      // ---- 2. mask samples of this pass' objects at the tile's pixels ----
+      for (int e = tid; e < BOL * TPX; e += 256) {
+        const int oi = e / TPX, pp = e - oi * TPX;
+        const int y = ty0 + (pp >> 3), x = tx0 + (pp & 7);
+        float sv = 0.f;
+        if (oi < nobj && y < H && x < W) {
+          const int o = objs[oi];
+          const Foot f = footprint(boxes + 4LL * o, y, x, H, W, Min, align_corners);
+          sv = sample_map(mk, o, f);
+        }
+        S[oi][pp] = sv;
+      }
+      __syncthreads();
+      // ---- 3. contraction out of LDS: thread -> (float4 lane c4, objects k, k + KG, ...) ----
+      {
+        const int c4 = tid % D4, k0 = tid / D4;
+        const int KG = min(256 / D4, BOL);            // object rows of the thread grid (8 at 128 channels)
+        if (k0 < KG) {
+          for (int k = k0; k < nobj; k += 2 * KG) {  // two objects per sweep over the pixels
+            const int k1 = k + KG;
+            const bool two = k1 < nobj;
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+            #pragma unroll 8
+            for (int pp = 0; pp < TPX; ++pp) {
+              const float4 gv = *reinterpret_cast<const float4*>(&G[pp][4 * c4]);
+              const float s0 = S[k][pp], s1 = two ? S[k1][pp] : 0.f;
+              a0.x = fmaf(gv.x, s0, a0.x); a0.y = fmaf(gv.y, s0, a0.y); a0.z = fmaf(gv.z, s0, a0.z); a0.w = fmaf(gv.w, s0, a0.w);
+              a1.x = fmaf(gv.x, s1, a1.x); a1.y = fmaf(gv.y, s1, a1.y); a1.z = fmaf(gv.z, s1, a1.z); a1.w = fmaf(gv.w, s1, a1.w);
             }
+            // ---- 4. the tile's partial for these objects ----
+            *reinterpret_cast<float4*>(part + ((long long)blockIdx.x * O + objs[k]) * D + c0 + 4 * c4) = a0;
+            if (two) *reinterpret_cast<float4*>(part + ((long long)blockIdx.x * O + objs[k1]) * D + c0 + 4 * c4) = a1;
           }
         }
-      } else {
-        #pragma unroll
-        for (int k = 0; k < BOL; ++k)
-          if (k < nobj) *reinterpret_cast<float4*>(part + ((long long)blockIdx.x * O + objs[k]) * D + 4 * c4) = acc[k];
       }
     }
   }
@@ -500,7 +500,8 @@ __global__ void layout_bwd_reduce_kernel(const float* __restrict__ part, int n_t
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)O * D) return;
   float s = 0.f;
-  for (int t = 0; t < n_tiles; ++t) s += part[(long long)t * O * D + i];
+  #pragma unroll 8
+  for (int t = 0; t < n_tiles; ++t) s += part[(long long)t * O * D + i];      // (independent loads, adds in tile order)
   dvecs[(i / D) * ld_dvecs + (i % D)] = s;
 }
 
@@ -873,7 +874,9 @@ int sg2im_layout_pyramid_forward(const float* vecs, long long ld_vecs, const flo
 size_t sg2im_layout_backward_workspace(int n_objs, int dim, int height, int width) {
   const size_t vec_part = sizeof(float) * (size_t)((height * width + BP - 1) / BP) * (size_t)n_objs * (size_t)dim;
   const size_t g_planes = sizeof(float) * (size_t)n_objs * (size_t)height * (size_t)width;   // mask / box gradients
-  return vec_part > g_planes ? vec_part : g_planes;
+  // sg2im_layout_backward_vecs_levels: one partial per 8 x 8 pixel tile and object
+  const size_t lev_part = sizeof(float) * (size_t)((height + 7) / 8) * (size_t)((width + 7) / 8) * (size_t)n_objs * (size_t)dim;
+  return std::max(std::max(vec_part, g_planes), lev_part);
 }
 
 int sg2im_layout_backward(const float* dlayout, long long ld_dlayout, const float* vecs,
@@ -937,14 +940,14 @@ int sg2im_layout_backward_vecs_levels(const float* const* dlevels, const int* fa
     lv.p[l] = dlevels[l]; lv.ld[l] = (int)lds[l]; lv.shift[l] = __builtin_ctz((unsigned)f); lv.k[l] = 1.f / (float)(f * f);
   }
   const MaskRef mk{masks, masks_i64, (masks || masks_i64) ? mask_size : 0};
-  const int n_tiles = (height * width + BPL - 1) / BPL;
+  const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
+  const int n_tiles = tiles_x * tiles_y;
   const size_t vec_part = sizeof(float) * (size_t)n_tiles * (size_t)n_objs * (size_t)dim;
+  // (zero-filled: a workgroup writes the partials of ITS image's objects only)
   if (hipMemsetAsync(workspace, 0, vec_part, stream) != hipSuccess) return SG2IM_ERR_HIP;
-  const int D4 = dim / 4, TC = D4 < 256 ? D4 : 256, TR = 256 / TC;
-  const size_t lds_bytes = sizeof(float) * 4 * (size_t)8 * TR * TC;
   dim3 grid(n_tiles, n_images);
-  SG2IM_LAUNCH(layout_bwd_vecs_levels_kernel, grid, dim3(256), lds_bytes, stream, lv, boxes, mk, img_row_ptr, img_entries,
-                     n_objs, dim, height, width, align_corners, workspace);
+  SG2IM_LAUNCH(layout_bwd_vecs_levels_kernel, grid, dim3(256), 0, stream, lv, boxes, mk, img_row_ptr, img_entries,
+                     n_objs, dim, height, width, tiles_x, align_corners, workspace);
   const long long tot = (long long)n_objs * dim;
   SG2IM_LAUNCH(layout_bwd_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, workspace, n_tiles,
                      n_objs, dim, d_vecs, ld_dvecs);

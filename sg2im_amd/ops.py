@@ -607,16 +607,18 @@ def gconv_layer_backward(L, h1, new_t, pooled, h2, new_obj, g_obj, g_pred, d_tri
 
 GCN_PERSISTENT = os.environ.get('SG2IM_GCN_PERSIST', '1') != '0'      # (A/B knob: 0 = one call per layer)
 # The one-launch backward needs every one of its workgroups resident at once (grid barriers).  Inside the captured
-# training iteration it would start underneath the refinement network's released weight gradients, which occupy every
-# CU: its first barrier then waits ~0.5 ms for residency and the step gets slower (8.32 vs 7.99 ms,
-# profiles/r4_gcn_persistent_backward_ab.txt).  Default therefore: layer by layer (sg2im_gconv_layer_backward) -
-# in eager mode too, so that eager and replayed iterations stay bit-identical; SG2IM_GCN_PERSIST_BWD=1 selects the
-# one-launch form (standalone 419 us for the five layers, tested against the layer-by-layer form in sec_gconv_stack).
-GCN_PERSISTENT_BACKWARD = os.environ.get('SG2IM_GCN_PERSIST_BWD', '0') == '1'
+# training iteration it starts underneath the refinement network's released weight gradients, which occupy every CU.
+# 'full' (round 4: ~390 registers, 98 KB of LDS per workgroup = whole CUs): its first barrier waited ~0.5 ms for
+# residency, 8.32 vs 7.99 ms (profiles/r4_gcn_persistent_backward_ab.txt).  'low' (round 5: <= 168 registers, 41 KB
+# of LDS, 32 x 32 tiles, sg2im_gconv_stack_grads.low_footprint): its workgroups fit next to the weight gradients'.
+# SG2IM_GCN_PERSIST_BWD = 0 | full | low (1 = full); the same form runs in eager mode too, so that eager and replayed
+# iterations stay bit-identical.  Both forms are tested against the layer-by-layer launches in sec_gconv_stack.
+_bwd_mode = os.environ.get('SG2IM_GCN_PERSIST_BWD', '0')
+GCN_PERSISTENT_BACKWARD = {'0': False, '': False, '1': 'full', 'full': 'full', 'low': 'low', '2': 'low'}.get(_bwd_mode, False)
 
 
 def gconv_stack_backward_in_one_launch():
-  return GCN_PERSISTENT_BACKWARD
+  return bool(GCN_PERSISTENT_BACKWARD)
 
 
 def gconv_stack_supported(dims):
@@ -677,6 +679,7 @@ def gconv_stack_backward(S, g_obj, g_pred, d_triple, d_obj, grads, accumulate, d
     for k, t in zip(('dw1a', 'db1a', 'dw1b', 'db1b', 'dw2a', 'db2a', 'dw2b', 'db2b'), gl):
       setattr(G.layer[l], k, _f(t).value if t is not None else None)
     G.layer[l].accumulate = int(bool(accumulate))
+  G.low_footprint = 1 if GCN_PERSISTENT_BACKWARD == 'low' else 0
   sy = sync_area(device)
   _timed('igemm_dgrad', 2.0 * S._flops, lambda: call('sg2im_gconv_stack_backward', byref(S), byref(G), c_void_p(sy.data_ptr()),
                                                      sy.numel() * 4, _stream()))

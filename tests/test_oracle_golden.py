@@ -199,3 +199,52 @@ def test_fp32_gradient_of_the_step_is_only_accurate_to_1e2():
   assert len(errs) > 90
   assert sum(1 for e in errs if e > 1e-3) >= 5, sorted(errs)[-8:]
   assert max(errs) < 0.2, max(errs)
+
+
+def test_bf16_operand_emulation_of_the_oracle():
+  """oracle.OPERAND_ROUND = 'bf16' (the CPU statement of what the HIP library's bf16 operand mode computes, used by
+  tests/test_gpu_parity.py::test_bf16_*): off by default and then bit-identical to F.conv2d; when on, the forward
+  value and both gradients of a spatial convolution equal plain autograd through F.conv2d on operands rounded to
+  bfloat16 (each pass rounding ITS two operands), the rounding follows the library's dispatch rules (input channels
+  not a multiple of 4: nothing rounds; output channels not a multiple of 4: only the forward pass rounds; the first
+  refinement module's dropped zero channel), and linear layers never round."""
+  import torch.nn.functional as F
+  from oracle import sg2im_oracle as orc
+  r = lambda t: t.to(torch.bfloat16).to(t.dtype)
+  g = torch.Generator().manual_seed(5)
+  assert orc.OPERAND_ROUND is None
+  x = torch.randn(2, 8, 6, 6, generator=g, dtype=torch.float64)
+  w = torch.randn(12, 8, 3, 3, generator=g, dtype=torch.float64)
+  b = torch.randn(12, generator=g, dtype=torch.float64)
+  assert torch.equal(orc.conv2d(x, w, b, padding=1), F.conv2d(x, w, b, padding=1))
+  orc.OPERAND_ROUND = 'bf16'
+  try:
+    for (cin, cout, stride, pad, k, cin_eff, rf, rd, rw) in ((8, 12, 1, 1, 3, None, True, True, True), (8, 3, 1, 0, 1, None, True, False, False),
+                                                             (3, 8, 2, 0, 4, None, False, False, False), (9, 8, 1, 1, 3, 8, True, True, True),
+                                                             (4, 8, 1, 1, 3, None, True, False, True)):
+      x = torch.randn(2, cin, 7, 7, generator=g, dtype=torch.float64, requires_grad=True)
+      w = torch.randn(cout, cin, k, k, generator=g, dtype=torch.float64, requires_grad=True)
+      b = torch.randn(cout, generator=g, dtype=torch.float64, requires_grad=True)
+      y = orc.conv2d(x, w, b, stride=stride, padding=pad, cin_eff=cin_eff)
+      assert torch.equal(y, F.conv2d(r(x) if rf else x, r(w) if rf else w, b, stride=stride, padding=pad)), (cin, cout)
+      gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+      y.backward(gy)
+      # independent statement of the two gradients: plain autograd of F.conv2d, linear in each operand
+      x2 = x.detach().clone().requires_grad_(True)
+      F.conv2d(x2, (r(w) if rd else w).detach(), None, stride=stride, padding=pad).backward(r(gy) if rd else gy)
+      w2 = w.detach().clone().requires_grad_(True)
+      F.conv2d((r(x) if rw else x).detach(), w2, None, stride=stride, padding=pad).backward(r(gy) if rw else gy)
+      assert torch.allclose(x.grad, x2.grad, rtol=1e-12, atol=1e-12), (cin, cout)
+      assert torch.allclose(w.grad, w2.grad, rtol=1e-12, atol=1e-12), (cin, cout)
+      assert torch.allclose(b.grad, gy.sum((0, 2, 3)), rtol=1e-12, atol=1e-12)
+      if rf:
+        assert not torch.equal(y, F.conv2d(x, w, b, stride=stride, padding=pad))        # (the rounding is really there)
+    # linear layers (GraphTripleConv, heads) are untouched
+    P = {}
+    orc._lin(P, 'm.0', 8, 6, g); orc._lin(P, 'm.2', 4, 8, g)
+    v = torch.randn(5, 6, generator=g)
+    on = orc.mlp(P, 'm', v)
+    orc.OPERAND_ROUND = None
+    assert torch.equal(on, orc.mlp(P, 'm', v))
+  finally:
+    orc.OPERAND_ROUND = None

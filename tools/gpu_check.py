@@ -570,7 +570,7 @@ def _masked_stack_reference(Wcpu, dims, ov, pv, s, o, pooling, acts):
   return xin, pin, x, pr, Wd
 
 
-def _gconv_stack_case(tag, O, T, dims, pooling, g, s=None, o=None):
+def _gconv_stack_case(tag, O, T, dims, pooling, g, s=None, o=None, mode='full'):
   """dims: [(din, H, dout)] per layer.  The persistent stack kernels (HF.GraphTripleConvStackFn): outputs against the
   oracle's layer-by-layer composition; the saved `pooled` against sg2im_segment_sum over its OWN new_t (bit-exact: the
   loader-side pool follows the reference's accumulation order); every gradient against the float64 reference of the
@@ -599,7 +599,8 @@ def _gconv_stack_case(tag, O, T, dims, pooling, g, s=None, o=None):
   csr = ops.Csr(sd, od, O)
   ovd, pvd = ov.to(D).requires_grad_(True), pv.to(D).requires_grad_(True)
   assert ops.gconv_stack_supported(dims), dims
-  keep_bwd, ops.GCN_PERSISTENT_BACKWARD = ops.GCN_PERSISTENT_BACKWARD, True      # (the one-launch backward is what is checked)
+  tag = '%s [%s]' % (tag, mode)
+  keep_bwd, ops.GCN_PERSISTENT_BACKWARD = ops.GCN_PERSISTENT_BACKWARD, mode      # (the one-launch backward is what is checked: 'full' / 'low' footprint)
   xd, prd = HF.GraphTripleConvStackFn.apply(ovd, pvd, sd, od, csr, pooling == 'avg', *W)
   ops.gconv_stack_check(D)
   report(tag + ' obj out', xd, x); report(tag + ' pred out', prd, pr)
@@ -697,14 +698,15 @@ def _gconv_stack_plain_case(tag, O, T, dims, pooling):
   csr = ops.Csr(sd, od, O)
   keep_bwd = ops.GCN_PERSISTENT_BACKWARD
   try:
-    for one_launch in (True, False):
+    for one_launch in ('full', 'low', False):
       ops.GCN_PERSISTENT_BACKWARD = one_launch
       W = [w.to(D).requires_grad_(True) for w in Wc]
       ovd, pvd = ov.to(D).requires_grad_(True), pv.to(D).requires_grad_(True)
       xd, prd = HF.GraphTripleConvStackFn.apply(ovd, pvd, sd, od, csr, pooling == 'avg', *W)
       (xd * go.to(D)).sum().add((prd * gp.to(D)).sum()).backward()
       ops.gconv_stack_check(D)
-      t = '%s (seed %d, margin %.1e, %s backward) vs the plain float64 oracle: ' % (tag, seed, margin, 'one-launch' if one_launch else 'per-layer')
+      t = '%s (seed %d, margin %.1e, %s backward) vs the plain float64 oracle: ' % (
+        tag, seed, margin, ('one-launch ' + one_launch) if one_launch else 'per-layer')
       report(t + 'obj out', xd, xr); report(t + 'pred out', prd, prr)
       report(t + 'd obj', ovd.grad, ovr.grad); report(t + 'd pred', pvd.grad, pvr.grad)
       for i, n in enumerate(names):
@@ -715,21 +717,22 @@ def _gconv_stack_plain_case(tag, O, T, dims, pooling):
 
 def sec_gconv_stack():
   _gconv_stack_plain_case('stack small plain', 8, 12, [(32, 32, 32)] * 2, 'avg')
-  g = torch.Generator().manual_seed(7)
-  batch = synthetic_batch(32, seed=3)
-  objs, triples = batch[1], batch[4]
-  # the training shape: 5 layers 128 -> 512 -> 128 on a COCO-style batch of 32 images
-  _gconv_stack_case('stack coco b32', objs.numel(), triples.size(0), [(128, 512, 128)] * 5, 'avg', g,
-                    triples[:, 0].contiguous(), triples[:, 2].contiguous())
-  # ragged sizes (rows not multiples of 32), a narrower first layer, 'sum' pooling, rows with many entries
-  _gconv_stack_case('stack ragged sum', 45, 333, [(64, 128, 96), (96, 128, 96)], 'sum', g)
-  # one object collects most entries (a long CSR row), several isolated objects
-  s = torch.randint(0, 3, (150,), generator=g); o = torch.randint(0, 3, (150,), generator=g)
-  _gconv_stack_case('stack long rows', 40, 150, [(32, 64, 32)] * 3, 'avg', g, s, o)
-  # no triples at all: every object pools to zero (net2(0))
-  _gconv_stack_case('stack no triples', 37, 0, [(32, 64, 32)] * 2, 'avg', g)
-  # one layer, more than 256 tiles per stage (several rounds over the resident grid)
-  _gconv_stack_case('stack large', 700, 2100, [(128, 512, 128)], 'avg', g)
+  for mode in ('full', 'low'):       # the one-launch backward in both footprints (sg2im_gconv_stack_grads.low_footprint)
+    g = torch.Generator().manual_seed(7)
+    batch = synthetic_batch(32, seed=3)
+    objs, triples = batch[1], batch[4]
+    # the training shape: 5 layers 128 -> 512 -> 128 on a COCO-style batch of 32 images
+    _gconv_stack_case('stack coco b32', objs.numel(), triples.size(0), [(128, 512, 128)] * 5, 'avg', g,
+                      triples[:, 0].contiguous(), triples[:, 2].contiguous(), mode=mode)
+    # ragged sizes (rows not multiples of 32), a narrower first layer, 'sum' pooling, rows with many entries
+    _gconv_stack_case('stack ragged sum', 45, 333, [(64, 128, 96), (96, 128, 96)], 'sum', g, mode=mode)
+    # one object collects most entries (a long CSR row), several isolated objects
+    s = torch.randint(0, 3, (150,), generator=g); o = torch.randint(0, 3, (150,), generator=g)
+    _gconv_stack_case('stack long rows', 40, 150, [(32, 64, 32)] * 3, 'avg', g, s, o, mode=mode)
+    # no triples at all: every object pools to zero (net2(0))
+    _gconv_stack_case('stack no triples', 37, 0, [(32, 64, 32)] * 2, 'avg', g, mode=mode)
+    # one layer, more than 256 tiles per stage (several rounds over the resident grid)
+    _gconv_stack_case('stack large', 700, 2100, [(128, 512, 128)], 'avg', g, mode=mode)
 
 
 def sec_layout():
