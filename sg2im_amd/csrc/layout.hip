@@ -387,15 +387,19 @@ struct GradLevels { const float* p[5]; int ld[5]; int shift[5]; float k[5]; int 
 // Round 5 form (the round-4 kernel - 256-pixel tiles, 16 float4 accumulators + 2 x 8 staged loads
 // per thread = 196 registers, 512 workgroups - ran at 0.23 of 8 TB/s isolated and 172 us under the weight-gradient
 // lane): many light workgroups.  A workgroup owns an 8 x 8 PIXEL TILE of one image and a slab of <= 128 channels:
-//   1. g[pixel][channel] = sum over levels of level[l][pixel >> l] / 4^l (pyramid_bwd_v4_kernel's order, level 0
-//      first) is formed ONCE - every level's loads of a half tile issued back to back - and parked in LDS (32 KB);
-//   2. S[object][pixel], the bilinear mask samples of the image's objects at the tile's pixels (<= 16 objects per pass);
+//   1. S[object][pixel], the bilinear mask samples of the image's objects at the tile's pixels (<= 16 objects per pass);
+//   2. per HALF tile (4 x 8 pixels): g[pixel][channel] = sum over levels of level[l][pixel >> l] / 4^l
+//      (pyramid_bwd_v4_kernel's order, level 0 first) is formed once - every level's loads issued back to back - and
+//      parked in LDS (16 KB);
 //   3. the contraction d_vecs[o][c] += sum_pixel S[o][pixel] g[pixel][c] runs out of LDS: a thread owns one float4
-//      of channels for one or two objects and walks the 64 pixels in order (fixed order: reproducible);
+//      of channels for one or two objects and walks the pixels in order (fixed order: reproducible), accumulating
+//      over the two halves in registers;
 //   4. one partial per (tile, object) - summed over the tiles by layout_bwd_reduce_kernel.
-// ~70 registers, 36 KB of LDS: four workgroups per CU, 2 048 workgroups at the bench shape.
+// ~90 registers, 20.6 KB of LDS: two workgroups fit into the 48 KB a CU has left next to the refinement network's
+// background weight gradients (the kernel runs in their shadow), 2 048 workgroups at the bench shape.
 constexpr int BOL = 16;     // objects per pass (an image rarely has more)
 constexpr int TPX = 64;     // pixels per tile (8 x 8)
+constexpr int HPX = 32;     // pixels per half tile (4 x 8): the unit that is staged in LDS
 constexpr int TCH = 128;    // channels per slab
 
 __global__ __launch_bounds__(256) void layout_bwd_vecs_levels_kernel(GradLevels lv, const float* __restrict__ boxes, MaskRef mk,
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(256) void layout_bwd_vecs_levels_kernel(GradLevels 
                                                                      const int* __restrict__ img_entries, int O, int D,
                                                                      int H, int W, int tiles_x, int align_corners,
                                                                      float* __restrict__ part) {
-  __shared__ __attribute__((aligned(16))) float G[TPX][TCH];
+  __shared__ __attribute__((aligned(16))) float G[HPX][TCH];
   __shared__ float S[BOL][TPX + 1];
   __shared__ int objs[BOL];
   const int n = blockIdx.y, tid = threadIdx.x;
@@ -413,50 +417,15 @@ __global__ __launch_bounds__(256) void layout_bwd_vecs_levels_kernel(GradLevels 
   const int Min = mk.M == 0 ? 8 : mk.M;
   for (int c0 = 0; c0 < D; c0 += TCH) {
     const int DS = min(TCH, D - c0), D4 = DS >> 2;   // this slab's channels / float4 lanes (D % 4 == 0)
-    // ---- 1. the summed level gradient of the tile -> LDS ----
-    __syncthreads();                                  // (the previous slab's contraction is done with G)
-    {
-      const int c4 = tid % D4, prow = tid / D4, PR = 256 / D4;     // PR pixel rows of the thread grid
-      if (prow < PR) {
-        #pragma unroll 1
-        for (int pb = prow; pb < TPX; pb += 4 * PR) {
-          float4 g[4];
-          #pragma unroll
-          for (int i = 0; i < 4; ++i) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-          #pragma unroll
-          for (int l = 0; l < 5; ++l) {
-            if (l < lv.n) {
-              const int sh = lv.shift[l];
-              const float kk = lv.k[l];
-              const float* const base = lv.p[l] + c0 + 4 * c4;
-              const int hl = H >> sh, wl = W >> sh, ldl = lv.ld[l];
-              float4 v[4];
-              #pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                const int pp = min(pb + i * PR, TPX - 1);
-                const int y = min(ty0 + (pp >> 3), H - 1), x = min(tx0 + (pp & 7), W - 1);
-                v[i] = *reinterpret_cast<const float4*>(base + ((long long)(n * hl + (y >> sh)) * wl + (x >> sh)) * ldl);
-              }
-              #pragma unroll
-              for (int i = 0; i < 4; ++i) {            // (pyramid_bwd_v4_kernel's sum: level 0 first)
-                g[i].x += v[i].x * kk; g[i].y += v[i].y * kk; g[i].z += v[i].z * kk; g[i].w += v[i].w * kk;
-              }
-            }
-          }
-          #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int pp = pb + i * PR;
-            if (pp < TPX) *reinterpret_cast<float4*>(&G[pp][4 * c4]) = g[i];     // (pixels outside the image: S is 0 there)
-          }
-        }
-      }
-    }
+    const int c4 = tid % D4, trow = tid / D4;        // thread grid: float4 lane x (pixel row | object row)
+    const int PR = 256 / D4;                          // pixel rows of the loader's thread grid
+    const int KG = min(256 / D4, BOL);                // object rows of the contraction's thread grid (8 at 128 channels)
     for (int cb = ob; cb < oe; cb += BOL) {
       const int nobj = min(BOL, oe - cb);
-      __syncthreads();                                // (G complete; the previous pass is done with S / objs)
+      __syncthreads();                                // (the previous pass / slab is done with S, objs and G)
       if (tid < nobj) objs[tid] = img_entries[cb + tid];
       __syncthreads();
-      // ---- 2. mask samples of this pass' objects at the tile's pixels ----
+      // ---- 1. mask samples of this pass' objects at the tile's pixels ----
       for (int e = tid; e < BOL * TPX; e += 256) {
         const int oi = e / TPX, pp = e - oi * TPX;
         const int y = ty0 + (pp >> 3), x = tx0 + (pp & 7);
@@ -468,28 +437,62 @@ __global__ __launch_bounds__(256) void layout_bwd_vecs_levels_kernel(GradLevels 
         }
         S[oi][pp] = sv;
       }
-      __syncthreads();
-      // ---- 3. contraction out of LDS: thread -> (float4 lane c4, objects k, k + KG, ...) ----
-      {
-        const int c4 = tid % D4, k0 = tid / D4;
-        const int KG = min(256 / D4, BOL);            // object rows of the thread grid (8 at 128 channels)
-        if (k0 < KG) {
-          for (int k = k0; k < nobj; k += 2 * KG) {  // two objects per sweep over the pixels
-            const int k1 = k + KG;
-            const bool two = k1 < nobj;
-            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-            #pragma unroll 8
-            for (int pp = 0; pp < TPX; ++pp) {
-              const float4 gv = *reinterpret_cast<const float4*>(&G[pp][4 * c4]);
-              const float s0 = S[k][pp], s1 = two ? S[k1][pp] : 0.f;
-              a0.x = fmaf(gv.x, s0, a0.x); a0.y = fmaf(gv.y, s0, a0.y); a0.z = fmaf(gv.z, s0, a0.z); a0.w = fmaf(gv.w, s0, a0.w);
-              a1.x = fmaf(gv.x, s1, a1.x); a1.y = fmaf(gv.y, s1, a1.y); a1.z = fmaf(gv.z, s1, a1.z); a1.w = fmaf(gv.w, s1, a1.w);
+      const int k = trow, k1 = trow + KG;             // this thread's objects (when trow < KG): k, k + KG
+      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+      #pragma unroll 1
+      for (int half = 0; half < 2; ++half) {
+        __syncthreads();                              // (S complete; the previous half's contraction is done with G)
+        // ---- 2. the summed level gradient of this half tile -> LDS ----
+        if (trow < PR) {
+          #pragma unroll 1
+          for (int pb = trow; pb < HPX; pb += 4 * PR) {
+            float4 g[4];
+            #pragma unroll
+            for (int i = 0; i < 4; ++i) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            #pragma unroll
+            for (int l = 0; l < 5; ++l) {
+              if (l < lv.n) {
+                const int sh = lv.shift[l];
+                const float kk = lv.k[l];
+                const float* const base = lv.p[l] + c0 + 4 * c4;
+                const int hl = H >> sh, wl = W >> sh, ldl = lv.ld[l];
+                float4 v[4];
+                #pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  const int pp = HPX * half + min(pb + i * PR, HPX - 1);
+                  const int y = min(ty0 + (pp >> 3), H - 1), x = min(tx0 + (pp & 7), W - 1);
+                  v[i] = *reinterpret_cast<const float4*>(base + ((long long)(n * hl + (y >> sh)) * wl + (x >> sh)) * ldl);
+                }
+                #pragma unroll
+                for (int i = 0; i < 4; ++i) {          // (pyramid_bwd_v4_kernel's sum: level 0 first)
+                  g[i].x += v[i].x * kk; g[i].y += v[i].y * kk; g[i].z += v[i].z * kk; g[i].w += v[i].w * kk;
+                }
+              }
             }
-            // ---- 4. the tile's partial for these objects ----
-            *reinterpret_cast<float4*>(part + ((long long)blockIdx.x * O + objs[k]) * D + c0 + 4 * c4) = a0;
-            if (two) *reinterpret_cast<float4*>(part + ((long long)blockIdx.x * O + objs[k1]) * D + c0 + 4 * c4) = a1;
+            #pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int pl = pb + i * PR;
+              if (pl < HPX) *reinterpret_cast<float4*>(&G[pl][4 * c4]) = g[i];     // (pixels outside the image: S is 0 there)
+            }
           }
         }
+        __syncthreads();
+        // ---- 3. contraction out of LDS ----
+        if (trow < KG && k < nobj) {
+          const bool two = k1 < nobj;
+          #pragma unroll 8
+          for (int pl = 0; pl < HPX; ++pl) {
+            const float4 gv = *reinterpret_cast<const float4*>(&G[pl][4 * c4]);
+            const float s0 = S[k][HPX * half + pl], s1 = two ? S[k1][HPX * half + pl] : 0.f;
+            a0.x = fmaf(gv.x, s0, a0.x); a0.y = fmaf(gv.y, s0, a0.y); a0.z = fmaf(gv.z, s0, a0.z); a0.w = fmaf(gv.w, s0, a0.w);
+            a1.x = fmaf(gv.x, s1, a1.x); a1.y = fmaf(gv.y, s1, a1.y); a1.z = fmaf(gv.z, s1, a1.z); a1.w = fmaf(gv.w, s1, a1.w);
+          }
+        }
+      }
+      // ---- 4. the tile's partial for this thread's objects ----
+      if (trow < KG && k < nobj) {
+        *reinterpret_cast<float4*>(part + ((long long)blockIdx.x * O + objs[k]) * D + c0 + 4 * c4) = a0;
+        if (k1 < nobj) *reinterpret_cast<float4*>(part + ((long long)blockIdx.x * O + objs[k1]) * D + c0 + 4 * c4) = a1;
       }
     }
   }
@@ -942,9 +945,8 @@ int sg2im_layout_backward_vecs_levels(const float* const* dlevels, const int* fa
   const MaskRef mk{masks, masks_i64, (masks || masks_i64) ? mask_size : 0};
   const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
   const int n_tiles = tiles_x * tiles_y;
-  const size_t vec_part = sizeof(float) * (size_t)n_tiles * (size_t)n_objs * (size_t)dim;
-  // (zero-filled: a workgroup writes the partials of ITS image's objects only)
-  if (hipMemsetAsync(workspace, 0, vec_part, stream) != hipSuccess) return SG2IM_ERR_HIP;
+  // (no zero fill: every object belongs to exactly one image, and the workgroup (tile, image) writes the partial of every
+  // object of its image for every channel - each part[tile][object][channel] is written exactly once)
   dim3 grid(n_tiles, n_images);
   SG2IM_LAUNCH(layout_bwd_vecs_levels_kernel, grid, dim3(256), 0, stream, lv, boxes, mk, img_row_ptr, img_entries,
                      n_objs, dim, height, width, tiles_x, align_corners, workspace);

@@ -629,7 +629,9 @@ class LayoutFn(Function):
       only_vecs = d_masks is None and d_boxes is None
       if (only_vecs and d_vecs is not None and D % 4 == 0 and D <= Cg and
           (g.size(1), g.size(2)) == (H, W) and all(t.size(3) % 4 == 0 for t in levels)):
+        ops.mark('layout_bwd_start')
         ops.layout_backward_vecs_levels(levels, factors, vecs, boxes, masks, ctx.img_csr, n_images, H, W, ac, d_vecs)
+        ops.mark('layout_bwd_done')
         return d_vecs, d_boxes, d_masks, None, None, None, None, None, None, None, None, None
       if d_vecs is not None or not only_vecs:             # the summed gradient is needed as a tensor after all
         if Cg < g.size(3):
