@@ -62,6 +62,9 @@ def parse():
                        '--eval_mode_after iterations (train.py:509-512); not the headline workload')
   ap.add_argument('--force_dist', action='store_true',
                   help='debug: 1-rank RCCL group with real all-reduces (exercises the N>1 code path on one GPU)')
+  ap.add_argument('--dp_schedule', type=int, default=None, choices=[0, 1, 2],
+                  help='data-parallel graph schedule (sg2im_amd/trainer.py): default 0 at N > 1 (iteration graph -> exposed '
+                       'all-reduces -> Adam graph), 2 = RCCL all-reduces recorded inside the iteration graph (default with --force_dist)')
   ap.add_argument('--launcher_selftest', action='store_true',
                   help='CPU-only check of the --gpus N self-launcher: every rank joins a gloo group, all-reduces its rank, '
                        'rank 0 prints one JSON line (tests/test_bench_launcher.py)')
@@ -200,7 +203,8 @@ def main():
   bucket = tuple(int(v) for v in args.bucket.split(','))
   trainer = Trainer(vocab, device, generator_kwargs={'image_size': (S, S)}, world_size=world, seed=1234,
                     use_graphs=not args.no_graphs, bucket=bucket, rank=rank, compute_dtype=args.dtype,
-                    verify_replicas=False)      # (checked here, around the timed loop: Trainer.check_replicas)
+                    verify_replicas=False,      # (checked here, around the timed loop: Trainer.check_replicas)
+                    dp_schedule=args.dp_schedule)
   peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == 'bf16' else FP32_MFMA_PEAK_TFLOPS
   # (data parallel: the same overlapped graph without its Adam updates, the four all-reduces issued
   # eagerly, then an Adam graph - DESIGN.md section 6; --no_graphs selects the eager segments)

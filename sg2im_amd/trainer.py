@@ -194,10 +194,17 @@ class Trainer(object):
       if seed is not None:
         torch.cuda.manual_seed(seed * 1000003 + 7919 * (rank + 1))
     self.use_graphs = use_graphs
-    # data-parallel graph schedule (see _capture): 2 (default with RCCL) = ONE graph with the all-reduces recorded
-    # inside it, bucketed and overlapped; 0 = one iteration graph, exchange, Adam graph; 1 = segmented, the D_obj
-    # step replayed while the generator's all-reduce is in flight
-    self.dp_schedule = int(os.environ.get('SG2IM_DP_SCHEDULE', '2')) if dp_schedule is None else int(dp_schedule)
+    # data-parallel graph schedule (see _capture): 2 = ONE graph with the all-reduces recorded inside it, bucketed and
+    # overlapped; 0 = one iteration graph, exchange, Adam graph; 1 = segmented, the D_obj step replayed while the
+    # generator's all-reduce is in flight
+    # Default: 0 for a real multi-rank job - the in-graph exchange (2) has only ever been EXECUTED in a 1-rank RCCL
+    # group (no second GPU on the boxes this was developed on: every check that can be made on one GPU is green -
+    # tests/test_gpu_parity.py::test_in_graph_exchange_* - but a capture that clr or RCCL cannot digest at N > 1
+    # would crash, not fall back).  SG2IM_DP_SCHEDULE=2 / dp_schedule=2 selects it (bench.py --dp_schedule 2);
+    # with the 1-rank group (GradReducer.force) it is the default, so that it keeps being exercised.
+    if dp_schedule is None:
+      dp_schedule = os.environ.get('SG2IM_DP_SCHEDULE', '2' if world_size <= 1 else '0')
+    self.dp_schedule = int(dp_schedule)
     # Under dp_schedule 2 the replicas' parameter arenas are compared every now and then (replicas_in_sync: two tiny
     # all-reduces of checksums + a host sync; steps 1, 2, 4, 8 ... 1024, then every 1024th - step counts are the
     # same on every rank, which a "first replay of a new graph" trigger would not be).  If they ever differ - the
