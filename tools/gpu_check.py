@@ -348,6 +348,11 @@ def sec_conv_bn():
   dgrad_bn_case('dgrad_bn 3x3 C64 <- 64 64x64 batch 8 (epilogue form)', 8, 64, 64, 64, 64, 3, 1, False)
   dgrad_bn_case('dgrad_bn 3x3 C512 <- 256 8x8 pool2 (finish form)', 8, 4, 4, 512, 256, 3, 1, True)
   dgrad_bn_case('dgrad_bn 3x3 C6 <- 20 9x11 (scalar loaders: standalone fallback)', 3, 9, 11, 6, 20, 3, 1, False)
+  # round 5: small maps with enough rows for the epilogue forms (no split-K)
+  conv_bn_case('conv_bn 3x3 32->128 4x4 batch 2048 (epilogue form)', 2048, 4, 4, 32, 128, 3, 1, 1)
+  conv_bn_case('conv_bn 3x3 64->128 8x8 batch 512 (epilogue form)', 512, 8, 8, 64, 128, 3, 1, 1)
+  dgrad_bn_case('dgrad_bn 3x3 C128 <- 32 4x4 batch 2048 (epilogue form)', 2048, 4, 4, 128, 32, 3, 1, False)
+  dgrad_bn_case('dgrad_bn 3x3 C128 <- 32 4x4 -> 8x8 pool2 batch 512 (epilogue form)', 512, 4, 4, 128, 32, 3, 1, True)
 
 
 def sec_conv():
@@ -381,6 +386,13 @@ def sec_conv():
   conv_case('halo conv3x3 64+64up->64 6x64 (2x64 patches)', 2, 6, 64, 64, 64, 1, 64, 3, 1, 1)
   conv_case('halo conv3x3 64+64up->64 64x64 (8x16 patches)', 2, 64, 64, 64, 64, 1, 64, 3, 1, 1)
   conv_case('halo conv3x3 32->256 16x16 (128-wide tiles / split-K)', 16, 16, 16, 32, 0, 0, 256, 3, 1, 1)
+  # round 5: the 4 x 4 / 8 x 8 levels at several batch sizes (a multi-image-patch form of the halo'd kernel was probed on
+  # these shapes and removed: profiles/r5_halo_small_maps_ab.txt)
+  conv_case('conv3x3 bnact 64->96 4x4 batch 16 (split-K)', 16, 4, 4, 64, 0, 0, 96, 3, 1, 1, bnact=True)
+  conv_case('conv3x3 64->64 4x4 batch 8', 8, 4, 4, 64, 0, 0, 64, 3, 1, 1)
+  conv_case('conv3x3 160+128up->64 8x8 batch 6', 6, 8, 8, 160, 128, 1, 64, 3, 1, 1)
+  conv_case('conv3x3 bnact 36->40 8x8 batch 2 (ragged chunks)', 2, 8, 8, 36, 0, 0, 40, 3, 1, 1, bnact=True)
+  conv_case('conv3x3 64->64 4x4 batch 12', 12, 4, 4, 64, 0, 0, 64, 3, 1, 1)
   # weight gradients of <= 64 output channels over rows of 32 k pixels (pending affine, ragged blocks, two sources)
   conv_case('conv3x3 bnact 64->64 32x32', 4, 32, 32, 64, 0, 0, 64, 3, 1, 1, bnact=True)
   conv_case('conv3x3 96+40up->48 8x32 (ragged channel block, 48 outputs)', 3, 8, 32, 96, 40, 1, 48, 3, 1, 1)
