@@ -147,6 +147,94 @@ def test_layout_and_crops_align_corners_true():
   _run('sec_layout_align_corners')
 
 
+def test_persistent_kernel_barrier_timeout_is_sticky_and_loud():
+  """a grid barrier of the persistent GraphTripleConv kernel that times out lets the kernel run on with
+  incomplete data.  The per-launch error word is gone with the next launch's memset; the STICKY word is not: a later
+  healthy launch on the same lane must leave it alone and ops.persistent_kernels_check (called by
+  Trainer.losses_to_host) must raise.  The timeout itself cannot be provoked on a healthy box, so the sticky word is
+  poked by hand - what the kernel does on a timeout (csrc/gcn_persist.hip::spin_ge)."""
+  from sg2im_amd import _lib, ops
+  from sg2im_amd.graph import GraphTripleConvNet
+  from sg2im_amd.trainer import Trainer
+  D = torch.device('cuda', 0)
+  ops.persistent_kernels_check()                       # healthy so far in this process
+  area = ops.sync_area(D)
+  STICKY = 2040                                        # gcn::kStickyWord
+  assert area.numel() * 4 == int(_lib.load().sg2im_gconv_stack_sync_bytes()) and area.numel() > STICKY
+  try:
+    area[STICKY] = 3
+    # a healthy persistent launch on this lane (the model's forward uses it) clears everything BUT the sticky word
+    from sg2im_amd.model import Sg2ImModel
+    from sg2im_amd.synthetic import make_vocab, synthetic_batch
+    vocab = make_vocab(184, 7)
+    model = Sg2ImModel(vocab, image_size=(16, 16), embedding_dim=32, gconv_dim=32, gconv_hidden_dim=64, gconv_num_layers=2,
+                       refinement_dims=(32, 16), mask_size=16, layout_noise_dim=0).to(D)
+    b = [t.to(D) if torch.is_tensor(t) else t for t in synthetic_batch(2, image_size=(16, 16), seed=4)]
+    with torch.no_grad():
+      model(b[1], b[4], b[5], boxes_gt=b[2], masks_gt=b[3], num_images=2)
+    torch.cuda.synchronize()
+    assert int(area[STICKY]) == 3 and int(area[64]) == 0          # (word 64: the per-launch error word)
+    with pytest.raises(_lib.Sg2imHipError):
+      ops.persistent_kernels_check()
+    with pytest.raises(_lib.Sg2imHipError):
+      Trainer.losses_to_host({'total_loss': torch.ones((), device=D)})
+  finally:
+    area[STICKY] = 0
+  ops.persistent_kernels_check()
+
+
+def test_layout_link_refuses_a_second_consumer_of_the_layout_on_the_gpu():
+  """functional.LayoutLink on the real Functions: with a link the refinement network hands the per-level layout
+  gradients to LayoutFn.backward instead of a written tensor - which is only sound while the refinement network is
+  the layout's ONLY consumer.  A second consumer makes autograd SUM the unwritten tensor with another gradient; that
+  must raise, not train on uninitialised memory.  Without a link the same graph is fine."""
+  from sg2im_amd import functional as HF
+  from sg2im_amd import ops
+  from sg2im_amd.crn import RefinementNetwork
+  from sg2im_amd.layout import layout_nhwc
+  D = torch.device('cuda', 0)
+  g = torch.Generator().manual_seed(3)
+  O, N, Dv, S = 5, 2, 32, 32
+  o2i = torch.tensor([0, 0, 0, 1, 1], device=D)
+  x0 = torch.rand(O, 2, generator=g) * 0.5
+  boxes = torch.cat([x0, x0 + 0.1 + torch.rand(O, 2, generator=g) * 0.3], 1).clamp(max=1.0).to(D)
+  net = RefinementNetwork((Dv, 32, 16), normalization='batch', activation='leakyrelu-0.2').to(D).train()
+
+  def run(link, second_consumer):
+    vecs = torch.randn(O, Dv, generator=g).to(D).requires_grad_(True)
+    lay = layout_nhwc(vecs, boxes, None, o2i, S, n_images=N, pyramid_levels=1, link=link)
+    img = net.forward_nhwc(lay, layout_grad_channels=Dv, link=link)
+    loss = img.sum() + (lay.sum() * 0.5 if second_consumer else 0.0)
+    loss.backward()
+    torch.cuda.synchronize()
+    return vecs.grad.clone()
+  plain = run(None, True)                               # no link: materialised gradient, two consumers are fine
+  assert torch.isfinite(plain).all()
+  one = run(HF.LayoutLink(), False)                     # link, single consumer: the lazy path
+  assert torch.isfinite(one).all()
+  with pytest.raises(RuntimeError, match='LayoutLink'):
+    run(HF.LayoutLink(), True)
+
+
+def test_copy_ahead_delivers_device_batches_in_order():
+  """sg2im_amd/data/prefetch.py::CopyAhead on the GPU (the input pipeline of scripts/train.py): pinned host batches,
+  copies issued on a stream of their own one batch ahead; every batch arrives on the device, intact and in order,
+  also when the consumer launches work on each batch before asking for the next."""
+  from sg2im_amd.data.prefetch import CopyAhead
+  from sg2im_amd.synthetic import synthetic_batch
+  D = torch.device('cuda', 0)
+  host = [synthetic_batch(3, image_size=(16, 16), seed=70 + i) for i in range(5)]
+  it = CopyAhead(iter(host), D)
+  sums = []
+  for k, dev in enumerate(it):
+    assert all(t.is_cuda for t in dev if torch.is_tensor(t))
+    for a, b in zip(dev, host[k]):
+      if torch.is_tensor(a):
+        assert torch.equal(a.cpu(), b), k
+    sums.append(float((dev[0] * 2.0).sum()))            # (work on the consumer's stream between two batches)
+  assert len(sums) == 5 and it.copies == 5
+
+
 @pytest.mark.parametrize('H,L,nd,masks', [(64, 5, 32, 'float'), (64, 3, 0, 'float'), (32, 2, 32, 'int'),
                                           (128, 5, 32, None), (16, 5, 32, 'float')])
 def test_layout_noise_pyramid_in_one_launch_is_bit_exact(H, L, nd, masks):
