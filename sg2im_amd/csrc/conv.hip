@@ -1567,6 +1567,7 @@ static hipError_t prepare_wgrad_halo() {
   if (g_wgrad_halo_ready) return hipSuccess;
   hipError_t e = ensure_lds(conv_wgrad_halo_kernel<4, 16>, wgrad_halo_lds<4, 16>());
   if (e == hipSuccess) e = ensure_lds(conv_wgrad_halo_kernel<8, 8>, wgrad_halo_lds<8, 8>());
+  if (e == hipSuccess) e = ensure_lds(conv_wgrad_halo_h_kernel, wgrad_halo_h_lds());
   if (e == hipSuccess) g_wgrad_halo_ready = true;
   return e;
 }
@@ -2117,8 +2118,11 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
   const size_t bias_room = dbias ? sizeof(float) * 512 * (size_t)cout : 0;
   const bool can_split = workspace != nullptr && workspace_bytes > bias_room;
   // 3x3 / stride 1 / pad 1 over maps that 64-pixel patches tile: the halo'd-tile kernel (wgrad_halo.h)
-  if (g_wgrad_halo && v4 && d->compute_dtype == 0 && !any_gather(p.g) && halo_geometry(d) &&
-      ((d->in_w % 16 == 0 && d->in_h % 4 == 0) || (d->in_w % 8 == 0 && d->in_h % 8 == 0))) {
+  // (bf16 operands, round 5: conv_wgrad_halo_h_kernel, 4 x 16 patches only; SG2IM_WGRAD_HALO_BF16=0: the per-tap bf16 kernels)
+  static const bool g_wgrad_halo_h = !(getenv("SG2IM_WGRAD_HALO_BF16") && atoi(getenv("SG2IM_WGRAD_HALO_BF16")) == 0);
+  const bool hb = d->compute_dtype == 1;
+  if (g_wgrad_halo && v4 && !any_gather(p.g) && halo_geometry(d) &&
+      ((d->in_w % 16 == 0 && d->in_h % 4 == 0) || (!hb && d->in_w % 8 == 0 && d->in_h % 8 == 0)) && (!hb || g_wgrad_halo_h)) {
     const bool wide = d->in_w % 16 == 0;
     WgHaloParams q;
     q.g = p.g; q.dY = dy; q.ldy = ld_dy; q.Cout = cout;
@@ -2145,7 +2149,9 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
     // its 147 KB of partial sums, and loses on the widest concats (dY is re-read once per 64-channel block):
     // m4.conv0 97 -> 106, the 64-channel 64x64 layers 76 -> 89, m2.conv1 84 -> 94, m1.conv1 80 -> 92 TFLOP/s;
     // m2.conv0 (672 channels) 97 -> 93, m1.conv0 (1184) 87 -> 86, mask_net's 8x8 layer (4 patches each) 67 -> 61
-    const bool halo_pays = Ctot <= 512 && q.per >= 6;
+    // bf16: the alternative re-reads and re-activates the fp32 input once per tap for 1/8 of the MFMA instructions - the
+    // halo'd form wherever a workgroup gets at least two patches
+    const bool halo_pays = hb ? q.per >= 2 : (Ctot <= 512 && q.per >= 6);
     const int nsplit = (q.npatch + q.per - 1) / q.per;
     q.e = Epi{dweight, (long long)taps * p.g.Wtap, nullptr, 1.f, accumulate, workspace, nsplit};
     if (p.g.Wtap != Ctot) { q.e.col_ctot = Ctot; q.e.col_wtap = p.g.Wtap; }
@@ -2156,7 +2162,8 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
                                 wide ? "4x16" : "8x8", ncb, nkb, nsplit);
       dim3 grid(ncb, nkb, nsplit);
       if (prepare_wgrad_halo() != hipSuccess) return SG2IM_ERR_HIP;
-      if (wide) SG2IM_LAUNCH((conv_wgrad_halo_kernel<4, 16>), grid, dim3(NTHREADS), (wgrad_halo_lds<4, 16>()), stream, q);
+      if (hb) SG2IM_LAUNCH(conv_wgrad_halo_h_kernel, grid, dim3(NTHREADS), wgrad_halo_h_lds(), stream, q);
+      else if (wide) SG2IM_LAUNCH((conv_wgrad_halo_kernel<4, 16>), grid, dim3(NTHREADS), (wgrad_halo_lds<4, 16>()), stream, q);
       else SG2IM_LAUNCH((conv_wgrad_halo_kernel<8, 8>), grid, dim3(NTHREADS), (wgrad_halo_lds<8, 8>()), stream, q);
       if (hipGetLastError() != hipSuccess) return SG2IM_ERR_HIP;
       return finish_split(q.e, cout, Ntot, stream, q.ws_bias, dbias, cout) == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;

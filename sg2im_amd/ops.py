@@ -611,10 +611,15 @@ GCN_PERSISTENT = os.environ.get('SG2IM_GCN_PERSIST', '1') != '0'      # (A/B kno
 # 'full' (round 4: ~390 registers, 98 KB of LDS per workgroup = whole CUs): its first barrier waited ~0.5 ms for
 # residency, 8.32 vs 7.99 ms (profiles/r4_gcn_persistent_backward_ab.txt).  'low' (round 5: <= 168 registers, 41 KB
 # of LDS, 32 x 32 tiles, sg2im_gconv_stack_grads.low_footprint): its workgroups fit next to the weight gradients'.
-# SG2IM_GCN_PERSIST_BWD = 0 | full | low (1 = full); the same form runs in eager mode too, so that eager and replayed
+# SG2IM_GCN_PERSIST_BWD = auto | 0 | full | low (1 = full); the same form runs in eager mode too, so that eager and replayed
 # iterations stay bit-identical.  Both forms are tested against the layer-by-layer launches in sec_gconv_stack.
-_bwd_mode = os.environ.get('SG2IM_GCN_PERSIST_BWD', '0')
-GCN_PERSISTENT_BACKWARD = {'0': False, '': False, '1': 'full', 'full': 'full', 'low': 'low', '2': 'low'}.get(_bwd_mode, False)
+# 'auto' (the default): the Trainer picks per configuration (trainer.Trainer._gcn_backward_mode) - 'low' where the main
+# lane's small-kernel tail ENDS the step (VG-style batches / a trained mask_net: its backward sits in that tail; measured
+# 9.51 -> 9.24 ms fp32, 5.84 -> 5.61 ms bf16 at VG-64), layer-by-layer launches where the weight-gradient lane ends it
+# (the COCO-style headline configuration: 7.75 vs 7.90 ms) - profiles/r5_gcn_persistent_backward_low_footprint_ab.txt.
+GCN_PERSISTENT_BACKWARD_MODE = os.environ.get('SG2IM_GCN_PERSIST_BWD', 'auto')
+GCN_PERSISTENT_BACKWARD = {'0': False, '': False, 'auto': False, '1': 'full', 'full': 'full', 'low': 'low', '2': 'low'}.get(
+  GCN_PERSISTENT_BACKWARD_MODE, False)
 
 
 def gconv_stack_backward_in_one_launch():

@@ -509,12 +509,27 @@ class Trainer(object):
     Returns a dict of 0-dim device tensors (no host sync)."""
     self.t += 1
     keep, ops.CONV_COMPUTE = ops.CONV_COMPUTE, (1 if self.compute_dtype == 'bf16' else 0)
+    keep_bwd = ops.GCN_PERSISTENT_BACKWARD
+    if ops.GCN_PERSISTENT_BACKWARD_MODE == 'auto':
+      ops.GCN_PERSISTENT_BACKWARD = self._gcn_backward_mode(batch)
     try:
       out = self._step(batch)
     finally:
       ops.CONV_COMPUTE = keep
+      ops.GCN_PERSISTENT_BACKWARD = keep_bwd
     self._maybe_check_replicas()
     return out
+
+  def _gcn_backward_mode(self, batch):
+    """The GraphTripleConv stack's backward as ONE co-resident persistent launch ('low') or layer by layer (False) -
+    whichever lane ends the step decides (both forms are parity-tested; measured in round 5).  When
+    mask_net is trained through the layout (no ground-truth masks in the batch: the VG style of BASELINE configs[2..4];
+    or a mask loss) its backward lengthens the main lane's small-kernel tail, the tail ends the step, and the 74 fewer
+    dependent launches pay: -2.8 % fp32 / -3.8 % bf16 at VG-64.  In the COCO-style configuration the refinement network's
+    weight-gradient lane ends the step and resident workgroups polling grid barriers cost it 0.13 ms: layer by layer."""
+    masks = batch[3] if len(batch) > 3 else None
+    trains_mask_net = self.model.mask_net is not None and (masks is None or self.w['mask_loss_weight'] > 0)
+    return 'low' if trains_mask_net else False
 
   def _step(self, batch):
     if self.use_graphs:
