@@ -10,6 +10,7 @@
 // section 8a row 6: 4.8e-7 abs), so the layout is checked with a tolerance; the
 // per-image accumulation order (objects in index order) is the reference's.
 #include <algorithm>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include "launch_count.h"
 #include "sg2im_hip.h"
@@ -532,6 +533,60 @@ __global__ void layout_bwd_g_kernel(const float* __restrict__ dl, long long ld_d
   G[(long long)o * HW + px] = ds;
 }
 
+// The same G, one pass over the gradient (round 5; the VG-style steps' layout backward): the per-object kernel above
+// re-reads its image's H x W x D gradient once per OBJECT, a thread walking one pixel's channels (stride-D accesses:
+// 567 us of the 5.6 ms bfloat16 VG-64 step, and the weight-gradient lane's split-K finishes starved next to it).  Here a
+// workgroup owns 64 pixels of ONE image, keeps their D <= 128 channels in registers - thread = (pixel, quarter q), its
+// float4 columns are q, q + 4, q + 8, ...: the four lanes of a pixel read 64 contiguous bytes per load - and walks the
+// image's objects, whose vectors pass through LDS: 67 MB read once instead of O / N times.  Per (object, pixel): four
+// 32-term chains, then a fixed xor tree over the pixel's four lanes.
+constexpr int GOB = 16;     // objects per LDS pass
+__global__ __launch_bounds__(256) void layout_bwd_g_tiles_kernel(const float* __restrict__ dl, long long ld_dl,
+                                                                 const float* __restrict__ vecs, long long ld_vecs,
+                                                                 const int* __restrict__ img_row_ptr,
+                                                                 const int* __restrict__ img_entries, int D, int HW,
+                                                                 float* __restrict__ G) {
+  __shared__ float4 vs[GOB][32];
+  __shared__ int objs[GOB];
+  const int n = blockIdx.y, tid = threadIdx.x, q = tid & 3;
+  const int px = blockIdx.x * 64 + (tid >> 2);
+  const bool live = px < HW;
+  const int nj = D >> 2;
+  float4 t[8];
+  {
+    const float4* __restrict__ g4 = reinterpret_cast<const float4*>(dl + ((long long)n * HW + (live ? px : 0)) * ld_dl);
+    #pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int j = q + 4 * k;
+      t[k] = (live && j < nj) ? g4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const int ob = img_row_ptr[n], oe = img_row_ptr[n + 1];
+  for (int cb = ob; cb < oe; cb += GOB) {
+    const int nobj = min(GOB, oe - cb);
+    __syncthreads();
+    if (tid < nobj) objs[tid] = img_entries[cb + tid];
+    __syncthreads();
+    for (int e = tid; e < nobj * 32; e += 256) {
+      const int oi = e >> 5, j = e & 31;
+      vs[oi][j] = j < nj ? *reinterpret_cast<const float4*>(vecs + (long long)objs[oi] * ld_vecs + 4 * j)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    for (int oi = 0; oi < nobj; ++oi) {
+      float s = 0.f;
+      #pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float4 v = vs[oi][q + 4 * k];
+        s = fmaf(t[k].x, v.x, s); s = fmaf(t[k].y, v.y, s); s = fmaf(t[k].z, v.z, s); s = fmaf(t[k].w, v.w, s);
+      }
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      if (q == 0 && live) G[(long long)objs[oi] * HW + px] = s;
+    }
+  }
+}
+
 // pixel range [lo, hi] along one axis whose footprint can touch map cell `cell`
 __device__ __forceinline__ void layout_axis_range(float b0, float b1, int cell, int L, int Min, int align_corners,
                                                   int& lo, int& hi) {
@@ -913,9 +968,18 @@ int sg2im_layout_backward(const float* dlayout, long long ld_dlayout, const floa
     // G_o(y, x) for all objects: [O][H*W] floats at the start of the workspace (the d_vecs partials,
     // if any, were consumed by layout_bwd_reduce_kernel above - same stream)
     const int HW = height * width;
-    dim3 gg((HW + 255) / 256, n_objs);
-    SG2IM_LAUNCH(layout_bwd_g_kernel, gg, dim3(256), 0, stream, dlayout, ld_dlayout, vecs, ld_vecs, obj_to_img,
-                       dim, HW, workspace);
+    static const bool g_tiles = [] { const char* e = getenv("SG2IM_LAYOUT_G_TILES"); return !(e && e[0] == '0'); }();   // (A/B knob)
+    if (g_tiles && img_entries && dim <= 128 && !(dim & 3) && !(ld_dlayout & 3) && !(ld_vecs & 3) &&
+        !((uintptr_t)dlayout & 15) && !((uintptr_t)vecs & 15)) {
+      // (every object is an entry of exactly one image's row - padded objects belong to the last image - so every
+      // G[o] plane is written)
+      SG2IM_LAUNCH(layout_bwd_g_tiles_kernel, dim3((HW + 63) / 64, n_images), dim3(256), 0, stream, dlayout, ld_dlayout,
+                         vecs, ld_vecs, img_row_ptr, img_entries, dim, HW, workspace);
+    } else {
+      dim3 gg((HW + 255) / 256, n_objs);
+      SG2IM_LAUNCH(layout_bwd_g_kernel, gg, dim3(256), 0, stream, dlayout, ld_dlayout, vecs, ld_vecs, obj_to_img,
+                         dim, HW, workspace);
+    }
     SG2IM_LAUNCH(layout_bwd_masks_kernel, dim3(n_objs), dim3(256), 0, stream, workspace, boxes, mk, height, width,
                        align_corners, d_masks, d_boxes);
   }

@@ -13,6 +13,7 @@ D = torch.device('cuda', 0)
 NB = 32
 PLAIN = '--plain' in sys.argv
 WGRAD_ONLY = '--wgrad' in sys.argv          # time the weight gradients only
+BF16 = '--bf16' in sys.argv                  # bfloat16 operands on the 32x32x16 MFMA (Trainer(compute_dtype='bf16'))
 ONLY = [a[7:].split(',') for a in sys.argv if a.startswith('--only=')]      # --only=m3,m4,out: layer name prefixes
 LAYERS = [  # name, H, C0, C1(up), Cout, k, stride, pad
   ('m0.conv0', 4, 160, 1, 1024, 3, 1, 1), ('m0.conv1', 4, 1024, 0, 1024, 3, 1, 1),
@@ -45,6 +46,8 @@ def timeit(fn, iters=10):
 
 
 def main():
+  if BF16:
+    ops.CONV_COMPUTE = 1
   tot = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
   totf = 0.0
   print('%-10s %9s | %8s %7s | %8s %7s | %8s %7s' % ('layer', 'GFLOP', 'fwd ms', 'TF/s', 'dgrad ms', 'TF/s', 'wgrad ms', 'TF/s'))

@@ -786,6 +786,18 @@ def sec_layout_mode(AC):
       report('layout %s %s dboxes' % (tag, name), bd.grad, br.grad)
       if md is not None and md.is_floating_point():
         report('layout %s %s dmasks' % (tag, name), md.grad, mr.grad)
+    # every object in ONE image: more objects than one LDS pass of the per-image kernels holds (layout.hip GOB / LO)
+    o2c = torch.full_like(o2i, N - 1)           # (the last image: the oracle takes the image count from obj_to_img)
+    vr, br, mr = vecs.clone().requires_grad_(True), boxes.clone().requires_grad_(True), soft.clone().requires_grad_(True)
+    want = orc.masks_to_layout(vr, br, mr, o2c, S, align_corners=AC)
+    gl = torch.randn(want.shape, generator=g)
+    want.backward(gl)
+    vd, bd, md = vecs.to(D).requires_grad_(True), boxes.to(D).requires_grad_(True), soft.to(D).requires_grad_(True)
+    got = layout_nhwc(vd, bd, md, o2c.to(D), S, n_images=N, align_corners=AC)
+    got.backward(gl.permute(0, 2, 3, 1).contiguous().to(D))
+    report('layout %s crowded (%d objects in one image) fwd' % (tag, O), got.permute(0, 3, 1, 2), want)
+    for nm, a, b in (('dvecs', vd.grad, vr.grad), ('dboxes', bd.grad, br.grad), ('dmasks', md.grad, mr.grad)):
+      report('layout %s crowded %s' % (tag, nm), a, b)
     # crops
     ir = imgs.clone().requires_grad_(True)
     want = orc.crop_bbox_batch(ir, boxes, o2i, 32, align_corners=AC)
