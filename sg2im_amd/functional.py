@@ -1159,18 +1159,23 @@ class MaskNetFn(Function):
     ni = ctx.needs_input_grad[4:]
     grads = [None] * len(params)
     Wf, bf = params[4 * nb:4 * nb + 2]
+    # (Round 5 measured these five weight gradients on the weight-gradient lane instead of between the data gradients of
+    # this chain, which is part of the tail that ends a VG-style step: SLOWER, 9.27 vs 8.85 ms fp32 / 5.44 vs 5.12 ms
+    # bfloat16 - in lane order they land behind the refinement network's and run next to the one-launch GraphTripleConv
+    # backward, whose grid barriers then wait longer.  profiles/r5_mask_net_wgrad_lane_ab.txt)
+    wgrad = _conv_param_grads
     ds = ops.sigmoid_backward(masks, g.contiguous(), _new(g, O, s, s, 1))
-    grads[4 * nb], grads[4 * nb + 1] = _conv_param_grads(df, ds, 1, (1, 1, 1, D), ni[4 * nb], ni[4 * nb + 1], Wf, bf)
+    grads[4 * nb], grads[4 * nb + 1] = wgrad(df, ds, 1, (1, 1, 1, D), ni[4 * nb], ni[4 * nb + 1], Wf, bf)
     gz = _new(g, O, s, s, D)
-    ops.conv2d_backward_data(df, _cl_weight(Wf), 1, ds, 1, 0, D, gz, D)
+    # (the last block's ReLU mask rides in the 1x1 convolution's data gradient)
+    ops.conv2d_backward_data_act(df, _cl_weight(Wf), 1, ds, 1, 0, D, gz, D, saved[nb - 1][2], D, 0.0)
     for b in range(nb - 1, -1, -1):
       x, st, y, sb = saved[b]
       gam, bet, Wp, bias = params[4 * b:4 * b + 4]
       s2 = 2 * sb
-      dpre = ops.act_backward(_fptr(gz), D, 0, O, s2, s2, y, D, D, 0.0, gz)
+      dpre = gz if b == nb - 1 else ops.act_backward(_fptr(gz), D, 0, O, s2, s2, y, D, D, 0.0, gz)
       d = conv_desc([nhwc_src(x, 1, st.scale, st.shift, 1.0)], O, s2, s2, 3, 3, 1, 1)
-      grads[4 * b + 2], grads[4 * b + 3] = _conv_param_grads(d, dpre, D, (D, 3, 3, D), ni[4 * b + 2], ni[4 * b + 3],
-                                                              Wp, bias)
+      grads[4 * b + 2], grads[4 * b + 3] = wgrad(d, dpre, D, (D, 3, 3, D), ni[4 * b + 2], ni[4 * b + 3], Wp, bias)
       gup = _new(g, O, s2, s2, D)
       dgam, dbet, accb, grads[4 * b], grads[4 * b + 1] = _bn_grad_bufs(g, D, gam, bet, ni[4 * b], ni[4 * b + 1])
       bcnt = None if count is None else (count[0], count[1] * sb * sb)
