@@ -26,7 +26,7 @@ extern "C" {
 #define SG2IM_ERR_ARG 1   /* invalid argument (the reference would raise / assert) */
 #define SG2IM_ERR_HIP 2   /* a HIP runtime call failed; see hipGetLastError() */
 
-int sg2im_abi_version(void);   /* 8 */
+int sg2im_abi_version(void);   /* 9 */
 
 /* Statistics: kernels this library has launched (or recorded into a stream capture) so far in this process;
  * which = 0: all of them, 1: the implicit-GEMM family incl. its split-K finishes.  bench.py reads it around the
@@ -429,6 +429,19 @@ int sg2im_layout_backward_vecs_levels(const float* const* dlevels, const int* fa
                                       const int* img_row_ptr, const int* img_entries, int n_images, int n_objs, int dim,
                                       int height, int width, int align_corners, float* d_vecs, long long ld_dvecs,
                                       float* workspace, hipStream_t stream);
+/* d_masks / d_boxes of the layout (the other half of sg2im_layout_backward) from the same PER-LEVEL gradients:
+ * G_o(y, x) = <d layout[obj_to_img[o], y, x, :], vecs[o]> is formed per image from one pass over the levels (summed on the
+ * fly, as above), then transposed through the bilinear footprint into d_masks [O][M][M] (float masks only) and / or
+ * d_boxes [O][4] (layout.py:60-61,87-88,117-127 through grid_sample's backward).  VG-style training, where mask_net is
+ * trained through the layout (model.py:146-147,152-157): the step then never materialises the full-resolution layout
+ * gradient.  dim a multiple of 4, <= 128; vecs 16-byte aligned with ld_vecs a multiple of 4 (SG2IM_ERR_ARG otherwise: the
+ * caller materialises the gradient and calls sg2im_layout_backward).  workspace: sg2im_layout_backward_workspace() bytes. */
+int sg2im_layout_backward_maps_levels(const float* const* dlevels, const int* factors, const long long* lds, int n_levels,
+                                      const float* vecs, long long ld_vecs, const float* boxes, const float* masks,
+                                      const long long* masks_i64, int mask_size, const int* img_row_ptr,
+                                      const int* img_entries, int n_images, int n_objs, int dim, int height, int width,
+                                      int align_corners, float* d_masks, float* d_boxes, float* workspace,
+                                      hipStream_t stream);
 /* Object crops for the object discriminator (sg2im/bilinear.py:28-132, 'cudnn' path):
  * crops[o] = bilinear sample of image obj_to_img[o] on linspace(2*x0-1, 2*x1-1, size).
  * imgs are NHWC [N][H][W][C] (row stride ld_img); crops NHWC [O][size][size][C]. */

@@ -126,6 +126,8 @@ _SIGNATURES = {
                             _P, _P, _P],
   'sg2im_layout_backward_vecs_levels': [POINTER(c_void_p), POINTER(c_int), POINTER(c_longlong), _I, _P, _P, _P, _I, _P, _P, _I,
                                         _I, _I, _I, _I, _I, _P, _L, _P, _P],
+  'sg2im_layout_backward_maps_levels': [POINTER(c_void_p), POINTER(c_int), POINTER(c_longlong), _I, _P, _L, _P, _P, _P, _I, _P,
+                                        _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
   'sg2im_crop_forward': [_P, _L, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _P],
   'sg2im_crop_backward_workspace': [_I, _I, _I, _I],
   'sg2im_crop_backward': [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _L, _P, _P],

@@ -540,8 +540,12 @@ __global__ void layout_bwd_g_kernel(const float* __restrict__ dl, long long ld_d
 // float4 columns are q, q + 4, q + 8, ...: the four lanes of a pixel read 64 contiguous bytes per load - and walks the
 // image's objects, whose vectors pass through LDS: 67 MB read once instead of O / N times.  Per (object, pixel): four
 // 32-term chains, then a fixed xor tree over the pixel's four lanes.
+// LEVELS: the gradient is the refinement network's per-level gradients, summed on the fly in pyramid_bwd_v4_kernel's
+// order (level 0 first) exactly as layout_bwd_vecs_levels_kernel forms it - the full-resolution tensor is never written.
 constexpr int GOB = 16;     // objects per LDS pass
-__global__ __launch_bounds__(256) void layout_bwd_g_tiles_kernel(const float* __restrict__ dl, long long ld_dl,
+template <bool LEVELS>
+__global__ __launch_bounds__(256) void layout_bwd_g_tiles_kernel(const float* __restrict__ dl, long long ld_dl, GradLevels lv,
+                                                                 int H, int W,
                                                                  const float* __restrict__ vecs, long long ld_vecs,
                                                                  const int* __restrict__ img_row_ptr,
                                                                  const int* __restrict__ img_entries, int D, int HW,
@@ -553,12 +557,37 @@ __global__ __launch_bounds__(256) void layout_bwd_g_tiles_kernel(const float* __
   const bool live = px < HW;
   const int nj = D >> 2;
   float4 t[8];
-  {
+  if constexpr (!LEVELS) {
     const float4* __restrict__ g4 = reinterpret_cast<const float4*>(dl + ((long long)n * HW + (live ? px : 0)) * ld_dl);
     #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int j = q + 4 * k;
       t[k] = (live && j < nj) ? g4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else {
+    #pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int pl = live ? px : 0;
+    const int y = pl / W, x = pl - y * W;
+    #pragma unroll
+    for (int l = 0; l < 5; ++l) {
+      if (l < lv.n) {
+        const int sh = lv.shift[l];
+        const float kk = lv.k[l];
+        const int hl = H >> sh, wl = W >> sh;
+        const float4* __restrict__ g4 =
+          reinterpret_cast<const float4*>(lv.p[l] + ((long long)(n * hl + (y >> sh)) * wl + (x >> sh)) * lv.ld[l]);
+        float4 v[8];
+        #pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int j = q + 4 * k;
+          v[k] = (live && j < nj) ? g4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        #pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          t[k].x += v[k].x * kk; t[k].y += v[k].y * kk; t[k].z += v[k].z * kk; t[k].w += v[k].w * kk;
+        }
+      }
     }
   }
   const int ob = img_row_ptr[n], oe = img_row_ptr[n + 1];
@@ -973,8 +1002,8 @@ int sg2im_layout_backward(const float* dlayout, long long ld_dlayout, const floa
         !((uintptr_t)dlayout & 15) && !((uintptr_t)vecs & 15)) {
       // (every object is an entry of exactly one image's row - padded objects belong to the last image - so every
       // G[o] plane is written)
-      SG2IM_LAUNCH(layout_bwd_g_tiles_kernel, dim3((HW + 63) / 64, n_images), dim3(256), 0, stream, dlayout, ld_dlayout,
-                         vecs, ld_vecs, img_row_ptr, img_entries, dim, HW, workspace);
+      SG2IM_LAUNCH(layout_bwd_g_tiles_kernel<false>, dim3((HW + 63) / 64, n_images), dim3(256), 0, stream, dlayout,
+                         ld_dlayout, GradLevels{}, height, width, vecs, ld_vecs, img_row_ptr, img_entries, dim, HW, workspace);
     } else {
       dim3 gg((HW + 255) / 256, n_objs);
       SG2IM_LAUNCH(layout_bwd_g_kernel, gg, dim3(256), 0, stream, dlayout, ld_dlayout, vecs, ld_vecs, obj_to_img,
@@ -986,6 +1015,26 @@ int sg2im_layout_backward(const float* dlayout, long long ld_dlayout, const floa
   return ok_or(hipGetLastError());
 }
 
+}  // extern "C"
+
+// per-level gradient descriptors of sg2im_layout_backward_{vecs,maps}_levels; false: an argument does not qualify
+static bool fill_grad_levels(sg2im::GradLevels& lv, const float* const* dlevels, const int* factors, const long long* lds,
+                             int n_levels, int dim, int height, int width) {
+  lv.n = n_levels;
+  for (int l = 0; l < 5; ++l) {
+    lv.p[l] = nullptr; lv.ld[l] = 0; lv.shift[l] = 0; lv.k[l] = 0.f;
+    if (l >= n_levels) continue;
+    const int f = factors[l];
+    if (f < 1 || (f & (f - 1)) || height % f || width % f || !dlevels[l] || (lds[l] & 3) || lds[l] < dim ||
+        ((uintptr_t)dlevels[l] & 15))
+      return false;
+    lv.p[l] = dlevels[l]; lv.ld[l] = (int)lds[l]; lv.shift[l] = __builtin_ctz((unsigned)f); lv.k[l] = 1.f / (float)(f * f);
+  }
+  return true;
+}
+
+extern "C" {
+
 int sg2im_layout_backward_vecs_levels(const float* const* dlevels, const int* factors, const long long* lds, int n_levels,
                                       const float* boxes, const float* masks, const long long* masks_i64, int mask_size,
                                       const int* img_row_ptr, const int* img_entries, int n_images, int n_objs, int dim,
@@ -996,16 +1045,7 @@ int sg2im_layout_backward_vecs_levels(const float* const* dlevels, const int* fa
     return SG2IM_ERR_ARG;
   if (n_objs == 0) return SG2IM_OK;
   GradLevels lv;
-  lv.n = n_levels;
-  for (int l = 0; l < 5; ++l) {
-    lv.p[l] = nullptr; lv.ld[l] = 0; lv.shift[l] = 0; lv.k[l] = 0.f;
-    if (l >= n_levels) continue;
-    const int f = factors[l];
-    if (f < 1 || (f & (f - 1)) || height % f || width % f || !dlevels[l] || (lds[l] & 3) || lds[l] < dim ||
-        ((uintptr_t)dlevels[l] & 15))
-      return SG2IM_ERR_ARG;
-    lv.p[l] = dlevels[l]; lv.ld[l] = (int)lds[l]; lv.shift[l] = __builtin_ctz((unsigned)f); lv.k[l] = 1.f / (float)(f * f);
-  }
+  if (!fill_grad_levels(lv, dlevels, factors, lds, n_levels, dim, height, width)) return SG2IM_ERR_ARG;
   const MaskRef mk{masks, masks_i64, (masks || masks_i64) ? mask_size : 0};
   const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
   const int n_tiles = tiles_x * tiles_y;
@@ -1017,6 +1057,28 @@ int sg2im_layout_backward_vecs_levels(const float* const* dlevels, const int* fa
   const long long tot = (long long)n_objs * dim;
   SG2IM_LAUNCH(layout_bwd_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, workspace, n_tiles,
                      n_objs, dim, d_vecs, ld_dvecs);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_layout_backward_maps_levels(const float* const* dlevels, const int* factors, const long long* lds, int n_levels,
+                                      const float* vecs, long long ld_vecs, const float* boxes, const float* masks,
+                                      const long long* masks_i64, int mask_size, const int* img_row_ptr,
+                                      const int* img_entries, int n_images, int n_objs, int dim, int height, int width,
+                                      int align_corners, float* d_masks, float* d_boxes, float* workspace,
+                                      hipStream_t stream) {
+  if (!dlevels || !factors || !lds || n_levels < 1 || n_levels > 5 || !vecs || !boxes || !img_row_ptr || !img_entries ||
+      !workspace || (!d_masks && !d_boxes) || (d_masks && (!masks || mask_size < 1)) || dim < 4 || (dim & 3) || dim > 128 ||
+      (ld_vecs & 3) || ((uintptr_t)vecs & 15) || height < 1 || width < 1)
+    return SG2IM_ERR_ARG;
+  if (n_objs == 0) return SG2IM_OK;
+  GradLevels lv;
+  if (!fill_grad_levels(lv, dlevels, factors, lds, n_levels, dim, height, width)) return SG2IM_ERR_ARG;
+  const MaskRef mk{masks, masks_i64, (masks || masks_i64) ? mask_size : 0};
+  const int HW = height * width;
+  SG2IM_LAUNCH(layout_bwd_g_tiles_kernel<true>, dim3((HW + 63) / 64, n_images), dim3(256), 0, stream, nullptr, 0LL, lv,
+                     height, width, vecs, ld_vecs, img_row_ptr, img_entries, dim, HW, workspace);
+  SG2IM_LAUNCH(layout_bwd_masks_kernel, dim3(n_objs), dim3(256), 0, stream, workspace, boxes, mk, height, width,
+                     align_corners, d_masks, d_boxes);
   return ok_or(hipGetLastError());
 }
 

@@ -623,23 +623,29 @@ class LayoutFn(Function):
     d_masks = None
     if ni[2] and masks is not None and masks.is_floating_point():
       d_masks = _new(vecs, *masks.shape)
+    todo_vecs, todo_maps = d_vecs is not None, d_masks is not None or d_boxes is not None
     if lazy is not None:
       levels, factors, Cg = lazy
       D = vecs.size(1)
-      only_vecs = d_masks is None and d_boxes is None
-      if (only_vecs and d_vecs is not None and D % 4 == 0 and D <= Cg and
-          (g.size(1), g.size(2)) == (H, W) and all(t.size(3) % 4 == 0 for t in levels)):
+      if (D % 4 == 0 and D <= Cg and (g.size(1), g.size(2)) == (H, W) and all(t.size(3) % 4 == 0 for t in levels) and
+          LAYOUT_GRAD_FROM_LEVELS):
+        # both halves straight from the per-level gradients: the full-resolution sum is never written (COCO style: only
+        # d_vecs; VG style / predicted boxes: d_masks, d_boxes too - mask_net trains through the layout)
         ops.mark('layout_bwd_start')
-        ops.layout_backward_vecs_levels(levels, factors, vecs, boxes, masks, ctx.img_csr, n_images, H, W, ac, d_vecs)
+        if todo_vecs:
+          ops.layout_backward_vecs_levels(levels, factors, vecs, boxes, masks, ctx.img_csr, n_images, H, W, ac, d_vecs)
+          todo_vecs = False
+        if todo_maps:
+          todo_maps = not ops.layout_backward_maps_levels(levels, factors, vecs, boxes, masks, ctx.img_csr, n_images, H, W,
+                                                          ac, d_masks, d_boxes)
         ops.mark('layout_bwd_done')
-        return d_vecs, d_boxes, d_masks, None, None, None, None, None, None, None, None, None
-      if d_vecs is not None or not only_vecs:             # the summed gradient is needed as a tensor after all
+      if todo_vecs or todo_maps:                         # the summed gradient is needed as a tensor after all
         if Cg < g.size(3):
           g[..., Cg:].zero_()
         ops.pyramid_backward(levels, factors, [Cg] * len(levels), g.size(0), H, W, Cg, g)
-    if d_vecs is not None or d_masks is not None or d_boxes is not None:
-      ops.layout_backward(g, vecs, boxes, masks, obj_to_img, ctx.img_csr, n_images, H, W, ac, d_vecs, d_masks,
-                          d_boxes)
+    if todo_vecs or todo_maps:
+      ops.layout_backward(g, vecs, boxes, masks, obj_to_img, ctx.img_csr, n_images, H, W, ac,
+                          d_vecs if todo_vecs else None, d_masks if todo_maps else None, d_boxes if todo_maps else None)
     return d_vecs, d_boxes, d_masks, None, None, None, None, None, None, None, None, None
 
 
@@ -698,6 +704,7 @@ class LayoutLink(object):
 
 import os as _os
 LAZY_LAYOUT_GRAD = _os.environ.get('SG2IM_LAZY_LAYOUT_GRAD', '1') != '0'     # (A/B knob)
+LAYOUT_GRAD_FROM_LEVELS = _os.environ.get('SG2IM_LAYOUT_GRAD_LEVELS', '1') != '0'      # (A/B knob: 0 = materialise the sum)
 
 
 def _hand_over_layout_grad(like, dlevels, N, H, W, Cg, Cl, link):

@@ -811,6 +811,27 @@ def layout_backward_vecs_levels(levels, factors, vecs, boxes, masks, img_csr, n_
     int(n_images), O, D, int(H), int(W), int(align_corners), pd, ldd, _f(ws), _stream()))
 
 
+def layout_backward_maps_levels(levels, factors, vecs, boxes, masks, img_csr, n_images, H, W, align_corners, d_masks, d_boxes):
+  """d_masks / d_boxes of the layout straight from the per-level layout gradients (sg2im_layout_backward_maps_levels);
+  False (nothing launched) when the shapes do not qualify - the caller then materialises the gradient"""
+  O, D = vecs.size(0), vecs.size(1)
+  if D % 4 or D > 128 or vecs.stride(1) != 1 or vecs.stride(0) % 4 or vecs.data_ptr() % 16:
+    return False
+  mf, mi, M = _mask_args(masks)
+  need = _lib.load().sg2im_layout_backward_workspace(O, D, int(H), int(W))
+  ws = workspace(vecs.device)
+  if need > ws.numel() * 4:
+    raise _lib.Sg2imHipError('layout backward needs %d workspace bytes' % need)
+  n = len(levels)
+  ptrs = (c_void_p * n)(*[t.data_ptr() for t in levels])
+  fs = (c_int * n)(*factors)
+  ls = (c_longlong * n)(*[t.size(3) for t in levels])
+  call('sg2im_layout_backward_maps_levels', ptrs, fs, ls, n, _f(vecs), vecs.stride(0), _f(boxes), mf, mi, M,
+       _i32(img_csr.row_ptr), _i32(img_csr.entries), int(n_images), O, D, int(H), int(W), int(align_corners),
+       _f(d_masks), _f(d_boxes), _f(ws), _stream())
+  return True
+
+
 def crop_forward(imgs_nhwc, boxes, obj_to_img, size, align_corners, out):
   N, H, W, C = imgs_nhwc.shape
   call('sg2im_crop_forward', _f(imgs_nhwc), C, N, H, W, C, _f(boxes), _i64(obj_to_img), boxes.size(0), int(size),

@@ -305,6 +305,22 @@ def test_layout_vector_gradient_straight_from_the_level_gradients(H, L, masks):
   torch.cuda.synchronize()
   err = float((got - want).abs().max()) / max(float(want.abs().max()), 1e-30)
   assert err <= 1e-5, err
+  # the other half from the same levels (sg2im_layout_backward_maps_levels): d_boxes always, d_masks for float masks
+  fm = mk if masks == 'float' else None
+  want_m = torch.empty_like(fm) if fm is not None else None
+  want_b = torch.empty(O, 4, device=D)
+  ops.layout_backward(summed, vecs, boxes, mk, o2i.to(D), img_csr, N, H, H, False, None, want_m, want_b)
+  got_m = torch.full_like(fm, 7.0) if fm is not None else None
+  got_b = torch.full((O, 4), 7.0, device=D)
+  assert ops.layout_backward_maps_levels(levels, factors, vecs, boxes, mk, img_csr, N, H, H, False, got_m, got_b)
+  torch.cuda.synchronize()
+  for a, b in ((got_b, want_b), (got_m, want_m)):
+    if a is not None:
+      err = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+      assert err <= 1e-5, err
+  # a vector width the tiled kernel does not take: declined, nothing launched
+  assert not ops.layout_backward_maps_levels(levels, factors, torch.randn(O, 132, device=D), boxes, mk, img_csr, N, H, H, False,
+                                             None, got_b)
 
 
 def test_losses_and_adam():
