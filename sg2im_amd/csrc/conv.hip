@@ -1304,6 +1304,7 @@ __global__ void splitk_finish_parity_kernel(const float* __restrict__ ws, int ns
 
 }  // namespace sg2im
 #include "conv_halo.h"
+#include "conv_fewout.h"
 #include "wgrad_halo.h"
 namespace sg2im {
 
@@ -1320,6 +1321,8 @@ static const size_t g_bg_lds = 56 * 1024;
 static const bool g_plan_tune = getenv("SG2IM_PLAN_TUNE") != nullptr;     // honour SG2IM_FORCE_PLAN
 // A/B knob: 0 = the *_bn entry points run conv + the standalone BatchNorm reduction passes (the round-2 launches)
 static const bool g_fuse_bn = !(getenv("SG2IM_FUSE_BN") && atoi(getenv("SG2IM_FUSE_BN")) == 0);
+// SG2IM_FEWOUT=0: the 1 x 1 convolutions with <= 4 output channels back on the implicit-GEMM kernels (A/B knob, conv_fewout.h)
+static const bool g_fewout = !(getenv("SG2IM_FEWOUT") && atoi(getenv("SG2IM_FEWOUT")) == 0);
 
 template <typename K>
 static hipError_t ensure_lds(K kernel, size_t bytes) {
@@ -1914,6 +1917,20 @@ static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int co
     if (ld_dx != c_count) return SG2IM_ERR_ARG;
     return sg2im_act_backward(dx, ld_dx, 0, d->batch, d->in_h, d->in_w, am->act, am->ld, c_count, am->slope, dx, stream);
   };
+  // 1 x 1 with at most four OUTPUT channels (output_conv[2], mask_net's last layer): one elementwise pass (conv_fewout.h)
+  if (g_fewout && taps == 1 && d->stride == 1 && d->pad == 0 && cout <= 4 && !bb && !accumulate && !(c_count & 3) &&
+      !(c_begin & 3) && !(g.Wtap & 3) && !(ld_dx & 3) && !((uintptr_t)dx & 15) && !((uintptr_t)weight & 15) &&
+      (!am || (!(am->ld & 3) && !((uintptr_t)am->act & 15)))) {
+    const int c4n = c_count >> 2;
+    const dim3 fgrid((unsigned)((Mfull * c4n + 255) / 256));
+#define SG2IM_FEWOUT_DG(CO_)                                                                                               \
+    SG2IM_LAUNCH((conv1x1_fewout_dgrad_kernel<CO_>), fgrid, dim3(256), 0, stream, dy, ld_dy, weight, g.Wtap, c_begin, c4n, \
+                       Mfull, dx, ld_dx, am ? am->act : nullptr, am ? am->ld : 0LL, am ? am->slope : 1.f)
+    if (cout == 1) SG2IM_FEWOUT_DG(1); else if (cout == 2) SG2IM_FEWOUT_DG(2); else if (cout == 3) SG2IM_FEWOUT_DG(3);
+    else SG2IM_FEWOUT_DG(4);
+#undef SG2IM_FEWOUT_DG
+    return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+  }
   if (c_count <= 4 && (size_t)taps * cout * c_count * sizeof(float) <= 48 * 1024) {
     const size_t lds = (size_t)taps * cout * c_count * sizeof(float);
     // at most 2 x 2 taps per pixel, 16-byte dY loads
@@ -2110,6 +2127,31 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
     if (!accumulate && dbias && hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)cout, stream) != hipSuccess)
       return SG2IM_ERR_HIP;
     return SG2IM_OK;
+  }
+  // 1 x 1 with at most four OUTPUT channels over ONE plain NHWC source: a two-stage column reduction (conv_fewout.h)
+  {
+    const Src& s0 = p.g.s0;
+    const int C4 = s0.C >> 2;
+    if (g_fewout && taps == 1 && d->stride == 1 && d->pad == 0 && cout <= 4 && p.g.nsrc == 1 && !s0.gidx && !s0.up &&
+        !(s0.C & 3) && C4 >= 4 && C4 <= 64 && !(C4 & (C4 - 1)) && !(s0.ld & 3) && !((uintptr_t)s0.p & 15) &&
+        (!s0.scale || (s0.shift && !((uintptr_t)s0.scale & 15) && !((uintptr_t)s0.shift & 15))) && workspace) {
+      const long long M = p.P;
+      long long nblk = std::min<long long>(1024, (M + 127) / 128);
+      const long long per = (M + nblk - 1) / nblk;
+      nblk = (M + per - 1) / per;
+      if (sizeof(float) * (size_t)nblk * cout * (s0.C + 1) <= workspace_bytes) {
+#define SG2IM_FEWOUT_WG(CO_)                                                                                             \
+        SG2IM_LAUNCH((conv1x1_fewout_wgrad_kernel<CO_>), dim3((unsigned)nblk), dim3(256), 0, stream, s0.p, (long long)s0.ld, \
+                           s0.scale, s0.shift, s0.slope, C4, dy, ld_dy, M, per, (int)nblk, workspace)
+        if (cout == 1) SG2IM_FEWOUT_WG(1); else if (cout == 2) SG2IM_FEWOUT_WG(2); else if (cout == 3) SG2IM_FEWOUT_WG(3);
+        else SG2IM_FEWOUT_WG(4);
+#undef SG2IM_FEWOUT_WG
+        const int nel = cout * s0.C + cout;
+        SG2IM_LAUNCH(conv1x1_fewout_wgrad_finish_kernel, dim3(nel), dim3(64), 0, stream, workspace, (int)nblk,
+                           cout, s0.C, dweight, p.g.Wtap, dbias, accumulate);
+        return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+      }
+    }
   }
   p.iters = (p.P + BK - 1) / BK;
   const bool v4 = geom_vec4(p.g) && (cout % 4 == 0) && (ld_dy % 4 == 0) && !((uintptr_t)dy & 15);

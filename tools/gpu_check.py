@@ -372,6 +372,12 @@ def sec_conv():
   conv_case('conv2x2 1->12 valid 7x7 (four lanes per pixel, stride 1)', 2, 7, 7, 1, 0, 0, 12, 2, 1, 0)
   conv_case('conv1x1 64->3 32x32', 2, 32, 32, 64, 0, 0, 3, 1, 1, 0)
   conv_case('conv1x1 128->1 16x16', 8, 16, 16, 128, 0, 0, 1, 1, 1, 0)
+  # (csrc/conv_fewout.h: ragged last row block, pending affine in the weight gradient's loader, 2 and 4 output channels,
+  #  a channel count the row-group layout does not take -> implicit GEMM)
+  conv_case('conv1x1 bnact 64->3 40x40 batch 3 (few outputs, ragged blocks)', 3, 40, 40, 64, 0, 0, 3, 1, 1, 0, bnact=True)
+  conv_case('conv1x1 32->4 20x20 (few outputs)', 2, 20, 20, 32, 0, 0, 4, 1, 1, 0)
+  conv_case('conv1x1 16->2 8x8 (few outputs)', 5, 8, 8, 16, 0, 0, 2, 1, 1, 0)
+  conv_case('conv1x1 48->3 12x12 (12 float4 lanes: not a power of two)', 2, 12, 12, 48, 0, 0, 3, 1, 1, 0)
   conv_case('conv3x3 1184->512 8x8 (m1.conv0 shape)', 4, 8, 8, 160, 1024, 1, 512, 3, 1, 1)
   # plain sources, stride 1, channels % 32 == 0
   conv_case('v2 conv3x3 160+128up->64 32x32 (256x64 tile)', 16, 32, 32, 160, 128, 1, 64, 3, 1, 1)
