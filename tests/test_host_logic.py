@@ -471,3 +471,20 @@ def test_shared_pass_adoption_needs_no_kernel_and_rejects_a_foreign_recording():
     HF.DiscCnnFn.apply(None, None, specs[:1], 0.2, True, None, sp, *params[:2])  # another architecture
   with pytest.raises(RuntimeError):
     HF.DiscCnnFn.apply(None, None, specs, 0.2, False, None, sp, *params)         # eval mode
+
+
+def test_one_launch_gcn_backward_is_chosen_where_mask_net_trains():
+  """Trainer._gcn_backward_mode (SG2IM_GCN_PERSIST_BWD=auto): the low-footprint one-launch GraphTripleConv backward
+  for the steps whose main-lane tail carries mask_net's backward - no ground-truth masks in the batch (VG style,
+  model.py:146-157) or a mask loss (train.py:407-410) - and the launch sequence otherwise."""
+  from types import SimpleNamespace
+  from sg2im_amd.trainer import Trainer
+  with_net = SimpleNamespace(model=SimpleNamespace(mask_net=object()), w={'mask_loss_weight': 0.0})
+  no_net = SimpleNamespace(model=SimpleNamespace(mask_net=None), w={'mask_loss_weight': 0.0})
+  coco = (0, 1, 2, torch.zeros(3, 16, 16), 4, 5)
+  vg = (0, 1, 2, None, 4, 5)
+  mode = Trainer._gcn_backward_mode
+  assert mode(with_net, coco) is False and mode(with_net, vg) == 'low'
+  assert mode(no_net, vg) is False and mode(no_net, coco) is False
+  with_net.w['mask_loss_weight'] = 0.1
+  assert mode(with_net, coco) == 'low'
