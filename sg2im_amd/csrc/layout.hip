@@ -859,6 +859,92 @@ __global__ void crop_bwd_object_kernel(const float* __restrict__ dcrops, int H, 
   }
 }
 
+// The same planes, SEPARABLY (round 5).  The crop is a tensor product of two 1-D interpolations, so its transpose is too:
+//   T[i][x] = sum_j wx(j, x) g[i][j]   (x over the rectangle's columns),   plane[y][x] = sum_i wy(i, y) T[i][x].
+// The kernel above walks (samples in y) x (samples in x) per pixel - ~150 dependent iterations for the pixels of a small
+// box, each with a data-dependent global load - and was the longest kernel of the generator-loss backward (77-110 us
+// inside the step, 1 120 workgroups).  Here the object's crop gradient is staged in LDS once, phase A runs one thread
+// per (sample row i, column x) over the <= ~12 samples j that touch x, phase B one thread per pixel over the samples i
+// that touch y, both out of LDS.  Same weights (crop_axis), fixed summation order (j ascending, then i ascending);
+// products are grouped (g wx) wy instead of g (wx wy): equal up to fp32 rounding.  C <= 4, size <= 32, rectangles of
+// <= 64 columns (anything else: the kernel above).
+constexpr int CS_MAXSIZE = 32;
+constexpr int CS_MAXW = 64;
+__global__ __launch_bounds__(256) void crop_bwd_object_sep_kernel(const float* __restrict__ dcrops, int H, int W, int C,
+                                                                  const float* __restrict__ boxes, int size,
+                                                                  int align_corners, float* __restrict__ planes) {
+  __shared__ int s_p0[2][CS_MAXSIZE];
+  __shared__ float s_t[2][CS_MAXSIZE];
+  __shared__ float s_g[CS_MAXSIZE * CS_MAXSIZE * 4];        // [i][j][c]
+  __shared__ float s_T[CS_MAXSIZE * CS_MAXW * 4];           // [i][x - x0][c]
+  __shared__ short s_jl[CS_MAXW], s_jh[CS_MAXW];
+  const int o = blockIdx.x, tid = threadIdx.x;
+  const float* box = boxes + 4LL * o;
+  for (int k = tid; k < 2 * size; k += 256) {
+    const int smp = k % size, ax = k / size;
+    const CropAxis r = ax == 0 ? crop_axis(box[0], box[2], smp, size, W, align_corners)
+                               : crop_axis(box[1], box[3], smp, size, H, align_corners);
+    s_p0[ax][smp] = r.p0; s_t[ax][smp] = r.t;
+  }
+  const CropRect R = crop_rect(box, size, H, W, align_corners);
+  const int rw = R.x1 - R.x0 + 1, rh = R.y1 - R.y0 + 1;
+  if (rw <= 0 || rh <= 0) return;                            // (workgroup-uniform)
+  // this workgroup's pixel rows (gridDim.y workgroups share an object) and the sample rows that can touch them
+  const int rows_per = (rh + gridDim.y - 1) / gridDim.y;
+  const int ya = R.y0 + blockIdx.y * rows_per, yb = min(R.y1, ya + rows_per - 1);
+  if (ya > yb) return;
+  int ilo, ihi, dummy;
+  crop_axis_range(box[1], box[3], ya, size, H, align_corners, ilo, dummy);
+  crop_axis_range(box[1], box[3], yb, size, H, align_corners, dummy, ihi);
+  if (ihi < ilo) { ilo = 0; ihi = size - 1; }               // (degenerate boxes: crop_axis_range gave the full range)
+  const float* gobj = dcrops + (long long)o * size * size * C;
+  for (int e = tid; e < (ihi - ilo + 1) * size * C; e += 256) s_g[ilo * size * C + e] = gobj[ilo * size * C + e];
+  for (int x = tid; x < rw; x += 256) {
+    int jl, jh;
+    crop_axis_range(box[0], box[2], R.x0 + x, size, W, align_corners, jl, jh);
+    s_jl[x] = (short)jl; s_jh[x] = (short)jh;
+  }
+  __syncthreads();
+  // ---- A: T[i][x][c] ----
+  for (int e = tid; e < (ihi - ilo + 1) * rw; e += 256) {
+    const int i = ilo + e / rw, x = e % rw, X = R.x0 + x;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int j = s_jl[x]; j <= s_jh[x]; ++j) {
+      const int px = s_p0[0][j];
+      const float tx = s_t[0][j];
+      const float wx = px == X ? 1.f - tx : (px + 1 == X ? tx : 0.f);
+      const float* g = &s_g[(i * size + j) * C];
+      a0 += g[0] * wx;
+      if (C > 1) a1 += g[1] * wx;
+      if (C > 2) a2 += g[2] * wx;
+      if (C > 3) a3 += g[3] * wx;
+    }
+    float* t = &s_T[(i * CS_MAXW + x) * 4];
+    t[0] = a0; t[1] = a1; t[2] = a2; t[3] = a3;
+  }
+  __syncthreads();
+  // ---- B: plane[y][x][c] ----
+  float* plane = planes + (long long)o * H * W * C;
+  for (int q = tid; q < (yb - ya + 1) * rw; q += 256) {
+    const int y = ya + q / rw, x = q % rw;
+    int il, ih;
+    crop_axis_range(box[1], box[3], y, size, H, align_corners, il, ih);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int i = max(il, ilo); i <= min(ih, ihi); ++i) {
+      const int py = s_p0[1][i];
+      const float ty = s_t[1][i];
+      const float wy = py == y ? 1.f - ty : (py + 1 == y ? ty : 0.f);
+      const float* t = &s_T[(i * CS_MAXW + x) * 4];
+      a0 += t[0] * wy; a1 += t[1] * wy; a2 += t[2] * wy; a3 += t[3] * wy;
+    }
+    float* dst = plane + ((long long)y * W + R.x0 + x) * C;
+    dst[0] = a0;
+    if (C > 1) dst[1] = a1;
+    if (C > 2) dst[2] = a2;
+    if (C > 3) dst[3] = a3;
+  }
+}
+
 __global__ void crop_bwd_sum_kernel(const float* __restrict__ planes, int H, int W, int C,
                                     const float* __restrict__ boxes, const long long* __restrict__ obj_to_img,
                                     int O, int size, int align_corners, float* __restrict__ dimgs, long long ld) {
@@ -1109,8 +1195,13 @@ int sg2im_crop_backward(const float* d_crops, int n_images, int height, int widt
   if (n_images < 1 || height < 1 || width < 1) return SG2IM_OK;
   if (n_objs > 0) {
     const int share = std::max(1, std::min(8, (1024 + n_objs - 1) / n_objs));
-    SG2IM_LAUNCH(crop_bwd_object_kernel, dim3(n_objs, share), dim3(256), 0, stream, d_crops, height, width, channels,
-                       boxes, size, align_corners, workspace);
+    static const bool g_sep = [] { const char* e = getenv("SG2IM_CROP_SEPARABLE"); return !(e && e[0] == '0'); }();   // (A/B knob)
+    if (g_sep && channels <= 4 && size <= CS_MAXSIZE && width <= CS_MAXW)
+      SG2IM_LAUNCH(crop_bwd_object_sep_kernel, dim3(n_objs, share), dim3(256), 0, stream, d_crops, height, width, channels,
+                         boxes, size, align_corners, workspace);
+    else
+      SG2IM_LAUNCH(crop_bwd_object_kernel, dim3(n_objs, share), dim3(256), 0, stream, d_crops, height, width, channels,
+                         boxes, size, align_corners, workspace);
   }
   // every pixel of d_imgs is WRITTEN (zero where no crop touches it): no pre-zeroing needed
   dim3 grid((height * width + 255) / 256, n_images);
