@@ -18,7 +18,7 @@ tot = collections.defaultdict(float); launches = collections.Counter()
 for f in glob.glob('/tmp/pmcs_*/**/*counter_collection.csv', recursive=True):
   for r in csv.DictReader(open(f)):
     k = r['Kernel_Name']
-    if 'conv_fwd' not in k and 'conv_dgrad' not in k and 'conv_wgrad' not in k and 'conv_halo' not in k and 'splitk_finish' not in k and 'gcn_stack' not in k and 'two_heads' not in k: continue
+    if 'conv_fwd' not in k and 'conv_dgrad' not in k and 'conv_wgrad' not in k and 'conv_halo' not in k and 'splitk_finish' not in k and 'gcn_stack' not in k and 'two_heads' not in k and 'conv1x1_fewout' not in k: continue
     tot[r['Counter_Name']] += float(r['Counter_Value']); launches[r['Counter_Name']] += 1
 n = launches['FETCH_SIZE'] / steps
 fetch_mb = 2 * tot['FETCH_SIZE'] / 1024 / steps        # KB units; x2: the guide's gfx950 FETCH_SIZE correction
@@ -26,7 +26,7 @@ write_mb = tot['WRITE_SIZE'] / 1024 / steps
 out = {'steps': steps, 'launches_per_step': n, 'fetch_mb_per_step': round(fetch_mb, 1), 'write_mb_per_step': round(write_mb, 1),
        'traffic_mb_per_launch': round((fetch_mb + write_mb) / max(n, 1), 2),
        'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KB units, FETCH_SIZE x2 on gfx950), '
-                 'summed over conv_fwd/dgrad/wgrad/halo + splitk_finish + gcn_stack + two_heads kernels of %d eager steps' % steps}
+                 'summed over conv_fwd/dgrad/wgrad/halo/1x1-fewout + splitk_finish + gcn_stack + two_heads kernels of %d eager steps' % steps}
 print(json.dumps(out))
 open('$R/gpurun_out/pmc_step.json', 'w').write(json.dumps(out, indent=1))
 PY

@@ -30,6 +30,11 @@ timeout 300 python bench.py --steps 40 --warmup 10 --cpu_baseline_steps 0 --no_r
 timeout 300 python bench.py --steps 20 --warmup 5 --cpu_baseline_steps 0 --no_roofline --no_graphs 2>/dev/null | grep '^{"metric' | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('variant [--no_graphs]', d['ms_per_step'], 'ms/step', d['value'], 'img/s')"
 } > $O/bench_variants.log 2>&1; cat $O/bench_variants.log
 timeout 300 python tools/bench_conv.py 2>&1 | grep -v amdgpu.ids > $O/conv_layers.log; tail -2 $O/conv_layers.log
+timeout 300 python tools/bench_conv.py --bf16 2>&1 | grep -v amdgpu.ids > $O/conv_layers_bf16.log; tail -1 $O/conv_layers_bf16.log
+for cfg in "bf16 coco" "f32 vg" "bf16 vg"; do set -- $cfg
+  SG2IM_MARKS=1 python bench.py --steps 60 --warmup 20 --cpu_baseline_steps 0 --no_roofline --dtype $1 --style $2 2>&1 >/dev/null | grep '\[mark\]' > $O/schedule_marks_$1_$2.txt
+done
+tools/trace_step.sh gpurun_out/ev5/step_bf16_vg --dtype bf16 --style vg > /dev/null 2>&1
 timeout 300 python tools/bench_layout.py 2>&1 | grep -v amdgpu.ids > $O/layout_kernels.log; cat $O/layout_kernels.log
 timeout 300 python tools/gcn_stack_probe.py 2>&1 | grep -v amdgpu.ids > $O/gcn_stack_probe.log; head -4 $O/gcn_stack_probe.log
 cd $R && timeout 600 python __graft_entry__.py smoke > $O/smoke.log 2>&1; tail -3 $O/smoke.log
