@@ -479,8 +479,8 @@ def test_one_launch_gcn_backward_is_chosen_where_mask_net_trains():
   model.py:146-157) or a mask loss (train.py:407-410) - and the launch sequence otherwise."""
   from types import SimpleNamespace
   from sg2im_amd.trainer import Trainer
-  with_net = SimpleNamespace(model=SimpleNamespace(mask_net=object()), w={'mask_loss_weight': 0.0})
-  no_net = SimpleNamespace(model=SimpleNamespace(mask_net=None), w={'mask_loss_weight': 0.0})
+  with_net = SimpleNamespace(model=SimpleNamespace(mask_net=object()), w={'mask_loss_weight': 0.0}, compute_dtype='f32')
+  no_net = SimpleNamespace(model=SimpleNamespace(mask_net=None), w={'mask_loss_weight': 0.0}, compute_dtype='f32')
   coco = (0, 1, 2, torch.zeros(3, 16, 16), 4, 5)
   vg = (0, 1, 2, None, 4, 5)
   mode = Trainer._gcn_backward_mode
@@ -488,3 +488,5 @@ def test_one_launch_gcn_backward_is_chosen_where_mask_net_trains():
   assert mode(no_net, vg) is False and mode(no_net, coco) is False
   with_net.w['mask_loss_weight'] = 0.1
   assert mode(with_net, coco) == 'low'
+  no_net.compute_dtype = 'bf16'                # (bfloat16 operands: the tail ends the step in every style)
+  assert mode(no_net, coco) == 'low'
