@@ -1166,10 +1166,11 @@ class MaskNetFn(Function):
     ni = ctx.needs_input_grad[4:]
     grads = [None] * len(params)
     Wf, bf = params[4 * nb:4 * nb + 2]
-    # (Round 5 measured these five weight gradients on the weight-gradient lane instead of between the data gradients of
-    # this chain, which is part of the tail that ends a VG-style step: SLOWER, 9.27 vs 8.85 ms fp32 / 5.44 vs 5.12 ms
-    # bfloat16 - in lane order they land behind the refinement network's and run next to the one-launch GraphTripleConv
-    # backward, whose grid barriers then wait longer.  profiles/r5_mask_net_wgrad_lane_ab.txt)
+    # (Round 5 measured these five weight gradients OFF this chain - it is part of the tail that ends a VG-style step - in
+    # two placements: on the weight-gradient lane behind the refinement network's, and on a lane that is idle during the
+    # tail.  Both made the step 4-6 % SLOWER: the tail itself got 0.3 ms longer with ten launches fewer on it - every extra
+    # fork / join edge there changes how clr maps the graph's branches onto hardware queues, as round 4 saw with an Adam
+    # slice on a stream of its own.  profiles/r5_mask_net_wgrad_lane_ab.txt)
     wgrad = _conv_param_grads
     ds = ops.sigmoid_backward(masks, g.contiguous(), _new(g, O, s, s, 1))
     grads[4 * nb], grads[4 * nb + 1] = wgrad(df, ds, 1, (1, 1, 1, D), ni[4 * nb], ni[4 * nb + 1], Wf, bf)
