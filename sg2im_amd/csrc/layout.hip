@@ -661,8 +661,20 @@ __global__ __launch_bounds__(256) void layout_bwd_masks_kernel(const float* __re
   const float bw = box[2] - box[0], bh = box[3] - box[1];
   const float mult = align_corners ? 0.5f * (float)(Min - 1) : 0.5f * (float)Min;
   float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-  for (int px = tid; px < HW; px += 256) {
-    const int y = px / W, x = px % W;
+  // only the pixels whose footprint can touch the map: the rectangle spanned by the ranges of its first and last cell
+  // (conservative; the weights decide).  Outside it every term is exactly zero - the loop used to evaluate a footprint
+  // for all H * W pixels of every object.
+  int rx0, rx1, ry0, ry1, t0, t1;
+  layout_axis_range(box[0], box[2], 0, W, Min, align_corners, rx0, t0);
+  layout_axis_range(box[0], box[2], Min - 1, W, Min, align_corners, t1, rx1);
+  layout_axis_range(box[1], box[3], 0, H, Min, align_corners, ry0, t0);
+  layout_axis_range(box[1], box[3], Min - 1, H, Min, align_corners, t1, ry1);
+  if (rx0 > rx1 || ry0 > ry1) { rx0 = 0; rx1 = W - 1; ry0 = 0; ry1 = H - 1; }      // (degenerate boxes: everything, as before)
+  rx0 = max(rx0, 0); ry0 = max(ry0, 0); rx1 = min(rx1, W - 1); ry1 = min(ry1, H - 1);
+  const int rw = rx1 - rx0 + 1, rn = rw * (ry1 - ry0 + 1);
+  for (int q = tid; q < rn; q += 256) {
+    const int y = ry0 + q / rw, x = rx0 + q % rw;
+    const int px = y * W + x;
     const Foot f = footprint(box, y, x, H, W, Min, align_corners);
     if ((f.wx0 == 0.f && f.wx1 == 0.f) || (f.wy0 == 0.f && f.wy1 == 0.f)) continue;
     const float ds = Go[px];
@@ -996,6 +1008,7 @@ __global__ void crop_bwd_sum_kernel(const float* __restrict__ planes, int H, int
 }
 
 static inline int ok_or(hipError_t e) { return e == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP; }
+
 
 }  // namespace sg2im
 
