@@ -17,6 +17,16 @@ validation pass (Trainer.broadcast_state, scripts/train.py); within a training s
 batch statistics are per replica (the reference's batch-32 semantics on every rank) and the running
 statistics drift apart between two broadcasts - a checkpoint holds rank 0's.
 
+Two forms of the exchange (GradReducer(exchange=...), SG2IM_DP_EXCHANGE): 'allreduce' - one library SUM all-reduce per
+arena (slice), RCCL's choice of ring / tree - and 'direct' - the reduce-scatter / all-gather over ALL links that
+SURVEY.md section 5 specifies, spelled out: an all-to-all of the W shards of the arena (every rank sends 1/W of its
+gradients to every peer: 7 concurrent xGMI links on an 8-GPU node instead of one ring direction), a LOCAL sum of the W
+received shards in fp32 (also with the bfloat16 payload: one rounding of each shard and one of the finished sum,
+instead of W - 1 roundings of a bfloat16 running sum inside the library's ring), an all-gather of the reduced shards.
+Every rank ends up with bit-identical arenas.  'direct' has never run on more than one GPU (1-rank RCCL and 2-rank gloo
+tests); it is opt-in, eager / schedule 0 / 1 only (the in-graph schedule keeps the comm stream free of elementwise
+kernels, which the local sum is).
+
 Gradient semantics (tested in tests/test_dp_gloo.py): every rank computes the reference's
 per-shard loss (means over ITS objects / pixels), so the applied gradient is the mean over
 ranks of the per-shard gradients - not the gradient of the concatenated batch.
@@ -82,10 +92,20 @@ class _Then(object):
     self.after(self.tensor)
 
 
+class _Join(object):
+  """handle of a direct exchange started on the reducer's own stream"""
+
+  def __init__(self, stream, device):
+    self.stream, self.device = stream, device
+
+  def wait(self):
+    torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+
 class GradReducer(object):
   """Sum-reduces flat gradient arenas across ranks, asynchronously."""
 
-  def __init__(self, world_size=None, group=None, force=False, payload='f32'):
+  def __init__(self, world_size=None, group=None, force=False, payload='f32', exchange='allreduce'):
     if world_size is None:
       world_size = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     self.world_size = world_size
@@ -104,7 +124,12 @@ class GradReducer(object):
     if payload not in ('f32', 'bf16'):
       raise ValueError('payload must be "f32" or "bf16"')
     self.payload = payload
+    if exchange not in ('allreduce', 'direct'):
+      raise ValueError('exchange must be "allreduce" or "direct"')
+    self.exchange = exchange
     self._staging = {}               # (arena address, elements) -> bfloat16 buffer (allocated once, see staging())
+    self._direct = {}                # (arena address, elements) -> the buffers of the direct exchange (see _direct_bufs)
+    self._xstream = None             # the stream the direct exchange runs on (start ... finish)
 
   @property
   def grad_scale(self):
@@ -119,15 +144,53 @@ class GradReducer(object):
     return (self.world_size > 1 or self.force) and not self.mute
 
   def capturable(self):
-    """can the collectives be recorded into a hipGraph?  RCCL: yes (tools/rccl_capture_probe.py,
-    profiles/r3_rccl_capture_probe.log); the host-staged gloo form: no"""
-    return (self.world_size > 1 or self.force) and dist.is_initialized() and dist.get_backend(self.group) == 'nccl'
+    """can the collectives be recorded into a hipGraph?  RCCL all-reduces: yes (tools/rccl_capture_probe.py,
+    profiles/r3_rccl_capture_probe.log); the host-staged gloo form: no; the direct exchange: not offered (its local
+    sum would be an elementwise kernel on the comm stream - module docstring)"""
+    return ((self.world_size > 1 or self.force) and dist.is_initialized() and dist.get_backend(self.group) == 'nccl' and
+            self.exchange == 'allreduce')
+
+  # ---- the direct exchange: all-to-all of shards, local fp32 sum, all-gather ------------------------------------
+  def _direct_bufs(self, tensor):
+    """(send, recv, reduced, out, n): payload-typed buffers of W * s elements (s = ceil(n / W); the pad is zero and
+    never written), an fp32 + payload-typed reduced shard.  One set per distinct arena (slice), kept."""
+    key = (tensor.data_ptr(), tensor.numel())
+    bufs = self._direct.get(key)
+    if bufs is None:
+      W, n = self._group_size(), tensor.numel()
+      s_ = -(-n // W)
+      dt = torch.bfloat16 if (self.payload == 'bf16' and n > 1) else torch.float32
+      dev = torch.device('cpu') if _host_staged(tensor, self.group) else tensor.device
+      mk = lambda m, d: torch.zeros(m, dtype=d, device=dev)
+      bufs = (mk(W * s_, dt), mk(W * s_, dt), mk(s_, torch.float32), mk(s_, dt), mk(W * s_, dt))
+      self._direct[key] = bufs
+    return bufs
+
+  def _group_size(self):
+    return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+  def _exchange_direct(self, tensor):
+    """SUM over the ranks of ``tensor`` (in place), ordered on the current stream"""
+    send, recv, red32, red, out = self._direct_bufs(tensor)
+    W, n = self._group_size(), tensor.numel()
+    send[:n].copy_(tensor)                                        # (rounds to bfloat16 with that payload)
+    dist.all_to_all_single(recv, send, group=self.group)          # recv[i * s : (i + 1) * s] = rank i's shard `me`
+    torch.sum(recv.view(W, -1), dim=0, dtype=torch.float32, out=red32)      # rank order, fp32 accumulation
+    if red.dtype == torch.float32:
+      red = red32
+    else:
+      red.copy_(red32)                                            # (ONE rounding of the finished sum)
+    dist.all_gather_into_tensor(out, red, group=self.group)
+    self._reduced(out)
+    tensor.copy_(out[:n])
 
   def reduce_here(self, tensor):
     """SUM all-reduce of ``tensor`` ordered on the CURRENT stream (which waits for it; the collective itself
     runs on the process group's own stream) - the form that is recorded into a stream capture"""
     if self.live():
-      if self.payload == 'bf16' and tensor.numel() > 1:
+      if self.exchange == 'direct':
+        self._exchange_direct(tensor)
+      elif self.payload == 'bf16' and tensor.numel() > 1:
         buf = self.staging(tensor)
         buf.copy_(tensor)
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
@@ -174,11 +237,24 @@ class GradReducer(object):
 
   def drop_staging(self):
     self._staging = {}
+    self._direct = {}
 
   def start(self, tensor):
     """begin an all-reduce (SUM) of ``tensor`` in place; returns immediately"""
     if self.live():
-      if self.payload == 'bf16' and tensor.numel() > 1:
+      if self.exchange == 'direct':
+        # the whole exchange on a stream of the reducer's own, behind everything issued so far on the current one:
+        # the caller keeps launching (the D_obj step while the generator's arena travels), finish() joins
+        if tensor.is_cuda:
+          if self._xstream is None:
+            self._xstream = torch.cuda.Stream(device=tensor.device)
+          self._xstream.wait_stream(torch.cuda.current_stream(tensor.device))
+          with torch.cuda.stream(self._xstream):
+            self._exchange_direct(tensor)
+          self.pending.append(_Join(self._xstream, tensor.device))
+        else:
+          self._exchange_direct(tensor)
+      elif self.payload == 'bf16' and tensor.numel() > 1:
         buf = self.staging(tensor)
         buf.copy_(tensor)
         self.pending.append(_Widen(all_reduce_sum_async(buf, self.group), buf, tensor, self._reduced))

@@ -186,7 +186,8 @@ class Trainer(object):
     self.opt_do = FlatAdam(self.flat_do, lr=learning_rate) if self.d_obj is not None else None
     self.opt_di = FlatAdam(self.flat_di, lr=learning_rate) if self.d_img is not None else None
     # (bf16 mode: the gradient arenas travel as bfloat16, sg2im_amd/distributed.py; SG2IM_GRAD_PAYLOAD overrides)
-    self.reducer = GradReducer(world_size, payload=os.environ.get('SG2IM_GRAD_PAYLOAD', 'bf16' if compute_dtype == 'bf16' else 'f32'))
+    self.reducer = GradReducer(world_size, payload=os.environ.get('SG2IM_GRAD_PAYLOAD', 'bf16' if compute_dtype == 'bf16' else 'f32'),
+                               exchange=os.environ.get('SG2IM_DP_EXCHANGE', 'allreduce'))
     if world_size > 1:
       # replicas must start from identical weights / buffers whatever the seeds were, and draw
       # different layout noise (model.py:164-168) per rank

@@ -84,6 +84,35 @@ def _worker(rank, world, port, ret):
         bound = sum(w[k].abs() for w in want) / world * 2.0 ** -7 + 1e-12
         worst_h = max(worst_h, float(((p.grad * redh.grad_scale - mean).abs() / bound).max()))
     assert flat.grad.dtype == torch.float32 and worst_h <= 1.0, worst_h
+    # the DIRECT exchange (GradReducer(exchange='direct'): all-to-all of shards, local fp32 sum, all-gather - SURVEY.md
+    # section 5's reduce-scatter / all-gather over all links): the same sums as the all-reduce, on every rank the same bits
+    for k, p in module.named_parameters():
+      if k in mine:
+        p.grad.copy_(mine[k])
+    redd = GradReducer(exchange='direct')
+    redd.start(flat.grad)
+    gd = guard.clone() if rank == 0 else torch.tensor([1.0])
+    redd.start(gd)                         # (one element over two ranks: a padded shard)
+    redd.finish()
+    worst_d = 0.0
+    for k, p in module.named_parameters():
+      if k in mine:
+        worst_d = max(worst_d, float((p.grad - sum(w[k] for w in want)).abs().max()))
+    assert worst_d <= 1e-7 * max(1.0, float(flat.grad.abs().max())), worst_d
+    assert not bool(torch.isfinite(gd).all())              # (rank 0's NaN reached everybody)
+    # ... with the bfloat16 payload: each shard rounded once, summed in fp32, the sum rounded once - EXACTLY
+    # bf16(sum_r fp32(bf16(shard_r))), a tighter statement than the all-reduce form's bound above; length not a multiple of 2
+    g = torch.Generator().manual_seed(5)
+    shards = [torch.randn(1001, generator=g) * 3.0 for _ in range(world)]
+    x = shards[rank].clone()
+    reddh = GradReducer(payload='bf16', exchange='direct')
+    reddh.start(x)
+    reddh.finish()
+    exact = sum(sh.bfloat16().float() for sh in shards).bfloat16().float()
+    assert torch.equal(x, exact), float((x - exact).abs().max())
+    allx = [torch.empty_like(x) for _ in range(world)]
+    dist.all_gather(allx, x)
+    assert all(torch.equal(a, x) for a in allx)            # bit-identical replicas
     ret[rank] = (worst, bool(torch.isfinite(guard).all()))
     # shard_batch on the 4-image synthetic batch gives each rank 2 whole images
     from sg2im_amd.synthetic import synthetic_batch

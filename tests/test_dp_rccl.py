@@ -26,8 +26,9 @@ def _free_port():
   return port
 
 
-def _worker(rank, world, port, backend, share_gpu, use_graphs, dp_schedule, ret):
+def _worker(rank, world, port, backend, share_gpu, use_graphs, dp_schedule, ret, exchange='allreduce'):
   import torch.distributed as dist
+  os.environ['SG2IM_DP_EXCHANGE'] = exchange
   os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
   os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
   torch.set_num_threads(8)       # (two workers run CPU oracles side by side: no oversubscription)
@@ -94,16 +95,17 @@ def _worker(rank, world, port, backend, share_gpu, use_graphs, dp_schedule, ret)
     dist.destroy_process_group()
 
 
-def _run(backend, share_gpu, use_graphs, dp_schedule):
+def _run(backend, share_gpu, use_graphs, dp_schedule, exchange='allreduce'):
   import torch.multiprocessing as mp
   world, port = 2, _free_port()
   ret = mp.Manager().dict()
-  mp.spawn(_worker, args=(world, port, backend, share_gpu, use_graphs, dp_schedule, ret), nprocs=world, join=True)
+  mp.spawn(_worker, args=(world, port, backend, share_gpu, use_graphs, dp_schedule, ret, exchange), nprocs=world, join=True)
   assert len(ret) == world
   for rank in range(world):
     worst_loss, worst_grad, bad, same, stats = ret[rank]
-    line = 'dp 2 ranks %s%s graphs=%s schedule=%s rank %d: worst loss rel %.3e, worst e_hip64 %.3e (float32 oracle: E_ref %.3e)' % (
-      backend, ' (one GPU)' if share_gpu else '', use_graphs, dp_schedule, rank, worst_loss, worst_grad[0], worst_grad[1])
+    line = 'dp 2 ranks %s%s graphs=%s schedule=%s' % (backend, ' (one GPU)' if share_gpu else '', use_graphs, dp_schedule) + (
+      ' exchange=direct' if exchange == 'direct' else '') + ' rank %d: worst loss rel %.3e, worst e_hip64 %.3e (float32 oracle: E_ref %.3e)' % (
+      rank, worst_loss, worst_grad[0], worst_grad[1])
     print(line)
     try:
       os.makedirs('gpurun_out', exist_ok=True)
@@ -131,3 +133,17 @@ def test_two_rank_rccl_training_matches_the_dp_reference(use_graphs, dp_schedule
   if torch.cuda.device_count() < 2:
     pytest.skip('needs two GPUs')
   _run('nccl', False, use_graphs, dp_schedule)
+
+
+@pytest.mark.parametrize('use_graphs', [False, True])
+def test_two_ranks_on_one_gpu_direct_exchange(use_graphs):
+  """GradReducer(exchange='direct') - all-to-all of arena shards, local fp32 sum, all-gather (SG2IM_DP_EXCHANGE=direct;
+  sg2im_amd/distributed.py) - under the Trainer: eager segments and the iteration graph + exposed exchange + Adam graph"""
+  _run('gloo', True, use_graphs, 0, exchange='direct')
+
+
+@pytest.mark.parametrize('use_graphs', [False, True])
+def test_two_rank_rccl_direct_exchange(use_graphs):
+  if torch.cuda.device_count() < 2:
+    pytest.skip('needs two GPUs')
+  _run('nccl', False, use_graphs, 0, exchange='direct')

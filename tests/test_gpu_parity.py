@@ -655,11 +655,14 @@ def test_rccl_path_single_rank():
     kw = dict(generator_kwargs={'layout_noise_dim': 0}, seed=5, bucket=(32, 64))
     b = Trainer(vocab, dev, **kw)
     lb = [Trainer.losses_to_host(b.step(batch)) for _ in range(5)]
-    for use_graphs in (False, True):     # eager segments / iteration graph + all-reduces + Adam graph
+    # eager segments / iteration graph + all-reduces + Adam graph; then the same with the DIRECT exchange (all-to-all of
+    # shards + local sum + all-gather over RCCL, sg2im_amd/distributed.py: with one rank every collective is a copy)
+    for use_graphs, exchange in ((False, 'allreduce'), (True, 'allreduce'), (False, 'direct'), (True, 'direct')):
       a = Trainer(vocab, dev, world_size=1, use_graphs=use_graphs, **kw)
       a.reducer.force = True
+      a.reducer.exchange = exchange
       la = [Trainer.losses_to_host(a.step(batch)) for _ in range(5)]
-      assert la == lb, (use_graphs, la, lb)          # a 1-rank sum changes nothing: bit-identical
+      assert la == lb, (use_graphs, exchange, la, lb)          # a 1-rank sum changes nothing: bit-identical
       assert torch.equal(a.flat_g.flat, b.flat_g.flat)
   finally:
     dist.destroy_process_group()
