@@ -490,3 +490,49 @@ def test_one_launch_gcn_backward_is_chosen_where_mask_net_trains():
   assert mode(with_net, coco) == 'low'
   no_net.compute_dtype = 'bf16'                # (bfloat16 operands: the tail ends the step in every style)
   assert mode(no_net, coco) == 'low'
+
+
+def test_layout_backward_takes_both_halves_from_the_level_gradients_or_materialises_once(monkeypatch):
+  """LayoutFn.backward's routing (functional.py), with the kernels replaced by recorders: with the
+  refinement network's per-level gradients in the link, d_vecs AND d_masks / d_boxes come straight from the levels; a
+  shape the mask / box kernel declines materialises the sum ONCE and computes only what is still missing; without a
+  link everything goes through the materialised path."""
+  from types import SimpleNamespace
+  from sg2im_amd import functional as HF
+  from sg2im_amd import ops
+  calls = []
+  declines = {'maps': False}
+  monkeypatch.setattr(ops, 'mark', lambda name: None)
+  monkeypatch.setattr(ops, 'layout_backward_vecs_levels', lambda *a: calls.append(('vecs_levels',)))
+  monkeypatch.setattr(ops, 'layout_backward_maps_levels',
+                      lambda *a: (calls.append(('maps_levels', a[-2] is not None, a[-1] is not None)), not declines['maps'])[1])
+  monkeypatch.setattr(ops, 'pyramid_backward', lambda *a: calls.append(('pyramid',)))
+  monkeypatch.setattr(ops, 'layout_backward',
+                      lambda g, v, b, m, o2i, csr, n, H, W, ac, dv, dm, db=None: calls.append(
+                        ('layout_backward', dv is not None, dm is not None, db is not None)))
+  N, H, D, O, M = 2, 16, 8, 3, 4
+  vecs, boxes, masks = torch.randn(O, D), torch.rand(O, 4), torch.rand(O, M, M)
+  o2i = torch.tensor([0, 0, 1])
+  levels = [torch.randn(N, H >> l, H >> l, D) for l in range(2)]
+
+  def run(needs, with_link):
+    del calls[:]
+    link = None
+    g = torch.empty(N, H, H, D)
+    if with_link:
+      link = HF.LayoutLink()
+      link.leave_grad(g, levels, [1, 2], D)
+    ctx = SimpleNamespace(saved_tensors=(vecs, boxes, masks, o2i), geom=(N, H, H, False), needs_input_grad=needs,
+                          link=link, img_csr=None)
+    out = HF.LayoutFn.backward(ctx, g)
+    assert (out[0] is not None, out[1] is not None, out[2] is not None) == tuple(needs[:3])
+    return list(calls)
+
+  vg = (True, False, True) + (False,) * 9            # VG style: vectors and soft masks need gradients
+  assert run(vg, True) == [('vecs_levels',), ('maps_levels', True, False)]
+  assert run((True, False, False) + (False,) * 9, True) == [('vecs_levels',)]          # COCO style
+  assert run((True, True, True) + (False,) * 9, True) == [('vecs_levels',), ('maps_levels', True, True)]
+  declines['maps'] = True                            # (e.g. a vector width the tiled kernel does not take)
+  assert run(vg, True) == [('vecs_levels',), ('maps_levels', True, False), ('pyramid',),
+                           ('layout_backward', False, True, False)]
+  assert run(vg, False) == [('layout_backward', True, True, False)]
