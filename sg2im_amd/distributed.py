@@ -175,7 +175,10 @@ class GradReducer(object):
     W, n = self._group_size(), tensor.numel()
     send[:n].copy_(tensor)                                        # (rounds to bfloat16 with that payload)
     dist.all_to_all_single(recv, send, group=self.group)          # recv[i * s : (i + 1) * s] = rank i's shard `me`
-    torch.sum(recv.view(W, -1), dim=0, dtype=torch.float32, out=red32)      # rank order, fp32 accumulation
+    shards = recv.view(W, -1)
+    red32.copy_(shards[0])                                        # fp32 accumulation in RANK ORDER, spelled out: the sum
+    for r in range(1, W):                                         # is a defined function of the shards (a library
+      red32.add_(shards[r])                                       # reduction's order is not), W - 1 small kernels
     if red.dtype == torch.float32:
       red = red32
     else:

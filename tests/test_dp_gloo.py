@@ -171,3 +171,48 @@ def test_bf16_sum_of_eight_bf16_shards():
         assert rel <= 0.15 and cos >= 0.999, (n, start, rel, cos)
       else:
         assert rel <= 2e-2 and cos >= 0.9999, (n, start, rel, cos)
+
+
+def _direct_worker(rank, world, port, ret):
+  os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    from sg2im_amd.distributed import GradReducer
+    g = torch.Generator().manual_seed(17)
+    ok = True
+    for n in (1, 5, 8, 1003, 4096):                  # shorter than the group, not a multiple of it, a multiple
+      shards = [torch.randn(n, generator=g) * (1.0 + r) for r in range(world)]
+      for payload in ('f32', 'bf16'):
+        x = shards[rank].clone()
+        red = GradReducer(payload=payload, exchange='direct')
+        red.start(x)
+        red.finish()
+        if payload == 'f32' or n == 1:              # (a one-element tensor - the NaN guard - travels as fp32)
+          want = torch.zeros(n)
+          for sh in shards:                          # rank order, fp32: the local sum's order
+            want = want + sh
+        else:
+          acc = torch.zeros(n)
+          for sh in shards:
+            acc = acc + sh.bfloat16().float()
+          want = acc.bfloat16().float()
+        ok = ok and torch.equal(x, want)
+        # a second use of the same reducer and tensor re-uses its buffers (the pad must still be zero)
+        y = shards[rank].clone()
+        x.copy_(y)
+        red.start(x)
+        red.finish()
+        ok = ok and torch.equal(x, want)
+    ret[rank] = ok
+  finally:
+    dist.destroy_process_group()
+
+
+def test_direct_exchange_world_size_8():
+  """GradReducer(exchange='direct') with EIGHT ranks (the node size the exchange is designed for): lengths below,
+  across and at multiples of the group size; fp32: the rank-ordered sum, bit for bit on every rank; bfloat16 payload:
+  exactly bf16(sum_r fp32(bf16(shard_r)))."""
+  world, port = 8, _free_port()
+  ret = mp.Manager().dict()
+  mp.spawn(_direct_worker, args=(world, port, ret), nprocs=world, join=True)
+  assert len(ret) == world and all(ret[r] for r in range(world)), dict(ret)
