@@ -69,3 +69,20 @@ def test_product_path_has_no_oracle_import():
       if f.endswith('.py'):
         text = open(os.path.join(dirpath, f)).read()
         assert not re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M), f
+
+
+def test_plain_cpp_user_of_the_header_compiles_and_links():
+  """examples/abi_smoke.cpp - a C++ program with hipMalloc'd buffers and no torch - compiles against include/sg2im_hip.h
+  and links against the built library (cross-compiled here; it RUNS on the GPU box: profiles/r5_abi_smoke.log)."""
+  import subprocess
+  import tempfile
+  from sg2im_amd import build
+  lib = build.build(verbose=False)
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  with tempfile.TemporaryDirectory() as tmp:
+    out = os.path.join(tmp, 'abi_smoke')
+    cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-std=c++17', '-I' + os.path.join(root, 'include'),
+           os.path.join(root, 'examples', 'abi_smoke.cpp'), '-L' + os.path.dirname(lib), '-lsg2im_hip', '-o', out]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    assert os.path.getsize(out) > 0
