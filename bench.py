@@ -57,6 +57,12 @@ def parse():
                        "tensors) - BASELINE configs[2..4]; a SECONDARY line, the headline metric is quoted in fp32")
   ap.add_argument('--style', default='coco', choices=['coco', 'vg'],
                   help="'vg': VG-shape graphs without GT masks (BASELINE configs[2] shape, fp32) instead of the COCO headline workload")
+  ap.add_argument('--refinement_dims', default=None,
+                  help="comma-separated CRN widths (reference --refinement_network_dims, train.py:99; default 1024,512,256,128,64). "
+                       "BASELINE configs[3] 'deeper CRN' = 1024,512,256,128,64,64 (SURVEY.md 8d C3: seed map 4x4 at 128x128)")
+  ap.add_argument('--min_objs', type=int, default=None, help='real objects per image, lower bound (default 3)')
+  ap.add_argument('--max_objs', type=int, default=None, help='real objects per image, upper bound (default 8 coco / 10 vg; configs[4]: 29)')
+  ap.add_argument('--extra_rels', type=int, default=6, help="vg style: relationships per image ~ U{1..k+extra_rels} (configs[4]: 60 -> <= 100 triples with the __in_image__ ones)")
   ap.add_argument('--eval_generator', action='store_true',
                   help='generator in eval() mode (running BatchNorm statistics), as the reference trains after '
                        '--eval_mode_after iterations (train.py:509-512); not the headline workload')
@@ -189,19 +195,23 @@ def main():
   nb = max(1, args.n_batches)
   if args.style == 'vg':
     vocab = make_vocab(179, 46)
-    cpu_batches = [synthetic_batch(args.batch_size, image_size=(S, S), num_objs=179, num_preds=46, min_objs=3,
-                                   max_objs=10, mask_size=16, style='vg', seed=args.seed + rank + 1000 * i)
+    cpu_batches = [synthetic_batch(args.batch_size, image_size=(S, S), num_objs=179, num_preds=46, min_objs=args.min_objs or 3,
+                                   max_objs=args.max_objs or 10, mask_size=16, style='vg', extra_rels=args.extra_rels,
+                                   seed=args.seed + rank + 1000 * i)
                    for i in range(nb)]
   else:
     vocab = make_vocab(184, 7)            # COCO-Stuff: 184 object ids incl. __image__, 7 predicates
-    cpu_batches = [synthetic_batch(args.batch_size, image_size=(S, S), num_objs=184, num_preds=7, min_objs=3,
-                                   max_objs=8, mask_size=16, style='coco', seed=args.seed + rank + 1000 * i)
+    cpu_batches = [synthetic_batch(args.batch_size, image_size=(S, S), num_objs=184, num_preds=7, min_objs=args.min_objs or 3,
+                                   max_objs=args.max_objs or 8, mask_size=16, style='coco', seed=args.seed + rank + 1000 * i)
                    for i in range(nb)]
   cpu_batch = cpu_batches[0]
   batches = [tuple(t.to(device) if torch.is_tensor(t) else t for t in b) for b in cpu_batches]
   batch = batches[0]
   bucket = tuple(int(v) for v in args.bucket.split(','))
-  trainer = Trainer(vocab, device, generator_kwargs={'image_size': (S, S)}, world_size=world, seed=1234,
+  gkw = {'image_size': (S, S)}
+  if args.refinement_dims:
+    gkw['refinement_dims'] = tuple(int(v) for v in args.refinement_dims.split(','))
+  trainer = Trainer(vocab, device, generator_kwargs=gkw, world_size=world, seed=1234,
                     use_graphs=not args.no_graphs, bucket=bucket, rank=rank, compute_dtype=args.dtype,
                     verify_replicas=False,      # (checked here, around the timed loop: Trainer.check_replicas)
                     dp_schedule=args.dp_schedule)
@@ -462,11 +472,14 @@ def main():
       'vs_baseline': None,
       'dtype': 'f32' if args.dtype == 'f32' else 'bf16 (matrix-core operands of the spatial convolutions; fp32 accumulation, tensors, statistics and Adam)',
       'data': 'synthetic',
-      'config': {'workload': ('COCO-%d synthetic scene graphs (3-8 objects + __image__, <=16 triples per image), '
-                              if args.style == 'coco' else 'VG-%d synthetic scene graphs (3-10 objects, no GT masks), ') % S +
+      'config': {'workload': ('COCO-%d synthetic scene graphs (%d-%d objects + __image__, <=%d triples per image), ' % (
+                                S, args.min_objs or 3, args.max_objs or 8, 2 * (args.max_objs or 8))
+                              if args.style == 'coco' else 'VG-%d synthetic scene graphs (%d-%d objects, <=%d triples per image, no GT masks), ' % (
+                                S, args.min_objs or 3, args.max_objs or 10, 2 * (args.max_objs or 10) + args.extra_rels)) +
                              'batch %d per GPU, full G + D_obj + D_img step with 3x Adam' % args.batch_size +
                              (' (generator in eval mode)' if args.eval_generator else ''),
                  'global_batch': args.batch_size * world, 'image_size': S,
+                 'refinement_dims': list(trainer.model_kwargs['refinement_dims']),
                  'batch_stream': {'distinct_batches': nb, 'distinct_object_triple_shapes': len(shapes),
                                   'objects_min_max': [shapes[0][0], shapes[-1][0]],
                                   'triples_min_max': [min(t for _, t in shapes), max(t for _, t in shapes)],

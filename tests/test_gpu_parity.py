@@ -761,7 +761,8 @@ def test_step_is_bit_reproducible():
       assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize('case', ['vg64', 'vg64_batch32', 'vg128_deeper_crn', 'stretch256', 'vg64_no_normalization'])
+@pytest.mark.parametrize('case', ['vg64', 'vg64_batch32', 'vg128_deeper_crn', 'stretch256', 'vg64_no_normalization',
+                                  'vg128_batch16', 'stretch256_batch4'])
 def test_other_baseline_shapes_match_oracle(case):
   """BASELINE.json configs[2..4] as fp32 parity cases (one full iteration against the oracle):
   VG-shape graphs without GT masks (mask_net trains through the layout), the 128x128 config with
@@ -780,6 +781,10 @@ def test_other_baseline_shapes_match_oracle(case):
     S, bs, gk, bk = 64, 3, dict(normalization='none'), dict(min_objs=3, max_objs=10)
   elif case == 'vg128_deeper_crn':
     S, bs, gk, bk = 128, 2, dict(refinement_dims=(1024, 512, 256, 128, 64, 64)), dict(min_objs=3, max_objs=10)
+  elif case == 'vg128_batch16':                # configs[3] at a real per-GPU size (M = 16 x 128^2 rows at the last level)
+    S, bs, gk, bk = 128, 16, dict(refinement_dims=(1024, 512, 256, 128, 64, 64)), dict(min_objs=3, max_objs=10)
+  elif case == 'stretch256_batch4':            # configs[4]: 10-29 objects, <= 100 triples per image, 4 images
+    S, bs, gk, bk = 256, 4, dict(refinement_dims=(1024, 512, 256, 128, 64, 64)), dict(min_objs=10, max_objs=29, extra_rels=60)
   else:
     S, bs, gk, bk = 256, 1, dict(refinement_dims=(1024, 512, 256, 128, 64, 64)), dict(min_objs=10, max_objs=29, extra_rels=60)
   gk = dict(gk, image_size=(S, S))
