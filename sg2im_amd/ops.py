@@ -213,11 +213,24 @@ class SideLane(object):
       self.used = False
 
 
-def workspace(device):
+_ws_retired = []
+
+
+def workspace(device, min_bytes=0):
+  """Split-K / layout-backward work buffer of the current lane (device, stream): 256 MB, grown on demand (the
+  256 x 256 configuration with ~900 objects needs 0.5 GB for the layout backward's per-tile partials).  Like
+  `scratch`, an outgrown buffer is RETIRED, not freed (graphs captured earlier keep using its address), and it
+  cannot grow inside a stream capture - Trainer._prepare_lanes sizes it before the capture starts."""
   key = _lane(device)
   w = _ws.get(key)
-  if w is None:
-    w = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
+  if w is None or w.numel() * 4 < min_bytes:
+    if w is not None:
+      if torch.cuda.is_current_stream_capturing():
+        raise _lib.Sg2imHipError('the lane workspace (%d bytes) would have to grow to %d bytes inside a stream capture'
+                                 % (w.numel() * 4, min_bytes))
+      _ws_retired.append(w)
+    nbytes = max(WORKSPACE_BYTES, (int(min_bytes) + (1 << 20) - 1) >> 20 << 20)
+    w = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
     _ws[key] = w
   return w
 
@@ -783,9 +796,7 @@ def layout_backward(dlayout, vecs, boxes, masks, obj_to_img, img_csr, n_images, 
   mf, mi, M = _mask_args(masks)
   O, D = vecs.size(0), vecs.size(1)
   need = _lib.load().sg2im_layout_backward_workspace(O, D, int(H), int(W))
-  ws = workspace(vecs.device)
-  if need > ws.numel() * 4:
-    raise _lib.Sg2imHipError('layout backward needs %d workspace bytes' % need)
+  ws = workspace(vecs.device, need)
   pd, ldd = rows_ld(d_vecs) if d_vecs is not None else (None, 0)
   call('sg2im_layout_backward', _f(dlayout), dlayout.size(3), pv, ldv, _f(boxes), mf, mi, M, _i64(obj_to_img),
        _i32(img_csr.row_ptr), _i32(img_csr.entries), int(n_images), O, D, int(H), int(W), int(align_corners),
@@ -797,9 +808,7 @@ def layout_backward_vecs_levels(levels, factors, vecs, boxes, masks, img_csr, n_
   mf, mi, M = _mask_args(masks)
   O, D = vecs.size(0), vecs.size(1)
   need = _lib.load().sg2im_layout_backward_workspace(O, D, int(H), int(W))
-  ws = workspace(vecs.device)
-  if need > ws.numel() * 4:
-    raise _lib.Sg2imHipError('layout backward needs %d workspace bytes' % need)
+  ws = workspace(vecs.device, need)
   n = len(levels)
   ptrs = (c_void_p * n)(*[t.data_ptr() for t in levels])
   fs = (c_int * n)(*factors)
@@ -819,9 +828,7 @@ def layout_backward_maps_levels(levels, factors, vecs, boxes, masks, img_csr, n_
     return False
   mf, mi, M = _mask_args(masks)
   need = _lib.load().sg2im_layout_backward_workspace(O, D, int(H), int(W))
-  ws = workspace(vecs.device)
-  if need > ws.numel() * 4:
-    raise _lib.Sg2imHipError('layout backward needs %d workspace bytes' % need)
+  ws = workspace(vecs.device, need)
   n = len(levels)
   ptrs = (c_void_p * n)(*[t.data_ptr() for t in levels])
   fs = (c_int * n)(*factors)

@@ -548,7 +548,7 @@ class Trainer(object):
     return st['out']
 
   # -- hipGraph replay, one graph per batch-shape bucket ---------------------------
-  def _prepare_lanes(self, scratch_floats):
+  def _prepare_lanes(self, scratch_floats, workspace_bytes=0):
     """Streams and work buffers of every execution lane a capture uses, created EAGERLY (outside
     any capture, so that no captured graph's private memory pool ends up owning them): the capture
     stream, the side stream of the discriminator steps and the side stream the refinement network's
@@ -585,7 +585,7 @@ class Trainer(object):
     assert len(set(s.cuda_stream for s in lanes)) == len(lanes), 'two lanes of the captured iteration share a stream'
     for s in (self._cap_stream, self._side[0], self._aux2, self._wgrad_stream):
       with torch.cuda.stream(s):
-        ops.workspace(dev)
+        ops.workspace(dev, workspace_bytes)
         ops.scratch(dev, scratch_floats)
         ops.sync_area(dev)           # (grid-barrier state of the persistent GraphTripleConv kernels)
     if self.reducer.payload == 'bf16' and (self.world_size > 1 or self.reducer.force):
@@ -669,7 +669,11 @@ class Trainer(object):
     (static batch, graphs, state dict with the output tensors, launch epoch)."""
     imgs = sb.imgs
     # reduction scratch the crop backward wants: one image-sized plane per (padded) object
-    self._prepare_lanes(max(1 << 24, sb.o_pad * imgs.size(2) * imgs.size(3) * imgs.size(1) + (1 << 20)))
+    # ... and the layout backward's per-tile partials (0.5 GB at 256 x 256 with ~900 objects: the lane workspaces grow
+    # here, before the capture - ops.workspace)
+    H, W = self.model.image_size
+    ws_need = int(_lib.load().sg2im_layout_backward_workspace(int(sb.o_pad), int(self.model_kwargs['gconv_dim']), int(H), int(W)))
+    self._prepare_lanes(max(1 << 24, sb.o_pad * imgs.size(2) * imgs.size(3) * imgs.size(1) + (1 << 20)), ws_need)
     st = {'losses': {}, 'ocnt': sb.obj_count, 'tcnt': sb.triple_count}
     static = sb.tensors()
     dp = self.world_size > 1 or self.reducer.force
