@@ -26,7 +26,7 @@ extern "C" {
 #define SG2IM_ERR_ARG 1   /* invalid argument (the reference would raise / assert) */
 #define SG2IM_ERR_HIP 2   /* a HIP runtime call failed; see hipGetLastError() */
 
-int sg2im_abi_version(void);   /* 9 */
+int sg2im_abi_version(void);   /* 10 */
 
 /* Statistics: kernels this library has launched (or recorded into a stream capture) so far in this process;
  * which = 0: all of them, 1: the implicit-GEMM family incl. its split-K finishes.  bench.py reads it around the
@@ -90,6 +90,11 @@ typedef struct sg2im_conv_desc {
                              * all-zero feature channel (crn.py:105) - 161 channels, not a multiple of 4, which
                              * would push the layer onto the scalar loaders; the zero channel contributes nothing
                              * forward and has an exactly zero weight gradient, so it is simply left out. */
+  const void* weight_bf16;  /* optional (ABI 10): a bfloat16 copy of `weight` - same layout, element i = RNE(weight[i]),
+                             * readable 16 bytes past its last element - e.g. made by sg2im_cast_f32_to_bf16 once per
+                             * optimiser step.  With compute_dtype 1 the halo'd 3x3 kernels (forward, backward_data) then
+                             * load their weight slices from it: half the bytes of the stream that bounds them, no
+                             * conversion in the loader, bit-identical results.  NULL: the loaders round `weight`. */
 } sg2im_conv_desc;
 #define SG2IM_HINT_BACKGROUND 1
 
@@ -500,6 +505,10 @@ int sg2im_bn_act_backward(const float* g, long long ld_g, int pool2, int batch, 
 int sg2im_affine_act_forward(const float* x, long long ld_x, long long rows, int channels, const float* scale,
                              const float* shift, float slope, float* out, long long ld_out,
                              hipStream_t stream);
+/* dst[i] = bfloat16(src[i]) (round to nearest even), i < n; both pointers 16-byte aligned.  Makes the weight mirror of
+ * sg2im_conv_desc.weight_bf16 from the fp32 master weights (sg2im_amd.optim.FlatParams.refresh_mirror: one launch over
+ * the generator's parameter arena per iteration; the reference keeps fp32 weights only, scripts/train.py:418-423). */
+int sg2im_cast_f32_to_bf16(const float* src, void* dst, long long n, hipStream_t stream);
 /* InstanceNorm2d(channels) as get_normalization_2d(.., 'instance') builds it (sg2im/layers.py:27-28:
  * affine=False, no running statistics, eps 1e-5) on a dense NHWC tensor x[batch][hw][channels]:
  *   stats:    scale[n][c] = 1/sqrt(var_hw(x) + eps) (biased variance), shift[n][c] = -mean_hw(x) * scale

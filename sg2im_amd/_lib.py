@@ -25,7 +25,8 @@ class Src(Structure):
 class ConvDesc(Structure):
   _fields_ = [('src', Src * 4), ('nsrc', c_int), ('batch', c_int), ('in_h', c_int), ('in_w', c_int),
               ('out_h', c_int), ('out_w', c_int), ('kh', c_int), ('kw', c_int), ('stride', c_int),
-              ('pad', c_int), ('compute_dtype', c_int), ('launch_hints', c_int), ('weight_channels', c_int)]
+              ('pad', c_int), ('compute_dtype', c_int), ('launch_hints', c_int), ('weight_channels', c_int),
+              ('weight_bf16', c_void_p)]
 
 
 class BnFwd(Structure):
@@ -166,6 +167,7 @@ _SIGNATURES = {
   'sg2im_adam_step_guarded': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P, _P],
   'sg2im_adam_prepare_guarded': [_F, _F, _F, _P, _P, _P],
   'sg2im_adam_apply_guarded': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P],
+  'sg2im_cast_f32_to_bf16': [_P, _P, _L, _P],
   'sg2im_two_heads_supported': [_I, _I, _I],
   'sg2im_two_heads_forward': [_P, _L, _I, _I, _P, _P, _I, _P, _P, _I, _P, _L, _P, _L, _P],
   'sg2im_two_heads_backward_data': [_P, _L, _P, _L, _I, _I, _P, _I, _P, _I, _P, _L, _P],

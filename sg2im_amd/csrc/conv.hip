@@ -1709,12 +1709,38 @@ static bool halo_plan(int NB, int H, int W, int ncols, int nchunks, size_t ws_by
   return true;
 }
 
+// A/B knobs of the bf16 halo'd kernels: SG2IM_HALO9 = 1 stages all nine taps of a chunk at once (conv_halo.h T9; default
+// 0: measured slower in the step while the loads are fp32), SG2IM_HALO_WB = 0 ignores the bf16 weight mirror
+static const bool g_halo9 = getenv("SG2IM_HALO9") && atoi(getenv("SG2IM_HALO9")) != 0;
+static const bool g_halo_wb = !(getenv("SG2IM_HALO_WB") && atoi(getenv("SG2IM_HALO_WB")) == 0);
+template <int RT, int CT, int BN, bool DG, bool ST, bool H, bool T9, bool WB> bool g_halo_ready = false;
+template <int RT, int CT, int BN, bool DG, bool ST, bool H, bool T9, bool WB>
+static hipError_t prepare_halo() {
+  constexpr size_t lds = halo_lds<RT, CT, BN, DG, H, T9>();
+  if (g_halo_ready<RT, CT, BN, DG, ST, H, T9, WB>) return hipSuccess;
+  const hipError_t e = ensure_lds(conv_halo_kernel<RT, CT, BN, DG, ST, H, T9, WB>, lds);
+  if (e == hipSuccess) g_halo_ready<RT, CT, BN, DG, ST, H, T9, WB> = true;
+  return e;
+}
+template <int RT, int CT, int BN, bool DG, bool ST, bool H, bool T9, bool WB>
+static hipError_t launch_halo_v(HaloParams& p, const HaloPlan& pl, hipStream_t st) {
+  constexpr size_t lds = halo_lds<RT, CT, BN, DG, H, T9>();
+  dim3 grid((p.N + BN - 1) / BN, pl.patches, pl.nsplit);
+  // (sg2im_init prepares every form that needs > 64 KB of LDS up front; lazily here only for a caller that skipped it)
+  if (lds > 64 * 1024 && !g_halo_ready<RT, CT, BN, DG, ST, H, T9, WB> &&
+      prepare_halo<RT, CT, BN, DG, ST, H, T9, WB>() != hipSuccess) return hipErrorInvalidValue;
+  SG2IM_LAUNCH((conv_halo_kernel<RT, CT, BN, DG, ST, H, T9, WB>), grid, dim3(NTHREADS), lds, st, p);
+  return hipGetLastError();
+}
 template <int RT, int CT, int BN, bool DG, bool ST, bool H>
 static hipError_t launch_halo_t(HaloParams& p, const HaloPlan& pl, hipStream_t st) {
-  constexpr size_t lds = halo_lds<RT, CT, BN, DG, H>();
-  dim3 grid((p.N + BN - 1) / BN, pl.patches, pl.nsplit);
-  SG2IM_LAUNCH((conv_halo_kernel<RT, CT, BN, DG, ST, H>), grid, dim3(NTHREADS), lds, st, p);
-  return hipGetLastError();
+  if constexpr (H) {
+    const bool wb = g_halo_wb && p.Wh != nullptr;
+    if (g_halo9) return wb ? launch_halo_v<RT, CT, BN, DG, ST, true, true, true>(p, pl, st)
+                           : launch_halo_v<RT, CT, BN, DG, ST, true, true, false>(p, pl, st);
+    if (wb) return launch_halo_v<RT, CT, BN, DG, ST, true, false, true>(p, pl, st);
+  }
+  return launch_halo_v<RT, CT, BN, DG, ST, H, false, false>(p, pl, st);
 }
 // hb: bf16 operands (sg2im_conv_desc.compute_dtype 1)
 template <bool DG, bool ST>
@@ -1762,6 +1788,15 @@ int sg2im_init(void) {
 #undef SG2IM_PREP
   if (e == hipSuccess) e = ensure_lds(conv_wgrad_group_kernel, wgrad_lds<64, 64>());
   if (e == hipSuccess) e = prepare_wgrad_halo();
+#define SG2IM_PREP_HALO9(RT_, CT_) \
+  SG2IM_PREP9((prepare_halo<RT_, CT_, 64, false, false, true, true, false>())); SG2IM_PREP9((prepare_halo<RT_, CT_, 64, false, true, true, true, false>())); \
+  SG2IM_PREP9((prepare_halo<RT_, CT_, 64, true, false, true, true, false>())); SG2IM_PREP9((prepare_halo<RT_, CT_, 64, true, true, true, true, false>())); \
+  SG2IM_PREP9((prepare_halo<RT_, CT_, 64, false, false, true, true, true>())); SG2IM_PREP9((prepare_halo<RT_, CT_, 64, false, true, true, true, true>())); \
+  SG2IM_PREP9((prepare_halo<RT_, CT_, 64, true, false, true, true, true>())); SG2IM_PREP9((prepare_halo<RT_, CT_, 64, true, true, true, true, true>()))
+#define SG2IM_PREP9(call) do { if (e == hipSuccess) e = (call); } while (0)
+  SG2IM_PREP_HALO9(2, 64); SG2IM_PREP_HALO9(4, 32); SG2IM_PREP_HALO9(8, 16);
+#undef SG2IM_PREP9
+#undef SG2IM_PREP_HALO9
   if (e == hipSuccess) e = gcn::prepare();          // the persistent GraphTripleConv-stack kernels (gcn_persist.hip)
   if (e != hipSuccess) return SG2IM_ERR_HIP;
   SG2IM_LAUNCH(init_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)0, (int*)nullptr);
@@ -1808,7 +1843,7 @@ static int conv_forward_impl(const sg2im_conv_desc* d, const float* weight, int 
   if (v4 && !any_gather(p.g) && !accumulate && halo_geometry(d) && p.g.Wtap % 4 == 0 &&
       halo_plan(d->batch, d->in_h, d->in_w, cout, p.nch, workspace_bytes, workspace != nullptr, &hp)) {
     HaloParams q;
-    q.g = p.g; q.Wt = weight; q.N = cout; q.c_begin = 0; q.nchunks = p.nch;
+    q.g = p.g; q.Wt = weight; q.Wh = (const bf16_t*)d->weight_bf16; q.N = cout; q.c_begin = 0; q.nchunks = p.nch;
     q.tiles_x = d->in_w / hp.ct; q.tiles_y = d->in_h / hp.rt; q.M = p.M;
     q.e = Epi{out, ld_out, bias, out_slope, 0, workspace, hp.nsplit};
     q.st = StatSink{};
@@ -1966,7 +2001,7 @@ static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int co
   if (va4 && vb4 && !accumulate && halo_geometry(d) && g.Wtap % 4 == 0 &&
       halo_plan(d->batch, d->in_h, d->in_w, c_count, (cout + BK - 1) / BK, workspace_bytes, workspace != nullptr, &hp)) {
     HaloParams q;
-    q.g = g; q.Wt = weight; q.N = c_count; q.c_begin = c_begin; q.nchunks = (cout + BK - 1) / BK;
+    q.g = g; q.Wt = weight; q.Wh = (const bf16_t*)d->weight_bf16; q.N = c_count; q.c_begin = c_begin; q.nchunks = (cout + BK - 1) / BK;
     q.tiles_x = d->in_w / hp.ct; q.tiles_y = d->in_h / hp.rt; q.M = (int)Mfull;
     q.e = Epi{dx, ld_dx, nullptr, 1.f, 0, workspace, hp.nsplit};
     if (am) { q.e.mask = am->act; q.e.ld_mask = am->ld; q.e.mask_slope = am->slope; }     // (epilogue, or the split-K finish)

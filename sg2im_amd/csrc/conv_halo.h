@@ -28,9 +28,17 @@
 
 namespace sg2im {
 
+// compile-time loop over the nine taps: f(TapC<0>{}), ..., f(TapC<8>{}) - the tap / register-slot index of the nine-tap
+// staging is a constant in every use, so the per-tap register arrays never become indexable memory
+template <int T> struct TapC { static constexpr int v = T; };
+template <typename F> __device__ __forceinline__ void for_taps9(F f) {
+  f(TapC<0>{}); f(TapC<1>{}); f(TapC<2>{}); f(TapC<3>{}); f(TapC<4>{}); f(TapC<5>{}); f(TapC<6>{}); f(TapC<7>{}); f(TapC<8>{});
+}
+
 struct HaloParams {
   ConvGeom g;           // forward: the conv's sources; data gradient: s0 = dY (C = Cout, ld = ld_dy)
   const float* Wt;
+  const bf16_t* Wh;     // optional bf16 mirror of Wt, same layout (sg2im_conv_desc.weight_bf16; the WB kernels read it)
   int N;                // output columns: forward Cout, data gradient c_count
   int c_begin;          // data gradient: first input channel of the produced range
   int nchunks;          // 32-channel chunks of the reduction (forward: over all sources; dgrad: ceil(Cout / 32))
@@ -58,11 +66,23 @@ struct ChunkCursor {
 // as their 35-47 KB of LDS allow)
 // H: bf16 operand path (igemm.h): both LDS images hold bf16 (halo [pixel][32 + 8], weights [BN][32 + 8] resp.
 // k-major [32][BN + 32] read with the transposing ds_read_b64_tr_b16), v_mfma_f32_32x32x16_bf16, fp32 accumulate
-template <int RT, int CT, int BN, bool DG, bool ST, bool H = false>
+// T9 (bf16 only, round 6): the weight slices of ALL NINE taps of a 32-channel chunk are staged at once (9 tap images,
+// 46 / 55 KB): one barrier pair and one batch of 24 global loads per thread per CHUNK - 36 MFMAs per wave between two
+// barriers instead of 4.  The per-tap form of the bf16 path was bound by the latency of the two weight loads it had
+// in flight per tap (4 MFMAs = 128 matrix cycles to cover an L2 round trip) and by 18 barriers per chunk.  Same
+// order of accumulation (chunk, tap, K step): bit-identical results.  ~61-70 KB of LDS: two workgroups per CU.
+// WB (bf16 only, round 6): the weight slices come from a bf16 MIRROR of the weight tensor (HaloParams::Wh, refreshed
+// once per step from the fp32 master weights): one 16-byte load of 8 elements per thread and tap that goes to LDS as it
+// is, instead of two fp32 loads + conversions.  The weights are 3/4 of the bytes a 64-column workgroup pulls through
+// L2 (73.7 of 97 KB per chunk), and at bf16 matrix rates that stream - ~11 TB/s over the chip - is what bounds these
+// kernels.  Same values (RNE either way): bit-identical results.
+template <int RT, int CT, int BN, bool DG, bool ST, bool H = false, bool T9 = false, bool WB = false>
 // (the fp32 4 x 32 data-gradient form - 7 halo float4 per thread, maps that 8 x 16 patches do not tile - needs 130
 // registers: three waves per SIMD instead of a spilled offset that is reloaded every chunk)
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((BN == 64 && CT <= 32) ? ((RT == 4 && DG && !H) ? 3 : SG2IM_HALO_WAVES64) : 2)))
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(T9 ? 2 : (BN == 64 && CT <= 32) ? ((RT == 4 && DG && !H) ? 3 : SG2IM_HALO_WAVES64) : 2)))
 void conv_halo_kernel(const HaloParams p) {
+  static_assert(!T9 || H, "the nine-tap staging exists for the bf16 operand path only");
+  static_assert(!WB || (H && BN == 64), "the weight mirror is bf16: bf16 operand path, 64-column tiles");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BM = RT * CT;
   static_assert(BM == 128, "a patch is 128 output pixels");
@@ -175,7 +195,15 @@ void conv_halo_kernel(const HaloParams p) {
   };
 
   // ---- B loader: the weight tile of one (chunk, tap) ----
-  float4 rb[NVB];
+  constexpr int NT = T9 ? 9 : 1;                              // tap images staged at once
+  constexpr int TAPH = DG ? BK * (BN + KPADH) : BN * MLDH;    // bf16 elements of one tap image
+  float4 rb[WB ? 1 : NT][NVB];
+  f32x4v rbw[WB ? NT : 1];                                    // (WB: one 16-byte piece per tap; a VECTOR type - a float4
+                                                              // struct copied memory-to-memory keeps the array in scratch)
+  // WB: thread -> one 16-byte piece (8 bf16) of the tap image.  forward: row = tid >> 2 (output channel), piece =
+  // tid & 3 (8 channels of the chunk); data gradient: k row = tid >> 3 (output channel of the chunk), piece = tid & 7
+  // (8 input channels)
+  const int hrow = DG ? tid >> 3 : tid >> 2, hpc = DG ? tid & 7 : tid & 3;
   // forward: m-major rows = output channels n0 + r0 + 32 i, k = channels of the chunk
   unsigned wrow[NVB];
   #pragma unroll
@@ -188,7 +216,29 @@ void conv_halo_kernel(const HaloParams p) {
   const int bcol4 = tid % QB, bk0 = tid / QB;
   const int nn = n0 + 4 * bcol4;
   const bool nok4 = nn < p.N;
-  auto load_B = [&](const ChunkCursor& c, int tap) {
+  // slot: the register set / tap image the slice goes to (T9: = tap; per-tap form: 0)
+  auto load_B = [&](const ChunkCursor& c, int tap, auto slotc) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slotc)::v;
+    if constexpr (WB) {
+      unsigned off;       // bf16 element offset into the mirror
+      bool ok;
+      if (!DG) {
+        const int ch = c.cb + 8 * hpc, n = n0 + hrow;
+        ok = ch < c.S.C && n < p.N;
+        off = (unsigned)n * (unsigned)ldw + (unsigned)(tap * g.Wtap + c.cstart + ch);
+      } else {
+        const int co = c.cb + hrow, n8 = n0 + 8 * hpc;
+        ok = co < Cout && n8 < p.N;
+        off = (unsigned)co * (unsigned)ldw + (unsigned)(tap * g.Wtap + p.c_begin + n8);
+      }
+      // (16 bytes at a 2-byte-element offset: ld4_off takes float-element offsets - half of it, the base cast)
+      unsigned byte_off = ok ? off << 1 : 0u;
+      asm volatile("" : "+v"(byte_off));
+      rbw[slot] = *reinterpret_cast<const f32x4v*>(reinterpret_cast<const char*>(p.Wh) + (size_t)byte_off);
+      // (no select on a masked-off piece: it read element 0 - finite - and meets zeros of the A operand, or lands in a
+      // column that is never stored, like the fp32 loader's)
+      return;
+    } else
     if (!DG) {
       const int ch = c.cb + 4 * col4;
       const bool cok = ch < c.S.C;
@@ -196,7 +246,7 @@ void conv_halo_kernel(const HaloParams p) {
       #pragma unroll
       for (int i = 0; i < NVB; ++i) {
         const bool ok = cok && (n0 + r0 + 32 * i) < p.N;
-        rb[i] = ld4_off(p.Wt, ok ? wrow[i] + wcol : 0u);      // (no select: see conv_fwd_kernel)
+        rb[slot][i] = ld4_off(p.Wt, ok ? wrow[i] + wcol : 0u);      // (no select: see conv_fwd_kernel)
       }
     } else {
       const unsigned wcol = (unsigned)(tap * g.Wtap + p.c_begin + nn);
@@ -204,17 +254,21 @@ void conv_halo_kernel(const HaloParams p) {
       for (int i = 0; i < NVB; ++i) {
         const int co = c.cb + bk0 + (1024 / BN) * i;
         const bool ok = nok4 && co < Cout;
-        rb[i] = ld4_off(p.Wt, ok ? (unsigned)co * (unsigned)ldw + wcol : 0u);
+        rb[slot][i] = ld4_off(p.Wt, ok ? (unsigned)co * (unsigned)ldw + wcol : 0u);
       }
     }
   };
-  auto stage_B = [&]() {
-    if constexpr (H) {
-      if (!DG) store_tile_h<BN, false>(Bsh, rb, tid);
-      else store_tile_h<BN, true>(Bsh, rb, tid);
+  auto stage_B = [&](auto slotc) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slotc)::v;
+    if constexpr (WB) {
+      bf16_t* const dst = Bsh + slot * TAPH + (DG ? hrow * (BN + KPADH) : hrow * MLDH) + 8 * hpc;
+      *reinterpret_cast<f32x4v*>(dst) = rbw[slot];
+    } else if constexpr (H) {
+      if (!DG) store_tile_h<BN, false>(Bsh + slot * TAPH, rb[slot], tid);
+      else store_tile_h<BN, true>(Bsh + slot * TAPH, rb[slot], tid);
     } else {
-      if (!DG) store_tile<BN, false>(Bs, rb, tid);
-      else store_tile<BN, true>(Bs, rb, tid);
+      if (!DG) store_tile<BN, false>(Bs, rb[slot], tid);
+      else store_tile<BN, true>(Bs, rb[slot], tid);
     }
   };
 
@@ -236,8 +290,10 @@ void conv_halo_kernel(const HaloParams p) {
     #pragma unroll
     for (int b_ = 0; b_ < TN; ++b_) zero_acc(acc[a_][b_]);
 
-  auto mma_tap = [&](int tapoff) {
+  auto mma_tap = [&](int tapoff, auto slotc) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slotc)::v;
     if constexpr (H) {
+      const bf16_t* const Bt = Bsh + slot * TAPH;
       #pragma unroll
       for (int stp = 0; stp < 2; ++stp) {
         #pragma unroll
@@ -245,8 +301,8 @@ void conv_halo_kernel(const HaloParams p) {
           fh.a[tm][stp] = *reinterpret_cast<const bf16x8*>(Ash + (apix[tm] + tapoff) * MLDH + 16 * stp + 8 * lh);
         #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
-          if (!DG) fh.b[tn][stp] = *reinterpret_cast<const bf16x8*>(Bsh + (wn0 + tn * 32 + li) * MLDH + 16 * stp + 8 * lh);
-          else fh.b[tn][stp] = read_tr<BN>(Bsh, wn0 + tn * 32, stp, lane);
+          if (!DG) fh.b[tn][stp] = *reinterpret_cast<const bf16x8*>(Bt + (wn0 + tn * 32 + li) * MLDH + 16 * stp + 8 * lh);
+          else fh.b[tn][stp] = read_tr<BN>(Bt, wn0 + tn * 32, stp, lane);
         }
       }
       mma_frags_h<BM, BN>(fh, acc);
@@ -279,12 +335,39 @@ void conv_halo_kernel(const HaloParams p) {
   };
 
   // ---- main loop: chunks outer, the nine taps unrolled ----
-  if (c_lo < c_hi) {
+  if constexpr (T9) {
+    if (c_lo < c_hi) {
+      ChunkCursor cu = nx;
+      load_A(cu);
+      for_taps9([&](auto t) __attribute__((always_inline)) { load_B(cu, decltype(t)::v, t); });
+      stage_A();
+      for_taps9([&](auto t) __attribute__((always_inline)) { stage_B(t); });
+      __syncthreads();
+      #pragma unroll 1
+      for (int ch = c_lo; ch < c_hi; ++ch) {
+        const bool more = ch + 1 < c_hi;
+        nx = cu;
+        if (more) advance(nx);
+        load_A(nx);
+        for_taps9([&](auto t) __attribute__((always_inline)) { load_B(nx, decltype(t)::v, t); });
+        __builtin_amdgcn_sched_barrier(0);
+        for_taps9([&](auto t) __attribute__((always_inline)) {
+          constexpr int tap = decltype(t)::v, kh = tap / 3, kw = tap - 3 * kh;
+          mma_tap(DG ? (2 - kh) * HWD + (2 - kw) : kh * HWD + kw, t);
+        });
+        __syncthreads();
+        stage_A();
+        for_taps9([&](auto t) __attribute__((always_inline)) { stage_B(t); });
+        __syncthreads();
+        cu = nx;
+      }
+    }
+  } else if (c_lo < c_hi) {
     ChunkCursor cu = nx;
     load_A(cu);
-    load_B(cu, 0);
+    load_B(cu, 0, TapC<0>{});
     stage_A();
-    stage_B();
+    stage_B(TapC<0>{});
     __syncthreads();
     #pragma unroll 1
     for (int ch = c_lo; ch < c_hi; ++ch) {
@@ -296,12 +379,12 @@ void conv_halo_kernel(const HaloParams p) {
       #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int kh = tap / 3, kw = tap - 3 * kh;
-        if (tap < 8) load_B(cu, tap + 1); else load_B(nx, 0);
+        if (tap < 8) load_B(cu, tap + 1, TapC<0>{}); else load_B(nx, 0, TapC<0>{});
         // keep the global loads ahead of the MFMA block (see k_pipeline)
         __builtin_amdgcn_sched_barrier(0);
-        mma_tap(DG ? (2 - kh) * HWD + (2 - kw) : kh * HWD + kw);
+        mma_tap(DG ? (2 - kh) * HWD + (2 - kw) : kh * HWD + kw, TapC<0>{});
         __syncthreads();
-        stage_B();
+        stage_B(TapC<0>{});
         if (tap == 8) stage_A();
         __syncthreads();
       }
@@ -328,8 +411,8 @@ void conv_halo_kernel(const HaloParams p) {
   }
 }
 
-template <int RT, int CT, int BN, bool DG, bool H = false> constexpr size_t halo_lds() {
-  return H ? ((size_t)(RT + 2) * (CT + 2) * MLDH + (DG ? (size_t)BK * (BN + KPADH) : (size_t)BN * MLDH)) * 2
+template <int RT, int CT, int BN, bool DG, bool H = false, bool T9 = false> constexpr size_t halo_lds() {     // (WB: as its H form)
+  return H ? ((size_t)(RT + 2) * (CT + 2) * MLDH + (T9 ? 9 : 1) * (DG ? (size_t)BK * (BN + KPADH) : (size_t)BN * MLDH)) * 2
            : ((size_t)(RT + 2) * (CT + 2) * MLD + (DG ? (size_t)BK * (BN + KPAD) : (size_t)BN * MLD)) * sizeof(float);
 }
 

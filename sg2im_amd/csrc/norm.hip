@@ -879,6 +879,20 @@ int bn_bwd_standalone(const float* g, long long ld_g, int pool2, int batch, int 
   return ok_or(hipGetLastError());
 }
 
+
+// fp32 -> bfloat16 (RNE), 8 elements per thread: the weight mirror of sg2im_conv_desc.weight_bf16
+typedef __bf16 cast_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float cast_f32x8 __attribute__((ext_vector_type(8)));
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long long n8, long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+    const cast_f32x8 f = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    reinterpret_cast<cast_bf16x8*>(dst)[i] = __builtin_convertvector(f, cast_bf16x8);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - 8 * n8)) dst[8 * n8 + threadIdx.x] = (__bf16)src[8 * n8 + threadIdx.x];
+}
+
 }  // namespace sg2im
 
 using namespace sg2im;
@@ -979,6 +993,14 @@ int sg2im_affine_act_forward(const float* x, long long ld_x, long long rows, int
   else
     SG2IM_LAUNCH(affine_act_kernel, dim3(ew_blocks(rows * channels)), dim3(256), 0, stream, x, ld_x, rows, channels,
                        scale, shift, slope, out, ld_out);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_cast_f32_to_bf16(const float* src, void* dst, long long n, hipStream_t stream) {
+  if (!src || !dst || n < 0 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return SG2IM_ERR_ARG;
+  if (n == 0) return SG2IM_OK;
+  SG2IM_LAUNCH(cast_f32_bf16_kernel, dim3(ew_blocks(std::max<long long>(1, n / 8))), dim3(256), 0, stream, src, (__bf16*)dst,
+                     n / 8, n);
   return ok_or(hipGetLastError());
 }
 

@@ -61,6 +61,24 @@ def _sink(param):
   return view
 
 
+def _weight_mirror(w):
+  """device address of the bfloat16 mirror of conv weight ``w`` (FlatParams.refresh_mirror), or None: only while the
+  Trainer has refreshed it for this iteration (ops.WEIGHT_MIRROR) and ``w`` lives in an arena that has one"""
+  if not ops.WEIGHT_MIRROR or w is None:
+    return None
+  ref = GRAD_SINKS.get(w.data_ptr())
+  owner = ref() if ref is not None else None
+  if owner is None or owner.mirror is None:
+    return None
+  off = (w.data_ptr() - owner.flat.data_ptr()) // 4
+  if off < 0 or off + w.numel() > owner.numel:
+    return None
+  return owner.mirror.data_ptr() + 2 * off
+
+
+ops.WEIGHT_MIRROR_LOOKUP = _weight_mirror
+
+
 def _cl_grad(dw_phys):
   """[Cout][KH][KW][Cin] gradient -> (Cout,Cin,KH,KW)-shaped channels_last tensor"""
   return dw_phys.permute(0, 3, 1, 2)

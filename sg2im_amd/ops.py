@@ -302,11 +302,14 @@ def rows_src(t, gather=None):
 # matrix cores, 1 = bf16 operands with fp32 accumulation (sg2im_conv_desc.compute_dtype).  Linear
 # layers (row matrices) always compute in fp32.  Set by Trainer(compute_dtype='bf16') around its step.
 CONV_COMPUTE = 0
+# set by Trainer.step (bf16 mode) after FlatParams.refresh_mirror: convolutions may read bf16 weight mirrors
+WEIGHT_MIRROR = False
 
 
-def conv_desc(srcs, batch, in_h, in_w, kh=1, kw=1, stride=1, pad=0, compute=None, weight_channels=0):
+def conv_desc(srcs, batch, in_h, in_w, kh=1, kw=1, stride=1, pad=0, compute=None, weight_channels=0, weight_bf16=None):
   d = ConvDesc()
   d.weight_channels = int(weight_channels)     # (weight rows wider than the sources: include/sg2im_hip.h)
+  d.weight_bf16 = weight_bf16                  # (device address of the weights' bf16 mirror, or None)
   if compute is None:
     compute = CONV_COMPUTE if (kh * kw > 1 or in_h * in_w > 1) else 0
   d.compute_dtype = int(compute)
@@ -397,7 +400,17 @@ def _note_bytes(kind, nfloats):
     TIMER.alg_bytes[kind] = TIMER.alg_bytes.get(kind, 0.0) + 4.0 * nfloats
 
 
+WEIGHT_MIRROR_LOOKUP = None      # functional._weight_mirror (set at import): weight tensor -> mirror address | None
+
+
+def _set_mirror(desc, weight):
+  """the bf16 mirror of `weight` for the launches that can use it (bf16 operands, 3x3: the halo'd kernels)"""
+  desc.weight_bf16 = (WEIGHT_MIRROR_LOOKUP(weight) if (WEIGHT_MIRROR and desc.compute_dtype == 1 and desc.kh == 3 and
+                                                       WEIGHT_MIRROR_LOOKUP is not None) else None)
+
+
 def conv2d_forward(desc, weight, cout, bias, out, ld_out, out_slope=1.0, accumulate=False):
+  _set_mirror(desc, weight)
   ws = workspace(out.device)
   flops = 2.0 * desc.batch * desc.out_h * desc.out_w * cout * _desc_k(desc)
   _note_bytes('igemm_fwd', _desc_src_floats(desc) + cout * _desc_k(desc) + desc.batch * desc.out_h * desc.out_w * cout)
@@ -408,6 +421,7 @@ def conv2d_forward(desc, weight, cout, bias, out, ld_out, out_slope=1.0, accumul
 
 
 def conv2d_backward_data(desc, weight, cout, dy, ld_dy, c_begin, c_count, dx, ld_dx, accumulate=False):
+  _set_mirror(desc, weight)
   ws = workspace(dx.device)
   flops = 2.0 * desc.batch * desc.out_h * desc.out_w * cout * desc.kh * desc.kw * c_count
   _note_bytes('igemm_dgrad', desc.batch * desc.out_h * desc.out_w * cout + cout * desc.kh * desc.kw * c_count +
@@ -429,6 +443,7 @@ def conv2d_backward_data_act(desc, weight, cout, dy, ld_dy, c_begin, c_count, dx
     conv2d_backward_data(desc, weight, cout, dy, ld_dy, c_begin, c_count, dx, ld_dx)
     rows = dx.numel() // c_count
     return act_backward(c_void_p(dx.data_ptr()), ld_dx, 0, rows, 1, 1, act, ld_act, c_count, slope, dx)
+  _set_mirror(desc, weight)
   ws = workspace(dx.device)
   flops = 2.0 * desc.batch * desc.out_h * desc.out_w * cout * desc.kh * desc.kw * c_count
   _note_bytes('igemm_dgrad', desc.batch * desc.out_h * desc.out_w * cout + cout * desc.kh * desc.kw * c_count +
@@ -477,6 +492,15 @@ def conv2d_backward_weight_group(items, accumulate=True):
   if not _lib.CAPTURING:
     _lib.EAGER_EPOCH += 1
   return True
+
+
+def cast_f32_to_bf16(src, dst, n):
+  """dst[:n] = bfloat16(src[:n]) (sg2im_cast_f32_to_bf16)"""
+  if not (src.is_cuda and src.dtype == torch.float32 and dst.is_cuda and dst.dtype == torch.bfloat16 and
+          src.is_contiguous() and dst.is_contiguous() and src.numel() >= n and dst.numel() >= n):
+    raise TypeError('cast_f32_to_bf16: contiguous float32 source / bfloat16 destination on the GPU')
+  call('sg2im_cast_f32_to_bf16', c_void_p(src.data_ptr()), c_void_p(dst.data_ptr()), int(n), _stream())
+  return dst
 
 
 def column_sum(x_ptr, rows, cols, ld, out, accumulate=False):
@@ -900,6 +924,7 @@ def conv2d_forward_bn(desc, weight, cout, bias, out, ld_out, bn, training, eps=1
                       unbiased_rows=0, count=None):
   """conv2d_forward followed by bn_stats of its output, with the statistics' reductions riding in the
   convolution's own launches (sg2im_conv2d_forward_bn).  Returns the BnState."""
+  _set_mirror(desc, weight)
   ws = workspace(out.device)
   st = BnState(cout, out.device)
   M = desc.batch * desc.out_h * desc.out_w
@@ -928,6 +953,7 @@ def conv2d_backward_data_bn(desc, weight, cout, dy, ld_dy, c_begin, c_count, dx,
   """conv2d_backward_data whose result dx is the gradient w.r.t. the ACTIVATED output of a BatchNorm'd layer
   (pre-norm output y, statistics st), together with that BatchNorm's backward reductions
   (sg2im_conv2d_backward_data_bn).  Returns the coefficient tensor for bn_backward_apply."""
+  _set_mirror(desc, weight)
   ws = workspace(dx.device)
   rows_dx = desc.batch * desc.in_h * desc.in_w
   nfl = max(2 * c_count * ((rows_dx + 63) // 64), 2 * c_count * min((rows_dx + 7) // 8, 2048), 2 * c_count * 1024)

@@ -43,6 +43,19 @@ class FlatParams(object):
         self.sinks[view.data_ptr()] = self._sink_view(p, off)
         HF.GRAD_SINKS[view.data_ptr()] = me
     self.numel = total
+    self.mirror = None               # bfloat16 copy of `flat` (refresh_mirror), same element offsets
+
+  def refresh_mirror(self):
+    """bfloat16 mirror of the parameter arena (sg2im_conv_desc.weight_bf16): ONE launch over the arena, on the current
+    stream.  The Trainer calls it at the start of every bf16 iteration (inside the captured graph), so the mirror always
+    holds RNE(current fp32 weights) whoever changed them - Adam, a checkpoint restore, a broadcast, a test writing into
+    the parameters; functional._weight_mirror only hands it out while ops.WEIGHT_MIRROR is set (Trainer.step)."""
+    if self.mirror is None:
+      if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError('the weight mirror must be allocated before the capture (Trainer._prepare_lanes)')
+      self.mirror = torch.zeros(self.numel + 16, dtype=torch.bfloat16, device=self.flat.device)    # (+16: the loaders read whole 16-byte pieces)
+    ops.cast_f32_to_bf16(self.flat, self.mirror, self.numel)
+    return self.mirror
 
   def close(self):
     """forget the gradient sinks (also done when the object is collected)"""

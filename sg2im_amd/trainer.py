@@ -151,6 +151,9 @@ class Trainer(object):
     if compute_dtype not in ('f32', 'bf16'):
       raise ValueError('compute_dtype must be "f32" or "bf16"')
     self.compute_dtype = compute_dtype
+    # bf16 mode: the generator's 3x3 convolutions read their weights from a bfloat16 mirror of the parameter arena,
+    # refreshed by ONE launch at the start of every iteration (FlatParams.refresh_mirror; SG2IM_WEIGHT_MIRROR=0: A/B knob)
+    self.weight_mirror = compute_dtype == 'bf16' and os.environ.get('SG2IM_WEIGHT_MIRROR', '1') != '0'
     self.device = device
     self.world_size = world_size
     self.rank = rank
@@ -314,6 +317,8 @@ class Trainer(object):
     """train.py:524-530: the generator itself; `imgs_fake` is all the discriminator steps need"""
     imgs, objs, boxes, masks, triples, obj_to_img = batch[:6]
     ops.mark('start')
+    if self.weight_mirror:
+      self.flat_g.refresh_mirror()
     st['imgs_nhwc'] = HF.NchwToNhwc.apply(imgs)
     # captured iteration: whatever is not on the path to the image leaves the critical path (Sg2ImModel.forward_nhwc)
     aux = self._side[0] if (self._side is not None and torch.cuda.is_current_stream_capturing() and
@@ -510,6 +515,7 @@ class Trainer(object):
     Returns a dict of 0-dim device tensors (no host sync)."""
     self.t += 1
     keep, ops.CONV_COMPUTE = ops.CONV_COMPUTE, (1 if self.compute_dtype == 'bf16' else 0)
+    keep_mirror, ops.WEIGHT_MIRROR = ops.WEIGHT_MIRROR, self.weight_mirror
     keep_bwd = ops.GCN_PERSISTENT_BACKWARD
     if ops.GCN_PERSISTENT_BACKWARD_MODE == 'auto':
       ops.GCN_PERSISTENT_BACKWARD = self._gcn_backward_mode(batch)
@@ -517,6 +523,7 @@ class Trainer(object):
       out = self._step(batch)
     finally:
       ops.CONV_COMPUTE = keep
+      ops.WEIGHT_MIRROR = keep_mirror
       ops.GCN_PERSISTENT_BACKWARD = keep_bwd
     self._maybe_check_replicas()
     return out
@@ -597,6 +604,8 @@ class Trainer(object):
       early = [(a, b) for a, b, _ in self._generator_buckets()]
       for a, b in early + complement(early, self.flat_g.numel):
         self.reducer.staging(self.flat_g.grad[a:b])
+    if self.weight_mirror and self.flat_g.mirror is None:
+      self.flat_g.refresh_mirror()   # (allocates the mirror outside the capture)
     ops.unit(dev)                    # (cached process-wide: must not be born inside a capture)
     ops.marks_init(dev)
 

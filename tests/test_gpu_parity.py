@@ -137,6 +137,45 @@ def test_bf16_operand_conv_kernels_every_tile_shape(plan):
   assert tail and ' 0 above' in tail[-1], out.stdout[-4000:]
 
 
+@pytest.mark.parametrize('N,H,W,C0,C1,Cout', [(4, 32, 32, 64, 0, 96), (3, 12, 32, 80, 48, 48), (2, 6, 64, 64, 64, 64),
+                                              (16, 16, 16, 32, 0, 256), (2, 64, 64, 160, 128, 64), (2, 16, 16, 36, 0, 44)])
+def test_bf16_weight_mirror_is_bit_identical(N, H, W, C0, C1, Cout):
+  """sg2im_conv_desc.weight_bf16 (ABI 10): the halo'd 3x3 kernels of the bf16 operand path reading their weight slices
+  from a bfloat16 mirror (sg2im_cast_f32_to_bf16 of the fp32 weights) produce the SAME bits as the loaders that round
+  the fp32 weights themselves - forward (with the BatchNorm-statistics epilogue and without) and data gradient, every
+  patch form, two sources with an upsampled one, ragged channel chunks (36 -> 44: partial 8-element pieces), split-K."""
+  from sg2im_amd import ops
+  D = torch.device('cuda', 0)
+  g = torch.Generator().manual_seed(N * 1000 + H + Cout)
+  Cin = C0 + C1
+  x0 = torch.randn(N, H, W, C0, generator=g).to(D)
+  srcs = [ops.nhwc_src(x0)]
+  if C1:
+    x1 = torch.randn(N, H // 2, W // 2, C1, generator=g).to(D)
+    sc, sh = (torch.rand(C1, generator=g) + 0.5).to(D), torch.randn(C1, generator=g).to(D)
+    srcs.append(ops.nhwc_src(x1, 1, sc, sh, 0.2))
+  Wp = (torch.randn(Cout, 3, 3, Cin, generator=g) / (9 * Cin) ** 0.5).to(D)
+  b = torch.randn(Cout, generator=g).to(D)
+  mirror = torch.zeros(Wp.numel() + 16, dtype=torch.bfloat16, device=D)
+  ops.cast_f32_to_bf16(Wp.reshape(-1), mirror, Wp.numel())
+  assert torch.equal(mirror[:Wp.numel()], Wp.reshape(-1).to(torch.bfloat16))       # RNE, as torch rounds
+  dy = torch.randn(N, H, W, Cout, generator=g).to(D)
+  keep = ops.WEIGHT_MIRROR, ops.WEIGHT_MIRROR_LOOKUP
+  res = []
+  try:
+    for use in (False, True):
+      ops.WEIGHT_MIRROR, ops.WEIGHT_MIRROR_LOOKUP = use, (lambda w: mirror.data_ptr())
+      d = ops.conv_desc(srcs, N, H, W, 3, 3, 1, 1, compute=1)
+      out = ops.conv2d_forward(d, Wp, Cout, b, torch.empty(N, H, W, Cout, device=D), Cout, 0.2)
+      assert (d.weight_bf16 is not None) == use
+      dx = ops.conv2d_backward_data(d, Wp, Cout, dy, Cout, 0, C0, torch.empty(N, H, W, C0, device=D), C0)
+      res.append((out.clone(), dx.clone()))
+  finally:
+    ops.WEIGHT_MIRROR, ops.WEIGHT_MIRROR_LOOKUP = keep
+  assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+  assert float(res[0][0].abs().max()) > 0.1 and float(res[0][1].abs().max()) > 0.01
+
+
 def test_layout_and_crops():
   _run('sec_layout')
 
