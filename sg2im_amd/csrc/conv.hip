@@ -1709,38 +1709,41 @@ static bool halo_plan(int NB, int H, int W, int ncols, int nchunks, size_t ws_by
   return true;
 }
 
-// A/B knobs of the bf16 halo'd kernels: SG2IM_HALO9 = 1 stages all nine taps of a chunk at once (conv_halo.h T9; default
-// 0: measured slower in the step while the loads are fp32), SG2IM_HALO_WB = 0 ignores the bf16 weight mirror
+// A/B knobs of the bf16 halo'd kernels: SG2IM_HALO_TG = taps per staging group of the weight-mirror kernels (1, 3, 9:
+// conv_halo.h; default 3), SG2IM_HALO9 = 1 the nine-tap form also without a mirror, SG2IM_HALO_WB = 0 ignores the mirror
 static const bool g_halo9 = getenv("SG2IM_HALO9") && atoi(getenv("SG2IM_HALO9")) != 0;
 static const bool g_halo_wb = !(getenv("SG2IM_HALO_WB") && atoi(getenv("SG2IM_HALO_WB")) == 0);
-template <int RT, int CT, int BN, bool DG, bool ST, bool H, bool T9, bool WB> bool g_halo_ready = false;
-template <int RT, int CT, int BN, bool DG, bool ST, bool H, bool T9, bool WB>
+static const int g_halo_tg = getenv("SG2IM_HALO_TG") ? atoi(getenv("SG2IM_HALO_TG")) : 3;
+template <int RT, int CT, int BN, bool DG, bool ST, bool H, int TG, bool WB> bool g_halo_ready = false;
+template <int RT, int CT, int BN, bool DG, bool ST, bool H, int TG, bool WB>
 static hipError_t prepare_halo() {
-  constexpr size_t lds = halo_lds<RT, CT, BN, DG, H, T9>();
-  if (g_halo_ready<RT, CT, BN, DG, ST, H, T9, WB>) return hipSuccess;
-  const hipError_t e = ensure_lds(conv_halo_kernel<RT, CT, BN, DG, ST, H, T9, WB>, lds);
-  if (e == hipSuccess) g_halo_ready<RT, CT, BN, DG, ST, H, T9, WB> = true;
+  constexpr size_t lds = halo_lds<RT, CT, BN, DG, H, TG>();
+  if (g_halo_ready<RT, CT, BN, DG, ST, H, TG, WB>) return hipSuccess;
+  const hipError_t e = ensure_lds(conv_halo_kernel<RT, CT, BN, DG, ST, H, TG, WB>, lds);
+  if (e == hipSuccess) g_halo_ready<RT, CT, BN, DG, ST, H, TG, WB> = true;
   return e;
 }
-template <int RT, int CT, int BN, bool DG, bool ST, bool H, bool T9, bool WB>
+template <int RT, int CT, int BN, bool DG, bool ST, bool H, int TG, bool WB>
 static hipError_t launch_halo_v(HaloParams& p, const HaloPlan& pl, hipStream_t st) {
-  constexpr size_t lds = halo_lds<RT, CT, BN, DG, H, T9>();
+  constexpr size_t lds = halo_lds<RT, CT, BN, DG, H, TG>();
   dim3 grid((p.N + BN - 1) / BN, pl.patches, pl.nsplit);
   // (sg2im_init prepares every form that needs > 64 KB of LDS up front; lazily here only for a caller that skipped it)
-  if (lds > 64 * 1024 && !g_halo_ready<RT, CT, BN, DG, ST, H, T9, WB> &&
-      prepare_halo<RT, CT, BN, DG, ST, H, T9, WB>() != hipSuccess) return hipErrorInvalidValue;
-  SG2IM_LAUNCH((conv_halo_kernel<RT, CT, BN, DG, ST, H, T9, WB>), grid, dim3(NTHREADS), lds, st, p);
+  if (lds > 64 * 1024 && !g_halo_ready<RT, CT, BN, DG, ST, H, TG, WB> &&
+      prepare_halo<RT, CT, BN, DG, ST, H, TG, WB>() != hipSuccess) return hipErrorInvalidValue;
+  SG2IM_LAUNCH((conv_halo_kernel<RT, CT, BN, DG, ST, H, TG, WB>), grid, dim3(NTHREADS), lds, st, p);
   return hipGetLastError();
 }
 template <int RT, int CT, int BN, bool DG, bool ST, bool H>
 static hipError_t launch_halo_t(HaloParams& p, const HaloPlan& pl, hipStream_t st) {
   if constexpr (H) {
-    const bool wb = g_halo_wb && p.Wh != nullptr;
-    if (g_halo9) return wb ? launch_halo_v<RT, CT, BN, DG, ST, true, true, true>(p, pl, st)
-                           : launch_halo_v<RT, CT, BN, DG, ST, true, true, false>(p, pl, st);
-    if (wb) return launch_halo_v<RT, CT, BN, DG, ST, true, false, true>(p, pl, st);
+    if (g_halo_wb && p.Wh != nullptr) {
+      if (g_halo_tg == 9 || g_halo9) return launch_halo_v<RT, CT, BN, DG, ST, true, 9, true>(p, pl, st);
+      if (g_halo_tg == 3) return launch_halo_v<RT, CT, BN, DG, ST, true, 3, true>(p, pl, st);
+      return launch_halo_v<RT, CT, BN, DG, ST, true, 1, true>(p, pl, st);
+    }
+    if (g_halo9) return launch_halo_v<RT, CT, BN, DG, ST, true, 9, false>(p, pl, st);
   }
-  return launch_halo_v<RT, CT, BN, DG, ST, H, false, false>(p, pl, st);
+  return launch_halo_v<RT, CT, BN, DG, ST, H, 1, false>(p, pl, st);
 }
 // hb: bf16 operands (sg2im_conv_desc.compute_dtype 1)
 template <bool DG, bool ST>
@@ -1789,10 +1792,10 @@ int sg2im_init(void) {
   if (e == hipSuccess) e = ensure_lds(conv_wgrad_group_kernel, wgrad_lds<64, 64>());
   if (e == hipSuccess) e = prepare_wgrad_halo();
 #define SG2IM_PREP_HALO9(RT_, CT_) \
-  SG2IM_PREP9((prepare_halo<RT_, CT_, 64, false, false, true, true, false>())); SG2IM_PREP9((prepare_halo<RT_, CT_, 64, false, true, true, true, false>())); \
-  SG2IM_PREP9((prepare_halo<RT_, CT_, 64, true, false, true, true, false>())); SG2IM_PREP9((prepare_halo<RT_, CT_, 64, true, true, true, true, false>())); \
-  SG2IM_PREP9((prepare_halo<RT_, CT_, 64, false, false, true, true, true>())); SG2IM_PREP9((prepare_halo<RT_, CT_, 64, false, true, true, true, true>())); \
-  SG2IM_PREP9((prepare_halo<RT_, CT_, 64, true, false, true, true, true>())); SG2IM_PREP9((prepare_halo<RT_, CT_, 64, true, true, true, true, true>()))
+  SG2IM_PREP9((prepare_halo<RT_, CT_, 64, false, false, true, 9, false>())); SG2IM_PREP9((prepare_halo<RT_, CT_, 64, false, true, true, 9, false>())); \
+  SG2IM_PREP9((prepare_halo<RT_, CT_, 64, true, false, true, 9, false>())); SG2IM_PREP9((prepare_halo<RT_, CT_, 64, true, true, true, 9, false>())); \
+  SG2IM_PREP9((prepare_halo<RT_, CT_, 64, false, false, true, 9, true>())); SG2IM_PREP9((prepare_halo<RT_, CT_, 64, false, true, true, 9, true>())); \
+  SG2IM_PREP9((prepare_halo<RT_, CT_, 64, true, false, true, 9, true>())); SG2IM_PREP9((prepare_halo<RT_, CT_, 64, true, true, true, 9, true>()))
 #define SG2IM_PREP9(call) do { if (e == hipSuccess) e = (call); } while (0)
   SG2IM_PREP_HALO9(2, 64); SG2IM_PREP_HALO9(4, 32); SG2IM_PREP_HALO9(8, 16);
 #undef SG2IM_PREP9

@@ -21,6 +21,7 @@
 // offset is an immediate of the fragment reads.
 #pragma once
 #include "igemm.h"
+#include <utility>
 
 #ifndef SG2IM_HALO_WAVES64
 #define SG2IM_HALO_WAVES64 4
@@ -31,9 +32,8 @@ namespace sg2im {
 // compile-time loop over the nine taps: f(TapC<0>{}), ..., f(TapC<8>{}) - the tap / register-slot index of the nine-tap
 // staging is a constant in every use, so the per-tap register arrays never become indexable memory
 template <int T> struct TapC { static constexpr int v = T; };
-template <typename F> __device__ __forceinline__ void for_taps9(F f) {
-  f(TapC<0>{}); f(TapC<1>{}); f(TapC<2>{}); f(TapC<3>{}); f(TapC<4>{}); f(TapC<5>{}); f(TapC<6>{}); f(TapC<7>{}); f(TapC<8>{});
-}
+template <typename F, int... I> __device__ __forceinline__ void for_seq(F f, std::integer_sequence<int, I...>) { (f(TapC<I>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void for_n(F f) { for_seq(f, std::make_integer_sequence<int, N>{}); }
 
 struct HaloParams {
   ConvGeom g;           // forward: the conv's sources; data gradient: s0 = dY (C = Cout, ld = ld_dy)
@@ -76,12 +76,14 @@ struct ChunkCursor {
 // is, instead of two fp32 loads + conversions.  The weights are 3/4 of the bytes a 64-column workgroup pulls through
 // L2 (73.7 of 97 KB per chunk), and at bf16 matrix rates that stream - ~11 TB/s over the chip - is what bounds these
 // kernels.  Same values (RNE either way): bit-identical results.
-template <int RT, int CT, int BN, bool DG, bool ST, bool H = false, bool T9 = false, bool WB = false>
+// TG = taps per staging group: 1 (rounds 3-5: a barrier pair per tap), 3 (one kernel row: 12 MFMAs per wave between
+// barriers, three weight pieces in flight per thread, ~30 KB of LDS: four workgroups per CU) or 9 (T9 above).
+template <int RT, int CT, int BN, bool DG, bool ST, bool H = false, int TG = 1, bool WB = false>
 // (the fp32 4 x 32 data-gradient form - 7 halo float4 per thread, maps that 8 x 16 patches do not tile - needs 130
 // registers: three waves per SIMD instead of a spilled offset that is reloaded every chunk)
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(T9 ? 2 : (BN == 64 && CT <= 32) ? ((RT == 4 && DG && !H) ? 3 : SG2IM_HALO_WAVES64) : 2)))
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(TG == 9 ? 2 : (BN == 64 && CT <= 32) ? ((RT == 4 && DG && !H) ? 3 : SG2IM_HALO_WAVES64) : 2)))
 void conv_halo_kernel(const HaloParams p) {
-  static_assert(!T9 || H, "the nine-tap staging exists for the bf16 operand path only");
+  static_assert(TG == 1 || (H && (TG == 3 || TG == 9)), "multi-tap staging exists for the bf16 operand path only");
   static_assert(!WB || (H && BN == 64), "the weight mirror is bf16: bf16 operand path, 64-column tiles");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BM = RT * CT;
@@ -195,7 +197,7 @@ void conv_halo_kernel(const HaloParams p) {
   };
 
   // ---- B loader: the weight tile of one (chunk, tap) ----
-  constexpr int NT = T9 ? 9 : 1;                              // tap images staged at once
+  constexpr int NT = TG;                                      // tap images staged at once
   constexpr int TAPH = DG ? BK * (BN + KPADH) : BN * MLDH;    // bf16 elements of one tap image
   float4 rb[WB ? 1 : NT][NVB];
   f32x4v rbw[WB ? NT : 1];                                    // (WB: one 16-byte piece per tap; a VECTOR type - a float4
@@ -335,13 +337,14 @@ void conv_halo_kernel(const HaloParams p) {
   };
 
   // ---- main loop: chunks outer, the nine taps unrolled ----
-  if constexpr (T9) {
+  if constexpr (TG > 1) {
+    constexpr int G = 9 / TG;                                   // staging groups per chunk
     if (c_lo < c_hi) {
       ChunkCursor cu = nx;
       load_A(cu);
-      for_taps9([&](auto t) __attribute__((always_inline)) { load_B(cu, decltype(t)::v, t); });
+      for_n<TG>([&](auto t) __attribute__((always_inline)) { load_B(cu, decltype(t)::v, t); });
       stage_A();
-      for_taps9([&](auto t) __attribute__((always_inline)) { stage_B(t); });
+      for_n<TG>([&](auto t) __attribute__((always_inline)) { stage_B(t); });
       __syncthreads();
       #pragma unroll 1
       for (int ch = c_lo; ch < c_hi; ++ch) {
@@ -349,16 +352,22 @@ void conv_halo_kernel(const HaloParams p) {
         nx = cu;
         if (more) advance(nx);
         load_A(nx);
-        for_taps9([&](auto t) __attribute__((always_inline)) { load_B(nx, decltype(t)::v, t); });
-        __builtin_amdgcn_sched_barrier(0);
-        for_taps9([&](auto t) __attribute__((always_inline)) {
-          constexpr int tap = decltype(t)::v, kh = tap / 3, kw = tap - 3 * kh;
-          mma_tap(DG ? (2 - kh) * HWD + (2 - kw) : kh * HWD + kw, t);
+        for_n<G>([&](auto gc) __attribute__((always_inline)) {
+          constexpr int gi = decltype(gc)::v;
+          // the weights of the next group (the first of the next chunk behind the last) are in flight during the MFMAs
+          for_n<TG>([&](auto t) __attribute__((always_inline)) {
+            if constexpr (gi + 1 < G) load_B(cu, (gi + 1) * TG + decltype(t)::v, t); else load_B(nx, decltype(t)::v, t);
+          });
+          __builtin_amdgcn_sched_barrier(0);
+          for_n<TG>([&](auto t) __attribute__((always_inline)) {
+            constexpr int tap = gi * TG + decltype(t)::v, kh = tap / 3, kw = tap - 3 * kh;
+            mma_tap(DG ? (2 - kh) * HWD + (2 - kw) : kh * HWD + kw, t);
+          });
+          __syncthreads();
+          if constexpr (gi == G - 1) stage_A();
+          for_n<TG>([&](auto t) __attribute__((always_inline)) { stage_B(t); });
+          __syncthreads();
         });
-        __syncthreads();
-        stage_A();
-        for_taps9([&](auto t) __attribute__((always_inline)) { stage_B(t); });
-        __syncthreads();
         cu = nx;
       }
     }
@@ -411,8 +420,8 @@ void conv_halo_kernel(const HaloParams p) {
   }
 }
 
-template <int RT, int CT, int BN, bool DG, bool H = false, bool T9 = false> constexpr size_t halo_lds() {     // (WB: as its H form)
-  return H ? ((size_t)(RT + 2) * (CT + 2) * MLDH + (T9 ? 9 : 1) * (DG ? (size_t)BK * (BN + KPADH) : (size_t)BN * MLDH)) * 2
+template <int RT, int CT, int BN, bool DG, bool H = false, int TG = 1> constexpr size_t halo_lds() {     // (WB: as its H form)
+  return H ? ((size_t)(RT + 2) * (CT + 2) * MLDH + TG * (DG ? (size_t)BK * (BN + KPADH) : (size_t)BN * MLDH)) * 2
            : ((size_t)(RT + 2) * (CT + 2) * MLD + (DG ? (size_t)BK * (BN + KPAD) : (size_t)BN * MLD)) * sizeof(float);
 }
 
