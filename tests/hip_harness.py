@@ -197,19 +197,22 @@ def grad_parity_rows3(tr, o32, o64, scale=1.0):
   return rows
 
 
-def check_grad_rows(rows, rel=None, cos_min=None, vector_bound=None, cos_from_reference=False):
+def check_grad_rows(rows, rel=None, cos_min=None, vector_bound=None, cos_from_reference=False, strict=False, noise_factor=3.0):
   """-> (bad rows, summary dict).  rel None: the reference-arithmetic bound described above; a number: that
   bound on e_hip64 for every tensor (bf16) - with ``vector_bound`` = (rel, cos) a separate, looser pair for the
   one-dimensional parameters (biases, BatchNorm gamma / beta: sums of cancelling terms over a whole feature map),
   so that ``rel`` / ``cos_min`` can hold the matrices / filters / embedding tables to a bound that says something
   about magnitude.  Analytically-zero tensors (|g_f64| < 1e-6 everywhere: the bias of
   a convolution feeding a batch-statistics BatchNorm, parameters without a gradient) must be below 1e-6
-  absolute on the HIP side."""
+  absolute on the HIP side.  strict: the fixed bound ``rel`` holds for EVERY tensor with a gradient, however few elements
+  it has, and no flipped-decision escape (the tight form for steps without normalisation layers, VERDICT r5 item 5: with
+  rel None the bound is max(1e-4, noise_factor x E_ref) - noise_factor 1: the kernels must be AT LEAST as close to the exact
+  gradient as the reference's own fp32 arithmetic is)."""
   bad, summ = [], {}
   E_all = max([r[3] for r in rows if r[5] >= GRAD_ABS_ZERO] or [0.0])
-  flip_ok = rel is None
+  flip_ok = rel is None and not strict
   if rel is None:
-    rel, cos_min = max(GRAD_REL, 3.0 * E_all), (GRAD_COS if cos_min is None else cos_min)
+    rel, cos_min = max(GRAD_REL, noise_factor * E_all), (GRAD_COS if cos_min is None else cos_min)
     if cos_from_reference:
       # The cosine bound from the reference arithmetic too (the bf16-operand emulation: its fp32 run is itself only
       # cos ~0.995 from its float64 run at small batches - rounding to bfloat16 turns fp32 noise into 0.4 % operand
@@ -230,7 +233,7 @@ def check_grad_rows(rows, rel=None, cos_min=None, vector_bound=None, cos_from_re
         if r[2] * max(r[5], 1e-30) > GRAD_ABS_ZERO and r[4] * max(r[5], 1e-30) > GRAD_ABS_ZERO:
           bad.append(r)
         continue
-      if r[7] < 16 and not flip_ok:
+      if r[7] < 16 and not flip_ok and not strict:
         # (fixed-bound mode, i.e. bf16: a scalar / few-element gradient - the bias of mask_net's 1-channel output
         # conv - is one sum of cancelling terms: its relative error is unbounded and its cosine says nothing;
         # it is held to 1 % of the largest gradient magnitude of its network instead)
@@ -239,7 +242,10 @@ def check_grad_rows(rows, rel=None, cos_min=None, vector_bound=None, cos_from_re
           bad.append(r)
         continue
       r_rel, r_cos = (vector_bound if (vector_bound is not None and r[8] <= 1) else (rel, cos_min))
-      if (r[2] > r_rel or (r_cos is not None and r[6] < r_cos)) and not (flip_ok and r[6] >= 0.9999 and r[2] <= 0.1):
+      # strict: a tensor behind a LeakyReLU whose pre-activation changed sign under the forward pass' 1e-6 differences
+    # may exceed the bound - by at most 1e-3, and only with a cosine of six nines
+    if (r[2] > r_rel or (r_cos is not None and r[6] < r_cos)) and not (flip_ok and r[6] >= 0.9999 and r[2] <= 0.1) and \
+       not (strict and r[6] >= 0.999999 and r[2] <= 1e-3):
         bad.append(r)
     if live:
       w = max(live, key=lambda r: r[2])
@@ -251,13 +257,14 @@ def check_grad_rows(rows, rel=None, cos_min=None, vector_bound=None, cos_from_re
   return bad, summ
 
 
-def assert_grad_parity(tr, refs, label, rel=None, cos_min=None, scale=1.0, vector_bound=None, cos_from_reference=False):
+def assert_grad_parity(tr, refs, label, rel=None, cos_min=None, scale=1.0, vector_bound=None, cos_from_reference=False,
+                       strict=False, noise_factor=3.0):
   """every parameter gradient of G / D_obj / D_img against the float64 oracle under the bound above (``rel`` /
   ``cos_min``: fixed bounds instead, for bf16).  Appends the measured worst cases to
   gpurun_out/grad_parity.log and returns (worst e_hip64, worst cosine)."""
   import os
   rows = grad_parity_rows3(tr, refs.o32, refs.o64, scale)
-  bad, summ = check_grad_rows(rows, rel, cos_min, vector_bound, cos_from_reference)
+  bad, summ = check_grad_rows(rows, rel, cos_min, vector_bound, cos_from_reference, strict, noise_factor)
   line = '%-40s' % label + '  '.join(
     '%s: e_hip64 %.2e (%s) E_ref %.2e e_hip32 %.2e cos %.6f' % ((n,) + summ[n]) for n in ('G', 'Do', 'Di') if n in summ)
   if vector_bound is not None:

@@ -800,6 +800,79 @@ def test_step_is_bit_reproducible():
       assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('mode', ['eager', 'graph_padded', 'graph_replay_second_batch', 'two_passes'])
+def test_well_conditioned_step_holds_every_gradient_to_1e4(mode):
+  """`normalization='none'` in the generator and both discriminators (no batch statistics) at batch 8,
+  the full G + D_obj + D_img iteration eager, as a bucket-padded hipGraph, on the REPLAY of that graph with a second
+  (differently shaped) batch, and with the discriminators' passes over the generated images computed twice instead of
+  shared (functional.SharedPass off).  Two bounds:
+  (1) every gradient of every network, however small the tensor: e <= max(1e-4, E_ref) against the float64 oracle (at least
+      as close as the reference's own fp32 arithmetic - no 3x factor, no flipped-decision escape) and cosine >= 0.999999;
+  (2) the kernels themselves to 1e-5: what is left in (1) is a LeakyReLU whose pre-activation changes sign when its input
+      moves by 1e-6 (measured: D_img's first convolution 3e-4 from the float64 step, 1e-7 from the float64 D_img step
+      EVALUATED ON THE HIP IMAGE) - so the image discriminator's gradients are also compared with exactly that: the float64
+      oracle's D_img step on the image the HIP generator produced, bound 1e-5 of the tensor's max."""
+  from oracle import sg2im_oracle as orc
+  from sg2im_amd import trainer as trainer_mod
+  from sg2im_amd.synthetic import make_vocab, synthetic_batch
+  from sg2im_amd.trainer import Trainer, GENERATOR_DEFAULTS, D_OBJ_DEFAULTS, D_IMG_DEFAULTS
+  from tests import hip_harness as hh
+  dev = hh.dev()
+  vocab = make_vocab(184, 7)
+  bs = 8
+  gk, dk = dict(normalization='none'), dict(normalization='none')
+  gcfg = dict(GENERATOR_DEFAULTS, vocab=vocab, **gk)
+  docfg, dicfg = dict(D_OBJ_DEFAULTS, vocab=vocab, **dk), dict(D_IMG_DEFAULTS, **dk)
+  PG = orc.init_generator_params(gcfg, 21)
+  PDo = orc.init_ac_discriminator_params(docfg, 22)
+  PDi = orc.init_patch_discriminator_params(dicfg, 23)
+  graphs = mode.startswith('graph')
+  keep = trainer_mod.SHARE_FAKE_PASS
+  trainer_mod.SHARE_FAKE_PASS = mode != 'two_passes'
+  try:
+    tr = Trainer(vocab, dev, seed=0, generator_kwargs=gk, d_obj_kwargs=dk, d_img_kwargs=dk, use_graphs=graphs,
+                 bucket=(32, 64) if graphs else 'auto')
+    hh.load_params(tr.model, PG); hh.load_params(tr.d_obj, PDo); hh.load_params(tr.d_img, PDi)
+    seen, model_seg = {}, tr._seg_generator_model
+
+    def keep_fake(b, st):             # (the generated image of the compared step: a tensor the graph keeps writing into)
+      model_seg(b, st)
+      seen['fake'] = st['imgs_fake']
+    tr._seg_generator_model = keep_fake
+    cpu_batch = synthetic_batch(bs, seed=61)
+    noise = torch.randn(bs, 32, 64, 64, generator=torch.Generator().manual_seed(62))
+    otr = hh.OracleRefs(PG, PDo, PDi, gcfg, docfg, dicfg)
+    batch = tuple(t.to(dev) if torch.is_tensor(t) else t for t in cpu_batch)
+    other = synthetic_batch(bs, seed=63)       # (same (64, 128) bucket, other object / triple counts)
+    assert (other[1].numel(), other[4].size(0)) != (cpu_batch[1].numel(), cpu_batch[4].size(0))
+    with hh.fixed_noise(noise):        # (ONE context: a captured graph keeps reading the noise tensor staged here)
+      if mode == 'graph_replay_second_batch':
+        # capture on another batch of the same bucket, restore the weights, then REPLAY on the batch that is compared
+        tr.step(tuple(t.to(dev) if torch.is_tensor(t) else t for t in other))
+        hh.load_params(tr.model, PG); hh.load_params(tr.d_obj, PDo); hh.load_params(tr.d_img, PDi)
+        for o in (tr.opt_g, tr.opt_do, tr.opt_di):
+          o.reset_state()
+      got = Trainer.losses_to_host(tr.step(batch))
+    if mode == 'graph_replay_second_batch':
+      assert tr.graph_stats['captures'] == 1 and tr.graph_stats['replays'] == 2, (tr.graph_stats, list(tr._graphs))
+  finally:
+    trainer_mod.SHARE_FAKE_PASS = keep
+  want = otr.step(tuple(cpu_batch[:6]), noise)
+  for k, v in want.items():
+    assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (mode, k, got[k], v)
+  hh.assert_grad_parity(tr, otr, 'fp32 no-normalization b8 ' + mode, cos_min=0.999999, strict=True, noise_factor=1.0)
+  # (2) the float64 D_img step on the HIP image
+  fake = seen['fake'].detach().permute(0, 3, 1, 2).cpu().double()
+  P = hh.oracle_leafs({k: v.double() if v.is_floating_point() else v for k, v in PDi.items()})
+  sr, sf = orc.patch_discriminator(P, dicfg, cpu_batch[0].double()), orc.patch_discriminator(P, dicfg, fake)
+  (orc.bce_loss(sr, torch.ones_like(sr)) + orc.bce_loss(sf, torch.zeros_like(sf))).backward()
+  for k, p in tr.d_img.named_parameters():
+    if P[k].grad is not None:
+      den = float(P[k].grad.abs().max())
+      e = float((p.grad.cpu().double() - P[k].grad).abs().max()) / den
+      assert e <= 1e-5, (mode, k, e)
+
+
 @pytest.mark.parametrize('case', ['vg64', 'vg64_batch32', 'vg128_deeper_crn', 'stretch256', 'vg64_no_normalization',
                                   'vg128_batch16', 'stretch256_batch4'])
 def test_other_baseline_shapes_match_oracle(case):
