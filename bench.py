@@ -45,7 +45,8 @@ def parse():
   ap.add_argument('--warmup', type=int, default=10)
   ap.add_argument('--batch_size', type=int, default=32, help='images per GPU (reference default, train.py:51)')
   ap.add_argument('--image_size', type=int, default=64)
-  ap.add_argument('--cpu_baseline_steps', type=int, default=2, help='timed steps per thread count; 0 disables the CPU-oracle leg')
+  ap.add_argument('--cpu_baseline_steps', type=int, default=5,
+                  help='timed steps of the CPU-oracle leg at the best thread count of its sweep; 0 disables the leg')
   ap.add_argument('--no_roofline', action='store_true')
   ap.add_argument('--no_graphs', action='store_true', help='launch every kernel eagerly instead of hipGraph replay')
   ap.add_argument('--seed', type=int, default=0)
@@ -69,8 +70,9 @@ def parse():
   ap.add_argument('--force_dist', action='store_true',
                   help='debug: 1-rank RCCL group with real all-reduces (exercises the N>1 code path on one GPU)')
   ap.add_argument('--dp_schedule', type=int, default=None, choices=[0, 1, 2],
-                  help='data-parallel graph schedule (sg2im_amd/trainer.py): default 0 at N > 1 (iteration graph -> exposed '
-                       'all-reduces -> Adam graph), 2 = RCCL all-reduces recorded inside the iteration graph (default with --force_dist)')
+                  help='data-parallel graph schedule (sg2im_amd/trainer.py): default 2 = RCCL all-reduces recorded inside the '
+                       'iteration graph when the subprocess capture probe passes on every rank (else 1); 0 = iteration graph -> '
+                       'exposed all-reduces -> Adam graph; 1 = graph segments with the exchanges between them')
   ap.add_argument('--launcher_selftest', action='store_true',
                   help='CPU-only check of the --gpus N self-launcher: every rank joins a gloo group, all-reduces its rank, '
                        'rank 0 prints one JSON line (tests/test_bench_launcher.py)')
@@ -146,23 +148,27 @@ def cpu_baseline(vocab, batch, steps):
   cpu_batch = tuple(batch[:6])
   counts = sorted(set(min(c, cores) for c in (8, 16, 32, 64, 128, cores) if c >= 1))
   sweep, budget_t0 = {}, time.time()
-  for n in counts:
+  for n in counts:                      # sweep: one warm-up + one timed step per thread count
     torch.set_num_threads(n)
     tr.step(cpu_batch)                  # warm-up at this thread count (MKL-DNN primitive caches, thread pool)
     t0 = time.time()
-    for _ in range(steps):
-      tr.step(cpu_batch)
-    sweep[n] = (time.time() - t0) / steps
-    if time.time() - budget_t0 > 90:    # (bounded: the whole leg stays within ~2 minutes)
+    tr.step(cpu_batch)
+    sweep[n] = time.time() - t0
+    if time.time() - budget_t0 > 60:    # (bounded: the whole leg stays within ~2 minutes)
       break
   best = min(sweep, key=sweep.get)
-  dt = sweep[best]
+  torch.set_num_threads(best)           # the reported value: `steps` (>= 5 by default) warm steps at the best setting
+  tr.step(cpu_batch)
+  t0 = time.time()
+  for _ in range(steps):
+    tr.step(cpu_batch)
+  dt = (time.time() - t0) / steps
   nimg = cpu_batch[0].size(0)
   return {'value': round(nimg / dt, 2), 'unit': 'images/sec', 'cores': best, 'cpu': cpu_model,
           'kind': 'port', 'physical_cores': cores,
           'thread_sweep_images_per_sec': {str(n): round(nimg / t, 2) for n, t in sweep.items()},
-          'sample': '%d warm G+D steps per thread count of the first batch of the stream (batch %d, O=%d, T=%d); best: '
-                    '%d threads, %.2f s/step' % (steps, nimg, cpu_batch[1].numel(), cpu_batch[4].size(0), best, dt)}
+          'sample': '%d warm G+D steps of the first batch of the stream (batch %d, O=%d, T=%d) at the best thread count of a '
+                    'one-step-per-setting sweep: %d threads, %.2f s/step' % (steps, nimg, cpu_batch[1].numel(), cpu_batch[4].size(0), best, dt)}
 
 
 def main():

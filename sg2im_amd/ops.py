@@ -358,8 +358,9 @@ TIMER = None     # set to a KernelTimer to time every conv / linear launch
 TIMER_TAG = None # set by a network around its launches (e.g. 'crn') to attribute them
 
 
-def _timed(kind, flops, fn, bn_finish=False):
-  """bn_finish: fn is a *_bn entry point - its BatchNorm finish launch (not a GEMM) is timed as 'hbm_bn_finish'"""
+def _timed(kind, flops, fn, bn_finish=False, finish_bytes=0.0):
+  """bn_finish: fn is a *_bn entry point - its BatchNorm finish launch (not a GEMM) is timed as 'hbm_bn_finish';
+  finish_bytes: what that launch must move - the tile partials read once, the per-channel results written"""
   if TIMER is None:
     return fn()
   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -377,7 +378,7 @@ def _timed(kind, flops, fn, bn_finish=False):
   e1.record()
   if hit.value:
     TIMER.records.append((kind, flops, e0, em, TIMER_TAG))
-    TIMER.records.append(('hbm_bn_finish', 0.0, em, e1, TIMER_TAG))
+    TIMER.records.append(('hbm_bn_finish', float(finish_bytes), em, e1, TIMER_TAG))
   else:
     TIMER.records.append((kind, flops, e0, e1, TIMER_TAG))
 
@@ -944,7 +945,9 @@ def conv2d_forward_bn(desc, weight, cout, bias, out, ld_out, bn, training, eps=1
   _note_bytes('igemm_fwd', _desc_src_floats(desc) + cout * _desc_k(desc) + M * cout)
   _timed('igemm_fwd', flops, lambda: call(
     'sg2im_conv2d_forward_bn', byref(desc), _f(weight), int(cout), _f(bias), float(out_slope), _f(out), int(ld_out),
-    _f(ws), ws.numel() * 4, byref(a), _stream()), bn_finish=True)
+    _f(ws), ws.numel() * 4, byref(a), _stream()), bn_finish=True,
+    # (3 partial planes per 128-row tile and channel read once; mean / invstd / scale / shift + 2 running statistics written)
+    finish_bytes=4.0 * (3 * cout * ((M + 127) // 128) + 6 * cout))
   return st
 
 
@@ -973,7 +976,8 @@ def conv2d_backward_data_bn(desc, weight, cout, dy, ld_dy, c_begin, c_count, dx,
               rows_dx * c_count)
   _timed('igemm_dgrad', flops, lambda: call(
     'sg2im_conv2d_backward_data_bn', byref(desc), _f(weight), int(cout), _f(dy), int(ld_dy), int(c_begin), int(c_count),
-    _f(dx), int(ld_dx), _f(ws), ws.numel() * 4, byref(a), _stream()), bn_finish=True)
+    _f(dx), int(ld_dx), _f(ws), ws.numel() * 4, byref(a), _stream()), bn_finish=True,
+    finish_bytes=4.0 * (2 * c_count * ((rows_dx + 127) // 128) + 5 * c_count))     # (2 planes read; coef[3] + dgamma + dbeta written)
   return coef
 
 

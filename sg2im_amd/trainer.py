@@ -201,14 +201,30 @@ class Trainer(object):
     # data-parallel graph schedule (see _capture): 2 = ONE graph with the all-reduces recorded inside it, bucketed and
     # overlapped; 0 = one iteration graph, exchange, Adam graph; 1 = segmented, the D_obj step replayed while the
     # generator's all-reduce is in flight
-    # Default: 0 for a real multi-rank job - the in-graph exchange (2) has only ever been EXECUTED in a 1-rank RCCL
-    # group (no second GPU on the boxes this was developed on: every check that can be made on one GPU is green -
-    # tests/test_gpu_parity.py::test_in_graph_exchange_* - but a capture that clr or RCCL cannot digest at N > 1
-    # would crash, not fall back).  SG2IM_DP_SCHEDULE=2 / dp_schedule=2 selects it (bench.py --dp_schedule 2);
-    # with the 1-rank group (GradReducer.force) it is the default, so that it keeps being exercised.
+    # Default (round 6): 2 - decided by a probe, not by caution.  Whether THIS stack can capture the schedule-2 stream
+    # pattern with RCCL inside is asked in a subprocess (sg2im_amd/capture_probe.py: the one failure seen so far was a
+    # segfault at the end of a capture, not an error); every rank probes its own device, the verdicts are AND-ed over
+    # the ranks, and a failure selects schedule 1 (graph segments, the exchanges between them: the D_obj step still
+    # hides the generator's all-reduce).  What the probe cannot see - replicas that drift apart - is what
+    # check_replicas watches for (steps 1, 2, 4, ... then every 1024th), falling back to schedule 0.  Projected 8-GPU
+    # efficiencies of the three schedules: DESIGN.md section 6.  SG2IM_DP_SCHEDULE / dp_schedule= pin a schedule.
     if dp_schedule is None:
-      dp_schedule = os.environ.get('SG2IM_DP_SCHEDULE', '2' if world_size <= 1 else '0')
+      dp_schedule = os.environ.get('SG2IM_DP_SCHEDULE', '2')
     self.dp_schedule = int(dp_schedule)
+    if world_size > 1 and use_graphs and self.dp_schedule == 2:
+      from .capture_probe import choose_dp_schedule, probe
+      idx = device.index if device.index is not None else torch.cuda.current_device()
+
+      def agree(ok):
+        import torch.distributed as dist
+        t = torch.tensor([1.0 if ok else 0.0], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+      chosen = choose_dp_schedule(2, self.reducer.capturable(), lambda: probe(idx), agree if self.reducer.capturable() else None)
+      if chosen != 2 and rank == 0:
+        print('[sg2im_amd] dp_schedule 2 (all-reduces inside the iteration graph) is not available here: running schedule %d' % chosen,
+              flush=True)
+      self.dp_schedule = chosen
     # Under dp_schedule 2 the replicas' parameter arenas are compared every now and then (replicas_in_sync: two tiny
     # all-reduces of checksums + a host sync; steps 1, 2, 4, 8 ... 1024, then every 1024th - step counts are the
     # same on every rank, which a "first replay of a new graph" trigger would not be).  If they ever differ - the

@@ -675,6 +675,15 @@ def test_lanes_of_a_trainer_never_share_a_pooled_stream():
   assert len(seen) <= 32              # (the pool did wrap: the situation the test is about)
 
 
+def test_in_graph_capture_probe_passes_on_this_stack():
+  """sg2im_amd/capture_probe.py: a child process captures the schedule-2 stream pattern (origin, side stream, forked
+  lane, a comm stream carrying RCCL all-reduces) in a 1-rank group on this GPU, replays it twice and checks the values
+  - what a data-parallel Trainer asks before it records collectives into its iteration graph"""
+  from sg2im_amd import capture_probe
+  capture_probe._verdict.clear()
+  assert capture_probe.probe(0, timeout=300) is True
+
+
 def test_rccl_path_single_rank():
   """The N > 1 code path on one GPU: a 1-rank RCCL group with the gradient all-reduces really
   issued (GradReducer.force), in the eager form (async launch after each backward, wait before Adam)

@@ -536,3 +536,40 @@ def test_layout_backward_takes_both_halves_from_the_level_gradients_or_materiali
   assert run(vg, True) == [('vecs_levels',), ('maps_levels', True, False), ('pyramid',),
                            ('layout_backward', False, True, False)]
   assert run(vg, False) == [('layout_backward', True, True, False)]
+
+
+def test_dp_schedule_choice_follows_the_capture_probe():
+  """sg2im_amd/capture_probe.py::choose_dp_schedule (Trainer.__init__ at world_size > 1): schedule 2 only when the
+  process group can be captured AND the subprocess probe passed on every rank; a failed probe selects schedule 1, a
+  group that cannot be captured (gloo) schedule 0; pinned schedules 0 / 1 never probe."""
+  from sg2im_amd.capture_probe import choose_dp_schedule
+  calls = []
+
+  def probe_ok():
+    calls.append('ok')
+    return True
+
+  def probe_bad():
+    calls.append('bad')
+    return False
+  assert choose_dp_schedule(2, True, probe_ok) == 2
+  assert choose_dp_schedule(2, True, probe_bad) == 1
+  assert choose_dp_schedule(2, True, probe_ok, agree_fn=lambda ok: False) == 1       # another rank's probe failed
+  assert choose_dp_schedule(2, True, probe_ok, agree_fn=lambda ok: ok) == 2
+  n = len(calls)
+  assert choose_dp_schedule(2, False, probe_bad) == 0 and choose_dp_schedule(0, True, probe_bad) == 0
+  assert choose_dp_schedule(1, True, probe_bad) == 1 and len(calls) == n              # (no probe for those)
+
+
+def test_capture_probe_child_that_dies_is_a_failed_probe_not_a_crash():
+  """the probe runs in a subprocess precisely because the failure it guards against is a segfault: a child that aborts
+  (SG2IM_PROBE_FORCE_FAIL=1, before it touches any GPU) must come back as False"""
+  import os
+  from sg2im_amd import capture_probe
+  capture_probe._verdict.clear()
+  os.environ['SG2IM_PROBE_FORCE_FAIL'] = '1'
+  try:
+    assert capture_probe.probe(0, timeout=120) is False
+  finally:
+    del os.environ['SG2IM_PROBE_FORCE_FAIL']
+    capture_probe._verdict.clear()
