@@ -62,6 +62,10 @@ typedef struct sg2im_src {
   int channels;
   int ld;                   /* floats between consecutive pixels / rows (>= channels) */
   int upsample_log2;        /* 0, or 1 = source is nearest-upsampled x2 on the fly */
+  int dtype;                /* 0: `data` holds float; 1 (ABI 10): bfloat16 STORAGE - `data` points at bfloat16 elements (same
+                             * NHWC layout, `ld` counts elements).  Only the bf16 halo'd 3x3 kernels read it (compute_dtype 1,
+                             * stride 1, pad 1, maps that 128-pixel patches tile, no split-K: sg2im_conv_halo_unsplit);
+                             * every other launch returns SG2IM_ERR_ARG instead of misreading the tensor. */
 } sg2im_src;
 
 typedef struct sg2im_conv_desc {
@@ -90,6 +94,11 @@ typedef struct sg2im_conv_desc {
                              * all-zero feature channel (crn.py:105) - 161 channels, not a multiple of 4, which
                              * would push the layer onto the scalar loaders; the zero channel contributes nothing
                              * forward and has an exactly zero weight gradient, so it is simply left out. */
+  int out_dtype;            /* (ABI 10) 1: the result - `out` of sg2im_conv2d_forward[_bn], `dx` of sg2im_conv2d_backward_data[_bn]
+                             * - is written as bfloat16 (RNE of the fp32 value that the fused BatchNorm reductions still see
+                             * unrounded); `ld_out` / `ld_dx` count elements.  Same launches as sg2im_src.dtype = 1. */
+  int dy_dtype;             /* (ABI 10) 1: `dy` of sg2im_conv2d_backward_data[_bn] / sg2im_conv2d_backward_weight holds
+                             * bfloat16 (the weight gradient: the bf16 halo'd kernel, 3x3 over maps that 4 x 16 patches tile) */
   const void* weight_bf16;  /* optional (ABI 10): a bfloat16 copy of `weight` - same layout, element i = RNE(weight[i]),
                              * readable 16 bytes past its last element - e.g. made by sg2im_cast_f32_to_bf16 once per
                              * optimiser step.  With compute_dtype 1 the halo'd 3x3 kernels (forward, backward_data) then
@@ -193,6 +202,7 @@ typedef struct sg2im_bn_bwd {
   size_t partial_floats;
   const int* count;         /* padded row batch: count[0] * count_unit real rows OF y (NULL: all) */
   int count_unit;
+  int y_dtype;              /* (ABI 10) 1: `y` holds bfloat16 (ld_y in elements); launches as sg2im_src.dtype = 1 */
 } sg2im_bn_bwd;
 /* dx = the data gradient of sg2im_conv2d_backward_data (accumulate = 0) for the channel range [c_begin,
  * c_begin + c_count), which is the gradient w.r.t. the ACTIVATED output z = leaky(scale * y + shift) of a
@@ -207,6 +217,16 @@ int sg2im_conv2d_backward_data_bn(const sg2im_conv_desc* desc, const float* weig
 int sg2im_bn_backward_apply(const float* g, long long ld_g, int pool2, int batch, int h, int w, const float* y,
                             long long ld_y, int channels, const float* scale, const float* shift, float slope,
                             const float* coef, float* dy, const int* count, int count_unit, hipStream_t stream);
+
+/* sg2im_bn_backward_apply with bfloat16 STORAGE of any of g (dz), y, dy (x_dtype 1; ld_* in elements; channels, ld_g, ld_y
+ * multiples of 4, 16-byte aligned): fp32 arithmetic, dy rounded (RNE) when it holds bfloat16; no padded-batch count. */
+int sg2im_bn_backward_apply_ex(const void* g, long long ld_g, int pool2, int batch, int h, int w, const void* y,
+                               long long ld_y, int channels, const float* scale, const float* shift, float slope,
+                               const float* coef, void* dy, int g_dtype, int y_dtype, int dy_dtype, hipStream_t stream);
+/* 1 when the halo'd 3x3 kernels run a (batch, h, w) map with `cols` output columns and `chunks` 32-channel reduction
+ * chunks WITHOUT split-K (the launches that can carry bfloat16 storage keep every CU busy on their own), else 0.  The
+ * host side asks before it chooses the storage type of a layer's tensors (sg2im_amd.functional.RefinementFn). */
+int sg2im_conv_halo_unsplit(int batch, int h, int w, int cols, int chunks);
 
 /* out[n] = sum_m x[m][n] (+ out): bias gradients (autograd of Conv2d/Linear bias) */
 /* partial: scratch float[2 * cols * 1024] */
@@ -293,15 +313,21 @@ int sg2im_gconv_layer_backward(const sg2im_gconv_layer* layer, const float* h1, 
  * activations h1 [T][hidden], new_t [T][2 hidden + dout], pooled [O][hidden], h2 [O][hidden], new_obj [O][dout]
  * (dense, caller-owned; what backward reads).  Requirements (else SG2IM_ERR_ARG - use the per-layer entry points):
  * din, hidden, dout multiples of 32 (sg2im_gconv_stack_supported), 16-byte aligned pointers, mlp_normalization
- * 'none'.  sync: >= sg2im_gconv_stack_sync_bytes() of device memory private to the call (zeroed by the launcher on
- * `stream` - all but ONE word, see below); after completion word 64 is non-zero iff a grid barrier of THIS launch
+ * 'none'.  sync: >= sg2im_gconv_stack_sync_bytes() of device memory private to the call.  THE CALLER ZEROES THE WHOLE AREA
+ * ONCE, when it allocates it (hipMemset; sg2im_amd.ops.sync_area uses torch.zeros); every launch then re-zeroes all
+ * of it but ONE word on `stream` (see below); after completion word 64 is non-zero iff a grid barrier of THIS launch
  * timed out (never on a healthy device with the grid fully resident: every spin is bounded instead of hanging the
  * queue); word 2040 is a STICKY count of timed-out spins over all launches that ever used the area - the launcher's
  * memset leaves it alone, so a caller that only looks every now and then (sg2im_amd.trainer does, wherever it
  * synchronises with the host anyway) cannot miss a launch that produced garbage.  sg2im_gconv_stack_status() of a
  * host copy: 0 = healthy; bit 0 = the last launch timed out, bits 1.. = the sticky count.  Only ONE persistent
  * launch may be in flight per device at a time (two whole-chip resident grids can starve each other's barriers);
- * the Trainer issues the forward on its main lane only and keeps the backward layer-by-layer by default. */
+ * the Trainer issues the forward on its main lane only; its backward is chosen per configuration
+ * (SG2IM_GCN_PERSIST_BWD=auto, sg2im_amd.trainer.Trainer._gcn_backward_mode): the one-launch low_footprint form where
+ * the small-kernel tail ends the step (bf16 operands, VG-style batches / a trained mask_net), layer by layer otherwise.
+ * A barrier that times out (grid not fully resident: another process on the GPU) lets the launch carry on with
+ * incomplete data - its results are garbage; the sticky word is what reports it (sg2im_gconv_stack_status, checked by
+ * the Trainer wherever it synchronises with the host: Trainer.losses_to_host). */
 #define SG2IM_GCONV_MAX_LAYERS 8
 typedef struct sg2im_gconv_stack_layer {
   const float *w1a, *b1a, *w1b, *b1b, *w2a, *b2a, *w2b, *b2b;   /* nn.Linear layout, see sg2im_gconv_layer */

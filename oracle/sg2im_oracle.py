@@ -34,9 +34,76 @@ BN_MOMENTUM = 0.1
 # ----------------------------------------------------------------------------
 OPERAND_ROUND = None
 
+# bfloat16 STORAGE of the refinement network's chain (round 6; only with OPERAND_ROUND = 'bf16'): on the refinement
+# modules whose maps qualify (_storage_level: the shape rule of the library's planner - a map that 128-pixel patches
+# tile and that fills the GPU without split-K) the pre-normalisation convolution outputs y, the gradients w.r.t. the
+# activated outputs and the BatchNorm-backward results are ROUNDED to bfloat16 where the library stores them:
+#   forward   y_s = round(conv + b);  batch statistics from the UNROUNDED values;  a = leaky(scale * y_s + shift)
+#   backward  g = d loss / d a (unrounded accumulators):  dgamma, dbeta and the two sums from du = g * leaky'(.) with
+#             x_hat from y_s;  the stored g_s = round(g);  dy = gamma * invstd * (g_s * leaky'(.) [2x2-summed behind an
+#             upsampling] - mean(du) - x_hat * mean(du * x_hat)),  stored as round(dy)
+# (_BnLeakyStored).  The layout, the output convolutions' z / dz, statistics and parameter gradients stay unrounded.
+STORAGE_ROUND = True
+
 
 def _round_bf16(t):
   return t.to(torch.bfloat16).to(t.dtype)
+
+
+def _storage_level(N, h, w, C):
+  """the planner's rule (csrc/conv.hip halo_plan, 256 CUs): 8 x 16, 4 x 32 or 2 x 64 patches tile the map and the
+  launch has at least 1.5 workgroups per CU without split-K - (N h w / 128) * ceil(min(C, 128) / 64) >= 384"""
+  if not ((w % 16 == 0 and h % 8 == 0) or (w % 32 == 0 and h % 4 == 0) or (w % 64 == 0 and h % 2 == 0)):
+    return False
+  return (N * h * w // 128) * ((min(C, 128) + 63) // 64) >= 384
+
+
+class _BnLeakyStored(torch.autograd.Function):
+  """leaky(BatchNorm2d(y)) [+ nearest upsampling x2] with the bfloat16 storage points of the HIP path (see above)"""
+
+  @staticmethod
+  def forward(ctx, y, gamma, beta, rm, rv, nbt, training, slope, up2):
+    if training:
+      mean = y.mean((0, 2, 3))
+      var = y.var((0, 2, 3), unbiased=False)
+      n = y.numel() // y.size(1)
+      with torch.no_grad():
+        if rm is not None:
+          rm.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * mean)
+          rv.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * var * n / max(n - 1, 1))
+        if nbt is not None:
+          nbt += 1
+    else:
+      mean, var = rm, rv
+    invstd = (var + BN_EPS).rsqrt()
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    ys = _round_bf16(y)
+    u = ys * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    ctx.save_for_backward(ys, gamma, mean, invstd, u)
+    ctx.cfg = (training, slope, up2)
+    a = F.leaky_relu(u, slope)
+    return F.interpolate(a, scale_factor=2, mode='nearest') if up2 else a
+
+  @staticmethod
+  def backward(ctx, g):
+    ys, gamma, mean, invstd, u = ctx.saved_tensors
+    training, slope, up2 = ctx.cfg
+    mask = torch.where(u > 0, torch.ones((), dtype=g.dtype), torch.full((), slope, dtype=g.dtype))
+    xhat = (ys - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+    up = (lambda t: F.interpolate(t, scale_factor=2, mode='nearest')) if up2 else (lambda t: t)
+    du = g * up(mask)
+    s0, s1 = du.sum((0, 2, 3)), (du * up(xhat)).sum((0, 2, 3))
+    dus = _round_bf16(g) * up(mask)                       # from the STORED gradient
+    if up2:
+      dus = F.avg_pool2d(dus, 2) * 4.0
+    M = ys.numel() // ys.size(1)
+    a = (gamma * invstd).view(1, -1, 1, 1)
+    if training:
+      dy = a * (dus - (s0 / M).view(1, -1, 1, 1) - xhat * (s1 / M).view(1, -1, 1, 1))
+    else:
+      dy = a * dus
+    return _round_bf16(dy), s1, s0, None, None, None, None, None, None
 
 
 class _RoundedConv2d(torch.autograd.Function):
@@ -285,8 +352,11 @@ def refinement_network(P, prefix, layout, n_modules, slope, training, normalizat
     w //= 2
   assert h != 0 and w != 0
   feats = torch.zeros(N, 1, h, w).to(layout)
+  pre_upsampled = False              # (_BnLeakyStored hands the features over already upsampled)
   for i in range(n_modules):
-    feats = F.interpolate(feats, scale_factor=2, mode='nearest')
+    if not pre_upsampled:
+      feats = F.interpolate(feats, scale_factor=2, mode='nearest')
+    pre_upsampled = False
     hh = feats.size(2)
     lay = layout
     if H > hh:
@@ -304,6 +374,14 @@ def refinement_network(P, prefix, layout, n_modules, slope, training, normalizat
       x = F.leaky_relu(F.instance_norm(x, eps=BN_EPS), slope)
       x = conv2d(x, P[p + '.3.weight'], P[p + '.3.bias'], padding=1)
       feats = F.leaky_relu(F.instance_norm(x, eps=BN_EPS), slope)
+      continue
+    if OPERAND_ROUND == 'bf16' and STORAGE_ROUND and _storage_level(N, hh, hh * W // H, x.size(1)):
+      bnl = lambda q, t, up2: _BnLeakyStored.apply(t, P[q + '.weight'], P[q + '.bias'], P.get(q + '.running_mean'),
+                                                   P.get(q + '.running_var'), P.get(q + '.num_batches_tracked'),
+                                                   training, slope, up2)
+      x = conv2d(bnl(p + '.1', x, False), P[p + '.3.weight'], P[p + '.3.bias'], padding=1)
+      feats = bnl(p + '.4', x, i + 1 < n_modules)
+      pre_upsampled = i + 1 < n_modules
       continue
     x = F.leaky_relu(batch_norm(P, p + '.1', x, training), slope)
     x = conv2d(x, P[p + '.3.weight'], P[p + '.3.bias'], padding=1)

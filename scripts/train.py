@@ -11,6 +11,7 @@ container: no datasets), batches come from the seeded synthetic generator that r
 accepted; flags whose feature is not on the HIP path yet fail loudly.
 """
 import argparse
+import collections
 import json
 import os
 import sys
@@ -312,17 +313,21 @@ def main(args):
     trainer.broadcast_state()
 
   epoch_box = [0]
+  # the epoch every training batch belongs to, in the order the batches were PRODUCED: CopyAhead pulls host batch k + 1
+  # while iteration k runs, so the counter (what a checkpoint stores, reference train.py:506-514) moves when a batch is
+  # CONSUMED by the loop below, not when the loader hands it out
+  pending_epochs = collections.deque()
 
   def batches(split, start, training=False):
     """the train / val DataLoader, cycled over epochs (reference train.py:506-514; ``training``: the iterator that
     feeds the optimisation loop counts the epochs) - or its endless seeded synthetic stand-in"""
     def host_batches():
+      produced = epoch_box[0]
       while real_data:
-        if training:
-          epoch_box[0] += 1
-          if rank == 0:
-            print('Starting epoch %d' % epoch_box[0])
+        produced += 1
         for cpu_batch in (train_dl if split == 'train' else val_dl):
+          if training:
+            pending_epochs.append(produced)
           yield cpu_batch
       i = start
       while True:
@@ -375,6 +380,12 @@ def main(args):
       trainer.set_generator_eval()
     t += 1
     batch = next(train_loader)
+    if pending_epochs:
+      ep = pending_epochs.popleft()
+      if ep != epoch_box[0]:
+        epoch_box[0] = ep
+        if rank == 0:
+          print('Starting epoch %d' % ep)
     with timeit('step', args.timing):
       losses = trainer.step(batch)
     if t % args.print_every == 0:

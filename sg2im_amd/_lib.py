@@ -19,14 +19,14 @@ class Sg2imHipError(RuntimeError):
 
 class Src(Structure):
   _fields_ = [('data', c_void_p), ('gather', c_void_p), ('scale', c_void_p), ('shift', c_void_p),
-              ('slope', c_float), ('channels', c_int), ('ld', c_int), ('upsample_log2', c_int)]
+              ('slope', c_float), ('channels', c_int), ('ld', c_int), ('upsample_log2', c_int), ('dtype', c_int)]
 
 
 class ConvDesc(Structure):
   _fields_ = [('src', Src * 4), ('nsrc', c_int), ('batch', c_int), ('in_h', c_int), ('in_w', c_int),
               ('out_h', c_int), ('out_w', c_int), ('kh', c_int), ('kw', c_int), ('stride', c_int),
               ('pad', c_int), ('compute_dtype', c_int), ('launch_hints', c_int), ('weight_channels', c_int),
-              ('weight_bf16', c_void_p)]
+              ('out_dtype', c_int), ('dy_dtype', c_int), ('weight_bf16', c_void_p)]
 
 
 class BnFwd(Structure):
@@ -43,7 +43,7 @@ class BnBwd(Structure):
   _fields_ = [('y', c_void_p), ('ld_y', c_longlong), ('pool2', c_int), ('gamma', c_void_p), ('mean', c_void_p),
               ('invstd', c_void_p), ('scale', c_void_p), ('shift', c_void_p), ('slope', c_float), ('training', c_int),
               ('dgamma', c_void_p), ('dbeta', c_void_p), ('accumulate', c_int), ('coef', c_void_p), ('partial', c_void_p),
-              ('partial_floats', c_size_t), ('count', c_void_p), ('count_unit', c_int)]
+              ('partial_floats', c_size_t), ('count', c_void_p), ('count_unit', c_int), ('y_dtype', c_int)]
 
 
 class GconvLayer(Structure):
@@ -168,6 +168,8 @@ _SIGNATURES = {
   'sg2im_adam_prepare_guarded': [_F, _F, _F, _P, _P, _P],
   'sg2im_adam_apply_guarded': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P],
   'sg2im_cast_f32_to_bf16': [_P, _P, _L, _P],
+  'sg2im_bn_backward_apply_ex': [_P, _L, _I, _I, _I, _I, _P, _L, _I, _P, _P, _F, _P, _P, _I, _I, _I, _P],
+  'sg2im_conv_halo_unsplit': [_I, _I, _I, _I, _I],
   'sg2im_two_heads_supported': [_I, _I, _I],
   'sg2im_two_heads_forward': [_P, _L, _I, _I, _P, _P, _I, _P, _P, _I, _P, _L, _P, _L, _P],
   'sg2im_two_heads_backward_data': [_P, _L, _P, _L, _I, _I, _P, _I, _P, _I, _P, _L, _P],

@@ -194,6 +194,21 @@ __device__ __forceinline__ float4 ld4_off(const float* base, unsigned elem_off) 
   return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + (size_t)byte_off);
 }
 
+// bfloat16 storage (Src::bf, dY of a bf16-storage layer): FOUR bf16 = 8 bytes per lane, returned in .x / .y of the same
+// float4 register quad the fp32 loaders fill (unpack_bf16x4 at staging time, igemm.h); element offsets as above
+typedef float f32x2g __attribute__((ext_vector_type(2)));
+__device__ f32x2g llvm_raw_buffer_load_f32x2(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ __forceinline__ float4 ld2h_buf(BufRsrc r, unsigned byte_off) {
+  const f32x2g v = llvm_raw_buffer_load_f32x2(r, (int)byte_off, 0, 0);
+  return make_float4(v.x, v.y, 0.f, 0.f);
+}
+__device__ __forceinline__ float4 ld2h_off(const float* base, unsigned elem_off) {
+  unsigned byte_off = elem_off << 1;
+  asm volatile("" : "+v"(byte_off));
+  const f32x2g v = *reinterpret_cast<const f32x2g*>(reinterpret_cast<const char*>(base) + (size_t)byte_off);
+  return make_float4(v.x, v.y, 0.f, 0.f);
+}
+
 __device__ __forceinline__ void fetch_aff(Aff& a, const Src& S, int c, bool cok) {
   const bool has = S.scale != nullptr && cok;
   const float* scp = has ? S.scale + c : k_ones4;
@@ -1349,10 +1364,10 @@ static void fill_geom(ConvGeom& g, const sg2im_conv_desc* d) {
     if (i < d->nsrc) {
       const sg2im_src& q = d->src[i];
       s.p = q.data; s.gidx = q.gather; s.scale = q.scale; s.shift = q.shift; s.slope = q.slope;
-      s.C = q.channels; s.ld = q.ld; s.up = q.upsample_log2;
+      s.C = q.channels; s.ld = q.ld; s.up = q.upsample_log2; s.bf = q.dtype == 1;
       g.Ctot += q.channels;
     } else {
-      s = Src{nullptr, nullptr, nullptr, nullptr, 1.f, 0, 0, 0};
+      s = Src{nullptr, nullptr, nullptr, nullptr, 1.f, 0, 0, 0, 0};
     }
   }
   g.NB = d->batch; g.H = d->in_h; g.W = d->in_w; g.Ho = d->out_h; g.Wo = d->out_w;
@@ -1843,15 +1858,27 @@ static int conv_forward_impl(const sg2im_conv_desc* d, const float* weight, int 
   hipError_t err;
   HaloPlan hp;
   int nsplit = 0;
+  // bfloat16 STORAGE (sg2im_src.dtype / sg2im_conv_desc.out_dtype): the bf16 halo'd kernel only, without split-K (the
+  // finish kernels read and write fp32) - anything else is refused, never silently misread
+  bool sb = d->out_dtype == 1;
+  for (int i = 0; i < d->nsrc; ++i) sb = sb || d->src[i].dtype == 1;
+  if (sb && (d->compute_dtype != 1 || accumulate || (bn && bn->count))) return SG2IM_ERR_ARG;
   if (v4 && !any_gather(p.g) && !accumulate && halo_geometry(d) && p.g.Wtap % 4 == 0 &&
-      halo_plan(d->batch, d->in_h, d->in_w, cout, p.nch, workspace_bytes, workspace != nullptr, &hp)) {
+      halo_plan(d->batch, d->in_h, d->in_w, cout, p.nch, workspace_bytes, workspace != nullptr && !sb, &hp)) {
     HaloParams q;
     q.g = p.g; q.Wt = weight; q.Wh = (const bf16_t*)d->weight_bf16; q.N = cout; q.c_begin = 0; q.nchunks = p.nch;
     q.tiles_x = d->in_w / hp.ct; q.tiles_y = d->in_h / hp.rt; q.M = p.M;
     q.e = Epi{out, ld_out, bias, out_slope, 0, workspace, hp.nsplit};
+    q.e.out_bf = d->out_dtype == 1;
+    q.dy_bf = 0;
     q.st = StatSink{};
     p.e = q.e;
     nsplit = hp.nsplit;
+    if (sb && bn_train && !(st_ok && (size_t)hp.patches * 3 * cout <= bn->partial_floats)) return SG2IM_ERR_ARG;
+    if (sb && bn && !bn_train) {       // eval-mode BatchNorm: no statistics to reduce, the folded affine comes from the running ones
+      if (launch_halo<false, false>(q, hp, stream, true) != hipSuccess) return SG2IM_ERR_HIP;
+      return bn_fwd_standalone(bn, (const float*)nullptr, p.M, cout, ld_out, stream);
+    }
     if (st_ok && !bn->count && hp.nsplit == 1 && (size_t)hp.patches * 3 * cout <= bn->partial_floats) {
       q.st.partial = bn->partial; q.st.tiles = hp.patches;
       if (launch_halo<false, true>(q, hp, stream, d->compute_dtype == 1) != hipSuccess) return SG2IM_ERR_HIP;
@@ -1859,6 +1886,7 @@ static int conv_forward_impl(const sg2im_conv_desc* d, const float* weight, int 
     }
     err = launch_halo<false, false>(q, hp, stream, d->compute_dtype == 1);
   } else {
+  if (sb) return SG2IM_ERR_ARG;
   const Plan pl = make_plan(PASS_FWD, p.M, cout, p.iters, (long long)p.M * cout, workspace_bytes, workspace != nullptr, 4, !v4,
                             [&](int bn) { return (long long)(cout + bn - 1) / bn; });
   p.e = Epi{out, ld_out, bias, out_slope, accumulate, workspace, pl.nsplit};
@@ -1900,6 +1928,13 @@ static int conv_forward_impl(const sg2im_conv_desc* d, const float* weight, int 
   return bn ? bn_fwd_standalone(bn, out, p.M, cout, ld_out, stream) : SG2IM_OK;
 }
 
+int sg2im_conv_halo_unsplit(int batch, int h, int w, int cols, int chunks) {
+  HaloPlan hp;
+  if (!g_halo || batch < 1 || h < 1 || w < 1 || cols < 1 || chunks < 1) return 0;
+  if (!halo_plan(batch, h, w, cols, chunks, (size_t)1 << 40, true, &hp)) return 0;
+  return hp.nsplit == 1 ? 1 : 0;
+}
+
 int sg2im_conv2d_forward(const sg2im_conv_desc* d, const float* weight, int cout, const float* bias,
                          float out_slope, float* out, long long ld_out, int accumulate,
                          float* workspace, size_t workspace_bytes, hipStream_t stream) {
@@ -1933,7 +1968,7 @@ static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int co
   ConvGeom& g = p.g;
   fill_geom(g, d);
   g.nsrc = 1;
-  for (int i = 0; i < 4; ++i) *src_at(g, i) = Src{nullptr, nullptr, nullptr, nullptr, 1.f, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) *src_at(g, i) = Src{nullptr, nullptr, nullptr, nullptr, 1.f, 0, 0, 0, 0};
   g.s0.p = dy; g.s0.C = cout; g.s0.ld = ld_dy;
   if (c_begin < 0 || c_begin + c_count > g.Ctot) return SG2IM_ERR_ARG;
   // (dY is read through a buffer resource with an out-of-range offset of 2 GiB for invalid rows)
@@ -1956,7 +1991,9 @@ static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int co
     return sg2im_act_backward(dx, ld_dx, 0, d->batch, d->in_h, d->in_w, am->act, am->ld, c_count, am->slope, dx, stream);
   };
   // 1 x 1 with at most four OUTPUT channels (output_conv[2], mask_net's last layer): one elementwise pass (conv_fewout.h)
-  if (g_fewout && taps == 1 && d->stride == 1 && d->pad == 0 && cout <= 4 && !bb && !accumulate && !(c_count & 3) &&
+  // (bf16 operands: cout == 4 is a shape the bf16 mode is SPECIFIED to round - oracle conv2d rd / rw - so it stays on the
+  // matrix-core path there)
+  if (g_fewout && taps == 1 && d->stride == 1 && d->pad == 0 && (cout < 4 || (cout == 4 && d->compute_dtype == 0)) && !bb && !accumulate && !(c_count & 3) &&
       !(c_begin & 3) && !(g.Wtap & 3) && !(ld_dx & 3) && !((uintptr_t)dx & 15) && !((uintptr_t)weight & 15) &&
       (!am || (!(am->ld & 3) && !((uintptr_t)am->act & 15)))) {
     const int c4n = c_count >> 2;
@@ -2001,12 +2038,18 @@ static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int co
   const bool vb4 = (g.Ctot % 4 == 0) && (c_begin % 4 == 0) && (c_count % 4 == 0) && !((uintptr_t)weight & 15);
   // 3x3 / stride 1 / pad 1: the halo'd-tile kernel (conv_halo.h)
   HaloPlan hp;
-  if (va4 && vb4 && !accumulate && halo_geometry(d) && g.Wtap % 4 == 0 &&
-      halo_plan(d->batch, d->in_h, d->in_w, c_count, (cout + BK - 1) / BK, workspace_bytes, workspace != nullptr, &hp)) {
+  // bfloat16 storage of dy / dx / the BatchNorm'd layer's y: the bf16 halo'd kernel, no split-K (see conv_forward_impl)
+  const bool sbd = d->dy_dtype == 1 || d->out_dtype == 1 || (bb && bb->y_dtype == 1);
+  const bool va4h = d->dy_dtype == 1 ? ((cout % 4 == 0) && (ld_dy % 4 == 0) && !((uintptr_t)dy & 7)) : va4;
+  if (sbd && (d->compute_dtype != 1 || accumulate || am)) return SG2IM_ERR_ARG;
+  if (va4h && vb4 && !accumulate && halo_geometry(d) && g.Wtap % 4 == 0 &&
+      halo_plan(d->batch, d->in_h, d->in_w, c_count, (cout + BK - 1) / BK, workspace_bytes, workspace != nullptr && !sbd, &hp)) {
     HaloParams q;
     q.g = g; q.Wt = weight; q.Wh = (const bf16_t*)d->weight_bf16; q.N = c_count; q.c_begin = c_begin; q.nchunks = (cout + BK - 1) / BK;
     q.tiles_x = d->in_w / hp.ct; q.tiles_y = d->in_h / hp.rt; q.M = (int)Mfull;
     q.e = Epi{dx, ld_dx, nullptr, 1.f, 0, workspace, hp.nsplit};
+    q.e.out_bf = d->out_dtype == 1;
+    q.dy_bf = d->dy_dtype == 1;
     if (am) { q.e.mask = am->act; q.e.ld_mask = am->ld; q.e.mask_slope = am->slope; }     // (epilogue, or the split-K finish)
     q.st = StatSink{};
     const long long bn_rows_h = bb ? (bb->pool2 ? Mfull / 4 : Mfull) : 0;
@@ -2016,7 +2059,9 @@ static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int co
     if (st_h) {
       ss.partial = bb->partial; ss.y = bb->y; ss.ld_y = bb->ld_y; ss.mean = bb->mean; ss.invstd = bb->invstd;
       ss.scale = bb->scale; ss.shift = bb->shift; ss.slope = bb->slope; ss.pool2 = bb->pool2; ss.H = d->in_h; ss.W = d->in_w;
+      ss.y_bf = bb->y_dtype == 1;
     }
+    if (sbd && bb && !(st_h && (size_t)hp.patches * 2 * c_count <= bb->partial_floats)) return SG2IM_ERR_ARG;
     if (st_h && hp.nsplit == 1 && (size_t)hp.patches * 2 * c_count <= bb->partial_floats) {
       q.st = ss; q.st.tiles = hp.patches;
       if (launch_halo<true, true>(q, hp, stream, d->compute_dtype == 1) != hipSuccess) return SG2IM_ERR_HIP;
@@ -2038,6 +2083,7 @@ static int conv_dgrad_impl(const sg2im_conv_desc* d, const float* weight, int co
     if (finish_split(q.e, Mfull, c_count, stream) != hipSuccess) return SG2IM_ERR_HIP;
     return bn_after();
   }
+  if (sbd) return SG2IM_ERR_ARG;
   // stride-2 parity decomposition: needs the chunked (VA=4) K enumeration; split-K partials of
   // this form are laid out per class and finished by splitk_finish_parity_kernel
   p.parity = (d->stride == 2 && va4 && d->kh >= 2 && d->kw >= 2) ? 1 : 0;
@@ -2170,7 +2216,7 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
   {
     const Src& s0 = p.g.s0;
     const int C4 = s0.C >> 2;
-    if (g_fewout && taps == 1 && d->stride == 1 && d->pad == 0 && cout <= 4 && p.g.nsrc == 1 && !s0.gidx && !s0.up &&
+    if (g_fewout && taps == 1 && d->stride == 1 && d->pad == 0 && (cout < 4 || (cout == 4 && d->compute_dtype == 0)) && p.g.nsrc == 1 && !s0.gidx && !s0.up &&
         !(s0.C & 3) && C4 >= 4 && C4 <= 64 && !(C4 & (C4 - 1)) && !(s0.ld & 3) && !((uintptr_t)s0.p & 15) &&
         (!s0.scale || (s0.shift && !((uintptr_t)s0.scale & 15) && !((uintptr_t)s0.shift & 15))) && workspace) {
       const long long M = p.P;
@@ -2192,7 +2238,10 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
     }
   }
   p.iters = (p.P + BK - 1) / BK;
-  const bool v4 = geom_vec4(p.g) && (cout % 4 == 0) && (ld_dy % 4 == 0) && !((uintptr_t)dy & 15);
+  // bfloat16 storage of a source or of dy: the bf16 halo'd weight-gradient kernel only (else refused, see below)
+  bool sbw = d->dy_dtype == 1;
+  for (int i = 0; i < d->nsrc; ++i) sbw = sbw || d->src[i].dtype == 1;
+  const bool v4 = geom_vec4(p.g) && (cout % 4 == 0) && (ld_dy % 4 == 0) && !((uintptr_t)dy & (d->dy_dtype == 1 ? 7 : 15));
   const int Ctot = p.g.Ctot;
   // (room for the bias-gradient partials of up to 512 splits is kept behind the dW partials)
   const size_t bias_room = dbias ? sizeof(float) * 512 * (size_t)cout : 0;
@@ -2201,11 +2250,12 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
   // (bf16 operands, round 5: conv_wgrad_halo_h_kernel, 4 x 16 patches only; SG2IM_WGRAD_HALO_BF16=0: the per-tap bf16 kernels)
   static const bool g_wgrad_halo_h = !(getenv("SG2IM_WGRAD_HALO_BF16") && atoi(getenv("SG2IM_WGRAD_HALO_BF16")) == 0);
   const bool hb = d->compute_dtype == 1;
+  if (sbw && !hb) return SG2IM_ERR_ARG;
   if (g_wgrad_halo && v4 && !any_gather(p.g) && halo_geometry(d) &&
       ((d->in_w % 16 == 0 && d->in_h % 4 == 0) || (!hb && d->in_w % 8 == 0 && d->in_h % 8 == 0)) && (!hb || g_wgrad_halo_h)) {
     const bool wide = d->in_w % 16 == 0;
     WgHaloParams q;
-    q.g = p.g; q.dY = dy; q.ldy = ld_dy; q.Cout = cout;
+    q.g = p.g; q.dY = dy; q.ldy = ld_dy; q.Cout = cout; q.dy_bf = d->dy_dtype == 1;
     q.tiles_x = d->in_w / (wide ? 16 : 8); q.tiles_y = d->in_h / (wide ? 4 : 8);
     q.npatch = d->batch * q.tiles_x * q.tiles_y;
     const int ncb = (Ctot + 63) / 64, nkb = (cout + 63) / 64;
@@ -2231,7 +2281,7 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
     // m2.conv0 (672 channels) 97 -> 93, m1.conv0 (1184) 87 -> 86, mask_net's 8x8 layer (4 patches each) 67 -> 61
     // bf16: the alternative re-reads and re-activates the fp32 input once per tap for 1/8 of the MFMA instructions - the
     // halo'd form wherever a workgroup gets at least two patches
-    const bool halo_pays = hb ? q.per >= 2 : (Ctot <= 512 && q.per >= 6);
+    const bool halo_pays = sbw || (hb ? q.per >= 2 : (Ctot <= 512 && q.per >= 6));
     const int nsplit = (q.npatch + q.per - 1) / q.per;
     q.e = Epi{dweight, (long long)taps * p.g.Wtap, nullptr, 1.f, accumulate, workspace, nsplit};
     if (p.g.Wtap != Ctot) { q.e.col_ctot = Ctot; q.e.col_wtap = p.g.Wtap; }
@@ -2249,6 +2299,7 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
       return finish_split(q.e, cout, Ntot, stream, q.ws_bias, dbias, cout) == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
     }
   }
+  if (sbw) return SG2IM_ERR_ARG;       // (bf16 storage outside the bf16 halo'd kernel's geometry: not supported)
   const Plan pl = make_plan(PASS_WGRAD, cout, Ntot, p.iters, (long long)cout * Ntot, can_split ? workspace_bytes - bias_room : 0,
                             can_split, 2, !v4, [&](int bn) { return (long long)(Ntot + bn - 1) / bn; });
   p.ntile_c = 0;

@@ -44,6 +44,7 @@ struct HaloParams {
   int nchunks;          // 32-channel chunks of the reduction (forward: over all sources; dgrad: ceil(Cout / 32))
   int tiles_x, tiles_y; // patches per image along x / y
   int M;                // NB * H * W
+  int dy_bf;            // data gradient: dY holds bfloat16 (sg2im_conv_desc.dy_dtype)
   Epi e;
   StatSink st;
 };
@@ -81,7 +82,7 @@ struct ChunkCursor {
 template <int RT, int CT, int BN, bool DG, bool ST, bool H = false, int TG = 1, bool WB = false>
 // (the fp32 4 x 32 data-gradient form - 7 halo float4 per thread, maps that 8 x 16 patches do not tile - needs 130
 // registers: three waves per SIMD instead of a spilled offset that is reloaded every chunk)
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(TG == 9 ? 2 : (BN == 64 && CT <= 32) ? ((RT == 4 && DG && !H) ? 3 : SG2IM_HALO_WAVES64) : 2)))
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(TG == 9 ? 2 : (BN == 64 && CT <= 32) ? ((RT == 4 && ((DG && !H) || (!DG && TG == 3))) ? 3 : SG2IM_HALO_WAVES64) : 2)))
 void conv_halo_kernel(const HaloParams p) {
   static_assert(TG == 1 || (H && (TG == 3 || TG == 9)), "multi-tap staging exists for the bf16 operand path only");
   static_assert(!WB || (H && BN == 64), "the weight mirror is bf16: bf16 operand path, 64-column tiles");
@@ -165,19 +166,39 @@ void conv_halo_kernel(const HaloParams p) {
   float4 ra[NA];
   Aff aaff;
   unsigned ramask = 0;
-  const BufRsrc rsY = rsrc_of(g.s0.p, (unsigned)p.M * (unsigned)g.s0.ld * 4u);     // (DG: dY; out-of-range offset -> zeros)
+  const BufRsrc rsY = rsrc_of(g.s0.p, (unsigned)p.M * (unsigned)g.s0.ld * (p.dy_bf ? 2u : 4u));     // (DG: dY; out-of-range offset -> zeros)
   int off_src = -1;
+  int ra_bf = 0;                                              // the staged halo registers hold bf16 pairs (wave-uniform)
   auto load_A = [&](const ChunkCursor& c) {
     const int ch = c.cb + 4 * col4;
     const bool cok = ch < c.S.C;
     if (off_src != c.s) { pixel_offsets(c.S); off_src = c.s; }        // (wave-uniform: the source changed)
     if (DG) {
+      if constexpr (H) {
+        if (p.dy_bf) {
+          #pragma unroll
+          for (int j = 0; j < NA; ++j)
+            ra[j] = ld2h_buf(rsY, ((amask >> j & 1u) && cok) ? (aoff[j] + (unsigned)ch) << 1 : kOobByte);
+          ra_bf = 1;
+          return;
+        }
+      }
       #pragma unroll
       for (int j = 0; j < NA; ++j)
         ra[j] = ld4_buf(rsY, ((amask >> j & 1u) && cok) ? (aoff[j] + (unsigned)ch) << 2 : kOobByte);
     } else {
       fetch_aff(aaff, c.S, ch, cok);
       ramask = cok ? amask : 0u;
+      if constexpr (H) {
+        if (c.S.bf) {                                               // (wave-uniform: the source's storage type)
+          #pragma unroll
+          for (int j = 0; j < NA; ++j)
+            ra[j] = ld2h_off(c.S.p, (ramask >> j & 1u) ? aoff[j] + (unsigned)ch : 0u);
+          ra_bf = 1;
+          return;
+        }
+      }
+      ra_bf = 0;
       #pragma unroll
       for (int j = 0; j < NA; ++j)
         ra[j] = ld4_off(c.S.p, (ramask >> j & 1u) ? aoff[j] + (unsigned)ch : 0u);
@@ -188,6 +209,7 @@ void conv_halo_kernel(const HaloParams p) {
     for (int j = 0; j < NA; ++j) {
       const int hp = r0 + 32 * j;
       float4 v = ra[j];
+      if constexpr (H) { if (ra_bf) v = unpack_bf16x4(v); }
       if (!DG) v = apply_aff(v, aaff, (ramask >> j & 1u) != 0);
       if (NA * 32 <= HP || hp < HP) {
         if constexpr (H) *reinterpret_cast<bf16x4*>(Ash + hp * MLDH + 4 * col4) = to_bf16x4(v);

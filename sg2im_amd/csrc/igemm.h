@@ -38,6 +38,8 @@ struct Src {
   int C;                   // channels supplied by this source
   int ld;                  // floats between consecutive pixels / rows
   int up;                  // log2 of nearest-neighbour upsampling (0 or 1)
+  int bf;                  // 1: the tensor holds bfloat16 (sg2im_src.dtype; `ld` counts ELEMENTS either way) - the bf16
+                           // halo'd kernels only (conv_halo.h, wgrad_halo.h)
 };
 
 struct ConvGeom {
@@ -69,6 +71,8 @@ struct Epi {
   const float* mask;
   long long ld_mask;
   float mask_slope;
+  int out_bf;              // 1: C holds bfloat16 (sg2im_conv_desc.out_dtype): the finished value is rounded (RNE) when it is
+                           // stored; launches without split-K and without accumulate only (the entry points check)
 };
 __device__ __forceinline__ int epi_col(const Epi& e, int n) {
   return e.col_wtap ? (n / e.col_ctot) * e.col_wtap + n % e.col_ctot : n;
@@ -86,7 +90,7 @@ template <typename T> __device__ __forceinline__ T sel4(int s, T a, T b, T c, T 
 __device__ __forceinline__ Src pick_src(const ConvGeom& g, int s) {
   Src S;
   S.p = SG2IM_PICK(p); S.gidx = SG2IM_PICK(gidx); S.scale = SG2IM_PICK(scale); S.shift = SG2IM_PICK(shift);
-  S.slope = SG2IM_PICK(slope); S.C = SG2IM_PICK(C); S.ld = SG2IM_PICK(ld); S.up = SG2IM_PICK(up);
+  S.slope = SG2IM_PICK(slope); S.C = SG2IM_PICK(C); S.ld = SG2IM_PICK(ld); S.up = SG2IM_PICK(up); S.bf = SG2IM_PICK(bf);
   return S;
 }
 #undef SG2IM_PICK
@@ -100,7 +104,7 @@ __device__ __forceinline__ Src kernarg_src(int s) {
   const KSrc k = (KSrc)__builtin_amdgcn_kernarg_segment_ptr() + s;
   Src S;
   S.p = k->p; S.gidx = k->gidx; S.scale = k->scale; S.shift = k->shift;
-  S.slope = k->slope; S.C = k->C; S.ld = k->ld; S.up = k->up;
+  S.slope = k->slope; S.C = k->C; S.ld = k->ld; S.up = k->up; S.bf = k->bf;
   return S;
 }
 
@@ -242,9 +246,13 @@ __device__ __forceinline__ void epilogue(const Epi& e, int M, int N, int nlimit,
           v = leaky(v + bv, e.slope);
           const long long drow = rowmap(m);
           if (MASK) v *= e.mask[drow * e.ld_mask + n] > 0.f ? 1.f : e.mask_slope;
-          float* dst = e.C + drow * e.ldc + ncol;
-          if (e.accumulate) v += *dst;
-          *dst = v;
+          if (e.out_bf) {
+            reinterpret_cast<__bf16*>(e.C)[drow * e.ldc + ncol] = (__bf16)v;
+          } else {
+            float* dst = e.C + drow * e.ldc + ncol;
+            if (e.accumulate) v += *dst;
+            *dst = v;
+          }
         }
       }
     }
@@ -270,6 +278,7 @@ struct StatSink {
   const float* mean; const float* invstd; const float* scale; const float* shift;
   float slope;
   int pool2, H, W;         // pool2: this launch's rows are pixels (n, h, w) of an H x W map at TWICE y's resolution
+  int y_bf;                // backward: y holds bfloat16 (sg2im_bn_bwd.y_dtype)
 };
 
 __device__ __forceinline__ int live_limit(const StatSink& ss, int M) {
@@ -375,7 +384,7 @@ __device__ __forceinline__ void epilogue_bnbwd(const StatSink& ss, int M, int N,
       for (int tn = 0; tn < TN; ++tn) {
         const int n = n0 + wn0 + tn * 32 + j;
         if (n >= N) continue;
-        const float yv = yrow[n];
+        const float yv = ss.y_bf ? (float)reinterpret_cast<const __bf16*>(ss.y)[row * ss.ld_y + n] : yrow[n];
         const float du = acc[tm][tn][r] * (fmaf(yv, sc[tn], sh[tn]) > 0.f ? 1.f : ss.slope);
         s0[tn] += du; s1[tn] = fmaf(du, (yv - mu[tn]) * is[tn], s1[tn]);
       }
@@ -430,6 +439,13 @@ template <int ROWS, bool KMAJOR> struct LdsTileH {
 template <bool BF, int ROWS, bool KMAJOR> struct TileBytes {
   static constexpr int value = BF ? LdsTileH<ROWS, KMAJOR>::HALFS * 2 : LdsTile<ROWS, KMAJOR>::FLOATS * 4;
 };
+
+// four bfloat16 (the 8 bytes a bf16-storage loader fetched into .x / .y of a float4 register quad) -> four floats
+__device__ __forceinline__ float4 unpack_bf16x4(const float4& raw) {
+  const unsigned lo = __float_as_uint(raw.x), hi = __float_as_uint(raw.y);
+  return make_float4(__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u),
+                     __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u));
+}
 
 __device__ __forceinline__ bf16x4 to_bf16x4(const float4& v) {
   const f32x4v f = {v.x, v.y, v.z, v.w};

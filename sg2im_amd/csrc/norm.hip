@@ -756,6 +756,51 @@ __global__ void bn_bwd_apply_v4_kernel(GradSrc gs, const float* __restrict__ y, 
   }
 }
 
+// the same with bfloat16 STORAGE of any of the three tensors (sg2im_bn_backward_apply_ex): g (dz), y, dy hold fp32 or
+// bf16 independently; the arithmetic is fp32, the result is rounded (RNE) when dy holds bf16
+__device__ __forceinline__ float4 ld4x(const void* base, long long elem, int bf) {
+  if (!bf) return ld4(reinterpret_cast<const float*>(base) + elem);
+  const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + elem);
+  return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
+                     __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+}
+__global__ void bn_bwd_apply_x_kernel(const void* __restrict__ g, long long ld_g, int pool2, int h, int w, int g_bf,
+                                      const void* __restrict__ y, long long ld_y, int y_bf, long long rows, int C,
+                                      const float* __restrict__ scale, const float* __restrict__ shift, float slope,
+                                      const float* __restrict__ coef, void* __restrict__ dy, int dy_bf) {
+  const int CQ = C >> 2;
+  const long long total = rows * CQ;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / CQ; const int c = 4 * (int)(i - r * CQ);
+    const float4 yv = ld4x(y, r * ld_y + c, y_bf);
+    float4 dz;
+    if (!pool2) dz = ld4x(g, r * ld_g + c, g_bf);
+    else {
+      const long long hw = (long long)h * w;
+      const long long n = r / hw; const int rem = (int)(r - n * hw);
+      const int yy = rem / w, xx = rem - yy * w;
+      const long long W2 = 2LL * w;
+      const long long e0 = ((n * 2 * h + 2 * yy) * W2 + 2 * xx) * ld_g + c;
+      dz = f4add(f4add(ld4x(g, e0, g_bf), ld4x(g, e0 + ld_g, g_bf)), f4add(ld4x(g, e0 + W2 * ld_g, g_bf), ld4x(g, e0 + (W2 + 1) * ld_g, g_bf)));
+    }
+    const float4 sc = ld4(scale + c), sh = ld4(shift + c);
+    const float4 a = ld4(coef + c), k1 = ld4(coef + C + c), k0 = ld4(coef + 2 * C + c);
+    float4 o;
+    o.x = fmaf(a.x, du1(dz.x, yv.x, sc.x, sh.x, slope), fmaf(k1.x, yv.x, k0.x));
+    o.y = fmaf(a.y, du1(dz.y, yv.y, sc.y, sh.y, slope), fmaf(k1.y, yv.y, k0.y));
+    o.z = fmaf(a.z, du1(dz.z, yv.z, sc.z, sh.z, slope), fmaf(k1.z, yv.z, k0.z));
+    o.w = fmaf(a.w, du1(dz.w, yv.w, sc.w, sh.w, slope), fmaf(k1.w, yv.w, k0.w));
+    if (!dy_bf) *reinterpret_cast<float4*>(reinterpret_cast<float*>(dy) + r * C + c) = o;
+    else {
+      typedef __bf16 bfx4 __attribute__((ext_vector_type(4)));
+      typedef float fx4 __attribute__((ext_vector_type(4)));
+      const fx4 f = {o.x, o.y, o.z, o.w};
+      *reinterpret_cast<bfx4*>(reinterpret_cast<__bf16*>(dy) + r * C + c) = __builtin_convertvector(f, bfx4);
+    }
+  }
+}
+
 __global__ void act_bwd_v4_kernel(GradSrc gs, const float* __restrict__ y, long long ld_y, long long rows, int C,
                                   float slope, float* __restrict__ dx) {
   const int CQ = C >> 2;
@@ -963,6 +1008,21 @@ int sg2im_bn_backward_apply(const float* g, long long ld_g, int pool2, int batch
   else
     SG2IM_LAUNCH(bn_bwd_apply_kernel, dim3(ew_blocks(rows * channels)), dim3(256), 0, stream, gs, y, ld_y, rows,
                        channels, scale, shift, slope, coef, dy, count, count_unit);
+  return ok_or(hipGetLastError());
+}
+
+int sg2im_bn_backward_apply_ex(const void* g, long long ld_g, int pool2, int batch, int h, int w, const void* y,
+                               long long ld_y, int channels, const float* scale, const float* shift, float slope,
+                               const float* coef, void* dy, int g_dtype, int y_dtype, int dy_dtype, hipStream_t stream) {
+  if (!g || !y || !dy || !coef || channels < 1 || !scale || !shift) return SG2IM_ERR_ARG;
+  if ((g_dtype | y_dtype | dy_dtype) & ~1) return SG2IM_ERR_ARG;
+  const long long rows = (long long)batch * h * w;
+  if (rows < 1) return SG2IM_ERR_ARG;
+  if (channels % 4 || ld_g % 4 || ld_y % 4 || ((uintptr_t)g & 15) || ((uintptr_t)y & 15) || ((uintptr_t)dy & 15) || !al16(scale) ||
+      !al16(shift) || !al16(coef))
+    return SG2IM_ERR_ARG;
+  SG2IM_LAUNCH(bn_bwd_apply_x_kernel, dim3(ew_blocks(rows * channels / 4)), dim3(256), 0, stream, g, ld_g, pool2, h, w, g_dtype,
+                     y, ld_y, y_dtype, rows, channels, scale, shift, slope, coef, dy, dy_dtype);
   return ok_or(hipGetLastError());
 }
 

@@ -28,6 +28,7 @@ struct WgHaloParams {
   Epi e;                  // C = dW (ldc = 9 * Wtap floats per row), ws = split-K partials [nsplit][Cout][9 * Ctot]
   float* dbias;           // optional: the bias gradient (column sums of dY), produced by the workgroups of channel block 0
   float* ws_bias;         // its split-K partials [nsplit][Cout]
+  int dy_bf;              // dY holds bfloat16 (sg2im_conv_desc.dy_dtype; conv_wgrad_halo_h_kernel only)
 };
 
 template <int RT, int CT>
@@ -307,7 +308,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(SG2IM_
   const int Hs = g.H >> XS.up, Ws = g.W >> XS.up;
   const int yk = k0 + 4 * col4;
   const bool yok = yk < p.Cout;
-  const BufRsrc rsY = rsrc_of(p.dY, (unsigned)(g.NB * g.H * g.W) * (unsigned)p.ldy * 4u);
+  const BufRsrc rsY = rsrc_of(p.dY, (unsigned)(g.NB * g.H * g.W) * (unsigned)p.ldy * (p.dy_bf ? 2u : 4u));
+  const bool xbf = XS.bf != 0;                        // (per thread: its four channels' source holds bfloat16)
 
   float4 rx[NX], ry[NY];
   unsigned rxm = 0;
@@ -325,13 +327,16 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(SG2IM_
       const bool ok = xok && hp < HP && (unsigned)ay < (unsigned)g.H && (unsigned)ax < (unsigned)g.W;
       rxm |= (ok ? 1u : 0u) << j;
       const int ayc = min(max(ay, 0), g.H - 1), axc = min(max(ax, 0), g.W - 1);
-      rx[j] = ld4_off(XS.p, (unsigned)((nb * Hs + (ayc >> XS.up)) * Ws + (axc >> XS.up)) * (unsigned)XS.ld + (unsigned)xcs);
+      const unsigned xo = (unsigned)((nb * Hs + (ayc >> XS.up)) * Ws + (axc >> XS.up)) * (unsigned)XS.ld + (unsigned)xcs;
+      // (a 64-channel block may straddle two sources of different storage types: per-lane choice of the load)
+      if (xbf) rx[j] = ld2h_off(XS.p, xo); else rx[j] = ld4_off(XS.p, xo);
     }
     #pragma unroll
     for (int j = 0; j < NY; ++j) {
       const int q = r0 + 16 * j;
       const int pix = (nb * g.H + y0 + q / CT) * g.W + x0 + q % CT;
-      ry[j] = ld4_buf(rsY, yok ? ((unsigned)pix * (unsigned)p.ldy + (unsigned)yk) << 2 : kOobByte);     // (zeros when !yok)
+      if (p.dy_bf) ry[j] = ld2h_buf(rsY, yok ? ((unsigned)pix * (unsigned)p.ldy + (unsigned)yk) << 1 : kOobByte);
+      else ry[j] = ld4_buf(rsY, yok ? ((unsigned)pix * (unsigned)p.ldy + (unsigned)yk) << 2 : kOobByte);     // (zeros when !yok)
     }
   };
   const bool want_db = p.dbias != nullptr && blockIdx.x == 0;
@@ -340,6 +345,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(SG2IM_
     #pragma unroll
     for (int j = 0; j < NY; ++j) {
       const int q = r0 + 16 * j;
+      if (p.dy_bf) ry[j] = unpack_bf16x4(ry[j]);
       if (want_db) { dbs.x += ry[j].x; dbs.y += ry[j].y; dbs.z += ry[j].z; dbs.w += ry[j].w; }     // (the bias gradient sums the fp32 dY)
       *reinterpret_cast<bf16x4*>(img + q * WGH_LD + 4 * col4) = to_bf16x4(ry[j]);
     }
@@ -347,7 +353,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(SG2IM_
     for (int j = 0; j < NX; ++j) {
       const int hp = r0 + 16 * j;
       if (NX * 16 <= HP || hp < HP)
-        *reinterpret_cast<bf16x4*>(img + (PX + hp) * WGH_LD + 4 * col4) = to_bf16x4(apply_aff(rx[j], xaff, (rxm >> j & 1u) != 0));
+        *reinterpret_cast<bf16x4*>(img + (PX + hp) * WGH_LD + 4 * col4) =
+          to_bf16x4(apply_aff(xbf ? unpack_bf16x4(rx[j]) : rx[j], xaff, (rxm >> j & 1u) != 0));
     }
   };
 

@@ -3,6 +3,7 @@ forward AND backward are explicit sequences of HIP kernels (sg2im_amd.ops).  Int
 image-like tensors are NHWC and BatchNorm+LeakyReLU stay *pending* (folded into the next
 convolution's operand loader), so no torch compute kernel runs on the hot path.
 """
+import os
 from ctypes import c_void_p
 
 import torch
@@ -20,6 +21,28 @@ def _fptr(t, offset_floats=0):
 
 def _new(like, *shape):
   return torch.empty(*shape, dtype=torch.float32, device=like.device)
+
+
+def _new_s(like, bf, *shape):
+  """a tensor of the refinement network's chain in its STORAGE type: bfloat16 where the layer qualifies (see
+  _storage_levels), float32 otherwise"""
+  return torch.empty(*shape, dtype=torch.bfloat16 if bf else torch.float32, device=like.device)
+
+
+# A/B knob: 0 = every tensor of the bf16 mode stays float32 in memory (rounds 2-5: operand rounding only)
+BF16_STORAGE = os.environ.get('SG2IM_BF16_STORAGE', '1') != '0'
+
+
+def _storage_levels(N, H, W, L, dims):
+  """Which refinement modules keep their chain tensors - the convolution outputs y0 / y1 (pre-normalisation), the
+  gradients w.r.t. the activated outputs and the BatchNorm-backward results dy0 / dy1 - as bfloat16 in HBM: bf16 compute
+  mode (Trainer(compute_dtype='bf16')) and a map that the halo'd 3x3 kernels run WITHOUT split-K for the module's channel
+  count (the launches that carry bfloat16 storage have no split-K form: sg2im_conv_halo_unsplit - at the COCO-64 batch
+  the 32 x 32 and 64 x 64 levels, 85 % of the chain's bytes).  BatchNorm statistics, the layout, the image and every
+  parameter gradient stay float32; the reductions inside the GEMM epilogues see the unrounded accumulators."""
+  if not (BF16_STORAGE and ops.CONV_COMPUTE == 1):
+    return [False] * L
+  return [ops.halo_unsplit(N, H >> (L - 1 - i), W >> (L - 1 - i), min(int(dims[i]), 128)) for i in range(L)]
 
 
 def _cl_weight(w):
@@ -867,6 +890,7 @@ class RefinementFn(Function):
     saved = []
     pyr, from_link = _layout_pyramid(layout, L, link)
     ctx.link = link if from_link else None
+    sbm = _storage_levels(N, H, W, L, [convp[4 * i].size(0) for i in range(L)])
 
     def activated(y, st, up):
       """the source the next convolution reads: leaky(bn(y)), pending in its loader"""
@@ -879,11 +903,11 @@ class RefinementFn(Function):
       bn0, bn1 = bns[i]
       d0 = _crn_conv0_desc(lay, feat_src, N, h, w, W0p)
       # (the BatchNorm statistics of a conv output come out of the conv's own launches: epilogue or split-K finish)
-      y0 = _new(layout, N, h, w, C)
+      y0 = _new_s(layout, sbm[i], N, h, w, C)
       st0 = ops.conv2d_forward_bn(d0, _cl_weight(W0p), C, b0, y0, C, bn0, training, BN_EPS, BN_MOMENTUM)
       src0 = activated(y0, st0, 0)
       d1 = conv_desc([src0], N, h, w, 3, 3, 1, 1)
-      y1 = _new(layout, N, h, w, C)
+      y1 = _new_s(layout, sbm[i], N, h, w, C)
       st1 = ops.conv2d_forward_bn(d1, _cl_weight(W1p), C, b1, y1, C, bn1, training, BN_EPS, BN_MOMENTUM)
       saved.append((lay, feat_src, y0, st0, y1, st1, h, w, C, src0))
       feat_src = activated(y1, st1, 1)
@@ -899,6 +923,7 @@ class RefinementFn(Function):
                              Wo2.size(0))
     ctx.saved = saved
     ctx.misc = (L, slope, training, z, do0, do2, Cl, Cf, grad_channels)
+    ctx.sbm = sbm
     ctx.save_for_backward(*params)
     ctx.shape = (N, H, W, Cl)
     return img
@@ -949,7 +974,8 @@ class RefinementFn(Function):
     ops.conv2d_backward_data_act(do2, _cl_weight(Wo2), Wo2.size(0), g, Wo2.size(0), 0, Co, dz, Co, z, Co, slope)
     grads[4 * L + 2], grads[4 * L + 3] = wgrad(do2, g, Wo2.size(0), (Wo2.size(0), 1, 1, Co),
                                                ni[4 * L + 2], ni[4 * L + 3], Wo2, bo2)
-    gz = _new(g, N, H, W, Cf)                      # grad w.r.t. activated feats of the last module
+    sbm = ctx.sbm
+    gz = _new_s(g, sbm[L - 1], N, H, W, Cf)        # grad w.r.t. activated feats of the last module
     side.barrier()
     # Every data gradient below that produces the gradient of a BatchNorm'd layer's activated output also
     # produces that BatchNorm's backward reductions (epilogue / split-K finish) and coefficients: per layer
@@ -973,9 +999,9 @@ class RefinementFn(Function):
       lay, feat_src, y0, st0, y1, st1, h, w, C, src0 = saved[i]
       W0p, b0, W1p, b1 = convp[4 * i:4 * i + 4]
       dy1 = ops.bn_backward_apply(_fptr(gz), gz.size(3), pool2, N, h, w, y1, C, C, st1, slope, coef1,
-                                  _new(g, N, h, w, C))
+                                  _new_s(g, sbm[i], N, h, w, C), g_dtype=ops._dt(gz))
       d1 = conv_desc([src0], N, h, w, 3, 3, 1, 1)
-      gz0 = _new(g, N, h, w, C)
+      gz0 = _new_s(g, sbm[i], N, h, w, C)
       side.barrier()
       g0, dg0, db0n, acc0 = bn_bufs(i, False)
       coef0 = ops.conv2d_backward_data_bn(d1, _cl_weight(W1p), C, dy1, C, 0, C, gz0, C, y0, C, 0, g0, st0, slope,
@@ -986,7 +1012,7 @@ class RefinementFn(Function):
         grads[4 * i + 3] = _shadowed_bias_grad(b1, ni[4 * i + 3])
       # (dy1's buffer is recycled for dy0 unless a side-stream weight gradient may still be reading it)
       dy0 = ops.bn_backward_apply(_fptr(gz0), C, 0, N, h, w, y0, C, C, st0, slope, coef0,
-                                  _new(g, N, h, w, C) if side.on else dy1)
+                                  _new_s(g, sbm[i], N, h, w, C) if side.on else dy1, g_dtype=ops._dt(gz0))
       Cprev = feat_src.channels if feat_src is not None else W0p.size(1) - Cl
       d0 = _crn_conv0_desc(lay, feat_src, N, h, w, W0p)
       side.barrier()
@@ -995,7 +1021,7 @@ class RefinementFn(Function):
         ops.conv2d_backward_data(d0, _cl_weight(W0p), C, dy0, C, 0, Cg, dl, Cg)
         dlevels.append((dl, H // h))
       if i > 0:
-        gz = _new(g, N, h, w, Cprev)               # at this (upsampled) resolution; summed 2x2 next
+        gz = _new_s(g, sbm[i - 1], N, h, w, Cprev)  # at this (upsampled) resolution; summed 2x2 next
         prevm = saved[i - 1]
         g1, dg1, db1n, acc1 = bn_bufs(i - 1, True)
         coef1 = ops.conv2d_backward_data_bn(d0, _cl_weight(W0p), C, dy0, C, Cl, Cprev, gz, Cprev, prevm[4], Cprev, 1, g1,

@@ -39,6 +39,20 @@ def _f(t):
   return c_void_p(t.data_ptr())
 
 
+def _fb(t):
+  """device pointer of an fp32 OR bfloat16 (storage) CUDA tensor (None -> NULL)"""
+  if t is None:
+    return None
+  if not (t.is_cuda and t.dtype in (torch.float32, torch.bfloat16)):
+    raise TypeError('expected a float32 / bfloat16 tensor on the GPU, got %s on %s' % (t.dtype, t.device))
+  return c_void_p(t.data_ptr())
+
+
+def _dt(t):
+  """storage type code of the C ABI: 0 float32, 1 bfloat16"""
+  return 1 if t.dtype == torch.bfloat16 else 0
+
+
 def _i64(t):
   if t is None:
     return None
@@ -286,6 +300,11 @@ class SrcSpec(object):
     self.gather, self.scale, self.shift, self.slope = gather, scale, shift, float(slope)
 
 
+def halo_unsplit(batch, h, w, cols):
+  """does the halo'd 3x3 kernel run this map with `cols` output columns without split-K (sg2im_conv_halo_unsplit)?"""
+  return bool(_lib.load().sg2im_conv_halo_unsplit(int(batch), int(h), int(w), int(cols), 64))
+
+
 def nhwc_src(t, up=0, scale=None, shift=None, slope=1.0):
   """source from a contiguous NHWC tensor"""
   assert t.dim() == 4 and t.is_contiguous()
@@ -321,8 +340,9 @@ def conv_desc(srcs, batch, in_h, in_w, kh=1, kw=1, stride=1, pad=0, compute=None
     q.scale = s.scale.data_ptr() if s.scale is not None else None
     q.shift = s.shift.data_ptr() if s.shift is not None else None
     q.slope, q.channels, q.ld, q.upsample_log2 = s.slope, s.channels, s.ld, s.up
-    if not (s.t.is_cuda and s.t.dtype == torch.float32):
-      raise TypeError('conv source must be a float32 GPU tensor')
+    if not (s.t.is_cuda and s.t.dtype in (torch.float32, torch.bfloat16)):
+      raise TypeError('conv source must be a float32 (or bfloat16-storage) GPU tensor')
+    q.dtype = _dt(s.t)              # (bfloat16 storage: the bf16 halo'd kernels only, include/sg2im_hip.h)
   d.batch, d.in_h, d.in_w = int(batch), int(in_h), int(in_w)
   d.kh, d.kw, d.stride, d.pad = int(kh), int(kw), int(stride), int(pad)
   d.out_h = (in_h + 2 * pad - kh) // stride + 1
@@ -415,8 +435,9 @@ def conv2d_forward(desc, weight, cout, bias, out, ld_out, out_slope=1.0, accumul
   ws = workspace(out.device)
   flops = 2.0 * desc.batch * desc.out_h * desc.out_w * cout * _desc_k(desc)
   _note_bytes('igemm_fwd', _desc_src_floats(desc) + cout * _desc_k(desc) + desc.batch * desc.out_h * desc.out_w * cout)
+  desc.out_dtype = _dt(out)
   _timed('igemm_fwd', flops, lambda: call(
-    'sg2im_conv2d_forward', byref(desc), _f(weight), int(cout), _f(bias), float(out_slope), _f(out),
+    'sg2im_conv2d_forward', byref(desc), _f(weight), int(cout), _f(bias), float(out_slope), _fb(out),
     int(ld_out), int(accumulate), _f(ws), ws.numel() * 4, _stream()))
   return out
 
@@ -427,9 +448,10 @@ def conv2d_backward_data(desc, weight, cout, dy, ld_dy, c_begin, c_count, dx, ld
   flops = 2.0 * desc.batch * desc.out_h * desc.out_w * cout * desc.kh * desc.kw * c_count
   _note_bytes('igemm_dgrad', desc.batch * desc.out_h * desc.out_w * cout + cout * desc.kh * desc.kw * c_count +
               desc.batch * desc.in_h * desc.in_w * c_count)
+  desc.dy_dtype, desc.out_dtype = _dt(dy), _dt(dx)
   _timed('igemm_dgrad', flops, lambda: call(
-    'sg2im_conv2d_backward_data', byref(desc), _f(weight), int(cout), _f(dy), int(ld_dy), int(c_begin),
-    int(c_count), _f(dx), int(ld_dx), int(accumulate), _f(ws), ws.numel() * 4, _stream()))
+    'sg2im_conv2d_backward_data', byref(desc), _f(weight), int(cout), _fb(dy), int(ld_dy), int(c_begin),
+    int(c_count), _fb(dx), int(ld_dx), int(accumulate), _f(ws), ws.numel() * 4, _stream()))
   return dx
 
 
@@ -449,6 +471,7 @@ def conv2d_backward_data_act(desc, weight, cout, dy, ld_dy, c_begin, c_count, dx
   flops = 2.0 * desc.batch * desc.out_h * desc.out_w * cout * desc.kh * desc.kw * c_count
   _note_bytes('igemm_dgrad', desc.batch * desc.out_h * desc.out_w * cout + cout * desc.kh * desc.kw * c_count +
               2 * desc.batch * desc.in_h * desc.in_w * c_count)
+  desc.dy_dtype, desc.out_dtype = 0, 0
   _timed('igemm_dgrad', flops, lambda: call(
     'sg2im_conv2d_backward_data_act', byref(desc), _f(weight), int(cout), _f(dy), int(ld_dy), int(c_begin),
     int(c_count), _f(dx), int(ld_dx), _f(act), int(ld_act), float(slope), _f(ws), ws.numel() * 4, _stream()))
@@ -460,8 +483,9 @@ def conv2d_backward_weight(desc, dy, ld_dy, cout, dweight, accumulate=False, dbi
   ws = workspace(dweight.device)
   flops = 2.0 * desc.batch * desc.out_h * desc.out_w * cout * _desc_k(desc)
   _note_bytes('igemm_wgrad', _desc_src_floats(desc) + desc.batch * desc.out_h * desc.out_w * cout + cout * _desc_k(desc))
+  desc.dy_dtype = _dt(dy)
   _timed('igemm_wgrad', flops, lambda: call(
-    'sg2im_conv2d_backward_weight', byref(desc), _f(dy), int(ld_dy), int(cout), _f(dweight),
+    'sg2im_conv2d_backward_weight', byref(desc), _fb(dy), int(ld_dy), int(cout), _f(dweight),
     _f(dbias) if dbias is not None else None, int(accumulate), _f(ws), ws.numel() * 4, _stream()))
   return dweight
 
@@ -943,8 +967,9 @@ def conv2d_forward_bn(desc, weight, cout, bias, out, ld_out, bn, training, eps=1
   a.count, a.count_unit = (cp.value if cp is not None else None), cu
   flops = 2.0 * M * cout * _desc_k(desc)
   _note_bytes('igemm_fwd', _desc_src_floats(desc) + cout * _desc_k(desc) + M * cout)
+  desc.out_dtype = _dt(out)
   _timed('igemm_fwd', flops, lambda: call(
-    'sg2im_conv2d_forward_bn', byref(desc), _f(weight), int(cout), _f(bias), float(out_slope), _f(out), int(ld_out),
+    'sg2im_conv2d_forward_bn', byref(desc), _f(weight), int(cout), _f(bias), float(out_slope), _fb(out), int(ld_out),
     _f(ws), ws.numel() * 4, byref(a), _stream()), bn_finish=True,
     # (3 partial planes per 128-row tile and channel read once; mean / invstd / scale / shift + 2 running statistics written)
     finish_bytes=4.0 * (3 * cout * ((M + 127) // 128) + 6 * cout))
@@ -964,6 +989,8 @@ def conv2d_backward_data_bn(desc, weight, cout, dy, ld_dy, c_begin, c_count, dx,
   coef = torch.empty(3 * c_count, dtype=torch.float32, device=dx.device)
   a = BnBwd()
   a.y, a.ld_y, a.pool2 = y.data_ptr(), int(ld_y), int(pool2)
+  a.y_dtype = _dt(y)
+  desc.dy_dtype, desc.out_dtype = _dt(dy), _dt(dx)
   a.gamma = _ptr(gamma)
   a.mean, a.invstd, a.scale, a.shift = st.mean.data_ptr(), st.invstd.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr()
   a.slope, a.training = float(slope), int(training)
@@ -975,14 +1002,21 @@ def conv2d_backward_data_bn(desc, weight, cout, dy, ld_dy, c_begin, c_count, dx,
   _note_bytes('igemm_dgrad', desc.batch * desc.out_h * desc.out_w * cout + cout * desc.kh * desc.kw * c_count +
               rows_dx * c_count)
   _timed('igemm_dgrad', flops, lambda: call(
-    'sg2im_conv2d_backward_data_bn', byref(desc), _f(weight), int(cout), _f(dy), int(ld_dy), int(c_begin), int(c_count),
-    _f(dx), int(ld_dx), _f(ws), ws.numel() * 4, byref(a), _stream()), bn_finish=True,
+    'sg2im_conv2d_backward_data_bn', byref(desc), _f(weight), int(cout), _fb(dy), int(ld_dy), int(c_begin), int(c_count),
+    _fb(dx), int(ld_dx), _f(ws), ws.numel() * 4, byref(a), _stream()), bn_finish=True,
     finish_bytes=4.0 * (2 * c_count * ((rows_dx + 127) // 128) + 5 * c_count))     # (2 planes read; coef[3] + dgamma + dbeta written)
   return coef
 
 
-def bn_backward_apply(g, ld_g, pool2, batch, h, w, y, ld_y, C, st, slope, coef, dy, count=None):
-  """dy = coef[0] * du + coef[1] * y + coef[2] (the third pass of bn_act_backward; g is a raw pointer)"""
+def bn_backward_apply(g, ld_g, pool2, batch, h, w, y, ld_y, C, st, slope, coef, dy, count=None, g_dtype=0):
+  """dy = coef[0] * du + coef[1] * y + coef[2] (the third pass of bn_act_backward; g is a raw pointer, g_dtype its
+  storage type).  Any of g / y / dy in bfloat16 storage: sg2im_bn_backward_apply_ex."""
+  if g_dtype or _dt(y) or _dt(dy):
+    if count is not None:
+      raise ValueError('bfloat16 storage has no padded-batch form of the BatchNorm backward')
+    call('sg2im_bn_backward_apply_ex', g, int(ld_g), int(pool2), int(batch), int(h), int(w), _fb(y), int(ld_y), int(C),
+         _f(st.scale), _f(st.shift), float(slope), _f(coef), _fb(dy), int(g_dtype), _dt(y), _dt(dy), _stream())
+    return dy
   cp, cu = _count_args(count)
   call('sg2im_bn_backward_apply', g, int(ld_g), int(pool2), int(batch), int(h), int(w), _f(y), int(ld_y), int(C),
        _f(st.scale), _f(st.shift), float(slope), _f(coef), _f(dy), cp, cu, _stream())

@@ -15,6 +15,7 @@ Differences from the reference that do not change the mathematics:
     over its flat gradient arena and scaled by 1/world_size inside the Adam kernel.
 """
 import collections
+import itertools
 import math
 import os
 import time
@@ -617,9 +618,17 @@ class Trainer(object):
       for flat in (self.flat_g, self.flat_do, self.flat_di):
         if flat is not None:
           self.reducer.staging(flat.grad)
+      # (every slice that ANY subset of the early buckets can leave for the final exchange: a bucket whose weight
+      # gradients are not all among the released launches is never reported complete - ops.release_deferred - and its
+      # range then travels with the remainder)
       early = [(a, b) for a, b, _ in self._generator_buckets()]
-      for a, b in early + complement(early, self.flat_g.numel):
-        self.reducer.staging(self.flat_g.grad[a:b])
+      seen = set()
+      for k in range(len(early) + 1):
+        for sent in itertools.combinations(early, k):
+          for a, b in list(sent) + complement(list(sent), self.flat_g.numel):
+            if (a, b) not in seen:
+              seen.add((a, b))
+              self.reducer.staging(self.flat_g.grad[a:b])
     if self.weight_mirror and self.flat_g.mirror is None:
       self.flat_g.refresh_mirror()   # (allocates the mirror outside the capture)
     ops.unit(dev)                    # (cached process-wide: must not be born inside a capture)
@@ -883,7 +892,7 @@ class Trainer(object):
       if dp and self.rank == 0:
         self._log_schedule(
           ('2: all-reduces recorded inside the iteration graph, generator in %d bucket(s)%s' % (
-            len(sent) + 1, '')) if ingraph else
+            len(sent) + len(rest), '')) if ingraph else
           ('%d requested, running 0 (iteration graph -> exposed all-reduces -> Adam graph): in-graph collectives need '
            'RCCL and an unmuted reducer' % self.dp_schedule) if self.dp_schedule == 2 else
           '0: iteration graph -> exposed all-reduces -> Adam graph')

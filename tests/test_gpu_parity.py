@@ -19,6 +19,7 @@ Tolerances (fp32 throughout, stated per SURVEY.md section 8c):
 import os
 
 import pytest
+from ctypes import c_void_p
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -174,6 +175,96 @@ def test_bf16_weight_mirror_is_bit_identical(N, H, W, C0, C1, Cout):
     ops.WEIGHT_MIRROR, ops.WEIGHT_MIRROR_LOOKUP = keep
   assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
   assert float(res[0][0].abs().max()) > 0.1 and float(res[0][1].abs().max()) > 0.01
+
+
+def _bf(t):
+  return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _close_bf16(got, want, what, frac=0.02):
+  """a bfloat16-STORED result against its emulation: the two fp32 values in front of the rounding differ by summation
+  order (1e-6), so a few elements land on the other side of a rounding boundary - every element within one bf16 ulp
+  (2^-7 relative) + 1e-6 of the tensor's max, at most `frac` of them not bit-equal"""
+  got, want = got.float().cpu(), want.float().cpu()
+  tol = want.abs() * 2.0 ** -7 + 1e-6 * float(want.abs().max())
+  bad = (got - want).abs() > tol
+  assert not bool(bad.any()), (what, int(bad.sum()), float((got - want).abs().max()))
+  assert float((got != want).float().mean()) <= frac, (what, float((got != want).float().mean()))
+
+
+@pytest.mark.parametrize('N,H,W,C0,C1,Cout', [(8, 32, 32, 64, 0, 64), (4, 32, 32, 96, 64, 128), (2, 64, 64, 160, 128, 64),
+                                              (3, 12, 32, 80, 48, 48), (2, 6, 64, 64, 64, 64)])
+def test_bf16_storage_kernels_match_their_emulation(N, H, W, C0, C1, Cout):
+  """bfloat16 STORAGE (ABI 10: sg2im_src.dtype, sg2im_conv_desc.out_dtype / dy_dtype, sg2im_bn_bwd.y_dtype,
+  sg2im_bn_backward_apply_ex) of the refinement network's chain, op by op against torch on the same rounded values:
+  forward with BatchNorm statistics (a float32 source + an upsampled bfloat16 source with a pending affine -> bfloat16
+  y; statistics of the UNROUNDED accumulators), data gradient with the BatchNorm-backward sums (bfloat16 dY -> bfloat16
+  gz, y read as bfloat16), the apply pass (bf16 in / out, fp32 arithmetic), weight gradient (bf16 X and dY -> fp32 dW)."""
+  from sg2im_amd import ops
+  from tools.gpu_check import _Bn
+  import torch.nn.functional as F
+  D = torch.device('cuda', 0)
+  g = torch.Generator().manual_seed(N * 131 + H + Cout)
+  slope = 0.2
+  x0 = torch.randn(N, C0, H, W, generator=g)                             # float32 source (the layout level)
+  nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(D)
+  srcs, xs = [ops.nhwc_src(nhwc(x0))], [x0]
+  if C1:
+    x1 = _bf(torch.randn(N, C1, H // 2, W // 2, generator=g))            # bfloat16-stored previous features
+    sc, sh = torch.rand(C1, generator=g) + 0.5, torch.randn(C1, generator=g) * 0.3
+    srcs.append(ops.nhwc_src(nhwc(x1).to(torch.bfloat16), 1, sc.to(D), sh.to(D), slope))
+    xs.append(F.interpolate(F.leaky_relu(x1 * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), slope), scale_factor=2, mode='nearest'))
+  X = torch.cat(xs, 1)
+  Cin = C0 + C1
+  Wt = torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5
+  b = torch.randn(Cout, generator=g)
+  Wp = Wt.permute(0, 2, 3, 1).contiguous().to(D)
+  bn = _Bn(Cout, g)
+  d = ops.conv_desc(srcs, N, H, W, 3, 3, 1, 1, compute=1)
+  y = torch.empty(N, H, W, Cout, dtype=torch.bfloat16, device=D)
+  st = ops.conv2d_forward_bn(d, Wp, Cout, b.to(D), y, Cout, bn, True, 1e-5, 0.1)
+  y_acc = F.conv2d(_bf(X), _bf(Wt), b, padding=1)
+  _close_bf16(y.permute(0, 3, 1, 2), _bf(y_acc), 'y')
+  mean, var = y_acc.mean((0, 2, 3)), y_acc.var((0, 2, 3), unbiased=False)
+  assert float((st.mean.cpu() - mean).abs().max()) <= 1e-4 * float(mean.abs().max() + 1.0)
+  assert float((st.invstd.cpu() - (var + 1e-5).rsqrt()).abs().max()) <= 1e-4 * float((var + 1e-5).rsqrt().max())
+  # data gradient w.r.t. the bfloat16 source's channels, with the sums of the BatchNorm that produced it ... here: a
+  # BatchNorm'd layer `yp` (bfloat16, same resolution) whose activated output fed channels [C0, C0 + Cq) of this conv
+  Cq = C0                                                                 # gradient of the first C0 channels
+  yp = _bf(torch.randn(N, Cq, H, W, generator=g))
+  bnp = _Bn(Cq, g)
+  stp = ops.BnState(Cq, D)
+  mu, iv = yp.mean((0, 2, 3)), (yp.var((0, 2, 3), unbiased=False) + 1e-5).rsqrt()
+  gam, bet = bnp.weight.cpu(), bnp.bias.cpu()
+  stp.mean.copy_(mu); stp.invstd.copy_(iv); stp.scale.copy_(gam * iv); stp.shift.copy_(bet - mu * gam * iv)
+  dy = _bf(torch.randn(N, Cout, H, W, generator=g))
+  gz = torch.empty(N, H, W, Cq, dtype=torch.bfloat16, device=D)
+  dgam, dbet = torch.zeros(Cq, device=D), torch.zeros(Cq, device=D)
+  coef = ops.conv2d_backward_data_bn(d, Wp, Cout, nhwc(dy).to(torch.bfloat16), Cout, 0, Cq, gz, Cq, nhwc(yp).to(torch.bfloat16), Cq,
+                                     0, bnp.weight, stp, slope, True, dgam, dbet)
+  gz_acc = torch.nn.grad.conv2d_input((N, Cin, H, W), _bf(Wt), dy, padding=1)[:, :Cq]
+  _close_bf16(gz.permute(0, 3, 1, 2), _bf(gz_acc), 'gz')
+  u = yp * (gam * iv).view(1, -1, 1, 1) + (bet - mu * gam * iv).view(1, -1, 1, 1)
+  du = gz_acc * torch.where(u > 0, torch.ones(()), torch.full((), slope))
+  xhat = (yp - mu.view(1, -1, 1, 1)) * iv.view(1, -1, 1, 1)
+  s0, s1 = du.sum((0, 2, 3)), (du * xhat).sum((0, 2, 3))
+  assert float((dbet.cpu() - s0).abs().max()) <= 1e-3 * float(s0.abs().max() + 1e-3)
+  assert float((dgam.cpu() - s1).abs().max()) <= 1e-3 * float(s1.abs().max() + 1e-3)
+  # the apply pass on the STORED gradient
+  dyp = ops.bn_backward_apply(c_void_p(gz.data_ptr()), Cq, 0, N, H, W, nhwc(yp).to(torch.bfloat16), Cq, Cq, stp, slope, coef,
+                              torch.empty(N, H, W, Cq, dtype=torch.bfloat16, device=D), g_dtype=1)
+  M = N * H * W
+  gzs = gz.permute(0, 3, 1, 2).float().cpu()
+  dus = gzs * torch.where(u > 0, torch.ones(()), torch.full((), slope))
+  want = (gam * iv).view(1, -1, 1, 1) * (dus - (s0 / M).view(1, -1, 1, 1) - xhat * (s1 / M).view(1, -1, 1, 1))
+  _close_bf16(dyp.permute(0, 3, 1, 2), _bf(want), 'dy (apply)', frac=0.05)
+  # weight gradient: bfloat16 X (second source) and dY
+  if W % 16 == 0 and H % 4 == 0:
+    dW = torch.zeros(Cout, 3, 3, Cin, device=D)
+    ops.conv2d_backward_weight(d, nhwc(dy).to(torch.bfloat16), Cout, Cout, dW)
+    want_w = torch.nn.grad.conv2d_weight(_bf(X), Wt.shape, dy, padding=1)
+    e = float((dW.permute(0, 3, 1, 2).cpu() - want_w).abs().max()) / float(want_w.abs().max())
+    assert e <= 1e-4, e
 
 
 def test_layout_and_crops():
