@@ -46,6 +46,7 @@ LOSS_WEIGHTS = dict(l1_pixel_loss_weight=1.0, bbox_pred_loss_weight=10.0, predic
 
 
 SHARE_FAKE_PASS = os.environ.get('SG2IM_SHARE_FAKE_PASS', '1') != '0'      # (A/B knob)
+EARLY_ADAM_REST = os.environ.get('SG2IM_EARLY_ADAM_REST', '1') != '0'      # (A/B knob, Trainer._seg_generator_backward)
 
 # 'thread_local': other threads (the RCCL watchdog polls events) may call into HIP while this
 # thread captures; the default 'global' mode treats that as a capture error
@@ -334,12 +335,19 @@ class Trainer(object):
     """train.py:524-530: the generator itself; `imgs_fake` is all the discriminator steps need"""
     imgs, objs, boxes, masks, triples, obj_to_img = batch[:6]
     ops.mark('start')
-    if self.weight_mirror:
-      self.flat_g.refresh_mirror()
     st['imgs_nhwc'] = HF.NchwToNhwc.apply(imgs)
     # captured iteration: whatever is not on the path to the image leaves the critical path (Sg2ImModel.forward_nhwc)
     aux = self._side[0] if (self._side is not None and torch.cuda.is_current_stream_capturing() and
                             os.environ.get('SG2IM_AUX', '1') != '0' and not ops.SINGLE_STREAM) else None      # (A/B knob)
+    if self.weight_mirror:
+      if aux is not None:
+        # (28 us over the 120 MB arena: next to the graph-convolution phase on the aux stream - forward_nhwc joins that
+        # stream in front of the layout, long before the first convolution that reads the mirror)
+        aux.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(aux):
+          self.flat_g.refresh_mirror()
+      else:
+        self.flat_g.refresh_mirror()
     w = self.w
     st['gen_out'] = self.model.forward_nhwc(objs, triples, obj_to_img, boxes_gt=boxes, masks_gt=masks,
                                             num_images=imgs.size(0), obj_count=st.get('ocnt'),
@@ -430,6 +438,15 @@ class Trainer(object):
     finally:
       lanes, ops.DEFERRED = ops.DEFERRED, None
     ops.mark('g_bwd_done')
+    early = st.get('g_adam_early')
+    if early is not None and st.get('g_adam_prepared') and EARLY_ADAM_REST:
+      # every gradient outside the refinement network's slice is complete HERE (the slice itself is updated at the end
+      # of the weight-gradient lane): update the rest now, under the lane's remaining weight gradients, instead of
+      # behind the join (two of the four Adam launches that used to end the iteration)
+      gs = self.reducer.grad_scale
+      self.opt_g.apply_guarded(0, early[0], gs)
+      self.opt_g.apply_guarded(early[1], self.flat_g.numel, gs)
+      st['g_adam_done'] = True
     for lane in lanes or ():
       lane.join()
 
@@ -472,7 +489,9 @@ class Trainer(object):
     # no forward/backward above reads another network's *updated* parameters
     gs, guard = self.reducer.grad_scale, st['guard']
     early = st.get('g_adam_early')
-    if early is not None:            # (captured iteration: [a, b) was updated under the weight gradients already)
+    if st.get('g_adam_done'):        # (captured iteration: the whole arena was updated inside the backward segment)
+      pass
+    elif early is not None:          # (captured iteration: [a, b) was updated under the weight gradients already)
       self.opt_g.apply_guarded(0, early[0], gs)
       self.opt_g.apply_guarded(early[1], self.flat_g.numel, gs)
     else:
