@@ -1585,7 +1585,9 @@ static hipError_t prepare_wgrad_halo() {
   if (g_wgrad_halo_ready) return hipSuccess;
   hipError_t e = ensure_lds(conv_wgrad_halo_kernel<4, 16>, wgrad_halo_lds<4, 16>());
   if (e == hipSuccess) e = ensure_lds(conv_wgrad_halo_kernel<8, 8>, wgrad_halo_lds<8, 8>());
-  if (e == hipSuccess) e = ensure_lds(conv_wgrad_halo_h_kernel, wgrad_halo_h_lds());
+#define SG2IM_WGH(XB_, YB_) if (e == hipSuccess) e = ensure_lds(conv_wgrad_halo_h_kernel<XB_, YB_>, wgrad_halo_h_lds())
+  SG2IM_WGH(0, false); SG2IM_WGH(1, false); SG2IM_WGH(2, false); SG2IM_WGH(0, true); SG2IM_WGH(1, true); SG2IM_WGH(2, true);
+#undef SG2IM_WGH
   if (e == hipSuccess) g_wgrad_halo_ready = true;
   return e;
 }
@@ -1724,41 +1726,34 @@ static bool halo_plan(int NB, int H, int W, int ncols, int nchunks, size_t ws_by
   return true;
 }
 
-// A/B knobs of the bf16 halo'd kernels: SG2IM_HALO_TG = taps per staging group of the weight-mirror kernels (1, 3, 9:
-// conv_halo.h; default 3), SG2IM_HALO9 = 1 the nine-tap form also without a mirror, SG2IM_HALO_WB = 0 ignores the mirror
-static const bool g_halo9 = getenv("SG2IM_HALO9") && atoi(getenv("SG2IM_HALO9")) != 0;
+// A/B knobs of the bf16 halo'd kernels: SG2IM_HALO_TG = taps per staging group of the weight-mirror kernels (1 or 3:
+// conv_halo.h; default 3 - the nine-tap form measured slower and is not instantiated), SG2IM_HALO_WB = 0 ignores the mirror
 static const bool g_halo_wb = !(getenv("SG2IM_HALO_WB") && atoi(getenv("SG2IM_HALO_WB")) == 0);
 static const int g_halo_tg = getenv("SG2IM_HALO_TG") ? atoi(getenv("SG2IM_HALO_TG")) : 3;
-template <int RT, int CT, int BN, bool DG, bool ST, bool H, int TG, bool WB> bool g_halo_ready = false;
-template <int RT, int CT, int BN, bool DG, bool ST, bool H, int TG, bool WB>
-static hipError_t prepare_halo() {
-  constexpr size_t lds = halo_lds<RT, CT, BN, DG, H, TG>();
-  if (g_halo_ready<RT, CT, BN, DG, ST, H, TG, WB>) return hipSuccess;
-  const hipError_t e = ensure_lds(conv_halo_kernel<RT, CT, BN, DG, ST, H, TG, WB>, lds);
-  if (e == hipSuccess) g_halo_ready<RT, CT, BN, DG, ST, H, TG, WB> = true;
-  return e;
-}
-template <int RT, int CT, int BN, bool DG, bool ST, bool H, int TG, bool WB>
+template <int RT, int CT, int BN, bool DG, bool ST, bool H, int TG, bool WB, bool AB>
 static hipError_t launch_halo_v(HaloParams& p, const HaloPlan& pl, hipStream_t st) {
   constexpr size_t lds = halo_lds<RT, CT, BN, DG, H, TG>();
+  static_assert(lds <= 64 * 1024, "the instantiated forms fit the default dynamic-LDS limit");
   dim3 grid((p.N + BN - 1) / BN, pl.patches, pl.nsplit);
-  // (sg2im_init prepares every form that needs > 64 KB of LDS up front; lazily here only for a caller that skipped it)
-  if (lds > 64 * 1024 && !g_halo_ready<RT, CT, BN, DG, ST, H, TG, WB> &&
-      prepare_halo<RT, CT, BN, DG, ST, H, TG, WB>() != hipSuccess) return hipErrorInvalidValue;
-  SG2IM_LAUNCH((conv_halo_kernel<RT, CT, BN, DG, ST, H, TG, WB>), grid, dim3(NTHREADS), lds, st, p);
+  SG2IM_LAUNCH((conv_halo_kernel<RT, CT, BN, DG, ST, H, TG, WB, AB>), grid, dim3(NTHREADS), lds, st, p);
   return hipGetLastError();
 }
 template <int RT, int CT, int BN, bool DG, bool ST, bool H>
 static hipError_t launch_halo_t(HaloParams& p, const HaloPlan& pl, hipStream_t st) {
   if constexpr (H) {
-    if (g_halo_wb && p.Wh != nullptr) {
-      if (g_halo_tg == 9 || g_halo9) return launch_halo_v<RT, CT, BN, DG, ST, true, 9, true>(p, pl, st);
-      if (g_halo_tg == 3) return launch_halo_v<RT, CT, BN, DG, ST, true, 3, true>(p, pl, st);
-      return launch_halo_v<RT, CT, BN, DG, ST, true, 1, true>(p, pl, st);
+    // AB: bfloat16 storage on the A side (forward: any source; data gradient: dY)
+    bool ab = DG ? p.dy_bf != 0 : false;
+    if (!DG) { ConvGeom& g = p.g; for (int i = 0; i < g.nsrc; ++i) ab = ab || src_at(g, i)->bf; }
+    const bool wb = g_halo_wb && p.Wh != nullptr;
+    if (ab) {
+      if (wb && g_halo_tg == 3) return launch_halo_v<RT, CT, BN, DG, ST, true, 3, true, true>(p, pl, st);
+      if (wb) return launch_halo_v<RT, CT, BN, DG, ST, true, 1, true, true>(p, pl, st);
+      return launch_halo_v<RT, CT, BN, DG, ST, true, 1, false, true>(p, pl, st);
     }
-    if (g_halo9) return launch_halo_v<RT, CT, BN, DG, ST, true, 9, false>(p, pl, st);
+    if (wb && g_halo_tg == 3) return launch_halo_v<RT, CT, BN, DG, ST, true, 3, true, false>(p, pl, st);
+    if (wb) return launch_halo_v<RT, CT, BN, DG, ST, true, 1, true, false>(p, pl, st);
   }
-  return launch_halo_v<RT, CT, BN, DG, ST, H, 1, false>(p, pl, st);
+  return launch_halo_v<RT, CT, BN, DG, ST, H, 1, false, false>(p, pl, st);
 }
 // hb: bf16 operands (sg2im_conv_desc.compute_dtype 1)
 template <bool DG, bool ST>
@@ -1806,15 +1801,6 @@ int sg2im_init(void) {
 #undef SG2IM_PREP
   if (e == hipSuccess) e = ensure_lds(conv_wgrad_group_kernel, wgrad_lds<64, 64>());
   if (e == hipSuccess) e = prepare_wgrad_halo();
-#define SG2IM_PREP_HALO9(RT_, CT_) \
-  SG2IM_PREP9((prepare_halo<RT_, CT_, 64, false, false, true, 9, false>())); SG2IM_PREP9((prepare_halo<RT_, CT_, 64, false, true, true, 9, false>())); \
-  SG2IM_PREP9((prepare_halo<RT_, CT_, 64, true, false, true, 9, false>())); SG2IM_PREP9((prepare_halo<RT_, CT_, 64, true, true, true, 9, false>())); \
-  SG2IM_PREP9((prepare_halo<RT_, CT_, 64, false, false, true, 9, true>())); SG2IM_PREP9((prepare_halo<RT_, CT_, 64, false, true, true, 9, true>())); \
-  SG2IM_PREP9((prepare_halo<RT_, CT_, 64, true, false, true, 9, true>())); SG2IM_PREP9((prepare_halo<RT_, CT_, 64, true, true, true, 9, true>()))
-#define SG2IM_PREP9(call) do { if (e == hipSuccess) e = (call); } while (0)
-  SG2IM_PREP_HALO9(2, 64); SG2IM_PREP_HALO9(4, 32); SG2IM_PREP_HALO9(8, 16);
-#undef SG2IM_PREP9
-#undef SG2IM_PREP_HALO9
   if (e == hipSuccess) e = gcn::prepare();          // the persistent GraphTripleConv-stack kernels (gcn_persist.hip)
   if (e != hipSuccess) return SG2IM_ERR_HIP;
   SG2IM_LAUNCH(init_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)0, (int*)nullptr);
@@ -2292,7 +2278,16 @@ int sg2im_conv2d_backward_weight(const sg2im_conv_desc* d, const float* dy, int 
                                 wide ? "4x16" : "8x8", ncb, nkb, nsplit);
       dim3 grid(ncb, nkb, nsplit);
       if (prepare_wgrad_halo() != hipSuccess) return SG2IM_ERR_HIP;
-      if (hb) SG2IM_LAUNCH(conv_wgrad_halo_h_kernel, grid, dim3(NTHREADS), wgrad_halo_h_lds(), stream, q);
+      if (hb) {
+        // storage of the sources: all float32 / all bfloat16 / mixed (template forms of the kernel, wgrad_halo.h)
+        int nbf = 0;
+        for (int i = 0; i < p.g.nsrc; ++i) nbf += src_at(p.g, i)->bf ? 1 : 0;
+        const int xb = nbf == 0 ? 0 : (nbf == p.g.nsrc ? 1 : 2);
+#define SG2IM_WGH(XB_, YB_) SG2IM_LAUNCH((conv_wgrad_halo_h_kernel<XB_, YB_>), grid, dim3(NTHREADS), wgrad_halo_h_lds(), stream, q)
+        if (q.dy_bf) { if (xb == 0) SG2IM_WGH(0, true); else if (xb == 1) SG2IM_WGH(1, true); else SG2IM_WGH(2, true); }
+        else { if (xb == 0) SG2IM_WGH(0, false); else if (xb == 1) SG2IM_WGH(1, false); else SG2IM_WGH(2, false); }
+#undef SG2IM_WGH
+      }
       else if (wide) SG2IM_LAUNCH((conv_wgrad_halo_kernel<4, 16>), grid, dim3(NTHREADS), (wgrad_halo_lds<4, 16>()), stream, q);
       else SG2IM_LAUNCH((conv_wgrad_halo_kernel<8, 8>), grid, dim3(NTHREADS), (wgrad_halo_lds<8, 8>()), stream, q);
       if (hipGetLastError() != hipSuccess) return SG2IM_ERR_HIP;

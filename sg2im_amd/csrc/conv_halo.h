@@ -79,12 +79,16 @@ struct ChunkCursor {
 // kernels.  Same values (RNE either way): bit-identical results.
 // TG = taps per staging group: 1 (rounds 3-5: a barrier pair per tap), 3 (one kernel row: 12 MFMAs per wave between
 // barriers, three weight pieces in flight per thread, ~30 KB of LDS: four workgroups per CU) or 9 (T9 above).
-template <int RT, int CT, int BN, bool DG, bool ST, bool H = false, int TG = 1, bool WB = false>
+// AB (bf16 only, round 6): the A side may hold bfloat16 STORAGE - forward: per source (Src::bf, a wave-uniform branch per
+// chunk), data gradient: dY (HaloParams::dy_bf).  A separate instantiation so that the fp32-storage loaders keep their
+// branch-free basic blocks.
+template <int RT, int CT, int BN, bool DG, bool ST, bool H = false, int TG = 1, bool WB = false, bool AB = false>
 // (the fp32 4 x 32 data-gradient form - 7 halo float4 per thread, maps that 8 x 16 patches do not tile - needs 130
 // registers: three waves per SIMD instead of a spilled offset that is reloaded every chunk)
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(TG == 9 ? 2 : (BN == 64 && CT <= 32) ? ((RT == 4 && ((DG && !H) || (!DG && TG == 3))) ? 3 : SG2IM_HALO_WAVES64) : 2)))
 void conv_halo_kernel(const HaloParams p) {
   static_assert(TG == 1 || (H && (TG == 3 || TG == 9)), "multi-tap staging exists for the bf16 operand path only");
+  static_assert(!AB || H, "bfloat16 storage is read by the bf16 operand path only");
   static_assert(!WB || (H && BN == 64), "the weight mirror is bf16: bf16 operand path, 64-column tiles");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BM = RT * CT;
@@ -166,7 +170,7 @@ void conv_halo_kernel(const HaloParams p) {
   float4 ra[NA];
   Aff aaff;
   unsigned ramask = 0;
-  const BufRsrc rsY = rsrc_of(g.s0.p, (unsigned)p.M * (unsigned)g.s0.ld * (p.dy_bf ? 2u : 4u));     // (DG: dY; out-of-range offset -> zeros)
+  const BufRsrc rsY = rsrc_of(g.s0.p, (unsigned)p.M * (unsigned)g.s0.ld * (AB ? 2u : 4u));     // (DG: dY; out-of-range offset -> zeros)
   int off_src = -1;
   int ra_bf = 0;                                              // the staged halo registers hold bf16 pairs (wave-uniform)
   auto load_A = [&](const ChunkCursor& c) {
@@ -174,14 +178,12 @@ void conv_halo_kernel(const HaloParams p) {
     const bool cok = ch < c.S.C;
     if (off_src != c.s) { pixel_offsets(c.S); off_src = c.s; }        // (wave-uniform: the source changed)
     if (DG) {
-      if constexpr (H) {
-        if (p.dy_bf) {
-          #pragma unroll
-          for (int j = 0; j < NA; ++j)
-            ra[j] = ld2h_buf(rsY, ((amask >> j & 1u) && cok) ? (aoff[j] + (unsigned)ch) << 1 : kOobByte);
-          ra_bf = 1;
-          return;
-        }
+      if constexpr (AB) {
+        #pragma unroll
+        for (int j = 0; j < NA; ++j)
+          ra[j] = ld2h_buf(rsY, ((amask >> j & 1u) && cok) ? (aoff[j] + (unsigned)ch) << 1 : kOobByte);
+        ra_bf = 1;
+        return;
       }
       #pragma unroll
       for (int j = 0; j < NA; ++j)
@@ -189,7 +191,7 @@ void conv_halo_kernel(const HaloParams p) {
     } else {
       fetch_aff(aaff, c.S, ch, cok);
       ramask = cok ? amask : 0u;
-      if constexpr (H) {
+      if constexpr (AB) {
         if (c.S.bf) {                                               // (wave-uniform: the source's storage type)
           #pragma unroll
           for (int j = 0; j < NA; ++j)
@@ -209,7 +211,7 @@ void conv_halo_kernel(const HaloParams p) {
     for (int j = 0; j < NA; ++j) {
       const int hp = r0 + 32 * j;
       float4 v = ra[j];
-      if constexpr (H) { if (ra_bf) v = unpack_bf16x4(v); }
+      if constexpr (AB) { if (DG || ra_bf) v = unpack_bf16x4(v); }
       if (!DG) v = apply_aff(v, aaff, (ramask >> j & 1u) != 0);
       if (NA * 32 <= HP || hp < HP) {
         if constexpr (H) *reinterpret_cast<bf16x4*>(Ash + hp * MLDH + 4 * col4) = to_bf16x4(v);

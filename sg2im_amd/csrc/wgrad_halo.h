@@ -282,6 +282,10 @@ __device__ __forceinline__ bf16x8 read_tr_at(const bf16_t* img, int row0, int co
 #ifndef SG2IM_WGH_WAVES
 #define SG2IM_WGH_WAVES 1         // wavefronts per SIMD the register budget is cut for.  1: 180 + 144 registers, no spill -
 #endif                            // measured faster than 2 (256 registers, 3 reloads per patch): bf16 step 4.39-4.40 vs 4.42-4.43 ms
+// XB: storage of the input sources - 0 every source float32, 1 every source bfloat16, 2 mixed (per-lane loads: a
+// 64-channel block may straddle two sources); YB: dY holds bfloat16.  Template parameters, not run-time flags: a branch
+// inside the loaders splits the stage into basic blocks and cost 30-45 % on every layer (round 6, measured).
+template <int XB, bool YB>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(SG2IM_WGH_WAVES))) void conv_wgrad_halo_h_kernel(const WgHaloParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int RT = 4, CT = 16;
@@ -308,8 +312,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(SG2IM_
   const int Hs = g.H >> XS.up, Ws = g.W >> XS.up;
   const int yk = k0 + 4 * col4;
   const bool yok = yk < p.Cout;
-  const BufRsrc rsY = rsrc_of(p.dY, (unsigned)(g.NB * g.H * g.W) * (unsigned)p.ldy * (p.dy_bf ? 2u : 4u));
-  const bool xbf = XS.bf != 0;                        // (per thread: its four channels' source holds bfloat16)
+  const BufRsrc rsY = rsrc_of(p.dY, (unsigned)(g.NB * g.H * g.W) * (unsigned)p.ldy * (YB ? 2u : 4u));
+  const bool xbf = XB == 1 || (XB == 2 && XS.bf != 0);   // (per thread: its four channels' source holds bfloat16)
 
   float4 rx[NX], ry[NY];
   unsigned rxm = 0;
@@ -328,14 +332,15 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(SG2IM_
       rxm |= (ok ? 1u : 0u) << j;
       const int ayc = min(max(ay, 0), g.H - 1), axc = min(max(ax, 0), g.W - 1);
       const unsigned xo = (unsigned)((nb * Hs + (ayc >> XS.up)) * Ws + (axc >> XS.up)) * (unsigned)XS.ld + (unsigned)xcs;
-      // (a 64-channel block may straddle two sources of different storage types: per-lane choice of the load)
-      if (xbf) rx[j] = ld2h_off(XS.p, xo); else rx[j] = ld4_off(XS.p, xo);
+      if constexpr (XB == 0) rx[j] = ld4_off(XS.p, xo);
+      else if constexpr (XB == 1) rx[j] = ld2h_off(XS.p, xo);
+      else { if (xbf) rx[j] = ld2h_off(XS.p, xo); else rx[j] = ld4_off(XS.p, xo); }
     }
     #pragma unroll
     for (int j = 0; j < NY; ++j) {
       const int q = r0 + 16 * j;
       const int pix = (nb * g.H + y0 + q / CT) * g.W + x0 + q % CT;
-      if (p.dy_bf) ry[j] = ld2h_buf(rsY, yok ? ((unsigned)pix * (unsigned)p.ldy + (unsigned)yk) << 1 : kOobByte);
+      if constexpr (YB) ry[j] = ld2h_buf(rsY, yok ? ((unsigned)pix * (unsigned)p.ldy + (unsigned)yk) << 1 : kOobByte);
       else ry[j] = ld4_buf(rsY, yok ? ((unsigned)pix * (unsigned)p.ldy + (unsigned)yk) << 2 : kOobByte);     // (zeros when !yok)
     }
   };
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(SG2IM_
     #pragma unroll
     for (int j = 0; j < NY; ++j) {
       const int q = r0 + 16 * j;
-      if (p.dy_bf) ry[j] = unpack_bf16x4(ry[j]);
+      if constexpr (YB) ry[j] = unpack_bf16x4(ry[j]);
       if (want_db) { dbs.x += ry[j].x; dbs.y += ry[j].y; dbs.z += ry[j].z; dbs.w += ry[j].w; }     // (the bias gradient sums the fp32 dY)
       *reinterpret_cast<bf16x4*>(img + q * WGH_LD + 4 * col4) = to_bf16x4(ry[j]);
     }
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(SG2IM_
       const int hp = r0 + 16 * j;
       if (NX * 16 <= HP || hp < HP)
         *reinterpret_cast<bf16x4*>(img + (PX + hp) * WGH_LD + 4 * col4) =
-          to_bf16x4(apply_aff(xbf ? unpack_bf16x4(rx[j]) : rx[j], xaff, (rxm >> j & 1u) != 0));
+          to_bf16x4(apply_aff(XB == 0 ? rx[j] : XB == 1 ? unpack_bf16x4(rx[j]) : (xbf ? unpack_bf16x4(rx[j]) : rx[j]), xaff, (rxm >> j & 1u) != 0));
     }
   };
 
