@@ -54,8 +54,9 @@ def parse():
                   help='distinct synthetic batches (seeds seed+rank+1000*i) cycled through by the timed loop')
   ap.add_argument('--bucket', default='32,64', help='object,triple padding multiples of the hipGraph shape buckets')
   ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
-                  help="'bf16': spatial convolutions on the bf16 matrix cores (bf16-rounded operands, fp32 accumulation, fp32 "
-                       "tensors) - BASELINE configs[2..4]; a SECONDARY line, the headline metric is quoted in fp32")
+                  help="'bf16': spatial convolutions on the bf16 matrix cores (bf16-rounded operands, fp32 accumulation, bf16 weight "
+                       "mirror, bfloat16 storage of the refinement chain) - BASELINE configs[2..4]; a SECONDARY line, the headline "
+                       "metric is quoted in fp32")
   ap.add_argument('--style', default='coco', choices=['coco', 'vg'],
                   help="'vg': VG-shape graphs without GT masks (BASELINE configs[2] shape, fp32) instead of the COCO headline workload")
   ap.add_argument('--refinement_dims', default=None,
@@ -476,7 +477,8 @@ def main():
                                    graph_launch_min=round(launch_samples[0] * 1e3, 3) if launch_samples else None),
       'higher_is_better': True, 'scaling': 'weak',
       'vs_baseline': None,
-      'dtype': 'f32' if args.dtype == 'f32' else 'bf16 (matrix-core operands of the spatial convolutions; fp32 accumulation, tensors, statistics and Adam)',
+      'dtype': 'f32' if args.dtype == 'f32' else 'bf16 (matrix-core operands of the spatial convolutions, bf16 weight mirror, bfloat16 storage of the refinement '
+               'chain on the unsplit levels; fp32 accumulation, statistics, losses, master weights and Adam)',
       'data': 'synthetic',
       'config': {'workload': ('COCO-%d synthetic scene graphs (%d-%d objects + __image__, <=%d triples per image), ' % (
                                 S, args.min_objs or 3, args.max_objs or 8, 2 * (args.max_objs or 8))
