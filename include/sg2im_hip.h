@@ -65,7 +65,9 @@ typedef struct sg2im_src {
   int dtype;                /* 0: `data` holds float; 1 (ABI 10): bfloat16 STORAGE - `data` points at bfloat16 elements (same
                              * NHWC layout, `ld` counts elements).  Only the bf16 halo'd 3x3 kernels read it (compute_dtype 1,
                              * stride 1, pad 1, maps that 128-pixel patches tile, no split-K: sg2im_conv_halo_unsplit);
-                             * every other launch returns SG2IM_ERR_ARG instead of misreading the tensor. */
+                             * every other launch returns SG2IM_ERR_ARG instead of misreading the tensor.  A bfloat16 source
+                             * must be readable 16 bytes past its last element (the weight gradient over sources of
+                             * mixed types loads 16 bytes per lane where a bfloat16 lane needs 8). */
 } sg2im_src;
 
 typedef struct sg2im_conv_desc {

@@ -334,7 +334,14 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(SG2IM_
       const unsigned xo = (unsigned)((nb * Hs + (ayc >> XS.up)) * Ws + (axc >> XS.up)) * (unsigned)XS.ld + (unsigned)xcs;
       if constexpr (XB == 0) rx[j] = ld4_off(XS.p, xo);
       else if constexpr (XB == 1) rx[j] = ld2h_off(XS.p, xo);
-      else { if (xbf) rx[j] = ld2h_off(XS.p, xo); else rx[j] = ld4_off(XS.p, xo); }
+      else {
+        // mixed block: ONE 16-byte load per lane at a per-lane BYTE offset (a bfloat16 lane fetches 8 elements and uses
+        // the first four) - no per-lane branch around the loads.  A bfloat16 source must therefore be readable 8 bytes
+        // past its last element (include/sg2im_hip.h; sg2im_amd.functional._new_s allocates the slack).
+        unsigned bo = xbf ? xo << 1 : xo << 2;
+        asm volatile("" : "+v"(bo));
+        rx[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(XS.p) + (size_t)bo);
+      }
     }
     #pragma unroll
     for (int j = 0; j < NY; ++j) {

@@ -26,7 +26,13 @@ def _new(like, *shape):
 def _new_s(like, bf, *shape):
   """a tensor of the refinement network's chain in its STORAGE type: bfloat16 where the layer qualifies (see
   _storage_levels), float32 otherwise"""
-  return torch.empty(*shape, dtype=torch.bfloat16 if bf else torch.float32, device=like.device)
+  if not bf:
+    return torch.empty(*shape, dtype=torch.float32, device=like.device)
+  n = 1
+  for d in shape:
+    n *= int(d)
+  # (8 elements of slack: the mixed-storage weight gradient loads 16 bytes where it needs 8, include/sg2im_hip.h)
+  return torch.empty(n + 8, dtype=torch.bfloat16, device=like.device)[:n].view(*shape)
 
 
 # A/B knob: 0 = every tensor of the bf16 mode stays float32 in memory (rounds 2-5: operand rounding only)

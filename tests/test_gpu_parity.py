@@ -181,6 +181,14 @@ def _bf(t):
   return t.to(torch.bfloat16).to(torch.float32)
 
 
+def _bf_store(t):
+  """a bfloat16-STORAGE copy of a device tensor, readable 16 bytes past its end (include/sg2im_hip.h, sg2im_src.dtype)"""
+  buf = torch.empty(t.numel() + 8, dtype=torch.bfloat16, device=t.device)
+  v = buf[:t.numel()].view(t.shape)
+  v.copy_(t)
+  return v
+
+
 def _close_bf16(got, want, what, frac=0.02):
   """a bfloat16-STORED result against its emulation: the two fp32 values in front of the rounding differ by summation
   order (1e-6), so a few elements land on the other side of a rounding boundary - every element within one bf16 ulp
@@ -212,7 +220,7 @@ def test_bf16_storage_kernels_match_their_emulation(N, H, W, C0, C1, Cout):
   if C1:
     x1 = _bf(torch.randn(N, C1, H // 2, W // 2, generator=g))            # bfloat16-stored previous features
     sc, sh = torch.rand(C1, generator=g) + 0.5, torch.randn(C1, generator=g) * 0.3
-    srcs.append(ops.nhwc_src(nhwc(x1).to(torch.bfloat16), 1, sc.to(D), sh.to(D), slope))
+    srcs.append(ops.nhwc_src(_bf_store(nhwc(x1)), 1, sc.to(D), sh.to(D), slope))
     xs.append(F.interpolate(F.leaky_relu(x1 * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), slope), scale_factor=2, mode='nearest'))
   X = torch.cat(xs, 1)
   Cin = C0 + C1

@@ -14,6 +14,9 @@ NB = 32
 PLAIN = '--plain' in sys.argv
 WGRAD_ONLY = '--wgrad' in sys.argv          # time the weight gradients only
 BF16 = '--bf16' in sys.argv                  # bfloat16 operands on the 32x32x16 MFMA (Trainer(compute_dtype='bf16'))
+MIRROR = '--mirror' in sys.argv              # (with --bf16) weights read from a bfloat16 mirror (sg2im_conv_desc.weight_bf16)
+STORAGE = '--storage' in sys.argv            # (with --bf16) feature sources, outputs and gradients in bfloat16 STORAGE where the
+                                             # halo'd kernels run the layer (3x3 convolutions on maps >= 16 x 16); implies --mirror
 ONLY = [a[7:].split(',') for a in sys.argv if a.startswith('--only=')]      # --only=m3,m4,out: layer name prefixes
 LAYERS = [  # name, H, C0, C1(up), Cout, k, stride, pad
   ('m0.conv0', 4, 160, 1, 1024, 3, 1, 1), ('m0.conv1', 4, 1024, 0, 1024, 3, 1, 1),
@@ -45,9 +48,23 @@ def timeit(fn, iters=10):
   return a.elapsed_time(b) / iters
 
 
+def _st(t, dt):
+  """t in storage type dt (bfloat16: with the 16 bytes of slack sg2im_src.dtype asks for)"""
+  if dt != torch.bfloat16:
+    return t
+  buf = torch.empty(t.numel() + 8, dtype=dt, device=t.device)
+  v = buf[:t.numel()].view(t.shape)
+  v.copy_(t)
+  return v
+
+
 def main():
   if BF16:
     ops.CONV_COMPUTE = 1
+  mirrors = {}
+  if BF16 and (MIRROR or STORAGE):
+    ops.WEIGHT_MIRROR = True
+    ops.WEIGHT_MIRROR_LOOKUP = lambda w: mirrors[w.data_ptr()].data_ptr() if w.data_ptr() in mirrors else None
   tot = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
   totf = 0.0
   print('%-10s %9s | %8s %7s | %8s %7s | %8s %7s' % ('layer', 'GFLOP', 'fwd ms', 'TF/s', 'dgrad ms', 'TF/s', 'wgrad ms', 'TF/s'))
@@ -60,28 +77,34 @@ def main():
     # as in the network: the previous layer's BatchNorm + LeakyReLU is PENDING on the feature source (applied by the
     # operand loader); the layout levels are plain.  --plain: no pending affine anywhere
     aff = lambda C: (None, None, 1.0) if PLAIN else (torch.rand(C, device=D) + 0.5, torch.randn(C, device=D) * 0.1, 0.2)
+    # --storage: the tensors a bf16-storage step keeps in bfloat16 (3x3 layers of the refinement network on maps the
+    # halo'd kernels tile; the layout levels - a first source next to an upsampled one - stay float32)
+    st_layer = BF16 and STORAGE and k == 3 and s == 1 and H >= 16 and name[0] in 'mo'
+    sdt = torch.bfloat16 if st_layer else torch.float32
     if C0:
       sc, sh, sl = aff(C0) if (C1 == 0 and k == 3 and s == 1) else (None, None, 1.0)
-      srcs.append(ops.nhwc_src(torch.randn(N, H, H, C0, device=D), 0, sc, sh, sl))
+      srcs.append(ops.nhwc_src(_st(torch.randn(N, H, H, C0, device=D), sdt if C1 == 0 else torch.float32), 0, sc, sh, sl))
     if C1 > 1:
       sc, sh, sl = aff(C1)
-      srcs.append(ops.nhwc_src(torch.randn(N, H // 2, H // 2, C1, device=D), 1, sc, sh, sl))
+      srcs.append(ops.nhwc_src(_st(torch.randn(N, H // 2, H // 2, C1, device=D), sdt), 1, sc, sh, sl))
     # (C1 == 1: the first refinement module - the all-zero feature channel is left out, the weight rows keep it)
     d = ops.conv_desc(srcs, N, H, H, k, k, s, p, weight_channels=C0 + C1 if C1 == 1 else 0)
     Ct = C0 + C1
     W = torch.randn(Cout, k, k, Ct, device=D) * 0.01
+    if BF16 and (MIRROR or STORAGE) and k == 3:
+      mirrors[W.data_ptr()] = torch.cat([W.reshape(-1).to(torch.bfloat16), torch.zeros(16, dtype=torch.bfloat16, device=D)])
     b = torch.randn(Cout, device=D)
-    y = torch.empty(N, d.out_h, d.out_w, Cout, device=D)
-    gy = torch.randn_like(y)
+    y = torch.empty(N, d.out_h, d.out_w, Cout, device=D, dtype=sdt)
+    gy = torch.randn(N, d.out_h, d.out_w, Cout, device=D).to(sdt)
     Cx = C0 if C1 == 1 else Ct
-    dx = torch.empty(N, H, H, Cx, device=D)
+    dx = torch.empty(N, H, H, Cx, device=D, dtype=sdt)
     dw = torch.empty_like(W)
     gf = 2.0 * N * d.out_h * d.out_w * Cout * Ct * k * k / 1e9
     t1 = 1e-9 if WGRAD_ONLY else timeit(lambda: ops.conv2d_forward(d, W, Cout, b, y, Cout))
     if WGRAD_ONLY:
       t2 = 1e-9
     elif C1 > 1:       # as the network issues it: the layout channels (128 of 160 need gradients) and the feature channels
-      dl, dz = torch.empty(N, H, H, 128, device=D), torch.empty(N, H, H, C1, device=D)
+      dl, dz = torch.empty(N, H, H, 128, device=D), torch.empty(N, H, H, C1, device=D, dtype=sdt)
       t2 = timeit(lambda: (ops.conv2d_backward_data(d, W, Cout, gy, Cout, 0, 128, dl, 128),
                            ops.conv2d_backward_data(d, W, Cout, gy, Cout, C0, C1, dz, C1)))
       t2 *= Ct / float(128 + C1)       # (per FLOP of the full layer, so that the TF/s column stays comparable)
