@@ -1496,6 +1496,12 @@ static Plan make_plan(int pass, long long M, long long N, int iters, long long M
 static hipError_t finish_split(const Epi& e, long long M, int N, hipStream_t st,
                                const float* ws2 = nullptr, float* C2 = nullptr, int N2 = 0) {
   if (e.nsplit <= 1) return hipSuccess;
+#ifdef SG2IM_PROBE_SKIP_FINISH
+  // timing probe only (WRONG results): what would the step cost if the split-K finish launches - all of them (1) or the
+  // weight gradients' (2: they pass a bias-partial pointer or write dW rows) - did not exist?  tools/r6_probe_finish.sh
+  { static const int mode = getenv("SG2IM_SKIP_FINISH_PROBE") ? atoi(getenv("SG2IM_SKIP_FINISH_PROBE")) : 0;
+    if (mode == 1 || (mode == 2 && e.accumulate)) return hipSuccess; }
+#endif
   const long long MN = M * N;
   int SL = 1;
   // (up to 8 workgroups per CU: the loop over the splits is a chain of load latencies, not bandwidth - 256 splits of a
