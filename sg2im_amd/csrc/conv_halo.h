@@ -49,11 +49,22 @@ struct HaloParams {
   StatSink st;
 };
 
-// tile-local output pixel q (row-major inside the patch) -> row of the NHWC result
+// Which patch column a tile-local output pixel q = 16 r + c of a 16-wide patch works on: (c - 2 r) mod 16.
+// Why (round 6, found with SQ_LDS_BANK_CONFLICT = one conflict cycle per MFMA in the 8 x 16 kernels, fp32 and bf16):
+// a ds_read_b128 of the A fragments serves lanes {0-3, 12-15, 20-27} (and {4-11, 16-19, 28-31}) in one LDS pass, i.e. 8
+// pixels of patch row r and 8 of row r + 1.  The bank window of a halo pixel depends on (pixel index mod 16) for both
+// image strides (36 floats, 40 bf16), and a halo row is 18 pixels: row r + 1 sits 2 classes further, so with the
+// identity mapping columns {0-3, 12-15} of one row meet columns {4-11} + 2 = {6-13} of the next - two 2-way conflicts
+// per read, for every tap.  Rotating the columns by -2 per row makes the class of lane i equal to (i mod 16) + const:
+// conflict free.  A bijection inside each patch row; the epilogue's row map applies the same rotation.  32- and
+// 64-wide patches keep a fragment's 32 pixels in one row: nothing to fix.
+template <int CT> __device__ __forceinline__ int patch_col(int r, int c) { return CT == 16 ? ((c - 2 * r) & 15) : c; }
+
+// tile-local output pixel q (row-major inside the patch, columns rotated as above) -> row of the NHWC result
 template <int CT> struct PatchRow {
   int nb, H, W, y0, x0;
   __device__ __forceinline__ long long operator()(int q) const {
-    return ((long long)nb * H + y0 + q / CT) * W + x0 + q % CT;
+    return ((long long)nb * H + y0 + q / CT) * W + x0 + patch_col<CT>(q / CT, q % CT);
   }
 };
 
@@ -306,7 +317,7 @@ void conv_halo_kernel(const HaloParams p) {
   #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int q = wm0 + tm * 32 + li;
-    apix[tm] = (q / CT) * HWD + q % CT;
+    apix[tm] = (q / CT) * HWD + patch_col<CT>(q / CT, q % CT);
   }
   Frags<BM, BN> f;
   FragsH<BM, BN> fh;
@@ -431,7 +442,13 @@ void conv_halo_kernel(const HaloParams p) {
   const int e_lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int e_wm0 = (s_wave >> 1) * (BM / 2), e_wn0 = (s_wave & 1) * (BN / 2);
   const int e_tid = s_wave * 64 + e_lane;
-  const PatchRow<CT> rowmap{nb, g.H, g.W, y0, x0};
+  // (the patch origin too: workgroup-uniform, but the divisions leave it in vector registers, and held across the loop it
+  // was spilled at the 128-register budget - re-derived from an opaque copy of the block index)
+  int e_tile = blockIdx.y, e_nx = p.tiles_x, e_ny = p.tiles_y;
+  asm volatile("" : "+s"(e_tile), "+s"(e_nx), "+s"(e_ny));       // (the divisions' reciprocals are not carried across the loop either)
+  const int e_tx = e_tile % e_nx; e_tile /= e_nx;
+  const int e_ty = e_tile % e_ny;
+  const PatchRow<CT> rowmap{e_tile / e_ny, g.H, g.W, e_ty * RT, e_tx * CT};
   if (DG && p.e.mask != nullptr && p.e.nsplit == 1)       // (workgroup-uniform; the activation mask of sg2im_conv2d_backward_data_act)
     epilogue<BM, BN, PatchRow<CT>, true, true>(p.e, p.M, p.N, p.N, 0, n0, e_wm0, e_wn0, e_lane, split, acc, rowmap);
   else

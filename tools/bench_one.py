@@ -8,7 +8,10 @@ from sg2im_amd import ops
 from tools.bench_conv import LAYERS, NB as N, D
 name = sys.argv[1]
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-bn = len(sys.argv) > 3 and sys.argv[3] == 'bn'
+bn = len(sys.argv) > 3 and 'bn' in sys.argv[3:]
+BF16 = 'bf16' in sys.argv[3:]              # bf16 operands + weight mirror (the kernels a bf16 Trainer step runs)
+if BF16:
+  ops.CONV_COMPUTE = 1
 for L in LAYERS:
   if L[0] == name:
     _, H, C0, C1, Cout, k, s, p = L[:8]
@@ -22,6 +25,9 @@ if C1:      # (as in the network: the previous module's BatchNorm + LeakyReLU pe
 d = ops.conv_desc(srcs, N, H, H, k, k, s, p)
 Ct = C0 + C1
 W = torch.randn(Cout, k, k, Ct, device=D) * 0.01
+if BF16 and k == 3:
+  _mir = torch.cat([W.reshape(-1).to(torch.bfloat16), torch.zeros(16, dtype=torch.bfloat16, device=D)])
+  ops.WEIGHT_MIRROR, ops.WEIGHT_MIRROR_LOOKUP = True, (lambda w: _mir.data_ptr())
 b = torch.randn(Cout, device=D)
 y = torch.empty(N, d.out_h, d.out_w, Cout, device=D)
 gy = torch.randn_like(y)
