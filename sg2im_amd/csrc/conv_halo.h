@@ -66,7 +66,12 @@ template <int CT> struct PatchRow {
   __device__ __forceinline__ long long operator()(int q) const {
     return ((long long)nb * H + y0 + q / CT) * W + x0 + patch_col<CT>(q / CT, q % CT);
   }
+  // the same pixel's row in a map of HALF the resolution (igemm.h epilogue_bnbwd, pool2)
+  __device__ __forceinline__ long long pool2(int q) const {
+    return ((long long)nb * (H >> 1) + ((y0 + q / CT) >> 1)) * (W >> 1) + ((x0 + patch_col<CT>(q / CT, q % CT)) >> 1);
+  }
 };
+template <int CT> struct HasPool2<PatchRow<CT>> { static constexpr bool value = true; };
 
 // wave-uniform cursor over the 32-channel chunks of the virtual channel concat
 struct ChunkCursor {
@@ -450,13 +455,13 @@ void conv_halo_kernel(const HaloParams p) {
   const int e_ty = e_tile % e_ny;
   const PatchRow<CT> rowmap{e_tile / e_ny, g.H, g.W, e_ty * RT, e_tx * CT};
   if (DG && p.e.mask != nullptr && p.e.nsplit == 1)       // (workgroup-uniform; the activation mask of sg2im_conv2d_backward_data_act)
-    epilogue<BM, BN, PatchRow<CT>, true, true>(p.e, p.M, p.N, p.N, 0, n0, e_wm0, e_wn0, e_lane, split, acc, rowmap);
+    epilogue<BM, BN, PatchRow<CT>, true, true, true>(p.e, p.M, p.N, p.N, 0, n0, e_wm0, e_wn0, e_lane, split, acc, rowmap);
   else
-    epilogue<BM, BN, PatchRow<CT>, true>(p.e, p.M, p.N, p.N, 0, n0, e_wm0, e_wn0, e_lane, split, acc, rowmap);
+    epilogue<BM, BN, PatchRow<CT>, true, false, true>(p.e, p.M, p.N, p.N, 0, n0, e_wm0, e_wn0, e_lane, split, acc, rowmap);
   if constexpr (ST) {
     if (p.e.nsplit == 1) {
       if (!DG) epilogue_stats<BM, BN>(p.e, p.st, BM, p.N, 0, n0, e_wm0, e_wn0, e_lane, e_tid, blockIdx.y, acc, smem);
-      else epilogue_bnbwd<BM, BN, PatchRow<CT>>(p.st, BM, p.N, 0, n0, e_wm0, e_wn0, e_lane, e_tid, blockIdx.y, acc, smem, rowmap);
+      else epilogue_bnbwd<BM, BN, PatchRow<CT>, true>(p.st, BM, p.N, 0, n0, e_wm0, e_wn0, e_lane, e_tid, blockIdx.y, acc, smem, rowmap);
     }
   }
 }

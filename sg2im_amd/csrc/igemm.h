@@ -220,39 +220,78 @@ struct IdentityRow { __device__ __forceinline__ long long operator()(int m) cons
 // `rowmap` turns a tile-local GEMM row into the destination row (identity except for the
 // stride-2 parity classes of the data gradient and the 2-D pixel patches of conv_halo.h); split-K
 // partials are only remapped with WSMAP (patches: [split][M][N] over the destination rows).
-template <int BM, int BN, typename RowMap = IdentityRow, bool WSMAP = false, bool MASK = false>
+// FULL: every tile row is a real row (the 128-pixel patches of conv_halo.h) - no row bound test.
+// The workgroup-uniform cases (split-K partials / bfloat16 destination / accumulate / plain store) are decided ONCE per
+// column fragment and each has its own branch-free store loop: as one loop with the tests inside, the 32 stores of a
+// thread were 32 x ~80 instructions of exec-mask juggling - as many VALU instructions as the whole main loop of a bf16
+// launch (round 6, found in the ISA after SQ_INSTS_VALU / SQ_INSTS_MFMA = 9.4 on the bf16 forward kernel).
+template <int BM, int BN, typename RowMap = IdentityRow, bool WSMAP = false, bool MASK = false, bool FULL = false>
 __device__ __forceinline__ void epilogue(const Epi& e, int M, int N, int nlimit, int m0, int n0, int wm0,
                                          int wn0, int lane, int split,
                                          const f32x16 (&acc)[BM / 64][BN / 64], RowMap rowmap = RowMap()) {
   constexpr int TM = BM / 64, TN = BN / 64;
   const int j = lane & 31, h = lane >> 5;
+  auto row_of = [&](int tm, int r) __attribute__((always_inline)) { return m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h; };
   #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int n = n0 + wn0 + tn * 32 + j;
     if (n >= nlimit) continue;
-    const float bv = (e.nsplit == 1 && e.bias) ? e.bias[n] : 0.f;
-    const int ncol = epi_col(e, n);
-    #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
+    if (e.nsplit > 1) {                                   // split-K partials [split][M][N]
+      float* const wsn = e.ws + (long long)split * M * N + n;
       #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m >= M) continue;
-        float v = acc[tm][tn][r];
-        if (e.nsplit > 1) {
+      for (int tm = 0; tm < TM; ++tm) {
+        #pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = row_of(tm, r);
+          if (!FULL && m >= M) continue;
           const long long mw = WSMAP ? (long long)rowmap(m) : (long long)m;
-          e.ws[((long long)split * M + mw) * N + n] = v;
-        } else {
-          v = leaky(v + bv, e.slope);
+          wsn[mw * N] = acc[tm][tn][r];
+        }
+      }
+      continue;
+    }
+    const float bv = e.bias ? e.bias[n] : 0.f;
+    const int ncol = epi_col(e, n);
+    if (e.out_bf) {                                       // bfloat16 destination (no accumulate: the entry points check)
+      __bf16* const cb = reinterpret_cast<__bf16*>(e.C) + ncol;
+      #pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        #pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = row_of(tm, r);
+          if (!FULL && m >= M) continue;
           const long long drow = rowmap(m);
+          float v = leaky(acc[tm][tn][r] + bv, e.slope);
           if (MASK) v *= e.mask[drow * e.ld_mask + n] > 0.f ? 1.f : e.mask_slope;
-          if (e.out_bf) {
-            reinterpret_cast<__bf16*>(e.C)[drow * e.ldc + ncol] = (__bf16)v;
-          } else {
-            float* dst = e.C + drow * e.ldc + ncol;
-            if (e.accumulate) v += *dst;
-            *dst = v;
-          }
+          cb[drow * e.ldc] = (__bf16)v;
+        }
+      }
+    } else if (e.accumulate) {
+      float* const cf = e.C + ncol;
+      #pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        #pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = row_of(tm, r);
+          if (!FULL && m >= M) continue;
+          const long long drow = rowmap(m);
+          float v = leaky(acc[tm][tn][r] + bv, e.slope);
+          if (MASK) v *= e.mask[drow * e.ld_mask + n] > 0.f ? 1.f : e.mask_slope;
+          cf[drow * e.ldc] += v;
+        }
+      }
+    } else {
+      float* const cf = e.C + ncol;
+      #pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        #pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = row_of(tm, r);
+          if (!FULL && m >= M) continue;
+          const long long drow = rowmap(m);
+          float v = leaky(acc[tm][tn][r] + bv, e.slope);
+          if (MASK) v *= e.mask[drow * e.ld_mask + n] > 0.f ? 1.f : e.mask_slope;
+          cf[drow * e.ldc] = v;
         }
       }
     }
@@ -347,7 +386,23 @@ __device__ __forceinline__ void epilogue_stats(const Epi& e, const StatSink& ss,
 // pool2: the rows are at twice y's resolution (nearest-upsample backward): by linearity the sums of the 2x2-pooled
 // gradient equal the sums over the fine pixels with y read at the coarse pixel.
 // rowmap: tile-local row -> row of the launch's result tensor (identity, or a conv_halo.h pixel patch)
-template <int BM, int BN, typename RowMap = IdentityRow>
+template <bool B> struct BoolC { static constexpr bool value = B; };
+// (row of the BatchNorm'd layer's y for a result row at TWICE its resolution: generic form by division; a row map that
+// knows the pixel's coordinates - conv_halo.h PatchRow - provides pool2() and saves the two divisions per element)
+template <typename RowMap> struct HasPool2 { static constexpr bool value = false; };
+template <typename RowMap>
+__device__ __forceinline__ long long pooled_row(const RowMap& rowmap, int m, const StatSink& ss) {
+  if constexpr (HasPool2<RowMap>::value) return rowmap.pool2(m);
+  else {
+    const int HW = ss.H * ss.W;
+    const int mg = (int)rowmap(m);
+    const int nb = mg / HW, rem = mg - nb * HW;
+    const int hi = rem / ss.W, wi = rem - hi * ss.W;
+    return ((long long)nb * (ss.H >> 1) + (hi >> 1)) * (ss.W >> 1) + (wi >> 1);
+  }
+}
+
+template <int BM, int BN, typename RowMap = IdentityRow, bool FULL = false>
 __device__ __forceinline__ void epilogue_bnbwd(const StatSink& ss, int M, int N, int m0, int n0, int wm0, int wn0,
                                                int lane, int tid, int tile,
                                                const f32x16 (&acc)[BM / 64][BN / 64], float* lds, RowMap rowmap = RowMap()) {
@@ -356,40 +411,42 @@ __device__ __forceinline__ void epilogue_bnbwd(const StatSink& ss, int M, int N,
   const int wave_m = wm0 / (BM / 2);
   float* red = lds;                  // [2][4][BN]
   const int Mlive = live_limit(ss, M);
-  const int HW = ss.H * ss.W;
   float s0[TN], s1[TN], sc[TN], sh[TN], mu[TN], is[TN];
+  bool okn[TN];
   #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int n = n0 + wn0 + tn * 32 + j;
     const bool ok = n < N;
+    okn[tn] = ok;
     s0[tn] = 0.f; s1[tn] = 0.f;
     sc[tn] = ok ? ss.scale[n] : 0.f; sh[tn] = ok ? ss.shift[n] : 0.f;
     mu[tn] = ok ? ss.mean[n] : 0.f; is[tn] = ok ? ss.invstd[n] : 0.f;
   }
-  #pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
+  // the two workgroup-uniform facts (rows at twice y's resolution / y stored as bfloat16) pick one of four branch-free
+  // accumulation loops
+  auto sums = [&](auto pool_c, auto bf_c) __attribute__((always_inline)) {
+    constexpr bool POOL = decltype(pool_c)::value, YBF = decltype(bf_c)::value;
     #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (m >= Mlive) continue;
-      long long row = rowmap(m);
-      if (ss.pool2) {
-        const int mg = (int)row;
-        const int nb = mg / HW, rem = mg - nb * HW;
-        const int hi = rem / ss.W, wi = rem - hi * ss.W;
-        row = ((long long)nb * (ss.H >> 1) + (hi >> 1)) * (ss.W >> 1) + (wi >> 1);
-      }
-      const float* yrow = ss.y + row * ss.ld_y;
+    for (int tm = 0; tm < TM; ++tm) {
       #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        const int n = n0 + wn0 + tn * 32 + j;
-        if (n >= N) continue;
-        const float yv = ss.y_bf ? (float)reinterpret_cast<const __bf16*>(ss.y)[row * ss.ld_y + n] : yrow[n];
-        const float du = acc[tm][tn][r] * (fmaf(yv, sc[tn], sh[tn]) > 0.f ? 1.f : ss.slope);
-        s0[tn] += du; s1[tn] = fmaf(du, (yv - mu[tn]) * is[tn], s1[tn]);
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (!FULL && m >= Mlive) continue;
+        const long long row = POOL ? pooled_row(rowmap, m, ss) : (long long)rowmap(m);
+        #pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int n = n0 + wn0 + tn * 32 + j;
+          if (!okn[tn]) continue;
+          const float yv = YBF ? (float)reinterpret_cast<const __bf16*>(ss.y)[row * ss.ld_y + n] : ss.y[row * ss.ld_y + n];
+          const float du = acc[tm][tn][r] * (fmaf(yv, sc[tn], sh[tn]) > 0.f ? 1.f : ss.slope);
+          s0[tn] += du; s1[tn] = fmaf(du, (yv - mu[tn]) * is[tn], s1[tn]);
+        }
       }
     }
-  }
+  };
+  using T_ = BoolC<true>; using F_ = BoolC<false>;
+  if (ss.pool2) { if (ss.y_bf) sums(T_{}, T_{}); else sums(T_{}, F_{}); }
+  else { if (ss.y_bf) sums(F_{}, T_{}); else sums(F_{}, F_{}); }
   __syncthreads();                   // (every wave is done with the operand image)
   #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
