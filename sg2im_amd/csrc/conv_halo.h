@@ -460,7 +460,7 @@ void conv_halo_kernel(const HaloParams p) {
     epilogue<BM, BN, PatchRow<CT>, true, false, true>(p.e, p.M, p.N, p.N, 0, n0, e_wm0, e_wn0, e_lane, split, acc, rowmap);
   if constexpr (ST) {
     if (p.e.nsplit == 1) {
-      if (!DG) epilogue_stats<BM, BN>(p.e, p.st, BM, p.N, 0, n0, e_wm0, e_wn0, e_lane, e_tid, blockIdx.y, acc, smem);
+      if (!DG) epilogue_stats<BM, BN, true>(p.e, p.st, BM, p.N, 0, n0, e_wm0, e_wn0, e_lane, e_tid, blockIdx.y, acc, smem);
       else epilogue_bnbwd<BM, BN, PatchRow<CT>, true>(p.st, BM, p.N, 0, n0, e_wm0, e_wn0, e_lane, e_tid, blockIdx.y, acc, smem, rowmap);
     }
   }

@@ -328,7 +328,7 @@ __device__ __forceinline__ int live_limit(const StatSink& ss, int M) {
 
 // forward: statistics of the values the epilogue stored, v = leaky(acc + bias), as pivot-shifted sums with the
 // tile's first row as the pivot (sum d, sum d^2 with d = v - pivot: free of the cancellation of E[x^2] - mean^2)
-template <int BM, int BN>
+template <int BM, int BN, bool FULL = false>
 __device__ __forceinline__ void epilogue_stats(const Epi& e, const StatSink& ss, int M, int N, int m0, int n0, int wm0,
                                                int wn0, int lane, int tid, int tile,
                                                const f32x16 (&acc)[BM / 64][BN / 64], float* lds) {
@@ -359,7 +359,7 @@ __device__ __forceinline__ void epilogue_stats(const Epi& e, const StatSink& ss,
       #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < Mlive) {
+        if (FULL || m < Mlive) {
           const float d = leaky(acc[tm][tn][r] + bv, e.slope) - pv;
           s0 += d; s1 = fmaf(d, d, s1);
         }
