@@ -573,9 +573,10 @@ class Trainer(object):
     weight-gradient lane ends the step and resident workgroups polling grid barriers cost it 0.13 ms: layer by layer."""
     masks = batch[3] if len(batch) > 3 else None
     trains_mask_net = self.model.mask_net is not None and (masks is None or self.w['mask_loss_weight'] > 0)
-    # bfloat16 operands: the weight-gradient lane is 2.3x shorter and the tail ends the step in the COCO style too
-    # (g_bwd_done 4.23 ms, wgrad_lane_done 3.92 ms): 4.27 -> 4.23 ms with the one-launch form (round 5, final build)
-    return 'low' if trains_mask_net or self.compute_dtype == 'bf16' else False
+    # (round 5 also took the one-launch form for every bf16 step; since the GEMM epilogues got cheap - round 6 - the
+    # layer-by-layer launches win in the COCO style in both modes: bf16 3.82-3.83 -> 3.69-3.75 ms; VG style, one launch:
+    # fp32 8.34 vs 8.57, bf16 4.39 vs 4.56 ms)
+    return 'low' if trains_mask_net else False
 
   def _step(self, batch):
     if self.use_graphs:
