@@ -249,6 +249,12 @@ int sg2im_column_sum(const float* x, long long rows, int cols, long long ld, flo
  * row_ptr[n_rows]. */
 int sg2im_csr_build(const long long* keys_a, int n_a, const long long* keys_b, int n_b, int n_rows,
                     int* row_ptr, int* entries, int* scratch, const int* live_keys, hipStream_t stream);
+/* The pooling CSR of a GraphTripleConv stack straight from the (n_triples, 3) int64 triples tensor (graph.py:73-75
+ * chunks it into s, p, o): sg2im_csr_build(s, T, o, T, n_rows, ...) AND the three columns as contiguous arrays
+ * split[0..T) = s, split[T..2T) = p, split[2T..3T) = o, in one launch for the sizes of a training batch (the head of
+ * the critical path of the step: three strided copies + the build before).  scratch / live_keys as above. */
+int sg2im_csr_build_triples(const long long* triples, int n_triples, int n_rows, long long* split, int* row_ptr,
+                            int* entries, int* scratch, const int* live_keys, hipStream_t stream);
 /* out[j][0:width] = sum over row j's entries, in CSR order, starting from +0.0f, of
  *   src_a[e*ld_a + 0:width]            (e <  n_a)
  *   src_b[(e-n_a)*ld_b + 0:width]      (e >= n_a)

@@ -102,6 +102,7 @@ _SIGNATURES = {
                                          _I, _P, _Z, _P],
   'sg2im_column_sum': [_P, _L, _I, _L, _P, _I, _P, _P],
   'sg2im_csr_build': [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P],
+  'sg2im_csr_build_triples': [_P, _I, _I, _P, _P, _P, _P, _P, _P],
   'sg2im_segment_sum': [_P, _L, _I, _P, _L, _P, _P, _I, _I, _I, _I, _P, _L, _P],
   'sg2im_gather_rows': [_P, _L, _P, _I, _I, _P, _P, _L, _P],
   'sg2im_gconv_pool_backward': [_P, _L, _P, _P, _I, _P, _P, _L, _P, _L, _I, _I, _F, _P, _L, _P],

@@ -67,34 +67,57 @@ __global__ void csr_scan_kernel(int* __restrict__ counts, int n, int* __restrict
 }
 
 // The whole build in ONE launch for the sizes of a training batch (a few hundred rows, a few hundred to a few
-// thousand keys): one workgroup stages the live keys in LDS, every thread owns rows r = tid, tid + 1024, ... and
-// walks the keys twice - count, then (after a block scan of the counts) append in entry order, which is the
-// stable order by construction.  Replaces memset + count + scan + fill + sort (five dependent launches at the very
-// head of the training step).
+// thousand keys): one workgroup stages the live keys in LDS; a row is owned by P = 2^lp threads, each of which walks
+// ONE contiguous slice of the keys twice - count, then (after a block scan of the counts in (row, slice) order)
+// append in entry order, which is the stable order by construction.  Replaces memset + count + scan + fill + sort
+// (five dependent launches at the very head of the training step).
+//   P: the walk of a thread is a chain of LDS reads with nothing else to do - at one thread per row and ~1000 keys
+//      the 2 x 256 dependent-latency iterations were 35 us on the critical path of the step (profiles/
+//      r6_step_bf16_kernel_sequence.txt); with P slices a walk is 1/P as long and the reads of a slice are unrolled.
+//      The slice length is odd (in 16-byte units): the P distinct addresses of a wave's ds_read_b128 fall on
+//      distinct bank groups.
+//   strided keys (sa / sb elements between keys) + `split`: the keys of the pooling CSR are columns 0 and 2 of the
+//      (T, 3) triples tensor (graph.py:73-75 chunks it); the same launch writes the three columns out as contiguous
+//      arrays split[0..T) = s, [T..2T) = p, [2T..3T) = o, which the step used to get from three strided copies.
 constexpr int kCsrSmallKeys = 8192;
-__global__ __launch_bounds__(1024) void csr_build_small_kernel(const long long* __restrict__ ka, int na,
-                                                               const long long* __restrict__ kb, int nb, int n_rows,
-                                                               int* __restrict__ row_ptr, int* __restrict__ entries,
-                                                               const int* __restrict__ live) {
+constexpr int kCsrMaxLp = 5;
+__global__ __launch_bounds__(1024) void csr_build_small_kernel(const long long* __restrict__ ka, int sa, int na,
+                                                               const long long* __restrict__ kb, int sb, int nb,
+                                                               int n_rows, int lp, int* __restrict__ row_ptr,
+                                                               int* __restrict__ entries, const int* __restrict__ live,
+                                                               long long* __restrict__ split) {
   __shared__ __attribute__((aligned(16))) int keys[kCsrSmallKeys];        // -1: padding entry (not live)
   __shared__ int warp_sums[16];
   __shared__ int carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = na + nb;
   const int n4 = (n + 3) >> 2;               // (walked four keys per LDS read; the tail is padding)
-  for (int e = tid; e < 4 * n4; e += blockDim.x)
-    keys[e] = e < n && csr_entry_live(e, na, live) ? (int)(e < na ? ka[e] : kb[e - na]) : -1;
+  for (int e = tid; e < 4 * n4; e += blockDim.x) {
+    int k = -1;
+    if (e < n && csr_entry_live(e, na, live)) k = (int)(e < na ? ka[(long long)e * sa] : kb[(long long)(e - na) * sb]);
+    keys[e] = k;
+  }
+  if (split)                                 // (ka is then the (na, 3) triples tensor itself)
+    for (int e = tid; e < 3 * na; e += blockDim.x) {
+      const int c = e / na, t = e - c * na;
+      split[e] = ka[3LL * t + c];
+    }
   if (tid == 0) carry = 0;
   __syncthreads();
   const int4* keys4 = reinterpret_cast<const int4*>(keys);
-  for (int base = 0; base < n_rows; base += blockDim.x) {
-    const int r = base + tid;
+  const int P = 1 << lp, j = tid & (P - 1), rows_per_pass = blockDim.x >> lp;
+  const int sl = ((n4 + P - 1) >> lp) | 1;
+  const int q0 = min(j * sl, n4), q1 = min(q0 + sl, n4);
+  for (int base = 0; base < n_rows; base += rows_per_pass) {
+    const int r = base + (tid >> lp);
     int v = 0;
-    if (r < n_rows)
-      for (int q = 0; q < n4; ++q) {
+    if (r < n_rows) {
+      #pragma unroll 4
+      for (int q = q0; q < q1; ++q) {
         const int4 k = keys4[q];
         v += (k.x == r ? 1 : 0) + (k.y == r ? 1 : 0) + (k.z == r ? 1 : 0) + (k.w == r ? 1 : 0);
       }
+    }
     int x = v;
     #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -108,15 +131,17 @@ __global__ __launch_bounds__(1024) void csr_build_small_kernel(const long long* 
     const int c = carry;
     const int begin = c + woff + x - v;
     if (r < n_rows) {
-      row_ptr[r] = begin;
-      int pos = begin;
-      const int end = begin + v;
-      for (int q = 0; q < n4 && pos < end; ++q) {
-        const int4 k = keys4[q];
-        if (k.x == r) entries[pos++] = 4 * q;
-        if (k.y == r) entries[pos++] = 4 * q + 1;
-        if (k.z == r) entries[pos++] = 4 * q + 2;
-        if (k.w == r) entries[pos++] = 4 * q + 3;
+      if (j == 0) row_ptr[r] = begin;
+      if (v > 0) {
+        int pos = begin;
+        #pragma unroll 2
+        for (int q = q0; q < q1; ++q) {
+          const int4 k = keys4[q];
+          if (k.x == r) entries[pos++] = 4 * q;
+          if (k.y == r) entries[pos++] = 4 * q + 1;
+          if (k.z == r) entries[pos++] = 4 * q + 2;
+          if (k.w == r) entries[pos++] = 4 * q + 3;
+        }
       }
     }
     __syncthreads();
@@ -124,6 +149,14 @@ __global__ __launch_bounds__(1024) void csr_build_small_kernel(const long long* 
     __syncthreads();
   }
   if (tid == 0) row_ptr[n_rows] = carry;
+}
+
+// (T, 3) -> three contiguous columns [3][T]: the large-batch path of sg2im_csr_build_triples
+__global__ void split_triples_kernel(const long long* __restrict__ tri, int T, long long* __restrict__ split) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 3 * T) return;
+  const int c = e / T, t = e - c * T;
+  split[e] = tri[3LL * t + c];
 }
 
 __global__ void csr_fill_kernel(const long long* __restrict__ ka, int na, const long long* __restrict__ kb,
@@ -329,14 +362,26 @@ int sg2im_timestamp(unsigned long long* slot, hipStream_t stream) {
 
 unsigned long long sg2im_launch_count(int which) { return which == 1 ? sg2im::g_gemm_launches : sg2im::g_launches; }
 
+static int csr_small_lp(int n_rows) {
+  int lp = 0;
+  while (lp < sg2im::kCsrMaxLp && ((long long)n_rows << (lp + 1)) <= 1024) ++lp;
+  return lp;
+}
+// the single-workgroup form: the keys fit the LDS image and the walks stay short
+static bool csr_small_ok(int n, int n_rows) {
+  const int lp = csr_small_lp(n_rows);
+  const long long passes = ((long long)n_rows + (1024 >> lp) - 1) / (1024 >> lp);
+  return n <= sg2im::kCsrSmallKeys && (long long)(n >> lp) * passes <= 65536;
+}
+
 int sg2im_csr_build(const long long* keys_a, int n_a, const long long* keys_b, int n_b, int n_rows,
                     int* row_ptr, int* entries, int* scratch, const int* live_keys, hipStream_t stream) {
   if (n_a < 0 || n_b < 0 || n_rows < 1 || !row_ptr || !scratch || (n_a && !keys_a) || (n_b && !keys_b))
     return SG2IM_ERR_ARG;
   const int n = n_a + n_b;
-  if (n <= kCsrSmallKeys && (long long)n * ((n_rows + 1023) / 1024) <= 65536 && (n == 0 || entries)) {
-    SG2IM_LAUNCH(csr_build_small_kernel, dim3(1), dim3(1024), 0, stream, keys_a, n_a, keys_b, n_b, n_rows, row_ptr, entries,
-                 live_keys);
+  if (csr_small_ok(n, n_rows) && (n == 0 || entries)) {
+    SG2IM_LAUNCH(csr_build_small_kernel, dim3(1), dim3(1024), 0, stream, keys_a, 1, n_a, keys_b, 1, n_b, n_rows,
+                 csr_small_lp(n_rows), row_ptr, entries, live_keys, (long long*)nullptr);
     return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
   }
   int* counts = scratch;            // [n_rows]
@@ -353,6 +398,21 @@ int sg2im_csr_build(const long long* keys_a, int n_a, const long long* keys_b, i
     SG2IM_LAUNCH(csr_ranksort_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream, row_ptr, tmp, n_rows, entries);
   }
   return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+}
+
+int sg2im_csr_build_triples(const long long* triples, int n_triples, int n_rows, long long* split, int* row_ptr,
+                            int* entries, int* scratch, const int* live_keys, hipStream_t stream) {
+  if (n_triples < 0 || n_rows < 1 || !row_ptr || !scratch || (n_triples && (!triples || !split || !entries)))
+    return SG2IM_ERR_ARG;
+  const int T = n_triples;
+  if (csr_small_ok(2 * T, n_rows)) {
+    SG2IM_LAUNCH(csr_build_small_kernel, dim3(1), dim3(1024), 0, stream, triples, 3, T, triples + 2, 3, T, n_rows,
+                 csr_small_lp(n_rows), row_ptr, entries, live_keys, split);
+    return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+  }
+  SG2IM_LAUNCH(split_triples_kernel, dim3((3 * T + 255) / 256), dim3(256), 0, stream, triples, T, split);
+  if (hipGetLastError() != hipSuccess) return SG2IM_ERR_HIP;
+  return sg2im_csr_build(split, T, split + 2LL * T, T, n_rows, row_ptr, entries, scratch, live_keys, stream);
 }
 
 int sg2im_segment_sum(const float* src_a, long long ld_a, int n_a, const float* src_b, long long ld_b,

@@ -12,6 +12,7 @@ from .layout import ALIGN_CORNERS, layout_nhwc
 
 import os as _os
 EMB_CSR_AHEAD = _os.environ.get('SG2IM_EMB_CSR_AHEAD', '1') != '0'      # (A/B knob)
+TRIPLES_CSR = _os.environ.get('SG2IM_TRIPLES_CSR', '1') != '0'          # (A/B knob: 0 = three strided copies + sg2im_csr_build)
 
 
 class Sg2ImModel(nn.Module):
@@ -94,9 +95,6 @@ class Sg2ImModel(nn.Module):
     mask_net and rel_aux_net, whose outputs are then returned detached.  [mask_net is 0.37 ms of the 0.9 ms the
     refinement network used to wait for at the head of every step.]"""
     O = objs.size(0)
-    s = triples[:, 0].contiguous()
-    p = triples[:, 1].contiguous()
-    o = triples[:, 2].contiguous()
     if obj_to_img is None:
       obj_to_img = torch.zeros(O, dtype=objs.dtype, device=objs.device)
       num_images = 1
@@ -106,6 +104,14 @@ class Sg2ImModel(nn.Module):
     emb_csr = (None, None)            # the CSRs the embeddings' backward sums over, built ahead of time
     if aux_stream is not None and num_images is not None:
       aux_stream.wait_stream(main)
+    # (s, p, o = triples.chunk(3, dim=1) of model.py:116-118 and the pooling CSR of the graph convolutions: one launch;
+    # padded batch: the padding triples stay out of the CSR - no long tail row on the dummy object)
+    if TRIPLES_CSR:
+      s, p, o, pool_csr = ops.triples_csr(triples, O, live=triple_count)
+    else:
+      s, p, o = (triples[:, c].contiguous() for c in range(3))
+      pool_csr = ops.Csr(s, o, O, live=triple_count)
+    if aux_stream is not None and num_images is not None:
       with torch.cuda.stream(aux_stream):
         if self.layout_noise_dim > 0:                           # reference sg2im/model.py:164-168
           noise = torch.randn((num_images, self.layout_noise_dim, H, W), dtype=torch.float32, device=objs.device)
@@ -114,10 +120,10 @@ class Sg2ImModel(nn.Module):
         ev_pre.record(aux_stream)
         # (not waited for by the layout: joined with everything else of this stream at the end of the forward pass)
         if torch.is_grad_enabled() and self.obj_embeddings.weight.requires_grad and EMB_CSR_AHEAD:
+          aux_stream.wait_stream(main)                          # (p)
           emb_csr = (ops.Csr(objs, None, self.obj_embeddings.weight.size(0)),
                      ops.Csr(p, None, self.pred_embeddings.weight.size(0)))
-    # (padded batch: the padding triples stay out of the pooling CSR - no long tail row on the dummy object)
-    edges = (s, o, ops.Csr(s, o, O, live=triple_count))
+    edges = (s, o, pool_csr)
 
     ops.mark('csr_done')
     obj_vecs = HF.Embedding.apply(self.obj_embeddings.weight, objs, emb_csr[0])

@@ -557,6 +557,25 @@ class Csr(object):
          _i32(self.entries), _i32(tmp), _count_args(live)[0], _stream())
 
 
+def triples_csr(triples, n_rows, live=None):
+  """(s, p, o, Csr(s, o, n_rows, live)) from the (T, 3) int64 triples tensor in one launch
+  (sg2im_csr_build_triples): the three columns come back as contiguous views of one (3, T) tensor."""
+  T = triples.size(0)
+  if triples.dtype != torch.int64 or triples.dim() != 2 or triples.size(1) != 3:
+    raise ValueError('triples_csr: an int64 tensor of shape (T, 3) is expected')
+  triples = triples.contiguous()
+  split = torch.empty(3, max(T, 1), dtype=torch.int64, device=triples.device)
+  csr = Csr.__new__(Csr)
+  csr.n_a = csr.n_b = T
+  csr.n_rows = int(n_rows)
+  csr.row_ptr = torch.empty(csr.n_rows + 1, dtype=torch.int32, device=triples.device)
+  csr.entries = torch.empty(max(2 * T, 1), dtype=torch.int32, device=triples.device)
+  tmp = torch.empty(csr.n_rows + max(2 * T, 1), dtype=torch.int32, device=triples.device)
+  call('sg2im_csr_build_triples', _i64(triples), T, csr.n_rows, _i64(split), _i32(csr.row_ptr), _i32(csr.entries),
+       _i32(tmp), _count_args(live)[0], _stream())
+  return split[0, :T], split[1, :T], split[2, :T], csr
+
+
 def segment_sum(src_a, src_b, csr, width, average, out, accumulate=False):
   pa, lda = rows_ld(src_a)
   pb, ldb = rows_ld(src_b) if src_b is not None else (None, 0)

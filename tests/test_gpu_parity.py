@@ -504,6 +504,49 @@ def test_empty_and_ragged_graphs():
   assert float(out0.abs().max()) == 0.0
 
 
+def _stable_csr(keys, n_rows, live=None, half=None):
+  """numpy restatement of sg2im_csr_build's contract: row j lists its entry ids in increasing order; with `live` only
+  the first `live` keys of each half (keys_a | keys_b) take part"""
+  import numpy as np
+  keys = np.asarray(keys)
+  ids = np.arange(keys.size)
+  if live is not None:
+    keep = (ids % half if half else ids) < live
+    ids = ids[keep]
+  order = ids[np.argsort(keys[ids], kind='stable')]
+  counts = np.bincount(keys[ids], minlength=n_rows)
+  return np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), order.astype(np.int32)
+
+
+@pytest.mark.parametrize('T,O,live', [(0, 6, None), (5, 1, None), (450, 224, None), (521, 290, 433), (1200, 31, None),
+                                      (2000, 1500, None), (4096, 700, 4000), (5000, 900, None), (300, 2100, None)])
+def test_csr_from_triples_matches_the_stable_order(T, O, live):
+  """sg2im_csr_build_triples (the (T, 3) triples tensor -> s, p, o + the pooling CSR in one launch) and sg2im_csr_build
+  at the sizes of every row-slice count of the single-workgroup kernel (1 ... 32 threads per row), of its multi-pass
+  form (more rows than threads) and of the large-batch path; entry order = the stable order, bit for bit"""
+  import numpy as np
+  from sg2im_amd import ops
+  D = torch.device('cuda', 0)
+  g = torch.Generator().manual_seed(T * 31 + O)
+  tri = torch.stack([torch.randint(0, O, (T,), generator=g), torch.randint(0, 46, (T,), generator=g),
+                     torch.randint(0, O, (T,), generator=g)], dim=1)
+  if T > 8:
+    tri[: T // 3, 0] = O - 1                     # one long row (the __image__ object of a big scene)
+  lv = (torch.tensor([live], dtype=torch.int32, device=D), 1) if live is not None else None
+  s, p, o, csr = ops.triples_csr(tri.to(D), O, live=lv)
+  assert torch.equal(s.cpu(), tri[:, 0]) and torch.equal(p.cpu(), tri[:, 1]) and torch.equal(o.cpu(), tri[:, 2])
+  assert s.is_contiguous() and p.is_contiguous() and o.is_contiguous()
+  keys = np.concatenate([tri[:, 0].numpy(), tri[:, 2].numpy()])
+  rp, en = _stable_csr(keys, O, live, T if live is not None else None)
+  assert csr.row_ptr.cpu().numpy().tolist() == rp.tolist()
+  assert csr.entries.cpu().numpy()[:rp[-1]].tolist() == en.tolist()
+  ref = ops.Csr(tri[:, 0].contiguous().to(D), tri[:, 2].contiguous().to(D), O, live=lv)
+  assert torch.equal(ref.row_ptr, csr.row_ptr) and torch.equal(ref.entries[:rp[-1]], csr.entries[:rp[-1]])
+  one = ops.Csr(tri[:, 1].contiguous().to(D), None, 46, live=lv)          # a single key array (the embedding CSRs)
+  rp1, en1 = _stable_csr(tri[:, 1].numpy(), 46, live, None)
+  assert one.row_ptr.cpu().numpy().tolist() == rp1.tolist() and one.entries.cpu().numpy()[:rp1[-1]].tolist() == en1.tolist()
+
+
 @pytest.mark.parametrize('batch_size,steps,use_graphs', [(4, 2, False), (32, 1, False), (32, 1, True)])
 def test_trainer_two_steps_match_oracle(batch_size, steps, use_graphs):
   """Full G + D_obj + D_img iterations (flat arenas, guarded fused Adam) at the reference's
