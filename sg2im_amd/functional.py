@@ -750,6 +750,7 @@ class LayoutLink(object):
 
 
 import os as _os
+WGRAD_FLUSH_AT = int(_os.environ.get('SG2IM_WGRAD_FLUSH_AT', '-1'))          # (probe knob: early release at module i)
 LAZY_LAYOUT_GRAD = _os.environ.get('SG2IM_LAZY_LAYOUT_GRAD', '1') != '0'     # (A/B knob)
 LAYOUT_GRAD_FROM_LEVELS = _os.environ.get('SG2IM_LAYOUT_GRAD_LEVELS', '1') != '0'      # (A/B knob: 0 = materialise the sum)
 
@@ -1004,6 +1005,8 @@ class RefinementFn(Function):
     for i in range(L - 1, -1, -1):
       lay, feat_src, y0, st0, y1, st1, h, w, C, src0 = saved[i]
       W0p, b0, W1p, b1 = convp[4 * i:4 * i + 4]
+      if deferred and i == WGRAD_FLUSH_AT:
+        side.flush(final=False)
       dy1 = ops.bn_backward_apply(_fptr(gz), gz.size(3), pool2, N, h, w, y1, C, C, st1, slope, coef1,
                                   _new_s(g, sbm[i], N, h, w, C), g_dtype=ops._dt(gz))
       d1 = conv_desc([src0], N, h, w, 3, 3, 1, 1)

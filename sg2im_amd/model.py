@@ -79,7 +79,8 @@ class Sg2ImModel(nn.Module):
     return HF.MaskNetFn.apply(obj_vecs, bns, self.training, obj_count, *params)
 
   def forward_nhwc(self, objs, triples, obj_to_img=None, boxes_gt=None, masks_gt=None, num_images=None,
-                   obj_count=None, triple_count=None, aux_stream=None, detach_masks=False, detach_rel=False):
+                   obj_count=None, triple_count=None, aux_stream=None, detach_masks=False, detach_rel=False,
+                   aux_work=None):
     """Same computation as ``forward`` (reference sg2im/model.py:108-171) but the image
     is returned NHWC, the internal layout of the kernels.  ``num_images`` avoids the host
     sync of reference sg2im/layout.py:143 (N = obj_to_img.max()+1).  ``obj_count``: (int32 device
@@ -93,14 +94,17 @@ class Sg2ImModel(nn.Module):
     when the caller does not back-propagate through them (``detach_masks``: ground-truth masks are laid out and
     the mask loss is off, as in the reference's COCO configuration; ``detach_rel``: the predicate loss is off) -
     mask_net and rel_aux_net, whose outputs are then returned detached.  [mask_net is 0.37 ms of the 0.9 ms the
-    refinement network used to wait for at the head of every step.]"""
+    refinement network used to wait for at the head of every step.]  ``aux_work``: a callable of the caller's that
+    the refinement network depends on (the Trainer: the bf16 weight mirror refresh, 28 us over 180 MB) - issued on
+    ``aux_stream`` BEHIND the small launches at the head of the step (issued first, its 8192 workgroups kept the
+    one-workgroup CSR build waiting for a free CU: +25 us on the critical path) and joined behind the graph convolutions."""
     O = objs.size(0)
     if obj_to_img is None:
       obj_to_img = torch.zeros(O, dtype=objs.dtype, device=objs.device)
       num_images = 1
     H, W = self.image_size
     main = torch.cuda.current_stream() if aux_stream is not None else None
-    noise = img_csr = ev_pre = None
+    noise = img_csr = ev_pre = ev_work = None
     emb_csr = (None, None)            # the CSRs the embeddings' backward sums over, built ahead of time
     if aux_stream is not None and num_images is not None:
       aux_stream.wait_stream(main)
@@ -123,6 +127,13 @@ class Sg2ImModel(nn.Module):
           aux_stream.wait_stream(main)                          # (p)
           emb_csr = (ops.Csr(objs, None, self.obj_embeddings.weight.size(0)),
                      ops.Csr(p, None, self.pred_embeddings.weight.size(0)))
+        if aux_work is not None:
+          aux_stream.wait_stream(main)                          # (behind the pooling CSR)
+          aux_work()
+          ev_work = torch.cuda.Event()
+          ev_work.record(aux_stream)
+    elif aux_work is not None:
+      aux_work()
     edges = (s, o, pool_csr)
 
     ops.mark('csr_done')
@@ -144,6 +155,8 @@ class Sg2ImModel(nn.Module):
         obj_vecs, pred_vecs = self.gconv_net(obj_vecs, pred_vecs, edges, (obj_count, triple_count))
 
     ops.mark('gcn_layers_done')
+    if ev_work is not None:
+      main.wait_event(ev_work)                                  # (mask_net's convolutions are the first to read the mirror)
     masks_pred = rel_scores = None
     on_aux = aux_stream is not None and ((self.mask_net is not None and detach_masks) or detach_rel)
     if on_aux:

@@ -139,13 +139,14 @@ def marks_report():
   return sorted(((n, (v[i] - t0) / 100.0) for n, i in _marks['names'].items()), key=lambda r: r[1])
 
 
-def release_deferred(queue, stream):
+def release_deferred(queue, stream, pending=None):
   """issue the queued (fn, tags) launches, last queued first (the layers the data-gradient chain reached last first:
   8.80 vs 8.84-8.85 ms in queue order), the first BG_COUNT as background launches; each AFTER_DEFERRED bucket's
-  callback runs right after the last launch that completes one of its parameters"""
-  queued = frozenset().union(*(tags for _, tags in queue))
-  # (a bucket whose parameters are not all among the released launches is never reported complete)
-  pending = [[set(ids), cb] for ids, cb in (AFTER_DEFERRED or ()) if ids and ids <= queued]
+  callback runs right after the last launch that completes one of its parameters.  pending: the open buckets of a lane
+  that releases its queue in several parts (SideLane.flush) - [[ids still to come, callback], ...], updated in place."""
+  if pending is None:
+    pending = [[set(ids), cb] for ids, cb in (AFTER_DEFERRED or ()) if ids]
+  # (a bucket whose parameters are not all among the released launches is never reported complete: its set never empties)
   for k, (fn, tags) in enumerate(reversed(queue)):
     fn(k < BG_COUNT)
     for ent in pending:
@@ -171,6 +172,7 @@ class SideLane(object):
     self.keep = []
     self.queue = []
     self.deferring = False     # (deferred mode: no joins before the final one)
+    self.pending = None        # (open gradient buckets between two flush() calls)
     if self.on:
       idx = device.index if device.index is not None else torch.cuda.current_device()
       self.main = torch.cuda.current_stream(idx)
@@ -198,20 +200,24 @@ class SideLane(object):
     self.queue.append((fn, frozenset(p.data_ptr() for p in completes if p is not None)))
     self.keep.extend(reads)
 
-  def flush(self):
+  def flush(self, final=True):
     """all queued launches on the side stream, ordered after everything launched so far on the calling
-    stream (ONE fork)"""
-    if not self.queue:
+    stream (one fork per call; final=False: more launches will be queued and released by a later call)"""
+    if not self.queue and not (final and self.used):
       return
+    if self.pending is None:
+      self.pending = [[set(ids), cb] for ids, cb in (AFTER_DEFERRED or ()) if ids]
     ev = torch.cuda.Event()
     ev.record(self.main)
     self.side.wait_event(ev)
     with torch.cuda.stream(self.side):
-      mark('wgrad_lane_start')
-      release_deferred(self.queue, self.side)
-      mark('wgrad_lane_done')
-      if AFTER_ALL_DEFERRED is not None:
-        AFTER_ALL_DEFERRED(self.side)
+      if not self.used:
+        mark('wgrad_lane_start')
+      release_deferred(self.queue, self.side, self.pending)
+      if final:
+        mark('wgrad_lane_done')
+        if AFTER_ALL_DEFERRED is not None:
+          AFTER_ALL_DEFERRED(self.side)
     self.queue = []
     self.used = True
 

@@ -339,10 +339,12 @@ class Trainer(object):
     # captured iteration: whatever is not on the path to the image leaves the critical path (Sg2ImModel.forward_nhwc)
     aux = self._side[0] if (self._side is not None and torch.cuda.is_current_stream_capturing() and
                             os.environ.get('SG2IM_AUX', '1') != '0' and not ops.SINGLE_STREAM) else None      # (A/B knob)
-    if self.weight_mirror:
+    # (the bf16 weight mirror: 28 us over the 120 MB arena, next to the graph-convolution phase on the aux stream -
+    # forward_nhwc issues it there behind the head of the step and joins it in front of the layout, long before the
+    # first convolution that reads the mirror; without an aux stream: right away)
+    late = os.environ.get('SG2IM_MIRROR_LATE', '1') != '0'      # (A/B knob: 0 = refreshed first thing, as before)
+    if self.weight_mirror and not late:
       if aux is not None:
-        # (28 us over the 120 MB arena: next to the graph-convolution phase on the aux stream - forward_nhwc joins that
-        # stream in front of the layout, long before the first convolution that reads the mirror)
         aux.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(aux):
           self.flat_g.refresh_mirror()
@@ -352,6 +354,7 @@ class Trainer(object):
     st['gen_out'] = self.model.forward_nhwc(objs, triples, obj_to_img, boxes_gt=boxes, masks_gt=masks,
                                             num_images=imgs.size(0), obj_count=st.get('ocnt'),
                                             triple_count=st.get('tcnt'), aux_stream=aux,
+                                            aux_work=self.flat_g.refresh_mirror if self.weight_mirror and late else None,
                                             detach_masks=masks is not None and not w['mask_loss_weight'] > 0,
                                             detach_rel=not w['predicate_pred_loss_weight'] > 0)
     st['imgs_fake'] = st['gen_out'][0].detach()
