@@ -332,7 +332,7 @@ int sg2im_gconv_layer_backward(const sg2im_gconv_layer* layer, const float* h1, 
  * launch may be in flight per device at a time (two whole-chip resident grids can starve each other's barriers);
  * the Trainer issues the forward on its main lane only; its backward is chosen per configuration
  * (SG2IM_GCN_PERSIST_BWD=auto, sg2im_amd.trainer.Trainer._gcn_backward_mode): the one-launch low_footprint form where
- * the small-kernel tail ends the step (bf16 operands, VG-style batches / a trained mask_net), layer by layer otherwise.
+ * the small-kernel tail ends the step (VG-style batches / a trained mask_net, either compute mode), layer by layer otherwise.
  * A barrier that times out (grid not fully resident: another process on the GPU) lets the launch carry on with
  * incomplete data - its results are garbage; the sticky word is what reports it (sg2im_gconv_stack_status, checked by
  * the Trainer wherever it synchronises with the host: Trainer.losses_to_host). */
