@@ -42,7 +42,7 @@ int main() {
   for (auto& v : b) v = u(rng);
   for (auto& v : dy) v = u(rng);
   for (auto& v : act) v = u(rng);                      // (the activated output of the layer the gradient flows into)
-  std::printf("abi %d, %d entry points declared in include/sg2im_hip.h\n", sg2im_abi_version(), 75);
+  std::printf("abi %d, %d entry points declared in include/sg2im_hip.h\n", sg2im_abi_version(), 79);
   ABI_OK(sg2im_init());
   float *dx_ = to_device(x), *dw_ = to_device(w), *db_ = to_device(b), *ddy = to_device(dy), *dact = to_device(act);
   float *y = nullptr, *gx = nullptr, *gxm = nullptr, *gw = nullptr, *gb = nullptr, *ws = nullptr;

@@ -26,7 +26,7 @@ extern "C" {
 #define SG2IM_ERR_ARG 1   /* invalid argument (the reference would raise / assert) */
 #define SG2IM_ERR_HIP 2   /* a HIP runtime call failed; see hipGetLastError() */
 
-int sg2im_abi_version(void);   /* 10 */
+int sg2im_abi_version(void);   /* 11 (11: + sg2im_csr_build_triples; 10: bfloat16 storage, weight mirror) */
 
 /* Statistics: kernels this library has launched (or recorded into a stream capture) so far in this process;
  * which = 0: all of them, 1: the implicit-GEMM family incl. its split-K finishes.  bench.py reads it around the

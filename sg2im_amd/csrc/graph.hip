@@ -332,7 +332,7 @@ using namespace sg2im;
 
 extern "C" {
 
-int sg2im_abi_version(void) { return 10; }
+int sg2im_abi_version(void) { return 11; }
 
 int sg2im_stage_batch(int n, void* const* dst, const void* const* src, const size_t* bytes, hipStream_t stream) {
   if (n < 0 || n > 16 || (n && (!dst || !src || !bytes))) return SG2IM_ERR_ARG;
