@@ -372,7 +372,10 @@ typedef struct sg2im_gconv_stack_grads {
                              * tiles - its workgroups fit NEXT TO resident workgroups of other kernels, so the launch can
                              * run inside a busy multi-stream graph (sg2im_amd/trainer.py: under the refinement network's
                              * weight gradients) without waiting for whole CUs to drain.  Same results up to the fp32
-                             * summation order of the weight gradients' tiles. */
+                             * summation order of the weight gradients' tiles.
+                             * 2 / 3 (ABI 11): STAGED - the same stages as 5 n_layers ordinary launches of kernel 1 / 0,
+                             * one stage each: no grid barrier executes, nothing has to be co-resident and nothing polls
+                             * (the sync area is only counted in).  Bit-identical to the one-launch form of the same kernel. */
   int reserved;
 } sg2im_gconv_stack_grads;
 size_t sg2im_gconv_stack_backward_scratch(const sg2im_gconv_stack* stack);

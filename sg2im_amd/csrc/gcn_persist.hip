@@ -730,6 +730,11 @@ struct BwdArgs {
   // scratch carve-up: element offsets from g.scratch
   long long off_dpooled, off_dnt, off_dp1, off_dtriple0, off_dtriple1, off_dobj0, off_dobj1;
   unsigned* sync;
+  // The stages this launch runs: [stage_lo, stage_hi) of the sequence layer nl-1: P1..P5, layer nl-2: P1..P5, ...
+  // (5 per layer).  0 .. 5 nl = the whole backward in one co-resident launch; a launch of ONE stage executes no grid
+  // barrier at all - the "staged" form: the same tiles (32 x 32, four wavefronts splitting K, the weight / bias gradients
+  // riding as extra tiles) as 25 ordinary launches that need no co-residency and poll nothing.
+  int stage_lo, stage_hi;
 };
 
 __device__ __forceinline__ sg2im_gconv_grads fetch_grads(int l) {
@@ -859,7 +864,15 @@ __device__ __forceinline__ void gcn_stack_bwd_body(const BwdArgs& a) {
   float* const dpooled = dp3 + a.off_dpooled;             // [O][H]
   float* const dnt = dp3 + a.off_dnt;                     // [T][2H + Dout]
   float* const dp1 = dp3 + a.off_dp1;                     // [T][H]
-  for (int l = nl - 1; l >= 0; --l) {
+  int gs = 0;                                               // global stage index (workgroup-uniform)
+  const int lo = a.stage_lo, hi = a.stage_hi;
+  for (int l = nl - 1; l >= 0; --l, gs += 5) {
+    if (gs + 5 <= lo || gs >= hi) {                         // (none of this layer's stages is in this launch)
+      const sg2im_gconv_stack_layer Lq = fetch_layer(l);
+      float* const dq = l == 0 ? a.g.d_triple : dp3 + (l & 1 ? a.off_dtriple1 : a.off_dtriple0);
+      g_obj = l == 0 ? a.g.d_obj : dp3 + (l & 1 ? a.off_dobj1 : a.off_dobj0); g_pred = dq + Lq.din; ld_gp = 3 * Lq.din;
+      continue;
+    }
     const sg2im_gconv_stack_layer L = fetch_layer(l);
     const sg2im_gconv_grads G = fetch_grads(l);
     const int H = L.hidden, Dout = L.dout, Din = L.din, NTc = 2 * H + Dout;
@@ -875,7 +888,7 @@ __device__ __forceinline__ void gcn_stack_bwd_body(const BwdArgs& a) {
     float* const d_obj = l == 0 ? a.g.d_obj : dp3 + (l & 1 ? a.off_dobj1 : a.off_dobj0);
 
     // ---- P1: dp3 = ((g_obj * relu'(new_obj)) W2b) * relu'(h2);  dW2b, db2b
-    {
+    if (gs >= lo && gs < hi) {
       DgradStage st = {};
       st.a = g_obj; st.y = L.new_obj; st.M = O; st.N = H; st.K = Dout; st.W = L.w2b; st.out = dp3; st.act = L.h2;
       WgradStage wg = {};
@@ -888,9 +901,9 @@ __device__ __forceinline__ void gcn_stack_bwd_body(const BwdArgs& a) {
         else colsum_tile<true, CFG>(g_obj, L.new_obj, O, Dout, (t - nd - nw) << 5, G.db2b, G.accumulate, smem);
       }
     }
-    grid_barrier(sy);
+    if (gs >= lo && gs + 1 < hi) grid_barrier(sy);
     // ---- P2: dpooled = dp3 W2a;  dW2a, db2a
-    {
+    if (gs + 1 >= lo && gs + 1 < hi) {
       DgradStage st = {};
       st.a = dp3; st.M = O; st.N = H; st.K = H; st.W = L.w2a; st.out = dpooled; st.act = nullptr;
       WgradStage wg = {};
@@ -904,9 +917,9 @@ __device__ __forceinline__ void gcn_stack_bwd_body(const BwdArgs& a) {
       }
     }
     if (T > 0) {
-      grid_barrier(sy);
+      if (gs + 1 >= lo && gs + 2 < hi) grid_barrier(sy);
       // ---- P3: dp1 = (dnt W1b) * relu'(h1), dnt rebuilt in the loader and written by the first column block
-      {
+      if (gs + 2 >= lo && gs + 2 < hi) {
         DgradStage st = {};
         st.M = T; st.N = H; st.K = NTc; st.W = L.w1b; st.out = dp1; st.act = L.h1;
         st.dpooled = dpooled; st.g_pred = g_pred; st.ld_gp = ld_gp; st.new_t = L.new_t; st.H = H; st.Dout = Dout;
@@ -915,9 +928,9 @@ __device__ __forceinline__ void gcn_stack_bwd_body(const BwdArgs& a) {
         const TileWalk tw(nrb * (H >> 5));
         for (int t = tw.first; t < tw.end; t += tw.step) dgrad_tile<2, CFG>(st, t, nrb, smem, ix, LN);
       }
-      grid_barrier(sy);
+      if (gs + 2 >= lo && gs + 3 < hi) grid_barrier(sy);
       // ---- P4: d_triple = dp1 W1a;  dW1a, db1a, db1b
-      {
+      if (gs + 3 >= lo && gs + 3 < hi) {
         DgradStage st = {};
         st.a = dp1; st.M = T; st.N = 3 * Din; st.K = H; st.W = L.w1a; st.out = d_triple; st.act = nullptr;
         WgradStage wg = {};
@@ -933,9 +946,9 @@ __device__ __forceinline__ void gcn_stack_bwd_body(const BwdArgs& a) {
           else colsum_tile<false, CFG>(dnt, nullptr, T, NTc, (t - nd - nw - nc1) << 5, G.db1b, G.accumulate, smem);
         }
       }
-      grid_barrier(sy);
+      if (gs + 3 >= lo && gs + 4 < hi) grid_barrier(sy);
       // ---- P5: d_obj = CSR sum of d_triple's subject / object blocks;  dW1b
-      {
+      if (gs + 4 >= lo && gs + 4 < hi) {
         WgradStage wg = {};
         wg.dy = dnt; wg.NI = NTc; wg.x = L.h1; wg.NJ = H; wg.R = T; wg.dw = G.dw1b; wg.accumulate = G.accumulate;
         const int nw = wgrad_tiles<CFG>(wg);
@@ -944,7 +957,7 @@ __device__ __forceinline__ void gcn_stack_bwd_body(const BwdArgs& a) {
         if (d_obj) pool_stage(d_triple, 3 * Din, 2 * Din, a.s.row_ptr, a.s.entries, T, Din, false, O, d_obj, LN);
       }
     }
-    if (l > 0) grid_barrier(sy);
+    if (l > 0 && gs + 4 >= lo && gs + 5 < hi) grid_barrier(sy);
     g_obj = d_obj; g_pred = d_triple + Din; ld_gp = 3 * Din;
   }
   if (threadIdx.x == 0) stamp(sy);
@@ -1094,12 +1107,19 @@ int sg2im_gconv_stack_backward(const sg2im_gconv_stack* S, const sg2im_gconv_sta
   a.off_dobj0 = (long long)off; off += up4(O * D);
   a.off_dobj1 = (long long)off; off += up4(O * D);
   a.sync = static_cast<unsigned*>(sync);
-  if (G->low_footprint)
-    SG2IM_LAUNCH(gcn::gcn_stack_bwd_low_kernel, dim3(gcn::grid_for(S, true)), dim3(gcn::kThreads),
-                 gcn::LdsPlan<gcn::LowFootprint>::kBytes, stream, a);
-  else
-    SG2IM_LAUNCH(gcn::gcn_stack_bwd_kernel, dim3(gcn::grid_for(S, true)), dim3(gcn::kThreads), gcn::kLdsBytes, stream, a);
-  return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
+  const int n_stages = 5 * S->n_layers;
+  const bool staged = G->low_footprint >= 2, low = G->low_footprint == 1 || G->low_footprint == 2;
+  for (int g = 0; g < (staged ? n_stages : 1); ++g) {
+    a.stage_lo = staged ? g : 0;
+    a.stage_hi = staged ? g + 1 : n_stages;
+    if (low)
+      SG2IM_LAUNCH(gcn::gcn_stack_bwd_low_kernel, dim3(gcn::grid_for(S, true)), dim3(gcn::kThreads),
+                   gcn::LdsPlan<gcn::LowFootprint>::kBytes, stream, a);
+    else
+      SG2IM_LAUNCH(gcn::gcn_stack_bwd_kernel, dim3(gcn::grid_for(S, true)), dim3(gcn::kThreads), gcn::kLdsBytes, stream, a);
+    if (hipGetLastError() != hipSuccess) return SG2IM_ERR_HIP;
+  }
+  return SG2IM_OK;
 }
 
 int sg2im_gconv_stack_stamps(const void* sync_host_copy, unsigned long long* out, int max_out) {

@@ -705,8 +705,8 @@ GCN_PERSISTENT = os.environ.get('SG2IM_GCN_PERSIST', '1') != '0'      # (A/B kno
 # 9.51 -> 9.24 ms fp32, 5.84 -> 5.61 ms bf16 at VG-64), layer-by-layer launches where the weight-gradient lane ends it
 # (the COCO-style headline configuration: 7.75 vs 7.90 ms) - profiles/r5_gcn_persistent_backward_low_footprint_ab.txt.
 GCN_PERSISTENT_BACKWARD_MODE = os.environ.get('SG2IM_GCN_PERSIST_BWD', 'auto')
-GCN_PERSISTENT_BACKWARD = {'0': False, '': False, 'auto': False, '1': 'full', 'full': 'full', 'low': 'low', '2': 'low'}.get(
-  GCN_PERSISTENT_BACKWARD_MODE, False)
+GCN_PERSISTENT_BACKWARD = {'0': False, '': False, 'auto': False, '1': 'full', 'full': 'full', 'low': 'low', '2': 'low',
+                           'staged': 'staged', 'staged_full': 'staged_full'}.get(GCN_PERSISTENT_BACKWARD_MODE, False)
 
 
 def gconv_stack_backward_in_one_launch():
@@ -771,7 +771,7 @@ def gconv_stack_backward(S, g_obj, g_pred, d_triple, d_obj, grads, accumulate, d
     for k, t in zip(('dw1a', 'db1a', 'dw1b', 'db1b', 'dw2a', 'db2a', 'dw2b', 'db2b'), gl):
       setattr(G.layer[l], k, _f(t).value if t is not None else None)
     G.layer[l].accumulate = int(bool(accumulate))
-  G.low_footprint = 1 if GCN_PERSISTENT_BACKWARD == 'low' else 0
+  G.low_footprint = {'low': 1, 'staged': 2, 'staged_full': 3}.get(GCN_PERSISTENT_BACKWARD, 0)
   sy = sync_area(device)
   _timed('igemm_dgrad', 2.0 * S._flops, lambda: call('sg2im_gconv_stack_backward', byref(S), byref(G), c_void_p(sy.data_ptr()),
                                                      sy.numel() * 4, _stream()))

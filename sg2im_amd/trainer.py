@@ -579,7 +579,12 @@ class Trainer(object):
     # (round 5 also took the one-launch form for every bf16 step; since the GEMM epilogues got cheap - round 6 - the
     # layer-by-layer launches win in the COCO style in both modes: bf16 3.82-3.83 -> 3.69-3.75 ms; VG style, one launch:
     # fp32 8.34 vs 8.57, bf16 4.39 vs 4.56 ms)
-    return 'low' if trains_mask_net else False
+    if trains_mask_net:
+      return 'low'
+    # (round 6, COCO style under the bf16 mode: the small-kernel tail ends that step too, by ~0.13 ms - the STAGED form, the
+    # persistent kernel's 25 stages as 25 ordinary launches with the weight gradients riding as extra tiles, shortens the tail
+    # without resident workgroups that poll: 3.73 -> 3.68 ms; fp32: the weight-gradient lane ends the step, 7.41 vs 7.45)
+    return 'staged' if self.compute_dtype == 'bf16' else False
 
   def _step(self, batch):
     if self.use_graphs:

@@ -735,7 +735,7 @@ def _gconv_stack_plain_case(tag, O, T, dims, pooling):
 
 def sec_gconv_stack():
   _gconv_stack_plain_case('stack small plain', 8, 12, [(32, 32, 32)] * 2, 'avg')
-  for mode in ('full', 'low'):       # the one-launch backward in both footprints (sg2im_gconv_stack_grads.low_footprint)
+  for mode in ('full', 'low', 'staged', 'staged_full'):   # the one-launch backward in both footprints and its staged form (sg2im_gconv_stack_grads.low_footprint)
     g = torch.Generator().manual_seed(7)
     batch = synthetic_batch(32, seed=3)
     objs, triples = batch[1], batch[4]
