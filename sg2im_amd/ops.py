@@ -698,8 +698,9 @@ GCN_PERSISTENT = os.environ.get('SG2IM_GCN_PERSIST', '1') != '0'      # (A/B kno
 # 'full' (round 4: ~390 registers, 98 KB of LDS per workgroup = whole CUs): its first barrier waited ~0.5 ms for
 # residency, 8.32 vs 7.99 ms (profiles/r4_gcn_persistent_backward_ab.txt).  'low' (round 5: <= 168 registers, 41 KB
 # of LDS, 32 x 32 tiles, sg2im_gconv_stack_grads.low_footprint): its workgroups fit next to the weight gradients'.
-# SG2IM_GCN_PERSIST_BWD = auto | 0 | full | low (1 = full); the same form runs in eager mode too, so that eager and replayed
-# iterations stay bit-identical.  Both forms are tested against the layer-by-layer launches in sec_gconv_stack.
+# SG2IM_GCN_PERSIST_BWD = auto | 0 | full | low | staged | staged_full (1 = full; staged: the low / full kernel launched once
+# per stage - no grid barrier, nothing co-resident); the same form runs in eager mode too, so that eager and replayed
+# iterations stay bit-identical.  Every form is tested against the layer-by-layer launches in sec_gconv_stack.
 # 'auto' (the default): the Trainer picks per configuration (trainer.Trainer._gcn_backward_mode) - 'low' where the main
 # lane's small-kernel tail ENDS the step (VG-style batches / a trained mask_net: its backward sits in that tail; measured
 # 9.51 -> 9.24 ms fp32, 5.84 -> 5.61 ms bf16 at VG-64), layer-by-layer launches where the weight-gradient lane ends it

@@ -414,6 +414,15 @@ def test_deferred_release_reports_each_bucket_only_when_all_its_weight_gradients
     ops.AFTER_DEFERRED = None
     ops.release_deferred(lane.queue, 'stream')
     assert issued == [4, 3, 2, 1, 0] and fired == []
+    # a queue released in two parts (SideLane.flush(final=False) then flush()): a bucket whose launches straddle the
+    # two releases fires with the LAST of them, buckets are not re-armed in between
+    del issued[:], fired[:]
+    pending = [[{ps[4].data_ptr(), ps[1].data_ptr()}, lambda stream: fired.append(('A', len(issued)))],
+               [{ps[0].data_ptr()}, lambda stream: fired.append(('B', len(issued)))]]
+    ops.release_deferred(lane.queue[:2], 'stream', pending)         # launches 1, 0
+    assert issued == [1, 0] and fired == [('B', 2)]
+    ops.release_deferred(lane.queue[2:], 'stream', pending)         # launches 4, 3, 2
+    assert issued == [1, 0, 4, 3, 2] and fired == [('B', 2), ('A', 3)]
   finally:
     ops.AFTER_DEFERRED = None
 
