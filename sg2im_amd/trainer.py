@@ -580,7 +580,11 @@ class Trainer(object):
     # layer-by-layer launches win in the COCO style in both modes: bf16 3.82-3.83 -> 3.69-3.75 ms; VG style, one launch:
     # fp32 8.34 vs 8.57, bf16 4.39 vs 4.56 ms)
     if trains_mask_net:
-      return 'low'
+      # (the persistent kernel's 32 x 32 tiles are built for a few hundred rows; at the 256 x 256 shape - 700-960 objects,
+      # <= 3 200 triples - its low-footprint form takes 2.1 ms and the implicit-GEMM family's 64 x 64+ tiles win:
+      # fp32 53.0 -> 52.0 ms, bf16 20.3 -> 19.7 ms, profiles/r6_gcn_backward_staged_ab.txt)
+      triples = batch[4] if len(batch) > 4 else None
+      return 'low' if triples is None or not hasattr(triples, 'size') or triples.size(0) <= 1024 else False
     # (round 6, COCO style under the bf16 mode: the small-kernel tail ends that step too, by ~0.13 ms - the STAGED form, the
     # persistent kernel's 25 stages as 25 ordinary launches with the weight gradients riding as extra tiles, shortens the tail
     # without resident workgroups that poll: 3.73 -> 3.68 ms; fp32: the weight-gradient lane ends the step, 7.41 vs 7.45)

@@ -490,10 +490,11 @@ def test_one_launch_gcn_backward_is_chosen_where_mask_net_trains():
   from sg2im_amd.trainer import Trainer
   with_net = SimpleNamespace(model=SimpleNamespace(mask_net=object()), w={'mask_loss_weight': 0.0}, compute_dtype='f32')
   no_net = SimpleNamespace(model=SimpleNamespace(mask_net=None), w={'mask_loss_weight': 0.0}, compute_dtype='f32')
-  coco = (0, 1, 2, torch.zeros(3, 16, 16), 4, 5)
-  vg = (0, 1, 2, None, 4, 5)
+  coco = (0, 1, 2, torch.zeros(3, 16, 16), torch.zeros(400, 3), 5)
+  vg = (0, 1, 2, None, torch.zeros(500, 3), 5)
+  vg_large = (0, 1, 2, None, torch.zeros(2900, 3), 5)         # (the 256 x 256 shape: thousands of triples)
   mode = Trainer._gcn_backward_mode
-  assert mode(with_net, coco) is False and mode(with_net, vg) == 'low'
+  assert mode(with_net, coco) is False and mode(with_net, vg) == 'low' and mode(with_net, vg_large) is False
   assert mode(no_net, vg) is False and mode(no_net, coco) is False
   with_net.w['mask_loss_weight'] = 0.1
   assert mode(with_net, coco) == 'low'
