@@ -222,7 +222,9 @@ class Trainer(object):
         t = torch.tensor([1.0 if ok else 0.0], device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item() > 0.5)
-      chosen = choose_dp_schedule(2, self.reducer.capturable(), lambda: probe(idx), agree if self.reducer.capturable() else None)
+      # (the children of all ranks form their own RCCL group: a multi-rank collective inside a graph is tried THERE first)
+      chosen = choose_dp_schedule(2, self.reducer.capturable(), lambda: probe(idx, rank=rank, world_size=world_size),
+                                  agree if self.reducer.capturable() else None)
       if chosen != 2 and rank == 0:
         print('[sg2im_amd] dp_schedule 2 (all-reduces inside the iteration graph) is not available here: running schedule %d' % chosen,
               flush=True)

@@ -573,6 +573,29 @@ def test_dp_schedule_choice_follows_the_capture_probe():
   assert choose_dp_schedule(1, True, probe_bad) == 1 and len(calls) == n              # (no probe for those)
 
 
+def test_capture_probe_expected_values_follow_the_replayed_pattern():
+  """capture_probe.expected_values(world): the child's pattern (capture_probe._child) simulated on the host with an
+  all-reduce that sums `world` equal copies - the values the multi-rank probe of a data-parallel job checks"""
+  from sg2im_amd.capture_probe import expected_values, group_port
+  for world in (1, 2, 8):
+    g_lo = g_hi = d = guard = 1.0
+    w_lo = w_hi = 0.0
+    g_lo, g_hi, d, guard = g_lo * world, g_hi * world, d * world, guard * world      # communicator set-up reductions
+    for _ in range(2):                                                               # two replays
+      w_lo += 1; w_hi += 1
+      guard *= world
+      d = d * 2 * world
+      w_lo += 1; w_hi += 1
+      g_lo = g_lo * 2 * world
+      g_hi = g_hi * 3
+      w_lo += 1; w_hi += 1
+      g_hi *= world
+      w_lo += g_lo; w_hi += g_hi
+    assert expected_values(world) == (w_lo, w_hi, d, guard)
+  assert expected_values(1) == (12.0, 18.0, 4.0, 1.0)
+  assert group_port(29500) == 29529 and group_port('64990') == 64961 and group_port(29500) != 29500
+
+
 def test_capture_probe_child_that_dies_is_a_failed_probe_not_a_crash():
   """the probe runs in a subprocess precisely because the failure it guards against is a segfault: a child that aborts
   (SG2IM_PROBE_FORCE_FAIL=1, before it touches any GPU) must come back as False"""
@@ -582,6 +605,8 @@ def test_capture_probe_child_that_dies_is_a_failed_probe_not_a_crash():
   os.environ['SG2IM_PROBE_FORCE_FAIL'] = '1'
   try:
     assert capture_probe.probe(0, timeout=120) is False
+    capture_probe._verdict.clear()
+    assert capture_probe.probe(0, timeout=120, rank=1, world_size=2, master_port=29500) is False     # (the multi-rank form)
   finally:
     del os.environ['SG2IM_PROBE_FORCE_FAIL']
     capture_probe._verdict.clear()
