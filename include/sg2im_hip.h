@@ -463,7 +463,7 @@ int sg2im_layout_backward(const float* dlayout, long long ld_dlayout, const floa
 
 /* d_vecs of the layout (the d_vecs part of sg2im_layout_backward) straight from the refinement network's PER-LEVEL
  * layout gradients: dlevels[l] [n_images][height / factors[l]][width / factors[l]][>= dim] with row stride lds[l] is the
- * gradient w.r.t. the layout average-pooled by factors[l] (crn.py:58-62; factors powers of two, <= 5 levels), so
+ * gradient w.r.t. the layout average-pooled by factors[l] (crn.py:58-62; factors powers of two, <= 6 levels), so
  * d layout = sum_l upsample(dlevels[l]) / factors[l]^2 - what sg2im_pyramid_backward would write - is summed on the fly
  * and never materialised.  workspace: sg2im_layout_backward_workspace() bytes.  dim a multiple of 4. */
 int sg2im_layout_backward_vecs_levels(const float* const* dlevels, const int* factors, const long long* lds, int n_levels,

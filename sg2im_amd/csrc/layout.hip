@@ -383,7 +383,8 @@ __global__ __launch_bounds__(256) void layout_bwd_vecs_kernel(const float* __res
 // or re-read: sg2im_pyramid_backward + layout_bwd_vecs_kernel moved 89 + 67 + 67 MB, this pass reads the 89 MB of
 // level gradients once (coarse levels are re-read by the 4^k fine pixels that share them: cache hits).  float4
 // lanes along the channels, several pixels in flight per thread.
-struct GradLevels { const float* p[5]; int ld[5]; int shift[5]; float k[5]; int n; };
+constexpr int kGradLevels = 6;         // (a six-module refinement network - BASELINE configs[3..4] - has six)
+struct GradLevels { const float* p[kGradLevels]; int ld[kGradLevels]; int shift[kGradLevels]; float k[kGradLevels]; int n; };
 
 // Round 5 form (the round-4 kernel - 256-pixel tiles, 16 float4 accumulators + 2 x 8 staged loads
 // per thread = 196 registers, 512 workgroups - ran at 0.23 of 8 TB/s isolated and 172 us under the weight-gradient
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(256) void layout_bwd_vecs_levels_kernel(GradLevels 
             #pragma unroll
             for (int i = 0; i < 4; ++i) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             #pragma unroll
-            for (int l = 0; l < 5; ++l) {
+            for (int l = 0; l < kGradLevels; ++l) {
               if (l < lv.n) {
                 const int sh = lv.shift[l];
                 const float kk = lv.k[l];
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(256) void layout_bwd_g_tiles_kernel(const float* __
     const int pl = live ? px : 0;
     const int y = pl / W, x = pl - y * W;
     #pragma unroll
-    for (int l = 0; l < 5; ++l) {
+    for (int l = 0; l < kGradLevels; ++l) {
       if (l < lv.n) {
         const int sh = lv.shift[l];
         const float kk = lv.k[l];
@@ -1120,7 +1121,7 @@ int sg2im_layout_backward(const float* dlayout, long long ld_dlayout, const floa
 static bool fill_grad_levels(sg2im::GradLevels& lv, const float* const* dlevels, const int* factors, const long long* lds,
                              int n_levels, int dim, int height, int width) {
   lv.n = n_levels;
-  for (int l = 0; l < 5; ++l) {
+  for (int l = 0; l < sg2im::kGradLevels; ++l) {
     lv.p[l] = nullptr; lv.ld[l] = 0; lv.shift[l] = 0; lv.k[l] = 0.f;
     if (l >= n_levels) continue;
     const int f = factors[l];
@@ -1139,7 +1140,7 @@ int sg2im_layout_backward_vecs_levels(const float* const* dlevels, const int* fa
                                       const int* img_row_ptr, const int* img_entries, int n_images, int n_objs, int dim,
                                       int height, int width, int align_corners, float* d_vecs, long long ld_dvecs,
                                       float* workspace, hipStream_t stream) {
-  if (!dlevels || !factors || !lds || n_levels < 1 || n_levels > 5 || !boxes || !img_row_ptr || !d_vecs || !workspace ||
+  if (!dlevels || !factors || !lds || n_levels < 1 || n_levels > sg2im::kGradLevels || !boxes || !img_row_ptr || !d_vecs || !workspace ||
       dim < 4 || (dim & 3) || height < 1 || width < 1)
     return SG2IM_ERR_ARG;
   if (n_objs == 0) return SG2IM_OK;
@@ -1165,7 +1166,7 @@ int sg2im_layout_backward_maps_levels(const float* const* dlevels, const int* fa
                                       const int* img_entries, int n_images, int n_objs, int dim, int height, int width,
                                       int align_corners, float* d_masks, float* d_boxes, float* workspace,
                                       hipStream_t stream) {
-  if (!dlevels || !factors || !lds || n_levels < 1 || n_levels > 5 || !vecs || !boxes || !img_row_ptr || !img_entries ||
+  if (!dlevels || !factors || !lds || n_levels < 1 || n_levels > sg2im::kGradLevels || !vecs || !boxes || !img_row_ptr || !img_entries ||
       !workspace || (!d_masks && !d_boxes) || (d_masks && (!masks || mask_size < 1)) || dim < 4 || (dim & 3) || dim > 128 ||
       (ld_vecs & 3) || ((uintptr_t)vecs & 15) || height < 1 || width < 1)
     return SG2IM_ERR_ARG;

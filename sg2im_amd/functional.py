@@ -757,7 +757,7 @@ LAYOUT_GRAD_FROM_LEVELS = _os.environ.get('SG2IM_LAYOUT_GRAD_LEVELS', '1') != '0
 
 def _hand_over_layout_grad(like, dlevels, N, H, W, Cg, Cl, link):
   """the full-resolution d layout as LayoutFn.backward's input: lazily through the link (see LayoutLink) or summed now"""
-  lazy = link is not None and LAZY_LAYOUT_GRAD and len(dlevels) <= 5 and all(f & (f - 1) == 0 for _, f in dlevels)
+  lazy = link is not None and LAZY_LAYOUT_GRAD and len(dlevels) <= 6 and all(f & (f - 1) == 0 for _, f in dlevels)
   if lazy:
     dlayout = _new(like, N, H, W, Cl)                  # never read as a tensor: LayoutFn.backward takes the levels
     link.leave_grad(dlayout, [t for t, _ in dlevels], [f for _, f in dlevels], Cg)

@@ -412,7 +412,7 @@ def test_layout_noise_pyramid_in_one_launch_is_bit_exact(H, L, nd, masks):
   assert float(got[0][2, :, :, :Dv].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('H,L,masks', [(64, 5, 'int'), (32, 3, 'float'), (16, 1, None)])
+@pytest.mark.parametrize('H,L,masks', [(64, 5, 'int'), (32, 3, 'float'), (16, 1, None), (128, 6, 'float')])
 def test_layout_vector_gradient_straight_from_the_level_gradients(H, L, masks):
   """sg2im_layout_backward_vecs_levels (d_vecs from the refinement network's per-level layout gradients, the summed
   full-resolution gradient never materialised) against sg2im_pyramid_backward + sg2im_layout_backward."""

@@ -36,6 +36,22 @@ LAYERS = [  # name, H, C0, C1(up), Cout, k, stride, pad
 ]
 
 
+# --size=128 --dims=1024,512,256,128,64,64: the refinement network of another configuration (BASELINE configs[3..4]) instead
+# of the COCO-64 table (the discriminator / mask / graph layers stay out)
+_size = [a[7:] for a in sys.argv if a.startswith('--size=')]
+_dims = [a[7:] for a in sys.argv if a.startswith('--dims=')]
+if _size:
+  S = int(_size[0])
+  dims = [int(v) for v in (_dims[0] if _dims else '1024,512,256,128,64').split(',')]
+  LAYERS, prev = [], 0
+  for i, c in enumerate(dims):
+    h = S >> (len(dims) - 1 - i)
+    LAYERS.append(('m%d.conv0' % i, h, 160, prev if prev else 1, c, 3, 1, 1))
+    LAYERS.append(('m%d.conv1' % i, h, c, 0, c, 3, 1, 1))
+    prev = c
+  LAYERS += [('out.conv0', S, dims[-1], 0, dims[-1], 3, 1, 1), ('out.conv1', S, dims[-1], 0, 3, 1, 1, 0)]
+
+
 def timeit(fn, iters=10):
   fn(); fn()
   torch.cuda.synchronize()
