@@ -318,12 +318,23 @@ __global__ void copy_2d_kernel(const float* __restrict__ src, long long ld_src, 
 
 // batch hand-over of a captured iteration: up to 16 (dst, src, 4-byte words) copies in ONE launch
 struct StageJobs { unsigned* dst[16]; const unsigned* src[16]; unsigned words[16]; };
+// (16-byte pieces where both ends allow it, up to 1 024 workgroups per job: the 25 MB image tensor of a 256 x 256 batch took
+// 155 us at the head of the step as 4-byte copies on 64 workgroups)
 __global__ void stage_batch_kernel(const StageJobs j) {
   const int job = blockIdx.y;
   unsigned* __restrict__ d = j.dst[job];
   const unsigned* __restrict__ s = j.src[job];
   const unsigned n = j.words[job];
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = s[i];
+  const unsigned stride = gridDim.x * blockDim.x, i0 = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((((uintptr_t)d | (uintptr_t)s) & 15) == 0) {               // (job-uniform)
+    const unsigned n4 = n >> 2;
+    uint4* __restrict__ d4 = reinterpret_cast<uint4*>(d);
+    const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(s);
+    for (unsigned i = i0; i < n4; i += stride) d4[i] = s4[i];
+    for (unsigned i = 4 * n4 + i0; i < n; i += stride) d[i] = s[i];
+  } else {
+    for (unsigned i = i0; i < n; i += stride) d[i] = s[i];
+  }
 }
 
 }  // namespace sg2im
@@ -349,7 +360,7 @@ int sg2im_stage_batch(int n, void* const* dst, const void* const* src, const siz
     j.words[i] = live ? (unsigned)(bytes[i] / 4) : 0u;
     if (live) most = bytes[i] / 4 > most ? bytes[i] / 4 : most;
   }
-  const int bx = (int)std::max<size_t>(1, std::min<size_t>((most + 256 * 8 - 1) / (256 * 8), 64));
+  const int bx = (int)std::max<size_t>(1, std::min<size_t>((most + 256 * 8 - 1) / (256 * 8), 1024));
   SG2IM_LAUNCH(stage_batch_kernel, dim3(bx, n), dim3(256), 0, stream, j);
   return hipGetLastError() == hipSuccess ? SG2IM_OK : SG2IM_ERR_HIP;
 }
@@ -371,7 +382,9 @@ static int csr_small_lp(int n_rows) {
 static bool csr_small_ok(int n, int n_rows) {
   const int lp = csr_small_lp(n_rows);
   const long long passes = ((long long)n_rows + (1024 >> lp) - 1) / (1024 >> lp);
-  return n <= sg2im::kCsrSmallKeys && (long long)(n >> lp) * passes <= 65536;
+  // (a thread walks n >> lp keys twice per pass, ~27 ns per key: beyond ~1 500 keys per walk - the 256 x 256 shape: 6 400 keys
+  // over 700-960 rows took 171 us - the five-launch path is shorter)
+  return n <= sg2im::kCsrSmallKeys && (n >> lp) <= 1536 && (long long)(n >> lp) * passes <= 65536;
 }
 
 int sg2im_csr_build(const long long* keys_a, int n_a, const long long* keys_b, int n_b, int n_rows,

@@ -504,6 +504,26 @@ def test_empty_and_ragged_graphs():
   assert float(out0.abs().max()) == 0.0
 
 
+def test_batch_staging_copies_every_word():
+  """sg2im_stage_batch (the hand-over of a batch to a captured iteration's static buffers, one launch): 16-byte pieces
+  where both ends are 16-byte aligned, 4-byte words otherwise, tails, empty jobs, the 25 MB image tensor of a 256 x 256
+  batch - every byte arrives, nothing past the end is touched"""
+  from sg2im_amd import bucketing
+  D = torch.device('cuda', 0)
+  g = torch.Generator().manual_seed(5)
+  big = torch.randn(32 * 3 * 256 * 256 + 3, generator=g).to(D)
+  srcs = [big[:32 * 3 * 256 * 256], big[1:1 + 1027], big[4:4 + 1030], torch.randint(0, 9, (777, 3), generator=g).to(D),
+          torch.zeros(0, device=D), torch.arange(5, dtype=torch.int32, device=D)]
+  pads = [torch.full((s.numel() + 16,), -3, dtype=s.dtype, device=D) for s in srcs]
+  # destinations at offsets 0 / 1 / 4 elements of a canary-filled buffer: aligned and unaligned ends
+  dsts = [p[o:o + s.numel()].view(s.shape) for p, s, o in zip(pads, srcs, (0, 4, 1, 0, 0, 1))]
+  assert bucketing._stage_with_library({'x': (dsts, srcs)})
+  torch.cuda.synchronize()
+  for p, d, s, o in zip(pads, dsts, srcs, (0, 4, 1, 0, 0, 1)):
+    assert torch.equal(d, s)
+    assert bool((p[:o] == -3).all()) and bool((p[o + s.numel():] == -3).all())
+
+
 def _stable_csr(keys, n_rows, live=None, half=None):
   """numpy restatement of sg2im_csr_build's contract: row j lists its entry ids in increasing order; with `live` only
   the first `live` keys of each half (keys_a | keys_b) take part"""
