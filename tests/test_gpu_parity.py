@@ -424,7 +424,11 @@ def test_layout_vector_gradient_straight_from_the_level_gradients(H, L, masks):
   o2i = torch.cat([torch.full((c,), i, dtype=torch.long) for i, c in enumerate(counts)])
   O = int(o2i.numel())
   x0 = torch.rand(O, 2, generator=g) * 0.6
-  boxes = torch.cat([x0, x0 + 0.05 + torch.rand(O, 2, generator=g) * 0.35], 1).clamp(max=1.0).to(D)
+  boxes = torch.cat([x0, x0 + 0.05 + torch.rand(O, 2, generator=g) * 0.35], 1).clamp(max=1.0)
+  # (tile-level culling: a box outside the unit square - the dummy objects of a padded batch -, a zero-width box, whose
+  # grid is inf / NaN in the reference, and one that covers the whole image)
+  boxes[1] = torch.tensor([2.0, 2.0, 3.0, 3.0]); boxes[2] = torch.tensor([0.3, 0.2, 0.3, 0.7]); boxes[4] = torch.tensor([0.0, 0.0, 1.0, 1.0])
+  boxes = boxes.to(D)
   vecs = torch.randn(O, Dv, generator=g).to(D)
   mk = None
   if masks == 'int':
