@@ -419,8 +419,10 @@ def test_layout_vector_gradient_straight_from_the_level_gradients(H, L, masks):
   from sg2im_amd import ops
   D = torch.device('cuda', 0)
   g = torch.Generator().manual_seed(11)
-  N, Dv, Cl = 5, 128, 160
+  N, Dv, Cl = (6 if H == 128 else 5), 128, 160
   counts = [3, 9, 1, 0, 6]                                # an image without objects, one with more than a register pass
+  if H == 128:
+    counts = [3, 21, 1, 0, 30, 37]                        # more than 16 objects (four per thread), more than one 32-object pass
   o2i = torch.cat([torch.full((c,), i, dtype=torch.long) for i, c in enumerate(counts)])
   O = int(o2i.numel())
   x0 = torch.rand(O, 2, generator=g) * 0.6
